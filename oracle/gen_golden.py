@@ -1,0 +1,202 @@
+"""Generate tests/golden/*.npz by running THE REFERENCE ITSELF (lightkurve from /root/reference/src on
+astropy 4.3.1 / scipy 1.7.1).  Test infrastructure; run in this container only:
+
+    PYTHONPATH=oracle/shims:/root/reference/src:. /opt/conda/bin/python3.9 -W ignore oracle/gen_golden.py
+
+The fixtures hold inputs AND reference outputs, so nothing at test time needs /root/reference.
+"""
+import os
+import sys
+
+import numpy as np
+
+import lightkurve as lk
+from astropy.timeseries import BoxLeastSquares, LombScargle
+import astropy.units as u
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from lightkurve_amd import synth  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", name, {k: np.asarray(v).shape for k, v in kw.items()})
+
+
+def gen_ls():
+    # (1) TESS-like 2-min cadence, regular grid up to Nyquist, amplitude + psd, exact and fast
+    t, y, e, truth = synth.ls_target(1, 0, 3000)
+    lc = lk.LightCurve(time=t + 2458325.0 - 2457000.0, flux=y, flux_err=e)  # BTJD-like offset
+    f = synth.ls_frequency_grid(2000)
+    out = dict(time=lc.time.value, flux=y, flux_err=e, frequency=f)
+    for meth in ("slow", "fast", "cython"):
+        pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method=meth)
+        out["amp_" + meth] = np.asarray(pg.power.value)
+    f_uhz = f * 1e6 / 86400.0
+    out["frequency_uhz"] = f_uhz
+    for meth in ("slow", "fast"):
+        pg = lc.to_periodogram(frequency=f_uhz, normalization="psd", ls_method=meth)
+        out["psd_" + meth] = np.asarray(pg.power.value)
+    pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method="slow")
+    out["max_power"] = float(pg.max_power.value)
+    out["frequency_at_max_power"] = float(pg.frequency_at_max_power.value)
+    save("ls_tess3000", **out)
+
+    # (2) config C1: 4k cadences @ 30 min, lightkurve default grid (oversample 5), default method 'fast'
+    t, y, e, truth = synth.ls_target(0, 0, 4000, cadence_days=30.0 / 1440.0)
+    lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+    pg_fast = lc.to_periodogram()
+    pg_slow = lc.to_periodogram(ls_method="slow")
+    pg_psd = lc.to_periodogram(normalization="psd", ls_method="slow")
+    save("ls_c1_default", time=t, flux=y, flux_err=e, frequency=pg_fast.frequency.value,
+         amp_fast=pg_fast.power.value, amp_slow=pg_slow.power.value, nyquist=pg_fast.nyquist.value,
+         psd_frequency_uhz=pg_psd.frequency.value, psd_slow=pg_psd.power.value,
+         psd_nyquist=pg_psd.nyquist.value, period_at_max_power=pg_slow.period_at_max_power.value,
+         true_period=truth["period"])
+
+    # (3) NaNs in flux + float32 flux + regular PERIOD grid (=> irregular frequency => 'slow')
+    t, y, e, truth = synth.ls_target(1, 1, 1500)
+    y32 = y.astype(np.float32)
+    y32[[5, 100, 777]] = np.nan
+    lc = lk.LightCurve(time=t, flux=y32, flux_err=e)
+    period = np.linspace(0.05, 5.0, 700)
+    pg = lc.to_periodogram(period=period, normalization="amplitude")
+    save("ls_nan_period_grid", time=t, flux=y32, flux_err=e, period=period, ls_method=pg.ls_method,
+         frequency=pg.frequency.value, amp=pg.power.value)
+
+    # (4) heteroscedastic dy passed through kwargs (periodogram.py:961-963 **kwargs -> LombScargle(dy=))
+    t, y, e, truth = synth.ls_target(1, 2, 1200)
+    rng = np.random.default_rng(7)
+    dy = e * rng.uniform(0.5, 2.0, len(e))
+    f = synth.ls_frequency_grid(900, fmax=100.0)
+    lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+    pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method="slow", dy=dy)
+    pg2 = lc.to_periodogram(frequency=f * 1e6 / 86400, normalization="psd", ls_method="slow", dy=dy)
+    # astropy-level normalisations at this boundary too
+    ls = LombScargle(t - t[0], y, dy)
+    save("ls_dy", time=t, flux=y, dy=dy, frequency=f, amp=pg.power.value, psd=pg2.power.value,
+         astropy_standard=ls.power(f, method="slow", normalization="standard"),
+         astropy_psd=ls.power(f, method="slow", normalization="psd"))
+
+    # (5) constant flux -> power exactly 0 (tests/test_periodogram.py:445-457 analogue)
+    t = np.arange(300) * 0.02
+    lc = lk.LightCurve(time=t, flux=np.ones(300))
+    pg = lc.to_periodogram(ls_method="slow")
+    save("ls_constant", time=t, flux=np.ones(300), frequency=pg.frequency.value, amp=pg.power.value)
+
+
+def gen_bls():
+    t, y, e, truth = synth.bls_target(3, 0, 2500, cadence_days=10.0 / 1440.0)
+    lc = lk.LightCurve(time=t + 1325.5, flux=y, flux_err=e)
+    period, duration = synth.bls_grid(400, 20, pmin=0.6, pmax=6.0, dmin=0.02, dmax=0.5)
+    out = dict(time=lc.time.value, flux=y, flux_err=e, period=period, duration=duration)
+    for objective in ("likelihood", "snr"):
+        pg = lc.to_periodogram(method="bls", period=period, duration=duration, objective=objective)
+        for k in ("power", "depth", "depth_err", "duration", "transit_time", "depth_snr", "log_likelihood"):
+            v = getattr(pg, "snr") if k == "depth_snr" else (
+                pg._BLS_result[k] if k in ("depth_err", "log_likelihood") else getattr(pg, k))
+            out[objective + "_" + k] = np.asarray(getattr(v, "value", v), dtype=float)
+        out[objective + "_period_at_max_power"] = float(pg.period_at_max_power.value)
+    # raw bls_fast boundary (inputs exactly as astropy hands them to the C kernel)
+    bls = BoxLeastSquares(lc.time, lc.flux, lc.flux_err)
+    trel = np.asarray(bls._trel.value if hasattr(bls._trel, "value") else bls._trel, float)
+    out["raw_t"] = trel - trel.min()
+    out["raw_y"] = y - np.median(y)
+    out["raw_ivar"] = 1.0 / e ** 2
+    save("bls_2500", **out)
+
+    # lightkurve defaults (duration list, autoperiod grid) with a coarser frequency_factor to stay small
+    t, y, e, truth = synth.bls_target(3, 1, 1500, cadence_days=30.0 / 1440.0)
+    lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+    pg = lc.to_periodogram(method="bls", frequency_factor=200)
+    save("bls_default", time=t, flux=y, flux_err=e, period=pg.period.value, power=pg.power.value,
+         depth=pg.depth.value, duration=pg.duration.value, transit_time=pg.transit_time.value,
+         snr=np.asarray(pg.snr), true_period=truth["period"],
+         period_at_max_power=pg.period_at_max_power.value)
+
+    # no flux_err (NaN errors) -> ivar = 1 (periodogram.py:1096-1099)
+    lc = lk.LightCurve(time=t, flux=y)
+    pg = lc.to_periodogram(method="bls", period=np.linspace(1.0, 9.0, 150), duration=[0.1, 0.2])
+    save("bls_noerr", time=t, flux=y, period=pg.period.value, power=pg.power.value, depth=pg.depth.value,
+         duration=pg.duration.value, transit_time=pg.transit_time.value)
+
+
+def gen_flatten():
+    rng = np.random.default_rng(11)
+    t, y, e, truth = synth.ls_target(4, 0, 3000)
+    y = y * (1 + 0.01 * np.sin(2 * np.pi * t / 3.3) + 0.002 * t)
+    y[rng.integers(0, 3000, 12)] += 0.02          # outliers
+    y[[3, 500, 1999]] = np.nan
+    for w, p, bt, ni, sg in [(101, 2, 5, 3, 3), (401, 3, 5, 3, 3), (51, 2, None, 2, 4)]:
+        lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+        flat, trend = lc.flatten(window_length=w, polyorder=p, break_tolerance=bt, niters=ni, sigma=sg,
+                                 return_trend=True)
+        save("flatten_w%d" % w, time=t, flux=y, flux_err=e, window_length=w, polyorder=p,
+             break_tolerance=np.nan if bt is None else bt, niters=ni, sigma=sg,
+             trend=trend.flux.value, flat_flux=flat.flux.value, flat_err=flat.flux_err.value)
+    # user mask + short segments
+    t2 = np.concatenate([t[:40], t[40:] + 3.0])
+    user_mask = np.zeros(3000, bool)
+    user_mask[1000:1100] = True
+    lc = lk.LightCurve(time=t2, flux=y, flux_err=e)
+    flat, trend = lc.flatten(window_length=101, mask=user_mask, return_trend=True)
+    save("flatten_mask", time=t2, flux=y, flux_err=e, mask=user_mask, trend=trend.flux.value,
+         flat_flux=flat.flux.value)
+    # raw scipy boundary
+    from scipy.signal import savgol_filter
+    x = rng.normal(0, 1, 1000).cumsum()
+    save("savgol_raw", x=x, w101p2=savgol_filter(x, 101, 2), w401p3=savgol_filter(x, 401, 3),
+         w5p4=savgol_filter(x, 5, 4), w11p0=savgol_filter(x, 11, 0))
+
+
+def gen_regression():
+    from lightkurve.correctors import RegressionCorrector, DesignMatrix
+    import pandas as pd
+    rng = np.random.default_rng(5)
+    n, k = 2000, 8
+    t = np.linspace(0, 40, n)
+    X = np.column_stack([np.sin(2 * np.pi * t / p) for p in (1.3, 2.9, 7.7)] +
+                        [np.cos(2 * np.pi * t / p) for p in (1.3, 2.9, 7.7)] +
+                        [t / 40.0, np.ones(n)])
+    wtrue = rng.normal(0, 1, k) * 1e-2
+    wtrue[-1] = 1.0
+    err = rng.uniform(0.5, 2.0, n) * 1e-3
+    y = X @ wtrue + rng.normal(0, 1, n) * err
+    y[rng.integers(0, n, 25)] += 0.05
+    cm = np.ones(n, bool)
+    cm[300:360] = False
+    pmu = np.zeros(k)
+    psig = np.array([np.inf, 0.01, 0.1, np.inf, 1.0, 0.05, np.inf, np.inf])
+    lc = lk.LightCurve(time=t, flux=y, flux_err=err)
+    dm = DesignMatrix(pd.DataFrame(X), name="X", prior_mu=pmu, prior_sigma=psig)
+    rc = RegressionCorrector(lc)
+    clc = rc.correct(dm, cadence_mask=cm, sigma=5, niters=5)
+    save("regress_k8", time=t, flux=y, flux_err=err, X=X, cadence_mask=cm, prior_mu=pmu, prior_sigma=psig,
+         coefficients=rc.coefficients, corrected=clc.flux.value, model=rc.model_lc.flux.value,
+         outlier_mask=rc.outlier_mask)
+    # reference test KAT (tests/correctors/test_regressioncorrector.py:13-48)
+    lc2 = lk.LightCurve(flux=[5, 10], flux_err=[1, 1], time=[1, 2])
+    out = {}
+    for tag, mu, sg in [("noprior", None, None), ("tight", [99, 99], [1e-6, 1e-6])]:
+        kw = {} if mu is None else dict(prior_mu=np.array(mu, float), prior_sigma=np.array(sg, float))
+        dm2 = DesignMatrix(pd.DataFrame({"a": [1., 1.], "b": [1., 2.]}), **kw)
+        r2 = RegressionCorrector(lc2)
+        r2.correct(dm2)
+        out[tag] = r2.coefficients
+    save("regress_kat", **out)
+    # no flux_err (all NaN => ones), regressioncorrector.py:157-158
+    lc3 = lk.LightCurve(time=t, flux=y)
+    rc3 = RegressionCorrector(lc3)
+    clc3 = rc3.correct(DesignMatrix(pd.DataFrame(X), name="X"))
+    save("regress_noerr", time=t, flux=y, X=X, coefficients=rc3.coefficients, corrected=clc3.flux.value,
+         outlier_mask=rc3.outlier_mask)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ls", "bls", "flatten", "regression"]
+    for w in which:
+        globals()["gen_" + w]()

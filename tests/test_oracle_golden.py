@@ -1,0 +1,174 @@
+"""Pin the oracle (oracle/np_oracle.py + oracle/c) against outputs of THE REFERENCE ITSELF
+(tests/golden/*.npz, made by oracle/gen_golden.py from lightkurve@/root/reference + astropy 4.3.1)."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+
+
+def relmax(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b))
+
+
+# ------------------------------------------------------------------ Lomb-Scargle
+def test_ls_exact_amplitude_and_psd(golden):
+    g = golden("ls_tess3000")
+    amp = O.lk_ls_periodogram(g["time"], g["flux"], g["frequency"], "amplitude")
+    assert relmax(amp, g["amp_slow"]) < 1e-11
+    assert relmax(amp, g["amp_cython"]) < 1e-11
+    psd = O.lk_ls_periodogram(g["time"], g["flux"], g["frequency_uhz"], "psd")
+    assert relmax(psd, g["psd_slow"]) < 1e-11
+    assert abs(amp.max() - g["max_power"]) / g["max_power"] < 1e-11
+    assert g["frequency"][np.argmax(amp)] == g["frequency_at_max_power"]
+
+
+def test_ls_numpy_matches_c(golden):
+    g = golden("ls_tess3000")
+    t = g["time"] - g["time"][0]
+    f = g["frequency"][::7]
+    a = O.ls_power(t, g["flux"], None, f, normalization="lk_amplitude")
+    b = O.ls_power_numpy(t, g["flux"], None, f, normalization="lk_amplitude")
+    assert relmax(a, b) < 1e-11
+
+
+def test_ls_fast_restatement_matches_reference_default(golden):
+    g = golden("ls_tess3000")
+    amp = O.lk_ls_periodogram(g["time"], g["flux"], g["frequency"], "amplitude", exact=False)
+    ok = np.isfinite(g["amp_fast"])          # the reference's 'fast' path yields NaN at the very top bin here
+    assert ok.sum() >= len(ok) - 1 and np.array_equal(ok, np.isfinite(amp))
+    assert relmax(amp[ok], g["amp_fast"][ok]) < 1e-9
+    # and the reference's own fast-vs-exact gap is ~1e-3 (SURVEY.md finding 8)
+    assert 1e-6 < relmax(g["amp_fast"][ok], g["amp_slow"][ok]) < 1e-2
+
+
+def test_ls_c1_default_grid(golden):
+    g = golden("ls_c1_default")
+    f, fs, nyq = O.lk_ls_default_grid(g["time"], "amplitude")
+    assert len(f) == len(g["frequency"]) and np.allclose(f, g["frequency"], rtol=1e-14, atol=0)
+    assert np.isclose(nyq, g["nyquist"], rtol=1e-14)
+    amp = O.lk_ls_periodogram(g["time"], g["flux"], f, "amplitude")
+    assert relmax(amp, g["amp_slow"]) < 1e-11
+    f2, _, nyq2 = O.lk_ls_default_grid(g["time"], "psd")
+    assert len(f2) == len(g["psd_frequency_uhz"]) and np.allclose(f2, g["psd_frequency_uhz"], rtol=1e-13)
+    psd = O.lk_ls_periodogram(g["time"], g["flux"], f2, "psd")
+    assert relmax(psd, g["psd_slow"]) < 1e-11
+    assert abs(1 / f[np.argmax(amp)] - g["period_at_max_power"]) < 1e-12
+
+
+def test_ls_nan_float32_period_grid(golden):
+    g = golden("ls_nan_period_grid")
+    assert str(g["ls_method"]) == "slow"
+    ok = np.isfinite(g["flux"])
+    amp = O.lk_ls_periodogram(g["time"][ok], g["flux"][ok].astype(float), 1.0 / g["period"], "amplitude")
+    assert relmax(amp, g["amp"]) < 1e-10
+
+
+def test_ls_dy_weights(golden):
+    g = golden("ls_dy")
+    t = g["time"] - g["time"][0]
+    assert relmax(O.ls_power(t, g["flux"], g["dy"], g["frequency"], normalization="standard"),
+                  g["astropy_standard"]) < 1e-10
+    assert relmax(O.ls_power(t, g["flux"], g["dy"], g["frequency"], normalization="psd"),
+                  g["astropy_psd"]) < 1e-10
+    assert relmax(O.ls_power(t, g["flux"], g["dy"], g["frequency"], normalization="lk_amplitude"),
+                  g["amp"]) < 1e-10
+
+
+def test_ls_constant_flux_zero_power(golden):
+    g = golden("ls_constant")
+    amp = O.lk_ls_periodogram(g["time"], g["flux"], g["frequency"], "amplitude")
+    # the reference yields ~1e-29 here (its BLAS dot of w.y is off by an ulp); for the 3-cadence curve of
+    # tests/test_periodogram.py:445-457 it yields exactly 0.  The oracle centres about y[0] => exactly 0 always.
+    assert (g["amp"] < 1e-25).all() and (amp == 0).all()
+    t = np.array([1.0, 3.0, 4.0])
+    f, _, _ = O.lk_ls_default_grid(t, "amplitude")
+    assert (O.lk_ls_periodogram(t, np.ones(3), f, "amplitude") == 0).all()
+
+
+# ------------------------------------------------------------------ BLS
+@pytest.mark.parametrize("objective", ["likelihood", "snr"])
+def test_bls_bit_exact(golden, objective):
+    g = golden("bls_2500")
+    t, y, ivar, t_ref = O.lk_bls_inputs(g["time"], g["flux"], g["flux_err"])
+    assert np.array_equal(t, g["raw_t"]) and np.array_equal(y, g["raw_y"]) and np.array_equal(ivar, g["raw_ivar"])
+    res = O.bls(t, y, ivar, g["period"], g["duration"], 10, objective == "likelihood")
+    for name, arr in zip(O.BLS_FIELDS, res):
+        ref = g[objective + "_" + name]
+        if name == "transit_time":
+            arr = arr + t_ref + g["time"][0]
+            assert np.allclose(arr, ref, rtol=0, atol=1e-9)
+        else:
+            assert np.array_equal(arr, ref), name
+    assert g["period"][np.argmax(res[0])] == g[objective + "_period_at_max_power"]
+
+
+def test_bls_default_grid_and_noerr(golden):
+    g = golden("bls_default")
+    t, y, ivar, t_ref = O.lk_bls_inputs(g["time"], g["flux"], g["flux_err"])
+    dur = np.array([0.05, 0.10, 0.15, 0.20, 0.25, 0.33])
+    dt = np.median(np.diff(g["time"]))
+    pmin = max(4 * dt, dur.max() + dt)
+    pmax = (g["time"].max() - g["time"].min()) / 3.0
+    period = O.bls_autoperiod(g["time"] - g["time"][0], dur, pmin, pmax, frequency_factor=200)
+    assert len(period) == len(g["period"]) and np.allclose(period, g["period"], rtol=1e-14)
+    res = O.bls(t, y, ivar, g["period"], dur)
+    assert np.array_equal(res[0], g["power"]) and np.array_equal(res[1], g["depth"])
+    assert np.array_equal(res[3], g["duration"])
+    g = golden("bls_noerr")
+    t, y, ivar, t_ref = O.lk_bls_inputs(g["time"], g["flux"], None)
+    res = O.bls(t, y, ivar, g["period"], np.array([0.1, 0.2]))
+    assert np.array_equal(res[0], g["power"]) and np.array_equal(res[1], g["depth"])
+
+
+def test_bls_invalid_duration_raises():
+    t = np.linspace(0, 10, 200)
+    with pytest.raises(ValueError):
+        O.bls(t, np.zeros(200), np.ones(200), np.array([0.3, 1.0]), np.array([0.5]))
+
+
+# ------------------------------------------------------------------ flatten
+def test_savgol_raw(golden):
+    g = golden("savgol_raw")
+    for key, (w, p) in dict(w101p2=(101, 2), w401p3=(401, 3), w5p4=(5, 4), w11p0=(11, 0)).items():
+        assert np.max(np.abs(O.savgol_filter(g["x"], w, p) - g[key])) < 2e-11 * np.max(np.abs(g["x"]))
+
+
+@pytest.mark.parametrize("name", ["flatten_w101", "flatten_w401", "flatten_w51"])
+def test_flatten_trend(golden, name):
+    g = golden(name)
+    bt = None if np.isnan(g["break_tolerance"]) else float(g["break_tolerance"])
+    trend, _ = O.flatten_trend(g["time"], g["flux"], int(g["window_length"]), int(g["polyorder"]), bt,
+                               int(g["niters"]), float(g["sigma"]))
+    assert np.allclose(trend, g["trend"], rtol=1e-11, atol=0, equal_nan=True)
+    ok = np.isfinite(g["flux"])
+    assert np.allclose((g["flux"] / trend)[ok], g["flat_flux"][ok], rtol=1e-11)
+
+
+def test_flatten_user_mask(golden):
+    g = golden("flatten_mask")
+    trend, _ = O.flatten_trend(g["time"], g["flux"], mask=g["mask"])
+    assert np.allclose(trend, g["trend"], rtol=1e-11, atol=0)
+
+
+# ------------------------------------------------------------------ regression
+def test_regression_k8(golden):
+    g = golden("regress_k8")
+    r = O.regression_correct(g["X"], g["flux"], g["flux_err"], g["cadence_mask"], g["prior_mu"],
+                             g["prior_sigma"])
+    assert np.array_equal(r["outlier_mask"], g["outlier_mask"])
+    assert np.allclose(r["coefficients"], g["coefficients"], rtol=1e-9, atol=1e-13)
+    assert np.allclose(r["corrected"], g["corrected"], rtol=0, atol=1e-12)
+
+
+def test_regression_kat_and_noerr(golden):
+    g = golden("regress_kat")
+    X = np.array([[1., 1.], [1., 2.]])
+    r = O.regression_correct(X, np.array([5., 10.]), np.array([1., 1.]))
+    assert np.allclose(r["coefficients"], g["noprior"], atol=1e-9) and np.allclose(g["noprior"], [0, 5], atol=1e-7)
+    r = O.regression_correct(X, np.array([5., 10.]), np.array([1., 1.]), None, np.array([99., 99.]),
+                             np.array([1e-6, 1e-6]))
+    assert np.allclose(r["coefficients"], g["tight"], atol=1e-9)
+    g = golden("regress_noerr")
+    r = O.regression_correct(g["X"], g["flux"], None)
+    assert np.array_equal(r["outlier_mask"], g["outlier_mask"])
+    assert np.allclose(r["corrected"], g["corrected"], rtol=0, atol=1e-12)
