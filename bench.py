@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark: batched exact Lomb-Scargle on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one pass of the hot path over one batch: B targets x M trial frequencies through
+liblkhip.so's lk_ls_power_batch_dev + lk_argmax_batch_dev, inputs already resident in HBM.
+Prints ONE JSON line on rank 0 (metric frequencies*targets/sec, whole job over all ranks), carrying
+`roofline` (dominant kernel ls_grid_kernel: algorithmic 16 flop per (cadence, frequency) pair over the
+HIP-event kernel time, against the fp64 vector peak) and `cpu_baseline` (the reference's default 'fast'
+algorithm, numpy port, timed on this box's host cores on a bounded sample).
+
+Weak scaling: every rank owns B targets (targets are independent; no data-path collective is needed to
+compute).  With N>1 the per-shard power spectra are all-gathered over RCCL (north_star), chunked so the
+collective of chunk k overlaps the kernels of chunk k+1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 MFMA dense peak (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--targets", type=int, default=1000, help="targets per GPU (B)")
+    ap.add_argument("--cadences", type=int, default=20000, help="cadences per target (N)")
+    ap.add_argument("--freqs", type=int, default=100000, help="trial frequencies (M)")
+    ap.add_argument("--chunks", type=int, default=4, help="target chunks per step (comm/compute overlap)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of spectra for N>1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="ls", choices=["ls", "bls"])
+    ap.add_argument("--periods", type=int, default=50000)
+    ap.add_argument("--durations", type=int, default=200)
+    return ap.parse_args()
+
+
+def cpu_baseline_ls(args):
+    """Reference default path ('fast': extirpolation + FFT, astropy fast_impl.py) as a numpy port, one process
+    per host core over a bounded sample of the same workload.  Runs BEFORE torch/HIP is initialised (spawn pool)."""
+    import multiprocessing as mp
+    from oracle import cpu_baseline as cb
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    n_targets = cores * 2
+    jobs = [(1, i, args.cadences, args.freqs) for i in range(n_targets)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        pool.map(cb.ls_fast_one, jobs[:cores])          # warm (imports, FFT plans)
+        t0 = time.perf_counter()
+        pool.map(cb.ls_fast_one, jobs)
+        dt = time.perf_counter() - t0
+    exact_pairs_per_s = cb.ls_exact_rate(args.cadences)
+    return {
+        "value": n_targets * args.freqs / dt, "unit": "frequencies*targets/sec", "cores": cores, "kind": "port",
+        "sample": "%d targets x %d freqs, N=%d, numpy port of the reference default ls_method='fast' "
+                  "(Press-Rybicki FFT), %d processes" % (n_targets, args.freqs, args.cadences, cores),
+        "exact_port_1core": {"value": exact_pairs_per_s / args.cadences, "unit": "frequencies*targets/sec",
+                             "note": "C oracle (same exact direct-sum arithmetic as the GPU kernel), 1 core"},
+    }
+
+
+def cpu_baseline_bls(args):
+    from oracle import cpu_baseline as cb
+    rate = cb.bls_rate(args.cadences, args.durations)
+    return {"value": rate, "unit": "periods*targets/sec", "cores": 1, "kind": "port",
+            "sample": "C oracle (restated astropy run_bls), 1 target x 24 periods x %d durations, N=%d, 1 core"
+                      % (args.durations, args.cadences)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline_ls(args) if args.workload == "ls" else cpu_baseline_bls(args)
+
+    import torch
+    import torch.distributed as dist
+    from lightkurve_amd import _capi, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    handle = _capi.Handle.get(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    B, N, M = args.targets, args.cadences, args.freqs
+    out = {}
+    if args.workload == "ls":
+        # ---- synthetic inputs, rank r owns targets [r*B, (r+1)*B)
+        t, y, dy, off = synth.ls_batch(1, B, N, first_index=rank * B)
+        for b in range(B):
+            t[off[b]:off[b + 1]] -= t[off[b]]
+        df = 360.0 / M
+        d_t, d_y = torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev)
+        d_pow = torch.empty((B, M), dtype=torch.float64, device=dev)
+        d_max = torch.empty(B, dtype=torch.float64, device=dev)
+        d_arg = torch.empty(B, dtype=torch.int64, device=dev)
+        gather = world > 1 and not args.no_gather
+        nch = max(1, min(args.chunks, B))
+        bounds = np.linspace(0, B, nch + 1).astype(int)
+        d_all = [torch.empty((world, bounds[c + 1] - bounds[c], M), dtype=torch.float64, device=dev)
+                 for c in range(nch)] if gather else None
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps + args.warmup)]
+
+        def step(k):
+            works = []
+            e0, e1 = ev[k]
+            kern_ms_events = []
+            for c in range(nch):
+                b0, b1 = int(bounds[c]), int(bounds[c + 1])
+                offc = off[b0:b1 + 1] - off[b0]
+                if c == 0:
+                    e0.record()
+                _capi.ls_power_batch_dev(handle, b1 - b0, offc, d_t.data_ptr() + 8 * int(off[b0]),
+                                         d_y.data_ptr() + 8 * int(off[b0]), 0, 0, df, df, M, True, True,
+                                         "lk_amplitude", 0, d_pow.data_ptr() + 8 * b0 * M, stream)
+                if c == nch - 1:
+                    e1.record()
+                if gather:
+                    works.append(dist.all_gather_into_tensor(d_all[c], d_pow[b0:b1], async_op=True))
+            _capi.argmax_batch_dev(handle, B, M, d_pow.data_ptr(), d_max.data_ptr(), d_arg.data_ptr(), stream)
+            for w in works:
+                w.wait()
+
+        units_per_step = B * M
+        pairs_per_step = float(sum(int(off[b + 1] - off[b]) for b in range(B))) * M
+        metric, unit = "frequencies*targets/sec (Lomb-Scargle, exact GLS)", "frequencies*targets/sec"
+        workload = ("configs[1]: %d TESS-like %d-cadence targets x %d freqs Lomb-Scargle per GPU" % (B, N, M))
+    else:
+        t, y, dy, off = synth.bls_batch(3, B, N, first_index=rank * B)
+        ivar = 1.0 / dy ** 2
+        for b in range(B):
+            s = slice(off[b], off[b + 1])
+            t[s] -= t[s].min()
+            y[s] -= np.median(y[s])
+        period, duration = synth.bls_grid(args.periods, args.durations)
+        d_t, d_y, d_w = (torch.from_numpy(a).to(dev) for a in (t, y, ivar))
+        d_per = torch.from_numpy(period).to(dev)
+        d_out = torch.empty((7, B, len(period)), dtype=torch.float64, device=dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps + args.warmup)]
+
+        def step(k):
+            e0, e1 = ev[k]
+            e0.record()
+            _capi.bls_batch_dev(handle, B, off, d_t.data_ptr(), d_y.data_ptr(), d_w.data_ptr(), period,
+                                d_per.data_ptr(), duration, 10, True, d_out.data_ptr(), stream)
+            e1.record()
+
+        units_per_step = B * len(period)
+        nb = np.ceil(period / (duration.min() / 10)) + 10
+        durb = np.unique(np.round(duration / (duration.min() / 10)))
+        cand = float(np.sum(np.maximum(nb[:, None] - durb[None, :] + 1, 0)))
+        pairs_per_step = cand * B     # (start bin, duration) candidates
+        metric, unit = "BLS periods*targets/sec", "periods*targets/sec"
+        workload = ("configs[3]: %d targets x %d cadences, %d periods x %d durations BLS per GPU"
+                    % (B, N, len(period), len(duration)))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kern_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.warmup, args.warmup + args.steps)]))
+
+    if rank == 0:
+        value = units_per_step * world * args.steps / dt
+        out = {
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "targets_per_gpu": B, "cadences": N,
+                       "parallelism": "targets sharded over %d rank(s), no data-path collective%s"
+                                      % (world, "; RCCL all-gather of spectra overlapped" if world > 1 and
+                                         args.workload == "ls" and not args.no_gather else "")},
+        }
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        if args.workload == "ls":
+            flops = 16.0 * pairs_per_step
+            ach = flops / (kern_ms * 1e-3) / 1e12
+            algo_bytes = 16.0 * float(off[-1]) + 8.0 * B * M
+            out["roofline"] = {
+                "bound": "valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "kernel": "ls_grid_kernel<16> (+ls_prep_kernel)",
+                "kernel_ms_per_step": kern_ms,
+                "note": "fp64 direct trig sums: 16 flop (8 v_fma_f64) per (cadence, frequency) pair; arithmetic "
+                        "intensity ~3e4 flop/B so the fp64 VECTOR pipe binds (peak == fp64 MFMA dense peak), not HBM",
+                "hbm": {"achieved": algo_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_step": algo_bytes},
+            }
+        else:
+            out["roofline"] = {
+                "bound": "valu", "achieved": 12.0 * pairs_per_step / (kern_ms * 1e-3) / 1e12,
+                "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": 12.0 * pairs_per_step / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "traffic": traffic, "kernel": "bls_kernel", "kernel_ms_per_step": kern_ms,
+                "note": "algorithmic 12 flop per (start bin, duration) candidate (SURVEY.md §8(d)); the bit-exact "
+                        "kernel spends ~45 fp64 instructions per candidate on two IEEE divisions",
+            }
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+            out["speedup_vs_cpu_baseline"] = value / cpu_base["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+/* lkhip.h — C ABI of liblkhip.so: the MI355X (gfx950) hot path of lightkurve's periodogram +
+ * systematics-correction pipeline.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * lightkurve is pure Python and has no FFI of its own; each entry point below replaces the numerical
+ * call the reference makes at one of its four seams:
+ *
+ *   lk_ls_power_batch*   <- astropy METHODS[method](t, y, dy, frequency, center_data, fit_mean, normalization)
+ *                           reached from src/lightkurve/periodogram.py:961-964 (LS.power(frequency, method=ls_method)),
+ *                           plus lightkurve's own normalisation lines periodogram.py:969-975 (fused).
+ *   lk_argmax_batch*     <- Periodogram.max_power / frequency_at_max_power, periodogram.py:127-140 (nanmax/nanargmax).
+ *   lk_bls_batch*        <- astropy methods.bls_fast(t, y, ivar, period, duration, oversample, use_likelihood)
+ *                           == C run_bls(...), reached from periodogram.py:1169 (bls.power(period, duration, **kwargs)).
+ *   lk_savgol_trend_batch* <- scipy.signal.savgol_filter + interp1d inside LightCurve.flatten,
+ *                           src/lightkurve/lightcurve.py:996-1063.
+ *   lk_regress_batch*    <- RegressionCorrector._fit_coefficients + the sigma-clip loop of .correct,
+ *                           src/lightkurve/correctors/regressioncorrector.py:127-189, 243-279.
+ *
+ * Conventions
+ *   - Every function returns an int status: LK_OK, LK_EINVAL (-> ValueError), LK_ENOMEM (-> MemoryError),
+ *     LK_EHIP (-> RuntimeError; text from lk_last_error()).  Outputs are fully written on LK_OK.
+ *   - Ragged batches: target b owns elements [n_off[b], n_off[b+1]) of the concatenated arrays.
+ *   - `*_batch` takes HOST pointers (caller-owned numpy buffers; copied in/out inside the call).
+ *     `*_batch_dev` takes DEVICE pointers (already resident in HBM) and enqueues on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) without synchronising.
+ *   - One lk_handle drives one GPU (one process per GPU); it owns its scratch workspace and is not
+ *     thread-safe.  Multi-GPU = one handle per rank, targets sharded by the caller (no data-path collective).
+ */
+#ifndef LKHIP_H
+#define LKHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LK_OK 0
+#define LK_EINVAL 1
+#define LK_ENOMEM 2
+#define LK_EHIP 3
+
+/* LS normalisations: astropy 'standard', astropy 'psd', lightkurve 'amplitude' (periodogram.py:974-975),
+ * lightkurve 'psd' (periodogram.py:969-973; needs per-target scale = 2/(N*oversample*fs)). */
+#define LK_NORM_STANDARD 0
+#define LK_NORM_PSD 1
+#define LK_NORM_LK_AMPLITUDE 2
+#define LK_NORM_LK_PSD 3
+
+typedef struct lk_handle lk_handle;
+
+int lk_version(void);
+const char *lk_last_error(void);
+int lk_device_count(int *count);
+int lk_init(int device_id, lk_handle **out);
+void lk_destroy(lk_handle *h);
+/* bytes of device scratch currently held by the handle */
+int64_t lk_workspace_bytes(const lk_handle *h);
+
+/* ---- Lomb-Scargle (exact floating-mean GLS, direct trig sums) --------------------------------------
+ * t: times relative to the target's first cadence [d] (astropy: lombscargle/core.py:119-126);
+ * y: flux; dy: per-cadence errors or NULL (uniform weights, the lightkurve default);
+ * freq: M frequencies [1/d] or NULL for the regular grid f0 + df*j, j<M (the fast path);
+ * scale: per-target factor for LK_NORM_LK_PSD, or NULL (=1); power: B*M row-major, float64. */
+int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y,
+                      const double *dy, const double *freq, double f0, double df, int64_t M,
+                      int fit_mean, int center_data, int normalization, const double *scale,
+                      double *power);
+int lk_ls_power_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                          const double *dy, const double *freq, double f0, double df, int64_t M,
+                          int fit_mean, int center_data, int normalization, const double *scale,
+                          double *power, void *stream);
+
+/* ---- nanmax / nanargmax over each row of a B x M float64 matrix (first maximum wins) ---------------- */
+int lk_argmax_batch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out);
+int lk_argmax_batch_dev(lk_handle *h, int B, int64_t M, const double *x, double *max_out,
+                        int64_t *argmax_out, void *stream);
+
+/* ---- Box Least Squares (astropy run_bls semantics; bit-exact for time-sorted input) -------------------
+ * t: t - min(t); y: y - median(y); ivar: 1/dy^2 (ones if no errors) — exactly what bls/core.py:304-327
+ * hands to bls_fast.  period[nP], duration[nD] shared by all targets.  use_likelihood: 1 'likelihood', 0 'snr'.
+ * out7: 7 x B x nP row-major: power, depth, depth_err, duration, transit_time(phase), depth_snr, log_likelihood. */
+int lk_bls_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y,
+                 const double *ivar, const double *period, int64_t nP, const double *duration, int nD,
+                 int oversample, int use_likelihood, double *out7);
+int lk_bls_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                     const double *ivar, const double *period_host, const double *period_dev, int64_t nP,
+                     const double *duration_host, int nD, int oversample, int use_likelihood, double *out7,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LKHIP_H */

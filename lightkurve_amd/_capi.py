@@ -1,0 +1,213 @@
+"""ctypes binding of liblkhip.so (the C ABI in include/lkhip.h).
+
+No CPU fallback exists anywhere in this package: if the library is missing or there is no GPU the
+first compute call raises.  numpy arrays in -> numpy arrays out (host-pointer entry points); the
+``*_dev`` variants take raw device pointers (ints) for callers that already hold data in HBM
+(bench.py / batch.py pass ``torch.Tensor.data_ptr()``).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblkhip.so")
+
+LK_OK, LK_EINVAL, LK_ENOMEM, LK_EHIP = 0, 1, 2, 3
+NORM = {"standard": 0, "psd": 1, "lk_amplitude": 2, "lk_psd": 3}
+BLS_FIELDS = ("power", "depth", "depth_err", "duration", "transit_time", "depth_snr", "log_likelihood")
+
+_c_dp = ctypes.POINTER(ctypes.c_double)
+_c_ip = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+
+# (name, restype, argtypes) for EVERY symbol include/lkhip.h declares — tests/test_capi_symbols.py checks the list
+SIGNATURES = [
+    ("lk_version", ctypes.c_int, []),
+    ("lk_last_error", ctypes.c_char_p, []),
+    ("lk_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    ("lk_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    ("lk_destroy", None, [_vp]),
+    ("lk_workspace_bytes", ctypes.c_int64, [_vp]),
+    ("lk_ls_power_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
+    ("lk_ls_power_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_argmax_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, _c_dp, _c_ip]),
+    ("lk_argmax_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    ("lk_bls_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int64, _c_dp, ctypes.c_int, ctypes.c_int,
+      ctypes.c_int, _c_dp]),
+    ("lk_bls_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _c_dp, _vp, ctypes.c_int64, _c_dp, ctypes.c_int, ctypes.c_int,
+      ctypes.c_int, _vp, _vp]),
+]
+
+_lib = None
+
+
+class LkHipError(RuntimeError):
+    """HIP runtime failure inside liblkhip.so (LK_EHIP)."""
+
+
+def load_library(path=None):
+    """dlopen liblkhip.so and type every entry point.  Raises OSError if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise OSError(
+            "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "
+            "make -C lightkurve_amd/csrc).  lightkurve_amd has no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, restype, argtypes in SIGNATURES:
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc == LK_OK:
+        return
+    msg = (_lib.lk_last_error() or b"").decode("utf-8", "replace")
+    if rc == LK_EINVAL:
+        raise ValueError(msg)
+    if rc == LK_ENOMEM:
+        raise MemoryError(msg)
+    raise LkHipError(msg)
+
+
+class Handle:
+    """One lk_handle = one GPU.  Created lazily per device id and cached."""
+
+    _cache = {}
+
+    def __init__(self, device=0):
+        lib = load_library()
+        self._h = _vp()
+        _check(lib.lk_init(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    @classmethod
+    def get(cls, device=0):
+        device = int(device)
+        if device not in cls._cache:
+            cls._cache[device] = cls(device)
+        return cls._cache[device]
+
+    def close(self):
+        if self._h:
+            _lib.lk_destroy(self._h)
+            self._h = _vp()
+
+    def workspace_bytes(self):
+        return int(_lib.lk_workspace_bytes(self._h))
+
+
+def device_count():
+    lib = load_library()
+    n = ctypes.c_int(0)
+    rc = lib.lk_device_count(ctypes.byref(n))
+    return n.value if rc == LK_OK else 0
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ=_c_dp):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+def _offsets(n_off, total):
+    n_off = np.ascontiguousarray(n_off, dtype=np.int64)
+    if n_off.ndim != 1 or n_off.size < 1 or n_off[0] != 0 or n_off[-1] != total or np.any(np.diff(n_off) < 0):
+        raise ValueError("n_off must be non-decreasing prefix offsets starting at 0 and ending at len(t)")
+    return n_off
+
+
+# --------------------------------------------------------------------------------------------- Lomb-Scargle
+def ls_power_batch(t, y, n_off, dy=None, frequency=None, f0=0.0, df=0.0, M=None, fit_mean=True,
+                   center_data=True, normalization="psd", scale=None, device=0):
+    """Exact GLS power for B ragged targets -> float64[B, M].
+
+    ``t`` relative times [d], ``y`` flux, ``dy`` errors or None (uniform weights), concatenated over
+    targets with prefix offsets ``n_off``.  Either ``frequency`` (any 1-D array, 1/d) or the regular grid
+    ``f0 + df*arange(M)`` (the fast kernel)."""
+    h = Handle.get(device)
+    t, y = _f64(t), _f64(y)
+    n_off = _offsets(n_off, t.size)
+    if y.shape != t.shape:
+        raise ValueError("t and y must have the same length")
+    dy = None if dy is None else _f64(np.broadcast_to(dy, t.shape))
+    B = n_off.size - 1
+    if frequency is not None:
+        frequency = _f64(frequency).ravel()
+        M = frequency.size
+    M = int(M)
+    scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
+    power = np.empty((B, M), dtype=np.float64)
+    _check(_lib.lk_ls_power_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), _ptr(frequency),
+                                  float(f0), float(df), M, int(bool(fit_mean)), int(bool(center_data)),
+                                  NORM[normalization], _ptr(scale), _ptr(power)))
+    return power
+
+
+def ls_power_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, freq_ptr, f0, df, M, fit_mean, center_data,
+                       normalization, scale_ptr, power_ptr, stream=0):
+    """Device-pointer variant (ints from tensor.data_ptr()); enqueues on ``stream`` and returns."""
+    n_off_host = np.ascontiguousarray(n_off_host, dtype=np.int64)
+    _check(_lib.lk_ls_power_batch_dev(handle._h, int(B), _ptr(n_off_host, _c_ip), _vp(t_ptr), _vp(y_ptr),
+                                      _vp(dy_ptr or None), _vp(freq_ptr or None), float(f0), float(df), int(M),
+                                      int(bool(fit_mean)), int(bool(center_data)), NORM[normalization],
+                                      _vp(scale_ptr or None), _vp(power_ptr), _vp(stream or None)))
+
+
+def argmax_batch(x, device=0):
+    """Row-wise (nanmax, nanargmax) of float64[B, M]; first maximum wins; all-NaN row -> (nan, -1)."""
+    h = Handle.get(device)
+    x = _f64(x)
+    if x.ndim != 2:
+        raise ValueError("x must be 2-D")
+    B, M = x.shape
+    mx = np.empty(B, dtype=np.float64)
+    am = np.empty(B, dtype=np.int64)
+    _check(_lib.lk_argmax_batch(h._h, B, M, _ptr(x), _ptr(mx), _ptr(am, _c_ip)))
+    return mx, am
+
+
+def argmax_batch_dev(handle, B, M, x_ptr, max_ptr, arg_ptr, stream=0):
+    _check(_lib.lk_argmax_batch_dev(handle._h, int(B), int(M), _vp(x_ptr), _vp(max_ptr), _vp(arg_ptr),
+                                    _vp(stream or None)))
+
+
+# --------------------------------------------------------------------------------------------- BLS
+def bls_batch(t, y, ivar, n_off, period, duration, oversample=10, use_likelihood=True, device=0):
+    """astropy ``bls_fast`` for B ragged targets (inputs already t-min(t), y-median(y), ivar).
+    Returns a dict of float64[B, nP] arrays keyed by BLS_FIELDS (transit_time is the phase in (0, period))."""
+    h = Handle.get(device)
+    t, y, ivar = _f64(t), _f64(y), _f64(ivar)
+    n_off = _offsets(n_off, t.size)
+    if y.shape != t.shape or ivar.shape != t.shape:
+        raise ValueError("t, y, ivar must have the same length")
+    period, duration = _f64(period).ravel(), _f64(duration).ravel()
+    B, nP = n_off.size - 1, period.size
+    out = np.empty((7, B, nP), dtype=np.float64)
+    _check(_lib.lk_bls_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(ivar), _ptr(period), nP,
+                             _ptr(duration), duration.size, int(oversample), int(bool(use_likelihood)), _ptr(out)))
+    return {k: out[i] for i, k in enumerate(BLS_FIELDS)}
+
+
+def bls_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, ivar_ptr, period_host, period_ptr, duration_host, oversample,
+                  use_likelihood, out7_ptr, stream=0):
+    n_off_host = np.ascontiguousarray(n_off_host, dtype=np.int64)
+    period_host, duration_host = _f64(period_host).ravel(), _f64(duration_host).ravel()
+    _check(_lib.lk_bls_batch_dev(handle._h, int(B), _ptr(n_off_host, _c_ip), _vp(t_ptr), _vp(y_ptr), _vp(ivar_ptr),
+                                 _ptr(period_host), _vp(period_ptr), period_host.size, _ptr(duration_host),
+                                 duration_host.size, int(oversample), int(bool(use_likelihood)), _vp(out7_ptr),
+                                 _vp(stream or None)))

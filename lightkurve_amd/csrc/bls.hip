@@ -1,0 +1,430 @@
+// bls.hip — Box Least Squares periodogram with astropy `run_bls` semantics, fp64, gfx950.
+//
+// Replaces astropy methods.bls_fast -> C run_bls behind BoxLeastSquaresPeriodogram.from_lightcurve
+// (reference: src/lightkurve/periodogram.py:1161-1169; algorithm: SURVEY.md App. B.2).  Compiled with
+// -ffp-contract=off: every product, sum and quotient rounds separately, exactly as the reference C does,
+// and every per-bin sum is accumulated in cadence order, so for time-sorted input all seven outputs are
+// BIT-IDENTICAL to the reference (tests/test_bls_gpu.py compares with ==).
+//
+// One 256-thread workgroup per (target, period); everything lives in LDS:
+//   pass A  each thread walks a contiguous slice of the cadences, computes the cycle number k = floor(t/P)
+//           and phase r = fmod(t, P) exactly (fma remainder with +-1 correction) and marks where a new
+//           "round" starts (k changes or r decreases).  Inside a round the bin index is non-decreasing, so
+//           every bin is touched by ONE contiguous run of cadences.
+//   pass B  rounds are processed in order (one barrier each).  A round is split evenly over the threads; a
+//           thread owns the runs that START in its slice and adds them to the LDS bin one cadence at a time
+//           (bin += y*ivar, the reference's order).  No two threads ever touch the same bin in a round.
+//   wrap    pad + sequential inclusive prefix sum (two lanes, one per array; sequential = same rounding).
+//   scan    lanes stride over start bins, durations outermost; IEEE divisions; each lane keeps its first best
+//           (strict >), the block reduction breaks ties by (duration index, start bin) = the reference's
+//           duration-major / phase-minor "first wins" order.  The winner recomputes the reported statistics.
+// blockIdx -> (target, period) is XCD-aware (all periods of a target on one XCD; its t / y*ivar / ivar arrays,
+// 24 B per cadence, stay in that XCD's L2).
+#include <cfloat>
+#include <cmath>
+
+#include <algorithm>
+#include <numeric>
+
+#include "lk_common.hpp"
+
+namespace lk {
+
+struct BlsStats {
+    double min_t, sum_y, sum_ivar, pad;
+};
+
+// ------------------------------------------------------------------------------------------------ prep
+// per target: min_t (exact), sum_y / sum_ivar accumulated SEQUENTIALLY (reference order), tm = t - min_t,
+// yw = y * ivar.
+__global__ __launch_bounds__(256) void bls_prep_kernel(const double *__restrict__ t, const double *__restrict__ y,
+                                                        const double *__restrict__ ivar,
+                                                        const int64_t *__restrict__ n_off,
+                                                        double *__restrict__ tm, double *__restrict__ yw,
+                                                        BlsStats *__restrict__ stats) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
+    double m = INFINITY;
+    for (int64_t i = tid; i < n; i += 256) m = fmin(m, t[lo + i]);
+    sh[tid] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] = fmin(sh[tid], sh[tid + s]);
+        __syncthreads();
+    }
+    const double min_t = sh[0];
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 256) {
+        tm[lo + i] = t[lo + i] - min_t;
+        yw[lo + i] = y[lo + i] * ivar[lo + i];
+    }
+    if (tid == 0) {
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += y[lo + i] * ivar[lo + i];
+        sh[0] = s;
+    }
+    if (tid == 64) {
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += ivar[lo + i];
+        sh[1] = s;
+    }
+    __syncthreads();
+    if (tid == 0) stats[b] = BlsStats{min_t, sh[0], sh[1], 0.0};
+}
+
+// exact k = trunc(t/P), r = fmod(t, P) for t >= 0, P > 0 (fmod results are always representable, so the
+// fused remainder is exact once k is right; the reciprocal estimate is off by at most one).
+__device__ __forceinline__ void fold_exact(double t, double P, double invP, double *k_out, double *r_out) {
+    double k = floor(t * invP);
+    double r = fma(-k, P, t);
+    if (r < 0.0) {
+        k -= 1.0;
+        r = fma(-k, P, t);
+    }
+    if (r >= P) {
+        k += 1.0;
+        r = fma(-k, P, t);
+    }
+    *k_out = k;
+    *r_out = r;
+}
+
+__device__ __forceinline__ int bin_of(double r, double bin_duration) { return (int)(fabs(r) / bin_duration) + 1; }
+
+constexpr int BLS_RMAX = 2048;  // round boundaries kept in LDS; more rounds (badly unsorted time) -> serial path
+
+struct BlsBest {
+    double obj;
+    int k, n;
+};
+
+__global__ __launch_bounds__(256) void bls_kernel(
+    const double *__restrict__ tm, const double *__restrict__ yw, const double *__restrict__ ivar,
+    const int64_t *__restrict__ n_off, const BlsStats *__restrict__ stats, const double *__restrict__ period,
+    const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_bins, int n_dur,
+    double bin_duration, int oversample, int obj_flag, double *__restrict__ out7) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS is dynamic: keeps the base 16-B aligned
+
+    const unsigned bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const int target = (int)((slot / (unsigned)np_group) * 8u + xcd);
+    if (target >= B) return;
+    const int p = pidx[slot % (unsigned)np_group];
+    const int tid = threadIdx.x;
+    const double P = period[p];
+    const double invP = 1.0 / P;
+    const int n_bins = (int)(ceil(P / bin_duration)) + oversample;
+    const int64_t lo = n_off[target];
+    const int N = (int)(n_off[target + 1] - lo);
+    tm += lo;
+    yw += lo;
+    ivar += lo;
+
+    // LDS carve (every offset a multiple of 16): bins | s_best | rstart | s_cnt | s_nrounds
+    double2 *bins = reinterpret_cast<double2 *>(smem);  // [n_bins + 1] (y, ivar)
+    char *after = smem + (size_t)(n_bins + 1) * 16;
+    BlsBest *s_best = reinterpret_cast<BlsBest *>(after);                    // [256]
+    int *rstart = reinterpret_cast<int *>(after + 256 * sizeof(BlsBest));    // [BLS_RMAX + 2]
+    int *s_cnt = rstart + (BLS_RMAX + 4);                                    // [256]
+    int *s_nrounds_p = s_cnt + 256;
+
+    for (int i = tid; i <= n_bins; i += 256) bins[i] = make_double2(0.0, 0.0);
+
+    // ---- pass A: round boundaries
+    const int L = (N + 255) / 256;
+    const int a0 = min(tid * L, N), a1 = min(a0 + L, N);
+    int cnt = 0;
+    {
+        double kp = -1.0, rp = 0.0;
+        if (a0 > 0 && a0 < N) fold_exact(tm[a0 - 1], P, invP, &kp, &rp);
+        for (int i = a0; i < a1; ++i) {
+            double k, r;
+            fold_exact(tm[i], P, invP, &k, &r);
+            if (i > 0 && (k != kp || r < rp)) ++cnt;
+            kp = k;
+            rp = r;
+        }
+    }
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 1;  // round 0 starts at cadence 0
+        for (int i = 0; i < 256; ++i) {
+            int c = s_cnt[i];
+            s_cnt[i] = acc;
+            acc += c;
+        }
+        *s_nrounds_p = acc;
+        rstart[0] = 0;
+    }
+    __syncthreads();
+    const int nrounds = *s_nrounds_p;
+    const bool serial = nrounds > BLS_RMAX;
+    if (!serial) {
+        int w = s_cnt[tid];
+        double kp = -1.0, rp = 0.0;
+        if (a0 > 0 && a0 < N) fold_exact(tm[a0 - 1], P, invP, &kp, &rp);
+        for (int i = a0; i < a1; ++i) {
+            double k, r;
+            fold_exact(tm[i], P, invP, &k, &r);
+            if (i > 0 && (k != kp || r < rp)) rstart[w++] = i;
+            kp = k;
+            rp = r;
+        }
+        if (tid == 0) rstart[nrounds] = N;
+    }
+    __syncthreads();
+
+    // ---- pass B: ordered histogram
+    if (serial) {
+        if (tid == 0) {
+            for (int i = 0; i < N; ++i) {
+                double k, r;
+                fold_exact(tm[i], P, invP, &k, &r);
+                const int ind = bin_of(r, bin_duration);
+                double2 v = bins[ind];
+                v.x += yw[i];
+                v.y += ivar[i];
+                bins[ind] = v;
+            }
+        }
+        __syncthreads();
+    } else {
+        for (int rd = 0; rd < nrounds; ++rd) {
+            const int s = rstart[rd], e = rstart[rd + 1];
+            const int len = e - s;
+            const int per = (len + 255) / 256;
+            int i = min(s + tid * per, e);
+            const int iend = min(i + per, e);
+            if (i < iend) {
+                double k, r;
+                int prev = -1;
+                if (i > s) {
+                    fold_exact(tm[i - 1], P, invP, &k, &r);
+                    prev = bin_of(r, bin_duration);
+                }
+                fold_exact(tm[i], P, invP, &k, &r);
+                int ind = bin_of(r, bin_duration);
+                // skip the tail of a run that started in the previous slice (its owner finishes it)
+                while (ind == prev) {
+                    ++i;
+                    if (i >= iend) break;
+                    fold_exact(tm[i], P, invP, &k, &r);
+                    ind = bin_of(r, bin_duration);
+                }
+                while (i < iend) {
+                    // a run starts at i: accumulate it to its end, even past this slice (but not past the round)
+                    const int cur = ind;
+                    double2 v = bins[cur];
+                    do {
+                        v.x += yw[i];
+                        v.y += ivar[i];
+                        ++i;
+                        if (i >= e) break;
+                        fold_exact(tm[i], P, invP, &k, &r);
+                        ind = bin_of(r, bin_duration);
+                    } while (ind == cur);
+                    bins[cur] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- wrap pad (reference: for n=1..oversample: mean[n_bins-oversample+n-1] = mean[n], in that order),
+    //      then sequential inclusive prefix sums (y on wave 0, ivar on wave 1)
+    if (n_bins - oversample > oversample) {  // source [1, os] and destination [n_bins-os, n_bins-1] are disjoint
+        for (int q = 1 + tid; q <= oversample; q += 256) bins[n_bins - oversample + q - 1] = bins[q];
+    } else if (tid == 0) {
+        for (int q = 1; q <= oversample; ++q) bins[n_bins - oversample + q - 1] = bins[q];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double acc = bins[0].x;
+        for (int i = 1; i <= n_bins; ++i) {
+            acc = bins[i].x + acc;
+            bins[i].x = acc;
+        }
+    }
+    if (tid == 64) {
+        double acc = bins[0].y;
+        for (int i = 1; i <= n_bins; ++i) {
+            acc = bins[i].y + acc;
+            bins[i].y = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- scan
+    const BlsStats st = stats[target];
+    const double sum_y = st.sum_y, sum_ivar = st.sum_ivar;
+    double best = -INFINITY;
+    int bk = -1, bn = -1;
+    for (int k = 0; k < n_dur; ++k) {
+        const int dur = dur_bins[k];
+        const int n_max = n_bins - dur;
+        for (int n = tid; n <= n_max; n += 256) {
+            const double2 hi = bins[n + dur], lw = bins[n];
+            double y_in = hi.x - lw.x;
+            const double ivar_in = hi.y - lw.y;
+            double y_out = sum_y - y_in;
+            const double ivar_out = sum_ivar - ivar_in;
+            if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
+            y_in /= ivar_in;
+            y_out /= ivar_out;
+            double obj;
+            if (obj_flag) {
+                const double arg = y_out - y_in;
+                obj = 0.5 * ivar_in * arg * arg;
+            } else {
+                const double depth = y_out - y_in;
+                const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+                obj = depth / depth_err;
+            }
+            if (y_out >= y_in && obj > best) {
+                best = obj;
+                bk = k;
+                bn = n;
+            }
+        }
+    }
+    s_best[tid] = BlsBest{best, bk, bn};
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const BlsBest o = s_best[tid + s], m = s_best[tid];
+            const bool take = o.k >= 0 && (m.k < 0 || o.obj > m.obj ||
+                                            (o.obj == m.obj && (o.k < m.k || (o.k == m.k && o.n < m.n))));
+            if (take) s_best[tid] = o;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const BlsBest w = s_best[0];
+        const size_t stride = (size_t)B * (size_t)nP;
+        double *o = out7 + (size_t)target * (size_t)nP + (size_t)p;
+        if (w.k < 0) {
+            o[0] = -INFINITY;
+            for (int f = 1; f < 7; ++f) o[f * stride] = 0.0;
+        } else {
+            const int dur = dur_bins[w.k], n = w.n;
+            const double2 hi = bins[n + dur], lw = bins[n];
+            double y_in = hi.x - lw.x;
+            const double ivar_in = hi.y - lw.y;
+            double y_out = sum_y - y_in;
+            const double ivar_out = sum_ivar - ivar_in;
+            y_in /= ivar_in;
+            y_out /= ivar_out;
+            const double arg = y_out - y_in;
+            const double log_like = 0.5 * ivar_in * arg * arg;
+            const double depth = y_out - y_in;
+            const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+            const double depth_snr = depth / depth_err;
+            const double duration = dur * bin_duration;
+            const double phase = fmod(n * bin_duration + 0.5 * duration + st.min_t, P);
+            o[0] = w.obj;
+            o[1 * stride] = depth;
+            o[2 * stride] = depth_err;
+            o[3 * stride] = duration;
+            o[4 * stride] = phase;
+            o[5 * stride] = depth_snr;
+            o[6 * stride] = log_like;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *ivar,
+               const double *period_host, const double *period_dev, int64_t nP, const double *duration_host, int nD,
+               int oversample, int use_likelihood, double *out7, hipStream_t stream) {
+    LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    LK_REQUIRE(nP >= 0 && nD >= 1, "need nP >= 0 and nD >= 1");
+    if (B == 0 || nP == 0) return LK_OK;
+    LK_REQUIRE(t && y && ivar && period_host && period_dev && duration_host && out7, "NULL buffer");
+    LK_REQUIRE(oversample >= 1, "oversample must be greater than or equal to 1");
+    LK_REQUIRE(nP < ((int64_t)1 << 31), "too many periods");
+    LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");
+    for (int b = 0; b < B; ++b) {
+        const int64_t n = n_off_host[b + 1] - n_off_host[b];
+        LK_REQUIRE(n >= 1 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
+    }
+    // the reference's run_bls input checks (nonzero return -> ValueError "Invalid inputs for period and/or duration")
+    double min_period = period_host[0], max_period = period_host[0];
+    for (int64_t k = 0; k < nP; ++k) {
+        LK_REQUIRE(std::isfinite(period_host[k]), "Invalid inputs for period and/or duration (non-finite period)");
+        min_period = std::min(min_period, period_host[k]);
+        max_period = std::max(max_period, period_host[k]);
+    }
+    double min_duration = duration_host[0], max_duration = duration_host[0];
+    for (int k = 0; k < nD; ++k) {
+        LK_REQUIRE(std::isfinite(duration_host[k]), "Invalid inputs for period and/or duration (non-finite duration)");
+        min_duration = std::min(min_duration, duration_host[k]);
+        max_duration = std::max(max_duration, duration_host[k]);
+    }
+    LK_REQUIRE(min_period >= DBL_EPSILON, "Invalid inputs for period and/or duration");
+    LK_REQUIRE(max_duration <= min_period && min_duration >= DBL_EPSILON, "Invalid inputs for period and/or duration");
+
+    const double bin_duration = min_duration / ((double)oversample);
+    // duration in bins; duplicates (same dur -> identical candidates, the first one wins anyway) are dropped
+    std::vector<int> dur_bins;
+    for (int k = 0; k < nD; ++k) {
+        const int d = (int)(std::round(duration_host[k] / bin_duration));
+        if (std::find(dur_bins.begin(), dur_bins.end(), d) == dur_bins.end()) dur_bins.push_back(d);
+    }
+    // periods grouped by LDS need (n_bins), longest first
+    std::vector<int> order((size_t)nP);
+    std::iota(order.begin(), order.end(), 0);
+    auto nbins_of = [&](int p) { return (int)(std::ceil(period_host[p] / bin_duration)) + oversample; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return period_host[a] > period_host[b]; });
+    const int max_bins = nbins_of(order[0]);
+    const size_t lds_fixed = 256 * sizeof(BlsBest) + (size_t)(BLS_RMAX + 4) * 4 + 256 * 4 + 16;
+    const size_t lds_max = (size_t)(max_bins + 1) * 16 + lds_fixed;
+    LK_REQUIRE(lds_max <= 150 * 1024,
+               "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most %d", max_bins,
+               (int)((150 * 1024 - lds_fixed) / 16 - 1));
+
+    const size_t ntot = (size_t)n_off_host[B];
+    h->ws.reset();
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(BlsStats) + 2 * (ntot * 8 + 256) +
+                           (size_t)nP * 4 + dur_bins.size() * 4 + 4096);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    BlsStats *d_stats = (BlsStats *)h->ws.alloc((size_t)B * sizeof(BlsStats));
+    double *d_tm = (double *)h->ws.alloc(ntot * 8), *d_yw = (double *)h->ws.alloc(ntot * 8);
+    int *d_pidx = (int *)h->ws.alloc((size_t)nP * 4);
+    int *d_dur = (int *)h->ws.alloc(dur_bins.size() * 4);
+    LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_pidx, order.data(), (size_t)nP * 4, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_dur, dur_bins.data(), dur_bins.size() * 4, hipMemcpyHostToDevice, stream));
+    // pageable-host async copies are staged before return, but be explicit: the vectors die at scope exit
+    LK_HIP_CHECK(hipStreamSynchronize(stream));
+
+    hipLaunchKernelGGL(bls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, ivar, d_off, d_tm, d_yw, d_stats);
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr_set = true;
+    }
+    // groups: cut whenever the LDS need drops below 3/4 of the group's head (keeps occupancy close to the need)
+    size_t g0 = 0;
+    while (g0 < (size_t)nP) {
+        const int head_bins = nbins_of(order[g0]);
+        size_t g1 = g0 + 1;
+        while (g1 < (size_t)nP && nbins_of(order[g1]) * 4 >= head_bins * 3) ++g1;
+        const int npg = (int)(g1 - g0);
+        const size_t lds = (size_t)(head_bins + 1) * 16 + lds_fixed;
+        const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)npg;
+        LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
+        hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(256), lds, stream, d_tm, d_yw, ivar, d_off,
+                           d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, (int)dur_bins.size(), bin_duration,
+                           oversample, use_likelihood ? 1 : 0, out7);
+        g0 = g1;
+    }
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk

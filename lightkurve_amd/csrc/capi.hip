@@ -1,0 +1,204 @@
+// capi.hip — extern "C" boundary of liblkhip.so (declared in include/lkhip.h).
+// Host-pointer entry points stage caller buffers into HBM, call the device-pointer entry points and copy
+// the results back; the device-pointer entry points only validate, carve scratch and enqueue kernels.
+#include "lk_common.hpp"
+
+namespace lk {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int Arena::reserve(size_t bytes) {
+    if (bytes <= cap) return LK_OK;
+    if (used != 0) {
+        set_error("Arena::reserve while sub-allocations are live");
+        return LK_EHIP;
+    }
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = 0;
+    size_t want = bytes + (bytes >> 3) + 4096;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        base = nullptr;
+        return e == hipErrorOutOfMemory ? LK_ENOMEM : LK_EHIP;
+    }
+    cap = want;
+    return LK_OK;
+}
+
+void Arena::release() {
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = used = 0;
+}
+
+}  // namespace lk
+
+using lk::set_error;
+
+extern "C" {
+
+int lk_version(void) { return 100; }
+
+const char *lk_last_error(void) { return lk::g_err.c_str(); }
+
+int lk_device_count(int *count) {
+    LK_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return LK_EHIP;
+    }
+    *count = n;
+    return LK_OK;
+}
+
+int lk_init(int device_id, lk_handle **out) {
+    LK_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    LK_HIP_CHECK(hipGetDeviceCount(&n));
+    LK_REQUIRE(device_id >= 0 && device_id < n, "device_id %d out of range (have %d devices)", device_id, n);
+    LK_HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    LK_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    lk_handle *h = new (std::nothrow) lk_handle();
+    if (!h) return LK_ENOMEM;
+    h->device = device_id;
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = h;
+    return LK_OK;
+}
+
+void lk_destroy(lk_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->ws.release();
+    h->staging.release();
+    delete h;
+}
+
+int64_t lk_workspace_bytes(const lk_handle *h) { return h ? (int64_t)(h->ws.cap + h->staging.cap) : 0; }
+
+// ------------------------------------------------------------------------------------------------ LS
+int lk_ls_power_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                          const double *dy, const double *freq, double f0, double df, int64_t M, int fit_mean,
+                          int center_data, int normalization, const double *scale, double *power, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::ls_launch(h, B, n_off_host, t, y, dy, freq, f0, df, M, fit_mean, center_data, normalization, scale,
+                         power, static_cast<hipStream_t>(stream));
+}
+
+int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                      const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data,
+                      int normalization, const double *scale, double *power) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    LK_REQUIRE(M >= 0, "M must be >= 0");
+    if (B == 0 || M == 0) return LK_OK;
+    LK_REQUIRE(t && y && power, "t, y, power must be non-NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B];
+    const size_t nb = ntot * sizeof(double), fb = freq ? (size_t)M * sizeof(double) : 0;
+    const size_t pb = (size_t)B * (size_t)M * sizeof(double), sb = scale ? (size_t)B * sizeof(double) : 0;
+    h->staging.reset();
+    int rc = h->staging.reserve(3 * (nb + 256) + fb + pb + sb + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(nb), *dyv = (double *)h->staging.alloc(nb);
+    double *ddy = dy ? (double *)h->staging.alloc(nb) : nullptr;
+    double *dfreq = freq ? (double *)h->staging.alloc(fb) : nullptr;
+    double *dscale = scale ? (double *)h->staging.alloc(sb) : nullptr;
+    double *dpow = (double *)h->staging.alloc(pb);
+    LK_HIP_CHECK(hipMemcpy(dt, t, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dyv, y, nb, hipMemcpyHostToDevice));
+    if (dy) LK_HIP_CHECK(hipMemcpy(ddy, dy, nb, hipMemcpyHostToDevice));
+    if (freq) LK_HIP_CHECK(hipMemcpy(dfreq, freq, fb, hipMemcpyHostToDevice));
+    if (scale) LK_HIP_CHECK(hipMemcpy(dscale, scale, sb, hipMemcpyHostToDevice));
+    rc = lk::ls_launch(h, B, n_off, dt, dyv, ddy, dfreq, f0, df, M, fit_mean, center_data, normalization, dscale,
+                       dpow, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(power, dpow, pb, hipMemcpyDeviceToHost));  // null-stream copy orders after the kernels
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ argmax
+int lk_argmax_batch_dev(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out,
+                        void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::argmax_launch(h, B, M, x, max_out, argmax_out, static_cast<hipStream_t>(stream));
+}
+
+int lk_argmax_batch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && M >= 1, "need B >= 0 and M >= 1");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(x && max_out && argmax_out, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t xb = (size_t)B * (size_t)M * sizeof(double);
+    h->staging.reset();
+    int rc = h->staging.reserve(xb + (size_t)B * 16 + 4096);
+    if (rc) return rc;
+    double *dx = (double *)h->staging.alloc(xb), *dm = (double *)h->staging.alloc((size_t)B * 8);
+    int64_t *da = (int64_t *)h->staging.alloc((size_t)B * 8);
+    LK_HIP_CHECK(hipMemcpy(dx, x, xb, hipMemcpyHostToDevice));
+    rc = lk::argmax_launch(h, B, M, dx, dm, da, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(max_out, dm, (size_t)B * 8, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(argmax_out, da, (size_t)B * 8, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ BLS
+int lk_bls_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                     const double *ivar, const double *period_host, const double *period_dev, int64_t nP,
+                     const double *duration_host, int nD, int oversample, int use_likelihood, double *out7,
+                     void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::bls_launch(h, B, n_off_host, t, y, ivar, period_host, period_dev, nP, duration_host, nD, oversample,
+                          use_likelihood, out7, static_cast<hipStream_t>(stream));
+}
+
+int lk_bls_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *ivar,
+                 const double *period, int64_t nP, const double *duration, int nD, int oversample,
+                 int use_likelihood, double *out7) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    LK_REQUIRE(nP >= 0 && nD >= 1, "need nP >= 0 and nD >= 1");
+    if (B == 0 || nP == 0) return LK_OK;
+    LK_REQUIRE(t && y && ivar && period && duration && out7, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B], nb = ntot * sizeof(double);
+    const size_t pb = (size_t)nP * sizeof(double), ob = 7 * (size_t)B * (size_t)nP * sizeof(double);
+    h->staging.reset();
+    int rc = h->staging.reserve(3 * (nb + 256) + pb + ob + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(nb), *dyv = (double *)h->staging.alloc(nb);
+    double *div = (double *)h->staging.alloc(nb), *dper = (double *)h->staging.alloc(pb);
+    double *dout = (double *)h->staging.alloc(ob);
+    LK_HIP_CHECK(hipMemcpy(dt, t, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dyv, y, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(div, ivar, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dper, period, pb, hipMemcpyHostToDevice));
+    rc = lk::bls_launch(h, B, n_off, dt, dyv, div, period, dper, nP, duration, nD, oversample, use_likelihood, dout,
+                        nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(out7, dout, ob, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
+}  // extern "C"

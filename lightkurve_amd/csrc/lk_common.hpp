@@ -1,0 +1,70 @@
+// lk_common.hpp — handle, error plumbing and scratch workspace shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lkhip.h"
+
+namespace lk {
+
+void set_error(const char *fmt, ...);
+
+#define LK_HIP_CHECK(expr)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            lk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                          __LINE__);                                                          \
+            return e_ == hipErrorOutOfMemory ? LK_ENOMEM : LK_EHIP;                           \
+        }                                                                                     \
+    } while (0)
+
+#define LK_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            lk::set_error(__VA_ARGS__);  \
+            return LK_EINVAL;            \
+        }                                \
+    } while (0)
+
+// Grow-only device scratch arena.  Sub-allocations are 256-byte aligned and valid until reset().
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+    int reserve(size_t bytes);  // ensure capacity (may reallocate: only call before any alloc())
+    void *alloc(size_t bytes) {
+        size_t a = (used + 255) & ~size_t(255);
+        if (a + bytes > cap) return nullptr;
+        used = a + bytes;
+        return base + a;
+    }
+    void reset() { used = 0; }
+    void release();
+};
+
+}  // namespace lk
+
+struct lk_handle {
+    int device = 0;
+    int num_cu = 256;
+    lk::Arena ws;        // kernel scratch (prepped per-cadence records, per-target stats)
+    lk::Arena staging;   // device mirrors of host buffers for the *_batch (host pointer) entry points
+};
+
+// launchers implemented in the .hip files (device pointers, enqueue on stream, no sync)
+namespace lk {
+int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+              const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data,
+              int normalization, const double *scale, double *power, hipStream_t stream);
+int argmax_launch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out,
+                  hipStream_t stream);
+int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *ivar,
+               const double *period_host, const double *period_dev, int64_t nP, const double *duration_host,
+               int nD, int oversample, int use_likelihood, double *out7, hipStream_t stream);
+}  // namespace lk

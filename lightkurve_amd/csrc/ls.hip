@@ -1,0 +1,408 @@
+// ls.hip — exact generalised Lomb-Scargle periodogram (floating mean) by direct trig sums, fp64, gfx950.
+//
+// Replaces astropy METHODS[method](t, y, dy, frequency, ...) behind LombScarglePeriodogram.from_lightcurve
+// (reference: src/lightkurve/periodogram.py:961-964) and fuses lightkurve's normalisation (periodogram.py:969-975).
+// Closed form follows astropy lombscargle/implementations/fast_impl.py:74-131 with the six trig sums evaluated
+// exactly (utils.py:154-156), i.e. the numerics of 'slow' / 'cython' / 'chi2'.
+//
+// Design (VALU-fp64 bound; HBM traffic is ~1e-4 of the arithmetic):
+//   * one 64-lane wavefront per workgroup owns a tile of 64*F consecutive grid frequencies of ONE target;
+//     lane l owns frequencies j0 + l*F .. j0 + l*F + F-1 and keeps their 6*F fp64 sums in registers;
+//   * cadences stream through in chunks of 16.  For a chunk, lane (i = l&15, g = l>>4) evaluates ONE exactly
+//     range-reduced sincos (the phasor of cadence i at the first frequency of lane 16g) and walks it across 16
+//     lanes' start frequencies by complex rotation, writing the seeds to a padded LDS tile [16][65];
+//   * the consume loop reads the lane's seed (ds_read_b128, conflict free), fetches the cadence's constants
+//     through the scalar cache (wave-uniform address -> s_load), and advances the phasor over its F frequencies
+//     with the 3-term recurrence a[k+1] = 2cos(th) a[k] - a[k-1]  (2 FMA) + 6 accumulate FMA = 8 v_fma_f64 per
+//     (cadence, frequency) pair = the 16 flop/pair algorithmic figure.  Phasors carry amplitude sqrt(w_i) so the
+//     weighted and the uniform-weight (lightkurve default) cases cost the same.
+//   * blockIdx -> (target, tile) is XCD-aware: all tiles of a target land on one XCD (block b runs on XCD b%8),
+//     so the target's 64 B/cadence record stream is served by that XCD's L2.
+#include "lk_common.hpp"
+
+namespace lk {
+
+struct CadHot {  // 32 B, read wave-uniformly in the consume loop
+    double v;    // sqrt(w_i) * (y_i - ybar)
+    double u;    // sqrt(w_i)
+    double qc;   // cos(2 pi df t_i)
+    double qs;   // sin(2 pi df t_i)
+};
+struct CadGen {  // 32 B, read per lane in the seed generator
+    double t;    // t_i
+    double u;    // sqrt(w_i)
+    double gc;   // cos(2 pi F df t_i)
+    double gs;   // sin(2 pi F df t_i)
+};
+struct CadAny {  // 24 B, arbitrary-frequency kernel
+    double t, v, u;
+};
+struct TargetStats {
+    double wsum;  // sum dy^-2 (or N)
+    double ybar;  // weighted mean that was subtracted (0 if no centring)
+    double YY;    // sum w (y-ybar)^2
+    double pad;
+};
+
+// sin/cos of 2*pi*(f*t) with the product reduced exactly: p = f*t rounded, e its exact error (fma),
+// r = (p - rint(p)) + e in [-0.5, 0.5]: phase error ~1e-17 cycles even for f*t ~ 1e4.
+__device__ __forceinline__ void sincos2pi_prod(double f, double t, double *s, double *c) {
+    double p = f * t;
+    double e = fma(f, t, -p);
+    double r = (p - rint(p)) + e;
+    sincospi(2.0 * r, s, c);
+}
+
+// ------------------------------------------------------------------------------------------------ prep
+// One 256-thread workgroup per target: weights, weighted mean (about y[0] so that a constant curve centres
+// to exactly 0 — tests/test_periodogram.py:445-457), YY, and the per-cadence records.
+template <int NT>
+__device__ __forceinline__ double block_sum(double x, double *sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = x;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void ls_prep_kernel(const double *__restrict__ t, const double *__restrict__ y,
+                                                       const double *__restrict__ dy,
+                                                       const int64_t *__restrict__ n_off, int center, double df,
+                                                       int F, CadHot *__restrict__ hot, CadGen *__restrict__ gen,
+                                                       CadAny *__restrict__ any, TargetStats *__restrict__ stats) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
+    if (n <= 0) {
+        if (tid == 0) stats[b] = TargetStats{0.0, 0.0, 0.0, 0.0};
+        return;
+    }
+    double acc = 0.0;
+    if (dy) {
+        for (int64_t i = tid; i < n; i += 256) {
+            double d = dy[lo + i];
+            acc += 1.0 / (d * d);
+        }
+    }
+    const double wsum = dy ? block_sum<256>(acc, sh) : (double)n;
+    const double y0 = y[lo];
+    double ybar = 0.0;
+    if (center) {
+        acc = 0.0;
+        for (int64_t i = tid; i < n; i += 256) {
+            double d = dy ? dy[lo + i] : 1.0;
+            double w = (1.0 / (d * d)) / wsum;
+            acc = fma(w, y[lo + i] - y0, acc);
+        }
+        ybar = block_sum<256>(acc, sh) + y0;
+    }
+    acc = 0.0;
+    for (int64_t i = tid; i < n; i += 256) {
+        double d = dy ? dy[lo + i] : 1.0;
+        double w = (1.0 / (d * d)) / wsum;
+        double yc = y[lo + i] - ybar;
+        acc = fma(w * yc, yc, acc);
+        double u = sqrt(w), ti = t[lo + i];
+        if (any) any[lo + i] = CadAny{ti, u * yc, u};
+        if (hot) {
+            double s, c;
+            sincos2pi_prod(df, ti, &s, &c);
+            hot[lo + i] = CadHot{u * yc, u, c, s};
+            sincos2pi_prod(df * (double)F, ti, &s, &c);  // F is a small power of two: df*F is exact
+            gen[lo + i] = CadGen{ti, u, c, s};
+        }
+    }
+    const double YY = block_sum<256>(acc, sh);
+    if (tid == 0) stats[b] = TargetStats{wsum, ybar, YY, 0.0};
+}
+
+// ------------------------------------------------------------------------------------------------ epilogue
+// Closed-form GLS from the six sums (fast_impl.py:93-131) + normalisation.  S2acc = sum w sin cos,
+// C2acc = sum w cos^2 (so S2 = 2 S2acc, C2 = 2 C2acc - 1 since sum w = 1).
+__device__ __forceinline__ double gls_power(double Sh, double Ch, double S, double C, double S2acc, double C2acc,
+                                            int fit_mean, int norm, double YY, double psd_factor, double nN,
+                                            double scale) {
+    const double S2 = 2.0 * S2acc, C2 = fma(2.0, C2acc, -1.0);
+    double tan2;
+    if (fit_mean)
+        tan2 = (S2 - 2.0 * S * C) / (C2 - (C * C - S * S));
+    else
+        tan2 = S2 / C2;
+    const double C2w = 1.0 / sqrt(1.0 + tan2 * tan2);
+    const double S2w = tan2 * C2w;
+    const double Cw = sqrt(0.5) * sqrt(1.0 + C2w);
+    const double sgn = (S2w > 0.0) ? 1.0 : ((S2w < 0.0) ? -1.0 : 0.0);
+    const double Sw = sqrt(0.5) * sgn * sqrt(1.0 - C2w);
+    const double YC = Ch * Cw + Sh * Sw;
+    const double YS = Sh * Cw - Ch * Sw;
+    double CC = 0.5 * (1.0 + C2 * C2w + S2 * S2w);
+    double SS = 0.5 * (1.0 - C2 * C2w - S2 * S2w);
+    if (fit_mean) {
+        const double a = C * Cw + S * Sw, bq = S * Cw - C * Sw;
+        CC -= a * a;
+        SS -= bq * bq;
+    }
+    double p = YC * YC / CC + YS * YS / SS;
+    switch (norm) {
+        case LK_NORM_STANDARD: p /= YY; break;
+        case LK_NORM_PSD: p *= psd_factor; break;
+        case LK_NORM_LK_AMPLITUDE: p = sqrt(p * psd_factor) * sqrt(4.0 / nN); break;
+        default: p = p * psd_factor * scale; break;
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------ grid kernel
+constexpr int LS_CHUNK = 16;  // cadences per seed tile
+
+template <int F>
+__global__ __launch_bounds__(64) void ls_grid_kernel(const CadHot *__restrict__ hot,
+                                                      const CadGen *__restrict__ gen,
+                                                      const int64_t *__restrict__ n_off,
+                                                      const TargetStats *__restrict__ stats, int B, double f0,
+                                                      double df, int64_t M, int tiles, int norm, int fit_mean,
+                                                      const double *__restrict__ scale,
+                                                      double *__restrict__ power) {
+    __shared__ double2 seeds[LS_CHUNK][65];  // +1 column: the generator's 8 lanes x 1040 B stride hit 8 bank groups
+
+    // XCD-aware decode: block b -> XCD b%8; targets are dealt round-robin to XCDs, tiles of a target stay together
+    const unsigned bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const int target = (int)((slot / (unsigned)tiles) * 8u + xcd);
+    const int tile = (int)(slot % (unsigned)tiles);
+    if (target >= B) return;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    const int lane = threadIdx.x;
+    const int64_t j0 = (int64_t)tile * (64 * F);
+    hot += lo;
+    gen += lo;
+
+    double Sh[F], Ch[F], S[F], C[F], S2[F], C2[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) Sh[k] = Ch[k] = S[k] = C[k] = S2[k] = C2[k] = 0.0;
+
+    const int gi = lane & 15, gg = lane >> 4;
+    const double fstart = fma((double)(j0 + (int64_t)(16 * gg) * F), df, f0);
+
+    for (int i0 = 0; i0 < n; i0 += LS_CHUNK) {
+        // ---- seed generation: lane (gi, gg) covers lanes 16gg..16gg+15 of cadence i0+gi
+        {
+            double a = 0.0, b = 0.0, gc = 1.0, gs = 0.0;
+            if (i0 + gi < n) {
+                const CadGen g = gen[i0 + gi];
+                double sn, cs;
+                sincos2pi_prod(fstart, g.t, &sn, &cs);
+                a = g.u * cs;
+                b = g.u * sn;
+                gc = g.gc;
+                gs = g.gs;
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                seeds[gi][16 * gg + m] = make_double2(a, b);
+                const double an = fma(a, gc, -(b * gs));
+                b = fma(b, gc, a * gs);
+                a = an;
+            }
+        }
+        __syncthreads();
+        // ---- consume
+        const int ni = min(LS_CHUNK, n - i0);
+        CadHot hn = hot[i0];  // wave-uniform address -> scalar load
+        double2 pn = seeds[0][lane];
+        for (int ii = 0; ii < ni; ++ii) {
+            const CadHot h = hn;
+            const double2 p = pn;
+            // software prefetch of the next cadence (clamped: stays inside this target / this tile)
+            hn = hot[min(i0 + ii + 1, n - 1)];
+            pn = seeds[min(ii + 1, LS_CHUNK - 1)][lane];
+            const double alpha = h.qc + h.qc;
+            double am = p.x, bm = p.y;  // k-1 (starts as k = 0)
+            Sh[0] = fma(h.v, bm, Sh[0]);
+            Ch[0] = fma(h.v, am, Ch[0]);
+            S[0] = fma(h.u, bm, S[0]);
+            C[0] = fma(h.u, am, C[0]);
+            S2[0] = fma(am, bm, S2[0]);
+            C2[0] = fma(am, am, C2[0]);
+            double ac = fma(am, h.qc, -(bm * h.qs));  // k = 1 by rotation
+            double bc = fma(bm, h.qc, am * h.qs);
+#pragma unroll
+            for (int k = 1; k < F; ++k) {
+                Sh[k] = fma(h.v, bc, Sh[k]);
+                Ch[k] = fma(h.v, ac, Ch[k]);
+                S[k] = fma(h.u, bc, S[k]);
+                C[k] = fma(h.u, ac, C[k]);
+                S2[k] = fma(ac, bc, S2[k]);
+                C2[k] = fma(ac, ac, C2[k]);
+                if (k + 1 < F) {
+                    const double an = fma(alpha, ac, -am);
+                    const double bn = fma(alpha, bc, -bm);
+                    am = ac;
+                    bm = bc;
+                    ac = an;
+                    bc = bn;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const TargetStats st = stats[target];
+    const double psd_factor = 0.5 * st.wsum;
+    const double sc = scale ? scale[target] : 1.0;
+    double *out = power + (size_t)target * (size_t)M;
+    const int64_t jl = j0 + (int64_t)lane * F;
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        if (jl + k < M)
+            out[jl + k] = gls_power(Sh[k], Ch[k], S[k], C[k], S2[k], C2[k], fit_mean, norm, st.YY, psd_factor,
+                                    (double)n, sc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ arbitrary frequencies
+// One thread per frequency, one exactly-reduced sincos per (cadence, frequency) pair (~7x the grid kernel's cost).
+// Used when the requested grid is not regular in frequency (lightkurve then picks 'slow': periodogram.py:933-946).
+__global__ __launch_bounds__(256) void ls_any_kernel(const CadAny *__restrict__ cad,
+                                                      const int64_t *__restrict__ n_off,
+                                                      const TargetStats *__restrict__ stats,
+                                                      const double *__restrict__ freq, int64_t M, int norm,
+                                                      int fit_mean, const double *__restrict__ scale,
+                                                      double *__restrict__ power) {
+    const int target = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    cad += lo;
+    const double f = (j < M) ? freq[j] : 0.0;
+    double Sh = 0, Ch = 0, S = 0, C = 0, S2 = 0, C2 = 0;
+    for (int i = 0; i < n; ++i) {
+        const CadAny q = cad[i];  // uniform -> scalar load
+        double sn, cs;
+        sincos2pi_prod(f, q.t, &sn, &cs);
+        const double a = q.u * cs, b = q.u * sn;
+        Sh = fma(q.v, b, Sh);
+        Ch = fma(q.v, a, Ch);
+        S = fma(q.u, b, S);
+        C = fma(q.u, a, C);
+        S2 = fma(a, b, S2);
+        C2 = fma(a, a, C2);
+    }
+    if (j < M) {
+        const TargetStats st = stats[target];
+        power[(size_t)target * (size_t)M + j] =
+            gls_power(Sh, Ch, S, C, S2, C2, fit_mean, norm, st.YY, 0.5 * st.wsum, (double)n,
+                      scale ? scale[target] : 1.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+constexpr int LS_F = 16;
+
+int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+              const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
+              const double *scale, double *power, hipStream_t stream) {
+    LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    LK_REQUIRE(M >= 0, "M must be >= 0");
+    if (B == 0 || M == 0) return LK_OK;
+    LK_REQUIRE(t && y && power, "t, y, power must be non-NULL");
+    LK_REQUIRE(normalization >= LK_NORM_STANDARD && normalization <= LK_NORM_LK_PSD, "unknown normalization %d",
+               normalization);
+    for (int b = 0; b < B; ++b)
+        LK_REQUIRE(n_off_host[b + 1] > n_off_host[b], "target %d is empty (every light curve needs >= 1 cadence)", b);
+    LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");
+    if (!freq) {
+        LK_REQUIRE(f0 >= 0.0, "Frequencies must be positive");
+        LK_REQUIRE(df > 0.0, "Frequency steps must be positive");
+    }
+    const size_t ntot = (size_t)n_off_host[B];
+    for (int b = 0; b < B; ++b)
+        LK_REQUIRE(n_off_host[b + 1] - n_off_host[b] < (int64_t)1 << 30, "target %d too long", b);
+
+    h->ws.reset();
+    const size_t need = (size_t)(B + 1) * 8 + (size_t)B * sizeof(TargetStats) + ntot * (sizeof(CadHot) + sizeof(CadGen)) +
+                        4096;
+    int rc = h->ws.reserve(need);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    TargetStats *d_stats = (TargetStats *)h->ws.alloc((size_t)B * sizeof(TargetStats));
+    LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    const int center = (fit_mean || center_data) ? 1 : 0;
+
+    if (freq) {
+        CadAny *d_any = (CadAny *)h->ws.alloc(ntot * sizeof(CadAny));
+        hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, 0.0, 1,
+                           (CadHot *)nullptr, (CadGen *)nullptr, d_any, d_stats);
+        dim3 grid((unsigned)((M + 255) / 256), (unsigned)B);
+        hipLaunchKernelGGL(ls_any_kernel, grid, dim3(256), 0, stream, d_any, d_off, d_stats, freq, M, normalization,
+                           fit_mean, scale, power);
+    } else {
+        CadHot *d_hot = (CadHot *)h->ws.alloc(ntot * sizeof(CadHot));
+        CadGen *d_gen = (CadGen *)h->ws.alloc(ntot * sizeof(CadGen));
+        hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, df, LS_F, d_hot,
+                           d_gen, (CadAny *)nullptr, d_stats);
+        const int tiles = (int)((M + 64 * LS_F - 1) / (64 * LS_F));
+        const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)tiles;
+        LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large (B=%d, M=%lld)", B, (long long)M);
+        hipLaunchKernelGGL(ls_grid_kernel<LS_F>, dim3((unsigned)nblocks), dim3(64), 0, stream, d_hot, d_gen, d_off,
+                           d_stats, B, f0, df, M, tiles, normalization, fit_mean, scale, power);
+    }
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ nanargmax
+__global__ __launch_bounds__(256) void argmax_kernel(const double *__restrict__ x, int64_t M, double *max_out,
+                                                      int64_t *arg_out) {
+    __shared__ double sv[256];
+    __shared__ int64_t si[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *row = x + (size_t)b * (size_t)M;
+    double best = -INFINITY;
+    int64_t bi = -1;
+    for (int64_t j = tid; j < M; j += 256) {
+        const double v = row[j];
+        if (v == v && (bi < 0 || v > best)) {  // NaN skipped; strict > keeps the first maximum
+            best = v;
+            bi = j;
+        }
+    }
+    sv[tid] = best;
+    si[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double v2 = sv[tid + s];
+            const int64_t i2 = si[tid + s];
+            if (i2 >= 0 && (si[tid] < 0 || v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid]))) {
+                sv[tid] = v2;
+                si[tid] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        max_out[b] = si[0] >= 0 ? sv[0] : NAN;
+        arg_out[b] = si[0];
+    }
+}
+
+int argmax_launch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out,
+                  hipStream_t stream) {
+    (void)h;
+    LK_REQUIRE(B >= 0 && M >= 1, "need B >= 0 and M >= 1");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(x && max_out && argmax_out, "NULL buffer");
+    hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, stream, x, M, max_out, argmax_out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk
