@@ -18,6 +18,8 @@
 //     weighted and the uniform-weight (lightkurve default) cases cost the same.
 //   * blockIdx -> (target, tile) is XCD-aware: all tiles of a target land on one XCD (block b runs on XCD b%8),
 //     so the target's 64 B/cadence record stream is served by that XCD's L2.
+#include <cstdlib>
+
 #include "lk_common.hpp"
 
 namespace lk {
@@ -346,13 +348,22 @@ int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, c
     } else {
         CadHot *d_hot = (CadHot *)h->ws.alloc(ntot * sizeof(CadHot));
         CadGen *d_gen = (CadGen *)h->ws.alloc(ntot * sizeof(CadGen));
-        hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, df, LS_F, d_hot,
+        int F = LS_F;
+        if (const char *e = getenv("LK_LS_F")) F = atoi(e);  // tuning knob (8 | 16); F=32 would need 384 accumulator VGPRs > the 256 a VALU op can address
+        if (F != 8 && F != 16) F = LS_F;
+        hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, df, F, d_hot,
                            d_gen, (CadAny *)nullptr, d_stats);
-        const int tiles = (int)((M + 64 * LS_F - 1) / (64 * LS_F));
+        const int tiles = (int)((M + 64 * F - 1) / (64 * F));
         const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)tiles;
         LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large (B=%d, M=%lld)", B, (long long)M);
-        hipLaunchKernelGGL(ls_grid_kernel<LS_F>, dim3((unsigned)nblocks), dim3(64), 0, stream, d_hot, d_gen, d_off,
-                           d_stats, B, f0, df, M, tiles, normalization, fit_mean, scale, power);
+#define LK_LS_LAUNCH(FF)                                                                                       \
+    hipLaunchKernelGGL(ls_grid_kernel<FF>, dim3((unsigned)nblocks), dim3(64), 0, stream, d_hot, d_gen, d_off,  \
+                       d_stats, B, f0, df, M, tiles, normalization, fit_mean, scale, power)
+        if (F == 8)
+            LK_LS_LAUNCH(8);
+        else
+            LK_LS_LAUNCH(16);
+#undef LK_LS_LAUNCH
     }
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
