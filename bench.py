@@ -114,7 +114,7 @@ def main():
         d_max = torch.empty(B, dtype=torch.float64, device=dev)
         d_arg = torch.empty(B, dtype=torch.int64, device=dev)
         gather = world > 1 and not args.no_gather
-        nch = max(1, min(args.chunks, B))
+        nch = max(1, min(args.chunks, B)) if gather else 1
         bounds = np.linspace(0, B, nch + 1).astype(int)
         d_all = [torch.empty((world, bounds[c + 1] - bounds[c], M), dtype=torch.float64, device=dev)
                  for c in range(nch)] if gather else None

@@ -21,6 +21,7 @@
 // blockIdx -> (target, period) is XCD-aware (all periods of a target on one XCD; its t / y*ivar / ivar arrays,
 // 24 B per cadence, stay in that XCD's L2).
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 
 #include <algorithm>
@@ -92,18 +93,30 @@ __device__ __forceinline__ void fold_exact(double t, double P, double invP, doub
 
 __device__ __forceinline__ int bin_of(double r, double bin_duration) { return (int)(fabs(r) / bin_duration) + 1; }
 
-constexpr int BLS_RMAX = 2048;  // round boundaries kept in LDS; more rounds (badly unsorted time) -> serial path
+// Same value as bin_of without the IEEE division on the common path: q = r * fl(1/bd) is within 4.5e-16*q of the
+// correctly rounded quotient, so trunc(q) can only differ when q sits within that distance of an integer; those
+// (vanishingly rare) cadences take the exact division.
+__device__ __forceinline__ int bin_of_fast(double r, double bin_duration, double inv_bd) {
+    const double q = r * inv_bd;
+    const double f = q - floor(q);
+    const double guard = 1e-12 * (q + 1.0);
+    if (f > guard && (1.0 - f) > guard) return (int)q + 1;
+    return bin_of(r, bin_duration);
+}
+
+constexpr int BLS_RMAX = 512;   // most rounds ever kept (4-wave blocks)
+constexpr int BLS_RSEG = 2048;  // ints reserved for the per-round wave boundaries: (NW-1) * (BLS_RSEG/NW)  // round boundaries kept in LDS; more rounds (badly unsorted time) -> serial path
 
 struct BlsBest {
     double obj;
     int k, n;
 };
 
-__global__ __launch_bounds__(256) void bls_kernel(
+__global__ __launch_bounds__(1024) void bls_kernel(
     const double *__restrict__ tm, const double *__restrict__ yw, const double *__restrict__ ivar,
     const int64_t *__restrict__ n_off, const BlsStats *__restrict__ stats, const double *__restrict__ period,
     const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_bins, int n_dur,
-    double bin_duration, int oversample, int obj_flag, double *__restrict__ out7) {
+    double bin_duration, int oversample, int obj_flag, double *__restrict__ out7, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS is dynamic: keeps the base 16-B aligned
 
     const unsigned bid = blockIdx.x;
@@ -121,63 +134,70 @@ __global__ __launch_bounds__(256) void bls_kernel(
     yw += lo;
     ivar += lo;
 
-    // LDS carve (every offset a multiple of 16): bins | s_best | rstart | s_cnt | s_nrounds
+    // LDS carve (every offset a multiple of 16): bins | s_best[NT] | rstart | s_cnt | s_thr | segs
+    const int NT = blockDim.x, NW = NT >> 6;  // 4, 8 or 16 waves: big-LDS (long-period) groups get more waves
+    const int rmax = BLS_RSEG / NW;           // rounds kept in LDS; beyond that the serial path runs
     double2 *bins = reinterpret_cast<double2 *>(smem);  // [n_bins + 1] (y, ivar)
     char *after = smem + (size_t)(n_bins + 1) * 16;
-    BlsBest *s_best = reinterpret_cast<BlsBest *>(after);                    // [256]
-    int *rstart = reinterpret_cast<int *>(after + 256 * sizeof(BlsBest));    // [BLS_RMAX + 2]
-    int *s_cnt = rstart + (BLS_RMAX + 4);                                    // [256]
-    int *s_nrounds_p = s_cnt + 256;
+    BlsBest *s_best = reinterpret_cast<BlsBest *>(after);                       // [NT]
+    int *rstart = reinterpret_cast<int *>(after + (size_t)NT * sizeof(BlsBest));  // [BLS_RMAX + 4]
+    int *s_cnt = rstart + (BLS_RMAX + 4);                                       // [16]
+    long long *s_thr = reinterpret_cast<long long *>(s_cnt + 16);               // 8-B aligned
+    int *segs = s_cnt + 20;                                                     // [(NW-1) * rmax] <= BLS_RSEG
 
-    for (int i = tid; i <= n_bins; i += 256) bins[i] = make_double2(0.0, 0.0);
+    for (int i = tid; i <= n_bins; i += NT) bins[i] = make_double2(0.0, 0.0);
 
-    // ---- pass A: round boundaries
-    const int L = (N + 255) / 256;
-    const int a0 = min(tid * L, N), a1 = min(a0 + L, N);
-    int cnt = 0;
+    // ---- pass A: round boundaries.  Wave w sweeps cadences [w*Q, (w+1)*Q) 64 at a time (coalesced loads); the
+    //      predecessor's (k, r) comes from the lane below (lane 0: carried from the previous sweep step).
+    const int wave = tid >> 6, lane = tid & 63;
+    const int Q = (((N + NW - 1) / NW) + 63) & ~63;
+    const int w0 = min(wave * Q, N), w1 = min(w0 + Q, N);
+    auto sweep = [&](int write_base) -> int {
+        int found = 0;
+        double kc = -1.0, rc = 0.0;  // carry: (k, r) of cadence i0 - 1
+        if (w0 > 0 && w0 < N) fold_exact(tm[w0 - 1], P, invP, &kc, &rc);
+        for (int i0 = w0; i0 < w1; i0 += 64) {
+            const int i = i0 + lane;
+            double k = -1.0, r = 0.0;
+            if (i < w1) fold_exact(tm[i], P, invP, &k, &r);
+            double kp = __shfl_up(k, 1), rp = __shfl_up(r, 1);
+            if (lane == 0) {
+                kp = kc;
+                rp = rc;
+            }
+            const bool flag = (i < w1) && (i > 0) && (k != kp || r < rp);
+            const unsigned long long bal = __ballot(flag);
+            if (write_base >= 0 && flag) {
+                const int pos = write_base + found + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos <= rmax) rstart[pos] = i;
+            }
+            found += __popcll(bal);
+            kc = __shfl(k, 63);
+            rc = __shfl(r, 63);
+        }
+        return found;
+    };
     {
-        double kp = -1.0, rp = 0.0;
-        if (a0 > 0 && a0 < N) fold_exact(tm[a0 - 1], P, invP, &kp, &rp);
-        for (int i = a0; i < a1; ++i) {
-            double k, r;
-            fold_exact(tm[i], P, invP, &k, &r);
-            if (i > 0 && (k != kp || r < rp)) ++cnt;
-            kp = k;
-            rp = r;
-        }
+        const int cnt = sweep(-1);
+        if (lane == 0) s_cnt[wave] = cnt;
     }
-    s_cnt[tid] = cnt;
     __syncthreads();
+    int wbase = 1;  // round 0 starts at cadence 0
+    for (int w = 0; w < wave; ++w) wbase += s_cnt[w];
+    int nrounds = 1;
+    for (int w = 0; w < NW; ++w) nrounds += s_cnt[w];
+    const bool serial = nrounds > rmax;
     if (tid == 0) {
-        int acc = 1;  // round 0 starts at cadence 0
-        for (int i = 0; i < 256; ++i) {
-            int c = s_cnt[i];
-            s_cnt[i] = acc;
-            acc += c;
-        }
-        *s_nrounds_p = acc;
+        *s_thr = __double_as_longlong(-INFINITY);
         rstart[0] = 0;
+        if (!serial) rstart[nrounds] = N;
     }
-    __syncthreads();
-    const int nrounds = *s_nrounds_p;
-    const bool serial = nrounds > BLS_RMAX;
-    if (!serial) {
-        int w = s_cnt[tid];
-        double kp = -1.0, rp = 0.0;
-        if (a0 > 0 && a0 < N) fold_exact(tm[a0 - 1], P, invP, &kp, &rp);
-        for (int i = a0; i < a1; ++i) {
-            double k, r;
-            fold_exact(tm[i], P, invP, &k, &r);
-            if (i > 0 && (k != kp || r < rp)) rstart[w++] = i;
-            kp = k;
-            rp = r;
-        }
-        if (tid == 0) rstart[nrounds] = N;
-    }
+    if (!serial && !(ablate & 8)) (void)sweep(wbase);
     __syncthreads();
 
     // ---- pass B: ordered histogram
-    if (serial) {
+    if (ablate & 1) {
+    } else if (serial) {
         if (tid == 0) {
             for (int i = 0; i < N; ++i) {
                 double k, r;
@@ -191,86 +211,153 @@ __global__ __launch_bounds__(256) void bls_kernel(
         }
         __syncthreads();
     } else {
-        for (int rd = 0; rd < nrounds; ++rd) {
-            const int s = rstart[rd], e = rstart[rd + 1];
-            const int len = e - s;
-            const int per = (len + 255) / 256;
-            int i = min(s + tid * per, e);
-            const int iend = min(i + per, e);
-            if (i < iend) {
+        // Bins are split into four contiguous ranges, one per wave: inside a round the bin index is non-decreasing
+        // in cadence order, so each wave's cadences form one contiguous segment of the round, found by a
+        // per-thread binary search (all rounds x 3 boundaries at once).  A wave then walks the rounds in order on
+        // its own bins only: no workgroup barrier, and per-bin additions stay in cadence order.
+        const double inv_bd = 1.0 / bin_duration;
+        const int nb1 = NW - 1;
+        for (int q = tid; q < nb1 * nrounds; q += NT) {
+            const int rd = q / nb1, wb = q - nb1 * rd + 1;
+            const int bound = (int)(((long long)wb * (n_bins + 1)) / NW);  // first bin owned by wave wb
+            int lo_i = rstart[rd], hi_i = rstart[rd + 1];
+            while (lo_i < hi_i) {
+                const int mid = (lo_i + hi_i) >> 1;
                 double k, r;
-                int prev = -1;
-                if (i > s) {
-                    fold_exact(tm[i - 1], P, invP, &k, &r);
-                    prev = bin_of(r, bin_duration);
-                }
-                fold_exact(tm[i], P, invP, &k, &r);
-                int ind = bin_of(r, bin_duration);
-                // skip the tail of a run that started in the previous slice (its owner finishes it)
-                while (ind == prev) {
-                    ++i;
-                    if (i >= iend) break;
-                    fold_exact(tm[i], P, invP, &k, &r);
-                    ind = bin_of(r, bin_duration);
-                }
-                while (i < iend) {
-                    // a run starts at i: accumulate it to its end, even past this slice (but not past the round)
-                    const int cur = ind;
-                    double2 v = bins[cur];
-                    do {
-                        v.x += yw[i];
-                        v.y += ivar[i];
-                        ++i;
-                        if (i >= e) break;
-                        fold_exact(tm[i], P, invP, &k, &r);
-                        ind = bin_of(r, bin_duration);
-                    } while (ind == cur);
-                    bins[cur] = v;
-                }
+                fold_exact(tm[mid], P, invP, &k, &r);
+                if (bin_of_fast(r, bin_duration, inv_bd) < bound)
+                    lo_i = mid + 1;
+                else
+                    hi_i = mid;
             }
-            __syncthreads();
+            segs[q] = lo_i;
         }
+        __syncthreads();
+        for (int rd = 0; rd < nrounds; ++rd) {
+            const int s0 = (wave == 0) ? rstart[rd] : segs[nb1 * rd + wave - 1];
+            const int s1 = (wave == NW - 1) ? rstart[rd + 1] : segs[nb1 * rd + wave];
+            for (int i0 = s0; i0 < s1; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < s1;
+                int ind = -1 - lane;  // inactive lanes: unique negatives, never equal to a neighbour
+                double vy = 0.0, vi = 0.0;
+                if (act) {
+                    double k, r;
+                    fold_exact(tm[i], P, invP, &k, &r);
+                    ind = bin_of_fast(r, bin_duration, inv_bd);
+                    vy = yw[i];
+                    vi = ivar[i];
+                }
+                const int indp = __shfl_up(ind, 1);
+                const bool leader = act && (lane == 0 || ind != indp);
+                // the leader of a run folds the run's members into its bin one by one (reference order)
+                double2 v = make_double2(0.0, 0.0);
+                if (leader) {
+                    v = bins[ind];
+                    v.x += vy;
+                    v.y += vi;
+                }
+                for (int d = 1; d < 64; ++d) {
+                    const int indd = __shfl_down(ind, d);
+                    const bool more = leader && (lane + d < 64) && (indd == ind);
+                    if (!__any(more)) break;
+                    const double my = __shfl_down(vy, d), mi = __shfl_down(vi, d);
+                    if (more) {
+                        v.x += my;
+                        v.y += mi;
+                    }
+                }
+                if (leader) bins[ind] = v;
+            }
+        }
+        __syncthreads();
     }
 
     // ---- wrap pad (reference: for n=1..oversample: mean[n_bins-oversample+n-1] = mean[n], in that order),
     //      then sequential inclusive prefix sums (y on wave 0, ivar on wave 1)
     if (n_bins - oversample > oversample) {  // source [1, os] and destination [n_bins-os, n_bins-1] are disjoint
-        for (int q = 1 + tid; q <= oversample; q += 256) bins[n_bins - oversample + q - 1] = bins[q];
+        for (int q = 1 + tid; q <= oversample; q += NT) bins[n_bins - oversample + q - 1] = bins[q];
     } else if (tid == 0) {
         for (int q = 1; q <= oversample; ++q) bins[n_bins - oversample + q - 1] = bins[q];
     }
     __syncthreads();
-    if (tid == 0) {
-        double acc = bins[0].x;
-        for (int i = 1; i <= n_bins; ++i) {
-            acc = bins[i].x + acc;
-            bins[i].x = acc;
-        }
-    }
-    if (tid == 64) {
-        double acc = bins[0].y;
-        for (int i = 1; i <= n_bins; ++i) {
-            acc = bins[i].y + acc;
-            bins[i].y = acc;
+    // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  Wave 0 does y,
+    // wave 1 does ivar: 64 bins are fetched at once (one per lane) and the chain runs over v_readlane broadcasts,
+    // so no LDS round trip sits on the dependent-add path.  bins[0] is always (0, 0), so starting at i = 0 with
+    // acc = 0 is the same chain.
+    if (wave < 2 && !(ablate & 2)) {
+        double acc = 0.0;
+        double *comp = reinterpret_cast<double *>(bins) + wave;  // .x for wave 0, .y for wave 1 (stride 2 doubles)
+        for (int base = 0; base <= n_bins; base += 64) {
+            const int i = base + lane;
+            const double x = (i <= n_bins) ? comp[2 * i] : 0.0;
+            double out = 0.0;
+            const int lo_bits = __double2loint(x), hi_bits = __double2hiint(x);
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const double sj = __hiloint2double(__builtin_amdgcn_readlane(hi_bits, j),
+                                                   __builtin_amdgcn_readlane(lo_bits, j));
+                acc = sj + acc;
+                if (lane == j) out = acc;
+            }
+            if (i <= n_bins) comp[2 * i] = out;
         }
     }
     __syncthreads();
 
     // ---- scan
+    // Wave w takes durations w, w+4, ...; its lanes stride over the start bins.  Every candidate first goes
+    // through a DIVISION-FREE conservative filter against the best objective seen so far by anyone in the
+    // workgroup (s_thr): with a = y_out sum, b = ivar_in, c = y_in sum, e = ivar_out and Nn = a*b - c*e,
+    //     likelihood  0.5*b*(a/e - c/b)^2 > thr  <=>  0.5*Nn^2 > thr*b*e^2
+    //     snr         (a/e - c/b)/sqrt(1/b+1/e) > thr  <=>  Nn >= 0 and Nn^2 > thr^2*b*e*(b+e)
+    // evaluated with an absolute slack eN >= every rounding the exact chain can commit, so a rejected candidate
+    // is STRICTLY below the threshold and can never be the winner (ties always reach the exact path).  Survivors
+    // (a handful per workgroup) run the reference's exact arithmetic, which alone decides the result.
     const BlsStats st = stats[target];
     const double sum_y = st.sum_y, sum_ivar = st.sum_ivar;
     double best = -INFINITY;
     int bk = -1, bn = -1;
-    for (int k = 0; k < n_dur; ++k) {
+    for (int k = wave; k < ((ablate & 4) ? 0 : n_dur); k += NW) {
         const int dur = dur_bins[k];
         const int n_max = n_bins - dur;
-        for (int n = tid; n <= n_max; n += 256) {
-            const double2 hi = bins[n + dur], lw = bins[n];
+        const double thr_shared = __longlong_as_double(*s_thr);  // refreshed once per duration (filter only)
+        int n = lane;
+        double2 hi_n = make_double2(0.0, 0.0), lw_n = hi_n;
+        if (n <= n_max) {
+            hi_n = bins[n + dur];
+            lw_n = bins[n];
+        }
+        while (n <= n_max) {
+            const double2 hi = hi_n, lw = lw_n;
+            const int nc = n;
+            n += 64;
+            if (n <= n_max) {  // prefetch the next start bin before working on this one
+                hi_n = bins[n + dur];
+                lw_n = bins[n];
+            }
             double y_in = hi.x - lw.x;
             const double ivar_in = hi.y - lw.y;
             double y_out = sum_y - y_in;
             const double ivar_out = sum_ivar - ivar_in;
             if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
+            {
+                const double thr = fmax(best, thr_shared);
+                const double ab = y_out * ivar_in, ce = y_in * ivar_out;
+                const double Nn = ab - ce;
+                const double eN = (fabs(ab) + fabs(ce)) * 1e-15;
+                if (Nn + eN < 0.0) continue;  // certainly y_out < y_in
+                const double m = fabs(Nn) + eN;
+                double lhs, rhs;
+                if (obj_flag) {
+                    lhs = 0.5 * m * m;
+                    rhs = thr * ivar_in * ivar_out * ivar_out;
+                } else {
+                    lhs = m * m;
+                    rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
+                }
+                if (lhs * (1.0 + 1e-12) < rhs) continue;  // certainly objective < thr
+            }
             y_in /= ivar_in;
             y_out /= ivar_out;
             double obj;
@@ -285,13 +372,14 @@ __global__ __launch_bounds__(256) void bls_kernel(
             if (y_out >= y_in && obj > best) {
                 best = obj;
                 bk = k;
-                bn = n;
+                bn = nc;
+                atomicMax(s_thr, __double_as_longlong(obj));  // obj >= 0 here: the bit pattern orders like the value
             }
         }
     }
     s_best[tid] = BlsBest{best, bk, bn};
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = NT >> 1; s > 0; s >>= 1) {
         if (tid < s) {
             const BlsBest o = s_best[tid + s], m = s_best[tid];
             const bool take = o.k >= 0 && (m.k < 0 || o.obj > m.obj ||
@@ -378,7 +466,8 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     auto nbins_of = [&](int p) { return (int)(std::ceil(period_host[p] / bin_duration)) + oversample; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return period_host[a] > period_host[b]; });
     const int max_bins = nbins_of(order[0]);
-    const size_t lds_fixed = 256 * sizeof(BlsBest) + (size_t)(BLS_RMAX + 4) * 4 + 256 * 4 + 16;
+    auto lds_fixed_of = [](int nt) { return (size_t)nt * sizeof(BlsBest) + (size_t)(BLS_RMAX + 4) * 4 + 20 * 4 + (size_t)BLS_RSEG * 4; };
+    const size_t lds_fixed = lds_fixed_of(1024);
     const size_t lds_max = (size_t)(max_bins + 1) * 16 + lds_fixed;
     LK_REQUIRE(lds_max <= 150 * 1024,
                "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most %d", max_bins,
@@ -409,18 +498,24 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         attr_set = true;
     }
     // groups: cut whenever the LDS need drops below 3/4 of the group's head (keeps occupancy close to the need)
+    int ablate = 0;
+    if (const char *e = getenv("LK_BLS_ABLATE")) ablate = atoi(e);  // profiling only: skips phases, results wrong
     size_t g0 = 0;
     while (g0 < (size_t)nP) {
         const int head_bins = nbins_of(order[g0]);
         size_t g1 = g0 + 1;
         while (g1 < (size_t)nP && nbins_of(order[g1]) * 4 >= head_bins * 3) ++g1;
         const int npg = (int)(g1 - g0);
-        const size_t lds = (size_t)(head_bins + 1) * 16 + lds_fixed;
+        // threads per workgroup by LDS footprint: small-LDS groups fit >= 4 workgroups per CU with 4 waves each;
+        // long periods (one or two workgroups per CU) get 8 / 16 waves so the SIMDs still have waves to swap.
+        const size_t bins_bytes = (size_t)(head_bins + 1) * 16;
+        const int nt = bins_bytes <= 28 * 1024 ? 256 : (bins_bytes <= 64 * 1024 ? 512 : 1024);
+        const size_t lds = bins_bytes + lds_fixed_of(nt);
         const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)npg;
         LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
-        hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(256), lds, stream, d_tm, d_yw, ivar, d_off,
+        hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, ivar, d_off,
                            d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, (int)dur_bins.size(), bin_duration,
-                           oversample, use_likelihood ? 1 : 0, out7);
+                           oversample, use_likelihood ? 1 : 0, out7, ablate);
         g0 = g1;
     }
     LK_HIP_CHECK(hipGetLastError());
