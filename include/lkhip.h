@@ -87,6 +87,21 @@ int lk_bls_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const doubl
                      const double *duration_host, int nD, int oversample, int use_likelihood, double *out7,
                      void *stream);
 
+/* ---- RegressionCorrector: Gaussian-prior weighted least squares, iterated with sigma clipping ----------
+ * X: (sum N) x K row-major design matrix (same K for every target of the batch); y: flux; err: flux errors or
+ * NULL (ones, regressioncorrector.py:157-158); cadence_mask: 1 = use the cadence, or NULL (all);
+ * prior_mu / prior_sigma: B x K (sigma may be +inf) or both NULL; clip_sigma / niters as in .correct().
+ * Outputs: w B x K coefficients of the last iteration; model = X w - median(X w) per target (sum N);
+ * outlier: (sum N) bytes, 1 = clipped in some iteration (regressioncorrector.py:243-279). */
+int lk_regress_batch(lk_handle *h, int B, const int64_t *n_off, int K, const double *X, const double *y,
+                     const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                     const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                     uint8_t *outlier);
+int lk_regress_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
+                         const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                         const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                         uint8_t *outlier, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,3 +7,7 @@ The package is a thin host-side mirror of the reference interface for that one p
 does not load the library; the first compute call does, and fails loudly if it is missing.
 """
 __version__ = "0.1.0"
+
+from .lightcurve import FoldedLightCurve, LightCurve  # noqa: F401
+from .periodogram import (BoxLeastSquaresPeriodogram, LightkurveWarning, LombScarglePeriodogram,  # noqa: F401
+                          Periodogram)

@@ -20,6 +20,7 @@ BLS_FIELDS = ("power", "depth", "depth_err", "duration", "transit_time", "depth_
 _c_dp = ctypes.POINTER(ctypes.c_double)
 _c_ip = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
 
 # (name, restype, argtypes) for EVERY symbol include/lkhip.h declares — tests/test_capi_symbols.py checks the list
 SIGNATURES = [
@@ -43,6 +44,12 @@ SIGNATURES = [
     ("lk_bls_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _c_dp, _vp, ctypes.c_int64, _c_dp, ctypes.c_int, ctypes.c_int,
       ctypes.c_int, _vp, _vp]),
+    ("lk_regress_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_u8p, _c_dp, _c_dp, ctypes.c_double,
+      ctypes.c_int, _c_dp, _c_dp, _c_u8p]),
+    ("lk_regress_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_int, _vp,
+      _vp, _vp, _vp]),
 ]
 
 _lib = None
@@ -211,3 +218,34 @@ def bls_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, ivar_ptr, period_host, pe
                                  _ptr(period_host), _vp(period_ptr), period_host.size, _ptr(duration_host),
                                  duration_host.size, int(oversample), int(bool(use_likelihood)), _vp(out7_ptr),
                                  _vp(stream or None)))
+
+
+# --------------------------------------------------------------------------------------------- regression
+def regress_batch(X, y, n_off, err=None, cadence_mask=None, prior_mu=None, prior_sigma=None, sigma=5.0, niters=5,
+                  device=0):
+    """RegressionCorrector.correct numerics for B ragged targets sharing K columns.
+    X: (sum N, K); returns dict(coefficients[B,K], model[sum N] (median-subtracted), outlier_mask[sum N] bool)."""
+    h = Handle.get(device)
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("X must be 2-D (cadences x regressors)")
+    ntot, K = X.shape
+    y = _f64(y)
+    n_off = _offsets(n_off, ntot)
+    if y.shape != (ntot,):
+        raise ValueError("y must have one value per row of X")
+    B = n_off.size - 1
+    err = None if err is None else _f64(np.broadcast_to(err, (ntot,)))
+    cm = None if cadence_mask is None else np.ascontiguousarray(cadence_mask, dtype=np.uint8)
+    if (prior_mu is None) != (prior_sigma is None):
+        raise ValueError("Please specify both `prior_mu` and `prior_sigma`")
+    if prior_mu is not None:
+        prior_mu = _f64(np.broadcast_to(np.asarray(prior_mu, dtype=np.float64), (B, K)))
+        prior_sigma = _f64(np.broadcast_to(np.asarray(prior_sigma, dtype=np.float64), (B, K)))
+    w = np.empty((B, K), dtype=np.float64)
+    model = np.empty(ntot, dtype=np.float64)
+    outl = np.empty(ntot, dtype=np.uint8)
+    _check(_lib.lk_regress_batch(h._h, B, _ptr(n_off, _c_ip), K, _ptr(X), _ptr(y), _ptr(err), _ptr(cm, _c_u8p),
+                                 _ptr(prior_mu), _ptr(prior_sigma), float(sigma), int(niters), _ptr(w), _ptr(model),
+                                 _ptr(outl, _c_u8p)))
+    return dict(coefficients=w, model=model, outlier_mask=outl.astype(bool))

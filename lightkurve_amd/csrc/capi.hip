@@ -201,4 +201,53 @@ int lk_bls_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, con
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ regression
+int lk_regress_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
+                         const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                         const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                         uint8_t *outlier, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::regress_launch(h, B, n_off_host, K, X, y, err, cadence_mask, prior_mu, prior_sigma, clip_sigma,
+                              niters, w, model, outlier, static_cast<hipStream_t>(stream));
+}
+
+int lk_regress_batch(lk_handle *h, int B, const int64_t *n_off, int K, const double *X, const double *y,
+                     const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                     const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                     uint8_t *outlier) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(K >= 1, "K must be >= 1");
+    LK_REQUIRE(X && y && w && model && outlier, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B];
+    const size_t xb = ntot * (size_t)K * 8, nb = ntot * 8, kb = (size_t)B * K * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(xb + 3 * (nb + 256) + 2 * (ntot + 256) + 3 * (kb + 256) + 4096);
+    if (rc) return rc;
+    double *dX = (double *)h->staging.alloc(xb), *dy = (double *)h->staging.alloc(nb);
+    double *derr = err ? (double *)h->staging.alloc(nb) : nullptr;
+    double *dmodel = (double *)h->staging.alloc(nb);
+    uint8_t *dcm = cadence_mask ? (uint8_t *)h->staging.alloc(ntot) : nullptr;
+    uint8_t *dout = (uint8_t *)h->staging.alloc(ntot);
+    double *dmu = prior_mu ? (double *)h->staging.alloc(kb) : nullptr;
+    double *dsg = prior_sigma ? (double *)h->staging.alloc(kb) : nullptr;
+    double *dw = (double *)h->staging.alloc(kb);
+    LK_HIP_CHECK(hipMemcpy(dX, X, xb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dy, y, nb, hipMemcpyHostToDevice));
+    if (err) LK_HIP_CHECK(hipMemcpy(derr, err, nb, hipMemcpyHostToDevice));
+    if (cadence_mask) LK_HIP_CHECK(hipMemcpy(dcm, cadence_mask, ntot, hipMemcpyHostToDevice));
+    if (prior_mu) LK_HIP_CHECK(hipMemcpy(dmu, prior_mu, kb, hipMemcpyHostToDevice));
+    if (prior_sigma) LK_HIP_CHECK(hipMemcpy(dsg, prior_sigma, kb, hipMemcpyHostToDevice));
+    rc = lk::regress_launch(h, B, n_off, K, dX, dy, derr, dcm, dmu, dsg, clip_sigma, niters, dw, dmodel, dout,
+                            nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(w, dw, kb, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(model, dmodel, nb, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(outlier, dout, ntot, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 }  // extern "C"

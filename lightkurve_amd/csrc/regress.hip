@@ -1,0 +1,341 @@
+// regress.hip — RegressionCorrector numerics on gfx950: weighted normal equations with Gaussian priors,
+// iterated with sigma clipping (reference: src/lightkurve/correctors/regressioncorrector.py:127-189 and
+// 243-279; astropy.stats.sigma_clip defaults maxiters=5, median/std).
+//
+// Per iteration, for a batch of targets that share K (columns) but have ragged N (cadences):
+//   gram_mfma_kernel   G = [X | y]^T diag(m / err^2) [X | y]   (upper 64x64 blocks) on the fp64 matrix cores
+//                      (v_mfma_f64_16x16x4_f64); X tiles are staged through LDS with the weight folded into the
+//                      left operand.  This is the only MFMA-shaped contraction on the path (2 N K^2 flop).
+//   solve_kernel       A = G[:K,:K] + diag(1/sigma_p^2), b = G[:K,K] + mu_p/sigma_p^2, LU with partial pivoting
+//                      (the reference calls LAPACK gesv), one workgroup per target, in global scratch.
+//   resid_clip_kernel  r = y - X w over ALL cadences, then astropy's sigma_clip on r (median by radix select,
+//                      std, <=5 passes) and outlier |= clipped.   (reference quirk, SURVEY App. B.5: the clip
+//                      statistics include cadences outside cadence_mask and earlier outliers.)
+// Final: model = X w - median(X w).
+#include "block_select.hpp"
+#include "lk_common.hpp"
+
+namespace lk {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GR_BLK = 64;    // output block edge
+constexpr int GR_RC = 32;     // cadences per LDS stage
+constexpr int GR_LD = 80;     // LDS row stride in doubles (== 32 dwords mod 64: conflict-free ds_read_b64 fragments)
+
+// element (n, c) of the augmented matrix [X | y], zero beyond column K
+__device__ __forceinline__ double aug(const double *__restrict__ X, const double *__restrict__ y, int K, int64_t n,
+                                      int c) {
+    if (c < K) return X[n * K + c];
+    return c == K ? y[n] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict__ X, const double *__restrict__ y,
+                                                         const double *__restrict__ err,
+                                                         const uint8_t *__restrict__ cmask,
+                                                         const uint8_t *__restrict__ outl,
+                                                         const int64_t *__restrict__ n_off, int K, int KB,
+                                                         double *__restrict__ G) {
+    __shared__ double sa[GR_RC][GR_LD];  // weighted left tile  (rows: cadence, cols: 64 output rows)
+    __shared__ double sb[GR_RC][GR_LD];  // right tile          (cols: 64 output cols)
+    // upper-triangular block pair from the linear block index
+    int bi = 0, bj = blockIdx.x;
+    while (bj >= KB - bi) {
+        bj -= KB - bi;
+        ++bi;
+    }
+    bj += bi;
+    const int target = blockIdx.y;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    X += lo * K;
+    y += lo;
+    const int Kp = KB * GR_BLK, Ka = K + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;  // wave owns the 32x32 sub-block (wi, wj): 2x2 MFMA tiles
+    const int i0 = bi * GR_BLK, j0 = bj * GR_BLK;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const bool live_i0 = i0 + wi * 32 < Ka, live_i1 = i0 + wi * 32 + 16 < Ka;
+    const bool live_j0 = j0 + wj * 32 < Ka, live_j1 = j0 + wj * 32 + 16 < Ka;
+
+    for (int n0 = 0; n0 < n; n0 += GR_RC) {
+        // stage: 32 cadences x 64 columns for each operand; thread -> (row = tid/8 .. , 8 columns)
+        for (int e = tid; e < GR_RC * GR_BLK; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const int nn = n0 + r;
+            double va = 0.0, vb = 0.0;
+            if (nn < n) {
+                const int64_t g = lo + nn;
+                const bool use = (!cmask || cmask[g]) && !outl[g];
+                double w = 0.0;
+                if (use) {
+                    const double s = err ? err[g] : 1.0;
+                    w = 1.0 / (s * s);
+                }
+                va = aug(X, y, K, nn, i0 + c) * w;   // X / err^2 exactly as the reference forms it (:166)
+                vb = aug(X, y, K, nn, j0 + c);
+            }
+            sa[r][c] = va;
+            sb[r][c] = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GR_RC; kk += 4) {
+            const int kr = kk + (lane >> 4), cc = lane & 15;
+            const double a0 = sa[kr][wi * 32 + cc], a1 = sa[kr][wi * 32 + 16 + cc];
+            const double b0 = sb[kr][wj * 32 + cc], b1 = sb[kr][wj * 32 + 16 + cc];
+            if (live_i0 && live_j0) acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            if (live_i0 && live_j1) acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            if (live_i1 && live_j0) acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            if (live_i1 && live_j1) acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double *Gt = G + (size_t)target * Kp * Kp;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi * 32 + a * 16 + (lane >> 4) + 4 * r;
+                const int col = j0 + wj * 32 + b * 16 + (lane & 15);
+                Gt[(size_t)row * Kp + col] = acc[a][b][r];
+            }
+}
+
+// A w = b by LU with partial pivoting, one 256-thread workgroup per target.  A lives in global scratch
+// (K x (K+1) augmented, row-major); trailing updates are spread over the workgroup.
+__global__ __launch_bounds__(256) void solve_kernel(const double *__restrict__ G, int K, int Kp,
+                                                     const double *__restrict__ prior_mu,
+                                                     const double *__restrict__ prior_sigma,
+                                                     double *__restrict__ Awork, double *__restrict__ w) {
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    __shared__ double s_col[1024];  // pivot-column multipliers (K <= 1024)
+    const int target = blockIdx.x, tid = threadIdx.x;
+    const double *Gt = G + (size_t)target * Kp * Kp;
+    const int Ka = K + 1;
+    double *A = Awork + (size_t)target * K * Ka;
+    // build the augmented system from the upper-triangular Gram blocks
+    for (int e = tid; e < K * Ka; e += 256) {
+        const int i = e / Ka, j = e - i * Ka;
+        double v;
+        if (j < K) {
+            v = (j >= i || (j / GR_BLK) == (i / GR_BLK)) ? Gt[(size_t)i * Kp + j] : Gt[(size_t)j * Kp + i];
+            // blocks on the diagonal were computed in full; off-diagonal lower blocks come from the transpose
+            if (i == j && prior_sigma) {
+                const double s = prior_sigma[(size_t)target * K + i];
+                v += 1.0 / (s * s);
+            }
+        } else {
+            v = Gt[(size_t)i * Kp + K];
+            if (prior_sigma) {
+                const double s = prior_sigma[(size_t)target * K + i];
+                v += prior_mu[(size_t)target * K + i] / (s * s);
+            }
+        }
+        A[e] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < K; ++j) {
+        // pivot search in column j, rows j..K-1 (first maximum wins, like LAPACK idamax)
+        double best = -1.0;
+        int bi = j;
+        for (int i = j + tid; i < K; i += 256) {
+            const double v = fabs(A[(size_t)i * Ka + j]);
+            if (v > best) {
+                best = v;
+                bi = i;
+            }
+        }
+        s_val[tid] = best;
+        s_idx[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                const double v2 = s_val[tid + s];
+                const int i2 = s_idx[tid + s];
+                if (v2 > s_val[tid] || (v2 == s_val[tid] && i2 < s_idx[tid])) {
+                    s_val[tid] = v2;
+                    s_idx[tid] = i2;
+                }
+            }
+            __syncthreads();
+        }
+        const int p = s_idx[0];
+        __syncthreads();
+        if (p != j) {
+            for (int c = tid; c < Ka; c += 256) {
+                const double t0 = A[(size_t)j * Ka + c];
+                A[(size_t)j * Ka + c] = A[(size_t)p * Ka + c];
+                A[(size_t)p * Ka + c] = t0;
+            }
+        }
+        __syncthreads();
+        const double piv = A[(size_t)j * Ka + j];
+        for (int i = j + 1 + tid; i < K; i += 256) s_col[i] = A[(size_t)i * Ka + j] / piv;
+        __syncthreads();
+        // trailing update rows j+1..K-1, cols j+1..K (including the right-hand side)
+        const int nr = K - j - 1, nc = Ka - j - 1;
+        for (int e = tid; e < nr * nc; e += 256) {
+            const int i = j + 1 + e / nc, c = j + 1 + e % nc;
+            A[(size_t)i * Ka + c] = fma(-s_col[i], A[(size_t)j * Ka + c], A[(size_t)i * Ka + c]);
+        }
+        __syncthreads();
+    }
+    // back substitution (serial in i, parallel dot products)
+    for (int i = K - 1; i >= 0; --i) {
+        double part = 0.0;
+        for (int c = i + 1 + tid; c < K; c += 256) part = fma(A[(size_t)i * Ka + c], s_col[c], part);
+        s_val[tid] = part;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) s_val[tid] += s_val[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) s_col[i] = (A[(size_t)i * Ka + K] - s_val[0]) / A[(size_t)i * Ka + i];
+        __syncthreads();
+    }
+    for (int i = tid; i < K; i += 256) w[(size_t)target * K + i] = s_col[i];
+}
+
+// model[n] = sum_k X[n][k] w[k]; one wavefront per cadence row, lanes over k (coalesced), wave reduction.
+__global__ __launch_bounds__(256) void model_kernel(const double *__restrict__ X, const double *__restrict__ w,
+                                                     const int64_t *__restrict__ n_off, int K,
+                                                     double *__restrict__ model) {
+    extern __shared__ __attribute__((aligned(16))) double s_w[];
+    const int target = blockIdx.y;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    for (int k = threadIdx.x; k < K; k += 256) s_w[k] = w[(size_t)target * K + k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+        const double *row = X + (lo + r) * (int64_t)K;
+        double acc = 0.0;
+        for (int k = lane; k < K; k += 64) acc = fma(row[k], s_w[k], acc);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) model[lo + r] = acc;
+    }
+}
+
+// residuals over all cadences + astropy sigma_clip; outl |= clipped.  One 1024-thread workgroup per target.
+__global__ __launch_bounds__(1024) void clip_kernel(const double *__restrict__ y, const double *__restrict__ model,
+                                                     const int64_t *__restrict__ n_off, double sigma, int maxiters,
+                                                     uint8_t *__restrict__ flag, uint8_t *__restrict__ outl) {
+    __shared__ unsigned long long sh[1024];
+    const int target = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    y += lo;
+    model += lo;
+    flag += lo;
+    outl += lo;
+    auto val = [&](int i) { return y[i] - model[i]; };
+    auto keep = [&](int i) { return flag[i] != 0; };
+    long long cnt = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const double r = val(i);
+        const bool fin = isfinite(r);
+        flag[i] = fin ? 1 : 0;
+        cnt += fin;
+    }
+    __syncthreads();
+    long long count = block_count_dyn(cnt, reinterpret_cast<long long *>(sh));
+    double lo_b = -INFINITY, hi_b = INFINITY;
+    for (int it = 0; it < maxiters && count > 0; ++it) {
+        const double cen = block_median(n, count, val, keep, sh);
+        double part = 0.0;
+        for (int i = tid; i < n; i += 1024)
+            if (flag[i]) part += val(i);
+        const double mean = block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)count;
+        part = 0.0;
+        for (int i = tid; i < n; i += 1024)
+            if (flag[i]) {
+                const double d = val(i) - mean;
+                part = fma(d, d, part);
+            }
+        const double sd = sqrt(block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)count);
+        lo_b = cen - sd * sigma;
+        hi_b = cen + sd * sigma;
+        cnt = 0;
+        for (int i = tid; i < n; i += 1024) {
+            if (flag[i]) {
+                const double r = val(i);
+                const bool in = (r >= lo_b) && (r <= hi_b);
+                flag[i] = in ? 1 : 0;
+                cnt += in;
+            }
+        }
+        __syncthreads();
+        const long long newcount = block_count_dyn(cnt, reinterpret_cast<long long *>(sh));
+        const bool changed = newcount != count;
+        count = newcount;
+        if (!changed) break;
+    }
+    for (int i = tid; i < n; i += 1024) {
+        const double r = val(i);
+        const bool clipped = !isfinite(r) || r < lo_b || r > hi_b;
+        if (clipped) outl[i] = 1;
+    }
+}
+
+// model -= median(model)
+__global__ __launch_bounds__(1024) void demedian_kernel(const int64_t *__restrict__ n_off,
+                                                         double *__restrict__ model) {
+    __shared__ unsigned long long sh[1024];
+    const int target = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    model += lo;
+    auto val = [&](int i) { return model[i]; };
+    auto keep = [&](int) { return true; };
+    const double med = block_median(n, (long long)n, val, keep, sh);
+    for (int i = tid; i < n; i += 1024) model[i] -= med;
+}
+
+int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
+                   const double *err, const uint8_t *cmask, const double *prior_mu, const double *prior_sigma,
+                   double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream) {
+    LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(K >= 1 && K <= 1023, "K=%d outside the supported range 1..1023", K);
+    LK_REQUIRE(X && y && w && model && outl, "NULL buffer");
+    LK_REQUIRE((prior_mu == nullptr) == (prior_sigma == nullptr), "Please specify both `prior_mu` and `prior_sigma`");
+    LK_REQUIRE(niters >= 1, "niters must be >= 1");
+    LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");
+    for (int b = 0; b < B; ++b) {
+        const int64_t n = n_off_host[b + 1] - n_off_host[b];
+        LK_REQUIRE(n >= 1 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
+    }
+    const size_t ntot = (size_t)n_off_host[B];
+    const int KB = (K + 1 + GR_BLK - 1) / GR_BLK, Kp = KB * GR_BLK;
+    h->ws.reset();
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * Kp * Kp * 8 + (size_t)B * K * (K + 1) * 8 + ntot + 4096);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    double *d_G = (double *)h->ws.alloc((size_t)B * Kp * Kp * 8);
+    double *d_A = (double *)h->ws.alloc((size_t)B * K * (K + 1) * 8);
+    uint8_t *d_flag = (uint8_t *)h->ws.alloc(ntot);
+    LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemsetAsync(outl, 0, ntot, stream));
+    const int nblk = KB * (KB + 1) / 2;
+    for (int it = 0; it < niters; ++it) {
+        hipLaunchKernelGGL(gram_mfma_kernel, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K, KB,
+                           d_G);
+        hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(256), 0, stream, d_G, K, Kp, prior_mu, prior_sigma, d_A, w);
+        hipLaunchKernelGGL(model_kernel, dim3(64, B), dim3(256), (size_t)K * 8, stream, X, w, d_off, K, model);
+        hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, model, d_off, clip_sigma, 5, d_flag, outl);
+    }
+    hipLaunchKernelGGL(demedian_kernel, dim3(B), dim3(1024), 0, stream, d_off, model);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk

@@ -1,0 +1,124 @@
+"""Minimal light-curve container mirroring the slice of ``lightkurve.LightCurve`` the hot path touches.
+
+Reference: src/lightkurve/lightcurve.py — constructor :355, ``remove_nans`` :1300-1327, ``flatten`` :943-1078,
+``fold`` :1089-1214, ``to_periodogram`` :2490-2535.  Columns are plain float64 ndarrays (no astropy
+Time/Quantity in the product interpreter); ``meta`` carries TARGETID / LABEL / NORMALIZED like the reference.
+"""
+import copy as _copy
+
+import numpy as np
+
+__all__ = ["LightCurve", "FoldedLightCurve"]
+
+
+class LightCurve(object):
+    def __init__(self, time=None, flux=None, flux_err=None, meta=None, **extra):
+        if time is None and flux is not None:
+            time = np.arange(len(flux), dtype=np.float64)
+        self.time = np.array(time, dtype=np.float64)
+        if self.time.ndim != 1:
+            raise ValueError("time must be one-dimensional")
+        self.flux = np.array(flux, dtype=np.float64) if flux is not None else np.full(len(self.time), np.nan)
+        if flux_err is None:
+            self.flux_err = np.full(len(self.time), np.nan)
+        else:
+            self.flux_err = np.array(np.broadcast_to(np.asarray(flux_err, dtype=np.float64), self.time.shape))
+        if self.flux.shape != self.time.shape:
+            raise ValueError("time and flux must have the same length")
+        self.meta = dict(meta or {})
+        for k in ("targetid", "label"):
+            if k in extra:
+                self.meta[k.upper()] = extra.pop(k)
+        if extra:
+            raise TypeError("unexpected keyword argument(s): %s" % sorted(extra))
+
+    # ---------------------------------------------------------------- container plumbing
+    def __len__(self):
+        return len(self.time)
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return getattr(self, key)
+        new = _copy.copy(self)
+        new.meta = dict(self.meta)
+        new.time, new.flux, new.flux_err = self.time[key].copy(), self.flux[key].copy(), self.flux_err[key].copy()
+        return new
+
+    def copy(self):
+        return self[slice(None)]
+
+    @property
+    def targetid(self):
+        return self.meta.get("TARGETID")
+
+    @property
+    def label(self):
+        return self.meta.get("LABEL")
+
+    def __repr__(self):
+        return "<LightCurve length=%d targetid=%s>" % (len(self), self.targetid)
+
+    def remove_nans(self, column="flux"):
+        """New light curve without the cadences where ``column`` is NaN (reference :1300-1327)."""
+        return self[~np.isnan(self[column])]
+
+    # ---------------------------------------------------------------- hot-path entry points
+    def to_periodogram(self, method="lombscargle", **kwargs):
+        """``method`` in {"lombscargle", "ls", "boxleastsquares", "bls"} (reference :2490-2535)."""
+        from .periodogram import BoxLeastSquaresPeriodogram, LombScarglePeriodogram, validate_method
+        supported = ["ls", "bls", "lombscargle", "boxleastsquares"]
+        method = validate_method(method.replace(" ", ""), supported)
+        if method in ["bls", "boxleastsquares"]:
+            return BoxLeastSquaresPeriodogram.from_lightcurve(lc=self, **kwargs)
+        return LombScarglePeriodogram.from_lightcurve(lc=self, **kwargs)
+
+    def flatten(self, window_length=101, polyorder=2, return_trend=False, break_tolerance=5, niters=3, sigma=3,
+                mask=None, device=0):
+        """Savitzky-Golay detrending with gap splitting and iterative sigma clipping (reference :943-1078);
+        the trend is computed on the GPU (lk_savgol_trend_batch)."""
+        from .flatten import flatten_trend_batch
+        trend = flatten_trend_batch([self], window_length=window_length, polyorder=polyorder,
+                                    break_tolerance=break_tolerance, niters=niters, sigma=sigma,
+                                    masks=None if mask is None else [mask], device=device)[0]
+        flat = self.copy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            flat.flux = flat.flux / trend
+            flat.flux_err = flat.flux_err / trend
+        flat.meta["NORMALIZED"] = True
+        if return_trend:
+            tr = self.copy()
+            tr.flux = trend
+            return flat, tr
+        return flat
+
+    def fold(self, period=None, epoch_time=None, epoch_phase=0, wrap_phase=None, normalize_phase=False):
+        """Phase-fold (reference :1089-1214 over astropy TimeSeries.fold, timeseries/sampled.py:230-233):
+        phase = ((t - epoch) + epoch_phase + (P - wrap)) % P - (P - wrap), then a stable sort by phase."""
+        period = float(period)
+        if epoch_time is None:
+            epoch_time = float(self.time[0]) if len(self) else 0.0
+        if wrap_phase is None:
+            wrap_phase = period / 2.0 if not normalize_phase else 0.5
+        wrap = wrap_phase * period if normalize_phase else wrap_phase
+        eph = epoch_phase * period if normalize_phase else epoch_phase
+        rel = (self.time - epoch_time) + eph + (period - wrap)
+        phase = np.mod(rel, period) - (period - wrap)
+        cycle = np.round((self.time - epoch_time - phase) / period).astype(int)
+        if normalize_phase:
+            phase = phase / period
+        order = np.argsort(phase, kind="stable")
+        out = FoldedLightCurve(time=phase[order], flux=self.flux[order], flux_err=self.flux_err[order],
+                               meta=dict(self.meta))
+        out.time_original = self.time[order]
+        out.cycle = cycle[order]
+        out.period, out.epoch_time, out.epoch_phase, out.wrap_phase = period, epoch_time, epoch_phase, wrap_phase
+        out.normalize_phase = normalize_phase
+        return out
+
+
+class FoldedLightCurve(LightCurve):
+    """Folded light curve: ``time`` holds the phase; ``time_original`` and ``cycle`` as in the reference."""
+
+    @property
+    def phase(self):
+        return self.time

@@ -1,0 +1,391 @@
+"""Host-side mirror of lightkurve's periodogram constructors for the HIP hot path.
+
+Mirrors (same names, argument meaning and error behaviour) of
+``lightkurve.periodogram.{Periodogram, LombScarglePeriodogram, BoxLeastSquaresPeriodogram}``
+(reference: src/lightkurve/periodogram.py:33-140, 636-989, 1043-1192).  astropy is not importable in
+the product interpreter, so quantities are plain float64 ndarrays with the unit kept as a string
+attribute (``frequency_unit``: "1/d" or "uHz"; ``power_unit``).  All arithmetic that the reference
+delegates to astropy (LombScargle.power / BoxLeastSquares.power) runs in liblkhip.so on the GPU.
+"""
+import logging
+import warnings
+
+import numpy as np
+
+from . import _capi
+
+log = logging.getLogger(__name__)
+
+__all__ = ["Periodogram", "LombScarglePeriodogram", "BoxLeastSquaresPeriodogram", "LightkurveWarning"]
+
+UHZ_PER_CPD = 1e6 / 86400.0  # microhertz per (1/day)
+_FREQ_UNITS = {"1/d": 1.0, "1/day": 1.0, "d-1": 1.0, "uHz": UHZ_PER_CPD, "microhertz": UHZ_PER_CPD,
+               "Hz": 1.0 / 86400.0, "hertz": 1.0 / 86400.0}
+# every LS method name the reference accepts is served by the same exact HIP kernels
+_LS_METHODS = ("hip", "auto", "fast", "slow", "cython", "chi2", "fastchi2", "scipy", "fastnifty", "fastnifty_chi2")
+
+
+class LightkurveWarning(Warning):
+    """Mirror of lightkurve.utils.LightkurveWarning (utils.py:547)."""
+
+
+def validate_method(method, supported_methods):
+    """lightkurve.utils.validate_method (utils.py:577-600)."""
+    method = method.lower()
+    if method in supported_methods:
+        return method
+    raise ValueError("method '{}' is not supported; must be one of {}".format(method, supported_methods))
+
+
+def _freq_unit_factor(unit):
+    """units-per-(1/day) of a frequency unit string."""
+    try:
+        return _FREQ_UNITS[unit]
+    except KeyError:
+        raise ValueError("Frequency must be in units of 1/time (got %r; use one of %s)." % (unit, sorted(_FREQ_UNITS)))
+
+
+def is_regular(frequency):
+    """astropy lombscargle/implementations/main.py:40-50 ``_is_regular``."""
+    frequency = np.asarray(frequency)
+    if frequency.ndim != 1:
+        return False
+    if len(frequency) == 1:
+        return True
+    diff = np.diff(frequency)
+    return bool(np.allclose(diff[0], diff))
+
+
+def exact_grid(frequency):
+    """(f0, df) if ``frequency`` equals f0 + df*arange(M) to within 4 ulp of its largest value, else None.
+    astropy's ``_is_regular`` uses rtol=1e-5 on the steps; the exact kernels must not move a frequency by
+    that much, so the fast regular-grid kernel is only chosen when the grid is regular to rounding."""
+    f = np.asarray(frequency, dtype=np.float64)
+    if f.ndim != 1 or len(f) < 2:
+        return None
+    df = (f[-1] - f[0]) / (len(f) - 1)
+    if not df > 0 or f[0] < 0:
+        return None
+    resid = np.max(np.abs(f - (f[0] + df * np.arange(len(f)))))
+    return (float(f[0]), float(df)) if resid <= 4 * np.finfo(float).eps * np.max(np.abs(f)) else None
+
+
+class Periodogram(object):
+    """Generic power spectrum container (reference periodogram.py:33-140)."""
+
+    def __init__(self, frequency, power, nyquist=None, label=None, targetid=None, default_view="frequency",
+                 meta=None, frequency_unit="1/d", power_unit=""):
+        frequency = np.asarray(frequency, dtype=np.float64)
+        power = np.asarray(power, dtype=np.float64)
+        _freq_unit_factor(frequency_unit)
+        if frequency.ndim != 1 or frequency.shape[0] <= 1:
+            raise ValueError("frequency and power must have a length greater than 1.")
+        if frequency.shape != power.shape:
+            raise ValueError("frequency and power must have the same length.")
+        self.frequency = frequency
+        self.power = power
+        self.nyquist = nyquist
+        self.label = label
+        self.targetid = targetid
+        self.default_view = self._validate_view(default_view)
+        self.meta = {} if meta is None else meta
+        self.frequency_unit = frequency_unit
+        self.power_unit = power_unit
+
+    def _validate_view(self, view):
+        if view is None and hasattr(self, "default_view"):
+            view = self.default_view
+        return validate_method(view, ["frequency", "period"])
+
+    def _is_evenly_spaced(self):
+        freqdiff = np.diff(self.frequency)
+        return bool(np.allclose(freqdiff[0], freqdiff))
+
+    @property
+    def period(self):
+        """1/frequency (in 1/frequency_unit)."""
+        return 1.0 / self.frequency
+
+    @property
+    def max_power(self):
+        return np.nanmax(self.power)
+
+    @property
+    def frequency_at_max_power(self):
+        return self.frequency[np.nanargmax(self.power)]
+
+    @property
+    def period_at_max_power(self):
+        return 1.0 / self.frequency_at_max_power
+
+    def __repr__(self):
+        return "%s(ID: %s)" % (type(self).__name__, self.targetid)
+
+
+def _ls_plan(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=None, maximum_period=None,
+             frequency=None, period=None, nterms=1, nyquist_factor=1, oversample_factor=None, freq_unit=None,
+             normalization="amplitude", ls_method="hip", **kwargs):
+    """Everything LombScarglePeriodogram.from_lightcurve decides BEFORE it calls astropy
+    (reference periodogram.py:783-958): validated options, cleaned arrays, frequency grid, method name.
+    Returns a dict; shared by the single-curve constructor and the batched entry point."""
+    normalization = validate_method(normalization, ["psd", "amplitude"])
+    if np.isnan(lc.flux).any():
+        lc = lc.remove_nans()
+        log.debug("Lightcurve contains NaN values.These are removed before creating the periodogram.")
+    if freq_unit is None:
+        freq_unit = "1/d" if normalization == "amplitude" else "uHz"
+    unit = _freq_unit_factor(freq_unit)
+    if oversample_factor is None:
+        oversample_factor = 5.0 if normalization == "amplitude" else 1.0
+    for old, new in (("min_period", "minimum_period"), ("max_period", "maximum_period"),
+                     ("min_frequency", "minimum_frequency"), ("max_frequency", "maximum_frequency")):
+        if old in kwargs:
+            warnings.warn("`{}` keyword is deprecated, please use `{}` instead.".format(old, new), LightkurveWarning)
+            val = kwargs.pop(old, None)
+            if new == "minimum_period":
+                minimum_period = val
+            elif new == "maximum_period":
+                maximum_period = val
+            elif new == "minimum_frequency":
+                minimum_frequency = val
+            else:
+                maximum_frequency = val
+    period_args = not all(b is None for b in [period, minimum_period, maximum_period])
+    freq_args = not all(b is None for b in [frequency, minimum_frequency, maximum_frequency])
+    default_view = "period" if period_args else "frequency"
+    if period_args and freq_args:
+        raise ValueError("You have input keyword arguments for both frequency and period. Please only use one.")
+
+    time = np.asarray(lc.time, dtype=np.float64).copy()
+    flux = np.asarray(lc.flux, dtype=np.float64).copy()
+    if len(time) < 2:
+        raise ValueError("The light curve needs at least two cadences to build a periodogram.")
+    nyquist = 0.5 * (1.0 / np.median(np.diff(time))) * unit
+    fs = (1.0 / (time[-1] - time[0])) / oversample_factor * unit
+
+    if frequency is not None and any(a is not None for a in [minimum_frequency, maximum_frequency]):
+        log.warning("You have passed both a grid of frequencies and min_frequency/maximum_frequency arguments; "
+                    "the latter will be ignored.")
+    if period is not None and any(a is not None for a in [minimum_period, maximum_period]):
+        log.warning("You have passed a grid of periods and minimum_period/maximum_period arguments; "
+                    "the latter will be ignored.")
+    if maximum_period is not None:
+        minimum_frequency = 1.0 / maximum_period
+    if minimum_period is not None:
+        maximum_frequency = 1.0 / minimum_period
+    if period is not None:
+        frequency = 1.0 / np.asarray(period, dtype=np.float64)
+    if frequency is None:
+        if minimum_frequency is not None and maximum_frequency is not None:
+            if minimum_frequency > maximum_frequency:
+                if default_view == "frequency":
+                    raise ValueError("minimum_frequency cannot be larger than maximum_frequency")
+                raise ValueError("minimum_period cannot be larger than maximum_period")
+        if minimum_frequency is None:
+            minimum_frequency = fs
+        if maximum_frequency is None:
+            maximum_frequency = nyquist * nyquist_factor
+        frequency = np.arange(minimum_frequency, maximum_frequency, fs)
+    frequency = np.asarray(frequency, dtype=np.float64)
+
+    ls_method = validate_method(ls_method, list(_LS_METHODS))
+    if ls_method[:9] == "fastnifty":  # optional dependency in the reference; it falls back the same way
+        oldmethod = ls_method
+        ls_method = {"fastnifty": "fast", "fastnifty_chi2": "fastchi2"}[ls_method]
+        log.warning("nifty_ls is not available.\nMethod has been changed from '{}' to '{}'.".format(oldmethod,
+                                                                                                 ls_method))
+    if not is_regular(frequency) and ls_method in ["fastchi2", "fast"]:
+        oldmethod = ls_method
+        ls_method = {"fastchi2": "chi2", "fast": "slow"}[ls_method]
+        log.warning("The requested periodogram is not evenly sampled in frequency.\n"
+                    "Method has been changed from '{}' to '{}' to allow for this.".format(oldmethod, ls_method))
+    if nterms > 1 and ls_method not in ["fastchi2", "chi2"]:
+        warnings.warn(
+            "Building a Lomb Scargle Periodogram using the `slow` method. "
+            "`nterms` has been set to >1, however this is not supported under the `{}` method. "
+            "To run with higher nterms, set `ls_method` to either 'fastchi2', 'chi2', or 'fastnifty_chi2. "
+            "Please refer to the `astropy.timeseries.periodogram.LombScargle` documentation.".format(ls_method),
+            LightkurveWarning)
+        nterms = 1
+    if nterms > 1:
+        raise NotImplementedError("nterms > 1 (multi-term chi2 periodograms) is not on the HIP path yet "
+                                  "(SURVEY.md §8(f) N1)")
+    dy = kwargs.pop("dy", None)
+    fit_mean = kwargs.pop("fit_mean", True)
+    center_data = kwargs.pop("center_data", True)
+    if kwargs:
+        raise TypeError("unexpected keyword argument(s) for LombScargle: %s" % sorted(kwargs))
+    if dy is not None:
+        dy = np.broadcast_to(np.asarray(dy, dtype=np.float64), time.shape).copy()
+
+    # what the kernel needs: times relative to the first cadence (astropy lombscargle/core.py:119-126),
+    # frequencies in 1/d, and lightkurve's normalisation (periodogram.py:969-975)
+    f_day = frequency / unit
+    if normalization == "psd":
+        norm, scale = "lk_psd", 2.0 / (len(time) * oversample_factor * fs)
+        power_unit = "flux^2/" + freq_unit
+    else:
+        norm, scale = "lk_amplitude", 1.0
+        power_unit = "flux"
+    return dict(lc=lc, trel=time - time[0], flux=flux, dy=dy, frequency=frequency, f_day=f_day, norm=norm, scale=scale,
+                nyquist=nyquist, freq_unit=freq_unit, power_unit=power_unit, default_view=default_view,
+                ls_method=ls_method, nterms=nterms, fit_mean=fit_mean, center_data=center_data,
+                normalization=normalization)
+
+
+class LombScarglePeriodogram(Periodogram):
+    """Lomb-Scargle periodogram computed by the exact HIP kernels (reference periodogram.py:589-1018)."""
+
+    def __init__(self, *args, **kwargs):
+        self._LS_inputs = kwargs.pop("ls_obj", None)
+        self.nterms = kwargs.pop("nterms", 1)
+        self.ls_method = kwargs.pop("ls_method", "hip")
+        super(LombScarglePeriodogram, self).__init__(*args, **kwargs)
+
+    @staticmethod
+    def from_lightcurve(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=None,
+                        maximum_period=None, frequency=None, period=None, nterms=1, nyquist_factor=1,
+                        oversample_factor=None, freq_unit=None, normalization="amplitude", ls_method="hip",
+                        device=0, **kwargs):
+        """Same contract as the reference constructor.  ``ls_method``: any name the reference accepts plus
+        ``"hip"`` (default); all are served by the exact fp64 GPU kernels (the reference's default ``"fast"`` is
+        an FFT approximation that differs from its own exact methods by ~1e-3 of the peak; results here match
+        ``"slow"``/``"cython"`` to 1e-9)."""
+        plan = _ls_plan(lc, minimum_frequency, maximum_frequency, minimum_period, maximum_period, frequency, period,
+                        nterms, nyquist_factor, oversample_factor, freq_unit, normalization, ls_method, **kwargs)
+        n = len(plan["trel"])
+        grid = exact_grid(plan["f_day"])
+        common = dict(dy=plan["dy"], fit_mean=plan["fit_mean"], center_data=plan["center_data"],
+                      normalization=plan["norm"], scale=[plan["scale"]], device=device)
+        if grid is not None:
+            power = _capi.ls_power_batch(plan["trel"], plan["flux"], [0, n], f0=grid[0], df=grid[1],
+                                         M=len(plan["f_day"]), **common)[0]
+        else:
+            power = _capi.ls_power_batch(plan["trel"], plan["flux"], [0, n], frequency=plan["f_day"], **common)[0]
+        lcc = plan["lc"]
+        return LombScarglePeriodogram(
+            frequency=plan["frequency"], power=power, nyquist=plan["nyquist"], targetid=lcc.meta.get("TARGETID"),
+            label=lcc.meta.get("LABEL"), default_view=plan["default_view"],
+            ls_obj=dict(trel=plan["trel"], flux=plan["flux"], dy=plan["dy"]), nterms=plan["nterms"],
+            ls_method=plan["ls_method"], meta=lcc.meta, frequency_unit=plan["freq_unit"],
+            power_unit=plan["power_unit"])
+
+
+def _bls_plan(lc, **kwargs):
+    """Everything BoxLeastSquaresPeriodogram.from_lightcurve decides before calling astropy (reference
+    periodogram.py:1093-1168 + astropy bls/core.py:113-214, 277-327)."""
+    lc = lc.remove_nans()
+    time = np.asarray(lc.time, dtype=np.float64)
+    flux = np.asarray(lc.flux, dtype=np.float64)
+    dy = np.asarray(lc.flux_err, dtype=np.float64) if np.isfinite(lc.flux_err).all() else None
+    duration = kwargs.pop("duration", [0.05, 0.10, 0.15, 0.20, 0.25, 0.33])
+    if duration is not None and not np.all(np.isfinite(duration)):
+        raise ValueError("`duration` parameter contains illegal nan or inf value(s)")
+    period = kwargs.pop("period", None)
+    minimum_period = kwargs.pop("minimum_period", None)
+    maximum_period = kwargs.pop("maximum_period", None)
+    if period is not None and not np.all(np.isfinite(period)):
+        raise ValueError("`period` parameter contains illegal nan or inf value(s)")
+    dt_med = np.median(np.diff(time))
+    if minimum_period is None:
+        minimum_period = np.max([dt_med * 4, np.max(duration) + dt_med]) if period is None else np.min(period)
+    if maximum_period is None:
+        maximum_period = (np.max(time) - np.min(time)) / 3.0 if period is None else np.max(period)
+    time_unit = kwargs.pop("time_unit", "day")
+    if time_unit not in ("day", "d", "hour", "h", "minute", "min", "second", "s", "year", "yr"):
+        raise ValueError("{} is not a valid value for `time_unit`".format(time_unit))
+    frequency_factor = kwargs.pop("frequency_factor", 10)
+    baseline = np.max(time) - np.min(time)
+    df = frequency_factor * np.min(duration) / baseline ** 2
+    npoints = int(((1 / minimum_period) - (1 / maximum_period)) / df)
+    if npoints > 1e7:
+        raise ValueError("`period` contains {} points.Periodogram is too large to evaluate. "
+                         "Consider setting `frequency_factor` to a higher value.".format(np.round(npoints, 4)))
+    elif npoints > 1e5:
+        log.warning("`period` contains {} points.Periodogram is likely to be large, and slow to evaluate. "
+                    "Consider setting `frequency_factor` to a higher value.".format(np.round(npoints, 4)))
+    duration = np.atleast_1d(np.asarray(duration, dtype=np.float64))
+    trel = time - time[0]
+    if period is None:
+        # astropy BoxLeastSquares.autoperiod, bls/core.py:113-214
+        if minimum_period > maximum_period:
+            raise ValueError("The maximum period must be larger than the minimum period")
+        minimum_frequency, maximum_frequency = 1.0 / maximum_period, 1.0 / minimum_period
+        nf = 1 + int(np.round((maximum_frequency - minimum_frequency) / df))
+        period = 1.0 / (maximum_frequency - df * np.arange(nf))
+    period = np.atleast_1d(np.asarray(period, dtype=np.float64))
+    # astropy _validate_period_and_duration, bls/core.py:668-700
+    if period.ndim != 1 or period.size == 0:
+        raise ValueError("period must be 1-dimensional")
+    if duration.ndim != 1 or duration.size == 0:
+        raise ValueError("duration must be 1-dimensional")
+    if np.min(period) <= np.max(duration):
+        raise ValueError("The maximum transit duration must be shorter than the minimum period")
+    oversample = kwargs.pop("oversample", 10)
+    try:
+        oversample = int(oversample)
+    except TypeError:
+        raise ValueError("oversample must be an int, got {0}".format(oversample))
+    if oversample < 1:
+        raise ValueError("oversample must be greater than or equal to 1")
+    objective = kwargs.pop("objective", None) or "likelihood"
+    if objective not in ["snr", "likelihood"]:
+        raise ValueError("Unrecognized method '{0}'\nallowed methods are: {1}".format(objective,
+                                                                                    ["snr", "likelihood"]))
+    method = kwargs.pop("method", None) or "fast"
+    if method not in ["fast", "slow", "hip"]:
+        raise ValueError("Unrecognized method '{0}'\nallowed methods are: {1}".format(method, ["fast", "slow"]))
+    if kwargs:
+        raise TypeError("unexpected keyword argument(s) for BoxLeastSquares.power: %s" % sorted(kwargs))
+    t_ref = np.min(trel)
+    ivar = np.ones_like(flux) if dy is None else 1.0 / dy ** 2
+    return dict(lc=lc, t=trel - t_ref, y=flux - np.median(flux), ivar=ivar, t_ref=t_ref + time[0], period=period,
+                duration=duration, oversample=oversample, objective=objective, time_unit=time_unit)
+
+
+class BoxLeastSquaresPeriodogram(Periodogram):
+    """BLS periodogram computed by the bit-exact HIP kernel (reference periodogram.py:1021-1296)."""
+
+    def __init__(self, *args, **kwargs):
+        self.duration = kwargs.pop("duration", None)
+        self.depth = kwargs.pop("depth", None)
+        self.snr = kwargs.pop("snr", None)
+        self._BLS_result = kwargs.pop("bls_result", None)
+        self._BLS_inputs = kwargs.pop("bls_obj", None)
+        self.transit_time = kwargs.pop("transit_time", None)
+        self.time = kwargs.pop("time", None)
+        self.flux = kwargs.pop("flux", None)
+        self.time_unit = kwargs.pop("time_unit", None)
+        super(BoxLeastSquaresPeriodogram, self).__init__(*args, **kwargs)
+
+    @staticmethod
+    def from_lightcurve(lc, device=0, **kwargs):
+        """Same contract as the reference constructor: kwargs ``duration``, ``period``, ``minimum_period``,
+        ``maximum_period``, ``frequency_factor``, ``time_unit``, ``objective``, ``oversample``, ``method``."""
+        plan = _bls_plan(lc, **kwargs)
+        n = len(plan["t"])
+        res = _capi.bls_batch(plan["t"], plan["y"], plan["ivar"], [0, n], plan["period"], plan["duration"],
+                              plan["oversample"], plan["objective"] == "likelihood", device=device)
+        result = {k: v[0] for k, v in res.items()}
+        result["transit_time"] = result["transit_time"] + plan["t_ref"]   # astropy _format_results, core.py:702-745
+        result["period"] = plan["period"]
+        result["objective"] = plan["objective"]
+        lcc = plan["lc"]
+        return BoxLeastSquaresPeriodogram(
+            frequency=1.0 / plan["period"], power=result["power"], default_view="period",
+            label=lcc.meta.get("LABEL"), targetid=lcc.meta.get("TARGETID"), transit_time=result["transit_time"],
+            duration=result["duration"], depth=result["depth"], bls_result=result, snr=result["depth_snr"],
+            bls_obj=dict(t=plan["t"], y=plan["y"], ivar=plan["ivar"]), time=lcc.time, flux=lcc.flux,
+            time_unit=plan["time_unit"], frequency_unit="1/d", power_unit="")
+
+    @property
+    def duration_at_max_power(self):
+        return self.duration[np.nanargmax(self.power)]
+
+    @property
+    def transit_time_at_max_power(self):
+        return self.transit_time[np.nanargmax(self.power)]
+
+    @property
+    def depth_at_max_power(self):
+        return self.depth[np.nanargmax(self.power)]

@@ -1,0 +1,135 @@
+"""CPU tests of the host-side mirror (no GPU compute): grids, method switching, validation and error messages
+follow the reference (tests/test_periodogram.py:43-161, 364-442, 491-515 are the models)."""
+import logging
+import warnings
+
+import numpy as np
+import pytest
+
+from lightkurve_amd import LightCurve
+from lightkurve_amd import periodogram as P
+
+
+def make_lc(n=1000, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0, 50, n))
+    return LightCurve(time=t, flux=1 + 1e-3 * np.sin(2 * np.pi * t / 3.0) + rng.normal(0, 1e-4, n), flux_err=1e-4)
+
+
+def test_default_grid_matches_reference(golden):
+    g = golden("ls_c1_default")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    plan = P._ls_plan(lc)
+    assert plan["freq_unit"] == "1/d" and plan["norm"] == "lk_amplitude"
+    assert len(plan["frequency"]) == len(g["frequency"])
+    assert np.allclose(plan["frequency"], g["frequency"], rtol=1e-14, atol=0)
+    assert np.isclose(plan["nyquist"], g["nyquist"], rtol=1e-14)
+    assert P.exact_grid(plan["f_day"]) is not None
+    plan = P._ls_plan(lc, normalization="psd")
+    assert plan["freq_unit"] == "uHz" and len(plan["frequency"]) == len(g["psd_frequency_uhz"])
+    assert np.allclose(plan["frequency"], g["psd_frequency_uhz"], rtol=1e-13)
+    assert np.isclose(plan["nyquist"], g["psd_nyquist"], rtol=1e-13)
+    # lk psd scale = 2/(N*os*fs) == 2*T/N in 1/uHz
+    T = g["time"][-1] - g["time"][0]
+    assert np.isclose(plan["scale"], 2 * T / len(g["time"]) / P.UHZ_PER_CPD, rtol=1e-13)
+
+
+def test_frequency_period_grid_assignment():
+    lc = make_lc()
+    f = np.arange(1, 100) * 0.01
+    plan = P._ls_plan(lc, frequency=f)
+    assert np.array_equal(plan["frequency"], f) and plan["default_view"] == "frequency"
+    per = np.arange(1, 101) * 0.5
+    plan = P._ls_plan(lc, period=per, ls_method="fast")
+    assert np.allclose(1 / plan["frequency"], per, rtol=1e-14) and plan["default_view"] == "period"
+    assert plan["ls_method"] == "slow"          # irregular in frequency: fast -> slow (reference :933-946)
+    assert P.exact_grid(plan["f_day"]) is None
+    plan = P._ls_plan(lc, minimum_period=2.0, maximum_period=10.0)
+    assert plan["frequency"][0] == pytest.approx(0.1) and plan["frequency"][-1] < 0.5
+
+
+def test_ls_errors_and_warnings():
+    lc = make_lc()
+    with pytest.raises(ValueError, match="both frequency and period"):
+        P._ls_plan(lc, frequency=[1, 2], period=[1, 2])
+    with pytest.raises(ValueError, match="minimum_frequency cannot be larger"):
+        P._ls_plan(lc, minimum_frequency=2.0, maximum_frequency=1.0)
+    with pytest.raises(ValueError, match="minimum_period cannot be larger"):
+        P._ls_plan(lc, minimum_period=2.0, maximum_period=1.0)
+    with pytest.raises(ValueError, match="not supported"):
+        P._ls_plan(lc, normalization="power")
+    with pytest.raises(ValueError, match="not supported"):
+        P._ls_plan(lc, ls_method="nonsense")
+    with pytest.warns(P.LightkurveWarning, match="nterms"):
+        plan = P._ls_plan(lc, nterms=2, ls_method="slow")
+    assert plan["nterms"] == 1
+    with pytest.warns(P.LightkurveWarning, match="deprecated"):
+        P._ls_plan(lc, min_period=1.0)
+    with pytest.raises(ValueError, match="not supported"):
+        lc.to_periodogram(method="unknown")
+
+
+def test_nan_flux_removed_before_planning():
+    lc = make_lc()
+    lc.flux[[3, 50]] = np.nan
+    plan = P._ls_plan(lc)
+    assert len(plan["flux"]) == len(lc) - 2 and np.isfinite(plan["flux"]).all()
+    assert plan["trel"][0] == 0.0
+
+
+def test_bls_plan_defaults_match_reference(golden):
+    g = golden("bls_default")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    plan = P._bls_plan(lc, frequency_factor=200)
+    assert len(plan["period"]) == len(g["period"]) and np.allclose(plan["period"], g["period"], rtol=1e-14)
+    assert np.array_equal(plan["duration"], [0.05, 0.10, 0.15, 0.20, 0.25, 0.33])
+    assert plan["oversample"] == 10 and plan["objective"] == "likelihood"
+    g2 = golden("bls_2500")
+    lc = LightCurve(time=g2["time"], flux=g2["flux"], flux_err=g2["flux_err"])
+    plan = P._bls_plan(lc, period=g2["period"], duration=g2["duration"])
+    assert np.array_equal(plan["t"], g2["raw_t"]) and np.array_equal(plan["y"], g2["raw_y"])
+    assert np.array_equal(plan["ivar"], g2["raw_ivar"])
+
+
+def test_bls_errors(caplog):
+    lc = make_lc()
+    with pytest.raises(ValueError, match="period"):
+        P._bls_plan(lc, period=[1, 2, 3, np.nan, 4])           # reference tests/test_periodogram.py:434-442
+    with pytest.raises(ValueError, match="duration"):
+        P._bls_plan(lc, duration=[0.1, np.inf])
+    with pytest.raises(ValueError, match="too large to evaluate"):
+        P._bls_plan(lc, frequency_factor=1e-5)
+    with pytest.raises(ValueError, match="maximum transit duration"):
+        P._bls_plan(lc, period=[0.2, 1.0], duration=[0.3])
+    with pytest.raises(ValueError, match="oversample"):
+        P._bls_plan(lc, oversample=0)
+    with pytest.raises(ValueError, match="Unrecognized method"):
+        P._bls_plan(lc, objective="chi2")
+    with caplog.at_level(logging.WARNING):
+        P._bls_plan(lc, frequency_factor=0.02)
+    assert "slow to evaluate" in caplog.text
+    lc2 = LightCurve(time=lc.time, flux=lc.flux)      # no errors -> ivar = 1
+    assert np.array_equal(P._bls_plan(lc2)["ivar"], np.ones(len(lc2)))
+
+
+def test_periodogram_container_validation():
+    with pytest.raises(ValueError, match="length greater than 1"):
+        P.Periodogram([1.0], [1.0])
+    with pytest.raises(ValueError, match="same length"):
+        P.Periodogram([1.0, 2.0], [1.0])
+    with pytest.raises(ValueError, match="units of 1/time"):
+        P.Periodogram([1.0, 2.0], [1.0, 2.0], frequency_unit="kg")
+    pg = P.Periodogram([1.0, 2.0, 4.0], [1.0, np.nan, 3.0])
+    assert pg.max_power == 3.0 and pg.frequency_at_max_power == 4.0 and pg.period_at_max_power == 0.25
+
+
+def test_fold_properties():
+    """Model: reference tests/test_lightcurve.py:242-316 — phase range, cycle numbers, permutation of time."""
+    lc = make_lc(500)
+    f = lc.fold(period=3.3, epoch_time=1.0)
+    assert f.time.min() >= -1.65 and f.time.max() <= 1.65 and np.all(np.diff(f.time) >= 0)
+    assert np.array_equal(np.sort(f.time_original), lc.time)
+    assert f.cycle.min() >= -1 and f.cycle.max() <= 15
+    fn = lc.fold(period=3.3, epoch_time=1.0, normalize_phase=True)
+    assert fn.time.min() >= -0.5 and fn.time.max() <= 0.5
+    assert np.allclose(f.flux, fn.flux)
