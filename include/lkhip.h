@@ -102,6 +102,21 @@ int lk_regress_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, 
                          const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
                          uint8_t *outlier, void *stream);
 
+/* ---- LightCurve.flatten trend: masked, gap-segmented Savitzky-Golay + sigma-clip loop + linear re-interpolation
+ * t (non-decreasing per target), flux (may hold NaN); mask: 1 = EXCLUDE the cadence from the fit (lightkurve's
+ * `mask=` semantics) or NULL; window (odd), polyorder, break_tol (NaN = no gap splitting), niters, sigma as in
+ * LightCurve.flatten (lightcurve.py:943).  trend: (sum N), what flatten divides flux and flux_err by;
+ * fit_mask: (sum N) bytes or NULL, 1 = cadence survived every clip. */
+int lk_savgol_trend_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *flux,
+                          const uint8_t *mask, int window, int polyorder, double break_tol, int niters,
+                          double sigma, double *trend, uint8_t *fit_mask);
+int lk_savgol_trend_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
+                              const uint8_t *mask, int window, int polyorder, double break_tol, int niters,
+                              double sigma, double *trend, uint8_t *fit_mask, void *stream);
+/* Host-only helper (no GPU): the FIR taps (window doubles) and the two edge-refit operators
+ * (2 x (window/2) x window doubles, left then right) the kernel uses == scipy savgol_coeffs / mode='interp'. */
+int lk_savgol_design(int window, int polyorder, double *coeffs, double *edge);
+
 #ifdef __cplusplus
 }
 #endif

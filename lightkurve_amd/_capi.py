@@ -50,6 +50,13 @@ SIGNATURES = [
     ("lk_regress_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_int, _vp,
       _vp, _vp, _vp]),
+    ("lk_savgol_trend_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+      ctypes.c_double, _c_dp, _c_u8p]),
+    ("lk_savgol_trend_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+      ctypes.c_double, _vp, _vp, _vp]),
+    ("lk_savgol_design", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
 ]
 
 _lib = None
@@ -249,3 +256,32 @@ def regress_batch(X, y, n_off, err=None, cadence_mask=None, prior_mu=None, prior
                                  _ptr(prior_mu), _ptr(prior_sigma), float(sigma), int(niters), _ptr(w), _ptr(model),
                                  _ptr(outl, _c_u8p)))
     return dict(coefficients=w, model=model, outlier_mask=outl.astype(bool))
+
+
+# --------------------------------------------------------------------------------------------- flatten
+def savgol_design(window, polyorder):
+    """(taps[window], edge[2, window//2, window]) exactly as the kernel uses them (host-only, no GPU needed)."""
+    load_library()
+    half = window // 2
+    c = np.empty(window, dtype=np.float64)
+    e = np.empty((2, half, window), dtype=np.float64)
+    _check(_lib.lk_savgol_design(int(window), int(polyorder), _ptr(c), _ptr(e)))
+    return c, e
+
+
+def savgol_trend_batch(t, flux, n_off, mask=None, window_length=101, polyorder=2, break_tolerance=5, niters=3,
+                       sigma=3, return_fit_mask=False, device=0):
+    """The trend LightCurve.flatten divides by, for B ragged targets.  ``mask``: True = exclude from the fit."""
+    h = Handle.get(device)
+    t, flux = _f64(t), _f64(flux)
+    n_off = _offsets(n_off, t.size)
+    if flux.shape != t.shape:
+        raise ValueError("t and flux must have the same length")
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    bt = float("nan") if break_tolerance is None else float(break_tolerance)
+    trend = np.empty(t.size, dtype=np.float64)
+    fm = np.empty(t.size, dtype=np.uint8) if return_fit_mask else None
+    _check(_lib.lk_savgol_trend_batch(h._h, n_off.size - 1, _ptr(n_off, _c_ip), _ptr(t), _ptr(flux), _ptr(m, _c_u8p),
+                                      int(window_length), int(polyorder), bt, int(niters), float(sigma), _ptr(trend),
+                                      _ptr(fm, _c_u8p)))
+    return (trend, fm.astype(bool)) if return_fit_mask else trend

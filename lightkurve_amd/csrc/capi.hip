@@ -250,4 +250,44 @@ int lk_regress_batch(lk_handle *h, int B, const int64_t *n_off, int K, const dou
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ flatten
+int lk_savgol_design(int window, int polyorder, double *coeffs, double *edge) {
+    return lk::savgol_design_host(window, polyorder, coeffs, edge);
+}
+
+int lk_savgol_trend_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
+                              const uint8_t *mask, int window, int polyorder, double break_tol, int niters,
+                              double sigma, double *trend, uint8_t *fit_mask, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::flatten_launch(h, B, n_off_host, t, flux, mask, window, polyorder, break_tol, niters, sigma, trend,
+                              fit_mask, static_cast<hipStream_t>(stream));
+}
+
+int lk_savgol_trend_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *flux,
+                          const uint8_t *mask, int window, int polyorder, double break_tol, int niters, double sigma,
+                          double *trend, uint8_t *fit_mask) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(t && flux && trend, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B], nb = ntot * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(3 * (nb + 256) + 2 * (ntot + 256) + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(nb), *df = (double *)h->staging.alloc(nb);
+    double *dtr = (double *)h->staging.alloc(nb);
+    uint8_t *dm = mask ? (uint8_t *)h->staging.alloc(ntot) : nullptr;
+    uint8_t *dfm = fit_mask ? (uint8_t *)h->staging.alloc(ntot) : nullptr;
+    LK_HIP_CHECK(hipMemcpy(dt, t, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(df, flux, nb, hipMemcpyHostToDevice));
+    if (mask) LK_HIP_CHECK(hipMemcpy(dm, mask, ntot, hipMemcpyHostToDevice));
+    rc = lk::flatten_launch(h, B, n_off, dt, df, dm, window, polyorder, break_tol, niters, sigma, dtr, dfm, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(trend, dtr, nb, hipMemcpyDeviceToHost));
+    if (fit_mask) LK_HIP_CHECK(hipMemcpy(fit_mask, dfm, ntot, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 }  // extern "C"

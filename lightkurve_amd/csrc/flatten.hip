@@ -1,0 +1,344 @@
+// flatten.hip — the trend LightCurve.flatten divides by: masked, gap-segmented Savitzky-Golay filter with
+// iterative sigma clipping and linear re-interpolation (reference: src/lightkurve/lightcurve.py:996-1063 over
+// scipy.signal.savgol_filter, scipy/signal/_savitzky_golay.py:230-357 mode='interp', and
+// scipy.interpolate.interp1d(kind='linear', fill_value='extrapolate')).
+//
+// One 1024-thread workgroup per light curve runs every iteration of the loop; the curve (N ~ 2e4 doubles) lives
+// in a per-target scratch slab that stays in L2.  HBM traffic is the algorithmic 8 B x (time, flux in; trend
+// out) per cadence; the FIR itself is 2*window flop per cadence per iteration (the one HBM-leaning kernel of the
+// path).  Order statistics (nanmedian of flux, of the time steps, of short segments) use the
+// radix select of block_select.hpp; the FIR taps and the edge-fit operators are built once on the host in long
+// double (savgol_design) — the edge polynomial refit of scipy's mode='interp' is the linear map
+// y_edge = E x_window with E = V_eval (V^T V)^-1 V^T.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "block_select.hpp"
+#include "lk_common.hpp"
+
+namespace lk {
+
+// ------------------------------------------------------------------------------------------------ host design
+// Solve the small SPD system M a = b (n <= 16) by Gaussian elimination with partial pivoting in long double.
+static bool solve_small(std::vector<long double> &M, std::vector<long double> &b, int n) {
+    for (int j = 0; j < n; ++j) {
+        int p = j;
+        for (int i = j + 1; i < n; ++i)
+            if (fabsl(M[i * n + j]) > fabsl(M[p * n + j])) p = i;
+        if (M[p * n + j] == 0.0L) return false;
+        if (p != j) {
+            for (int c = 0; c < n; ++c) std::swap(M[j * n + c], M[p * n + c]);
+            std::swap(b[j], b[p]);
+        }
+        for (int i = j + 1; i < n; ++i) {
+            const long double f = M[i * n + j] / M[j * n + j];
+            for (int c = j; c < n; ++c) M[i * n + c] -= f * M[j * n + c];
+            b[i] -= f * b[j];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        long double s = b[i];
+        for (int c = i + 1; c < n; ++c) s -= M[i * n + c] * b[c];
+        b[i] = s / M[i * n + i];
+    }
+    return true;
+}
+
+// coeffs[w]: FIR taps (scipy savgol_coeffs(w, p): min-norm solution of sum_j c_j x_j^i = delta_i0 with
+// x = h..-h; symmetric for deriv=0).  edge[2][half][w]: rows of E for outputs 0..half-1 from the first w samples
+// and outputs w-half..w-1 from the last w samples.  Abscissae are scaled to [-1, 1] for conditioning.
+static bool savgol_design(int w, int p, std::vector<double> &coeffs, std::vector<double> &edge) {
+    const int half = w / 2, np1 = p + 1;
+    std::vector<long double> z(w);
+    const long double hs = half > 0 ? (long double)half : 1.0L;
+    for (int j = 0; j < w; ++j) z[j] = (long double)(half - j) / hs;  // x = arange(-half, w-half)[::-1], scaled
+    std::vector<long double> M(np1 * np1), rhs(np1, 0.0L);
+    for (int a = 0; a < np1; ++a)
+        for (int b = 0; b < np1; ++b) {
+            long double s = 0.0L;
+            for (int j = 0; j < w; ++j) s += powl(z[j], a + b);
+            M[a * np1 + b] = s;
+        }
+    rhs[0] = 1.0L;
+    {
+        std::vector<long double> Mc = M;
+        if (!solve_small(Mc, rhs, np1)) return false;
+    }
+    coeffs.assign(w, 0.0);
+    for (int j = 0; j < w; ++j) {
+        long double s = 0.0L;
+        for (int a = 0; a < np1; ++a) s += rhs[a] * powl(z[j], a);
+        coeffs[j] = (double)s;
+    }
+    // edge operators: polyfit over positions 0..w-1 (scaled u), evaluated at r
+    std::vector<long double> u(w);
+    const long double c0 = (long double)(w - 1) / 2.0L, sc = c0 > 0 ? c0 : 1.0L;
+    for (int j = 0; j < w; ++j) u[j] = ((long double)j - c0) / sc;
+    for (int a = 0; a < np1; ++a)
+        for (int b = 0; b < np1; ++b) {
+            long double s = 0.0L;
+            for (int j = 0; j < w; ++j) s += powl(u[j], a + b);
+            M[a * np1 + b] = s;
+        }
+    edge.assign((size_t)2 * half * w, 0.0);
+    for (int side = 0; side < 2; ++side)
+        for (int r = 0; r < half; ++r) {
+            const int pos = side == 0 ? r : (w - half + r);
+            std::vector<long double> Mc = M, g(np1);
+            for (int a = 0; a < np1; ++a) g[a] = powl(u[pos], a);
+            if (!solve_small(Mc, g, np1)) return false;  // g = M^-1 v(pos)  (M symmetric)
+            for (int j = 0; j < w; ++j) {
+                long double s = 0.0L;
+                for (int a = 0; a < np1; ++a) s += g[a] * powl(u[j], a);
+                edge[((size_t)side * half + r) * w + j] = (double)s;
+            }
+        }
+    return true;
+}
+
+int savgol_design_host(int window, int polyorder, double *coeffs, double *edge) {
+    LK_REQUIRE(window >= 1 && window % 2 == 1, "window_length must be a positive odd integer");
+    LK_REQUIRE(polyorder >= 0 && polyorder < window && polyorder <= 15, "polyorder must be less than window_length");
+    LK_REQUIRE(coeffs && edge, "NULL buffer");
+    std::vector<double> c, e;
+    LK_REQUIRE(savgol_design(window, polyorder, c, e), "singular Savitzky-Golay design");
+    std::copy(c.begin(), c.end(), coeffs);
+    std::copy(e.begin(), e.end(), edge);
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ device helpers
+// order-preserving compaction of {i < n : pred(i)} into out[]; returns the count (same in every thread)
+template <class Pred>
+__device__ int block_compact(int n, Pred pred, int *out, int *sh) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int chunk = (n + nt - 1) / nt;
+    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += pred(i) ? 1 : 0;
+    sh[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = tid >= off ? sh[tid - off] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    const int total = sh[nt - 1];
+    int w = sh[tid] - c;
+    __syncthreads();
+    for (int i = lo; i < hi; ++i)
+        if (pred(i)) out[w++] = i;
+    __syncthreads();
+    return total;
+}
+
+struct FlattenScratch {  // per-target slab offsets are computed from N by the launcher
+    double *tm, *fm, *tr;
+    int *idx, *idx2, *segs;
+    uint8_t *mask, *mask1;
+};
+
+__global__ __launch_bounds__(1024) void flatten_kernel(
+    const double *__restrict__ t, const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
+    const int64_t *__restrict__ n_off, int window, int polyorder, double break_tol, int niters, double sigma,
+    const double *__restrict__ coeffs, const double *__restrict__ edge, char *__restrict__ scratch,
+    const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask) {
+    __shared__ unsigned long long sh[1024];
+    __shared__ int shi[1024];
+    const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t lo = n_off[target];
+    const int N = (int)(n_off[target + 1] - lo);
+    t += lo;
+    flux += lo;
+    trend += lo;
+    if (user_mask) user_mask += lo;
+    if (final_mask) final_mask += lo;
+    // carve the slab (all 8-B aligned: Npad is a multiple of 8)
+    const int Npad = (N + 7) & ~7;
+    char *s = scratch + scratch_off[target];
+    double *tm = reinterpret_cast<double *>(s);
+    double *fm = tm + Npad;
+    double *tr = fm + Npad;
+    int *idx = reinterpret_cast<int *>(tr + Npad);
+    int *idx2 = idx + Npad;
+    int *segs = idx2 + Npad;
+    uint8_t *mask = reinterpret_cast<uint8_t *>(segs + Npad + 8);
+    uint8_t *mask1 = mask + Npad;
+    const int half = window / 2;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+
+    // ---- initial mask: finite & |flux - nanmedian| <= sigma * nanstd, & ~user_mask   (:1002-1010)
+    {
+        auto val = [&](int i) { return flux[i]; };
+        auto notnan = [&](int i) { return !isnan(flux[i]); };
+        long long c = 0;
+        double part = 0.0;
+        for (int i = tid; i < N; i += nt)
+            if (notnan(i)) {
+                ++c;
+                part += flux[i];
+            }
+        const long long cnt = block_count_dyn(c, reinterpret_cast<long long *>(sh));
+        const double mean = block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)cnt;
+        part = 0.0;
+        for (int i = tid; i < N; i += nt)
+            if (notnan(i)) {
+                const double d = flux[i] - mean;
+                part = fma(d, d, part);
+            }
+        const double sd = sqrt(block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)cnt);
+        const double med = block_median(N, cnt, val, notnan, sh);
+        for (int i = tid; i < N; i += nt) {
+            const double f = flux[i];
+            bool m = isfinite(f) && (fabs(f - med) <= sd * sigma);
+            if (user_mask && user_mask[i]) m = false;
+            mask[i] = m ? 1 : 0;
+        }
+        __syncthreads();
+    }
+
+    for (int it = 0; it < niters; ++it) {
+        const int nm = block_compact(N, [&](int i) { return mask[i] != 0; }, idx, shi);
+        for (int i = tid; i < nm; i += nt) {
+            tm[i] = t[idx[i]];
+            fm[i] = flux[idx[i]];
+        }
+        __syncthreads();
+        if (nm == 0) {
+            for (int i = tid; i < N; i += nt) trend[i] = qnan;
+            __syncthreads();
+            break;
+        }
+        // ---- gap segmentation: cut where dt > break_tol * nanmedian(dt)   (:1022-1027)
+        double dmed = qnan;
+        if (nm >= 2) {
+            auto dval = [&](int i) { return tm[i + 1] - tm[i]; };
+            auto dkeep = [&](int i) { return !isnan(tm[i + 1] - tm[i]); };
+            long long c = 0;
+            for (int i = tid; i < nm - 1; i += nt) c += dkeep(i) ? 1 : 0;
+            const long long cnt = block_count_dyn(c, reinterpret_cast<long long *>(sh));
+            dmed = block_median(nm - 1, cnt, dval, dkeep, sh);
+        }
+        const double thr = break_tol * dmed;  // NaN break_tol => every comparison false => no cuts
+        const int nseg = block_compact(
+            nm, [&](int i) { return i == 0 || (tm[i] - tm[i - 1]) > thr; }, segs, shi);
+        // ---- per segment: median for short ones, Savitzky-Golay otherwise   (:1030-1046)
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int l = segs[sg], h = (sg + 1 < nseg) ? segs[sg + 1] : nm;
+            const int len = h - l;
+            if (window > len || (double)len < break_tol) {
+                auto val = [&](int i) { return fm[l + i]; };
+                auto keep = [&](int i) { return true; };  // masked flux is finite
+                const double med = block_median(len, (long long)len, val, keep, sh);
+                for (int i = l + tid; i < h; i += nt) tr[i] = med;
+            } else {
+                // interior: correlate with the taps (window fully inside the segment)
+                for (int i = l + half + tid; i < h - half; i += nt) {
+                    const double *x = fm + (i - half);
+                    double acc = 0.0;
+                    for (int j = 0; j < window; ++j) acc = fma(coeffs[j], x[j], acc);
+                    tr[i] = acc;
+                }
+                // edges: polynomial refit of the first / last `window` samples (mode='interp')
+                for (int e = tid; e < 2 * half; e += nt) {
+                    const int side = e >= half, r = e - side * half;
+                    const double *x = side ? fm + (h - window) : fm + l;
+                    const double *E = edge + ((size_t)side * half + r) * window;
+                    double acc = 0.0;
+                    for (int j = 0; j < window; ++j) acc = fma(E[j], x[j], acc);
+                    tr[side ? (h - half + r) : (l + r)] = acc;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- clip: |flux - trend| < sigma * nanstd(flux - trend) + 1e-14   (:1049-1052)
+        {
+            double part = 0.0;
+            for (int i = tid; i < nm; i += nt) part += fm[i] - tr[i];
+            const double mean = block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)nm;
+            part = 0.0;
+            for (int i = tid; i < nm; i += nt) {
+                const double d = (fm[i] - tr[i]) - mean;
+                part = fma(d, d, part);
+            }
+            const double sd = sqrt(block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)nm);
+            const double lim = sd * sigma + 1e-14;
+            for (int i = tid; i < nm; i += nt) mask1[i] = (fabs(fm[i] - tr[i]) < lim) ? 1 : 0;
+            __syncthreads();
+        }
+        // ---- linear interpolation / extrapolation of the kept trend onto every cadence   (:1053-1058)
+        const int n2 = block_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
+        if (n2 < 2) {
+            for (int i = tid; i < N; i += nt) trend[i] = qnan;
+        } else {
+            for (int k = tid; k < N; k += nt) {
+                const double xn = t[k];
+                // np.searchsorted(x, xn, side='left') clipped to [1, n2-1]
+                int a = 0, b = n2;
+                while (a < b) {
+                    const int mid = (a + b) >> 1;
+                    if (tm[idx2[mid]] < xn)
+                        a = mid + 1;
+                    else
+                        b = mid;
+                }
+                const int hi_i = min(max(a, 1), n2 - 1), lo_i = hi_i - 1;
+                const double x0 = tm[idx2[lo_i]], x1 = tm[idx2[hi_i]];
+                const double y0 = tr[idx2[lo_i]], y1 = tr[idx2[hi_i]];
+                const double slope = (y1 - y0) / (x1 - x0);
+                trend[k] = isnan(xn) ? qnan : slope * (xn - x0) + y0;
+            }
+        }
+        // ---- mask[mask] &= mask1   (:1060-1063)
+        for (int i = tid; i < nm; i += nt)
+            if (!mask1[i]) mask[idx[i]] = 0;
+        __syncthreads();
+    }
+    if (final_mask)
+        for (int i = tid; i < N; i += nt) final_mask[i] = mask[i];
+}
+
+int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
+                   const uint8_t *user_mask, int window, int polyorder, double break_tol, int niters, double sigma,
+                   double *trend, uint8_t *final_mask, hipStream_t stream) {
+    LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(t && flux && trend, "NULL buffer");
+    LK_REQUIRE(window >= 1, "window_length must be a positive integer");
+    LK_REQUIRE(window % 2 == 1, "window_length must be odd");
+    LK_REQUIRE(niters >= 1, "niters must be >= 1");
+    if (polyorder >= window) polyorder = window - 1;  // the reference clamps with a warning (lightcurve.py:1015-1020)
+    LK_REQUIRE(polyorder >= 0 && polyorder <= 15, "polyorder %d outside 0..15", polyorder);
+    LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");
+    std::vector<double> coeffs, edge;
+    LK_REQUIRE(savgol_design(window, polyorder, coeffs, edge), "singular Savitzky-Golay design (window %d, order %d)",
+               window, polyorder);
+    std::vector<int64_t> soff((size_t)B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        const int64_t n = n_off_host[b + 1] - n_off_host[b];
+        LK_REQUIRE(n >= 1 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
+        const int64_t np = (n + 7) & ~(int64_t)7;
+        soff[b + 1] = soff[b] + ((3 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
+    }
+    h->ws.reset();
+    const size_t cb = coeffs.size() * 8, eb = edge.size() * 8;
+    int rc = h->ws.reserve((size_t)(B + 1) * 16 + cb + eb + (size_t)soff[B] + 4096);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    int64_t *d_soff = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    double *d_c = (double *)h->ws.alloc(cb), *d_e = (double *)h->ws.alloc(eb ? eb : 8);
+    char *d_s = (char *)h->ws.alloc((size_t)soff[B]);
+    LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_c, coeffs.data(), cb, hipMemcpyHostToDevice, stream));
+    if (eb) LK_HIP_CHECK(hipMemcpyAsync(d_e, edge.data(), eb, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
+    hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(1024), 0, stream, t, flux, user_mask, d_off, window, polyorder,
+                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk

@@ -1,0 +1,35 @@
+"""Batched front end of ``LightCurve.flatten`` (reference: src/lightkurve/lightcurve.py:943-1078)."""
+import logging
+
+import numpy as np
+
+from . import _capi
+
+log = logging.getLogger(__name__)
+
+
+def flatten_trend_batch(lcs, window_length=101, polyorder=2, break_tolerance=5, niters=3, sigma=3, masks=None,
+                        device=0):
+    """Trend of every light curve in ``lcs`` (list of objects with .time/.flux) in one GPU call.
+    ``masks``: optional list of boolean arrays, True = cadence excluded from the fit (the reference's ``mask=``).
+    Returns a list of float64 arrays."""
+    if polyorder >= window_length:
+        polyorder = window_length - 1
+        log.warning("polyorder must be smaller than window_length, using polyorder={}.".format(polyorder))
+    if window_length % 2 != 1:
+        raise ValueError("window_length must be odd (scipy.signal.savgol_filter with mode='interp')")
+    ts = [np.asarray(lc.time, dtype=np.float64) for lc in lcs]
+    for t in ts:
+        if len(t) > 1 and np.any(np.diff(t) < 0):
+            raise ValueError("flatten needs the light curve sorted by time")
+    off = np.zeros(len(lcs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(t) for t in ts])
+    t = np.concatenate(ts) if ts else np.zeros(0)
+    f = np.concatenate([np.asarray(lc.flux, dtype=np.float64) for lc in lcs]) if ts else np.zeros(0)
+    m = None
+    if masks is not None:
+        m = np.concatenate([np.zeros(len(ts[i]), bool) if mk is None else np.asarray(mk, dtype=bool)
+                            for i, mk in enumerate(masks)])
+    trend = _capi.savgol_trend_batch(t, f, off, mask=m, window_length=window_length, polyorder=polyorder,
+                                     break_tolerance=break_tolerance, niters=niters, sigma=sigma, device=device)
+    return [trend[off[i]:off[i + 1]] for i in range(len(lcs))]

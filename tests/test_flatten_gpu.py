@@ -1,0 +1,79 @@
+"""GPU parity: LightCurve.flatten trend (HIP, through the C ABI) vs golden vectors from the reference and the oracle.
+Tolerance (stated): trend within 1e-10 relative (fp64; scipy's correlate1d sums symmetric taps pairwise, the kernel
+sums taps in order, so last-bit differences are expected); clip decisions identical on the fixtures."""
+import numpy as np
+import pytest
+
+from lightkurve_amd import LightCurve, _capi, synth
+from lightkurve_amd.flatten import flatten_trend_batch
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.mark.parametrize("name", ["flatten_w101", "flatten_w401", "flatten_w51"])
+def test_golden_trend(golden, name):
+    g = golden(name)
+    bt = None if np.isnan(g["break_tolerance"]) else float(g["break_tolerance"])
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    flat, trend = lc.flatten(window_length=int(g["window_length"]), polyorder=int(g["polyorder"]), break_tolerance=bt,
+                             niters=int(g["niters"]), sigma=float(g["sigma"]), return_trend=True)
+    assert np.allclose(trend.flux, g["trend"], rtol=RTOL, atol=0, equal_nan=True)
+    ok = np.isfinite(g["flux"])
+    assert np.allclose(flat.flux[ok], g["flat_flux"][ok], rtol=RTOL) and np.isnan(flat.flux[~ok]).all()
+    assert np.allclose(flat.flux_err[ok], g["flat_err"][ok], rtol=RTOL)
+    assert flat.meta["NORMALIZED"] is True
+
+
+def test_golden_user_mask_and_short_segment(golden):
+    g = golden("flatten_mask")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    _, trend = lc.flatten(window_length=101, mask=g["mask"], return_trend=True)
+    assert np.allclose(trend.flux, g["trend"], rtol=RTOL, atol=0)
+
+
+def test_reference_robustness_cases():
+    """reference tests/test_lightcurve.py:1284-1361: NaNs kept, linear data flattens to 1, one outlier survives."""
+    lc = LightCurve(time=[1, 2, 3, 4, 5], flux=[np.nan, 1.1, 1.2, np.nan, 1.4])
+    assert np.isfinite(lc.flatten(window_length=3).flux).sum() == 3
+    t = np.arange(0, 100.0)
+    lc = LightCurve(time=t, flux=3 + 0.5 * t, flux_err=0.1)
+    for kw in (dict(window_length=3, polyorder=1), dict(window_length=11, polyorder=20), dict(window_length=7, polyorder=2,
+                                                                                        break_tolerance=None)):
+        flat, trend = lc.flatten(return_trend=True, **kw)
+        assert np.allclose(flat.flux, 1.0, rtol=1e-10) and np.allclose(lc.flux, flat.flux * trend.flux, rtol=1e-12)
+    n = 2000
+    flux = np.ones(n) + 1e-6 * np.sin(np.arange(n) / 50.0)
+    flux[1000] = 1.5
+    lc = LightCurve(time=np.arange(n, dtype=float), flux=flux)
+    flat = lc.flatten(window_length=11, niters=3, sigma=3)
+    assert np.isclose(flat.flux, 1.0, rtol=1e-5).sum() == n - 1
+
+
+def test_ragged_batch_vs_oracle():
+    rng = np.random.default_rng(21)
+    lcs, masks = [], []
+    for i, n in enumerate([3000, 150, 999, 20000, 60]):
+        t, y, e, _ = synth.ls_target(6, i, n)
+        y = y * (1 + 0.02 * np.sin(2 * np.pi * t / 2.1) + 1e-3 * t)
+        y[rng.integers(0, n, max(1, n // 300))] += 0.03
+        if n > 200:
+            y[rng.integers(0, n, 3)] = np.nan
+        lcs.append(LightCurve(time=t, flux=y))
+        mk = np.zeros(n, bool)
+        mk[n // 2:n // 2 + n // 40] = i % 2 == 0
+        masks.append(mk)
+    for w, p, bt, ni, sg in [(101, 2, 5, 3, 3), (31, 3, 2, 4, 2.5)]:
+        trends = flatten_trend_batch(lcs, window_length=w, polyorder=p, break_tolerance=bt, niters=ni, sigma=sg, masks=masks)
+        for lc, mk, tr in zip(lcs, masks, trends):
+            ref, _ = O.flatten_trend(lc.time, lc.flux, w, p, bt, ni, sg, mask=mk)
+            assert np.allclose(tr, ref, rtol=RTOL, atol=0, equal_nan=True), (len(lc), w)
+
+
+def test_flatten_errors():
+    lc = LightCurve(time=[3, 2, 1.0, 4, 5, 6, 7], flux=np.ones(7))
+    with pytest.raises(ValueError, match="sorted"):
+        lc.flatten(window_length=3)
+    with pytest.raises(ValueError, match="odd"):
+        LightCurve(time=np.arange(10.0), flux=np.ones(10)).flatten(window_length=4)
