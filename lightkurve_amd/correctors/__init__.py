@@ -1,0 +1,3 @@
+"""Host-side mirrors of lightkurve.correctors for the regression hot path."""
+from .designmatrix import DesignMatrix, DesignMatrixCollection  # noqa: F401
+from .regressioncorrector import RegressionCorrector  # noqa: F401

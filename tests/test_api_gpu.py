@@ -88,3 +88,22 @@ def test_bls_then_fold_recovers_transit(golden):
     assert np.array_equal(f1.flux, f2.flux) and np.allclose(f1.time, f2.time, atol=1e-9)
     in_tr = np.abs(f1.time) < 0.5 * pg.duration_at_max_power
     assert np.median(f1.flux[in_tr]) < np.median(f1.flux[~in_tr]) - 0.5 * pg.depth_at_max_power
+
+
+def test_batch_entry_points_match_per_target_calls():
+    from lightkurve_amd import batch, synth
+    lcs = []
+    for i, n in enumerate([900, 2000, 350, 1200]):
+        t, y, e, _ = synth.bls_target(5, i, n, cadence_days=10.0 / 1440.0)
+        lcs.append(LightCurve(time=t + 100.0 * i, flux=y, flux_err=e))
+    f = 0.02 * (1 + np.arange(1500))
+    P = batch.lombscargle_batch(lcs, f)
+    for b, lc in enumerate(lcs):
+        assert np.array_equal(P[b], lc.to_periodogram(frequency=f).power)
+    mx, am = batch.periodogram_peaks(P)
+    assert np.array_equal(am, np.argmax(P, axis=1)) and np.array_equal(mx, P.max(axis=1))
+    period = np.linspace(0.7, 5.0, 120)
+    R = batch.bls_batch(lcs, period, [0.05, 0.1, 0.2])
+    for b, lc in enumerate(lcs):
+        pg = lc.to_periodogram(method="bls", period=period, duration=[0.05, 0.1, 0.2])
+        assert np.array_equal(R[b, 0], pg.power) and np.array_equal(R[b, 4], pg.transit_time)

@@ -1,0 +1,76 @@
+"""CPU (gloo, world_size 2): the N>1 sharding path — cost-balanced contiguous partition, per-rank compute on
+the local block only, ragged all-gather back to every rank in input order.  The compute function injected
+here is the oracle (tests may use it as a stand-in; the product wires the HIP call into the same sharded_map)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from lightkurve_amd import distributed as D
+
+
+def test_partition_by_cost_properties():
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 64, 1000):
+            costs = rng.integers(1, 100, n).astype(float)
+            b = D.partition_by_cost(costs, world)
+            assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0) and len(b) == world + 1
+            if n >= 8 * world:
+                loads = np.array([costs[b[r]:b[r + 1]].sum() for r in range(world)])
+                assert loads.max() <= costs.sum() / world + costs.max()
+    assert np.array_equal(D.shard_bounds(10, 4), [0, 3, 6, 9, 10])
+    assert np.array_equal(D.shard_bounds(0, 4), [0, 0, 0, 0, 0])
+    with pytest.raises(ValueError):
+        D.partition_by_cost([1, -1], 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    from lightkurve_amd import synth
+    from oracle import np_oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ns = [300, 50, 800, 120, 640, 90, 10]               # ragged: 7 targets over 2 ranks
+        items = [synth.ls_target(7, i, n) for i, n in enumerate(ns)]
+        freq = 0.05 + 0.05 * np.arange(40)
+        seen = []
+
+        def fn(local):
+            seen.append(len(local))
+            if not local:
+                return np.zeros((0, len(freq)))
+            return np.stack([O.ls_power(t - t[0], y, None, freq, normalization="lk_amplitude") for t, y, e, _ in local])
+
+        full = D.sharded_map(items, fn, costs=[n * len(freq) for n in ns])
+        part = D.sharded_map(items, fn, costs=[n * len(freq) for n in ns], gather=False)
+        bounds = D.shard_bounds(len(ns), world, [n * len(freq) for n in ns])
+        np.savez(os.path.join(outdir, "r%d.npz" % rank), full=full, part=part, seen=np.array(seen), bounds=bounds)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_map_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    from lightkurve_amd import synth
+    from oracle import np_oracle as O
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ns = [300, 50, 800, 120, 640, 90, 10]
+    freq = 0.05 + 0.05 * np.arange(40)
+    ref = np.stack([O.ls_power(t - t[0], y, None, freq, normalization="lk_amplitude")
+                    for t, y, e, _ in (synth.ls_target(7, i, n) for i, n in enumerate(ns))])
+    r0, r1 = (np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(2))
+    assert np.array_equal(r0["full"], ref) and np.array_equal(r1["full"], ref)      # everyone has everything, in order
+    b = r0["bounds"]
+    assert np.array_equal(r0["part"], ref[b[0]:b[1]]) and np.array_equal(r1["part"], ref[b[1]:b[2]])
+    assert r0["seen"].tolist() == [b[1] - b[0]] * 2 and r1["seen"].tolist() == [b[2] - b[1]] * 2   # local work only
+    assert 0 < b[1] < len(ns)

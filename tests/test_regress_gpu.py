@@ -90,3 +90,40 @@ def test_full_width_k465_properties():
     ref = O.regression_correct(X, y, err, cm)
     assert np.array_equal(r["outlier_mask"], ref["outlier_mask"])
     assert np.max(np.abs(r["model"] - ref["model"])) < 1e-8 * np.std(y)
+
+
+def test_regressioncorrector_api_like_reference(golden):
+    """reference tests/correctors/test_regressioncorrector.py:13-118 (priors KAT, sinusoid removal, validation)."""
+    from lightkurve_amd import LightCurve
+    from lightkurve_amd.correctors import DesignMatrix, DesignMatrixCollection, RegressionCorrector
+    lc = LightCurve(flux=[5, 10], flux_err=[1, 1], time=[1, 2])
+    dm = DesignMatrix({"a": [1., 1.], "b": [1., 2.]})
+    rc = RegressionCorrector(lc)
+    rc.correct(dm)
+    assert np.allclose(rc.coefficients, [0, 5], atol=1e-7)
+    dm = DesignMatrix({"a": [1., 1.], "b": [1., 2.]}, prior_mu=[99., 99.], prior_sigma=[1e-6, 1e-6])
+    rc.correct(dm)
+    assert np.allclose(rc.coefficients, [99, 99], atol=1e-6)
+    # sinusoid removal, with and without flux_err
+    size = 100
+    time = np.linspace(1, 100, size)
+    true = np.ones(size)
+    noise = np.sin(time / 5)
+    for err in (np.ones(size), None):
+        lc = LightCurve(time=time, flux=true + noise, flux_err=err)
+        dmc = DesignMatrixCollection([DesignMatrix({"noise": noise}, name="noise"),
+                                      DesignMatrix({"offset": np.ones(size)}, name="offset")])
+        rc = RegressionCorrector(lc)
+        clc = rc.correct(dmc)
+        assert np.allclose(clc.flux, true, atol=1e-7)
+        assert set(rc.diagnostic_lightcurves) == {"noise", "offset"}
+    with pytest.raises(ValueError, match="NaNs in time or flux"):
+        RegressionCorrector(LightCurve(time=time, flux=np.r_[np.nan, true[1:]], flux_err=np.ones(size)))
+    with pytest.raises(ValueError, match="smaller than or equal to zero"):
+        RegressionCorrector(LightCurve(time=time, flux=true, flux_err=np.zeros(size)))
+    g = golden("regress_k8")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    rc = RegressionCorrector(lc)
+    clc = rc.correct(DesignMatrix(g["X"], name="X", prior_mu=g["prior_mu"], prior_sigma=g["prior_sigma"]),
+                     cadence_mask=g["cadence_mask"])
+    assert np.array_equal(rc.outlier_mask, g["outlier_mask"]) and np.allclose(clc.flux, g["corrected"], atol=1e-11)
