@@ -1,0 +1,51 @@
+"""Runs under the conda interpreter that has astropy (spawned by tests/test_seams_gpu.py on the GPU box):
+installs the HIP kernels behind astropy's own dispatch and compares with astropy's own CPU implementations."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from astropy.timeseries import BoxLeastSquares, LombScargle
+    from astropy.timeseries.periodograms.bls import methods as bls_methods
+    from lightkurve_amd import seams, synth
+    installed = seams.install()
+    out = {"installed": installed}
+    # S1: astropy LombScargle.power(method='hip') vs astropy's exact methods, both normalisations, dy on/off
+    t, y, e, _ = synth.ls_target(1, 3, 2500)
+    f = synth.ls_frequency_grid(1500)
+    errs = {}
+    for dy in (None, e * np.linspace(0.5, 2, len(e))):
+        ls = LombScargle(t - t[0], y, dy)
+        for norm in ("standard", "psd"):
+            ref = ls.power(f, method="cython", normalization=norm)
+            got = ls.power(f, method="hip", normalization=norm)
+            errs["%s_%s" % (norm, "dy" if dy is not None else "nody")] = float(np.max(np.abs(got - ref)) / np.max(ref))
+        per = np.linspace(0.1, 5, 400)     # irregular frequency grid
+        errs["irregular_%s" % ("dy" if dy is not None else "nody")] = float(
+            np.max(np.abs(ls.power(1 / per, method="hip") - ls.power(1 / per, method="slow"))))
+    out["ls_relerr"] = errs
+    # S2: patched bls_fast vs astropy's compiled run_bls, bit for bit, through BoxLeastSquares.power
+    t, y, e, _ = synth.bls_target(3, 7, 3000, cadence_days=10.0 / 1440.0)
+    bls = BoxLeastSquares(t, y, e)
+    period, duration = synth.bls_grid(300, 12, pmin=0.6, pmax=8.0)
+    exact = {}
+    for objective in ("likelihood", "snr"):
+        got = bls.power(period, duration, objective=objective)
+        bls_methods.bls_fast, saved = bls_methods._bls_fast_reference, bls_methods.bls_fast
+        ref = bls.power(period, duration, objective=objective)
+        bls_methods.bls_fast = saved
+        exact[objective] = all(bool(np.array_equal(np.asarray(getattr(got, k)), np.asarray(getattr(ref, k))))
+                               for k in ("power", "depth", "depth_err", "duration", "depth_snr", "log_likelihood"))
+        exact[objective + "_tt"] = float(np.max(np.abs(np.asarray(got.transit_time) - np.asarray(ref.transit_time))))
+    out["bls_bit_exact"] = exact
+    print("SEAMS_RESULT " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+"""GPU: the seams of INTEGRATION.md exercised against the reference's REAL numerical dependency.
+astropy only exists under /opt/conda/bin/python3.9 in this image, so the check runs there in a subprocess:
+astropy's own LombScargle / BoxLeastSquares objects dispatch into liblkhip.so and are compared with astropy's
+own compiled CPU kernels on the GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONDA = "/opt/conda/bin/python3.9"
+
+
+def test_astropy_seams_under_conda():
+    if not os.path.exists(CONDA):
+        pytest.skip("no conda interpreter with astropy on this box")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "oracle", "shims") + os.pathsep + ROOT)
+    # conda ships an older libstdc++ (6.0.28) that shadows the system one liblkhip.so / libamdhip64 were built against
+    sys_stdcxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_stdcxx):
+        env["LD_PRELOAD"] = sys_stdcxx
+    probe = subprocess.run([CONDA, "-W", "ignore", "-c", "import astropy.timeseries"], env=env, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("astropy not importable under conda here: " + probe.stderr.decode()[-200:])
+    p = subprocess.run([CONDA, "-W", "ignore", os.path.join(ROOT, "tests", "seams_worker.py")], env=env,
+                       capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_RESULT ")][-1]
+    res = json.loads(line[len("SEAMS_RESULT "):])
+    assert len(res["installed"]) == 2
+    for k, v in res["ls_relerr"].items():
+        assert v < 1e-9, (k, v)
+    assert res["bls_bit_exact"]["likelihood"] and res["bls_bit_exact"]["snr"]
+    assert res["bls_bit_exact"]["likelihood_tt"] < 1e-9
