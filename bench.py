@@ -46,12 +46,50 @@ def parse():
     return ap.parse_args()
 
 
+CONDA = "/opt/conda/bin/python3.9"
+SYS_STDCXX = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+
+
+def _astropy_baseline(argv):
+    """Run oracle/astropy_baseline.py under the conda interpreter that ships astropy (the reference's real
+    numerical dependency).  Returns its JSON dict, or None if that interpreter / astropy is not there."""
+    import subprocess
+    if not os.path.exists(CONDA):
+        return None
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "oracle", "shims") + os.pathsep + ROOT)
+    if os.path.exists(SYS_STDCXX):
+        env["LD_PRELOAD"] = SYS_STDCXX
+    try:
+        p = subprocess.run([CONDA, "-W", "ignore", os.path.join(ROOT, "oracle", "astropy_baseline.py")] +
+                           [str(a) for a in argv], env=env, capture_output=True, timeout=900)
+        for line in p.stdout.decode().splitlines():
+            if line.startswith("BASELINE "):
+                return json.loads(line[9:])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline_ls(args):
-    """Reference default path ('fast': extirpolation + FFT, astropy fast_impl.py) as a numpy port, one process
-    per host core over a bounded sample of the same workload.  Runs BEFORE torch/HIP is initialised (spawn pool)."""
+    """The reference's DEFAULT CPU path on this box's host cores, on a bounded sample of the same workload,
+    before torch/HIP is initialised.  Preferred: astropy itself (LombScargle.power(method='fast') exactly as
+    lightkurve calls it, periodogram.py:961-964) under the conda interpreter, one process per core (kind
+    "reference").  Fallback: the numpy port of the same algorithm from oracle/ (kind "port")."""
     import multiprocessing as mp
     from oracle import cpu_baseline as cb
     cores = max(1, min(os.cpu_count() or 1, 64))
+    exact_pairs_per_s = cb.ls_exact_rate(args.cadences)
+    extra = {"exact_port_1core": {"value": exact_pairs_per_s / args.cadences, "unit": "frequencies*targets/sec",
+                                  "note": "C oracle (the exact direct-sum arithmetic the GPU kernel performs), 1 core"}}
+    n_targets = cores * 16
+    r = _astropy_baseline(["ls", n_targets, args.cadences, args.freqs, cores, "fast"])
+    if r is not None:
+        out = {"value": r["units_per_s"], "unit": "frequencies*targets/sec", "cores": cores, "kind": "reference",
+               "sample": "astropy %s LombScargle.power(method='fast') as lightkurve calls it (periodogram.py:961-964), "
+                         "%d targets x %d freqs, N=%d, %d processes, %.1f s" % (r["astropy"], n_targets, args.freqs,
+                                                                              args.cadences, cores, r["seconds"])}
+        out.update(extra)
+        return out
     n_targets = cores * 2
     jobs = [(1, i, args.cadences, args.freqs) for i in range(n_targets)]
     ctx = mp.get_context("spawn")
@@ -60,18 +98,22 @@ def cpu_baseline_ls(args):
         t0 = time.perf_counter()
         pool.map(cb.ls_fast_one, jobs)
         dt = time.perf_counter() - t0
-    exact_pairs_per_s = cb.ls_exact_rate(args.cadences)
-    return {
-        "value": n_targets * args.freqs / dt, "unit": "frequencies*targets/sec", "cores": cores, "kind": "port",
-        "sample": "%d targets x %d freqs, N=%d, numpy port of the reference default ls_method='fast' "
-                  "(Press-Rybicki FFT), %d processes" % (n_targets, args.freqs, args.cadences, cores),
-        "exact_port_1core": {"value": exact_pairs_per_s / args.cadences, "unit": "frequencies*targets/sec",
-                             "note": "C oracle (same exact direct-sum arithmetic as the GPU kernel), 1 core"},
-    }
+    out = {"value": n_targets * args.freqs / dt, "unit": "frequencies*targets/sec", "cores": cores, "kind": "port",
+           "sample": "%d targets x %d freqs, N=%d, numpy port of the reference default ls_method='fast' "
+                     "(Press-Rybicki FFT), %d processes" % (n_targets, args.freqs, args.cadences, cores)}
+    out.update(extra)
+    return out
 
 
 def cpu_baseline_bls(args):
     from oracle import cpu_baseline as cb
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    r = _astropy_baseline(["bls", cores * 2, args.cadences, 48, args.durations, cores])
+    if r is not None:
+        return {"value": r["units_per_s"], "unit": "periods*targets/sec", "cores": cores, "kind": "reference",
+                "sample": "astropy %s BoxLeastSquares.power (compiled run_bls) as lightkurve calls it "
+                          "(periodogram.py:1161-1169), %d targets x 48 periods x %d durations, N=%d, %d processes, "
+                          "%.1f s" % (r["astropy"], cores * 2, args.durations, args.cadences, cores, r["seconds"])}
     rate = cb.bls_rate(args.cadences, args.durations)
     return {"value": rate, "unit": "periods*targets/sec", "cores": 1, "kind": "port",
             "sample": "C oracle (restated astropy run_bls), 1 target x 24 periods x %d durations, N=%d, 1 core"

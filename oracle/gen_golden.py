@@ -196,7 +196,58 @@ def gen_regression():
          outlier_mask=rc3.outlier_mask)
 
 
+def _pld_dump(name, tpf, aperture_mask, **correct_kw):
+    from lightkurve.correctors import PLDCorrector
+    pld = PLDCorrector(tpf, aperture_mask=aperture_mask)
+    clc = pld.correct(**correct_kw)
+    dmc = pld.design_matrix_collection
+    out = dict(time=pld.tpf.time.value, flux=np.asarray(pld.tpf.flux.value, dtype=np.float32),
+               flux_err=np.asarray(pld.tpf.flux_err.value, dtype=np.float32),
+               aperture_mask=np.asarray(pld.aperture_mask, bool),
+               pld_aperture_mask=np.asarray(pld.pld_aperture_mask, bool),
+               background_aperture_mask=np.asarray(pld.background_aperture_mask, bool),
+               threshold_mask=np.asarray(tpf.create_threshold_mask(3), bool),
+               lc_flux=np.asarray(pld.lc.flux.value, float), lc_flux_err=np.asarray(pld.lc.flux_err.value, float),
+               corrected=np.asarray(clc.flux.value, float), corrected_err=np.asarray(clc.flux_err.value, float),
+               outlier_mask=np.asarray(pld.outlier_mask, bool), X=np.asarray(dmc.X, float),
+               prior_sigma=np.asarray(dmc.prior_sigma, float), prior_mu=np.asarray(dmc.prior_mu, float),
+               block_names=np.array([m.name for m in dmc.matrices]),
+               block_widths=np.array([m.shape[1] for m in dmc.matrices]),
+               coefficients=np.asarray(pld.coefficients, float),
+               spline_diag=np.asarray(pld.diagnostic_lightcurves["spline"].flux.value, float))
+    for k, v in correct_kw.items():
+        if not isinstance(v, str) and v is not None:
+            out["kw_" + k] = v
+        elif isinstance(v, str):
+            out["kw_" + k] = np.array(v)
+    save(name, **out)
+
+
+def gen_pld():
+    import lightkurve as lk
+    ref_data = "/root/reference/tests/data/synthetic/"
+    tpf = lk.read(ref_data + "synthetic-k2-sinusoid.targ.fits.gz")
+    # (1) the 3rd-order pixel-product path; never exercised by the reference's offline tests
+    _pld_dump("pld_k2sin_order3", tpf, None, pld_order=3, pca_components=16, pld_aperture_mask="all",
+              normalize_background_pixels=True)
+    # (2) what the reference's own offline tests run (tests/test_synthetic_data.py:162-201): no MISSION keyword
+    #     => order 1, 3 PCA terms, pld_aperture_mask 'empty': background(3) + spline(10+1)
+    _pld_dump("pld_k2sin_default", tpf, None)
+    # (3) K2-like 11x11 factory cutout of the bench workload shape (fewer cadences), 2nd order, 8 components
+    from lightkurve.targetpixelfile import TargetPixelFileFactory
+    t, flux, err, truth = synth.pld_cutout(4, 0, n=600, npix=11)
+    fac = TargetPixelFileFactory(len(t), 11, 11)
+    for i in range(len(t)):
+        fac.add_cadence(frameno=i, flux=flux[i], flux_err=err[i],
+                        header={"TSTART": 2000.0 + t[i] - 0.0102, "TSTOP": 2000.0 + t[i] + 0.0102})
+    tpf2 = fac.get_tpf(hdu0_keywords={"TELESCOP": "Kepler", "INSTRUME": "Kepler Photometer", "MISSION": "K2",
+                                      "OBSMODE": "long cadence"},
+                       ext_info={"1CRV5P": 100, "2CRV5P": 200, "1CRV4P": 100, "2CRV4P": 200})
+    _pld_dump("pld_factory11_order2", tpf2, "all", pld_order=2, pca_components=8, pld_aperture_mask="all",
+              background_aperture_mask="all", spline_degree=3)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "bls", "flatten", "regression"]
+    which = sys.argv[1:] or ["ls", "bls", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

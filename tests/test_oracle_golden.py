@@ -172,3 +172,41 @@ def test_regression_kat_and_noerr(golden):
     r = O.regression_correct(g["X"], g["flux"], None)
     assert np.array_equal(r["outlier_mask"], g["outlier_mask"])
     assert np.allclose(r["corrected"], g["corrected"], rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ PLD
+def _pld_kw(g):
+    kw = {}
+    for k in ("pld_order", "pca_components", "spline_degree"):
+        if "kw_" + k in g:
+            kw[k] = int(g["kw_" + k])
+    if "kw_normalize_background_pixels" in g:
+        kw["normalize_background_pixels"] = bool(g["kw_normalize_background_pixels"])
+    return kw
+
+
+def test_threshold_mask_and_spline_block(golden):
+    for name in ("pld_k2sin_order3", "pld_factory11_order2"):
+        g = golden(name)
+        assert np.array_equal(O.threshold_mask(g["flux"]), g["threshold_mask"])
+        nk = int(g["block_widths"][-1]) - 1
+        deg = int(g["kw_spline_degree"]) if "kw_spline_degree" in g else 5
+        B = O.bspline_basis(g["time"], nk, deg)
+        assert np.allclose(B, g["X"][:, -nk - 1:-1], rtol=0, atol=1e-13)          # patsy bs(), App. B.7
+        assert np.array_equal(g["X"][:, -1], np.ones(len(g["time"])))
+
+
+@pytest.mark.parametrize("name", ["pld_k2sin_order3", "pld_k2sin_default", "pld_factory11_order2"])
+def test_pld_corrected_flux(golden, name):
+    """Parity on corrected flux (never on X columns / coefficients: PCA bases are defined up to rotations inside
+    a block)."""
+    g = golden(name)
+    ap = g["aperture_mask"] if g["aperture_mask"].shape else np.ones(g["flux"].shape[1:], bool)
+    kw = _pld_kw(g)
+    if name == "pld_k2sin_default":
+        kw.update(pld_order=1, pca_components=3, normalize_background_pixels=False)
+    r = O.pld_correct(g["time"], g["flux"], g["flux_err"], ap, g["pld_aperture_mask"], g["background_aperture_mask"], **kw)
+    assert np.allclose(r["lc_flux"], g["lc_flux"], rtol=1e-6) and np.allclose(r["lc_flux_err"], g["lc_flux_err"], rtol=1e-6)
+    assert r["X"].shape == g["X"].shape and np.allclose(r["prior_sigma"], g["prior_sigma"], rtol=1e-6)
+    assert np.array_equal(r["outlier_mask"], g["outlier_mask"])
+    assert np.max(np.abs(r["corrected"] - g["corrected"])) / np.median(g["corrected"]) < 1e-6
