@@ -117,6 +117,23 @@ int lk_savgol_trend_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, co
  * (2 x (window/2) x window doubles, left then right) the kernel uses == scipy savgol_coeffs / mode='interp'. */
 int lk_savgol_design(int window, int polyorder, double *coeffs, double *edge);
 
+/* ---- PLDCorrector.create_design_matrix (correctors/pldcorrector.py:186-287) for B same-shaped cutouts --------
+ * pld_pix: B x N x P float32 pixel fluxes inside the PLD aperture (NULL / P = 0: no pixel block);
+ * bkg_pix: B x N x Pb float32 background pixels; lc_flux: B x N float32 SAP flux; time: B x N;
+ * knots: B x (n_inner + 2) = [min(t), interior knots (percentiles of t, as patsy's bs()), max(t)];
+ * n_knots = n_inner + spline_degree + 1 spline columns (+1 constant).  normalize_bkg: divide background pixels
+ * by their row sum.  X: B x N x K row-major with K = lk_pld_design_width(...):
+ *   [ PCA(pixels/flux) | PCA(2-fold products) | ... | PCA(background) | B-splines | 1 ];  prior_sigma: B x K. */
+int lk_pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_knots);
+int lk_pld_design_batch(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
+                        const float *lc_flux, const double *time, const double *knots, int n_inner, int pld_order,
+                        int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,
+                        double *prior_sigma);
+int lk_pld_design_batch_dev(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
+                            const float *lc_flux, const double *time, const double *knots, int n_inner,
+                            int pld_order, int pca_components, int n_knots, int spline_degree, int normalize_bkg,
+                            int K, double *X, double *prior_sigma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ _c_dp = ctypes.POINTER(ctypes.c_double)
 _c_ip = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_c_fp = ctypes.POINTER(ctypes.c_float)
 
 # (name, restype, argtypes) for EVERY symbol include/lkhip.h declares — tests/test_capi_symbols.py checks the list
 SIGNATURES = [
@@ -57,6 +58,13 @@ SIGNATURES = [
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
       ctypes.c_double, _vp, _vp, _vp]),
     ("lk_savgol_design", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
+    ("lk_pld_design_width", ctypes.c_int, [ctypes.c_int] * 5),
+    ("lk_pld_design_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp, _c_fp, _c_fp, _c_dp, _c_dp, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
+    ("lk_pld_design_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
 ]
 
 _lib = None
@@ -285,3 +293,38 @@ def savgol_trend_batch(t, flux, n_off, mask=None, window_length=101, polyorder=2
                                       int(window_length), int(polyorder), bt, int(niters), float(sigma), _ptr(trend),
                                       _ptr(fm, _c_u8p)))
     return (trend, fm.astype(bool)) if return_fit_mask else trend
+
+
+# --------------------------------------------------------------------------------------------- PLD design matrix
+def pld_design_width(P, Pb, pld_order, pca_components, n_knots):
+    load_library()
+    return int(_lib.lk_pld_design_width(int(P), int(Pb), int(pld_order), int(pca_components), int(n_knots)))
+
+
+def pld_design_batch(pld_pix, bkg_pix, lc_flux, time, knots, pld_order, pca_components, spline_degree,
+                     normalize_bkg=True, device=0):
+    """PLD design matrices for B same-shaped cutouts.  pld_pix (B, N, P) or None, bkg_pix (B, N, Pb), lc_flux (B, N)
+    float32; time (B, N); knots (B, n_inner + 2) = [min t, interior knots, max t].
+    Returns (X[B, N, K], prior_sigma[B, K])."""
+    h = Handle.get(device)
+    bkg_pix = np.ascontiguousarray(bkg_pix, dtype=np.float32)
+    B, N, Pb = bkg_pix.shape
+    P = 0
+    if pld_pix is not None and np.size(pld_pix):
+        pld_pix = np.ascontiguousarray(pld_pix, dtype=np.float32)
+        P = pld_pix.shape[2]
+    else:
+        pld_pix = None
+    lc_flux = np.ascontiguousarray(lc_flux, dtype=np.float32)
+    time, knots = _f64(time), _f64(knots)
+    if lc_flux.shape != (B, N) or time.shape != (B, N) or knots.shape[0] != B:
+        raise ValueError("inconsistent PLD batch shapes")
+    n_inner = knots.shape[1] - 2
+    n_knots = n_inner + int(spline_degree) + 1
+    K = pld_design_width(P, Pb, pld_order, pca_components, n_knots)
+    X = np.empty((B, N, K), dtype=np.float64)
+    ps = np.empty((B, K), dtype=np.float64)
+    _check(_lib.lk_pld_design_batch(h._h, B, N, P, Pb, _ptr(pld_pix, _c_fp), _ptr(bkg_pix, _c_fp), _ptr(lc_flux, _c_fp),
+                                    _ptr(time), _ptr(knots), n_inner, int(pld_order), int(pca_components), n_knots,
+                                    int(spline_degree), int(bool(normalize_bkg)), K, _ptr(X), _ptr(ps)))
+    return X, ps

@@ -1,3 +1,4 @@
 """Host-side mirrors of lightkurve.correctors for the regression hot path."""
 from .designmatrix import DesignMatrix, DesignMatrixCollection  # noqa: F401
+from .pldcorrector import PixelCube, PLDCorrector, pld_correct_batch  # noqa: F401
 from .regressioncorrector import RegressionCorrector  # noqa: F401

@@ -1,0 +1,244 @@
+"""PLDCorrector over the GPU design-matrix + regression path
+(reference: src/lightkurve/correctors/pldcorrector.py:109-120, 125-287, 304-427).
+
+The reference takes a ``TargetPixelFile``; that container (FITS I/O, WCS, plotting) is out of scope, so the mirror
+takes a ``PixelCube``: time[N], flux[N, ny, nx], flux_err[N, ny, nx] and an optional mission string — the only
+things ``PLDCorrector`` reads from the TPF — with the two TPF helpers it calls
+(``create_threshold_mask`` targetpixelfile.py:680-742, aperture photometry :868-923)."""
+import logging
+
+import numpy as np
+
+from .. import _capi
+from ..lightcurve import LightCurve
+from .designmatrix import DesignMatrix, DesignMatrixCollection
+from .regressioncorrector import RegressionCorrector
+
+log = logging.getLogger(__name__)
+
+__all__ = ["PixelCube", "PLDCorrector", "pld_correct_batch"]
+
+
+class PixelCube(object):
+    """Minimal stand-in for the slice of TargetPixelFile that PLDCorrector touches."""
+
+    def __init__(self, time, flux, flux_err, mission=None, targetid=None):
+        self.time = np.asarray(time, dtype=np.float64)
+        self.flux = np.asarray(flux)
+        self.flux_err = np.asarray(flux_err)
+        if self.flux.ndim != 3 or self.flux.shape != self.flux_err.shape or len(self.time) != len(self.flux):
+            raise ValueError("flux and flux_err must be (cadence, row, column) cubes matching time")
+        self.meta = {"MISSION": mission, "TARGETID": targetid}
+
+    @property
+    def shape(self):
+        return self.flux.shape
+
+    def __getitem__(self, key):
+        c = PixelCube(self.time[key], self.flux[key], self.flux_err[key])
+        c.meta = dict(self.meta)
+        return c
+
+    def create_threshold_mask(self, threshold=3, reference_pixel="center"):
+        """Pixels whose median flux exceeds median + threshold * 1.4826 * MAD; with a reference pixel, only the
+        4-connected region closest to it (targetpixelfile.py:680-742)."""
+        if reference_pixel == "center":
+            reference_pixel = (self.shape[2] / 2, self.shape[1] / 2)
+        with np.errstate(all="ignore"):
+            median_image = np.nanmedian(np.asarray(self.flux, dtype=np.float64), axis=0)
+        vals = median_image[np.isfinite(median_image)].flatten()
+        mad = np.median(np.abs(vals - np.median(vals)))
+        mad_cut = (1.4826 * mad * threshold) + np.nanmedian(median_image)
+        mask = np.nan_to_num(median_image) >= mad_cut
+        if reference_pixel is None or not mask.any():
+            return mask
+        labels = np.zeros(mask.shape, dtype=int)
+        current = 0
+        for r in range(mask.shape[0]):
+            for c in range(mask.shape[1]):
+                if mask[r, c] and labels[r, c] == 0:
+                    current += 1
+                    labels[r, c] = current
+                    stack = [(r, c)]
+                    while stack:
+                        a, b = stack.pop()
+                        for da, db in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                            aa, bb = a + da, b + db
+                            if (0 <= aa < mask.shape[0] and 0 <= bb < mask.shape[1] and mask[aa, bb]
+                                    and labels[aa, bb] == 0):
+                                labels[aa, bb] = current
+                                stack.append((aa, bb))
+        args = np.argwhere(labels > 0)
+        dist = [np.hypot(a[0] - reference_pixel[1], a[1] - reference_pixel[0]) for a in args]
+        closest = args[int(np.argmin(dist))]
+        return labels == labels[closest[0], closest[1]]
+
+    def _parse_aperture_mask(self, aperture_mask):
+        """'all' / None, 'threshold', 'background' (= not threshold), 'empty', or a boolean (row, column) array
+        (targetpixelfile.py:603-678; 'pipeline' needs the FITS aperture extension and is not available here)."""
+        if aperture_mask is None or (isinstance(aperture_mask, str) and aperture_mask == "all"):
+            return np.ones(self.shape[1:], dtype=bool)
+        if isinstance(aperture_mask, str):
+            if aperture_mask == "threshold":
+                return self.create_threshold_mask()
+            if aperture_mask == "background":
+                return ~self.create_threshold_mask(threshold=0, reference_pixel=None)
+            if aperture_mask == "empty":
+                return np.zeros(self.shape[1:], dtype=bool)
+            raise ValueError("aperture_mask '{}' is not supported here".format(aperture_mask))
+        m = np.asarray(aperture_mask, dtype=bool)
+        if m.shape != self.shape[1:]:
+            raise ValueError("`aperture_mask` has shape {}, but the flux data has shape {}".format(m.shape,
+                                                                                                 self.shape[1:]))
+        return m
+
+    def to_lightcurve(self, aperture_mask=None):
+        """Simple aperture photometry, flux_method='sum' (targetpixelfile.py:868-923); numpy keeps float32 cubes
+        float32 here exactly like the reference does."""
+        ap = self._parse_aperture_mask(aperture_mask)
+        with np.errstate(all="ignore"):
+            flux = np.nansum(self.flux[:, ap], axis=1)
+            flux = np.asarray(flux)
+            flux[~np.any(np.isfinite(self.flux[:, ap]), axis=1)] = np.nan
+            flux[np.all(self.flux == 0, axis=(1, 2))] = np.nan
+            flux_err = np.nansum(self.flux_err[:, ap] ** 2, axis=1) ** 0.5
+        lc = LightCurve(time=self.time, flux=flux, flux_err=flux_err, meta=dict(self.meta))
+        lc._flux_f32 = np.asarray(flux, dtype=np.float32)   # the value the reference carries (float32 for FITS cubes)
+        return lc
+
+
+def _percentile_knots(time, n_knots, degree):
+    """[min, interior knots, max] of patsy's bs(x, df=n_knots, degree, include_intercept=True)."""
+    order = degree + 1
+    n_inner = n_knots - order
+    if n_inner < 0:
+        raise ValueError("df={} is too small for degree={}; must be >= {}".format(n_knots, degree, order))
+    inner = np.percentile(time, np.linspace(0, 100, n_inner + 2)[1:-1]) if n_inner > 0 else np.zeros(0)
+    return np.concatenate([[np.min(time)], inner, [np.max(time)]])
+
+
+def _finite_columns(cube2d):
+    return cube2d[:, np.all(np.isfinite(cube2d), axis=0)]
+
+
+class PLDCorrector(RegressionCorrector):
+    def __init__(self, tpf, aperture_mask=None):
+        if aperture_mask is None:
+            aperture_mask = tpf.create_threshold_mask(3)
+        self.aperture_mask = tpf._parse_aperture_mask(aperture_mask)
+        lc = tpf.to_lightcurve(aperture_mask=self.aperture_mask)
+        nan_mask = np.isnan(lc.flux) | np.isnan(lc.flux_err)
+        f32 = lc._flux_f32[~nan_mask]
+        lc = lc[~nan_mask]
+        lc._flux_f32 = f32
+        self.tpf = tpf[~nan_mask]
+        super().__init__(lc=lc)
+
+    def __repr__(self):
+        return "PLDCorrector (ID: {})".format(self.lc.label)
+
+    def _resolve(self, pld_order, pca_components, pld_aperture_mask, normalize_background_pixels):
+        """mission defaults of .correct() (pldcorrector.py:382-403)."""
+        k2 = self.tpf.meta.get("MISSION") == "K2"
+        if pld_order is None:
+            pld_order = 3 if k2 else 1
+        if pca_components is None:
+            pca_components = 16 if k2 else 3
+        if pld_aperture_mask is None:
+            pld_aperture_mask = "threshold" if k2 else "empty"
+        if normalize_background_pixels is None:
+            normalize_background_pixels = bool(k2)
+        return pld_order, pca_components, pld_aperture_mask, normalize_background_pixels
+
+    def create_design_matrix(self, pld_order=3, pca_components=16, pld_aperture_mask=None,
+                             background_aperture_mask="background", spline_n_knots=None, spline_degree=3,
+                             normalize_background_pixels=None, sparse=False, device=0):
+        """DesignMatrixCollection [pixel_series | background | spline] built on the GPU (one cutout = a batch of 1)."""
+        if sparse:
+            raise NotImplementedError("sparse design matrices are densified on the HIP path; pass sparse=False")
+        if pca_components is None or pca_components < 1:
+            raise NotImplementedError("pca_components must be >= 1 on the HIP path")
+        if pld_aperture_mask is None:
+            pld_aperture_mask = "empty"
+        self.pld_aperture_mask = self.tpf._parse_aperture_mask(pld_aperture_mask)
+        self.background_aperture_mask = self.tpf._parse_aperture_mask(background_aperture_mask)
+        n = len(self.lc)
+        if spline_n_knots is None:
+            spline_n_knots = int(n / 50)
+        if normalize_background_pixels is None:
+            normalize_background_pixels = False
+        cube = self.tpf.flux
+        pld_pix = _finite_columns(cube[:, self.pld_aperture_mask].reshape(n, -1))
+        bkg_pix = _finite_columns(cube[:, self.background_aperture_mask].reshape(n, -1))
+        knots = _percentile_knots(self.lc.time, spline_n_knots, spline_degree)
+        X, ps = _capi.pld_design_batch(pld_pix[None] if pld_pix.shape[1] else None, bkg_pix[None],
+                                       self.lc._flux_f32[None], self.lc.time[None], knots[None], pld_order,
+                                       pca_components, spline_degree, normalize_background_pixels, device=device)
+        X, ps = X[0], ps[0]
+        nsp = spline_n_knots + 1
+        kb = min(pca_components, bkg_pix.shape[1])
+        npld = X.shape[1] - nsp - kb
+        mats = []
+        if npld > 0:
+            mats.append(DesignMatrix(X[:, :npld], name="pixel_series", prior_sigma=ps[:npld]))
+        mats.append(DesignMatrix(X[:, npld:npld + kb], name="background", prior_sigma=ps[npld:npld + kb]))
+        mats.append(DesignMatrix(X[:, npld + kb:], name="spline", prior_sigma=ps[npld + kb:],
+                                 columns=["knot{}".format(i + 1) for i in range(spline_n_knots)] + ["offset"]))
+        return DesignMatrixCollection(mats)
+
+    def correct(self, pld_order=None, pca_components=None, pld_aperture_mask=None,
+                background_aperture_mask="background", spline_n_knots=None, spline_degree=5,
+                normalize_background_pixels=None, restore_trend=True, sparse=False, cadence_mask=None, sigma=5,
+                niters=5, propagate_errors=False, device=0):
+        """Same contract and defaults as the reference (pldcorrector.py:304-427)."""
+        self.restore_trend = restore_trend
+        pld_order, pca_components, pld_aperture_mask, normalize_background_pixels = self._resolve(
+            pld_order, pca_components, pld_aperture_mask, normalize_background_pixels)
+        dm = self.create_design_matrix(pld_aperture_mask=pld_aperture_mask,
+                                       background_aperture_mask=background_aperture_mask, pld_order=pld_order,
+                                       pca_components=pca_components, spline_n_knots=spline_n_knots,
+                                       spline_degree=spline_degree,
+                                       normalize_background_pixels=normalize_background_pixels, sparse=sparse,
+                                       device=device)
+        clc = super().correct(dm, cadence_mask=cadence_mask, sigma=sigma, niters=niters,
+                              propagate_errors=propagate_errors, device=device)
+        if restore_trend:
+            sp = self.diagnostic_lightcurves["spline"].flux
+            clc.flux = clc.flux + (sp - np.median(sp))
+        return clc
+
+
+def pld_correct_batch(cubes, aperture_mask="all", pld_aperture_mask="all", background_aperture_mask="all",
+                      pld_order=3, pca_components=16, spline_n_knots=None, spline_degree=5,
+                      normalize_background_pixels=True, restore_trend=True, sigma=5, niters=5, device=0):
+    """PLDCorrector(...).correct(...) for a list of same-shaped cutouts in two GPU calls (design + regression).
+    Masks are given once and shared by the batch.  Returns (corrected_flux[B, N], outlier_mask[B, N])."""
+    cors = [PLDCorrector(c, aperture_mask=aperture_mask) for c in cubes]
+    n = len(cors[0].lc)
+    if any(len(c.lc) != n for c in cors):
+        raise ValueError("pld_correct_batch needs cutouts with the same number of valid cadences")
+    pm = cors[0].tpf._parse_aperture_mask(pld_aperture_mask)
+    bm = cors[0].tpf._parse_aperture_mask(background_aperture_mask)
+    if spline_n_knots is None:
+        spline_n_knots = int(n / 50)
+    pld = np.stack([c.tpf.flux[:, pm].reshape(n, -1) for c in cors]).astype(np.float32)
+    bkg = np.stack([c.tpf.flux[:, bm].reshape(n, -1) for c in cors]).astype(np.float32)
+    if not (np.all(np.isfinite(pld)) and np.all(np.isfinite(bkg))):
+        raise ValueError("pld_correct_batch needs finite pixels inside the masks")
+    lcf = np.stack([c.lc._flux_f32 for c in cors])
+    t = np.stack([c.lc.time for c in cors])
+    knots = np.stack([_percentile_knots(c.lc.time, spline_n_knots, spline_degree) for c in cors])
+    X, ps = _capi.pld_design_batch(pld if pld.shape[2] else None, bkg, lcf, t, knots, pld_order, pca_components,
+                                   spline_degree, normalize_background_pixels, device=device)
+    B, _, K = X.shape
+    y = np.concatenate([c.lc.flux for c in cors])
+    err = np.concatenate([c.lc.flux_err for c in cors])
+    off = np.arange(B + 1, dtype=np.int64) * n
+    res = _capi.regress_batch(X.reshape(B * n, K), y, off, err=err, prior_mu=np.zeros((B, K)), prior_sigma=ps,
+                              sigma=sigma, niters=niters, device=device)
+    corrected = (y - res["model"]).reshape(B, n)
+    if restore_trend:
+        nsp = spline_n_knots + 1
+        sp = np.einsum("bnk,bk->bn", X[:, :, K - nsp:], res["coefficients"][:, K - nsp:])
+        corrected = corrected + sp - np.median(sp, axis=1)[:, None]
+    return corrected, res["outlier_mask"].reshape(B, n)

@@ -290,4 +290,51 @@ int lk_savgol_trend_batch(lk_handle *h, int B, const int64_t *n_off, const doubl
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ PLD design matrix
+int lk_pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_knots) {
+    return lk::pld_design_width(P, Pb, pld_order, pca_components, n_knots);
+}
+
+int lk_pld_design_batch_dev(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
+                            const float *lc_flux, const double *time, const double *knots, int n_inner, int pld_order,
+                            int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,
+                            double *prior_sigma, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::pld_design_launch(h, B, N, P, Pb, pld_pix, bkg_pix, lc_flux, time, knots, n_inner, pld_order,
+                                 pca_components, n_knots, spline_degree, normalize_bkg, K, X, prior_sigma,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int lk_pld_design_batch(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
+                        const float *lc_flux, const double *time, const double *knots, int n_inner, int pld_order,
+                        int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,
+                        double *prior_sigma) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 1 && N >= 2 && P >= 0 && Pb >= 1 && K >= 1, "bad shapes");
+    LK_REQUIRE(bkg_pix && lc_flux && time && knots && X && prior_sigma, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t bn = (size_t)B * N;
+    const size_t pb = bn * P * 4, bb = bn * Pb * 4, lb = bn * 4, tb = bn * 8, kb = (size_t)B * (n_inner + 2) * 8;
+    const size_t xb = bn * K * 8, sb = (size_t)B * K * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(pb + bb + lb + tb + kb + xb + sb + 8 * 256 + 4096);
+    if (rc) return rc;
+    float *dp = (P > 0 && pld_pix) ? (float *)h->staging.alloc(pb) : nullptr;
+    float *db = (float *)h->staging.alloc(bb), *dl = (float *)h->staging.alloc(lb);
+    double *dt = (double *)h->staging.alloc(tb), *dk = (double *)h->staging.alloc(kb);
+    double *dX = (double *)h->staging.alloc(xb), *ds = (double *)h->staging.alloc(sb);
+    if (dp) LK_HIP_CHECK(hipMemcpy(dp, pld_pix, pb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(db, bkg_pix, bb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dl, lc_flux, lb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dt, time, tb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dk, knots, kb, hipMemcpyHostToDevice));
+    rc = lk::pld_design_launch(h, B, N, dp ? P : 0, Pb, dp, db, dl, dt, dk, n_inner, pld_order, pca_components, n_knots,
+                               spline_degree, normalize_bkg, K, dX, ds, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(X, dX, xb, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(prior_sigma, ds, sb, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 }  // extern "C"

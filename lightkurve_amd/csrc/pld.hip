@@ -1,0 +1,586 @@
+// pld.hip — PLDCorrector.create_design_matrix on gfx950 (reference: src/lightkurve/correctors/pldcorrector.py:186-287,
+// DesignMatrix.pca correctors/designmatrix.py:252-282, create_spline_matrix :952-997).
+//
+// For a batch of B same-shaped cutouts (N cadences, P PLD pixels, Pb background pixels) build
+//     X = [ pld_order_1 | ... | pld_order_o | background | spline | 1 ]      (N x K, float64)
+// where every PLD/background block is the PCA (top-k left singular vectors of the column-centred matrix) of
+//   order 1: pixel flux / SAP flux;  order n: all n-fold products of the order-1 components;  background pixels.
+//
+// PCA = Gram + eigen: C = A^T A on the fp64 matrix cores (gram_mfma_kernel, the "MFMA A^T A" of config[4]), the
+// top-k eigenpairs of C by blocked subspace iteration with Rayleigh-Ritz and SVQB orthonormalisation (small
+// l x l eigenproblems by parallel cyclic Jacobi in LDS; for P <= 64 the Jacobi runs on C itself), then
+// U = A V diag(lambda)^-1/2 written straight into X.  The reference uses fbpca (randomised range finder, 10 power
+// iterations, 2 oversampling columns, unseeded RNG => not reproducible); the oracle uses an exact SVD; the
+// subspace iteration here converges the residual ||C r - theta r|| to 1e-13 theta_max, i.e. to the exact
+// answer wherever the spectrum has a gap.  PCA bases are only defined up to rotation inside a block and the
+// regression is invariant to it, so parity is stated on the corrected flux.
+// The order-1 block skips the reference's redundant re-PCA of an already orthonormal basis (same subspace).
+#include <vector>
+
+#include "block_select.hpp"
+#include "lk_common.hpp"
+
+namespace lk {
+
+constexpr int PLD_LMAX = 64;  // largest small eigenproblem kept in LDS
+
+static int ncombos(int k, int order) {  // C(k + order - 1, order)
+    long long r = 1;
+    for (int i = 1; i <= order; ++i) r = r * (k + i - 1) / i;
+    return (int)r;
+}
+
+int pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_knots) {
+    int K = 0;
+    if (P > 0 && pld_order > 0) {
+        const int k1 = std::min(pca_components, P);
+        for (int o = 1; o <= pld_order; ++o) K += std::min(pca_components, ncombos(k1, o));
+    }
+    K += std::min(pca_components, Pb);
+    return K + n_knots + 1;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+// out[b][n][p] = (double)( pix[b][n][p] / div[b][n] ) with the division in float32 like numpy's float32 / float32;
+// div = SAP flux (PLD pixels) or the float32 row sum of the background pixels (normalize) or 1.
+__global__ void pld_ratio_kernel(const float *__restrict__ pix, const float *__restrict__ lc, int mode, int N, int P,
+                                 double *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.y + threadIdx.y;
+    if (n >= N) return;
+    const float *row = pix + ((size_t)b * N + n) * P;
+    float d = 1.0f;
+    if (mode == 1) d = lc[(size_t)b * N + n];
+    if (mode == 2) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) {
+            const float v = row[p];
+            if (v == v) s += (double)v;
+        }
+        d = (float)s;  // np.nansum over float32 pixels (rounded once instead of pairwise: <= 1 ulp(f32) apart)
+    }
+    for (int p = threadIdx.x; p < P; p += blockDim.x)
+        out[((size_t)b * N + n) * P + p] = (double)(mode == 0 ? row[p] : row[p] / d);
+}
+
+// column means of A_b (N x P) subtracted in place; one workgroup per (column tile, b)
+__global__ __launch_bounds__(256) void pld_center_kernel(double *__restrict__ A, int N, int P) {
+    __shared__ double sh[8][33];
+    const int b = blockIdx.y, c0 = blockIdx.x * 32;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    double *Ab = A + (size_t)b * N * P;
+    const int c = c0 + cx;
+    double s = 0.0;
+    if (c < P)
+        for (int n = ry; n < N; n += 8) s += Ab[(size_t)n * P + c];
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0) {
+        double t = 0.0;
+        for (int r = 0; r < 8; ++r) t += sh[r][cx];
+        sh[0][cx] = t / (double)N;
+    }
+    __syncthreads();
+    const double mean = sh[0][cx];
+    if (c < P)
+        for (int n = ry; n < N; n += 8) Ab[(size_t)n * P + c] -= mean;
+}
+
+// all `order`-fold products (combinations with replacement, lexicographic) of the k columns of U (ldu = ldx)
+__global__ void pld_products_kernel(const double *__restrict__ X, int ldx, int col0, int k, int order, int N, int Pc,
+                                    double *__restrict__ out) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x;
+    const double *u = X + ((size_t)b * N + n) * ldx + col0;
+    double *o = out + ((size_t)b * N + n) * Pc;
+    // thread t handles combos t, t + blockDim, ...: unrank the combination index
+    for (int idx = threadIdx.x; idx < Pc; idx += blockDim.x) {
+        int rem = idx, lo = 0;
+        double prod = 1.0;
+        for (int pos = 0; pos < order; ++pos) {
+            // choose the smallest a >= lo such that the number of combos starting with a' < a is <= rem
+            for (int a = lo; a < k; ++a) {
+                // combos of the remaining (order - pos - 1) slots from values >= a: C(k - a + r - 1, r)
+                const int r = order - pos - 1;
+                long long cnt = 1;
+                for (int i = 1; i <= r; ++i) cnt = cnt * (k - a + i - 1) / i;
+                if (rem < cnt) {
+                    prod *= u[a];
+                    lo = a;
+                    break;
+                }
+                rem -= (int)cnt;
+            }
+        }
+        o[idx] = prod;
+    }
+}
+
+// prior_sigma blocks: 10 * nanstd(lc float32) (np.nanstd of a float32 array -> float32), / pca for the PLD blocks
+__global__ __launch_bounds__(256) void pld_prior_kernel(const float *__restrict__ lc, int N, int K, int n_pld_cols,
+                                                         int pca, double *__restrict__ prior_sigma) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *f = lc + (size_t)b * N;
+    double s = 0.0;
+    long long c = 0;
+    for (int i = tid; i < N; i += 256)
+        if (f[i] == f[i]) {
+            s += (double)f[i];
+            ++c;
+        }
+    const long long cnt = block_count_dyn(c, reinterpret_cast<long long *>(sh));
+    const double mean = block_sum_dyn(s, sh) / (double)cnt;
+    s = 0.0;
+    for (int i = tid; i < N; i += 256)
+        if (f[i] == f[i]) {
+            const double d = (double)f[i] - mean;
+            s = fma(d, d, s);
+        }
+    const double sd = (double)(float)sqrt(block_sum_dyn(s, sh) / (double)cnt) * 10.0;
+    for (int j = tid; j < K; j += 256) prior_sigma[(size_t)b * K + j] = j < n_pld_cols ? sd / (double)pca : sd;
+}
+
+// clamped B-spline basis (patsy bs(x, df, degree, include_intercept=True)) + constant column
+__global__ void pld_spline_kernel(const double *__restrict__ time, const double *__restrict__ knots, int n_inner,
+                                  int degree, int N, int ldx, int col0, double *__restrict__ X) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double *t = time + (size_t)b * N;
+    const double *kn = knots + (size_t)b * (n_inner + 2);  // [lo, inner..., hi]
+    const double x = t[n], lo = kn[0], hi = kn[n_inner + 1];
+    const int order = degree + 1, nb = n_inner + order;
+    auto T = [&](int i) -> double {  // full knot vector: order copies of lo, inner, order copies of hi
+        if (i < order) return lo;
+        if (i >= order + n_inner) return hi;
+        return kn[1 + i - order];
+    };
+    double *row = X + ((size_t)b * N + n) * ldx + col0;
+    for (int j = 0; j <= nb; ++j) row[j] = j == nb ? 1.0 : 0.0;
+    // knot span: largest mu with T(mu) <= x < T(mu+1), the right end belongs to the last non-empty span
+    int mu = order - 1;
+    const int last = order + n_inner - 1;
+    while (mu < last && !(x < T(mu + 1))) ++mu;
+    while (mu > order - 1 && T(mu) == T(mu + 1)) --mu;  // skip empty spans at repeated interior knots
+    double Nv[8] = {1.0, 0, 0, 0, 0, 0, 0, 0}, left[8], right[8];
+    for (int j = 1; j <= degree; ++j) {
+        left[j] = x - T(mu + 1 - j);
+        right[j] = T(mu + j) - x;
+        double saved = 0.0;
+        for (int r = 0; r < j; ++r) {
+            const double den = right[r + 1] + left[j - r];
+            const double tmp = den != 0.0 ? Nv[r] / den : 0.0;
+            Nv[r] = saved + right[r + 1] * tmp;
+            saved = left[j - r] * tmp;
+        }
+        Nv[j] = saved;
+    }
+    for (int j = 0; j <= degree; ++j) {
+        const int c = mu - degree + j;
+        if (c >= 0 && c < nb) row[c] = Nv[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small eigenproblems
+// Parallel cyclic Jacobi on a symmetric n x n matrix M (LDS, leading dim ld, n even); W <- eigenvectors (columns),
+// diag(M) <- eigenvalues.  All threads of the workgroup participate.  rot: n/2 x 4 doubles of LDS scratch.
+__device__ void jacobi_eig_lds(double *M, double *W, int n, int ld, double *rot, double *shred) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < n * n; e += nt) W[(e / n) * ld + (e % n)] = (e / n == e % n) ? 1.0 : 0.0;
+    __syncthreads();
+    const int half = n >> 1;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        // convergence: off-diagonal mass vs diagonal mass
+        double off = 0.0, dia = 0.0;
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e % n;
+            const double v = M[i * ld + j];
+            if (i == j)
+                dia = fma(v, v, dia);
+            else
+                off = fma(v, v, off);
+        }
+        const double offs = block_sum_dyn(off, shred), dias = block_sum_dyn(dia, shred);
+        if (offs <= 1e-30 * dias || offs == 0.0) break;
+        for (int r = 0; r < n - 1; ++r) {
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) {
+                    p = n - 1;
+                    q = r;
+                } else {
+                    p = (r + tid) % (n - 1);
+                    q = (r - tid + n - 1) % (n - 1);
+                }
+                if (p > q) {
+                    const int t0 = p;
+                    p = q;
+                    q = t0;
+                }
+                const double app = M[p * ld + p], aqq = M[q * ld + q], apq = M[p * ld + q];
+                double c = 1.0, s = 0.0;
+                if (fabs(apq) > 1e-300) {
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    s = t * c;
+                }
+                rot[tid * 4 + 0] = (double)p;
+                rot[tid * 4 + 1] = (double)q;
+                rot[tid * 4 + 2] = c;
+                rot[tid * 4 + 3] = s;
+            }
+            __syncthreads();
+            // rows: M <- J^T M
+            for (int e = tid; e < half * n; e += nt) {
+                const int pr = e / n, j = e % n;
+                const int p = (int)rot[pr * 4], q = (int)rot[pr * 4 + 1];
+                const double c = rot[pr * 4 + 2], s = rot[pr * 4 + 3];
+                const double mp = M[p * ld + j], mq = M[q * ld + j];
+                M[p * ld + j] = c * mp - s * mq;
+                M[q * ld + j] = s * mp + c * mq;
+            }
+            __syncthreads();
+            // columns: M <- M J, W <- W J
+            for (int e = tid; e < half * n; e += nt) {
+                const int pr = e / n, i = e % n;
+                const int p = (int)rot[pr * 4], q = (int)rot[pr * 4 + 1];
+                const double c = rot[pr * 4 + 2], s = rot[pr * 4 + 3];
+                const double mp = M[i * ld + p], mq = M[i * ld + q];
+                M[i * ld + p] = c * mp - s * mq;
+                M[i * ld + q] = s * mp + c * mq;
+                const double wp = W[i * ld + p], wq = W[i * ld + q];
+                W[i * ld + p] = c * wp - s * wq;
+                W[i * ld + q] = s * wp + c * wq;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// order[j] = index of the j-th largest diagonal entry of M (n <= 64); ties by index
+__device__ void sort_desc_lds(const double *M, int n, int ld, int *order) {
+    const int tid = threadIdx.x;
+    if (tid < n) {
+        const double v = M[tid * ld + tid];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double u = M[j * ld + j];
+            rank += (u > v || (u == v && j < tid)) ? 1 : 0;
+        }
+        order[rank] = tid;
+    }
+    __syncthreads();
+}
+
+// element (i, j) of the symmetric Gram matrix stored as upper 64x64 blocks with leading dimension ldg
+__device__ __forceinline__ double gsym(const double *__restrict__ G, int ldg, int i, int j) {
+    return (j >= i || (j >> 6) == (i >> 6)) ? G[(size_t)i * ldg + j] : G[(size_t)j * ldg + i];
+}
+
+// Top-k eigenpairs of the P x P Gram matrix of matrix b -> V (P x k, row-major), lam (k).  One workgroup per matrix.
+// scratch per matrix: 4 * P * l doubles (Q, Z, R, Y).
+__global__ __launch_bounds__(1024) void pld_topk_eig_kernel(const double *__restrict__ G, int ldg, int P, int k, int l,
+                                                             double *__restrict__ scratch, double *__restrict__ V,
+                                                             double *__restrict__ lam, int *__restrict__ iters_out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    const double *Gb = G + (size_t)b * ldg * ldg;
+    double *Vb = V + (size_t)b * P * k, *lamb = lam + (size_t)b * k;
+    const int ld = l + 1;                      // odd leading dimension: conflict-free column walks
+    double *T = lds;                           // l x ld
+    double *W = T + l * ld;                    // l x ld
+    double *rot = W + l * ld;                  // (l/2) x 4
+    double *shred = rot + 2 * l;               // nt doubles
+    double *vec = shred + nt;                  // 2 * l  (norms / theta)
+    int *order = reinterpret_cast<int *>(vec + 2 * l);  // l ints
+
+    if (P <= l) {
+        // ---- direct: Jacobi on C itself (l = P rounded up to even; the pad row/col is zero)
+        for (int e = tid; e < l * l; e += nt) {
+            const int i = e / l, j = e % l;
+            T[i * ld + j] = (i < P && j < P) ? gsym(Gb, ldg, i, j) : 0.0;
+        }
+        __syncthreads();
+        jacobi_eig_lds(T, W, l, ld, rot, shred);
+        if (tid < l && tid >= P) T[tid * ld + tid] = -1.0;  // pad eigenvalue sorts last
+        __syncthreads();
+        sort_desc_lds(T, l, ld, order);
+        for (int e = tid; e < P * k; e += nt) {
+            const int i = e / k, a = e % k;
+            Vb[e] = W[i * ld + order[a]];
+        }
+        if (tid < k) lamb[tid] = T[order[tid] * ld + order[tid]];
+        if (tid == 0 && iters_out) iters_out[b] = 0;
+        return;
+    }
+
+    double *Q = scratch + (size_t)b * 4 * P * l, *Z = Q + (size_t)P * l, *R = Z + (size_t)P * l, *Y = R + (size_t)P * l;
+    // SVQB orthonormalisation of the P x l matrix Y (in place): unit-scale columns, eig of the l x l Gram, Y S Phi^-1/2
+    auto svqb = [&](double *Y, double *tmp) {
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int a = tid; a < l; a += nt) vec[a] = 0.0;
+            __syncthreads();
+            // G = Y^T Y (thread per (a, b) entry)
+            for (int e = tid; e < l * l; e += nt) {
+                const int a = e / l, c = e % l;
+                double s = 0.0;
+                if (c >= a)
+                    for (int i = 0; i < P; ++i) s = fma(Y[(size_t)i * l + a], Y[(size_t)i * l + c], s);
+                T[a * ld + c] = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < l * l; e += nt) {
+                const int a = e / l, c = e % l;
+                if (c < a) T[a * ld + c] = T[c * ld + a];
+            }
+            __syncthreads();
+            if (tid < l) vec[tid] = T[tid * ld + tid] > 0.0 ? 1.0 / sqrt(T[tid * ld + tid]) : 0.0;
+            __syncthreads();
+            for (int e = tid; e < l * l; e += nt) {
+                const int a = e / l, c = e % l;
+                T[a * ld + c] *= vec[a] * vec[c];
+            }
+            __syncthreads();
+            jacobi_eig_lds(T, W, l, ld, rot, shred);
+            double mx = 0.0;
+            for (int a = 0; a < l; ++a) mx = fmax(mx, T[a * ld + a]);
+            if (tid < l) {
+                const double ph = fmax(T[tid * ld + tid], 1e-15 * mx);
+                vec[l + tid] = 1.0 / sqrt(ph);
+            }
+            __syncthreads();
+            // tmp = Y diag(vec) W diag(vec2); then copy back
+            for (int e = tid; e < P * l; e += nt) {
+                const int i = e / l, c = e % l;
+                double s = 0.0;
+                for (int a = 0; a < l; ++a) s = fma(Y[(size_t)i * l + a] * vec[a], W[a * ld + c], s);
+                tmp[e] = s * vec[l + c];
+            }
+            __syncthreads();
+            for (int e = tid; e < P * l; e += nt) Y[e] = tmp[e];
+            __syncthreads();
+        }
+    };
+
+    // deterministic pseudo-random start
+    for (int e = tid; e < P * l; e += nt) {
+        unsigned int x = (unsigned int)(e + 1) * 2654435761u;
+        x ^= x >> 15;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        Q[e] = (double)(x & 0xffffffu) / 8388608.0 - 1.0;
+    }
+    __syncthreads();
+    svqb(Q, R);
+    int it = 0;
+    for (; it < 400; ++it) {
+        // Z = C Q
+        for (int e = tid; e < P * l; e += nt) {
+            const int i = e / l, a = e % l;
+            double s = 0.0;
+            for (int j = 0; j < P; ++j) s = fma(gsym(Gb, ldg, i, j), Q[(size_t)j * l + a], s);
+            Z[e] = s;
+        }
+        __syncthreads();
+        // T = Q^T Z (symmetrised)
+        for (int e = tid; e < l * l; e += nt) {
+            const int a = e / l, c = e % l;
+            double s = 0.0;
+            for (int i = 0; i < P; ++i) s = fma(Q[(size_t)i * l + a], Z[(size_t)i * l + c], s);
+            W[a * ld + c] = s;
+        }
+        __syncthreads();
+        for (int e = tid; e < l * l; e += nt) {
+            const int a = e / l, c = e % l;
+            T[a * ld + c] = 0.5 * (W[a * ld + c] + W[c * ld + a]);
+        }
+        __syncthreads();
+        jacobi_eig_lds(T, W, l, ld, rot, shred);
+        sort_desc_lds(T, l, ld, order);
+        // R = Q W (Ritz vectors, sorted by Ritz value), Y = Z W = C R
+        for (int e = tid; e < P * l; e += nt) {
+            const int i = e / l, c = e % l;
+            const int oc = order[c];
+            double s = 0.0, y = 0.0;
+            for (int a = 0; a < l; ++a) {
+                const double w = W[a * ld + oc];
+                s = fma(Q[(size_t)i * l + a], w, s);
+                y = fma(Z[(size_t)i * l + a], w, y);
+            }
+            R[e] = s;
+            Y[e] = y;
+        }
+        __syncthreads();
+        // residual of the k wanted pairs: || C r - theta r ||
+        double part = 0.0;
+        for (int e = tid; e < P * k; e += nt) {
+            const int i = e / k, c = e % k;
+            const double th = T[order[c] * ld + order[c]];
+            const double d = Y[(size_t)i * l + c] - th * R[(size_t)i * l + c];
+            part = fma(d, d, part);
+        }
+        const double res = sqrt(block_sum_dyn(part, shred));
+        const double th0 = fabs(T[order[0] * ld + order[0]]);
+        if (res <= 1e-13 * th0 * sqrt((double)k)) break;
+        // next basis: orthonormalised C R
+        for (int e = tid; e < P * l; e += nt) Q[e] = Y[e];
+        __syncthreads();
+        svqb(Q, Z);
+    }
+    for (int e = tid; e < P * k; e += nt) {
+        const int i = e / k, a = e % k;
+        Vb[e] = R[(size_t)i * l + a];
+    }
+    if (tid < k) lamb[tid] = T[order[tid] * ld + order[tid]];
+    if (tid == 0 && iters_out) iters_out[b] = it;
+}
+
+// U = A V diag(lam)^-1/2 into X[:, col0 : col0 + k]
+__global__ __launch_bounds__(256) void pld_project_kernel(const double *__restrict__ A, const double *__restrict__ V,
+                                                           const double *__restrict__ lam, int N, int P, int k, int ldx,
+                                                           int col0, double *__restrict__ X) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const double *row = A + ((size_t)b * N + n) * P;
+    const double *Vb = V + (size_t)b * P * k;
+    for (int a0 = 0; a0 < k; a0 += 4) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int p = lane; p < P; p += 64) {
+            const double r = row[p];
+            const double *v = Vb + (size_t)p * k + a0;
+            s0 = fma(r, v[0], s0);
+            if (a0 + 1 < k) s1 = fma(r, v[1], s1);
+            if (a0 + 2 < k) s2 = fma(r, v[2], s2);
+            if (a0 + 3 < k) s3 = fma(r, v[3], s3);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_down(s0, off);
+            s1 += __shfl_down(s1, off);
+            s2 += __shfl_down(s2, off);
+            s3 += __shfl_down(s3, off);
+        }
+        if (lane == 0) {
+            double *x = X + ((size_t)b * N + n) * ldx + col0 + a0;
+            const double *lb = lam + (size_t)b * k + a0;
+            x[0] = s0 / sqrt(fmax(lb[0], 1e-300));
+            if (a0 + 1 < k) x[1] = s1 / sqrt(fmax(lb[1], 1e-300));
+            if (a0 + 2 < k) x[2] = s2 / sqrt(fmax(lb[2], 1e-300));
+            if (a0 + 3 < k) x[3] = s3 / sqrt(fmax(lb[3], 1e-300));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+// PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
+static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
+                     int col0, hipStream_t stream, Arena &ws) {
+    hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
+    const int KB = (P + 63) / 64, ldg = KB * 64;
+    double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
+    if (!G) {
+        set_error("PLD workspace exhausted (Gram)");
+        return LK_ENOMEM;
+    }
+    gram_plain_launch(A, d_off, B, P, G, stream);
+    int l;
+    if (P <= PLD_LMAX) {
+        l = (P + 1) & ~1;
+    } else {
+        l = std::min(PLD_LMAX, (k + 16 + 1) & ~1);
+    }
+    double *scr = nullptr;
+    if (P > l) {
+        scr = (double *)ws.alloc((size_t)B * 4 * P * l * 8);
+        if (!scr) {
+            set_error("PLD workspace exhausted (subspace)");
+            return LK_ENOMEM;
+        }
+    }
+    double *V = (double *)ws.alloc((size_t)B * P * k * 8), *lam = (double *)ws.alloc((size_t)B * k * 8);
+    if (!V || !lam) {
+        set_error("PLD workspace exhausted (V)");
+        return LK_ENOMEM;
+    }
+    const int ld = l + 1;
+    const size_t lds = ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l) * 8 + (size_t)l * 4 + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, scr, V, lam,
+                       (int *)nullptr);
+    hipLaunchKernelGGL(pld_project_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, A, V, lam, N, P, k, ldx, col0, X);
+    return LK_OK;
+}
+
+int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
+                      const float *lc_flux, const double *time, const double *knots, int n_inner, int pld_order,
+                      int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,
+                      double *prior_sigma, hipStream_t stream) {
+    LK_REQUIRE(B >= 1 && N >= 2, "need B >= 1 cutouts with N >= 2 cadences");
+    LK_REQUIRE(pca_components >= 1, "pca_components must be >= 1 on the HIP path");
+    LK_REQUIRE(pld_order >= 0 && pld_order <= 4, "pld_order outside 0..4");
+    LK_REQUIRE(Pb >= 1 && bkg_pix, "at least one background pixel is required");
+    LK_REQUIRE(spline_degree >= 0 && spline_degree <= 7, "spline_degree outside 0..7");
+    LK_REQUIRE(n_knots == n_inner + spline_degree + 1 && n_inner >= 0, "n_knots must equal n_inner + degree + 1");
+    LK_REQUIRE(K == pld_design_width(P, Pb, pld_order, pca_components, n_knots), "K does not match the design width");
+    LK_REQUIRE(lc_flux && time && knots && X && prior_sigma, "NULL buffer");
+    const int k1 = (P > 0 && pld_order > 0) ? std::min(pca_components, P) : 0;
+    int pmax = std::max(P, Pb);
+    for (int o = 2; o <= pld_order && k1 > 0; ++o) pmax = std::max(pmax, ncombos(k1, o));
+    LK_REQUIRE(pmax <= 4096, "a design block has %d columns before PCA; the HIP path supports up to 4096", pmax);
+    const int lmax = PLD_LMAX;
+    const int ldgmax = ((pmax + 63) / 64) * 64;
+    h->ws.reset();
+    const size_t per = (size_t)N * pmax * 8 + (size_t)ldgmax * ldgmax * 8 + (size_t)4 * pmax * lmax * 8 +
+                       (size_t)pmax * pca_components * 8 + 4096;
+    int rc = h->ws.reserve((size_t)B * per * 2 + (size_t)(B + 1) * 8 + 65536);
+    if (rc) return rc;
+    std::vector<int64_t> off((size_t)B + 1);
+    for (int b = 0; b <= B; ++b) off[b] = (int64_t)b * N;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    LK_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));
+    double *A = (double *)h->ws.alloc((size_t)B * N * pmax * 8);
+    LK_REQUIRE(A != nullptr, "PLD workspace exhausted");
+    int col = 0;
+    const size_t mark = h->ws.used;
+    if (k1 > 0) {
+        LK_REQUIRE(pld_pix != nullptr, "pld_pix is NULL");
+        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 3) / 4, B), dim3(64, 4), 0, stream, pld_pix, lc_flux, 1, N, P, A);
+        rc = pca_block(h, A, B, N, P, k1, d_off, X, K, col, stream, h->ws);
+        if (rc) return rc;
+        const int col1 = col;
+        col += k1;
+        for (int o = 2; o <= pld_order; ++o) {
+            h->ws.used = mark;  // the previous block's Gram / subspace scratch is dead once its kernels are enqueued
+            const int Pc = ncombos(k1, o), ko = std::min(pca_components, Pc);
+            hipLaunchKernelGGL(pld_products_kernel, dim3(N, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc, A);
+            rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws);
+            if (rc) return rc;
+            col += ko;
+        }
+    }
+    const int n_pld_cols = col;
+    h->ws.used = mark;
+    hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 3) / 4, B), dim3(64, 4), 0, stream, bkg_pix, lc_flux,
+                       normalize_bkg ? 2 : 0, N, Pb, A);
+    const int kb = std::min(pca_components, Pb);
+    rc = pca_block(h, A, B, N, Pb, kb, d_off, X, K, col, stream, h->ws);
+    if (rc) return rc;
+    col += kb;
+    hipLaunchKernelGGL(pld_spline_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, time, knots, n_inner,
+                       spline_degree, N, K, col, X);
+    hipLaunchKernelGGL(pld_prior_kernel, dim3(B), dim3(256), 0, stream, lc_flux, N, K, n_pld_cols, pca_components,
+                       prior_sigma);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+}  // namespace lk

@@ -27,7 +27,7 @@ constexpr int GR_LD = 80;     // LDS row stride in doubles (== 32 dwords mod 64:
 __device__ __forceinline__ double aug(const double *__restrict__ X, const double *__restrict__ y, int K, int64_t n,
                                       int c) {
     if (c < K) return X[n * K + c];
-    return c == K ? y[n] : 0.0;
+    return (c == K && y) ? y[n] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict__ X, const double *__restrict__ y,
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
     const int64_t lo = n_off[target];
     const int n = (int)(n_off[target + 1] - lo);
     X += lo * K;
-    y += lo;
-    const int Kp = KB * GR_BLK, Ka = K + 1;
+    if (y) y += lo;
+    const int Kp = KB * GR_BLK, Ka = K + (y ? 1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;  // wave owns the 32x32 sub-block (wi, wj): 2x2 MFMA tiles
     const int i0 = bi * GR_BLK, j0 = bj * GR_BLK;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
             double va = 0.0, vb = 0.0;
             if (nn < n) {
                 const int64_t g = lo + nn;
-                const bool use = (!cmask || cmask[g]) && !outl[g];
+                const bool use = (!cmask || cmask[g]) && !(outl && outl[g]);
                 double w = 0.0;
                 if (use) {
                     const double s = err ? err[g] : 1.0;
@@ -298,6 +298,14 @@ __global__ __launch_bounds__(1024) void demedian_kernel(const int64_t *__restric
     auto keep = [&](int) { return true; };
     const double med = block_median(n, (long long)n, val, keep, sh);
     for (int i = tid; i < n; i += 1024) model[i] -= med;
+}
+
+// plain Gram matrices G_b = A_b^T A_b of B row-major (N_b x K) blocks (no weights, no masks), for PCA (pld.hip)
+int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, double *G, hipStream_t stream) {
+    const int KB = (K + GR_BLK - 1) / GR_BLK;
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3(KB * (KB + 1) / 2, B), dim3(256), 0, stream, A, (const double *)nullptr,
+                       (const double *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, d_off, K, KB, G);
+    return KB * GR_BLK;  // leading dimension of each G_b
 }
 
 int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
