@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--chunks", type=int, default=4, help="target chunks per step (comm/compute overlap)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of spectra for N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ls", choices=["ls", "bls"])
+    ap.add_argument("--workload", default="ls", choices=["ls", "bls", "pld", "flatten"])
+    ap.add_argument("--cutouts", type=int, default=500, help="PLD: cutouts per GPU")
+    ap.add_argument("--pld-cadences", type=int, default=3500)
     ap.add_argument("--periods", type=int, default=50000)
     ap.add_argument("--durations", type=int, default=200)
     return ap.parse_args()
@@ -120,6 +122,36 @@ def cpu_baseline_bls(args):
                       % (args.durations, args.cadences)}
 
 
+def cpu_baseline_pld(args):
+    """numpy/LAPACK port of PLDCorrector.correct (oracle.np_oracle.pld_correct: exact SVD in place of fbpca), 1 core,
+    2 cutouts of the bench shape."""
+    from lightkurve_amd import synth
+    from oracle import np_oracle as O
+    allm = np.ones((11, 11), bool)
+    t0 = time.perf_counter()
+    n = 2
+    for i in range(n):
+        t, flux, err, _ = synth.pld_cutout(4, i, n=args.pld_cadences, npix=11)
+        O.pld_correct(t, flux, err, allm, allm, allm, pld_order=3, pca_components=16, spline_degree=5)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "cutouts/sec", "cores": 1, "kind": "port",
+            "sample": "%d cutouts 11x11 x %d cadences, order 3, 16 PCA comps, numpy port (LAPACK may thread)"
+                      % (n, args.pld_cadences)}
+
+
+def cpu_baseline_flatten(args):
+    from lightkurve_amd import synth
+    from oracle import np_oracle as O
+    n = 8
+    lcs = [synth.ls_target(6, i, args.cadences) for i in range(n)]
+    t0 = time.perf_counter()
+    for t, y, e, _ in lcs:
+        O.flatten_trend(t, y, 401, 2, 5, 3, 3)
+    dt = time.perf_counter() - t0
+    return {"value": n * args.cadences / dt, "unit": "cadences/sec", "cores": 1, "kind": "port",
+            "sample": "%d light curves x %d cadences, window 401, numpy port of LightCurve.flatten" % (n, args.cadences)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +160,8 @@ def main():
 
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_base = cpu_baseline_ls(args) if args.workload == "ls" else cpu_baseline_bls(args)
+        cpu_base = {"ls": cpu_baseline_ls, "bls": cpu_baseline_bls, "pld": cpu_baseline_pld,
+                    "flatten": cpu_baseline_flatten}[args.workload](args)
 
     import torch
     import torch.distributed as dist
@@ -187,6 +220,77 @@ def main():
         pairs_per_step = float(sum(int(off[b + 1] - off[b]) for b in range(B))) * M
         metric, unit = "frequencies*targets/sec (Lomb-Scargle, exact GLS)", "frequencies*targets/sec"
         workload = ("configs[1]: %d TESS-like %d-cadence targets x %d freqs Lomb-Scargle per GPU" % (B, N, M))
+    elif args.workload == "pld":
+        Bc, Nc, npix = args.cutouts, args.pld_cadences, 11
+        P = npix * npix
+        cubes = [synth.pld_cutout(4, rank * Bc + i, n=Nc, npix=npix) for i in range(Bc)]
+        tt = np.stack([c[0] for c in cubes])
+        pix = np.stack([c[1].reshape(Nc, P) for c in cubes]).astype(np.float32)
+        epx = np.stack([c[2].reshape(Nc, P) for c in cubes]).astype(np.float32)
+        lcf = pix.sum(axis=2, dtype=np.float32)
+        lce = np.sqrt((epx.astype(np.float64) ** 2).sum(axis=2))
+        deg, nkn = 5, Nc // 50
+        n_inner = nkn - deg - 1
+        knots = np.stack([np.concatenate([[t.min()], np.percentile(t, np.linspace(0, 100, n_inner + 2)[1:-1]), [t.max()]])
+                          for t in tt])
+        K = _capi.pld_design_width(P, P, 3, 16, nkn)
+        d_pix, d_lcf, d_t, d_kn = (torch.from_numpy(a).to(dev) for a in (pix, lcf, tt, knots))
+        d_y, d_err = torch.from_numpy(lcf.astype(np.float64).ravel()).to(dev), torch.from_numpy(lce.ravel()).to(dev)
+        d_X = torch.empty((Bc, Nc, K), dtype=torch.float64, device=dev)
+        d_ps = torch.empty((Bc, K), dtype=torch.float64, device=dev)
+        d_mu = torch.zeros((Bc, K), dtype=torch.float64, device=dev)
+        d_w = torch.empty((Bc, K), dtype=torch.float64, device=dev)
+        d_model = torch.empty(Bc * Nc, dtype=torch.float64, device=dev)
+        d_out = torch.empty(Bc * Nc, dtype=torch.uint8, device=dev)
+        offp = np.arange(Bc + 1, dtype=np.int64) * Nc
+        lib = _capi.load_library()
+        import ctypes
+        vp = ctypes.c_void_p
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps + args.warmup)]
+
+        def step(k):
+            e0, e1 = ev[k]
+            e0.record()
+            _capi._check(lib.lk_pld_design_batch_dev(handle._h, Bc, Nc, P, P, vp(d_pix.data_ptr()), vp(d_pix.data_ptr()),
+                                                     vp(d_lcf.data_ptr()), vp(d_t.data_ptr()), vp(d_kn.data_ptr()),
+                                                     n_inner, 3, 16, nkn, deg, 1, K, vp(d_X.data_ptr()),
+                                                     vp(d_ps.data_ptr()), vp(stream)))
+            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), K,
+                                                  vp(d_X.data_ptr()), vp(d_y.data_ptr()), vp(d_err.data_ptr()), None,
+                                                  vp(d_mu.data_ptr()), vp(d_ps.data_ptr()), 5.0, 5, vp(d_w.data_ptr()),
+                                                  vp(d_model.data_ptr()), vp(d_out.data_ptr()), vp(stream)))
+            e1.record()
+
+        units_per_step = Bc
+        gram_cols = [P, 136, 816, P]
+        pairs_per_step = float(Bc) * (2.0 * Nc * sum(c * c for c in gram_cols) + 5 * 2.0 * Nc * (K + 1) ** 2)  # MFMA flop
+        metric, unit = "PLD cutouts/sec (design matrix + regression)", "cutouts/sec"
+        workload = ("configs[4]: %d K2-like 11x11-pixel cutouts x %d cadences, 3rd-order design matrix (K=%d), "
+                    "MFMA Gram per GPU" % (Bc, Nc, K))
+        B, N = Bc, Nc
+    elif args.workload == "flatten":
+        t, y, dy, off = synth.ls_batch(6, B, N, first_index=rank * B)
+        d_t, d_y = torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev)
+        d_tr = torch.empty_like(d_y)
+        lib = _capi.load_library()
+        import ctypes
+        vp = ctypes.c_void_p
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps + args.warmup)]
+
+        def step(k):
+            e0, e1 = ev[k]
+            e0.record()
+            _capi._check(lib.lk_savgol_trend_batch_dev(handle._h, B, off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                       vp(d_t.data_ptr()), vp(d_y.data_ptr()), None, 401, 2, 5.0, 3, 3.0,
+                                                       vp(d_tr.data_ptr()), None, vp(stream)))
+            e1.record()
+
+        units_per_step = int(off[-1])
+        pairs_per_step = float(off[-1])
+        metric, unit = "flatten cadences/sec (window 401, niters 3)", "cadences/sec"
+        workload = "flatten: %d light curves x %d cadences, window 401, polyorder 2, niters 3 per GPU" % (B, N)
     else:
         t, y, dy, off = synth.bls_batch(3, B, N, first_index=rank * B)
         ivar = 1.0 / dy ** 2
@@ -269,6 +373,20 @@ def main():
                         "frac": algo_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_step": algo_bytes},
             }
+        elif args.workload == "pld":
+            ach = pairs_per_step / (kern_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                               "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
+                               "note": "algorithmic 2*N*P^2 flop per PCA Gram (P = 121, 136, 816, 121) + 5 x 2*N*(K+1)^2 "
+                                       "for the regression, over the WHOLE step time (eigen-solver, projections, LU, "
+                                       "clipping included), against the fp64 MFMA dense peak"}
+        elif args.workload == "flatten":
+            algo = 24.0 * pairs_per_step
+            out["roofline"] = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "flatten_kernel", "kernel_ms_per_step": kern_ms,
+                               "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
         else:
             out["roofline"] = {
                 "bound": "valu", "achieved": 12.0 * pairs_per_step / (kern_ms * 1e-3) / 1e12,
