@@ -24,6 +24,9 @@
 
 namespace lk {
 
+typedef int int8_t_v __attribute__((ext_vector_type(8)));
+typedef double double2_v __attribute__((ext_vector_type(2)));
+
 struct CadHot {  // 32 B, read wave-uniformly in the consume loop
     double v;    // sqrt(w_i) * (y_i - ybar)
     double u;    // sqrt(w_i)
@@ -162,8 +165,44 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
 // ------------------------------------------------------------------------------------------------ grid kernel
 constexpr int LS_CHUNK = 16;  // cadences per seed tile
 
+// one cadence folded into the 6 x F sums of a lane: k = 0 from the seed, k = 1 by rotation, k >= 2 by the
+// three-term recurrence; 8 v_fma_f64 per (cadence, frequency) pair
 template <int F>
-__global__ __launch_bounds__(64) void ls_grid_kernel(const CadHot *__restrict__ hot,
+__device__ __forceinline__ void ls_consume(const int8_t_v &hraw, const double2_v &p, double (&Sh)[F], double (&Ch)[F],
+                                           double (&S)[F], double (&C)[F], double (&S2)[F], double (&C2)[F]) {
+    CadHot h;
+    __builtin_memcpy(&h, &hraw, sizeof(h));
+    const double alpha = h.qc + h.qc;
+    double am = p.x, bm = p.y;  // k-1 (starts as k = 0)
+    Sh[0] = fma(h.v, bm, Sh[0]);
+    Ch[0] = fma(h.v, am, Ch[0]);
+    S[0] = fma(h.u, bm, S[0]);
+    C[0] = fma(h.u, am, C[0]);
+    S2[0] = fma(am, bm, S2[0]);
+    C2[0] = fma(am, am, C2[0]);
+    double ac = fma(am, h.qc, -(bm * h.qs));  // k = 1 by rotation
+    double bc = fma(bm, h.qc, am * h.qs);
+#pragma unroll
+    for (int k = 1; k < F; ++k) {
+        Sh[k] = fma(h.v, bc, Sh[k]);
+        Ch[k] = fma(h.v, ac, Ch[k]);
+        S[k] = fma(h.u, bc, S[k]);
+        C[k] = fma(h.u, ac, C[k]);
+        S2[k] = fma(ac, bc, S2[k]);
+        C2[k] = fma(ac, ac, C2[k]);
+        if (k + 1 < F) {
+            const double an = fma(alpha, ac, -am);
+            const double bn = fma(alpha, bc, -bm);
+            am = ac;
+            bm = bc;
+            ac = an;
+            bc = bn;
+        }
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(64, (F <= 10 ? 3 : 2)) void ls_grid_kernel(const CadHot *__restrict__ hot,
                                                       const CadGen *__restrict__ gen,
                                                       const int64_t *__restrict__ n_off,
                                                       const TargetStats *__restrict__ stats, int B, double f0,
@@ -190,6 +229,9 @@ __global__ __launch_bounds__(64) void ls_grid_kernel(const CadHot *__restrict__ 
     for (int k = 0; k < F; ++k) Sh[k] = Ch[k] = S[k] = C[k] = S2[k] = C2[k] = 0.0;
 
     const int gi = lane & 15, gg = lane >> 4;
+    // LDS byte address of seeds[0][lane] for the asm ds_read (address space 3 pointers are 32-bit LDS offsets)
+    const unsigned seed_lane_addr =
+        (unsigned)(size_t)(__attribute__((address_space(3))) char *)(&seeds[0][lane]);
     const double fstart = fma((double)(j0 + (int64_t)(16 * gg) * F), df, f0);
 
     for (int i0 = 0; i0 < n; i0 += LS_CHUNK) {
@@ -216,42 +258,33 @@ __global__ __launch_bounds__(64) void ls_grid_kernel(const CadHot *__restrict__ 
         __syncthreads();
         // ---- consume
         const int ni = min(LS_CHUNK, n - i0);
-        CadHot hn = hot[i0];  // wave-uniform address -> scalar load
-        double2 pn = seeds[0][lane];
-        for (int ii = 0; ii < ni; ++ii) {
-            const CadHot h = hn;
-            const double2 p = pn;
-            // software prefetch of the next cadence (clamped: stays inside this target / this tile)
-            hn = hot[min(i0 + ii + 1, n - 1)];
-            pn = seeds[min(ii + 1, LS_CHUNK - 1)][lane];
-            const double alpha = h.qc + h.qc;
-            double am = p.x, bm = p.y;  // k-1 (starts as k = 0)
-            Sh[0] = fma(h.v, bm, Sh[0]);
-            Ch[0] = fma(h.v, am, Ch[0]);
-            S[0] = fma(h.u, bm, S[0]);
-            C[0] = fma(h.u, am, C[0]);
-            S2[0] = fma(am, bm, S2[0]);
-            C2[0] = fma(am, am, C2[0]);
-            double ac = fma(am, h.qc, -(bm * h.qs));  // k = 1 by rotation
-            double bc = fma(bm, h.qc, am * h.qs);
-#pragma unroll
-            for (int k = 1; k < F; ++k) {
-                Sh[k] = fma(h.v, bc, Sh[k]);
-                Ch[k] = fma(h.v, ac, Ch[k]);
-                S[k] = fma(h.u, bc, S[k]);
-                C[k] = fma(h.u, ac, C[k]);
-                S2[k] = fma(ac, bc, S2[k]);
-                C2[k] = fma(ac, ac, C2[k]);
-                if (k + 1 < F) {
-                    const double an = fma(alpha, ac, -am);
-                    const double bn = fma(alpha, bc, -bm);
-                    am = ac;
-                    bm = bc;
-                    ac = an;
-                    bc = bn;
-                }
-            }
+        // Software prefetch of the next cadence's record (scalar load) and seed (LDS read), hidden from hipcc's own
+        // waitcnt bookkeeping with inline asm (cdna_hip_programming.md §5.7 form (ii): "=s"/"=v" loads, then ONE wait
+        // statement naming every destination "+s"/"+v" before the first consumer).  hipcc otherwise sinks both loads
+        // to the top of the iteration that uses them and stalls ~200 cycles per cadence on s_waitcnt lgkmcnt(0).
+        // Two register sets (A, B) ping-pong over a 2x unrolled loop so that no register copy of an in-flight
+        // destination is ever needed (audited in the .s: no v_mov/s_mov of hA/hB/pA/pB between a load and its wait).
+        int8_t_v hA, hB;
+        double2_v pA, pB;
+#define LS_PREFETCH(H, P, II)                                                                           \
+    {                                                                                                   \
+        const CadHot *hp_ = hot + min(i0 + (II), n - 1); /* clamped: stays inside this target */        \
+        const unsigned la_ = seed_lane_addr + (unsigned)(min((II), LS_CHUNK - 1) * (65 * 16));          \
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(H) : "s"(hp_));                                \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(P) : "v"(la_));                                       \
+        __builtin_amdgcn_sched_barrier(0); /* keep the loads ABOVE the consume body they overlap with */ \
+    }
+        LS_PREFETCH(hA, pA, 0)
+        for (int ii = 0; ii < ni; ii += 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hA), "+v"(pA));
+            LS_PREFETCH(hB, pB, ii + 1)
+            ls_consume<F>(hA, pA, Sh, Ch, S, C, S2, C2);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hB), "+v"(pB));
+            LS_PREFETCH(hA, pA, ii + 2)
+            if (ii + 1 < ni) ls_consume<F>(hB, pB, Sh, Ch, S, C, S2, C2);
         }
+#undef LS_PREFETCH
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hA), "+v"(pA));  // drain the last (clamped) prefetch
         __syncthreads();
     }
 
@@ -350,7 +383,7 @@ int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, c
         CadGen *d_gen = (CadGen *)h->ws.alloc(ntot * sizeof(CadGen));
         int F = LS_F;
         if (const char *e = getenv("LK_LS_F")) F = atoi(e);  // tuning knob (8 | 16); F=32 would need 384 accumulator VGPRs > the 256 a VALU op can address
-        if (F != 8 && F != 16) F = LS_F;
+        if (F != 8 && F != 10 && F != 16) F = LS_F;
         hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, df, F, d_hot,
                            d_gen, (CadAny *)nullptr, d_stats);
         const int tiles = (int)((M + 64 * F - 1) / (64 * F));
@@ -361,6 +394,8 @@ int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, c
                        d_stats, B, f0, df, M, tiles, normalization, fit_mean, scale, power)
         if (F == 8)
             LK_LS_LAUNCH(8);
+        else if (F == 10)
+            LK_LS_LAUNCH(10);
         else
             LK_LS_LAUNCH(16);
 #undef LK_LS_LAUNCH
