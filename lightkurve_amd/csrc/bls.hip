@@ -104,8 +104,8 @@ __device__ __forceinline__ int bin_of_fast(double r, double bin_duration, double
     return bin_of(r, bin_duration);
 }
 
-constexpr int BLS_RMAX = 512;   // most rounds ever kept (4-wave blocks)
-constexpr int BLS_RSEG = 2048;  // ints reserved for the per-round wave boundaries: (NW-1) * (BLS_RSEG/NW)  // round boundaries kept in LDS; more rounds (badly unsorted time) -> serial path
+constexpr int BLS_RMAX = 256;   // most rounds ever kept (4-wave blocks)
+constexpr int BLS_RSEG = 768;   // ints reserved for the per-round wave boundaries: (NW-1) * (BLS_RSEG/NW)  // round boundaries kept in LDS; more rounds (badly unsorted time) -> serial path
 
 struct BlsBest {
     double obj;
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
                     rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
                 }
                 if (lhs * (1.0 + 1e-12) < rhs) continue;  // certainly objective < thr
+                if ((ablate & 32) && best > -INFINITY) continue;  // profiling only: only the first survivor is evaluated
             }
             y_in /= ivar_in;
             y_out /= ivar_out;

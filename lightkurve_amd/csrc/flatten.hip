@@ -312,9 +312,29 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     if (polyorder >= window) polyorder = window - 1;  // the reference clamps with a warning (lightcurve.py:1015-1020)
     LK_REQUIRE(polyorder >= 0 && polyorder <= 15, "polyorder %d outside 0..15", polyorder);
     LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");
-    std::vector<double> coeffs, edge;
-    LK_REQUIRE(savgol_design(window, polyorder, coeffs, edge), "singular Savitzky-Golay design (window %d, order %d)",
-               window, polyorder);
+    // the design (taps + edge operators, ~1 MB at window 401) is built once per (device, window, polyorder) in long
+    // double on the host and kept resident; it is a few ms of host work that would otherwise dominate small batches
+    struct Design {
+        int device, window, polyorder;
+        double *d_c, *d_e;
+    };
+    static std::vector<Design> cache;
+    const Design *des = nullptr;
+    for (const Design &d : cache)
+        if (d.device == h->device && d.window == window && d.polyorder == polyorder) des = &d;
+    if (!des) {
+        std::vector<double> coeffs, edge;
+        LK_REQUIRE(savgol_design(window, polyorder, coeffs, edge),
+                   "singular Savitzky-Golay design (window %d, order %d)", window, polyorder);
+        Design d{h->device, window, polyorder, nullptr, nullptr};
+        LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.d_c), coeffs.size() * 8));
+        LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.d_e), edge.size() * 8 + 8));
+        LK_HIP_CHECK(hipMemcpy(d.d_c, coeffs.data(), coeffs.size() * 8, hipMemcpyHostToDevice));
+        if (!edge.empty()) LK_HIP_CHECK(hipMemcpy(d.d_e, edge.data(), edge.size() * 8, hipMemcpyHostToDevice));
+        cache.push_back(d);
+        des = &cache.back();
+    }
+    double *d_c = des->d_c, *d_e = des->d_e;
     std::vector<int64_t> soff((size_t)B + 1, 0);
     for (int b = 0; b < B; ++b) {
         const int64_t n = n_off_host[b + 1] - n_off_host[b];
@@ -323,18 +343,14 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         soff[b + 1] = soff[b] + ((3 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
-    const size_t cb = coeffs.size() * 8, eb = edge.size() * 8;
-    int rc = h->ws.reserve((size_t)(B + 1) * 16 + cb + eb + (size_t)soff[B] + 4096);
+    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + 4096);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     int64_t *d_soff = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
-    double *d_c = (double *)h->ws.alloc(cb), *d_e = (double *)h->ws.alloc(eb ? eb : 8);
     char *d_s = (char *)h->ws.alloc((size_t)soff[B]);
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
-    LK_HIP_CHECK(hipMemcpyAsync(d_c, coeffs.data(), cb, hipMemcpyHostToDevice, stream));
-    if (eb) LK_HIP_CHECK(hipMemcpyAsync(d_e, edge.data(), eb, hipMemcpyHostToDevice, stream));
-    LK_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
+    LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
     hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(1024), 0, stream, t, flux, user_mask, d_off, window, polyorder,
                        break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask);
     LK_HIP_CHECK(hipGetLastError());
