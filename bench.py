@@ -48,6 +48,25 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cores(cap=64):
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota) — the GPU box advertises
+    256 logical CPUs but its cgroup grants 16 (cpu.max = "1600000 100000")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, cap))
+
+
 CONDA = "/opt/conda/bin/python3.9"
 SYS_STDCXX = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
 
@@ -79,7 +98,7 @@ def cpu_baseline_ls(args):
     "reference").  Fallback: the numpy port of the same algorithm from oracle/ (kind "port")."""
     import multiprocessing as mp
     from oracle import cpu_baseline as cb
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = effective_cores()
     exact_pairs_per_s = cb.ls_exact_rate(args.cadences)
     extra = {"exact_port_1core": {"value": exact_pairs_per_s / args.cadences, "unit": "frequencies*targets/sec",
                                   "note": "C oracle (the exact direct-sum arithmetic the GPU kernel performs), 1 core"}}
@@ -109,13 +128,13 @@ def cpu_baseline_ls(args):
 
 def cpu_baseline_bls(args):
     from oracle import cpu_baseline as cb
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    r = _astropy_baseline(["bls", cores * 2, args.cadences, 48, args.durations, cores])
+    cores = effective_cores()
+    r = _astropy_baseline(["bls", cores * 4, args.cadences, 480, args.durations, cores])
     if r is not None:
         return {"value": r["units_per_s"], "unit": "periods*targets/sec", "cores": cores, "kind": "reference",
                 "sample": "astropy %s BoxLeastSquares.power (compiled run_bls) as lightkurve calls it "
-                          "(periodogram.py:1161-1169), %d targets x 48 periods x %d durations, N=%d, %d processes, "
-                          "%.1f s" % (r["astropy"], cores * 2, args.durations, args.cadences, cores, r["seconds"])}
+                          "(periodogram.py:1161-1169), %d targets x 480 periods x %d durations, N=%d, %d processes, "
+                          "%.1f s" % (r["astropy"], cores * 4, args.durations, args.cadences, cores, r["seconds"])}
     rate = cb.bls_rate(args.cadences, args.durations)
     return {"value": rate, "unit": "periods*targets/sec", "cores": 1, "kind": "port",
             "sample": "C oracle (restated astropy run_bls), 1 target x 24 periods x %d durations, N=%d, 1 core"

@@ -36,6 +36,37 @@ int Arena::reserve(size_t bytes) {
     return LK_OK;
 }
 
+int HostStage::copy(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    const int s = next;
+    next = (next + 1) % SLOTS;
+    if (ev[s]) LK_HIP_CHECK(hipEventSynchronize(ev[s]));  // the copy that last used this slot has finished
+    if (cap[s] < bytes) {
+        if (buf[s]) (void)hipHostFree(buf[s]);
+        buf[s] = nullptr;
+        cap[s] = 0;
+        LK_HIP_CHECK(hipHostMalloc(&buf[s], bytes + 4096, hipHostMallocDefault));
+        cap[s] = bytes + 4096;
+    }
+    if (!ev[s]) LK_HIP_CHECK(hipEventCreateWithFlags(&ev[s], hipEventDisableTiming));
+    memcpy(buf[s], src, bytes);
+    LK_HIP_CHECK(hipMemcpyAsync(dst, buf[s], bytes, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipEventRecord(ev[s], stream));
+    return LK_OK;
+}
+
+void HostStage::release() {
+    for (int s = 0; s < SLOTS; ++s) {
+        if (ev[s]) {
+            (void)hipEventSynchronize(ev[s]);
+            (void)hipEventDestroy(ev[s]);
+        }
+        if (buf[s]) (void)hipHostFree(buf[s]);
+        buf[s] = nullptr;
+        ev[s] = nullptr;
+        cap[s] = 0;
+    }
+}
+
 void Arena::release() {
     if (base) (void)hipFree(base);
     base = nullptr;
@@ -85,6 +116,7 @@ int lk_init(int device_id, lk_handle **out) {
 void lk_destroy(lk_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    h->stage.release();
     h->ws.release();
     h->staging.release();
     delete h;

@@ -50,9 +50,24 @@ struct Arena {
 
 }  // namespace lk
 
+namespace lk {
+// Ring of pinned host buffers for small asynchronous host->device copies (batch offsets): the caller's buffer is
+// captured before the entry point returns, and the device copy stays ordered on the caller's stream.
+struct HostStage {
+    static constexpr int SLOTS = 4;
+    void *buf[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[SLOTS] = {0, 0, 0, 0};
+    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int next = 0;
+    int copy(void *dst, const void *src, size_t bytes, hipStream_t stream);
+    void release();
+};
+}  // namespace lk
+
 struct lk_handle {
     int device = 0;
     int num_cu = 256;
+    lk::HostStage stage;
     lk::Arena ws;        // kernel scratch (prepped per-cadence records, per-target stats)
     lk::Arena staging;   // device mirrors of host buffers for the *_batch (host pointer) entry points
 };

@@ -368,7 +368,10 @@ int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, c
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     TargetStats *d_stats = (TargetStats *)h->ws.alloc((size_t)B * sizeof(TargetStats));
-    LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    {
+        const int rcs = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
+        if (rcs) return rcs;
+    }
     const int center = (fit_mean || center_data) ? 1 : 0;
 
     if (freq) {

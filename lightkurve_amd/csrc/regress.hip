@@ -331,7 +331,10 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     double *d_G = (double *)h->ws.alloc((size_t)B * Kp * Kp * 8);
     double *d_A = (double *)h->ws.alloc((size_t)B * K * (K + 1) * 8);
     uint8_t *d_flag = (uint8_t *)h->ws.alloc(ntot);
-    LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    {
+        const int rcs = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
+        if (rcs) return rcs;
+    }
     LK_HIP_CHECK(hipMemsetAsync(outl, 0, ntot, stream));
     const int nblk = KB * (KB + 1) / 2;
     for (int it = 0; it < niters; ++it) {
