@@ -70,6 +70,17 @@ int lk_ls_power_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const 
                           int fit_mean, int center_data, int normalization, const double *scale,
                           double *power, void *stream);
 
+/* ---- Lomb-Scargle, lightkurve's DEFAULT method ls_method="fast" (periodogram.py:650): Press & Rybicki extirpolation
+ * + FFT evaluation of the trig sums (astropy fast_impl.py / utils.py trig_sum, extirpolate), regular grid only.
+ * Agrees with the reference's 'fast' output to ~1e-10 (and, like it, is ~1e-3 of the peak from the exact methods).
+ * oversampling: FFT grid oversampling (astropy default 5; Nfft = bitceil(M * oversampling)). */
+int lk_ls_fast_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                     double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
+                     const double *scale, int oversampling, double *power);
+int lk_ls_fast_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                         const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                         int normalization, const double *scale, int oversampling, double *power, void *stream);
+
 /* ---- nanmax / nanargmax over each row of a B x M float64 matrix (first maximum wins) ---------------- */
 int lk_argmax_batch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out);
 int lk_argmax_batch_dev(lk_handle *h, int B, int64_t M, const double *x, double *max_out,

@@ -37,6 +37,12 @@ SIGNATURES = [
     ("lk_ls_power_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
       ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_ls_fast_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int, _c_dp]),
+    ("lk_ls_fast_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
     ("lk_argmax_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, _c_dp, _c_ip]),
     ("lk_argmax_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("lk_bls_batch", ctypes.c_int,
@@ -188,6 +194,34 @@ def ls_power_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, freq_ptr, f0
                                       _vp(dy_ptr or None), _vp(freq_ptr or None), float(f0), float(df), int(M),
                                       int(bool(fit_mean)), int(bool(center_data)), NORM[normalization],
                                       _vp(scale_ptr or None), _vp(power_ptr), _vp(stream or None)))
+
+
+def ls_fast_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True, normalization="psd",
+                  scale=None, oversampling=5, device=0):
+    """The reference's default ``ls_method="fast"`` (extirpolation + FFT) for B ragged targets on the regular grid
+    ``f0 + df*arange(M)`` -> float64[B, M]."""
+    h = Handle.get(device)
+    t, y = _f64(t), _f64(y)
+    n_off = _offsets(n_off, t.size)
+    if y.shape != t.shape:
+        raise ValueError("t and y must have the same length")
+    dy = None if dy is None else _f64(np.broadcast_to(dy, t.shape))
+    B, M = n_off.size - 1, int(M)
+    scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
+    power = np.empty((B, M), dtype=np.float64)
+    _check(_lib.lk_ls_fast_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), float(f0), float(df), M,
+                                 int(bool(fit_mean)), int(bool(center_data)), NORM[normalization], _ptr(scale),
+                                 int(oversampling), _ptr(power)))
+    return power
+
+
+def ls_fast_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, f0, df, M, fit_mean, center_data, normalization,
+                      scale_ptr, oversampling, power_ptr, stream=0):
+    n_off_host = np.ascontiguousarray(n_off_host, dtype=np.int64)
+    _check(_lib.lk_ls_fast_batch_dev(handle._h, int(B), _ptr(n_off_host, _c_ip), _vp(t_ptr), _vp(y_ptr),
+                                     _vp(dy_ptr or None), float(f0), float(df), int(M), int(bool(fit_mean)),
+                                     int(bool(center_data)), NORM[normalization], _vp(scale_ptr or None),
+                                     int(oversampling), _vp(power_ptr), _vp(stream or None)))
 
 
 def argmax_batch(x, device=0):

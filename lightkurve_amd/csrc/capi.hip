@@ -166,6 +166,45 @@ int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ LS 'fast'
+int lk_ls_fast_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                         const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                         int normalization, const double *scale, int oversampling, double *power, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::lsfast_launch(h, B, n_off_host, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
+                             oversampling, power, static_cast<hipStream_t>(stream));
+}
+
+int lk_ls_fast_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                     double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
+                     const double *scale, int oversampling, double *power) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    LK_REQUIRE(M >= 0, "M must be >= 0");
+    if (B == 0 || M == 0) return LK_OK;
+    LK_REQUIRE(t && y && power, "t, y, power must be non-NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B], nb = ntot * 8;
+    const size_t pb = (size_t)B * (size_t)M * 8, sb = scale ? (size_t)B * 8 : 0;
+    h->staging.reset();
+    int rc = h->staging.reserve(3 * (nb + 256) + pb + sb + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(nb), *dyv = (double *)h->staging.alloc(nb);
+    double *ddy = dy ? (double *)h->staging.alloc(nb) : nullptr;
+    double *dscale = scale ? (double *)h->staging.alloc(sb) : nullptr;
+    double *dpow = (double *)h->staging.alloc(pb);
+    LK_HIP_CHECK(hipMemcpy(dt, t, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dyv, y, nb, hipMemcpyHostToDevice));
+    if (dy) LK_HIP_CHECK(hipMemcpy(ddy, dy, nb, hipMemcpyHostToDevice));
+    if (scale) LK_HIP_CHECK(hipMemcpy(dscale, scale, sb, hipMemcpyHostToDevice));
+    rc = lk::lsfast_launch(h, B, n_off, dt, dyv, ddy, f0, df, M, fit_mean, center_data, normalization, dscale,
+                           oversampling, dpow, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(power, dpow, pb, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ argmax
 int lk_argmax_batch_dev(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out,
                         void *stream) {

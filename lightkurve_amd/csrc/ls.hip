@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "lk_common.hpp"
+#include "ls_epilogue.hpp"
 
 namespace lk {
 
@@ -126,40 +127,12 @@ __global__ __launch_bounds__(256) void ls_prep_kernel(const double *__restrict__
     if (tid == 0) stats[b] = TargetStats{wsum, ybar, YY, 0.0};
 }
 
-// ------------------------------------------------------------------------------------------------ epilogue
-// Closed-form GLS from the six sums (fast_impl.py:93-131) + normalisation.  S2acc = sum w sin cos,
-// C2acc = sum w cos^2 (so S2 = 2 S2acc, C2 = 2 C2acc - 1 since sum w = 1).
+// closed-form epilogue: gls_power_sums() in ls_epilogue.hpp.  The kernels below accumulate S2acc = sum w sin cos and
+// C2acc = sum w cos^2, so S2 = 2 S2acc and C2 = 2 C2acc - 1 (sum w = 1).
 __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, double C, double S2acc, double C2acc,
                                             int fit_mean, int norm, double YY, double psd_factor, double nN,
                                             double scale) {
-    const double S2 = 2.0 * S2acc, C2 = fma(2.0, C2acc, -1.0);
-    double tan2;
-    if (fit_mean)
-        tan2 = (S2 - 2.0 * S * C) / (C2 - (C * C - S * S));
-    else
-        tan2 = S2 / C2;
-    const double C2w = 1.0 / sqrt(1.0 + tan2 * tan2);
-    const double S2w = tan2 * C2w;
-    const double Cw = sqrt(0.5) * sqrt(1.0 + C2w);
-    const double sgn = (S2w > 0.0) ? 1.0 : ((S2w < 0.0) ? -1.0 : 0.0);
-    const double Sw = sqrt(0.5) * sgn * sqrt(1.0 - C2w);
-    const double YC = Ch * Cw + Sh * Sw;
-    const double YS = Sh * Cw - Ch * Sw;
-    double CC = 0.5 * (1.0 + C2 * C2w + S2 * S2w);
-    double SS = 0.5 * (1.0 - C2 * C2w - S2 * S2w);
-    if (fit_mean) {
-        const double a = C * Cw + S * Sw, bq = S * Cw - C * Sw;
-        CC -= a * a;
-        SS -= bq * bq;
-    }
-    double p = YC * YC / CC + YS * YS / SS;
-    switch (norm) {
-        case LK_NORM_STANDARD: p /= YY; break;
-        case LK_NORM_PSD: p *= psd_factor; break;
-        case LK_NORM_LK_AMPLITUDE: p = sqrt(p * psd_factor) * sqrt(4.0 / nN); break;
-        default: p = p * psd_factor * scale; break;
-    }
-    return p;
+    return gls_power_sums(Sh, Ch, S, C, 2.0 * S2acc, fma(2.0, C2acc, -1.0), fit_mean, norm, YY, psd_factor, nN, scale);
 }
 
 // ------------------------------------------------------------------------------------------------ grid kernel
