@@ -124,7 +124,7 @@ class Periodogram(object):
 
 def _ls_plan(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=None, maximum_period=None,
              frequency=None, period=None, nterms=1, nyquist_factor=1, oversample_factor=None, freq_unit=None,
-             normalization="amplitude", ls_method="hip", **kwargs):
+             normalization="amplitude", ls_method="fast", **kwargs):
     """Everything LombScarglePeriodogram.from_lightcurve decides BEFORE it calls astropy
     (reference periodogram.py:783-958): validated options, cleaned arrays, frequency grid, method name.
     Returns a dict; shared by the single-curve constructor and the batched entry point."""
@@ -245,19 +245,25 @@ class LombScarglePeriodogram(Periodogram):
     @staticmethod
     def from_lightcurve(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=None,
                         maximum_period=None, frequency=None, period=None, nterms=1, nyquist_factor=1,
-                        oversample_factor=None, freq_unit=None, normalization="amplitude", ls_method="hip",
+                        oversample_factor=None, freq_unit=None, normalization="amplitude", ls_method="fast",
                         device=0, **kwargs):
-        """Same contract as the reference constructor.  ``ls_method``: any name the reference accepts plus
-        ``"hip"`` (default); all are served by the exact fp64 GPU kernels (the reference's default ``"fast"`` is
-        an FFT approximation that differs from its own exact methods by ~1e-3 of the peak; results here match
-        ``"slow"``/``"cython"`` to 1e-9)."""
+        """Same contract and default as the reference constructor.  ``ls_method="fast"`` (default) runs the
+        reference's default algorithm — Press & Rybicki extirpolation + FFT — on the GPU and reproduces lightkurve's
+        default output to 1e-9; like the reference it needs a regular frequency grid and otherwise switches to
+        ``"slow"``.  Every other name (``"slow"``, ``"cython"``, ``"chi2"``, ``"scipy"``, ``"auto"``, ``"hip"``) runs
+        the exact fp64 direct-sum kernels (== the reference's exact methods to 1e-9)."""
         plan = _ls_plan(lc, minimum_frequency, maximum_frequency, minimum_period, maximum_period, frequency, period,
                         nterms, nyquist_factor, oversample_factor, freq_unit, normalization, ls_method, **kwargs)
         n = len(plan["trel"])
         grid = exact_grid(plan["f_day"])
         common = dict(dy=plan["dy"], fit_mean=plan["fit_mean"], center_data=plan["center_data"],
                       normalization=plan["norm"], scale=[plan["scale"]], device=device)
-        if grid is not None:
+        if plan["ls_method"] in ("fast", "fastchi2"):
+            # astropy _get_frequency_grid (main.py:53-80): f0 = frequency[0], df = frequency[1] - frequency[0]
+            fd = plan["f_day"]
+            f0, dfq = (float(fd[0]), float(fd[1] - fd[0])) if len(fd) > 1 else (float(fd[0]), float(fd[0]))
+            power = _capi.ls_fast_batch(plan["trel"], plan["flux"], [0, n], f0=f0, df=dfq, M=len(fd), **common)[0]
+        elif grid is not None:
             power = _capi.ls_power_batch(plan["trel"], plan["flux"], [0, n], f0=grid[0], df=grid[1],
                                          M=len(plan["f_day"]), **common)[0]
         else:
