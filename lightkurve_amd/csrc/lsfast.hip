@@ -15,6 +15,7 @@
 // and reduced to M powers.  Algorithmic HBM traffic per target: grids 3 x (zero 8 MB + 2 passes x (read + write)
 // 8 MB) = 120 MB, + 16 B/cadence in and 8 B/frequency out.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "lk_common.hpp"
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
                                                         const double *__restrict__ dy,
                                                         const int64_t *__restrict__ n_off, int center,
                                                         double *__restrict__ w_out, double *__restrict__ wy_out,
-                                                        FastStats *__restrict__ stats) {
+                                                        FastStats *__restrict__ stats, double df, int nfft, int m2,
+                                                        int *__restrict__ rows_used) {
     __shared__ double sh[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
@@ -46,13 +48,14 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
         __syncthreads();
         return r;
     };
-    double acc = 0.0, tmin = INFINITY;
+    double acc = 0.0, tmin = INFINITY, tmax = -INFINITY;
     for (int64_t i = tid; i < n; i += 256) {
         if (dy) {
             const double d = dy[lo + i];
             acc += 1.0 / (d * d);
         }
         tmin = fmin(tmin, t[lo + i]);
+        tmax = fmax(tmax, t[lo + i]);
     }
     const double wsum = dy ? bsum(acc) : (double)n;
     sh[tid] = tmin;
@@ -63,6 +66,30 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
     }
     const double t0 = sh[0];
     __syncthreads();
+    sh[tid] = tmax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] = fmax(sh[tid], sh[tid + s]);
+        __syncthreads();
+    }
+    const double t1 = sh[0];
+    __syncthreads();
+    if (tid < 3 && rows_used) {
+        // grid rows (of N2 cells) that can receive a sample: cells <= tnorm_max + 1; everything wraps if the span
+        // reaches Nfft.  Grids 0, 1 use df, grid 2 uses 2 df.
+        const double span = (t1 - t0) * (double)nfft * df * (tid == 2 ? 2.0 : 1.0);
+        const int nrows = nfft >> m2;
+        rows_used[b * 4 + tid] = (span >= (double)nfft - 8.0) ? nrows : min(nrows, (int)((span + 4.0) / (double)(1 << m2)) + 1);
+    }
+    if (rows_used) {
+        // "ordered" targets (time sorted, no wrap of the 2 df grid): grid positions are monotone in the cadence
+        // index, so the spreading kernel can own cell ranges and use plain stores instead of global atomics
+        int unsorted = 0;
+        for (int64_t i = tid; i + 1 < n; i += 256) unsorted |= (t[lo + i + 1] < t[lo + i]) ? 1 : 0;
+        const int any_unsorted = __syncthreads_or(unsorted);
+        const bool nowrap = (t1 - t0) * (double)nfft * df * 2.0 < (double)nfft - 8.0;
+        if (tid == 0) rows_used[b * 4 + 3] = (!any_unsorted && nowrap) ? 1 : 0;
+    }
     const double y0 = y[lo];
     double ybar = 0.0;
     if (center) {
@@ -118,7 +145,9 @@ __global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restri
                                                            const int64_t *__restrict__ n_off,
                                                            const FastStats *__restrict__ stats, int b0, double f0,
                                                            double df, int nfft, int fit_mean,
-                                                           double2 *__restrict__ grids) {
+                                                           double2 *__restrict__ grids,
+                                                           const int *__restrict__ rows_used) {
+    if (rows_used && rows_used[blockIdx.y * 4 + 3]) return;  // ordered target: handled by lsf_spread_owner_kernel
     const int b = b0 + blockIdx.y;
     const int64_t lo = n_off[b];
     const int n = (int)(n_off[b + 1] - lo);
@@ -140,6 +169,93 @@ __global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restri
             extirpolate4(g2, nfft, tn, wi * c, wi * s);
         }
     }
+}
+
+// Owner-computes spreading for ordered targets (sorted time, no wrap): grid positions grow with the cadence index,
+// so workgroup (x, target, g) owns cells [x W, (x+1) W) of grid g, finds the cadences whose 4-point stencils reach
+// them by two block-wide probes, accumulates in LDS (ds_add_f64) and writes its cells once with plain, coalesced
+// stores — zeros included, so no memset and no global atomics.  g: 0 = w*y at f, 1 = w at f, 2 = w at 2 f.
+constexpr int SPREAD_W = 1024;
+
+__global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__restrict__ t, const double *__restrict__ w,
+                                                                const double *__restrict__ wy,
+                                                                const int64_t *__restrict__ n_off,
+                                                                const FastStats *__restrict__ stats, int b0, double f0,
+                                                                double df, int nfft, int m2, int fit_mean,
+                                                                double2 *__restrict__ grids,
+                                                                const int *__restrict__ rows_used) {
+    __shared__ double2 acc[SPREAD_W];
+    const int lb = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
+    if (!rows_used[lb * 4 + 3]) return;
+    const int ncell = rows_used[lb * 4 + g] << m2;  // cells the column transform will read
+    const int c_lo = blockIdx.x * SPREAD_W, c_hi = min(c_lo + SPREAD_W, ncell);
+    if (c_lo >= ncell) return;
+    double2 *G = grids + ((size_t)lb * 3 + g) * (size_t)nfft;
+    if (g == 1 && !fit_mean) {  // unused grid: keep it defined
+        for (int c = c_lo + tid; c < c_hi; c += 256) G[c] = make_double2(0.0, 0.0);
+        return;
+    }
+    const int b = b0 + lb;
+    const int64_t lo = n_off[b];
+    const int n = (int)(n_off[b + 1] - lo);
+    t += lo;
+    const double t0 = stats[b].t0;
+    const double fac = g == 2 ? 2.0 : 1.0;
+    const double dff = df * fac, f0f = f0 * fac;
+    const double *amp = (g == 0 ? wy : w) + lo;
+    auto pos = [&](int i) { return fmod((t[i] - t0) * (double)nfft * dff, (double)nfft); };
+    // first cadence with pos >= x (positions are non-decreasing): 256-way probes until the bracket fits one pass
+    auto lower = [&](double x) -> int {
+        int lo_i = 0, hi_i = n;  // answer in [lo_i, hi_i]
+        while (hi_i - lo_i > 256) {
+            const int stride = (hi_i - lo_i + 255) / 256;
+            const int ip = lo_i + tid * stride;
+            const int cnt = __syncthreads_count(ip < hi_i && pos(ip) < x);  // probes below x form a prefix
+            if (cnt == 0) {
+                hi_i = lo_i;  // even the first element is >= x
+                break;
+            }
+            const int nlo = lo_i + (cnt - 1) * stride + 1;  // just after the last probe below x
+            hi_i = min(lo_i + cnt * stride, hi_i);
+            lo_i = nlo;
+        }
+        const int i2 = lo_i + tid;
+        const int cnt2 = __syncthreads_count(i2 < hi_i && pos(i2) < x);
+        return lo_i + cnt2;
+    };
+    const int i_lo = lower((double)c_lo - 4.0), i_hi = lower((double)c_hi + 3.0);
+    for (int c = tid; c < SPREAD_W; c += 256) acc[c] = make_double2(0.0, 0.0);
+    __syncthreads();
+    const double twopi = 6.283185307179586;
+    auto add = [&](int cell, double vr, double vi) {
+        if (cell >= c_lo && cell < c_hi) {
+            unsafeAtomicAdd(&acc[cell - c_lo].x, vr);
+            unsafeAtomicAdd(&acc[cell - c_lo].y, vi);
+        }
+    };
+    for (int i = i_lo + tid; i < i_hi; i += 256) {
+        const double tt = t[i] - t0;
+        double c = 1.0, s = 0.0;
+        if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
+        const double x = fmod(tt * (double)nfft * dff, (double)nfft);
+        const double hr = amp[i] * c, hi = amp[i] * s;
+        if (fmod(x, 1.0) == 0.0) {
+            add((int)x, hr, hi);
+        } else {
+            int ilo = (int)(x - 2.0);
+            ilo = min(max(ilo, 0), nfft - 4);
+            const double d0 = x - (double)ilo, d1 = d0 - 1.0, d2 = d0 - 2.0, d3 = d0 - 3.0;
+            const double prod = ((d0 * d1) * d2) * d3;
+            const double nr = hr * prod, ni = hi * prod;
+            const double q3 = 6.0 * d3, q2 = -2.0 * d2, q1 = 2.0 * d1, q0 = -6.0 * d0;
+            add(ilo + 3, nr / q3, ni / q3);
+            add(ilo + 2, nr / q2, ni / q2);
+            add(ilo + 1, nr / q1, ni / q1);
+            add(ilo, nr / q0, ni / q0);
+        }
+    }
+    __syncthreads();
+    for (int c = c_lo + tid; c < c_hi; c += 256) G[c] = acc[c - c_lo];
 }
 
 // ------------------------------------------------------------------------------------------------ four-step FFT
@@ -223,6 +339,150 @@ __global__ __launch_bounds__(256) void fft_rows_kernel(const double2 *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ register FFTs
+// Faster four-step kernels for 2^4 <= N1, N2 <= 2^10: a length-n = A*Bq block transform is itself split in two:
+// phase 1: Bq threads each run an A-point FFT entirely in registers (A <= 32), apply e^{2 pi i j ka / n} and park the
+// result in LDS; phase 2: A threads each run a Bq-point register FFT over the transposed data.  One LDS write +
+// one LDS read per point instead of log2(n) read-modify-write passes, two barriers instead of log2(n).
+__device__ constexpr double R32C[16] = {1.0, 0.98078528040323043, 0.92387953251128674, 0.83146961230254524,
+                                        0.70710678118654752, 0.55557023301960218, 0.38268343236508978,
+                                        0.19509032201612825, 0.0, -0.19509032201612825, -0.38268343236508978,
+                                        -0.55557023301960218, -0.70710678118654752, -0.83146961230254524,
+                                        -0.92387953251128674, -0.98078528040323043};
+__device__ constexpr double R32S[16] = {0.0, 0.19509032201612825, 0.38268343236508978, 0.55557023301960218,
+                                        0.70710678118654752, 0.83146961230254524, 0.92387953251128674,
+                                        0.98078528040323043, 1.0, 0.98078528040323043, 0.92387953251128674,
+                                        0.83146961230254524, 0.70710678118654752, 0.55557023301960218,
+                                        0.38268343236508978, 0.19509032201612825};
+
+__host__ __device__ constexpr int brev_c(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// in-place radix-2 decimation-in-frequency FFT of 2^L points in registers, kernel e^{+2 pi i nk/2^L};
+// the result is left in bit-reversed order: v[p] = X[brev(p)]
+template <int L>
+__device__ __forceinline__ void reg_fft(double2 (&v)[1 << L]) {
+#pragma unroll
+    for (int s = L; s >= 1; --s) {
+        const int half = 1 << (s - 1);
+#pragma unroll
+        for (int g = 0; g < (1 << L); g += (1 << s)) {
+#pragma unroll
+            for (int k = 0; k < half; ++k) {
+                const double2 a = v[g + k], b = v[g + k + half];
+                v[g + k] = make_double2(a.x + b.x, a.y + b.y);
+                const double dx = a.x - b.x, dy = a.y - b.y;
+                const int ti = k * (32 >> s);  // e^{2 pi i k / 2^s} as a 32nd root
+                if (ti == 0)
+                    v[g + k + half] = make_double2(dx, dy);
+                else if (ti == 8)
+                    v[g + k + half] = make_double2(-dy, dx);
+                else
+                    v[g + k + half] = make_double2(dx * R32C[ti] - dy * R32S[ti], dx * R32S[ti] + dy * R32C[ti]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// Block transform of NF sequences of length n = 2^(LA+LB).  load(f, e) returns element e of sequence f;
+// store(f, k, value) receives output k.  tile: NF * A * (Bq + 1) double2 of LDS.  Threads needed: NF * max(A, Bq).
+template <int LA, int LB, bool F_FASTEST, class Load, class Store>
+__device__ __forceinline__ void block_fft(int NF, double2 *tile, Load load, Store store) {
+    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
+    const int tid = threadIdx.x;
+    // phase 1: thread (f, j) transforms x[i*Bq + j], i < A.  F_FASTEST: neighbouring threads take neighbouring
+    // sequences (column transforms: sequences are adjacent in memory); otherwise neighbouring elements j
+    if (tid < NF * Bq) {
+        const int f = F_FASTEST ? tid % NF : tid / Bq, j = F_FASTEST ? tid / NF : tid % Bq;
+        double2 v[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) v[i] = load(f, i * Bq + j);
+        reg_fft<LA>(v);
+        double s1, c1;
+        sincospi(2.0 * (double)j / (double)n, &s1, &c1);
+        const double2 step = make_double2(c1, s1);
+        // outputs ka = 0..A-1 in order, twiddle e^{2 pi i j ka / n} by running product
+        double2 w = make_double2(1.0, 0.0);
+        double2 *row = tile + (size_t)f * FST + j;
+#pragma unroll
+        for (int ka = 0; ka < A; ++ka) {
+            row[ka * LDT] = cmul(v[brev_c(ka, LA)], w);
+            w = cmul(w, step);
+        }
+    }
+    __syncthreads();
+    // phase 2: thread (f, ka) transforms T[ka][j], j < Bq -> X[ka + A kb]
+    if (tid < NF * A) {
+        const int ka = tid / NF, f = tid - ka * NF;  // f fastest: neighbouring threads write neighbouring sequences
+        const double2 *row = tile + (size_t)f * FST + (size_t)ka * LDT;
+        double2 u[Bq];
+#pragma unroll
+        for (int j = 0; j < Bq; ++j) u[j] = row[j];
+        reg_fft<LB>(u);
+#pragma unroll
+        for (int kb = 0; kb < Bq; ++kb) store(f, ka + A * kb, u[brev_c(kb, LB)]);
+    }
+}
+
+// step 1 (register version): CT columns c0..c0+CT-1; rows >= rows_used[g] are known zeros and are not loaded
+template <int LA, int LB>
+__global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__ grids, int m2, int CT,
+                                                            const int *__restrict__ rows_used) {
+    extern __shared__ __attribute__((aligned(16))) double2 lds2[];
+    constexpr int m1 = LA + LB, A = 1 << LA;
+    const int N2 = 1 << m2;
+    double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
+    const int c0 = blockIdx.x * CT;
+    const int ru = rows_used ? rows_used[(blockIdx.y / 3) * 4 + (blockIdx.y % 3)] : (1 << m1);
+    const double invN = 1.0 / (double)((size_t)1 << (m1 + m2));
+    auto load = [&](int f, int r) -> double2 {
+        return r < ru ? G[(size_t)r * N2 + c0 + f] : make_double2(0.0, 0.0);
+    };
+    // outputs of one thread (fixed ka) come in order kb = 0, 1, ...: the inter-step twiddle e^{2 pi i c k1 / N},
+    // k1 = ka + A kb, advances by e^{2 pi i c A / N} each time
+    int last_f = -1;
+    double2 w = make_double2(1.0, 0.0), step = w;
+    auto store = [&](int f, int k1, double2 v) {
+        const int c = c0 + f;
+        if (f != last_f) {  // first output of this thread: k1 = ka
+            double s, cc;
+            sincospi(2.0 * (double)((long long)c * k1) * invN, &s, &cc);
+            w = make_double2(cc, s);
+            sincospi(2.0 * (double)((long long)c * A) * invN, &s, &cc);
+            step = make_double2(cc, s);
+            last_f = f;
+        }
+        G[(size_t)k1 * N2 + c] = cmul(v, w);
+        w = cmul(w, step);
+    };
+    block_fft<LA, LB, true>(CT, lds2, load, store);
+}
+
+// step 2 (register version): RT rows r0..r0+RT-1, outputs k = k1 + N1 k2 < nkeep kept
+template <int LA, int LB>
+__global__ __launch_bounds__(256) void fft_rows_reg_kernel(const double2 *__restrict__ grids, int m1, int RT, int nkeep,
+                                                            double2 *__restrict__ spec) {
+    extern __shared__ __attribute__((aligned(16))) double2 lds2[];
+    constexpr int m2 = LA + LB;
+    const int N2 = 1 << m2;
+    const double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
+    double2 *S = spec + (size_t)blockIdx.y * nkeep;
+    const int r0 = blockIdx.x * RT;
+    auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
+    auto store = [&](int f, int k2, double2 v) {
+        const long long k = (long long)(r0 + f) + ((long long)k2 << m1);
+        if (k < nkeep) S[k] = v;
+    };
+    block_fft<LA, LB, false>(RT, lds2, load, store);
+}
+
 // closed form from the three spectra (C = real, S = imag of the unnormalised inverse transform)
 __global__ __launch_bounds__(256) void lsf_power_kernel(const double2 *__restrict__ spec,
                                                          const int64_t *__restrict__ n_off,
@@ -248,6 +508,74 @@ __global__ __launch_bounds__(256) void lsf_power_kernel(const double2 *__restric
     const double n = (double)(n_off[b + 1] - n_off[b]);
     power[(size_t)b * (size_t)M + j] = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY,
                                                       0.5 * st.wsum, n, scale ? scale[b] : 1.0);
+}
+
+// zero only the grid rows that can receive samples (the column transform treats the others as zeros)
+__global__ __launch_bounds__(256) void lsf_zero_kernel(double2 *__restrict__ grids, int m1, int m2,
+                                                        const int *__restrict__ rows_used) {
+    if (rows_used[(blockIdx.y / 3) * 4 + 3]) return;  // ordered target: the owner-computes spreader writes every cell
+    const int ru = rows_used[(blockIdx.y / 3) * 4 + (blockIdx.y % 3)];
+    const int N2 = 1 << m2;
+    double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
+    for (int r = blockIdx.x * 8; r < min(blockIdx.x * 8 + 8, ru); ++r)
+        for (int c = threadIdx.x; c < N2; c += 256) G[(size_t)r * N2 + c] = make_double2(0.0, 0.0);
+}
+
+template <int LA, int LB>
+static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_used, hipStream_t stream) {
+    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
+    const int N2 = 1 << m2;
+    const int CT = std::max(1, std::min(N2, std::min(4096 / n, 256 / std::max(A, Bq))));
+    const int nt = ((CT * std::max(A, Bq) + 63) / 64) * 64;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * FST * 16, stream,
+                       grids, m2, CT, rows_used);
+}
+
+template <int LA, int LB>
+static void launch_rows_t(int m1, int ngrids, const double2 *grids, int nkeep, double2 *spec, hipStream_t stream) {
+    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
+    const int N1 = 1 << m1;
+    const int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
+    const int nt = ((RT * std::max(A, Bq) + 63) / 64) * 64;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_reg_kernel<LA, LB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((fft_rows_reg_kernel<LA, LB>), dim3(N1 / RT, ngrids), dim3(nt), (size_t)RT * FST * 16, stream,
+                       grids, m1, RT, nkeep, spec);
+}
+
+static void launch_cols_reg(int m1, int m2, int ngrids, double2 *grids, const int *rows_used, hipStream_t stream) {
+    switch (m1) {
+        case 4: launch_cols_t<2, 2>(m2, ngrids, grids, rows_used, stream); break;
+        case 5: launch_cols_t<3, 2>(m2, ngrids, grids, rows_used, stream); break;
+        case 6: launch_cols_t<3, 3>(m2, ngrids, grids, rows_used, stream); break;
+        case 7: launch_cols_t<4, 3>(m2, ngrids, grids, rows_used, stream); break;
+        case 8: launch_cols_t<4, 4>(m2, ngrids, grids, rows_used, stream); break;
+        case 9: launch_cols_t<5, 4>(m2, ngrids, grids, rows_used, stream); break;
+        default: launch_cols_t<5, 5>(m2, ngrids, grids, rows_used, stream); break;
+    }
+}
+
+static void launch_rows_reg(int m1, int m2, int ngrids, const double2 *grids, int nkeep, double2 *spec,
+                            hipStream_t stream) {
+    switch (m2) {
+        case 4: launch_rows_t<2, 2>(m1, ngrids, grids, nkeep, spec, stream); break;
+        case 5: launch_rows_t<3, 2>(m1, ngrids, grids, nkeep, spec, stream); break;
+        case 6: launch_rows_t<3, 3>(m1, ngrids, grids, nkeep, spec, stream); break;
+        case 7: launch_rows_t<4, 3>(m1, ngrids, grids, nkeep, spec, stream); break;
+        case 8: launch_rows_t<4, 4>(m1, ngrids, grids, nkeep, spec, stream); break;
+        case 9: launch_rows_t<5, 4>(m1, ngrids, grids, nkeep, spec, stream); break;
+        default: launch_rows_t<5, 5>(m1, ngrids, grids, nkeep, spec, stream); break;
+    }
 }
 
 static int ilog2_ceil(long long v) {
@@ -285,7 +613,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)2 << 30) / ((size_t)48 * nfft)));
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
-                           (size_t)Bc * 3 * nfft * 16 + (size_t)Bc * 3 * M * 16 + 8192);
+                           (size_t)Bc * 3 * nfft * 16 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 + 8192);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
@@ -302,17 +630,34 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         attr_set = true;
     }
+    const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10 && !getenv("LK_FFT_RADIX2");
+    int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
-                       d_w, d_wy, d_stats);
+                       d_w, d_wy, d_stats, df, nfft, m2, d_rows);
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
-        LK_HIP_CHECK(hipMemsetAsync(d_grids, 0, (size_t)nb * 3 * nfft * 16, stream));
+        if (reg_path) {
+            hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, stream, d_grids, m1, m2,
+                               d_rows + (size_t)b0 * 4);
+        } else {
+            LK_HIP_CHECK(hipMemsetAsync(d_grids, 0, (size_t)nb * 3 * nfft * 16, stream));
+        }
         hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, d_w,
-                           d_wy, d_off, d_stats, b0, f0, df, nfft, fit_mean, d_grids);
-        hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * 3), dim3(256), ldsA, stream, d_grids, m1, m2, CT);
-        hipLaunchKernelGGL(fft_rows_kernel, dim3(N1 / RT, nb * 3), dim3(256), ldsB, stream, d_grids, m1, m2, RT, (int)M,
-                           d_spec);
+                           d_wy, d_off, d_stats, b0, f0, df, nfft, fit_mean, d_grids,
+                           reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr);
+        if (reg_path)
+            hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)((nfft + SPREAD_W - 1) / SPREAD_W), nb, 3),
+                               dim3(256), 0, stream, t, d_w, d_wy, d_off, d_stats, b0, f0, df, nfft, m2, fit_mean,
+                               d_grids, d_rows + (size_t)b0 * 4);
+        if (reg_path) {
+            launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, stream);
+            launch_rows_reg(m1, m2, nb * 3, d_grids, (int)M, d_spec, stream);
+        } else {
+            hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * 3), dim3(256), ldsA, stream, d_grids, m1, m2, CT);
+            hipLaunchKernelGGL(fft_rows_kernel, dim3(N1 / RT, nb * 3), dim3(256), ldsB, stream, d_grids, m1, m2, RT,
+                               (int)M, d_spec);
+        }
         hipLaunchKernelGGL(lsf_power_kernel, dim3((unsigned)((M + 255) / 256), nb), dim3(256), 0, stream, d_spec,
                            d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power);
     }
