@@ -610,7 +610,9 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
     const size_t ntot = (size_t)n_off_host[B];
     // targets per chunk: keep the grids (3 x 16 B x Nfft per target) within ~2 GiB
-    const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)2 << 30) / ((size_t)48 * nfft)));
+    size_t chunk_bytes = (size_t)2 << 30;
+    if (const char *e = getenv("LK_FAST_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(e)) << 20;  // tuning knob
+    const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
                            (size_t)Bc * 3 * nfft * 16 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 + 8192);

@@ -1,7 +1,8 @@
 """Install the HIP kernels behind the reference's own seams when astropy is importable.
 
-* S1: register ``'hip'`` in astropy's Lomb-Scargle ``METHODS`` so ``LombScargle(...).power(f, method='hip')`` and
-  lightkurve's ``lc.to_periodogram(ls_method='hip')`` (src/lightkurve/periodogram.py:961-964) run on the GPU.
+* S1: register ``'hip'`` (exact) in astropy's Lomb-Scargle ``METHODS`` and replace ``'fast'`` (the default of
+  lightkurve's ``lc.to_periodogram()``, src/lightkurve/periodogram.py:650, 961-964) by the GPU FFT path; the CPU
+  original stays reachable as ``'fast_cpu'``.
 * S2: replace ``astropy.timeseries.periodograms.bls.methods.bls_fast`` (reached from periodogram.py:1169).
 
 astropy is NOT available in the product interpreter of this image; the seams are exercised on the GPU box by
@@ -29,6 +30,24 @@ def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit
     return _capi.ls_power_batch(t, y, [0, len(t)], frequency=frequency, **kw)[0]
 
 
+def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True, fit_mean=True,
+                         normalization="standard", use_fft=True, trig_sum_kwds=None, **unused):
+    """Signature of astropy's lombscargle_fast (fast_impl.py:6): the f0/df/Nf form 'fast*' methods receive."""
+    if normalization not in ("standard", "psd"):
+        raise ValueError("normalization='{}' not recognized".format(normalization))
+    if f0 < 0:
+        raise ValueError("Frequencies must be positive")
+    if df <= 0:
+        raise ValueError("Frequency steps must be positive")
+    if Nf <= 0:
+        raise ValueError("Number of frequencies must be positive")
+    kw = dict(trig_sum_kwds or {})
+    t = np.asarray(t, dtype=np.float64)
+    return _capi.ls_fast_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
+                               center_data=center_data, normalization=normalization,
+                               oversampling=int(kw.get("oversampling", 5)))[0]
+
+
 def bls_fast_hip(t, y, ivar, period, duration, oversample, use_likelihood):
     """Signature of astropy's methods.bls_fast (bls/methods.py:55-95)."""
     res = _capi.bls_batch(t, y, ivar, [0, len(t)], period, duration, oversample, use_likelihood)
@@ -40,6 +59,9 @@ def install():
     from astropy.timeseries.periodograms.bls import methods as bls_methods
     from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main
     ls_main.METHODS["hip"] = lombscargle_hip
+    # the reference's DEFAULT method: lc.to_periodogram() reaches the GPU with no change on the caller's side
+    ls_main.METHODS.setdefault("fast_cpu", ls_main.METHODS["fast"])
+    ls_main.METHODS["fast"] = lombscargle_fast_hip
     bls_methods._bls_fast_reference = getattr(bls_methods, "_bls_fast_reference", bls_methods.bls_fast)
     bls_methods.bls_fast = bls_fast_hip
-    return ["lombscargle:METHODS['hip']", "bls:methods.bls_fast"]
+    return ["lombscargle:METHODS['hip']", "lombscargle:METHODS['fast']", "bls:methods.bls_fast"]

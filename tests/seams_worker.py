@@ -26,6 +26,13 @@ def main():
             ref = ls.power(f, method="cython", normalization=norm)
             got = ls.power(f, method="hip", normalization=norm)
             errs["%s_%s" % (norm, "dy" if dy is not None else "nody")] = float(np.max(np.abs(got - ref)) / np.max(ref))
+            # the default method: GPU 'fast' vs astropy's own 'fast' (kept as 'fast_cpu')
+            ref = ls.power(f, method="fast_cpu", normalization=norm)
+            got = ls.power(f, method="fast", normalization=norm)
+            ok = np.isfinite(ref)
+            assert np.array_equal(ok, np.isfinite(got))
+            errs["fast_%s_%s" % (norm, "dy" if dy is not None else "nody")] = float(
+                np.max(np.abs(got[ok] - ref[ok])) / np.max(ref[ok]))
         per = np.linspace(0.1, 5, 400)     # irregular frequency grid
         errs["irregular_%s" % ("dy" if dy is not None else "nody")] = float(
             np.max(np.abs(ls.power(1 / per, method="hip") - ls.power(1 / per, method="slow"))))
