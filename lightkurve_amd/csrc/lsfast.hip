@@ -427,7 +427,7 @@ __device__ __forceinline__ void block_fft(int NF, double2 *tile, Load load, Stor
         for (int j = 0; j < Bq; ++j) u[j] = row[j];
         reg_fft<LB>(u);
 #pragma unroll
-        for (int kb = 0; kb < Bq; ++kb) store(f, ka + A * kb, u[brev_c(kb, LB)]);
+        for (int kb = 0; kb < Bq; ++kb) store(f, ka + A * kb, u[brev_c(kb, LB)], kb);
     }
 }
 
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__
     // k1 = ka + A kb, advances by e^{2 pi i c A / N} each time
     int last_f = -1;
     double2 w = make_double2(1.0, 0.0), step = w;
-    auto store = [&](int f, int k1, double2 v) {
+    auto store = [&](int f, int k1, double2 v, int) {
         const int c = c0 + f;
         if (f != last_f) {  // first output of this thread: k1 = ka
             double s, cc;
@@ -476,11 +476,80 @@ __global__ __launch_bounds__(256) void fft_rows_reg_kernel(const double2 *__rest
     double2 *S = spec + (size_t)blockIdx.y * nkeep;
     const int r0 = blockIdx.x * RT;
     auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
-    auto store = [&](int f, int k2, double2 v) {
+    auto store = [&](int f, int k2, double2 v, int) {
         const long long k = (long long)(r0 + f) + ((long long)k2 << m1);
         if (k < nkeep) S[k] = v;
     };
     block_fft<LA, LB, false>(RT, lds2, load, store);
+}
+
+// step 2 fused with the closed form: one workgroup transforms rows r0..r0+RT-1 of the THREE grids of a target in
+// turn (the LDS tile is reused), each phase-2 thread keeps the <= KB outputs it owns that fall below M, and the
+// power is computed in registers: the three spectra never go to memory.
+template <int LA, int LB, int KB>
+__global__ __launch_bounds__(256) void fft_rows_power_kernel(const double2 *__restrict__ grids, int m1, int RT,
+                                                              const int64_t *__restrict__ n_off,
+                                                              const FastStats *__restrict__ stats, int b0, double f0,
+                                                              double df, int64_t M, int fit_mean, int norm,
+                                                              const double *__restrict__ scale,
+                                                              double *__restrict__ power) {
+    extern __shared__ __attribute__((aligned(16))) double2 lds2[];
+    constexpr int m2 = LA + LB, A = 1 << LA;
+    const int N2 = 1 << m2;
+    const int lb = blockIdx.y, r0 = blockIdx.x * RT;
+    double2 keep0[KB], keep1[KB], keep2[KB];
+#pragma unroll
+    for (int q = 0; q < KB; ++q) keep0[q] = keep1[q] = keep2[q] = make_double2(0.0, 0.0);
+    {
+        const double2 *G = grids + ((size_t)(lb * 3 + 0) << (m1 + m2));
+        auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
+        auto store = [&](int, int, double2 v, int kb) {
+            if (kb < KB) keep0[kb < KB ? kb : 0] = v;
+        };
+        block_fft<LA, LB, false>(RT, lds2, load, store);
+    }
+    __syncthreads();
+    if (fit_mean) {
+        const double2 *G = grids + ((size_t)(lb * 3 + 1) << (m1 + m2));
+        auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
+        auto store = [&](int, int, double2 v, int kb) {
+            if (kb < KB) keep1[kb < KB ? kb : 0] = v;
+        };
+        block_fft<LA, LB, false>(RT, lds2, load, store);
+    }
+    __syncthreads();
+    {
+        const double2 *G = grids + ((size_t)(lb * 3 + 2) << (m1 + m2));
+        auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
+        auto store = [&](int, int, double2 v, int kb) {
+            if (kb < KB) keep2[kb < KB ? kb : 0] = v;
+        };
+        block_fft<LA, LB, false>(RT, lds2, load, store);
+    }
+    const int tid = threadIdx.x;
+    if (tid >= RT * A) return;
+    const int ka = tid / RT, f = tid - ka * RT;  // the phase-2 mapping of block_fft
+    const int b = b0 + lb;
+    const FastStats st = stats[b];
+    const double nn = (double)(n_off[b + 1] - n_off[b]);
+    const double sc = scale ? scale[b] : 1.0;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const long long k = (long long)(r0 + f) + ((long long)(ka + A * kb) << m1);
+        if (k >= M) continue;
+        double2 a = keep0[kb], bq = keep1[kb], c2 = keep2[kb];
+        if (st.t0 != 0.0) {
+            const double twopi = 6.283185307179586;
+            double s, c;
+            sincos(twopi * st.t0 * (f0 + df * (double)k), &s, &c);
+            a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+            bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
+            sincos(twopi * st.t0 * (2.0 * f0 + 2.0 * df * (double)k), &s, &c);
+            c2 = make_double2(c2.x * c - c2.y * s, c2.x * s + c2.y * c);
+        }
+        power[(size_t)b * (size_t)M + k] = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY,
+                                                          0.5 * st.wsum, nn, sc);
+    }
 }
 
 // closed form from the three spectra (C = real, S = imag of the unnormalised inverse transform)
@@ -551,6 +620,59 @@ static void launch_rows_t(int m1, int ngrids, const double2 *grids, int nkeep, d
     }
     hipLaunchKernelGGL((fft_rows_reg_kernel<LA, LB>), dim3(N1 / RT, ngrids), dim3(nt), (size_t)RT * FST * 16, stream,
                        grids, m1, RT, nkeep, spec);
+}
+
+struct FusedArgs {
+    const int64_t *n_off;
+    const FastStats *stats;
+    int b0;
+    double f0, df;
+    int64_t M;
+    int fit_mean, norm;
+    const double *scale;
+    double *power;
+};
+
+template <int LA, int LB, int KB>
+static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, hipStream_t stream) {
+    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
+    const int N1 = 1 << m1;
+    const int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
+    const int nt = ((RT * std::max(A, Bq) + 63) / 64) * 64;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_power_kernel<LA, LB, KB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((fft_rows_power_kernel<LA, LB, KB>), dim3(N1 / RT, ntargets), dim3(nt), (size_t)RT * FST * 16,
+                       stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm, a.scale,
+                       a.power);
+}
+
+// returns false if the (m2, outputs-per-thread) combination has no fused instantiation
+static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, hipStream_t stream) {
+    const int LA = (m2 + 1) / 2, Aa = 1 << LA;
+    const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
+    const int kb = (int)((k2need + Aa - 1) / Aa);
+    if (kb > 8) return false;
+#define LK_RP(la, lb)                                                                  \
+    if (kb <= 4)                                                                       \
+        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, stream);                \
+    else                                                                               \
+        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, stream);                \
+    return true;
+    switch (m2) {
+        case 4: LK_RP(2, 2)
+        case 5: LK_RP(3, 2)
+        case 6: LK_RP(3, 3)
+        case 7: LK_RP(4, 3)
+        case 8: LK_RP(4, 4)
+        case 9: LK_RP(5, 4)
+        case 10: LK_RP(5, 5)
+        default: return false;
+    }
+#undef LK_RP
 }
 
 static void launch_cols_reg(int m1, int m2, int ngrids, double2 *grids, const int *rows_used, hipStream_t stream) {
@@ -654,6 +776,8 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
                                d_grids, d_rows + (size_t)b0 * 4);
         if (reg_path) {
             launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, stream);
+            const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power};
+            if (!getenv("LK_FFT_UNFUSED") && launch_rows_power(m1, m2, nb, d_grids, fa, stream)) continue;
             launch_rows_reg(m1, m2, nb * 3, d_grids, (int)M, d_spec, stream);
         } else {
             hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * 3), dim3(256), ldsA, stream, d_grids, m1, m2, CT);
