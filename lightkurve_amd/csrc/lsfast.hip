@@ -393,14 +393,26 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 
 // Block transform of NF sequences of length n = 2^(LA+LB).  load(f, e) returns element e of sequence f;
 // store(f, k, value) receives output k.  tile: NF * A * (Bq + 1) double2 of LDS.  Threads needed: NF * max(A, Bq).
-template <int LA, int LB, bool F_FASTEST, class Load, class Store>
-__device__ __forceinline__ void block_fft(int NF, double2 *tile, Load load, Store store) {
+template <int LA, int LB, int MODE, class Load, class Store>
+__device__ __forceinline__ void block_fft(int NF, double2 *tile, Load load, Store store, int tw = 1) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int tid = threadIdx.x;
-    // phase 1: thread (f, j) transforms x[i*Bq + j], i < A.  F_FASTEST: neighbouring threads take neighbouring
-    // sequences (column transforms: sequences are adjacent in memory); otherwise neighbouring elements j
+    // phase 1: thread (f, j) transforms x[i*Bq + j], i < A.  Thread order, chosen for coalescing of load():
+    // MODE 0: j fastest (sequence elements are contiguous);  MODE 1: f fastest (sequences are adjacent in memory);
+    // MODE 2: (j % tw) fastest, then f, then j / tw (tiled intermediate layout: tw columns x all sequences)
     if (tid < NF * Bq) {
-        const int f = F_FASTEST ? tid % NF : tid / Bq, j = F_FASTEST ? tid / NF : tid % Bq;
+        int f, j;
+        if (MODE == 1) {
+            f = tid % NF;
+            j = tid / NF;
+        } else if (MODE == 2) {
+            const int jl = tid % tw, rest = tid / tw;
+            f = rest % NF;
+            j = jl + tw * (rest / NF);
+        } else {
+            f = tid / Bq;
+            j = tid % Bq;
+        }
         double2 v[A];
 #pragma unroll
         for (int i = 0; i < A; ++i) v[i] = load(f, i * Bq + j);
@@ -434,7 +446,8 @@ __device__ __forceinline__ void block_fft(int NF, double2 *tile, Load load, Stor
 // step 1 (register version): CT columns c0..c0+CT-1; rows >= rows_used[g] are known zeros and are not loaded
 template <int LA, int LB>
 __global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__ grids, int m2, int CT,
-                                                            const int *__restrict__ rows_used) {
+                                                            const int *__restrict__ rows_used,
+                                                            double2 *__restrict__ gout, int tw) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int m1 = LA + LB, A = 1 << LA;
     const int N2 = 1 << m2;
@@ -449,6 +462,7 @@ __global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__
     // k1 = ka + A kb, advances by e^{2 pi i c A / N} each time
     int last_f = -1;
     double2 w = make_double2(1.0, 0.0), step = w;
+    const int twl = 31 - __clz(tw);  // tw is a power of two
     auto store = [&](int f, int k1, double2 v, int) {
         const int c = c0 + f;
         if (f != last_f) {  // first output of this thread: k1 = ka
@@ -459,10 +473,15 @@ __global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__
             step = make_double2(cc, s);
             last_f = f;
         }
-        G[(size_t)k1 * N2 + c] = cmul(v, w);
+        // gout: separate buffer in the tiled layout [c / tw][k1][c % tw] (a workgroup's output is one contiguous
+        // run and step 2 reads 16 B x tw x RT runs); otherwise in place in the natural layout
+        if (gout)
+            gout[((size_t)blockIdx.y << (m1 + m2)) + ((((size_t)(c >> twl) << m1) + k1) << twl) + (c & (tw - 1))] = cmul(v, w);
+        else
+            G[(size_t)k1 * N2 + c] = cmul(v, w);
         w = cmul(w, step);
     };
-    block_fft<LA, LB, true>(CT, lds2, load, store);
+    block_fft<LA, LB, 1>(CT, lds2, load, store);
 }
 
 // step 2 (register version): RT rows r0..r0+RT-1, outputs k = k1 + N1 k2 < nkeep kept
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(256) void fft_rows_reg_kernel(const double2 *__rest
         const long long k = (long long)(r0 + f) + ((long long)k2 << m1);
         if (k < nkeep) S[k] = v;
     };
-    block_fft<LA, LB, false>(RT, lds2, load, store);
+    block_fft<LA, LB, 0>(RT, lds2, load, store);
 }
 
 // step 2 fused with the closed form: one workgroup transforms rows r0..r0+RT-1 of the THREE grids of a target in
@@ -492,39 +511,55 @@ __global__ __launch_bounds__(256) void fft_rows_power_kernel(const double2 *__re
                                                               const FastStats *__restrict__ stats, int b0, double f0,
                                                               double df, int64_t M, int fit_mean, int norm,
                                                               const double *__restrict__ scale,
-                                                              double *__restrict__ power) {
+                                                              double *__restrict__ power, int tw) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int m2 = LA + LB, A = 1 << LA;
     const int N2 = 1 << m2;
+    const int twl = tw ? 31 - __clz(tw) : 0;
     const int lb = blockIdx.y, r0 = blockIdx.x * RT;
     double2 keep0[KB], keep1[KB], keep2[KB];
 #pragma unroll
     for (int q = 0; q < KB; ++q) keep0[q] = keep1[q] = keep2[q] = make_double2(0.0, 0.0);
     {
         const double2 *G = grids + ((size_t)(lb * 3 + 0) << (m1 + m2));
-        auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
+        auto load = [&](int f, int c) -> double2 {
+            return tw ? G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
+        };
         auto store = [&](int, int, double2 v, int kb) {
             if (kb < KB) keep0[kb < KB ? kb : 0] = v;
         };
-        block_fft<LA, LB, false>(RT, lds2, load, store);
+        if (tw)
+            block_fft<LA, LB, 2>(RT, lds2, load, store, tw);
+        else
+            block_fft<LA, LB, 0>(RT, lds2, load, store);
     }
     __syncthreads();
     if (fit_mean) {
         const double2 *G = grids + ((size_t)(lb * 3 + 1) << (m1 + m2));
-        auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
+        auto load = [&](int f, int c) -> double2 {
+            return tw ? G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
+        };
         auto store = [&](int, int, double2 v, int kb) {
             if (kb < KB) keep1[kb < KB ? kb : 0] = v;
         };
-        block_fft<LA, LB, false>(RT, lds2, load, store);
+        if (tw)
+            block_fft<LA, LB, 2>(RT, lds2, load, store, tw);
+        else
+            block_fft<LA, LB, 0>(RT, lds2, load, store);
     }
     __syncthreads();
     {
         const double2 *G = grids + ((size_t)(lb * 3 + 2) << (m1 + m2));
-        auto load = [&](int f, int c) -> double2 { return G[(size_t)(r0 + f) * N2 + c]; };
+        auto load = [&](int f, int c) -> double2 {
+            return tw ? G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
+        };
         auto store = [&](int, int, double2 v, int kb) {
             if (kb < KB) keep2[kb < KB ? kb : 0] = v;
         };
-        block_fft<LA, LB, false>(RT, lds2, load, store);
+        if (tw)
+            block_fft<LA, LB, 2>(RT, lds2, load, store, tw);
+        else
+            block_fft<LA, LB, 0>(RT, lds2, load, store);
     }
     const int tid = threadIdx.x;
     if (tid >= RT * A) return;
@@ -591,7 +626,8 @@ __global__ __launch_bounds__(256) void lsf_zero_kernel(double2 *__restrict__ gri
 }
 
 template <int LA, int LB>
-static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_used, hipStream_t stream) {
+static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_used, double2 *gout, int tw,
+                          hipStream_t stream) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N2 = 1 << m2;
     const int CT = std::max(1, std::min(N2, std::min(4096 / n, 256 / std::max(A, Bq))));
@@ -603,7 +639,15 @@ static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_us
         attr = true;
     }
     hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * FST * 16, stream,
-                       grids, m2, CT, rows_used);
+                       grids, m2, CT, rows_used, gout, tw);
+}
+
+// width of the tiled intermediate layout: the column kernel's CT, capped by the row kernel's Bq (both powers of 2)
+static int tile_width(int m1, int m2) {
+    const int la1 = (m1 + 1) / 2, lb1 = m1 / 2, n1 = 1 << m1;
+    const int ct = std::max(1, std::min(1 << m2, std::min(4096 / n1, 256 / std::max(1 << la1, 1 << lb1))));
+    const int bq2 = 1 << (m2 / 2);
+    return std::min(ct, bq2);
 }
 
 template <int LA, int LB>
@@ -634,7 +678,8 @@ struct FusedArgs {
 };
 
 template <int LA, int LB, int KB>
-static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, hipStream_t stream) {
+static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
+                                hipStream_t stream) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N1 = 1 << m1;
     const int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
@@ -647,20 +692,27 @@ static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, cons
     }
     hipLaunchKernelGGL((fft_rows_power_kernel<LA, LB, KB>), dim3(N1 / RT, ntargets), dim3(nt), (size_t)RT * FST * 16,
                        stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm, a.scale,
-                       a.power);
+                       a.power, tw);
 }
 
 // returns false if the (m2, outputs-per-thread) combination has no fused instantiation
-static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, hipStream_t stream) {
+static bool rows_power_available(int m1, int m2, int64_t M) {
+    const int LA = (m2 + 1) / 2, Aa = 1 << LA;
+    const long long k2need = (M + ((long long)1 << m1) - 1) >> m1;
+    return m2 >= 4 && m2 <= 10 && (k2need + Aa - 1) / Aa <= 8;
+}
+
+static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
+                              hipStream_t stream) {
     const int LA = (m2 + 1) / 2, Aa = 1 << LA;
     const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
     const int kb = (int)((k2need + Aa - 1) / Aa);
     if (kb > 8) return false;
 #define LK_RP(la, lb)                                                                  \
     if (kb <= 4)                                                                       \
-        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, stream);                \
+        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, tw, stream);            \
     else                                                                               \
-        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, stream);                \
+        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, tw, stream);            \
     return true;
     switch (m2) {
         case 4: LK_RP(2, 2)
@@ -675,15 +727,16 @@ static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids
 #undef LK_RP
 }
 
-static void launch_cols_reg(int m1, int m2, int ngrids, double2 *grids, const int *rows_used, hipStream_t stream) {
+static void launch_cols_reg(int m1, int m2, int ngrids, double2 *grids, const int *rows_used, double2 *gout, int tw,
+                            hipStream_t stream) {
     switch (m1) {
-        case 4: launch_cols_t<2, 2>(m2, ngrids, grids, rows_used, stream); break;
-        case 5: launch_cols_t<3, 2>(m2, ngrids, grids, rows_used, stream); break;
-        case 6: launch_cols_t<3, 3>(m2, ngrids, grids, rows_used, stream); break;
-        case 7: launch_cols_t<4, 3>(m2, ngrids, grids, rows_used, stream); break;
-        case 8: launch_cols_t<4, 4>(m2, ngrids, grids, rows_used, stream); break;
-        case 9: launch_cols_t<5, 4>(m2, ngrids, grids, rows_used, stream); break;
-        default: launch_cols_t<5, 5>(m2, ngrids, grids, rows_used, stream); break;
+        case 4: launch_cols_t<2, 2>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
+        case 5: launch_cols_t<3, 2>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
+        case 6: launch_cols_t<3, 3>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
+        case 7: launch_cols_t<4, 3>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
+        case 8: launch_cols_t<4, 4>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
+        case 9: launch_cols_t<5, 4>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
+        default: launch_cols_t<5, 5>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
     }
 }
 
@@ -737,7 +790,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
-                           (size_t)Bc * 3 * nfft * 16 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 + 8192);
+                           (size_t)Bc * 3 * nfft * 16 * 2 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
@@ -755,6 +808,10 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         attr_set = true;
     }
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10 && !getenv("LK_FFT_RADIX2");
+    const bool fused = reg_path && !getenv("LK_FFT_UNFUSED") && rows_power_available(m1, m2, M);
+    const int tw = tile_width(m1, m2);
+    double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16) : nullptr;
+    LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
                        d_w, d_wy, d_stats, df, nfft, m2, d_rows);
@@ -775,9 +832,14 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
                                dim3(256), 0, stream, t, d_w, d_wy, d_off, d_stats, b0, f0, df, nfft, m2, fit_mean,
                                d_grids, d_rows + (size_t)b0 * 4);
         if (reg_path) {
-            launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, stream);
             const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power};
-            if (!getenv("LK_FFT_UNFUSED") && launch_rows_power(m1, m2, nb, d_grids, fa, stream)) continue;
+            if (fused) {
+                // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
+                launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
+                launch_rows_power(m1, m2, nb, d_grids2, fa, tw, stream);
+                continue;
+            }
+            launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, nullptr, 1, stream);
             launch_rows_reg(m1, m2, nb * 3, d_grids, (int)M, d_spec, stream);
         } else {
             hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * 3), dim3(256), ldsA, stream, d_grids, m1, m2, CT);
