@@ -443,9 +443,74 @@ __device__ __forceinline__ void block_fft(int NF, double2 *tile, Load load, Stor
     }
 }
 
+// Same transform with the LDS exchange done in two halves (real parts, then imaginary parts): the tile is
+// NF * (A * (Bq + 1) + pad) doubles — half the footprint, so twice the workgroups fit a CU — at the price of two more
+// barriers.  A thread holds im(v) (A doubles) and re(u) (Bq doubles) across the exchange, no more than v or u alone.
+// pad = 32 / NF doubles keeps the f-fastest phase-2 reads and phase-1 writes on distinct banks.
+template <int LA, int LB, int MODE, class Load, class Store>
+__device__ __forceinline__ void block_fft_split(int NF, double *tile, Load load, Store store, int tw = 1) {
+    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1;
+    const int FST = A * LDT + (NF >= 32 ? 1 : 32 / NF);
+    const int tid = threadIdx.x;
+    const bool p1 = tid < NF * Bq, p2 = tid < NF * A;
+    int f = 0, j = 0;
+    if (MODE == 1) {
+        f = tid % NF;
+        j = tid / NF;
+    } else if (MODE == 2) {
+        const int jl = tid % tw, rest = tid / tw;
+        f = rest % NF;
+        j = jl + tw * (rest / NF);
+    } else {
+        f = tid / Bq;
+        j = tid % Bq;
+    }
+    double2 v[A];
+    if (p1) {
+#pragma unroll
+        for (int i = 0; i < A; ++i) v[i] = load(f, i * Bq + j);
+        reg_fft<LA>(v);
+        double s1, c1;
+        sincospi(2.0 * (double)j / (double)n, &s1, &c1);
+        const double2 step = make_double2(c1, s1);
+        double2 w = make_double2(1.0, 0.0);
+#pragma unroll
+        for (int ka = 0; ka < A; ++ka) {
+            v[brev_c(ka, LA)] = cmul(v[brev_c(ka, LA)], w);
+            w = cmul(w, step);
+        }
+    }
+    double *row1 = tile + (size_t)f * FST + j;
+    const int ka2 = tid / NF, f2 = tid - ka2 * NF;
+    const double *row2 = tile + (size_t)f2 * FST + (size_t)ka2 * LDT;
+    double2 u[Bq];
+    if (p1) {
+#pragma unroll
+        for (int ka = 0; ka < A; ++ka) row1[ka * LDT] = v[brev_c(ka, LA)].x;
+    }
+    __syncthreads();
+    if (p2) {
+#pragma unroll
+        for (int q = 0; q < Bq; ++q) u[q].x = row2[q];
+    }
+    __syncthreads();
+    if (p1) {
+#pragma unroll
+        for (int ka = 0; ka < A; ++ka) row1[ka * LDT] = v[brev_c(ka, LA)].y;
+    }
+    __syncthreads();
+    if (p2) {
+#pragma unroll
+        for (int q = 0; q < Bq; ++q) u[q].y = row2[q];
+        reg_fft<LB>(u);
+#pragma unroll
+        for (int kb = 0; kb < Bq; ++kb) store(f2, ka2 + A * kb, u[brev_c(kb, LB)], kb);
+    }
+}
+
 // step 1 (register version): CT columns c0..c0+CT-1; rows >= rows_used[g] are known zeros and are not loaded
-template <int LA, int LB>
-__global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__ grids, int m2, int CT,
+template <int LA, int LB, bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double2 *__restrict__ grids, int m2, int CT,
                                                             const int *__restrict__ rows_used,
                                                             double2 *__restrict__ gout, int tw) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
@@ -481,7 +546,10 @@ __global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__
             G[(size_t)k1 * N2 + c] = cmul(v, w);
         w = cmul(w, step);
     };
-    block_fft<LA, LB, 1>(CT, lds2, load, store);
+    if (SPLIT)
+        block_fft_split<LA, LB, 1>(CT, reinterpret_cast<double *>(lds2), load, store);
+    else
+        block_fft<LA, LB, 1>(CT, lds2, load, store);
 }
 
 // step 2 (register version): RT rows r0..r0+RT-1, outputs k = k1 + N1 k2 < nkeep kept
@@ -632,14 +700,23 @@ static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_us
     const int N2 = 1 << m2;
     const int CT = std::max(1, std::min(N2, std::min(4096 / n, 256 / std::max(A, Bq))));
     const int nt = ((CT * std::max(A, Bq) + 63) / 64) * 64;
+    static const bool split = getenv("LK_FFT_SPLIT") ? atoi(getenv("LK_FFT_SPLIT")) != 0 : false;  // measured 4 % slower (spills at 2 waves/SIMD)
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * FST * 16, stream,
-                       grids, m2, CT, rows_used, gout, tw);
+    if (split) {
+        const int fsts = A * LDT + (CT >= 32 ? 1 : 32 / CT);
+        hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB, true>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * fsts * 8,
+                           stream, grids, m2, CT, rows_used, gout, tw);
+    } else {
+        hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB, false>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * FST * 16,
+                           stream, grids, m2, CT, rows_used, gout, tw);
+    }
 }
 
 // width of the tiled intermediate layout: the column kernel's CT, capped by the row kernel's Bq (both powers of 2)
