@@ -32,7 +32,7 @@
 namespace lk {
 
 struct BlsStats {
-    double min_t, sum_y, sum_ivar, pad;
+    double min_t, sum_y, sum_ivar, sorted;  // sorted: 1.0 if the target's times never decrease
 };
 
 // ------------------------------------------------------------------------------------------------ prep
@@ -56,10 +56,13 @@ __global__ __launch_bounds__(256) void bls_prep_kernel(const double *__restrict_
     }
     const double min_t = sh[0];
     __syncthreads();
+    int unsorted = 0;
     for (int64_t i = tid; i < n; i += 256) {
         tm[lo + i] = t[lo + i] - min_t;
         yw[lo + i] = y[lo + i] * ivar[lo + i];
+        if (i + 1 < n && !(t[lo + i] <= t[lo + i + 1])) unsorted = 1;
     }
+    unsorted = __syncthreads_or(unsorted);
     if (tid == 0) {
         double s = 0.0;
         for (int64_t i = 0; i < n; ++i) s += y[lo + i] * ivar[lo + i];
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void bls_prep_kernel(const double *__restrict_
         sh[1] = s;
     }
     __syncthreads();
-    if (tid == 0) stats[b] = BlsStats{min_t, sh[0], sh[1], 0.0};
+    if (tid == 0) stats[b] = BlsStats{min_t, sh[0], sh[1], unsorted ? 0.0 : 1.0};
 }
 
 // exact k = trunc(t/P), r = fmod(t, P) for t >= 0, P > 0 (fmod results are always representable, so the
@@ -115,7 +118,7 @@ struct BlsBest {
 __global__ __launch_bounds__(1024) void bls_kernel(
     const double *__restrict__ tm, const double *__restrict__ yw, const double *__restrict__ ivar,
     const int64_t *__restrict__ n_off, const BlsStats *__restrict__ stats, const double *__restrict__ period,
-    const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_bins, int n_dur,
+    const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur,
     double bin_duration, int oversample, int obj_flag, double *__restrict__ out7, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS is dynamic: keeps the base 16-B aligned
 
@@ -143,7 +146,15 @@ __global__ __launch_bounds__(1024) void bls_kernel(
     int *rstart = reinterpret_cast<int *>(after + (size_t)NT * sizeof(BlsBest));  // [BLS_RMAX + 4]
     int *s_cnt = rstart + (BLS_RMAX + 4);                                       // [16]
     long long *s_thr = reinterpret_cast<long long *>(s_cnt + 16);               // 8-B aligned
-    int *segs = s_cnt + 20;                                                     // [(NW-1) * rmax] <= BLS_RSEG
+    long long *s_red = reinterpret_cast<long long *>(s_cnt + 18);               // gmax, wmax (bit patterns), yabs (double)
+    int *segs = s_cnt + 32;                                                     // [(NW-1) * rmax] <= BLS_RSEG
+    // duration tables (sorted ascending by length): dur_bins[k] (k = n_dur: a sentinel no window fits), the caller's
+    // index korig[k] (tie-break order) and first_kd[L] = k | dur_bins[k] << 16 for the first k with dur_bins[k] >= L,
+    // L = 0 .. max_dur + 1
+    int *dur_bins = segs + BLS_RSEG;
+    int *korig = dur_bins + n_dur + 1;
+    int *first_kd = korig + n_dur;
+    for (int i = tid; i < 2 * n_dur + 1 + max_dur + 2; i += blockDim.x) dur_bins[i] = dur_tab[i];
 
     for (int i = tid; i <= n_bins; i += NT) bins[i] = make_double2(0.0, 0.0);
 
@@ -177,23 +188,55 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         }
         return found;
     };
-    {
-        const int cnt = sweep(-1);
-        if (lane == 0) s_cnt[wave] = cnt;
-    }
-    __syncthreads();
-    int wbase = 1;  // round 0 starts at cadence 0
-    for (int w = 0; w < wave; ++w) wbase += s_cnt[w];
+    // Time-sorted targets (the common case; flagged by bls_prep_kernel): inside one cycle k the phase r = t - k P
+    // grows with the cadence index, so the rounds are exactly the runs of equal k and round k starts at the first
+    // cadence with floor(t / P) >= k — one binary search per round instead of two sweeps over all cadences.
+    const bool tsorted = stats[target].sorted != 0.0 && !(ablate & 16);
     int nrounds = 1;
-    for (int w = 0; w < NW; ++w) nrounds += s_cnt[w];
-    const bool serial = nrounds > rmax;
-    if (tid == 0) {
-        *s_thr = __double_as_longlong(-INFINITY);
-        rstart[0] = 0;
-        if (!serial) rstart[nrounds] = N;
+    bool serial = false;
+    if (tsorted) {
+        double kl, rl;
+        fold_exact(tm[N - 1], P, invP, &kl, &rl);
+        serial = !(kl + 1.0 <= (double)rmax);
+        nrounds = serial ? 1 : (int)kl + 1;
+        if (!serial)
+            for (int q = tid; q <= nrounds; q += NT) {
+                int lo_i = 0, hi_i = N;  // first i with k_i >= q (q = nrounds: N)
+                while (lo_i < hi_i) {
+                    const int mid = (lo_i + hi_i) >> 1;
+                    double k, r;
+                    fold_exact(tm[mid], P, invP, &k, &r);
+                    if (k < (double)q)
+                        lo_i = mid + 1;
+                    else
+                        hi_i = mid;
+                }
+                rstart[q] = lo_i;
+            }
+        if (tid == 0) {
+            *s_thr = __double_as_longlong(-INFINITY);
+            s_red[0] = s_red[1] = s_red[2] = 0;
+        }
+        __syncthreads();
+    } else {
+        {
+            const int cnt = sweep(-1);
+            if (lane == 0) s_cnt[wave] = cnt;
+        }
+        __syncthreads();
+        int wbase = 1;  // round 0 starts at cadence 0
+        for (int w = 0; w < wave; ++w) wbase += s_cnt[w];
+        for (int w = 0; w < NW; ++w) nrounds += s_cnt[w];
+        serial = nrounds > rmax;
+        if (tid == 0) {
+            *s_thr = __double_as_longlong(-INFINITY);
+            s_red[0] = s_red[1] = s_red[2] = 0;
+            rstart[0] = 0;
+            if (!serial) rstart[nrounds] = N;
+        }
+        if (!serial && !(ablate & 8)) (void)sweep(wbase);
+        __syncthreads();
     }
-    if (!serial && !(ablate & 8)) (void)sweep(wbase);
-    __syncthreads();
 
     // ---- pass B: ordered histogram
     if (ablate & 1) {
@@ -233,42 +276,69 @@ __global__ __launch_bounds__(1024) void bls_kernel(
             segs[q] = lo_i;
         }
         __syncthreads();
-        for (int rd = 0; rd < nrounds; ++rd) {
-            const int s0 = (wave == 0) ? rstart[rd] : segs[nb1 * rd + wave - 1];
-            const int s1 = (wave == NW - 1) ? rstart[rd + 1] : segs[nb1 * rd + wave];
-            for (int i0 = s0; i0 < s1; i0 += 64) {
-                const int i = i0 + lane;
-                const bool act = i < s1;
-                int ind = -1 - lane;  // inactive lanes: unique negatives, never equal to a neighbour
-                double vy = 0.0, vi = 0.0;
-                if (act) {
-                    double k, r;
-                    fold_exact(tm[i], P, invP, &k, &r);
-                    ind = bin_of_fast(r, bin_duration, inv_bd);
-                    vy = yw[i];
-                    vi = ivar[i];
-                }
-                const int indp = __shfl_up(ind, 1);
-                const bool leader = act && (lane == 0 || ind != indp);
-                // the leader of a run folds the run's members into its bin one by one (reference order)
-                double2 v = make_double2(0.0, 0.0);
-                if (leader) {
-                    v = bins[ind];
-                    v.x += vy;
-                    v.y += vi;
-                }
-                for (int d = 1; d < 64; ++d) {
-                    const int indd = __shfl_down(ind, d);
-                    const bool more = leader && (lane + d < 64) && (indd == ind);
-                    if (!__any(more)) break;
-                    const double my = __shfl_down(vy, d), mi = __shfl_down(vi, d);
-                    if (more) {
-                        v.x += my;
-                        v.y += mi;
-                    }
-                }
-                if (leader) bins[ind] = v;
+        // (round, 64-cadence chunk) pairs of this wave are walked as one flat sequence so the next chunk's three
+        // global loads are in flight while the current one is folded into the bins
+        double2 *stage = reinterpret_cast<double2 *>(s_best) + (wave << 6);
+        int rd = -1, i0 = 0, s1 = 0;  // wave-uniform cursor
+        auto advance = [&]() {
+            i0 += 64;
+            while (i0 >= s1) {
+                if (++rd >= nrounds) return false;
+                i0 = (wave == 0) ? rstart[rd] : segs[nb1 * rd + wave - 1];
+                s1 = (wave == NW - 1) ? rstart[rd + 1] : segs[nb1 * rd + wave];
             }
+            return true;
+        };
+        bool have = advance();
+        double c_t = 0.0, c_y = 0.0, c_w = 0.0;
+        bool c_act = false;
+        if (have) {
+            c_act = i0 + lane < s1;
+            if (c_act) {
+                c_t = tm[i0 + lane];
+                c_y = yw[i0 + lane];
+                c_w = ivar[i0 + lane];
+            }
+        }
+        while (have) {
+            const bool act = c_act;
+            const double tv = c_t, vy = act ? c_y : 0.0, vi = act ? c_w : 0.0;
+            have = advance();
+            if (have) {
+                c_act = i0 + lane < s1;
+                if (c_act) {
+                    c_t = tm[i0 + lane];
+                    c_y = yw[i0 + lane];
+                    c_w = ivar[i0 + lane];
+                }
+            }
+            int ind = -1 - lane;  // inactive lanes: unique negatives, never equal to a neighbour
+            if (act) {
+                double k, r;
+                fold_exact(tv, P, invP, &k, &r);
+                ind = bin_of_fast(r, bin_duration, inv_bd);
+            }
+            // lane - 1's bin by a DPP wave shift (no LDS round trip); lane 0 keeps its own value and is a leader anyway
+            const int indp = __builtin_amdgcn_update_dpp(ind, ind, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const bool leader = act && (lane == 0 || ind != indp);
+            // the leader of a run folds the run's members into its bin one by one (reference order); the members'
+            // values are parked in this wave's 64 slots of s_best (free until the final reduction)
+            const unsigned long long lead = __ballot(leader || !act);
+            stage[lane] = make_double2(vy, vi);
+            double2 v = make_double2(0.0, 0.0);
+            if (leader) {
+                const unsigned long long above = lane < 63 ? (lead >> (lane + 1)) : 0ull;
+                const int run = above ? __ffsll((long long)above) : 64 - lane;  // members incl. the leader
+                v = bins[ind];
+                v.x += vy;
+                v.y += vi;
+                for (int c = 1; c < run; ++c) {
+                    const double2 mv = stage[lane + c];
+                    v.x += mv.x;
+                    v.y += mv.y;
+                }
+            }
+            if (leader) bins[ind] = v;
         }
         __syncthreads();
     }
@@ -279,6 +349,29 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         for (int q = 1 + tid; q <= oversample; q += NT) bins[n_bins - oversample + q - 1] = bins[q];
     } else if (tid == 0) {
         for (int q = 1; q <= oversample; ++q) bins[n_bins - oversample + q - 1] = bins[q];
+    }
+    __syncthreads();
+    // constants of the scan's skip bound, from the per-bin sums while they are still per-bin
+    const BlsStats st = stats[target];
+    const double sum_y = st.sum_y, sum_ivar = st.sum_ivar;
+    {
+        double g = 0.0, wm = 0.0, ya = 0.0;
+        for (int i = 1 + tid; i <= n_bins; i += NT) {
+            const double2 v = bins[i];
+            g = fmax(g, fabs(sum_y * v.y - sum_ivar * v.x));
+            wm = fmax(wm, v.y);
+            ya += fabs(v.x);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            g = fmax(g, __shfl_xor(g, o));
+            wm = fmax(wm, __shfl_xor(wm, o));
+            ya += __shfl_xor(ya, o);
+        }
+        if (lane == 0) {
+            atomicMax(&s_red[0], __double_as_longlong(g));
+            atomicMax(&s_red[1], __double_as_longlong(wm));
+            atomicAdd(reinterpret_cast<double *>(&s_red[2]), ya * (1.0 + 1e-6));
+        }
     }
     __syncthreads();
     // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  Wave 0 does y,
@@ -314,67 +407,86 @@ __global__ __launch_bounds__(1024) void bls_kernel(
     // evaluated with an absolute slack eN >= every rounding the exact chain can commit, so a rejected candidate
     // is STRICTLY below the threshold and can never be the winner (ties always reach the exact path).  Survivors
     // (a handful per workgroup) run the reference's exact arithmetic, which alone decides the result.
-    const BlsStats st = stats[target];
-    const double sum_y = st.sum_y, sum_ivar = st.sum_ivar;
     double best = -INFINITY;
     int bk = -1, bn = -1;
-    for (int k = wave; k < ((ablate & 4) ? 0 : n_dur); k += NW) {
-        const int dur = dur_bins[k];
-        const int n_max = n_bins - dur;
-        const double thr_shared = __longlong_as_double(*s_thr);  // refreshed once per duration (filter only)
-        int n = lane;
-        double2 hi_n = make_double2(0.0, 0.0), lw_n = hi_n;
-        if (n <= n_max) {
-            hi_n = bins[n + dur];
-            lw_n = bins[n];
-        }
-        while (n <= n_max) {
-            const double2 hi = hi_n, lw = lw_n;
-            const int nc = n;
-            n += 64;
-            if (n <= n_max) {  // prefetch the next start bin before working on this one
-                hi_n = bins[n + dur];
-                lw_n = bins[n];
-            }
-            double y_in = hi.x - lw.x;
-            const double ivar_in = hi.y - lw.y;
-            double y_out = sum_y - y_in;
-            const double ivar_out = sum_ivar - ivar_in;
-            if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
-            {
-                const double thr = fmax(best, thr_shared);
-                const double ab = y_out * ivar_in, ce = y_in * ivar_out;
+    if (!(ablate & 4)) {
+        const double S = sum_y, E = sum_ivar;
+        const double gmax = __longlong_as_double(s_red[0]) * (1.0 + 1e-9);  // max_i |S w_i - E y_i|
+        const double wmax = __longlong_as_double(s_red[1]);                 // max_i w_i
+        const double yabs = __longlong_as_double(s_red[2]);                 // sum_i |y_i|
+        // |Nn computed from the rounded prefix sums - Nn of the real bin sums| is below ~n_bins eps E (|S| + yabs);
+        // 1e-9 leaves four orders of magnitude
+        const double slack = 1e-9 * E * (fabs(S) + yabs);
+        const int dmin = dur_bins[0];
+        for (int n = tid; n + dmin <= n_bins; n += NT) {
+            const double2 lw = bins[n];
+            int k = 0, dur_k = dmin;  // dur_k == dur_bins[k] (the sentinel once k == n_dur)
+            while (n + dur_k <= n_bins) {  // durations ascend: once one overruns, every later one does too
+                const int dur = dur_k, kc = k;
+                const double2 hi = bins[n + dur];
+                dur_k = dur_bins[++k];
+                const double thr = fmax(best, __longlong_as_double(*s_thr));
+                double y_in = hi.x - lw.x;
+                const double ivar_in = hi.y - lw.y;
+                const double ivar_out = E - ivar_in;
+                if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
+                // Nn = y_out ivar_in - y_in ivar_out = S ivar_in - E y_in in real arithmetic
+                const double ab = S * ivar_in, ce = E * y_in;
                 const double Nn = ab - ce;
                 const double eN = (fabs(ab) + fabs(ce)) * 1e-15;
-                if (Nn + eN < 0.0) continue;  // certainly y_out < y_in
-                const double m = fabs(Nn) + eN;
-                double lhs, rhs;
-                if (obj_flag) {
-                    lhs = 0.5 * m * m;
-                    rhs = thr * ivar_in * ivar_out * ivar_out;
-                } else {
-                    lhs = m * m;
-                    rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
+                // ---- how many more bins this window may grow before it could reach thr: growing by one bin moves
+                //      Nn by at most gmax, ivar_in only up, ivar_out down by at most wmax
+                if (thr > 0.0 && !(ablate & 64)) {
+                    double mf;
+                    if (obj_flag) {
+                        const double q = __builtin_amdgcn_sqrt(2.0 * thr * ivar_in) * (1.0 - 1e-4);
+                        mf = (q * ivar_out - Nn - slack) * __builtin_amdgcn_rcp(gmax + q * wmax) * (1.0 - 1e-4) - 1.0;
+                    } else {
+                        const double e_lo = ivar_out - 64.0 * wmax;
+                        const double q = thr * __builtin_amdgcn_sqrt(ivar_in * e_lo * E) * (1.0 - 1e-4);
+                        mf = e_lo > 0.0 ? fmin((q - Nn - slack) * __builtin_amdgcn_rcp(gmax) * (1.0 - 1e-4) - 1.0, 64.0) : 0.0;
+                    }
+                    if (mf >= 1.0) {
+                        const int m = (int)fmin(mf, 1.0e6);
+                        const int kd = first_kd[min(dur + m, max_dur) + 1];  // >= kc + 1 since dur_bins[kc] < dur + m + 1
+                        k = kd & 0xffff;
+                        dur_k = (int)((unsigned)kd >> 16);
+                        continue;  // m >= 1 means this candidate itself is below thr as well
+                    }
                 }
-                if (lhs * (1.0 + 1e-12) < rhs) continue;  // certainly objective < thr
-                if ((ablate & 32) && best > -INFINITY) continue;  // profiling only: only the first survivor is evaluated
-            }
-            y_in /= ivar_in;
-            y_out /= ivar_out;
-            double obj;
-            if (obj_flag) {
-                const double arg = y_out - y_in;
-                obj = 0.5 * ivar_in * arg * arg;
-            } else {
-                const double depth = y_out - y_in;
-                const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
-                obj = depth / depth_err;
-            }
-            if (y_out >= y_in && obj > best) {
-                best = obj;
-                bk = k;
-                bn = nc;
-                atomicMax(s_thr, __double_as_longlong(obj));  // obj >= 0 here: the bit pattern orders like the value
+                if (Nn + eN < 0.0) continue;  // certainly y_out < y_in
+                {
+                    const double m = fabs(Nn) + eN;
+                    double lhs, rhs;
+                    if (obj_flag) {
+                        lhs = 0.5 * m * m;
+                        rhs = thr * ivar_in * ivar_out * ivar_out;
+                    } else {
+                        lhs = m * m;
+                        rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
+                    }
+                    if (lhs * (1.0 + 1e-12) < rhs) continue;  // certainly objective < thr
+                }
+                double y_out = S - y_in;
+                y_in /= ivar_in;
+                y_out /= ivar_out;
+                double obj;
+                if (obj_flag) {
+                    const double arg = y_out - y_in;
+                    obj = 0.5 * ivar_in * arg * arg;
+                } else {
+                    const double depth = y_out - y_in;
+                    const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+                    obj = depth / depth_err;
+                }
+                // the reference keeps the FIRST best in (caller's duration index, start bin) order
+                if (y_out >= y_in &&
+                    (obj > best || (obj == best && (korig[kc] < korig[bk] || (kc == bk && n < bn))))) {
+                    best = obj;
+                    bk = kc;
+                    bn = n;
+                    atomicMax(s_thr, __double_as_longlong(obj));  // obj >= 0 here: the bit pattern orders like the value
+                }
             }
         }
     }
@@ -384,7 +496,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         if (tid < s) {
             const BlsBest o = s_best[tid + s], m = s_best[tid];
             const bool take = o.k >= 0 && (m.k < 0 || o.obj > m.obj ||
-                                            (o.obj == m.obj && (o.k < m.k || (o.k == m.k && o.n < m.n))));
+                                            (o.obj == m.obj && (korig[o.k] < korig[m.k] || (o.k == m.k && o.n < m.n))));
             if (take) s_best[tid] = o;
         }
         __syncthreads();
@@ -461,32 +573,55 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         const int d = (int)(std::round(duration_host[k] / bin_duration));
         if (std::find(dur_bins.begin(), dur_bins.end(), d) == dur_bins.end()) dur_bins.push_back(d);
     }
+    // scan tables: durations sorted by length (the kernel's skip-ahead walks them in ascending order), the caller's
+    // index of each (the reference's tie-break order), and first_k[L] = first sorted k with dur_bins[k] >= L
+    const int nd = (int)dur_bins.size();
+    std::vector<int> sidx((size_t)nd);
+    std::iota(sidx.begin(), sidx.end(), 0);
+    std::stable_sort(sidx.begin(), sidx.end(), [&](int a, int b) { return dur_bins[a] < dur_bins[b]; });
+    const int max_dur = dur_bins[sidx[nd - 1]];
+    LK_REQUIRE(dur_bins[sidx[0]] >= 1, "Invalid inputs for period and/or duration (a duration shorter than half a bin)");
+    LK_REQUIRE(nd < 65535 && max_dur < 65535, "too many / too long durations for the packed duration table");
+    std::vector<int> dur_tab((size_t)(2 * nd + 1 + max_dur + 2));
+    for (int k = 0; k < nd; ++k) {
+        dur_tab[k] = dur_bins[sidx[k]];
+        dur_tab[nd + 1 + k] = sidx[k];
+    }
+    dur_tab[nd] = 0xffff;  // sentinel: longer than any bin array the LDS plan admits
+    for (int L = 0, k = 0; L <= max_dur + 1; ++L) {
+        while (k < nd && dur_tab[k] < L) ++k;
+        dur_tab[2 * nd + 1 + L] = (int)((unsigned)k | ((unsigned)dur_tab[k] << 16));
+    }
+    const size_t tab_bytes = ((dur_tab.size() * 4 + 15) / 16) * 16;
+    LK_REQUIRE(tab_bytes <= 24 * 1024, "%d durations up to %d bins: the LDS plan holds 24 KB of duration tables", nd, max_dur);
     // periods grouped by LDS need (n_bins), longest first
     std::vector<int> order((size_t)nP);
     std::iota(order.begin(), order.end(), 0);
     auto nbins_of = [&](int p) { return (int)(std::ceil(period_host[p] / bin_duration)) + oversample; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return period_host[a] > period_host[b]; });
     const int max_bins = nbins_of(order[0]);
-    auto lds_fixed_of = [](int nt) { return (size_t)nt * sizeof(BlsBest) + (size_t)(BLS_RMAX + 4) * 4 + 20 * 4 + (size_t)BLS_RSEG * 4; };
+    auto lds_fixed_of = [&](int nt) {
+        return (size_t)nt * sizeof(BlsBest) + (size_t)(BLS_RMAX + 4) * 4 + 32 * 4 + (size_t)BLS_RSEG * 4 + tab_bytes;
+    };
     const size_t lds_fixed = lds_fixed_of(1024);
     const size_t lds_max = (size_t)(max_bins + 1) * 16 + lds_fixed;
-    LK_REQUIRE(lds_max <= 150 * 1024,
+    LK_REQUIRE(lds_max <= 156 * 1024,
                "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most %d", max_bins,
-               (int)((150 * 1024 - lds_fixed) / 16 - 1));
+               (int)((156 * 1024 - lds_fixed) / 16 - 1));
 
     const size_t ntot = (size_t)n_off_host[B];
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(BlsStats) + 2 * (ntot * 8 + 256) +
-                           (size_t)nP * 4 + dur_bins.size() * 4 + 4096);
+                           (size_t)nP * 4 + dur_tab.size() * 4 + 4096);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     BlsStats *d_stats = (BlsStats *)h->ws.alloc((size_t)B * sizeof(BlsStats));
     double *d_tm = (double *)h->ws.alloc(ntot * 8), *d_yw = (double *)h->ws.alloc(ntot * 8);
     int *d_pidx = (int *)h->ws.alloc((size_t)nP * 4);
-    int *d_dur = (int *)h->ws.alloc(dur_bins.size() * 4);
+    int *d_dur = (int *)h->ws.alloc(dur_tab.size() * 4);
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_pidx, order.data(), (size_t)nP * 4, hipMemcpyHostToDevice, stream));
-    LK_HIP_CHECK(hipMemcpyAsync(d_dur, dur_bins.data(), dur_bins.size() * 4, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_dur, dur_tab.data(), dur_tab.size() * 4, hipMemcpyHostToDevice, stream));
     // pageable-host async copies are staged before return, but be explicit: the vectors die at scope exit
     LK_HIP_CHECK(hipStreamSynchronize(stream));
 
@@ -515,7 +650,7 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)npg;
         LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
         hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, ivar, d_off,
-                           d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, (int)dur_bins.size(), bin_duration,
+                           d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration,
                            oversample, use_likelihood ? 1 : 0, out7, ablate);
         g0 = g1;
     }
