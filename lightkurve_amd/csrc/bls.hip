@@ -267,7 +267,10 @@ __global__ __launch_bounds__(1024) void bls_kernel(
             while (lo_i < hi_i) {
                 const int mid = (lo_i + hi_i) >> 1;
                 double k, r;
-                fold_exact(tm[mid], P, invP, &k, &r);
+                if (tsorted)
+                    r = fma(-(double)rd, P, tm[mid]);  // the round index IS the cycle number: exact remainder
+                else
+                    fold_exact(tm[mid], P, invP, &k, &r);
                 if (bin_of_fast(r, bin_duration, inv_bd) < bound)
                     lo_i = mid + 1;
                 else
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         while (have) {
             const bool act = c_act;
             const double tv = c_t, vy = act ? c_y : 0.0, vi = act ? c_w : 0.0;
+            const double kcur = (double)rd;  // cycle number of the chunk being folded (time-sorted targets)
             have = advance();
             if (have) {
                 c_act = i0 + lane < s1;
@@ -315,7 +319,10 @@ __global__ __launch_bounds__(1024) void bls_kernel(
             int ind = -1 - lane;  // inactive lanes: unique negatives, never equal to a neighbour
             if (act) {
                 double k, r;
-                fold_exact(tv, P, invP, &k, &r);
+                if (tsorted)
+                    r = fma(-kcur, P, tv);
+                else
+                    fold_exact(tv, P, invP, &k, &r);
                 ind = bin_of_fast(r, bin_duration, inv_bd);
             }
             // lane - 1's bin by a DPP wave shift (no LDS round trip); lane 0 keeps its own value and is a leader anyway
@@ -374,26 +381,29 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         }
     }
     __syncthreads();
-    // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  Wave 0 does y,
-    // wave 1 does ivar: 64 bins are fetched at once (one per lane) and the chain runs over v_readlane broadcasts,
-    // so no LDS round trip sits on the dependent-add path.  bins[0] is always (0, 0), so starting at i = 0 with
-    // acc = 0 is the same chain.
-    if (wave < 2 && !(ablate & 2)) {
+    // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  bins[0] is always
+    // (0, 0), so starting at i = 0 with acc = 0 is the same chain.
+    if (wave == 0 && lane < 2 && !(ablate & 2)) {
+        // lane 0 runs the y chain, lane 1 the ivar chain (same instruction stream, adjacent addresses): per bin one
+        // LDS read, one dependent add and one LDS write, eight bins in flight
         double acc = 0.0;
-        double *comp = reinterpret_cast<double *>(bins) + wave;  // .x for wave 0, .y for wave 1 (stride 2 doubles)
-        for (int base = 0; base <= n_bins; base += 64) {
-            const int i = base + lane;
-            const double x = (i <= n_bins) ? comp[2 * i] : 0.0;
-            double out = 0.0;
-            const int lo_bits = __double2loint(x), hi_bits = __double2hiint(x);
+        double *comp = reinterpret_cast<double *>(bins) + lane;  // .x for lane 0, .y for lane 1 (stride 2 doubles)
+        int i = 0;
+        for (; i + 8 <= n_bins + 1; i += 8) {
+            double x[8];
 #pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                const double sj = __hiloint2double(__builtin_amdgcn_readlane(hi_bits, j),
-                                                   __builtin_amdgcn_readlane(lo_bits, j));
-                acc = sj + acc;
-                if (lane == j) out = acc;
+            for (int u = 0; u < 8; ++u) x[u] = comp[2 * (i + u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc = x[u] + acc;
+                x[u] = acc;
             }
-            if (i <= n_bins) comp[2 * i] = out;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) comp[2 * (i + u)] = x[u];
+        }
+        for (; i <= n_bins; ++i) {
+            acc = comp[2 * i] + acc;
+            comp[2 * i] = acc;
         }
     }
     __syncthreads();
@@ -418,22 +428,76 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         // 1e-9 leaves four orders of magnitude
         const double slack = 1e-9 * E * (fabs(S) + yabs);
         const int dmin = dur_bins[0];
+        // conservative filter, then the reference's exact arithmetic; keeps the FIRST best in (caller's duration
+        // index, start bin) order
+        auto finish = [&](int n, int kc, double y_in, double ivar_in, double ivar_out, double Nn, double eN, double thr) {
+            if (Nn + eN < 0.0) return;  // certainly y_out < y_in
+            {
+                const double m = fabs(Nn) + eN;
+                double lhs, rhs;
+                if (obj_flag) {
+                    lhs = 0.5 * m * m;
+                    rhs = thr * ivar_in * ivar_out * ivar_out;
+                } else {
+                    lhs = m * m;
+                    rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
+                }
+                if (lhs * (1.0 + 1e-12) < rhs) return;  // certainly objective < thr
+            }
+            double y_out = S - y_in;
+            y_in /= ivar_in;
+            y_out /= ivar_out;
+            double obj;
+            if (obj_flag) {
+                const double arg = y_out - y_in;
+                obj = 0.5 * ivar_in * arg * arg;
+            } else {
+                const double depth = y_out - y_in;
+                const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+                obj = depth / depth_err;
+            }
+            if (y_out >= y_in &&
+                (obj > best || (obj == best && (korig[kc] < korig[bk] || (kc == bk && n < bn))))) {
+                best = obj;
+                bk = kc;
+                bn = n;
+                atomicMax(s_thr, __double_as_longlong(obj));  // obj >= 0 here: the bit pattern orders like the value
+            }
+        };
+        // ---- warm start: every 8th start bin x every 8th duration (1.6 % of the candidates) gives the walk below a
+        //      threshold close to the final best from its first step
+        if (!(ablate & 128)) {
+            const int cn = (n_bins - dmin) / 8 + 1, ck = (n_dur + 7) / 8;
+            for (int c = tid; c < cn * ck; c += NT) {
+                const int kc = (c / cn) * 8, n = (c - (c / cn) * cn) * 8;
+                const int dur = dur_bins[kc];
+                if (n + dur > n_bins) continue;
+                const double2 lw = bins[n], hi = bins[n + dur];
+                const double y_in = hi.x - lw.x, ivar_in = hi.y - lw.y, ivar_out = E - ivar_in;
+                if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
+                const double ab = S * ivar_in, ce = E * y_in;
+                finish(n, kc, y_in, ivar_in, ivar_out, ab - ce, (fabs(ab) + fabs(ce)) * 1e-15,
+                       fmax(best, __longlong_as_double(*s_thr)));
+            }
+            __syncthreads();
+        }
         for (int n = tid; n + dmin <= n_bins; n += NT) {
             const double2 lw = bins[n];
+            double thr_sh = __longlong_as_double(*s_thr);  // workgroup-wide best so far
             int k = 0, dur_k = dmin;  // dur_k == dur_bins[k] (the sentinel once k == n_dur)
             while (n + dur_k <= n_bins) {  // durations ascend: once one overruns, every later one does too
                 const int dur = dur_k, kc = k;
                 const double2 hi = bins[n + dur];
                 dur_k = dur_bins[++k];
-                const double thr = fmax(best, __longlong_as_double(*s_thr));
-                double y_in = hi.x - lw.x;
+                const double thr = fmax(best, thr_sh);  // one iteration stale: still a valid (lower) bound
+                thr_sh = __longlong_as_double(*s_thr);
+                const double y_in = hi.x - lw.x;
                 const double ivar_in = hi.y - lw.y;
                 const double ivar_out = E - ivar_in;
                 if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
                 // Nn = y_out ivar_in - y_in ivar_out = S ivar_in - E y_in in real arithmetic
                 const double ab = S * ivar_in, ce = E * y_in;
                 const double Nn = ab - ce;
-                const double eN = (fabs(ab) + fabs(ce)) * 1e-15;
                 // ---- how many more bins this window may grow before it could reach thr: growing by one bin moves
                 //      Nn by at most gmax, ivar_in only up, ivar_out down by at most wmax
                 if (thr > 0.0 && !(ablate & 64)) {
@@ -454,39 +518,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
                         continue;  // m >= 1 means this candidate itself is below thr as well
                     }
                 }
-                if (Nn + eN < 0.0) continue;  // certainly y_out < y_in
-                {
-                    const double m = fabs(Nn) + eN;
-                    double lhs, rhs;
-                    if (obj_flag) {
-                        lhs = 0.5 * m * m;
-                        rhs = thr * ivar_in * ivar_out * ivar_out;
-                    } else {
-                        lhs = m * m;
-                        rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
-                    }
-                    if (lhs * (1.0 + 1e-12) < rhs) continue;  // certainly objective < thr
-                }
-                double y_out = S - y_in;
-                y_in /= ivar_in;
-                y_out /= ivar_out;
-                double obj;
-                if (obj_flag) {
-                    const double arg = y_out - y_in;
-                    obj = 0.5 * ivar_in * arg * arg;
-                } else {
-                    const double depth = y_out - y_in;
-                    const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
-                    obj = depth / depth_err;
-                }
-                // the reference keeps the FIRST best in (caller's duration index, start bin) order
-                if (y_out >= y_in &&
-                    (obj > best || (obj == best && (korig[kc] < korig[bk] || (kc == bk && n < bn))))) {
-                    best = obj;
-                    bk = kc;
-                    bn = n;
-                    atomicMax(s_thr, __double_as_longlong(obj));  // obj >= 0 here: the bit pattern orders like the value
-                }
+                finish(n, kc, y_in, ivar_in, ivar_out, Nn, (fabs(ab) + fabs(ce)) * 1e-15, thr);
             }
         }
     }
