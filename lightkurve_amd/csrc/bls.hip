@@ -37,11 +37,11 @@ struct BlsStats {
 
 // ------------------------------------------------------------------------------------------------ prep
 // per target: min_t (exact), sum_y / sum_ivar accumulated SEQUENTIALLY (reference order), tm = t - min_t,
-// yw = y * ivar.
+// yw = (y * ivar, ivar) interleaved (one 16-B load per cadence in the histogram pass).
 __global__ __launch_bounds__(256) void bls_prep_kernel(const double *__restrict__ t, const double *__restrict__ y,
                                                         const double *__restrict__ ivar,
                                                         const int64_t *__restrict__ n_off,
-                                                        double *__restrict__ tm, double *__restrict__ yw,
+                                                        double *__restrict__ tm, double2 *__restrict__ yw,
                                                         BlsStats *__restrict__ stats) {
     __shared__ double sh[256];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void bls_prep_kernel(const double *__restrict_
     int unsorted = 0;
     for (int64_t i = tid; i < n; i += 256) {
         tm[lo + i] = t[lo + i] - min_t;
-        yw[lo + i] = y[lo + i] * ivar[lo + i];
+        yw[lo + i] = make_double2(y[lo + i] * ivar[lo + i], ivar[lo + i]);
         if (i + 1 < n && !(t[lo + i] <= t[lo + i + 1])) unsorted = 1;
     }
     unsorted = __syncthreads_or(unsorted);
@@ -116,7 +116,7 @@ struct BlsBest {
 };
 
 __global__ __launch_bounds__(1024) void bls_kernel(
-    const double *__restrict__ tm, const double *__restrict__ yw, const double *__restrict__ ivar,
+    const double *__restrict__ tm, const double2 *__restrict__ yw,
     const int64_t *__restrict__ n_off, const BlsStats *__restrict__ stats, const double *__restrict__ period,
     const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur,
     double bin_duration, int oversample, int obj_flag, double *__restrict__ out7, int ablate) {
@@ -135,7 +135,6 @@ __global__ __launch_bounds__(1024) void bls_kernel(
     const int N = (int)(n_off[target + 1] - lo);
     tm += lo;
     yw += lo;
-    ivar += lo;
 
     // LDS carve (every offset a multiple of 16): bins | s_best[NT] | rstart | s_cnt | s_thr | segs
     const int NT = blockDim.x, NW = NT >> 6;  // 4, 8 or 16 waves: big-LDS (long-period) groups get more waves
@@ -247,8 +246,8 @@ __global__ __launch_bounds__(1024) void bls_kernel(
                 fold_exact(tm[i], P, invP, &k, &r);
                 const int ind = bin_of(r, bin_duration);
                 double2 v = bins[ind];
-                v.x += yw[i];
-                v.y += ivar[i];
+                v.x += yw[i].x;
+                v.y += yw[i].y;
                 bins[ind] = v;
             }
         }
@@ -293,27 +292,26 @@ __global__ __launch_bounds__(1024) void bls_kernel(
             return true;
         };
         bool have = advance();
-        double c_t = 0.0, c_y = 0.0, c_w = 0.0;
+        double c_t = 0.0;
+        double2 c_yw = make_double2(0.0, 0.0);
         bool c_act = false;
         if (have) {
             c_act = i0 + lane < s1;
             if (c_act) {
                 c_t = tm[i0 + lane];
-                c_y = yw[i0 + lane];
-                c_w = ivar[i0 + lane];
+                c_yw = yw[i0 + lane];
             }
         }
         while (have) {
             const bool act = c_act;
-            const double tv = c_t, vy = act ? c_y : 0.0, vi = act ? c_w : 0.0;
+            const double tv = c_t, vy = c_yw.x, vi = c_yw.y;  // inactive lanes hold stale values nobody reads
             const double kcur = (double)rd;  // cycle number of the chunk being folded (time-sorted targets)
             have = advance();
             if (have) {
                 c_act = i0 + lane < s1;
                 if (c_act) {
                     c_t = tm[i0 + lane];
-                    c_y = yw[i0 + lane];
-                    c_w = ivar[i0 + lane];
+                    c_yw = yw[i0 + lane];
                 }
             }
             int ind = -1 - lane;  // inactive lanes: unique negatives, never equal to a neighbour
@@ -643,12 +641,13 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
 
     const size_t ntot = (size_t)n_off_host[B];
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(BlsStats) + 2 * (ntot * 8 + 256) +
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(BlsStats) + 3 * (ntot * 8 + 256) +
                            (size_t)nP * 4 + dur_tab.size() * 4 + 4096);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     BlsStats *d_stats = (BlsStats *)h->ws.alloc((size_t)B * sizeof(BlsStats));
-    double *d_tm = (double *)h->ws.alloc(ntot * 8), *d_yw = (double *)h->ws.alloc(ntot * 8);
+    double *d_tm = (double *)h->ws.alloc(ntot * 8);
+    double2 *d_yw = (double2 *)h->ws.alloc(ntot * 16);
     int *d_pidx = (int *)h->ws.alloc((size_t)nP * 4);
     int *d_dur = (int *)h->ws.alloc(dur_tab.size() * 4);
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
@@ -681,7 +680,7 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         const size_t lds = bins_bytes + lds_fixed_of(nt);
         const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)npg;
         LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
-        hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, ivar, d_off,
+        hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off,
                            d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration,
                            oversample, use_likelihood ? 1 : 0, out7, ablate);
         g0 = g1;
