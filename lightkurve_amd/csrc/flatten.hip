@@ -134,6 +134,9 @@ __device__ int block_compact(int n, Pred pred, int *out, int *sh) {
     return total;
 }
 
+constexpr int FIR_TILE = 2048;  // outputs per LDS tile of the interior correlation
+constexpr int FIR_LDS = 4096;   // doubles of LDS for a tile's inputs (window <= FIR_LDS - FIR_TILE + 1)
+
 struct FlattenScratch {  // per-target slab offsets are computed from N by the launcher
     double *tm, *fm, *tr;
     int *idx, *idx2, *segs;
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask) {
     __shared__ unsigned long long sh[1024];
     __shared__ int shi[1024];
+    __shared__ __attribute__((aligned(16))) double fir[FIR_LDS + 2];
     const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int64_t lo = n_off[target];
     const int N = (int)(n_off[target + 1] - lo);
@@ -161,7 +165,9 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     double *tm = reinterpret_cast<double *>(s);
     double *fm = tm + Npad;
     double *tr = fm + Npad;
-    int *idx = reinterpret_cast<int *>(tr + Npad);
+    double *xk = tr + Npad;  // dense knots of the interpolation: times and trend of the cadences that survive the clip
+    double *yk = xk + Npad;
+    int *idx = reinterpret_cast<int *>(yk + Npad);
     int *idx2 = idx + Npad;
     int *segs = idx2 + Npad;
     uint8_t *mask = reinterpret_cast<uint8_t *>(segs + Npad + 8);
@@ -234,20 +240,57 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                 const double med = block_median(len, (long long)len, val, keep, sh);
                 for (int i = l + tid; i < h; i += nt) tr[i] = med;
             } else {
-                // interior: correlate with the taps (window fully inside the segment)
-                for (int i = l + half + tid; i < h - half; i += nt) {
-                    const double *x = fm + (i - half);
-                    double acc = 0.0;
-                    for (int j = 0; j < window; ++j) acc = fma(coeffs[j], x[j], acc);
-                    tr[i] = acc;
+                // interior: correlate with the taps (window fully inside the segment).  Tiles of FIR_TILE outputs:
+                // the FIR_TILE + window - 1 inputs are staged in LDS once (coalesced), every thread then produces two
+                // neighbouring outputs from 16-B LDS reads — 4 FMAs per read, so the fp64 pipe is the limit, not L1.
+                const int o_lo = l + half, o_hi = h - half;  // outputs [o_lo, o_hi)
+                if (window + FIR_TILE - 1 <= FIR_LDS) {
+                    for (int o0 = o_lo; o0 < o_hi; o0 += FIR_TILE) {
+                        const int no = min(FIR_TILE, o_hi - o0), ni = no + window - 1;
+                        __syncthreads();
+                        for (int i = tid; i < ni; i += nt) fir[i] = fm[o0 - half + i];
+                        if (tid < 2) fir[ni + tid] = 0.0;  // the pair reads run one past an odd end
+                        __syncthreads();
+                        for (int q = tid; 2 * q < no; q += nt) {
+                            const double2 *xp = reinterpret_cast<const double2 *>(fir + 2 * q);
+                            double a0 = 0.0, a1 = 0.0;
+                            double2 cur = xp[0];
+                            // out[2q] = sum_j c[j] x[2q+j], out[2q+1] = sum_j c[j] x[2q+1+j]
+                            int j = 0;
+                            for (; j + 1 < window; j += 2) {
+                                const double2 nxt = xp[(j >> 1) + 1];
+                                const double c0 = coeffs[j], c1 = coeffs[j + 1];
+                                a0 = fma(c0, cur.x, a0);
+                                a0 = fma(c1, cur.y, a0);
+                                a1 = fma(c0, cur.y, a1);
+                                a1 = fma(c1, nxt.x, a1);
+                                cur = nxt;
+                            }
+                            if (j < window) {  // odd window: last tap
+                                const double c0 = coeffs[j];
+                                a0 = fma(c0, cur.x, a0);
+                                a1 = fma(c0, cur.y, a1);
+                            }
+                            tr[o0 + 2 * q] = a0;
+                            if (2 * q + 1 < no) tr[o0 + 2 * q + 1] = a1;
+                        }
+                    }
+                } else {
+                    for (int i = o_lo + tid; i < o_hi; i += nt) {
+                        const double *x = fm + (i - half);
+                        double acc = 0.0;
+                        for (int j = 0; j < window; ++j) acc = fma(coeffs[j], x[j], acc);
+                        tr[i] = acc;
+                    }
                 }
                 // edges: polynomial refit of the first / last `window` samples (mode='interp')
+                // (the device copy of the operators is transposed, [side][tap][row]: lanes read neighbouring rows)
                 for (int e = tid; e < 2 * half; e += nt) {
                     const int side = e >= half, r = e - side * half;
                     const double *x = side ? fm + (h - window) : fm + l;
-                    const double *E = edge + ((size_t)side * half + r) * window;
+                    const double *E = edge + (size_t)side * half * window + r;
                     double acc = 0.0;
-                    for (int j = 0; j < window; ++j) acc = fma(E[j], x[j], acc);
+                    for (int j = 0; j < window; ++j) acc = fma(E[(size_t)j * half], x[j], acc);
                     tr[side ? (h - half + r) : (l + r)] = acc;
                 }
             }
@@ -273,23 +316,44 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         if (n2 < 2) {
             for (int i = tid; i < N; i += nt) trend[i] = qnan;
         } else {
+            // every cs-th knot time also goes to LDS: the binary search runs there and finishes with log2(cs)
+            // global steps (the all-global search was a chain of ~15 dependent L2 round trips per cadence)
+            const int cs = (n2 + FIR_LDS - 1) / FIR_LDS, nc = (n2 + cs - 1) / cs;
+            for (int j = tid; j < n2; j += nt) {
+                const double x = tm[idx2[j]];
+                xk[j] = x;
+                yk[j] = tr[idx2[j]];
+                if (j % cs == 0) fir[j / cs] = x;
+            }
+            __syncthreads();
             for (int k = tid; k < N; k += nt) {
                 const double xn = t[k];
-                // np.searchsorted(x, xn, side='left') clipped to [1, n2-1]
-                int a = 0, b = n2;
+                // np.searchsorted(x, xn, side='left') clipped to [1, n2-1]: first knot with x >= xn
+                int a = 0, b = nc;  // coarse: first coarse knot >= xn
                 while (a < b) {
                     const int mid = (a + b) >> 1;
-                    if (tm[idx2[mid]] < xn)
+                    if (fir[mid] < xn)
                         a = mid + 1;
                     else
                         b = mid;
                 }
-                const int hi_i = min(max(a, 1), n2 - 1), lo_i = hi_i - 1;
-                const double x0 = tm[idx2[lo_i]], x1 = tm[idx2[hi_i]];
-                const double y0 = tr[idx2[lo_i]], y1 = tr[idx2[hi_i]];
+                // the answer lies in ((a-1) cs, a cs]  (coarse knot a-1 is < xn, coarse knot a is >= xn or absent)
+                int lo_s = a == 0 ? 0 : (a - 1) * cs + 1, hi_s = min(a * cs, n2);
+                if (a == 0) hi_s = 0;
+                while (lo_s < hi_s) {
+                    const int mid = (lo_s + hi_s) >> 1;
+                    if (xk[mid] < xn)
+                        lo_s = mid + 1;
+                    else
+                        hi_s = mid;
+                }
+                const int hi_i = min(max(lo_s, 1), n2 - 1), lo_i = hi_i - 1;
+                const double x0 = xk[lo_i], x1 = xk[hi_i];
+                const double y0 = yk[lo_i], y1 = yk[hi_i];
                 const double slope = (y1 - y0) / (x1 - x0);
                 trend[k] = isnan(xn) ? qnan : slope * (xn - x0) + y0;
             }
+            __syncthreads();  // fir[] is reused by the next iteration's tiles
         }
         // ---- mask[mask] &= mask1   (:1060-1063)
         for (int i = tid; i < nm; i += nt)
@@ -330,7 +394,15 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.d_c), coeffs.size() * 8));
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.d_e), edge.size() * 8 + 8));
         LK_HIP_CHECK(hipMemcpy(d.d_c, coeffs.data(), coeffs.size() * 8, hipMemcpyHostToDevice));
-        if (!edge.empty()) LK_HIP_CHECK(hipMemcpy(d.d_e, edge.data(), edge.size() * 8, hipMemcpyHostToDevice));
+        if (!edge.empty()) {
+            const int half = window / 2;
+            std::vector<double> et(edge.size());  // [side][row][tap] -> [side][tap][row]
+            for (int sd = 0; sd < 2; ++sd)
+                for (int r = 0; r < half; ++r)
+                    for (int j = 0; j < window; ++j)
+                        et[((size_t)sd * window + j) * half + r] = edge[((size_t)sd * half + r) * window + j];
+            LK_HIP_CHECK(hipMemcpy(d.d_e, et.data(), et.size() * 8, hipMemcpyHostToDevice));
+        }
         cache.push_back(d);
         des = &cache.back();
     }
@@ -340,7 +412,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         const int64_t n = n_off_host[b + 1] - n_off_host[b];
         LK_REQUIRE(n >= 1 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
         const int64_t np = (n + 7) & ~(int64_t)7;
-        soff[b + 1] = soff[b] + ((3 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
+        soff[b + 1] = soff[b] + ((5 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + 4096);
@@ -351,7 +423,8 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
-    hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(1024), 0, stream, t, flux, user_mask, d_off, window, polyorder,
+    static const int flat_nt = getenv("LK_FLAT_NT") ? atoi(getenv("LK_FLAT_NT")) : 512;  // 512 threads x 3 workgroups per CU overlap the barrier-bound phases best
+    hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), 0, stream, t, flux, user_mask, d_off, window, polyorder,
                        break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
