@@ -23,6 +23,9 @@
 namespace lk {
 
 constexpr int PLD_LMAX = 64;  // largest small eigenproblem kept in LDS
+constexpr int PLD_KC = 128;   // rows of the basis staged in LDS per step of the MFMA product C Q
+constexpr int PLD_QS = PLD_LMAX + 2;  // LDS row stride of that stage (doubles)
+typedef double pld_d4 __attribute__((ext_vector_type(4)));
 
 static int ncombos(int k, int order) {  // C(k + order - 1, order)
     long long r = 1;
@@ -281,12 +284,12 @@ __device__ __forceinline__ double gsym(const double *__restrict__ G, int ldg, in
 
 // Top-k eigenpairs of the P x P Gram matrix of matrix b -> V (P x k, row-major), lam (k).  One workgroup per matrix.
 // scratch per matrix: 4 * P * l doubles (Q, Z, R, Y).
-__global__ __launch_bounds__(1024) void pld_topk_eig_kernel(const double *__restrict__ G, int ldg, int P, int k, int l,
+__global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__ G, int ldg, int P, int k, int l, int npow,
                                                              double *__restrict__ scratch, double *__restrict__ V,
                                                              double *__restrict__ lam, int *__restrict__ iters_out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
-    const double *Gb = G + (size_t)b * ldg * ldg;
+    double *Gb = G + (size_t)b * ldg * ldg;
     double *Vb = V + (size_t)b * P * k, *lamb = lam + (size_t)b * k;
     const int ld = l + 1;                      // odd leading dimension: conflict-free column walks
     double *T = lds;                           // l x ld
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(const double *__rest
     double *shred = rot + 2 * l;               // nt doubles
     double *vec = shred + nt;                  // 2 * l  (norms / theta)
     int *order = reinterpret_cast<int *>(vec + 2 * l);  // l ints
+    double *qstage = vec + 2 * l + (l + 1) / 2 + 1;      // PLD_KC x PLD_QS (subspace path only)
 
     if (P <= l) {
         // ---- direct: Jacobi on C itself (l = P rounded up to even; the pad row/col is zero)
@@ -364,6 +368,147 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(const double *__rest
         }
     };
 
+    // ---- the Gram kernel wrote the upper 64x64 blocks only: mirror them so the products below read plain rows
+    for (int e = tid; e < P * P; e += nt) {
+        const int i = e / P, j = e - i * P;
+        if ((j >> 6) < (i >> 6)) Gb[(size_t)i * ldg + j] = Gb[(size_t)j * ldg + i];
+    }
+    __syncthreads();
+
+    // ---- dst = C src (P x l, row-major) on the fp64 matrix cores: dst^T (l x P) = src^T (l x P) C (P x P).
+    // v_mfma_f64_16x16x4: A[row = lane & 15][k = lane >> 4] = src[k0 + k][a0 + row] from an LDS stage of PLD_KC rows,
+    // B[k = lane >> 4][col = lane & 15] = C[k0 + k][n0 + col] straight from global (4 x 128-B row segments per load),
+    // D[row = (lane >> 4) + 4 r][col = lane & 15] -> dst[n0 + col][a0 + row].  A wave owns up to four 16-column
+    // tiles of C and streams each of its C elements exactly once per product.
+    const int wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
+    const int na = (l + 15) >> 4, ntile = (P + 15) >> 4;
+    auto cq_mfma = [&](const double *src, double *dst) {
+        for (int tbase = 0; tbase < ntile; tbase += 4 * nwv) {
+            pld_d4 acc[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ai = 0; ai < 4; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < P; k0 += PLD_KC) {
+                __syncthreads();
+                for (int e = tid; e < PLD_KC * 16 * na; e += nt) {
+                    const int kk = e / (16 * na), a = e - kk * (16 * na);
+                    qstage[kk * PLD_QS + a] = (k0 + kk < P && a < l) ? src[(size_t)(k0 + kk) * l + a] : 0.0;
+                }
+                __syncthreads();
+                const int kend = min(PLD_KC, P - k0);
+                for (int kk = 0; kk < kend; kk += 4) {
+                    const int krow = k0 + kk + (lane >> 4);
+                    double bv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int ncol = (tbase + wave + t * nwv) * 16 + (lane & 15);
+                        bv[t] = (krow < P && ncol < P) ? Gb[(size_t)krow * ldg + ncol] : 0.0;
+                    }
+                    double av[4];
+#pragma unroll
+                    for (int ai = 0; ai < 4; ++ai)
+                        av[ai] = ai < na ? qstage[(kk + (lane >> 4)) * PLD_QS + ai * 16 + (lane & 15)] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ai = 0; ai < 4; ++ai)
+                            if (ai < na) acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv[t], acc[t][ai], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = (tbase + wave + t * nwv) * 16 + (lane & 15);
+#pragma unroll
+                for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int a = ai * 16 + (lane >> 4) + 4 * r;
+                        if (ai < na && n < P && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
+                    }
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---- Cholesky-QR of the P x l matrix Yin -> Qout (two passes).  The columns handed in are images C^q r of Ritz
+    // vectors, i.e. nearly orthogonal with wildly different norms: after scaling them to unit length the Gram matrix is
+    // close to the identity and its Cholesky factor is benign.  Returns false (in every thread) on a breakdown
+    // (pivot <= 1e-12), in which case the caller falls back to SVQB.
+    auto cholqr = [&](const double *Yin, double *Qout, double *tmp) -> bool {
+        const double *cur = Yin;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int e = tid; e < l * l; e += nt) {
+                const int a = e / l, c = e % l;
+                double sm = 0.0;
+                if (c >= a)
+                    for (int i = 0; i < P; ++i) sm = fma(cur[(size_t)i * l + a], cur[(size_t)i * l + c], sm);
+                T[a * ld + c] = sm;
+            }
+            __syncthreads();
+            if (tid < l) vec[tid] = T[tid * ld + tid] > 0.0 ? 1.0 / sqrt(T[tid * ld + tid]) : 0.0;
+            __syncthreads();
+            for (int e = tid; e < l * l; e += nt) {
+                const int a = e / l, c = e % l;
+                if (c >= a) {
+                    const double v = T[a * ld + c] * vec[a] * vec[c];
+                    T[a * ld + c] = v;
+                    T[c * ld + a] = v;
+                }
+            }
+            __syncthreads();
+            // T = L L^T in place (lower), then W = L^-1, both on one wave (l <= 64: lane = row)
+            if (tid < 64) {
+                int ok = 1;
+                for (int j = 0; j < l; ++j) {
+                    const double d = T[j * ld + j];
+                    if (!(d > 1e-12)) {
+                        ok = 0;
+                        break;
+                    }
+                    const double rs = 1.0 / sqrt(d);
+                    __builtin_amdgcn_wave_barrier();
+                    if (tid >= j && tid < l) T[tid * ld + j] *= rs;  // column j of L (diagonal included: sqrt(d))
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (tid > j && tid < l) {
+                        const double lij = T[tid * ld + j];
+                        for (int c = j + 1; c <= tid; ++c) T[tid * ld + c] -= lij * T[c * ld + j];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (tid == 0) order[0] = ok;
+                if (ok && tid < l) {
+                    // row `tid` of W = L^-1 is not independent of the others, but COLUMN c of L^-1 solves L x = e_c:
+                    // lane = column c, forward substitution down the rows
+                    const int c = tid;
+                    for (int i = 0; i < l; ++i) {
+                        double x = (i == c) ? 1.0 : 0.0;
+                        for (int m = c; m < i; ++m) x -= T[i * ld + m] * W[m * ld + c];
+                        W[i * ld + c] = i < c ? 0.0 : x / T[i * ld + i];
+                    }
+                }
+            }
+            __syncthreads();
+            const bool ok = order[0] != 0;
+            __syncthreads();
+            if (!ok) return false;
+            // out[i][c] = sum_{a <= c} cur[i][a] vec[a] Linv[c][a]
+            for (int e = tid; e < P * l; e += nt) {
+                const int i = e / l, c = e % l;
+                double sm = 0.0;
+                for (int a2 = 0; a2 <= c; ++a2) sm = fma(cur[(size_t)i * l + a2] * vec[a2], W[c * ld + a2], sm);
+                tmp[e] = sm;
+            }
+            __syncthreads();
+            for (int e = tid; e < P * l; e += nt) Qout[e] = tmp[e];
+            __syncthreads();
+            cur = Qout;
+        }
+        return true;
+    };
+
     // deterministic pseudo-random start
     for (int e = tid; e < P * l; e += nt) {
         unsigned int x = (unsigned int)(e + 1) * 2654435761u;
@@ -376,14 +521,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(const double *__rest
     svqb(Q, R);
     int it = 0;
     for (; it < 400; ++it) {
-        // Z = C Q
-        for (int e = tid; e < P * l; e += nt) {
-            const int i = e / l, a = e % l;
-            double s = 0.0;
-            for (int j = 0; j < P; ++j) s = fma(gsym(Gb, ldg, i, j), Q[(size_t)j * l + a], s);
-            Z[e] = s;
-        }
-        __syncthreads();
+        cq_mfma(Q, Z);  // Z = C Q
         // T = Q^T Z (symmetrised)
         for (int e = tid; e < l * l; e += nt) {
             const int a = e / l, c = e % l;
@@ -423,17 +561,26 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(const double *__rest
         }
         const double res = sqrt(block_sum_dyn(part, shred));
         const double th0 = fabs(T[order[0] * ld + order[0]]);
-        if (res <= 1e-13 * th0 * sqrt((double)k)) break;
-        // next basis: orthonormalised C R
-        for (int e = tid; e < P * l; e += nt) Q[e] = Y[e];
+        if (tid < k) lamb[tid] = T[order[tid] * ld + order[tid]];  // T is reused by the orthonormalisation below
         __syncthreads();
-        svqb(Q, Z);
+        if (res <= 1e-13 * th0 * sqrt((double)k)) break;
+        // next basis: orthonormalised C^npow R (npow - 1 more products between two Rayleigh-Ritz steps)
+        double *src = Y, *dst = Z;
+        for (int pw = 1; pw < npow; ++pw) {
+            cq_mfma(src, dst);
+            double *t2 = src;
+            src = dst;
+            dst = t2;
+        }
+        if (!cholqr(src, Q, dst)) {  // breakdown: one plain step from the (orthonormal) Ritz vectors, SVQB
+            cq_mfma(R, Q);
+            svqb(Q, Z);
+        }
     }
     for (int e = tid; e < P * k; e += nt) {
         const int i = e / k, a = e % k;
         Vb[e] = R[(size_t)i * l + a];
     }
-    if (tid < k) lamb[tid] = T[order[tid] * ld + order[tid]];
     if (tid == 0 && iters_out) iters_out[b] = it;
 }
 
@@ -506,14 +653,15 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         return LK_ENOMEM;
     }
     const int ld = l + 1;
-    const size_t lds = ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l) * 8 + (size_t)l * 4 + 64;
+    const size_t lds = ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1 + (P > l ? PLD_KC * PLD_QS : 0)) * 8 + 64;
     static bool attr_set = false;
     if (!attr_set) {
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, scr, V, lam,
+    static const int npow = getenv("LK_PLD_POWER") ? std::max(1, atoi(getenv("LK_PLD_POWER"))) : 3;
+    hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
                        (int *)nullptr);
     hipLaunchKernelGGL(pld_project_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, A, V, lam, N, P, k, ldx, col0, X);
     return LK_OK;
