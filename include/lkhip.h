@@ -70,6 +70,20 @@ int lk_ls_power_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const 
                           int fit_mean, int center_data, int normalization, const double *scale,
                           double *power, void *stream);
 
+/* ---- Lomb-Scargle with nterms Fourier terms (lightkurve nterms > 1 with ls_method "chi2" / "fastchi2",
+ * periodogram.py:948-967): astropy lombscargle_chi2 (chi2_impl.py:5-86), i.e. at every frequency the weighted
+ * least-squares fit of [1,] sin(m w t), cos(m w t), m = 1..nterms; power = (X^T y)^T (X^T X)^-1 (X^T y), normalised as
+ * above.  The trig sums are exact direct sums, so the result is what 'chi2' returns (which 'fastchi2' approximates by
+ * extirpolation + FFT).  nterms = 1 is lk_ls_power_batch.  1 <= nterms <= LK_MAX_NTERMS. */
+#define LK_MAX_NTERMS 4
+int lk_ls_chi2_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                     const double *freq, double f0, double df, int64_t M, int nterms, int fit_mean, int center_data,
+                     int normalization, const double *scale, double *power);
+int lk_ls_chi2_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                         const double *dy, const double *freq, double f0, double df, int64_t M, int nterms,
+                         int fit_mean, int center_data, int normalization, const double *scale, double *power,
+                         void *stream);
+
 /* ---- Lomb-Scargle, lightkurve's DEFAULT method ls_method="fast" (periodogram.py:650): Press & Rybicki extirpolation
  * + FFT evaluation of the trig sums (astropy fast_impl.py / utils.py trig_sum, extirpolate), regular grid only.
  * Agrees with the reference's 'fast' output to ~1e-10 (and, like it, is ~1e-3 of the peak from the exact methods).

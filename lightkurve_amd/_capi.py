@@ -37,6 +37,12 @@ SIGNATURES = [
     ("lk_ls_power_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
       ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_ls_chi2_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
+    ("lk_ls_chi2_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     ("lk_ls_fast_batch", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int, _c_dp]),
@@ -160,13 +166,18 @@ def _offsets(n_off, total):
 
 
 # --------------------------------------------------------------------------------------------- Lomb-Scargle
+MAX_NTERMS = 4  # LK_MAX_NTERMS in include/lkhip.h
+
+
 def ls_power_batch(t, y, n_off, dy=None, frequency=None, f0=0.0, df=0.0, M=None, fit_mean=True,
-                   center_data=True, normalization="psd", scale=None, device=0):
+                   center_data=True, normalization="psd", scale=None, device=0, nterms=1):
     """Exact GLS power for B ragged targets -> float64[B, M].
 
     ``t`` relative times [d], ``y`` flux, ``dy`` errors or None (uniform weights), concatenated over
     targets with prefix offsets ``n_off``.  Either ``frequency`` (any 1-D array, 1/d) or the regular grid
-    ``f0 + df*arange(M)`` (the fast kernel)."""
+    ``f0 + df*arange(M)`` (the fast kernel).  ``nterms`` > 1: astropy's multi-term ``chi2`` periodogram."""
+    if not 1 <= int(nterms) <= MAX_NTERMS:
+        raise ValueError("nterms must be between 1 and %d on the HIP path (got %r)" % (MAX_NTERMS, nterms))
     h = Handle.get(device)
     t, y = _f64(t), _f64(y)
     n_off = _offsets(n_off, t.size)
@@ -180,20 +191,20 @@ def ls_power_batch(t, y, n_off, dy=None, frequency=None, f0=0.0, df=0.0, M=None,
     M = int(M)
     scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
     power = np.empty((B, M), dtype=np.float64)
-    _check(_lib.lk_ls_power_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), _ptr(frequency),
-                                  float(f0), float(df), M, int(bool(fit_mean)), int(bool(center_data)),
-                                  NORM[normalization], _ptr(scale), _ptr(power)))
+    _check(_lib.lk_ls_chi2_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), _ptr(frequency),
+                                 float(f0), float(df), M, int(nterms), int(bool(fit_mean)), int(bool(center_data)),
+                                 NORM[normalization], _ptr(scale), _ptr(power)))
     return power
 
 
 def ls_power_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, freq_ptr, f0, df, M, fit_mean, center_data,
-                       normalization, scale_ptr, power_ptr, stream=0):
+                       normalization, scale_ptr, power_ptr, stream=0, nterms=1):
     """Device-pointer variant (ints from tensor.data_ptr()); enqueues on ``stream`` and returns."""
     n_off_host = np.ascontiguousarray(n_off_host, dtype=np.int64)
-    _check(_lib.lk_ls_power_batch_dev(handle._h, int(B), _ptr(n_off_host, _c_ip), _vp(t_ptr), _vp(y_ptr),
-                                      _vp(dy_ptr or None), _vp(freq_ptr or None), float(f0), float(df), int(M),
-                                      int(bool(fit_mean)), int(bool(center_data)), NORM[normalization],
-                                      _vp(scale_ptr or None), _vp(power_ptr), _vp(stream or None)))
+    _check(_lib.lk_ls_chi2_batch_dev(handle._h, int(B), _ptr(n_off_host, _c_ip), _vp(t_ptr), _vp(y_ptr),
+                                     _vp(dy_ptr or None), _vp(freq_ptr or None), float(f0), float(df), int(M),
+                                     int(nterms), int(bool(fit_mean)), int(bool(center_data)), NORM[normalization],
+                                     _vp(scale_ptr or None), _vp(power_ptr), _vp(stream or None)))
 
 
 def ls_fast_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True, normalization="psd",

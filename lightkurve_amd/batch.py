@@ -18,10 +18,11 @@ def _pack(arrs):
 
 
 def lombscargle_batch(lcs, frequency, normalization="amplitude", freq_unit=None, oversample_factor=None,
-                      ls_method="fast", device=0, gather=True):
+                      ls_method="fast", device=0, gather=True, nterms=1):
     """Lomb-Scargle power of every light curve on one shared frequency grid -> float64[len(lcs), M].
     Same semantics per target as ``LombScarglePeriodogram.from_lightcurve(lc, frequency=frequency, ...)``
-    (``ls_method="fast"``: the reference's default FFT method; any other name: the exact kernels).
+    (``ls_method="fast"``: the reference's default FFT method; any other name: the exact kernels; ``nterms`` > 1
+    with ``ls_method`` "chi2"/"fastchi2": the multi-term kernels).
     With torch.distributed initialised, rank r computes a contiguous block of targets (balanced by cadence
     count) and, if ``gather``, the spectra are all-gathered so every rank returns all rows."""
     frequency = np.asarray(frequency, dtype=np.float64)
@@ -30,12 +31,17 @@ def lombscargle_batch(lcs, frequency, normalization="amplitude", freq_unit=None,
         if not local:
             return np.zeros((0, len(frequency)))
         plans = [_ls_plan(lc, frequency=frequency, normalization=normalization, freq_unit=freq_unit,
-                          oversample_factor=oversample_factor, ls_method=ls_method) for lc in local]
+                          oversample_factor=oversample_factor, ls_method=ls_method, nterms=nterms) for lc in local]
         t, off = _pack([p["trel"] for p in plans])
         y, _ = _pack([p["flux"] for p in plans])
         f_day = plans[0]["f_day"]
         grid = exact_grid(f_day)
         kw = dict(normalization=plans[0]["norm"], scale=[p["scale"] for p in plans], device=device)
+        nt = plans[0]["nterms"]
+        if nt > 1:
+            if grid is not None:
+                return _capi.ls_power_batch(t, y, off, f0=grid[0], df=grid[1], M=len(f_day), nterms=nt, **kw)
+            return _capi.ls_power_batch(t, y, off, frequency=f_day, nterms=nt, **kw)
         if plans[0]["ls_method"] in ("fast", "fastchi2"):
             return _capi.ls_fast_batch(t, y, off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=len(f_day), **kw)
         if grid is not None:

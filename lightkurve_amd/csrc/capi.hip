@@ -125,18 +125,26 @@ void lk_destroy(lk_handle *h) {
 int64_t lk_workspace_bytes(const lk_handle *h) { return h ? (int64_t)(h->ws.cap + h->staging.cap) : 0; }
 
 // ------------------------------------------------------------------------------------------------ LS
+int lk_ls_chi2_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                         const double *dy, const double *freq, double f0, double df, int64_t M, int nterms,
+                         int fit_mean, int center_data, int normalization, const double *scale, double *power,
+                         void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::ls_chi2_launch(h, B, n_off_host, t, y, dy, freq, f0, df, M, nterms, fit_mean, center_data,
+                              normalization, scale, power, static_cast<hipStream_t>(stream));
+}
+
 int lk_ls_power_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
                           const double *dy, const double *freq, double f0, double df, int64_t M, int fit_mean,
                           int center_data, int normalization, const double *scale, double *power, void *stream) {
-    LK_REQUIRE(h != nullptr, "handle is NULL");
-    LK_HIP_CHECK(hipSetDevice(h->device));
-    return lk::ls_launch(h, B, n_off_host, t, y, dy, freq, f0, df, M, fit_mean, center_data, normalization, scale,
-                         power, static_cast<hipStream_t>(stream));
+    return lk_ls_chi2_batch_dev(h, B, n_off_host, t, y, dy, freq, f0, df, M, 1, fit_mean, center_data, normalization,
+                                scale, power, stream);
 }
 
-int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
-                      const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data,
-                      int normalization, const double *scale, double *power) {
+int lk_ls_chi2_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                     const double *freq, double f0, double df, int64_t M, int nterms, int fit_mean, int center_data,
+                     int normalization, const double *scale, double *power) {
     LK_REQUIRE(h != nullptr, "handle is NULL");
     LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
     LK_REQUIRE(M >= 0, "M must be >= 0");
@@ -159,11 +167,18 @@ int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t
     if (dy) LK_HIP_CHECK(hipMemcpy(ddy, dy, nb, hipMemcpyHostToDevice));
     if (freq) LK_HIP_CHECK(hipMemcpy(dfreq, freq, fb, hipMemcpyHostToDevice));
     if (scale) LK_HIP_CHECK(hipMemcpy(dscale, scale, sb, hipMemcpyHostToDevice));
-    rc = lk::ls_launch(h, B, n_off, dt, dyv, ddy, dfreq, f0, df, M, fit_mean, center_data, normalization, dscale,
-                       dpow, nullptr);
+    rc = lk::ls_chi2_launch(h, B, n_off, dt, dyv, ddy, dfreq, f0, df, M, nterms, fit_mean, center_data, normalization,
+                            dscale, dpow, nullptr);
     if (rc) return rc;
     LK_HIP_CHECK(hipMemcpy(power, dpow, pb, hipMemcpyDeviceToHost));  // null-stream copy orders after the kernels
     return LK_OK;
+}
+
+int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                      const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data,
+                      int normalization, const double *scale, double *power) {
+    return lk_ls_chi2_batch(h, B, n_off, t, y, dy, freq, f0, df, M, 1, fit_mean, center_data, normalization, scale,
+                            power);
 }
 
 // ------------------------------------------------------------------------------------------------ LS 'fast'

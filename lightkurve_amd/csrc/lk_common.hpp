@@ -77,6 +77,9 @@ namespace lk {
 int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
               const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data,
               int normalization, const double *scale, double *power, hipStream_t stream);
+int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+                   const double *freq, double f0, double df, int64_t M, int nterms, int fit_mean, int center_data,
+                   int normalization, const double *scale, double *power, hipStream_t stream);
 int argmax_launch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out,
                   hipStream_t stream);
 int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *ivar,

@@ -47,7 +47,7 @@ struct TargetStats {
     double wsum;  // sum dy^-2 (or N)
     double ybar;  // weighted mean that was subtracted (0 if no centring)
     double YY;    // sum w (y-ybar)^2
-    double pad;
+    double yws;   // sum w (y-ybar)
 };
 
 // sin/cos of 2*pi*(f*t) with the product reduced exactly: p = f*t rounded, e its exact error (fma),
@@ -124,7 +124,13 @@ __global__ __launch_bounds__(256) void ls_prep_kernel(const double *__restrict__
         }
     }
     const double YY = block_sum<256>(acc, sh);
-    if (tid == 0) stats[b] = TargetStats{wsum, ybar, YY, 0.0};
+    acc = 0.0;  // sum w (y - ybar): ~1e-17, but it is the bias entry of X^T y in the multi-term solve
+    for (int64_t i = tid; i < n; i += 256) {
+        double d = dy ? dy[lo + i] : 1.0;
+        acc = fma((1.0 / (d * d)) / wsum, y[lo + i] - ybar, acc);
+    }
+    const double yws = block_sum<256>(acc, sh);
+    if (tid == 0) stats[b] = TargetStats{wsum, ybar, YY, yws};
 }
 
 // closed-form epilogue: gls_power_sums() in ls_epilogue.hpp.  The kernels below accumulate S2acc = sum w sin cos and
@@ -311,12 +317,235 @@ __global__ __launch_bounds__(256) void ls_any_kernel(const CadAny *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ multi-term (chi2)
+// astropy lombscargle_chi2 / lombscargle_fastchi2 (chi2_impl.py:5-86, fastchi2_impl.py:60-137): at every frequency
+// the weighted least-squares fit of  [1,] sin(m w t), cos(m w t), m = 1..nterms.  X^T X and X^T y are assembled from
+// the trig sums  Sw[m], Cw[m] = sum w {sin, cos}(m w t), m <= 2 nterms  and  Syw[m], Cyw[m] = sum w (y - ybar) {...},
+// m <= nterms, through the product identities of fastchi2_impl.py:88-93; power = (X^T y)^T (X^T X)^-1 (X^T y).
+// The sums here are the EXACT direct sums (what 'chi2' computes); harmonics come from the fundamental by the
+// Chebyshev recurrence c_m = 2 c_1 c_{m-1} - c_{m-2} (2 FMA each).  Per (cadence, frequency) pair:
+// 4 (phasor) + 4 (2 nterms - 1) (harmonics) + 6 nterms (accumulates) FMAs.
+template <int NT>
+struct Chi2Sums {
+    double Sw[2 * NT], Cw[2 * NT], Sy[NT], Cy[NT];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int m = 0; m < 2 * NT; ++m) Sw[m] = Cw[m] = 0.0;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) Sy[m] = Cy[m] = 0.0;
+    }
+    // fold one cadence: (a, b) = (cos, sin) of the fundamental phase, w = weight, wy = w (y - ybar)
+    __device__ __forceinline__ void add(double a, double b, double w, double wy) {
+        const double two_a = a + a;
+        double cm = 1.0, sm = 0.0, c = a, s2 = b;
+#pragma unroll
+        for (int m = 0; m < 2 * NT; ++m) {
+            Sw[m] = fma(w, s2, Sw[m]);
+            Cw[m] = fma(w, c, Cw[m]);
+            if (m < NT) {
+                Sy[m] = fma(wy, s2, Sy[m]);
+                Cy[m] = fma(wy, c, Cy[m]);
+            }
+            const double cn = fma(two_a, c, -cm), sn = fma(two_a, s2, -sm);
+            cm = c;
+            sm = s2;
+            c = cn;
+            s2 = sn;
+        }
+    }
+    // (X^T y)^T (X^T X)^-1 (X^T y) with weights normalised to sum 1 (yws = sum w (y - ybar))
+    __device__ __forceinline__ double solve(double yws, int fit_mean) const {
+        constexpr int D = 2 * NT + 1;
+        auto CW = [&](int m) { return m == 0 ? 1.0 : Cw[m - 1]; };
+        auto SW = [&](int m) { return m == 0 ? 0.0 : Sw[m - 1]; };
+        // basis order: 0 = bias (cos 0), 2i-1 = sin i, 2i = cos i
+        double A[D][D], bv[D];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            const int mr = (r + 1) >> 1;
+            const bool rs = (r & 1) != 0;  // sine?
+            bv[r] = r == 0 ? yws : (rs ? Sy[mr - 1] : Cy[mr - 1]);
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                const int mc = (c + 1) >> 1;
+                const bool cs = (c & 1) != 0;
+                const int dm = mr - mc, sm = mr + mc;  // mr >= mc because r >= c
+                double v;
+                if (rs && cs)
+                    v = 0.5 * (CW(dm) - CW(sm));
+                else if (!rs && !cs)
+                    v = 0.5 * (CW(dm) + CW(sm));
+                else if (rs && !cs)  // sin(mr) cos(mc): 0.5 (sign(mr - mc) Sw[|mr - mc|] + Sw[mr + mc])
+                    v = 0.5 * ((dm > 0 ? SW(dm) : 0.0) + SW(sm));
+                else  // cos(mr) sin(mc): 0.5 (sign(mc - mr) Sw[|mc - mr|] + Sw[mr + mc])
+                    v = 0.5 * ((dm > 0 ? -SW(dm) : 0.0) + SW(sm));
+                A[r][c] = v;
+            }
+        }
+        if (!fit_mean) {  // drop the bias: identity row/column leaves the rest of the solve untouched
+            A[0][0] = 1.0;
+            bv[0] = 0.0;
+#pragma unroll
+            for (int r = 1; r < D; ++r) A[r][0] = 0.0;
+        }
+        // Cholesky A = L L^T (lower, in place), z = L^-1 b, power = |z|^2
+        double p = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double d = A[j][j];
+#pragma unroll
+            for (int m = 0; m < j; ++m) d = fma(-A[j][m], A[j][m], d);
+            const double inv = 1.0 / sqrt(d);
+            double z = bv[j];
+#pragma unroll
+            for (int m = 0; m < j; ++m) z = fma(-A[j][m], bv[m], z);
+            z *= inv;
+            bv[j] = z;
+            p = fma(z, z, p);
+#pragma unroll
+            for (int r = j + 1; r < D; ++r) {
+                double v = A[r][j];
+#pragma unroll
+                for (int m = 0; m < j; ++m) v = fma(-A[r][m], A[j][m], v);
+                A[r][j] = v * inv;
+            }
+        }
+        return p;
+    }
+};
+
+__device__ __forceinline__ double chi2_normalise(double p, int norm, double YY, double psd_factor, double nN,
+                                                 double scale) {
+    switch (norm) {
+        case LK_NORM_STANDARD: return p / YY;
+        case LK_NORM_PSD: return p * psd_factor;
+        case LK_NORM_LK_AMPLITUDE: return sqrt(p * psd_factor) * sqrt(4.0 / nN);
+        default: return p * psd_factor * scale;
+    }
+}
+
+constexpr int LS_CHI2_F = 4;  // frequencies per lane of the multi-term grid kernel (6 nterms sums each)
+
+template <int NT>
+__global__ __launch_bounds__(64) void ls_chi2_grid_kernel(const CadHot *__restrict__ hot, const CadGen *__restrict__ gen,
+                                                          const int64_t *__restrict__ n_off,
+                                                          const TargetStats *__restrict__ stats, int B, double f0,
+                                                          double df, int64_t M, int tiles, int norm, int fit_mean,
+                                                          const double *__restrict__ scale,
+                                                          double *__restrict__ power) {
+    constexpr int F = LS_CHI2_F;
+    __shared__ double2 seeds[LS_CHUNK][65];
+    const unsigned bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const int target = (int)((slot / (unsigned)tiles) * 8u + xcd);
+    const int tile = (int)(slot % (unsigned)tiles);
+    if (target >= B) return;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    const int lane = threadIdx.x;
+    const int64_t j0 = (int64_t)tile * (64 * F);
+    hot += lo;
+    gen += lo;
+    Chi2Sums<NT> acc[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) acc[k].zero();
+    const int gi = lane & 15, gg = lane >> 4;
+    const double fstart = fma((double)(j0 + (int64_t)(16 * gg) * F), df, f0);
+    for (int i0 = 0; i0 < n; i0 += LS_CHUNK) {
+        {  // unit-amplitude seeds: lane (gi, gg) covers lanes 16gg..16gg+15 of cadence i0+gi
+            double a = 1.0, b = 0.0, gc = 1.0, gs = 0.0;
+            if (i0 + gi < n) {
+                const CadGen g = gen[i0 + gi];
+                sincos2pi_prod(fstart, g.t, &b, &a);
+                gc = g.gc;
+                gs = g.gs;
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                seeds[gi][16 * gg + m] = make_double2(a, b);
+                const double an = fma(a, gc, -(b * gs));
+                b = fma(b, gc, a * gs);
+                a = an;
+            }
+        }
+        __syncthreads();
+        const int ni = min(LS_CHUNK, n - i0);
+        for (int ii = 0; ii < ni; ++ii) {
+            const CadHot h = hot[i0 + ii];  // wave-uniform: scalar load
+            const double w = h.u * h.u, wy = h.u * h.v;
+            const double2 p = seeds[ii][lane];
+            const double alpha = h.qc + h.qc;
+            double am = p.x, bm = p.y;
+            acc[0].add(am, bm, w, wy);
+            double ac = fma(am, h.qc, -(bm * h.qs)), bc = fma(bm, h.qc, am * h.qs);
+#pragma unroll
+            for (int k = 1; k < F; ++k) {
+                acc[k].add(ac, bc, w, wy);
+                if (k + 1 < F) {
+                    const double an = fma(alpha, ac, -am), bn = fma(alpha, bc, -bm);
+                    am = ac;
+                    bm = bc;
+                    ac = an;
+                    bc = bn;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const TargetStats st = stats[target];
+    const double sc = scale ? scale[target] : 1.0;
+    double *out = power + (size_t)target * (size_t)M;
+    const int64_t jl = j0 + (int64_t)lane * F;
+#pragma unroll
+    for (int k = 0; k < F; ++k)
+        if (jl + k < M)
+            out[jl + k] = chi2_normalise(acc[k].solve(st.yws, fit_mean), norm, st.YY, 0.5 * st.wsum, (double)n, sc);
+}
+
+// arbitrary frequencies: one thread per frequency, one exactly-reduced sincos per (cadence, frequency) pair
+template <int NT>
+__global__ __launch_bounds__(256) void ls_chi2_any_kernel(const CadAny *__restrict__ cad,
+                                                          const int64_t *__restrict__ n_off,
+                                                          const TargetStats *__restrict__ stats,
+                                                          const double *__restrict__ freq, int64_t M, int norm,
+                                                          int fit_mean, const double *__restrict__ scale,
+                                                          double *__restrict__ power) {
+    const int target = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    cad += lo;
+    const double f = (j < M) ? freq[j] : 0.0;
+    Chi2Sums<NT> acc;
+    acc.zero();
+    for (int i = 0; i < n; ++i) {
+        const CadAny q = cad[i];
+        double sn, cs;
+        sincos2pi_prod(f, q.t, &sn, &cs);
+        acc.add(cs, sn, q.u * q.u, q.u * q.v);
+    }
+    if (j < M) {
+        const TargetStats st = stats[target];
+        power[(size_t)target * (size_t)M + j] = chi2_normalise(acc.solve(st.yws, fit_mean), norm, st.YY, 0.5 * st.wsum,
+                                                               (double)n, scale ? scale[target] : 1.0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launcher
 constexpr int LS_F = 16;
 
 int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
               const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
               const double *scale, double *power, hipStream_t stream) {
+    return ls_chi2_launch(h, B, n_off_host, t, y, dy, freq, f0, df, M, 1, fit_mean, center_data, normalization, scale,
+                          power, stream);
+}
+
+// nterms = 1: the closed-form kernels above; nterms = 2..LK_MAX_NTERMS: the multi-term least-squares kernels
+int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+                   const double *freq, double f0, double df, int64_t M, int nterms, int fit_mean, int center_data,
+                   int normalization, const double *scale, double *power, hipStream_t stream) {
+    LK_REQUIRE(nterms >= 1 && nterms <= LK_MAX_NTERMS, "nterms must be between 1 and %d (got %d)", LK_MAX_NTERMS, nterms);
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
     LK_REQUIRE(M >= 0, "M must be >= 0");
     if (B == 0 || M == 0) return LK_OK;
@@ -352,8 +581,37 @@ int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, c
         hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, 0.0, 1,
                            (CadHot *)nullptr, (CadGen *)nullptr, d_any, d_stats);
         dim3 grid((unsigned)((M + 255) / 256), (unsigned)B);
-        hipLaunchKernelGGL(ls_any_kernel, grid, dim3(256), 0, stream, d_any, d_off, d_stats, freq, M, normalization,
-                           fit_mean, scale, power);
+#define LK_CHI2_ANY(NT)                                                                                              \
+    hipLaunchKernelGGL(ls_chi2_any_kernel<NT>, grid, dim3(256), 0, stream, d_any, d_off, d_stats, freq, M,           \
+                       normalization, fit_mean, scale, power)
+        switch (nterms) {
+            case 1:
+                hipLaunchKernelGGL(ls_any_kernel, grid, dim3(256), 0, stream, d_any, d_off, d_stats, freq, M,
+                                   normalization, fit_mean, scale, power);
+                break;
+            case 2: LK_CHI2_ANY(2); break;
+            case 3: LK_CHI2_ANY(3); break;
+            default: LK_CHI2_ANY(4); break;
+        }
+#undef LK_CHI2_ANY
+    } else if (nterms > 1) {
+        CadHot *d_hot = (CadHot *)h->ws.alloc(ntot * sizeof(CadHot));
+        CadGen *d_gen = (CadGen *)h->ws.alloc(ntot * sizeof(CadGen));
+        const int F = LS_CHI2_F;
+        hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, df, F, d_hot,
+                           d_gen, (CadAny *)nullptr, d_stats);
+        const int tiles = (int)((M + 64 * F - 1) / (64 * F));
+        const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)tiles;
+        LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large (B=%d, M=%lld)", B, (long long)M);
+#define LK_CHI2_GRID(NT)                                                                                             \
+    hipLaunchKernelGGL(ls_chi2_grid_kernel<NT>, dim3((unsigned)nblocks), dim3(64), 0, stream, d_hot, d_gen, d_off,   \
+                       d_stats, B, f0, df, M, tiles, normalization, fit_mean, scale, power)
+        switch (nterms) {
+            case 2: LK_CHI2_GRID(2); break;
+            case 3: LK_CHI2_GRID(3); break;
+            default: LK_CHI2_GRID(4); break;
+        }
+#undef LK_CHI2_GRID
     } else {
         CadHot *d_hot = (CadHot *)h->ws.alloc(ntot * sizeof(CadHot));
         CadGen *d_gen = (CadGen *)h->ws.alloc(ntot * sizeof(CadGen));

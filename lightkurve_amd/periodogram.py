@@ -207,9 +207,9 @@ def _ls_plan(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=
             "Please refer to the `astropy.timeseries.periodogram.LombScargle` documentation.".format(ls_method),
             LightkurveWarning)
         nterms = 1
-    if nterms > 1:
-        raise NotImplementedError("nterms > 1 (multi-term chi2 periodograms) is not on the HIP path yet "
-                                  "(SURVEY.md §8(f) N1)")
+    if nterms > _capi.MAX_NTERMS:
+        raise NotImplementedError("the HIP multi-term kernels are instantiated for nterms <= %d (got %d)"
+                                  % (_capi.MAX_NTERMS, nterms))
     dy = kwargs.pop("dy", None)
     fit_mean = kwargs.pop("fit_mean", True)
     center_data = kwargs.pop("center_data", True)
@@ -251,14 +251,25 @@ class LombScarglePeriodogram(Periodogram):
         reference's default algorithm — Press & Rybicki extirpolation + FFT — on the GPU and reproduces lightkurve's
         default output to 1e-9; like the reference it needs a regular frequency grid and otherwise switches to
         ``"slow"``.  Every other name (``"slow"``, ``"cython"``, ``"chi2"``, ``"scipy"``, ``"auto"``, ``"hip"``) runs
-        the exact fp64 direct-sum kernels (== the reference's exact methods to 1e-9)."""
+        the exact fp64 direct-sum kernels (== the reference's exact methods to 1e-9).  ``nterms`` > 1 (with
+        ``ls_method`` ``"chi2"`` or ``"fastchi2"``, as in the reference) runs the multi-term least-squares kernels,
+        which reproduce the reference's ``"chi2"`` output to 1e-9 (``"fastchi2"`` is its FFT approximation)."""
         plan = _ls_plan(lc, minimum_frequency, maximum_frequency, minimum_period, maximum_period, frequency, period,
                         nterms, nyquist_factor, oversample_factor, freq_unit, normalization, ls_method, **kwargs)
         n = len(plan["trel"])
         grid = exact_grid(plan["f_day"])
         common = dict(dy=plan["dy"], fit_mean=plan["fit_mean"], center_data=plan["center_data"],
                       normalization=plan["norm"], scale=[plan["scale"]], device=device)
-        if plan["ls_method"] in ("fast", "fastchi2"):
+        if plan["nterms"] > 1:
+            # multi-term least-squares periodogram ('chi2' arithmetic with exact sums; 'fastchi2' is the reference's
+            # extirpolated approximation of the same quantity): reference periodogram.py:948-967
+            if grid is not None:
+                power = _capi.ls_power_batch(plan["trel"], plan["flux"], [0, n], f0=grid[0], df=grid[1],
+                                             M=len(plan["f_day"]), nterms=plan["nterms"], **common)[0]
+            else:
+                power = _capi.ls_power_batch(plan["trel"], plan["flux"], [0, n], frequency=plan["f_day"],
+                                             nterms=plan["nterms"], **common)[0]
+        elif plan["ls_method"] in ("fast", "fastchi2"):
             # astropy _get_frequency_grid (main.py:53-80): f0 = frequency[0], df = frequency[1] - frequency[0]
             fd = plan["f_day"]
             f0, dfq = (float(fd[0]), float(fd[1] - fd[0])) if len(fd) > 1 else (float(fd[0]), float(fd[0]))

@@ -16,15 +16,15 @@ from . import _capi
 def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit_mean=True, center_data=True,
                     nterms=1, **unused):
     """Signature of astropy's METHODS entries (lombscargle/implementations/main.py:182-217)."""
-    if nterms != 1:
-        raise ValueError("nterms != 1 only supported with 'chi2' or 'fastchi2' methods")
+    if not 1 <= nterms <= _capi.MAX_NTERMS:
+        raise ValueError("the HIP kernels are instantiated for 1 <= nterms <= %d" % _capi.MAX_NTERMS)
     if normalization not in ("standard", "psd"):
         raise ValueError("normalization='{}' not recognized".format(normalization))
     t = np.asarray(t, dtype=np.float64)
     frequency = np.asarray(frequency, dtype=np.float64)
     from .periodogram import exact_grid
     grid = exact_grid(frequency)
-    kw = dict(dy=dy, fit_mean=fit_mean, center_data=center_data, normalization=normalization)
+    kw = dict(dy=dy, fit_mean=fit_mean, center_data=center_data, normalization=normalization, nterms=nterms)
     if grid is not None:
         return _capi.ls_power_batch(t, y, [0, len(t)], f0=grid[0], df=grid[1], M=len(frequency), **kw)[0]
     return _capi.ls_power_batch(t, y, [0, len(t)], frequency=frequency, **kw)[0]
@@ -59,9 +59,14 @@ def install():
     from astropy.timeseries.periodograms.bls import methods as bls_methods
     from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main
     ls_main.METHODS["hip"] = lombscargle_hip
+    # multi-term fits (lightkurve nterms > 1 requires the name 'chi2' or 'fastchi2', periodogram.py:948-958):
+    # 'chi2' receives the raw frequency array like 'hip' does, so it can be replaced one-to-one
+    ls_main.METHODS.setdefault("chi2_cpu", ls_main.METHODS["chi2"])
+    ls_main.METHODS["chi2"] = lombscargle_hip
     # the reference's DEFAULT method: lc.to_periodogram() reaches the GPU with no change on the caller's side
     ls_main.METHODS.setdefault("fast_cpu", ls_main.METHODS["fast"])
     ls_main.METHODS["fast"] = lombscargle_fast_hip
     bls_methods._bls_fast_reference = getattr(bls_methods, "_bls_fast_reference", bls_methods.bls_fast)
     bls_methods.bls_fast = bls_fast_hip
-    return ["lombscargle:METHODS['hip']", "lombscargle:METHODS['fast']", "bls:methods.bls_fast"]
+    return ["lombscargle:METHODS['hip']", "lombscargle:METHODS['chi2']", "lombscargle:METHODS['fast']",
+            "bls:methods.bls_fast"]

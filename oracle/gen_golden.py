@@ -89,6 +89,41 @@ def gen_ls():
     save("ls_constant", time=t, flux=np.ones(300), frequency=pg.frequency.value, amp=pg.power.value)
 
 
+def gen_ls_multiterm():
+    """nterms > 1 through lightkurve itself (periodogram.py:948-967): 'chi2' (exact) and 'fastchi2' (its FFT
+    approximation), regular and irregular grids, with and without dy, plus astropy-level normalisations."""
+    t, y, e, truth = synth.ls_target(1, 3, 900)
+    # add a second harmonic so the extra terms have something to fit
+    y = y + 4e-4 * np.sin(4 * np.pi * t / truth["period"] + 0.7)
+    lc = lk.LightCurve(time=t + 1325.0, flux=y, flux_err=e)
+    f = synth.ls_frequency_grid(600, fmax=40.0)
+    out = dict(time=lc.time.value, flux=y, flux_err=e, frequency=f)
+    for nt in (2, 3, 4):
+        pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method="chi2", nterms=nt)
+        out["amp_chi2_%d" % nt] = np.asarray(pg.power.value)
+    pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method="fastchi2", nterms=2)
+    out["amp_fastchi2_2"] = np.asarray(pg.power.value)
+    pg = lc.to_periodogram(frequency=f * 1e6 / 86400.0, normalization="psd", ls_method="chi2", nterms=2)
+    out["frequency_uhz"] = f * 1e6 / 86400.0
+    out["psd_chi2_2"] = np.asarray(pg.power.value)
+    # irregular grid (regular in period): lightkurve switches fastchi2 -> chi2 (periodogram.py:933-946)
+    period = np.linspace(0.1, 6.0, 300)
+    pg = lc.to_periodogram(period=period, normalization="amplitude", ls_method="fastchi2", nterms=2)
+    out["period"] = period
+    out["period_frequency"] = pg.frequency.value
+    out["amp_period_chi2_2"] = np.asarray(pg.power.value)
+    out["period_ls_method"] = pg.ls_method
+    # astropy boundary: dy, fit_mean on/off, standard + psd
+    rng = np.random.default_rng(11)
+    dy = e * rng.uniform(0.5, 2.0, len(e))
+    out["dy"] = dy
+    for fm in (True, False):
+        ls = LombScargle(t - t[0], y, dy, nterms=2, fit_mean=fm, center_data=True)
+        out["astropy_standard_fm%d" % fm] = ls.power(f, method="chi2", normalization="standard")
+        out["astropy_psd_fm%d" % fm] = ls.power(f, method="chi2", normalization="psd")
+    save("ls_multiterm", **out)
+
+
 def gen_bls():
     t, y, e, truth = synth.bls_target(3, 0, 2500, cadence_days=10.0 / 1440.0)
     lc = lk.LightCurve(time=t + 1325.5, flux=y, flux_err=e)
@@ -248,6 +283,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "bls", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "bls", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

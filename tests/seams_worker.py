@@ -36,6 +36,14 @@ def main():
         per = np.linspace(0.1, 5, 400)     # irregular frequency grid
         errs["irregular_%s" % ("dy" if dy is not None else "nody")] = float(
             np.max(np.abs(ls.power(1 / per, method="hip") - ls.power(1 / per, method="slow"))))
+    # multi-term: LombScargle(nterms=2).power(method='chi2') now runs on the GPU; astropy's own kept as 'chi2_cpu'
+    ls = LombScargle(t - t[0], y, e, nterms=2)
+    fm = f[f * (t[-1] - t[0]) >= 2.0]
+    from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main
+    # (astropy only lets the names 'chi2' / 'fastchi2' carry nterms != 1, so the kept original is called directly)
+    ref = ls_main.METHODS["chi2_cpu"](t - t[0], y, e, frequency=fm, normalization="psd", nterms=2)
+    got = ls.power(fm, method="chi2", normalization="psd")
+    errs["chi2_nterms2"] = float(np.max(np.abs(got - ref)) / np.max(ref))
     out["ls_relerr"] = errs
     # S2: patched bls_fast vs astropy's compiled run_bls, bit for bit, through BoxLeastSquares.power
     t, y, e, _ = synth.bls_target(3, 7, 3000, cadence_days=10.0 / 1440.0)

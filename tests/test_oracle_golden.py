@@ -74,6 +74,35 @@ def test_ls_dy_weights(golden):
                   g["amp"]) < 1e-10
 
 
+def test_ls_multiterm_chi2(golden):
+    """nterms > 1: the restatement of astropy's lombscargle_chi2 against lightkurve / astropy outputs.  Below one
+    cycle per baseline the (2 nterms + 1)-column fit is nearly singular (its answer depends on the last bits of the
+    sums), so the tight comparison is made where f T >= 1 and a loose one everywhere."""
+    g = golden("ls_multiterm")
+    T = g["time"][-1] - g["time"][0]
+    ok = g["frequency"] * T >= 1.0
+
+    def check(a, b, m):
+        assert relmax(a[m], b[m]) < 1e-9
+        assert relmax(a, b) < 1e-5
+
+    for nt in (2, 3, 4):
+        amp = O.lk_ls_periodogram(g["time"], g["flux"], g["frequency"], "amplitude", nterms=nt)
+        check(amp, g["amp_chi2_%d" % nt], ok)
+    psd = O.lk_ls_periodogram(g["time"], g["flux"], g["frequency_uhz"], "psd", nterms=2)
+    check(psd, g["psd_chi2_2"], ok)
+    assert str(g["period_ls_method"]) == "chi2"  # lightkurve's irregular-grid switch
+    amp = O.lk_ls_periodogram(g["time"], g["flux"], g["period_frequency"], "amplitude", nterms=2)
+    check(amp, g["amp_period_chi2_2"], g["period_frequency"] * T >= 1.0)
+    t = g["time"] - g["time"][0]
+    for fm in (1, 0):
+        for norm in ("standard", "psd"):
+            p = O.ls_power_chi2(t, g["flux"], g["dy"], g["frequency"], nterms=2, fit_mean=bool(fm), normalization=norm)
+            check(p, g["astropy_%s_fm%d" % (norm, fm)], ok)
+    # 'fastchi2' is an approximation of 'chi2' (extirpolation): close, not equal
+    assert relmax(g["amp_fastchi2_2"][ok], g["amp_chi2_2"][ok]) < 2e-2
+
+
 def test_ls_constant_flux_zero_power(golden):
     g = golden("ls_constant")
     amp = O.lk_ls_periodogram(g["time"], g["flux"], g["frequency"], "amplitude")
