@@ -84,6 +84,29 @@ int lk_ls_chi2_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const d
                          int fit_mean, int center_data, int normalization, const double *scale, double *power,
                          void *stream);
 
+/* ---- Periodogram.smooth / Periodogram.flatten (src/lightkurve/periodogram.py:182-284, 381-429) for B periodograms on
+ * one shared frequency grid of M points, power row-major [B][M].
+ *
+ * lk_pg_logmedian_batch: method='logmedian' (:265-284).  The caller prepares the window bookkeeping from the
+ * frequency grid exactly as the reference loop does (numpy log10 of the frequencies; window centres by the running
+ * sum x0 += 0.5 * filter_width; membership |log10 f - x0| < filter_width): window k covers the frequency indices
+ * [win_lo[k], win_hi[k]) and frequency j lies in the windows klo[j] .. khi[j] (inclusive; klo > khi = none).  Per
+ * window: nanmedian(power) / corr (corr = (8/9)^3); per frequency: mean of its windows' values, summed in window
+ * order.  All four tables are HOST arrays (also for the _dev flavour).
+ *
+ * lk_pg_boxsmooth_batch: method='boxkernel' (:236-263) = astropy.convolution.convolve(power, Box1DKernel(width)) with
+ * its defaults boundary='fill' (zeros), normalize_kernel=True, nan_treatment='interpolate'.  taps = the kernel array
+ * (flipped; nk odd), HOST array.  flatten = power / smooth is left to the caller (one division). */
+int lk_pg_logmedian_batch(lk_handle *h, int B, int64_t M, const double *power, int K, const int32_t *win_lo,
+                          const int32_t *win_hi, const int32_t *klo, const int32_t *khi, double corr, double *out);
+int lk_pg_logmedian_batch_dev(lk_handle *h, int B, int64_t M, const double *power, int K, const int32_t *win_lo,
+                              const int32_t *win_hi, const int32_t *klo, const int32_t *khi, double corr, double *out,
+                              void *stream);
+int lk_pg_boxsmooth_batch(lk_handle *h, int B, int64_t M, const double *power, const double *taps, int nk,
+                          double *out);
+int lk_pg_boxsmooth_batch_dev(lk_handle *h, int B, int64_t M, const double *power, const double *taps, int nk,
+                              double *out, void *stream);
+
 /* ---- Lomb-Scargle, lightkurve's DEFAULT method ls_method="fast" (periodogram.py:650): Press & Rybicki extirpolation
  * + FFT evaluation of the trig sums (astropy fast_impl.py / utils.py trig_sum, extirpolate), regular grid only.
  * Agrees with the reference's 'fast' output to ~1e-10 (and, like it, is ~1e-3 of the peak from the exact methods).

@@ -21,6 +21,7 @@ _c_dp = ctypes.POINTER(ctypes.c_double)
 _c_ip = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
 _c_fp = ctypes.POINTER(ctypes.c_float)
 
 # (name, restype, argtypes) for EVERY symbol include/lkhip.h declares — tests/test_capi_symbols.py checks the list
@@ -49,6 +50,15 @@ SIGNATURES = [
     ("lk_ls_fast_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
+    ("lk_pg_logmedian_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_i32p, ctypes.c_double,
+      _c_dp]),
+    ("lk_pg_logmedian_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_i32p, ctypes.c_double, _vp,
+      _vp]),
+    ("lk_pg_boxsmooth_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, _c_dp, ctypes.c_int, _c_dp]),
+    ("lk_pg_boxsmooth_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int64, _vp, _c_dp, ctypes.c_int, _vp, _vp]),
     ("lk_argmax_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, _c_dp, _c_ip]),
     ("lk_argmax_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("lk_bls_batch", ctypes.c_int,
@@ -233,6 +243,34 @@ def ls_fast_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, f0, df, M, fi
                                      _vp(dy_ptr or None), float(f0), float(df), int(M), int(bool(fit_mean)),
                                      int(bool(center_data)), NORM[normalization], _vp(scale_ptr or None),
                                      int(oversampling), _vp(power_ptr), _vp(stream or None)))
+
+
+# --------------------------------------------------------------------------------------------- Periodogram.smooth
+def pg_logmedian_batch(power, win_lo, win_hi, klo, khi, corr=(8.0 / 9.0) ** 3, device=0):
+    """Moving nanmedian in log-frequency windows for B periodograms on one grid (power float64[B, M]); the window
+    tables come from ``periodogram._logmedian_windows`` -> float64[B, M]."""
+    h = Handle.get(device)
+    power = np.ascontiguousarray(np.atleast_2d(power), dtype=np.float64)
+    B, M = power.shape
+    tabs = [np.ascontiguousarray(a, dtype=np.int32) for a in (win_lo, win_hi, klo, khi)]
+    if tabs[0].shape != tabs[1].shape or tabs[2].shape != (M,) or tabs[3].shape != (M,):
+        raise ValueError("window tables do not match the grid")
+    out = np.empty_like(power)
+    _check(_lib.lk_pg_logmedian_batch(h._h, B, M, _ptr(power), int(tabs[0].size), _ptr(tabs[0], _c_i32p),
+                                      _ptr(tabs[1], _c_i32p), _ptr(tabs[2], _c_i32p), _ptr(tabs[3], _c_i32p),
+                                      float(corr), _ptr(out)))
+    return out
+
+
+def pg_boxsmooth_batch(power, kernel, device=0):
+    """astropy.convolution.convolve(power[b], kernel) (boundary='fill', normalised, NaN-interpolating) for every row."""
+    h = Handle.get(device)
+    power = np.ascontiguousarray(np.atleast_2d(power), dtype=np.float64)
+    B, M = power.shape
+    taps = np.ascontiguousarray(np.asarray(kernel, dtype=np.float64)[::-1])
+    out = np.empty_like(power)
+    _check(_lib.lk_pg_boxsmooth_batch(h._h, B, M, _ptr(power), _ptr(taps), int(taps.size), _ptr(out)))
+    return out
 
 
 def argmax_batch(x, device=0):

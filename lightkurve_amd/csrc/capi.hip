@@ -181,6 +181,59 @@ int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t
                             power);
 }
 
+// ------------------------------------------------------------------------------------------------ Periodogram.smooth
+int lk_pg_logmedian_batch_dev(lk_handle *h, int B, int64_t M, const double *power, int K, const int32_t *win_lo,
+                              const int32_t *win_hi, const int32_t *klo, const int32_t *khi, double corr, double *out,
+                              void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::pg_logmedian_launch(h, B, M, power, K, win_lo, win_hi, klo, khi, corr, out,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int lk_pg_boxsmooth_batch_dev(lk_handle *h, int B, int64_t M, const double *power, const double *taps, int nk,
+                              double *out, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::pg_boxsmooth_launch(h, B, M, power, taps, nk, out, static_cast<hipStream_t>(stream));
+}
+
+// host-pointer flavours: stage power in, run, copy the smoothed rows back
+extern "C++" {
+template <class Launch>
+static int pg_host_stage(lk_handle *h, int B, int64_t M, const double *power, double *out, Launch launch) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && M >= 1, "need B >= 0 and M >= 1");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(power && out, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t pb = (size_t)B * (size_t)M * sizeof(double);
+    h->staging.reset();
+    int rc = h->staging.reserve(2 * (pb + 256) + 4096);
+    if (rc) return rc;
+    double *dp = (double *)h->staging.alloc(pb), *dout = (double *)h->staging.alloc(pb);
+    LK_HIP_CHECK(hipMemcpy(dp, power, pb, hipMemcpyHostToDevice));
+    rc = launch(dp, dout);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(out, dout, pb, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+}  // extern "C++"
+
+int lk_pg_logmedian_batch(lk_handle *h, int B, int64_t M, const double *power, int K, const int32_t *win_lo,
+                          const int32_t *win_hi, const int32_t *klo, const int32_t *khi, double corr, double *out) {
+    return pg_host_stage(h, B, M, power, out, [&](const double *dp, double *dout) {
+        return lk::pg_logmedian_launch(h, B, M, dp, K, win_lo, win_hi, klo, khi, corr, dout, nullptr);
+    });
+}
+
+int lk_pg_boxsmooth_batch(lk_handle *h, int B, int64_t M, const double *power, const double *taps, int nk,
+                          double *out) {
+    return pg_host_stage(h, B, M, power, out, [&](const double *dp, double *dout) {
+        return lk::pg_boxsmooth_launch(h, B, M, dp, taps, nk, dout, nullptr);
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ LS 'fast'
 int lk_ls_fast_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
                          const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,

@@ -98,6 +98,11 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
                       int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,
                       double *prior_sigma, hipStream_t stream);
 int pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_knots);
+int pg_logmedian_launch(lk_handle *h, int B, int64_t M, const double *power, int K, const int *win_lo_host,
+                        const int *win_hi_host, const int *klo_host, const int *khi_host, double corr, double *out,
+                        hipStream_t stream);
+int pg_boxsmooth_launch(lk_handle *h, int B, int64_t M, const double *power, const double *taps_host, int nk,
+                        double *out, hipStream_t stream);
 int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
                   double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
                   const double *scale, int oversampling, double *power, hipStream_t stream);

@@ -10,6 +10,8 @@ delegates to astropy (LombScargle.power / BoxLeastSquares.power) runs in liblkhi
 import logging
 import warnings
 
+import math
+
 import numpy as np
 
 from . import _capi
@@ -120,6 +122,81 @@ class Periodogram(object):
 
     def __repr__(self):
         return "%s(ID: %s)" % (type(self).__name__, self.targetid)
+
+    def copy(self):
+        import copy
+        return copy.deepcopy(self)
+
+    def smooth(self, method="boxkernel", filter_width=0.1, device=0):
+        """Smoothed copy of the power spectrum (reference periodogram.py:182-284): ``'boxkernel'`` convolves with a
+        box of ``filter_width`` (frequency units; needs an evenly spaced grid), ``'logmedian'`` is a moving median
+        in log10(frequency) windows of half-width ``filter_width``, divided by (8/9)^3."""
+        method = validate_method(method, ["boxkernel", "logmedian"])
+        out = self.copy()
+        if method == "boxkernel":
+            if filter_width <= 0.0:
+                raise ValueError("the `filter_width` parameter must be larger than 0 for the 'boxkernel' method.")
+            if not self._is_evenly_spaced():
+                raise ValueError("the 'boxkernel' method requires the periodogram to have a grid of evenly spaced "
+                                 "frequencies.")
+            fs = np.mean(np.diff(self.frequency))
+            kernel = _box1d_kernel(math.ceil(filter_width / fs))
+            out.power = _capi.pg_boxsmooth_batch(self.power, kernel, device=device)[0]
+            return out
+        out.power = _capi.pg_logmedian_batch(self.power, *_logmedian_windows(self.frequency, filter_width),
+                                             device=device)[0]
+        return out
+
+    def flatten(self, method="logmedian", filter_width=0.01, return_trend=False, device=0):
+        """Signal-to-noise spectrum: power divided by its smoothed background (reference periodogram.py:381-429)."""
+        bkg = self.smooth(method=method, filter_width=filter_width, device=device)
+        snr = SNRPeriodogram(self.frequency, self.power / bkg.power, nyquist=self.nyquist, targetid=self.targetid,
+                             label=self.label, meta=self.meta, frequency_unit=self.frequency_unit, power_unit="")
+        return (snr, bkg) if return_trend else snr
+
+
+class SNRPeriodogram(Periodogram):
+    """Power divided by a background estimate (reference periodogram.py:528-586); unitless power."""
+
+
+def _box1d_kernel(width):
+    """astropy ``Box1DKernel(width).array`` (astropy@4.3.1 convolution/kernels.py + utils.py:216-223): the box
+    ``1/width`` on ``|x| <= width/2`` sampled on the half-pixel grid, neighbours averaged (so an even width gets
+    half-weight end taps), normalised by its sum."""
+    size = int(math.ceil(width))
+    size += 1 - size % 2
+    x = np.arange(-(size // 2) - 0.5, size // 2 + 1.0)
+    v = np.where(np.logical_and(x >= -width / 2.0, x <= width / 2.0), 1.0 / width, 0.0)
+    k = 0.5 * (v[1:] + v[:-1])
+    return k / k.sum()
+
+
+def _logmedian_windows(frequency, filter_width):
+    """The bookkeeping of the reference's logmedian loop (periodogram.py:270-281), which depends on the frequency
+    grid only: window k is centred on x0_k (the same running sum ``x0 += 0.5 * filter_width``) and holds the
+    frequencies with ``|log10 f - x0_k| < filter_width``.  Returns (win_lo, win_hi, klo, khi): window k covers the
+    index range [win_lo[k], win_hi[k]); frequency j belongs to windows klo[j] .. khi[j] inclusive."""
+    f = np.asarray(frequency, dtype=np.float64)
+    if np.any(np.diff(f) < 0):
+        raise NotImplementedError("the HIP logmedian filter needs a frequency grid in ascending order")
+    lf = np.log10(f)
+    centres = []
+    x0 = np.log10(f[0])
+    top = np.log10(f[-1])
+    while x0 < top:
+        centres.append(x0)
+        x0 += 0.5 * filter_width
+    lo, hi = [], []
+    for c in centres:  # the mask |lf - c| < filter_width is a contiguous run of the sorted grid
+        m = np.flatnonzero(np.abs(lf - c) < filter_width)
+        if m.size:
+            lo.append(m[0])
+            hi.append(m[-1] + 1)
+    lo, hi = np.asarray(lo, dtype=np.int32), np.asarray(hi, dtype=np.int32)
+    j = np.arange(len(f))
+    klo = np.searchsorted(hi, j, side="right").astype(np.int32)      # first window with hi > j
+    khi = (np.searchsorted(lo, j, side="right") - 1).astype(np.int32)  # last window with lo <= j
+    return lo, hi, klo, khi
 
 
 def _ls_plan(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=None, maximum_period=None,

@@ -5,6 +5,7 @@ astropy 4.3.1 / scipy 1.7.1).  Test infrastructure; run in this container only:
 
 The fixtures hold inputs AND reference outputs, so nothing at test time needs /root/reference.
 """
+import math
 import os
 import sys
 
@@ -122,6 +123,31 @@ def gen_ls_multiterm():
         out["astropy_standard_fm%d" % fm] = ls.power(f, method="chi2", normalization="standard")
         out["astropy_psd_fm%d" % fm] = ls.power(f, method="chi2", normalization="psd")
     save("ls_multiterm", **out)
+
+
+def gen_pg_smooth():
+    """Periodogram.smooth / .flatten (periodogram.py:182-284, 381-429) on an LS periodogram of a TESS-like curve."""
+    t, y, e, truth = synth.ls_target(1, 4, 4000)
+    lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+    pg = lc.to_periodogram(normalization="psd", ls_method="slow", oversample_factor=2)
+    out = dict(frequency=pg.frequency.value, power=pg.power.value)
+    for fw in (0.01, 0.05, 0.3):
+        out["logmedian_%g" % fw] = pg.smooth(method="logmedian", filter_width=fw).power.value
+    for fw in (3.0, 10.5, 40.0):  # microhertz; ceil(fw / fs) = odd and even widths
+        out["boxkernel_%g" % fw] = pg.smooth(method="boxkernel", filter_width=fw).power.value
+    fs = np.mean(np.diff(pg.frequency.value))
+    out["box_widths"] = np.array([math.ceil(fw / fs) for fw in (3.0, 10.5, 40.0)])
+    snr, bkg = pg.flatten(return_trend=True)
+    out["flatten_snr"] = snr.power.value
+    out["flatten_bkg"] = bkg.power.value
+    # NaNs in the power (nanmedian / convolve's NaN interpolation)
+    p2 = pg.power.value.copy()
+    p2[[7, 8, 500, 1999]] = np.nan
+    pg2 = lk.periodogram.Periodogram(pg.frequency, p2 * pg.power.unit)
+    out["power_nan"] = p2
+    out["logmedian_nan"] = pg2.smooth(method="logmedian", filter_width=0.02).power.value
+    out["boxkernel_nan"] = pg2.smooth(method="boxkernel", filter_width=10.5).power.value
+    save("pg_smooth", **out)
 
 
 def gen_bls():
@@ -283,6 +309,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "bls", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "bls", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

@@ -114,6 +114,23 @@ def test_ls_constant_flux_zero_power(golden):
     assert (O.lk_ls_periodogram(t, np.ones(3), f, "amplitude") == 0).all()
 
 
+# ------------------------------------------------------------------ Periodogram.smooth / flatten
+def test_pg_smooth_and_flatten(golden):
+    g = golden("pg_smooth")
+    f, p = g["frequency"], g["power"]
+    for fw in (0.01, 0.05, 0.3):
+        assert relmax(O.pg_smooth_logmedian(f, p, fw), g["logmedian_%g" % fw]) < 1e-13
+    for fw, w in zip((3.0, 10.5, 40.0), g["box_widths"]):
+        assert int(np.ceil(fw / np.mean(np.diff(f)))) == w
+        assert relmax(O.pg_smooth_boxkernel(f, p, fw), g["boxkernel_%g" % fw]) < 1e-13
+    bkg = O.pg_smooth_logmedian(f, p, 0.01)
+    assert relmax(bkg, g["flatten_bkg"]) < 1e-13 and relmax(p / bkg, g["flatten_snr"]) < 1e-13
+    a, b = O.pg_smooth_logmedian(f, g["power_nan"], 0.02), g["logmedian_nan"]
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and relmax(a[~np.isnan(a)], b[~np.isnan(b)]) < 1e-13
+    a, b = O.pg_smooth_boxkernel(f, g["power_nan"], 10.5), g["boxkernel_nan"]
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and relmax(a[~np.isnan(a)], b[~np.isnan(b)]) < 1e-13
+
+
 # ------------------------------------------------------------------ BLS
 @pytest.mark.parametrize("objective", ["likelihood", "snr"])
 def test_bls_bit_exact(golden, objective):
