@@ -62,6 +62,40 @@ class LightCurve(object):
         """New light curve without the cadences where ``column`` is NaN (reference :1300-1327)."""
         return self[~np.isnan(self[column])]
 
+    def normalize(self, unit="unscaled"):
+        """Flux and flux_err divided by the median flux (reference :1216-1292); ``unit`` scales by 1e2/1e3/1e6."""
+        import warnings
+        from .periodogram import LightkurveWarning, validate_method
+        validate_method(unit, ["unscaled", "percent", "ppt", "ppm"])
+        median_flux = np.nanmedian(self.flux)
+        std_flux = np.nanstd(self.flux)
+        if (median_flux == 0) or (np.isfinite(std_flux) and (np.abs(median_flux) < 0.5 * std_flux)):
+            warnings.warn("The light curve appears to be zero-centered (median={:.2e} +/- {:.2e}); `normalize()` "
+                          "will divide the light curve by a value close to zero, which is probably not what you "
+                          "want.".format(median_flux, std_flux), LightkurveWarning)
+        if median_flux < 0:
+            warnings.warn("The light curve has a negative median flux ({:.2e}); `normalize()` will therefore divide "
+                          "by a negative number and invert the light curve, which is probably not what you "
+                          "want".format(median_flux), LightkurveWarning)
+        lc = self.copy()
+        scale = {"unscaled": 1.0, "percent": 1e2, "ppt": 1e3, "ppm": 1e6}[unit]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            lc.flux = lc.flux / median_flux * scale
+            lc.flux_err = lc.flux_err / median_flux * scale
+        lc.meta["NORMALIZED"] = True
+        return lc
+
+    def __sub__(self, other):
+        """lc - scalar shifts the flux (reference LightCurve.__add__/__sub__ :610-660, scalar case)."""
+        new = self.copy()
+        new.flux = new.flux - other
+        return new
+
+    def __add__(self, other):
+        new = self.copy()
+        new.flux = new.flux + other
+        return new
+
     # ---------------------------------------------------------------- hot-path entry points
     def to_periodogram(self, method="lombscargle", **kwargs):
         """``method`` in {"lombscargle", "ls", "boxleastsquares", "bls"} (reference :2490-2535)."""

@@ -150,6 +150,25 @@ def gen_pg_smooth():
     save("pg_smooth", **out)
 
 
+def gen_metrics():
+    """overfit_metric_lombscargle (correctors/metrics.py:24-138) with the global numpy RNG seeded before each call."""
+    from lightkurve.correctors.metrics import overfit_metric_lombscargle
+    t, y, e, truth = synth.ls_target(1, 5, 1500)
+    rng = np.random.default_rng(3)
+    y_over = y + 4e-4 * rng.standard_normal(len(y))                # a "correction" that injected white noise
+    y_mild = y + 1e-4 * rng.standard_normal(len(y))
+    y_clean = 1.0 + (y - 1.0) * 0.2                                # removed signal, added nothing
+    y_nan = y_over.copy()
+    y_nan[[3, 700]] = np.nan
+    out = dict(time=t, flux=y, flux_err=e, flux_over=y_over, flux_mild=y_mild, flux_clean=y_clean, flux_nan=y_nan)
+    orig = lk.LightCurve(time=t, flux=y, flux_err=e)
+    for name, yy, ns in (("over", y_over, 10), ("mild", y_mild, 10), ("clean", y_clean, 3), ("nan", y_nan, 4)):
+        np.random.seed(1234)
+        out["metric_" + name] = overfit_metric_lombscargle(orig, lk.LightCurve(time=t, flux=yy, flux_err=e), n_samples=ns)
+        out["nsamples_" + name] = ns
+    save("overfit_metric", **out)
+
+
 def gen_bls():
     t, y, e, truth = synth.bls_target(3, 0, 2500, cadence_days=10.0 / 1440.0)
     lc = lk.LightCurve(time=t + 1325.5, flux=y, flux_err=e)
@@ -309,6 +328,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "bls", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "metrics", "bls", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

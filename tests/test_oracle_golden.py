@@ -131,6 +131,15 @@ def test_pg_smooth_and_flatten(golden):
     assert np.array_equal(np.isnan(a), np.isnan(b)) and relmax(a[~np.isnan(a)], b[~np.isnan(b)]) < 1e-13
 
 
+def test_overfit_metric(golden):
+    g = golden("overfit_metric")
+    for name in ("over", "mild", "clean", "nan"):
+        np.random.seed(1234)
+        m = O.overfit_metric_lombscargle(g["time"], g["flux"], g["flux_err"], g["flux_" + name], g["flux_err"],
+                                         n_samples=int(g["nsamples_" + name]))
+        assert abs(m - float(g["metric_" + name])) < 1e-9, name
+
+
 # ------------------------------------------------------------------ BLS
 @pytest.mark.parametrize("objective", ["likelihood", "snr"])
 def test_bls_bit_exact(golden, objective):
