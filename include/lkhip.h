@@ -84,6 +84,21 @@ int lk_ls_chi2_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const d
                          int fit_mean, int center_data, int normalization, const double *scale, double *power,
                          void *stream);
 
+/* ---- LightCurve.fold (src/lightkurve/lightcurve.py:1089-1214 over astropy TimeSeries.fold, timeseries/sampled.py:
+ * 230-233) for B ragged targets: phase = ((t - epoch_time) + epoch_phase + (P - wrap)) % P - (P - wrap) (numpy `%`),
+ * divided by P if normalize_phase (epoch_phase and wrap_phase are then in phase units), followed by a STABLE sort by
+ * phase.  period / epoch_time / wrap_phase: one value per target (HOST arrays).  Outputs, all in sorted order:
+ * phase[sum N], order[sum N] (index of the cadence, relative to its target, that lands at each sorted slot) and
+ * cols_out[c][i] = cols_in[c][order[i]] for ncols value columns (flux, flux_err, ...).  The phases are bit-identical
+ * to numpy's and the permutation equals np.argsort(phase, kind="stable"). */
+int lk_fold_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *period,
+                  const double *epoch_time, double epoch_phase, const double *wrap_phase, int normalize_phase,
+                  int ncols, const double *const *cols_in, double *const *cols_out, double *phase, int64_t *order);
+int lk_fold_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *period,
+                      const double *epoch_time, double epoch_phase, const double *wrap_phase, int normalize_phase,
+                      int ncols, const double *const *cols_in, double *const *cols_out, double *phase, int64_t *order,
+                      void *stream);
+
 /* ---- Periodogram.smooth / Periodogram.flatten (src/lightkurve/periodogram.py:182-284, 381-429) for B periodograms on
  * one shared frequency grid of M points, power row-major [B][M].
  *

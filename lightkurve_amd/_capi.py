@@ -50,6 +50,12 @@ SIGNATURES = [
     ("lk_ls_fast_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
+    ("lk_fold_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, _c_dp, ctypes.c_int, ctypes.c_int,
+      ctypes.POINTER(_c_dp), ctypes.POINTER(_c_dp), _c_dp, _c_ip]),
+    ("lk_fold_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _c_dp, _c_dp, ctypes.c_double, _c_dp, ctypes.c_int, ctypes.c_int,
+      ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp]),
     ("lk_pg_logmedian_batch", ctypes.c_int,
      [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, ctypes.c_int, _c_i32p, _c_i32p, _c_i32p, _c_i32p, ctypes.c_double,
       _c_dp]),
@@ -289,6 +295,39 @@ def argmax_batch(x, device=0):
 def argmax_batch_dev(handle, B, M, x_ptr, max_ptr, arg_ptr, stream=0):
     _check(_lib.lk_argmax_batch_dev(handle._h, int(B), int(M), _vp(x_ptr), _vp(max_ptr), _vp(arg_ptr),
                                     _vp(stream or None)))
+
+
+# --------------------------------------------------------------------------------------------- fold
+def fold_batch(t, n_off, period, epoch_time, epoch_phase=0.0, wrap_phase=None, normalize_phase=False, columns=(),
+               device=0):
+    """LightCurve.fold for B ragged targets: returns (phase, order, [columns gathered into phase order]).
+    ``period`` / ``epoch_time`` / ``wrap_phase``: scalars or one value per target; ``wrap_phase`` defaults to
+    period/2 (0.5 with ``normalize_phase``), like astropy.  ``order`` indexes cadences relative to their target."""
+    h = Handle.get(device)
+    t = _f64(t)
+    n_off = _offsets(n_off, t.size)
+    B = n_off.size - 1
+    period = _f64(np.broadcast_to(np.asarray(period, dtype=np.float64), (B,)))
+    epoch_time = _f64(np.broadcast_to(np.asarray(epoch_time, dtype=np.float64), (B,)))
+    if wrap_phase is None:
+        wrap_phase = np.full(B, 0.5) if normalize_phase else period / 2.0
+    wrap_phase = _f64(np.broadcast_to(np.asarray(wrap_phase, dtype=np.float64), (B,)))
+    if not np.all(np.isfinite(period)) or np.any(period == 0):
+        raise ValueError("period must be finite and non-zero")
+    cols = [_f64(c) for c in columns]
+    for c in cols:
+        if c.shape != t.shape:
+            raise ValueError("every column must have the length of t")
+    outs = [np.empty_like(t) for _ in cols]
+    arr_t = _c_dp * max(len(cols), 1)
+    cin = arr_t(*[_ptr(c) for c in cols]) if cols else arr_t()
+    cout = arr_t(*[_ptr(o) for o in outs]) if cols else arr_t()
+    phase = np.empty_like(t)
+    order = np.empty(t.size, dtype=np.int64)
+    _check(_lib.lk_fold_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(period), _ptr(epoch_time), float(epoch_phase),
+                              _ptr(wrap_phase), int(bool(normalize_phase)), len(cols), cin, cout, _ptr(phase),
+                              _ptr(order, _c_ip)))
+    return phase, order, outs
 
 
 # --------------------------------------------------------------------------------------------- BLS

@@ -181,6 +181,51 @@ int lk_ls_power_batch(lk_handle *h, int B, const int64_t *n_off, const double *t
                             power);
 }
 
+// ------------------------------------------------------------------------------------------------ fold
+int lk_fold_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *period,
+                      const double *epoch_time, double epoch_phase, const double *wrap_phase, int normalize_phase,
+                      int ncols, const double *const *cols_in, double *const *cols_out, double *phase, int64_t *order,
+                      void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::fold_launch(h, B, n_off_host, t, period, epoch_time, epoch_phase, wrap_phase, normalize_phase, ncols,
+                           cols_in, cols_out, phase, order, static_cast<hipStream_t>(stream));
+}
+
+int lk_fold_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *period,
+                  const double *epoch_time, double epoch_phase, const double *wrap_phase, int normalize_phase,
+                  int ncols, const double *const *cols_in, double *const *cols_out, double *phase, int64_t *order) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(t && phase && order, "NULL buffer");
+    LK_REQUIRE(ncols >= 0 && ncols <= 16 && (ncols == 0 || (cols_in && cols_out)), "bad column list (at most 16 columns)");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B], nb = ntot * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve((size_t)(3 + 2 * ncols) * (nb + 256) + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(nb), *dph = (double *)h->staging.alloc(nb);
+    int64_t *dord = (int64_t *)h->staging.alloc(nb);
+    const double *din[16];
+    double *dout[16];
+    LK_HIP_CHECK(hipMemcpy(dt, t, nb, hipMemcpyHostToDevice));
+    for (int c = 0; c < ncols; ++c) {
+        LK_REQUIRE(cols_in[c] && cols_out[c], "column %d is NULL", c);
+        double *a = (double *)h->staging.alloc(nb);
+        dout[c] = (double *)h->staging.alloc(nb);
+        LK_HIP_CHECK(hipMemcpy(a, cols_in[c], nb, hipMemcpyHostToDevice));
+        din[c] = a;
+    }
+    rc = lk::fold_launch(h, B, n_off, dt, period, epoch_time, epoch_phase, wrap_phase, normalize_phase, ncols, din, dout,
+                         dph, dord, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(phase, dph, nb, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(order, dord, nb, hipMemcpyDeviceToHost));
+    for (int c = 0; c < ncols; ++c) LK_HIP_CHECK(hipMemcpy(cols_out[c], dout[c], nb, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ Periodogram.smooth
 int lk_pg_logmedian_batch_dev(lk_handle *h, int B, int64_t M, const double *power, int K, const int32_t *win_lo,
                               const int32_t *win_hi, const int32_t *klo, const int32_t *khi, double corr, double *out,

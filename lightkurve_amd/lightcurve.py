@@ -125,26 +125,27 @@ class LightCurve(object):
             return flat, tr
         return flat
 
-    def fold(self, period=None, epoch_time=None, epoch_phase=0, wrap_phase=None, normalize_phase=False):
+    def fold(self, period=None, epoch_time=None, epoch_phase=0, wrap_phase=None, normalize_phase=False, device=0):
         """Phase-fold (reference :1089-1214 over astropy TimeSeries.fold, timeseries/sampled.py:230-233):
-        phase = ((t - epoch) + epoch_phase + (P - wrap)) % P - (P - wrap), then a stable sort by phase."""
+        phase = ((t - epoch) + epoch_phase + (P - wrap)) % P - (P - wrap), then a stable sort by phase — both on
+        the GPU (lk_fold_batch: bit-identical phases, permutation == np.argsort(phase, kind="stable"))."""
+        from . import _capi
         period = float(period)
+        epoch_given = epoch_time is not None
         if epoch_time is None:
             epoch_time = float(self.time[0]) if len(self) else 0.0
         if wrap_phase is None:
             wrap_phase = period / 2.0 if not normalize_phase else 0.5
-        wrap = wrap_phase * period if normalize_phase else wrap_phase
-        eph = epoch_phase * period if normalize_phase else epoch_phase
-        rel = (self.time - epoch_time) + eph + (period - wrap)
-        phase = np.mod(rel, period) - (period - wrap)
-        cycle = np.round((self.time - epoch_time - phase) / period).astype(int)
-        if normalize_phase:
-            phase = phase / period
-        order = np.argsort(phase, kind="stable")
-        out = FoldedLightCurve(time=phase[order], flux=self.flux[order], flux_err=self.flux_err[order],
-                               meta=dict(self.meta))
+        phase, order, (flux, flux_err) = _capi.fold_batch(
+            self.time, [0, len(self)], period, epoch_time, epoch_phase=epoch_phase, wrap_phase=wrap_phase,
+            normalize_phase=normalize_phase, columns=(self.flux, self.flux_err), device=device)
+        out = FoldedLightCurve(time=phase, flux=flux, flux_err=flux_err, meta=dict(self.meta))
         out.time_original = self.time[order]
-        out.cycle = cycle[order]
+        # FoldedLightCurve.cycle (reference :3213-3229): floor((t - (epoch - P/2)) / P), first cycle = 0; without an
+        # explicit epoch_time the reference takes the smallest folded time as the epoch
+        cyc_epoch = epoch_time if epoch_given else (float(np.min(phase)) if len(phase) else 0.0)
+        cyc = np.floor((out.time_original - (cyc_epoch - period / 2.0)) / period).astype(int)
+        out.cycle = cyc - cyc.min() if len(cyc) else cyc
         out.period, out.epoch_time, out.epoch_phase, out.wrap_phase = period, epoch_time, epoch_phase, wrap_phase
         out.normalize_phase = normalize_phase
         return out

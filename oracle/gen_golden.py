@@ -169,6 +169,29 @@ def gen_metrics():
     save("overfit_metric", **out)
 
 
+def gen_fold():
+    """LightCurve.fold (lightcurve.py:1089-1214): phase, flux in phase order, cycle; ties and NaN time excluded."""
+    t, y, e, truth = synth.bls_target(3, 11, 2500, cadence_days=10.0 / 1440.0)
+    t = t.copy()
+    t[100] = t[99]          # a tie: the stable sort must keep cadence order
+    lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+    out = dict(time=t, flux=y, flux_err=e)
+    cases = {"a": dict(period=2.37, epoch_time=t[0] + 0.4),
+             "b": dict(period=0.731, epoch_time=t[0] + 0.1, epoch_phase=0.2, wrap_phase=0.5),
+             "c": dict(period=5.5, epoch_time=t[0] - 3.0, normalize_phase=True),
+             "d": dict(period=1.9, epoch_time=t[0] + 1.0, epoch_phase=0.25, wrap_phase=0.8, normalize_phase=True)}
+    for k, kw in cases.items():
+        f = lc.fold(**kw)
+        ph = f.time.value if hasattr(f.time, "value") else np.asarray(f.time)
+        out["phase_" + k] = np.asarray(ph, dtype=float)
+        out["flux_" + k] = np.asarray(f.flux.value, dtype=float)
+        out["time_original_" + k] = np.asarray(f.time_original.value, dtype=float)
+        out["cycle_" + k] = np.asarray(f.cycle)
+        for kk, v in kw.items():
+            out["%s_%s" % (kk, k)] = v
+    save("fold", **out)
+
+
 def gen_bls():
     t, y, e, truth = synth.bls_target(3, 0, 2500, cadence_days=10.0 / 1440.0)
     lc = lk.LightCurve(time=t + 1325.5, flux=y, flux_err=e)
@@ -328,6 +351,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "metrics", "bls", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "metrics", "fold", "bls", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

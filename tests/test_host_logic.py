@@ -121,15 +121,3 @@ def test_periodogram_container_validation():
         P.Periodogram([1.0, 2.0], [1.0, 2.0], frequency_unit="kg")
     pg = P.Periodogram([1.0, 2.0, 4.0], [1.0, np.nan, 3.0])
     assert pg.max_power == 3.0 and pg.frequency_at_max_power == 4.0 and pg.period_at_max_power == 0.25
-
-
-def test_fold_properties():
-    """Model: reference tests/test_lightcurve.py:242-316 — phase range, cycle numbers, permutation of time."""
-    lc = make_lc(500)
-    f = lc.fold(period=3.3, epoch_time=1.0)
-    assert f.time.min() >= -1.65 and f.time.max() <= 1.65 and np.all(np.diff(f.time) >= 0)
-    assert np.array_equal(np.sort(f.time_original), lc.time)
-    assert f.cycle.min() >= -1 and f.cycle.max() <= 15
-    fn = lc.fold(period=3.3, epoch_time=1.0, normalize_phase=True)
-    assert fn.time.min() >= -0.5 and fn.time.max() <= 0.5
-    assert np.allclose(f.flux, fn.flux)
