@@ -236,7 +236,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LK_BENCH_FORCE_DIST=1 runs the N>1 code paths (RCCL init, gathers, barrier, max over ranks) with a single rank —
+    # the only way to exercise them on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("LK_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         dist.init_process_group("nccl", device_id=dev)
     handle = _capi.Handle.get(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
@@ -253,8 +256,8 @@ def main():
         d_pow = torch.empty((B, M), dtype=torch.float64, device=dev)
         d_max = torch.empty(B, dtype=torch.float64, device=dev)
         d_arg = torch.empty(B, dtype=torch.int64, device=dev)
-        gather_spec = world > 1 and args.gather == "spectra"
-        gather_sum = world > 1 and args.gather == "summary"
+        gather_spec = dist_on and args.gather == "spectra"
+        gather_sum = dist_on and args.gather == "summary"
         nch = max(1, min(args.chunks, B)) if gather_spec else 1
         bounds = np.linspace(0, B, nch + 1).astype(int)
         d_all = [torch.empty((world, bounds[c + 1] - bounds[c], M), dtype=torch.float64, device=dev)
@@ -482,7 +485,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -494,7 +497,7 @@ def main():
         step(k)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -512,7 +515,7 @@ def main():
             ls_step(k, other)
         sync()
         dt2 = time.perf_counter() - t1
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([dt2], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt2 = float(tt.item())
@@ -634,7 +637,7 @@ def main():
             out["cpu_baseline"] = cpu_base
             out["speedup_vs_cpu_baseline"] = value / cpu_base["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
