@@ -240,7 +240,19 @@ def main():
     # the only way to exercise them on a 1-GPU box
     dist_on = world > 1 or os.environ.get("LK_BENCH_FORCE_DIST") == "1"
     if dist_on:
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on STDOUT when the first communicator is created; this script's stdout is one
+        # JSON line, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     handle = _capi.Handle.get(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
 
