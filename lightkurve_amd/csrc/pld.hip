@@ -23,6 +23,7 @@
 namespace lk {
 
 constexpr int PLD_LMAX = 64;  // largest small eigenproblem kept in LDS
+constexpr int PLD_DIRECT_MAX = 138;  // largest P whose Gram matrix fits LDS for the direct Jacobi (512 threads)
 constexpr int PLD_KC = 128;   // rows of the basis staged in LDS per step of the MFMA product C Q
 constexpr int PLD_QS = PLD_LMAX + 2;  // LDS row stride of that stage (doubles)
 typedef double pld_d4 __attribute__((ext_vector_type(4)));
@@ -188,9 +189,14 @@ __global__ void pld_spline_kernel(const double *__restrict__ time, const double 
 // ------------------------------------------------------------------------------------------------ small eigenproblems
 // Parallel cyclic Jacobi on a symmetric n x n matrix M (LDS, leading dim ld, n even); W <- eigenvectors (columns),
 // diag(M) <- eigenvalues.  All threads of the workgroup participate.  rot: n/2 x 4 doubles of LDS scratch.
-__device__ void jacobi_eig_lds(double *M, double *W, int n, int ld, double *rot, double *shred) {
+// Wt != nullptr: the eigenvectors are kept TRANSPOSED in global memory (Wt[p * n + i] = W[i][p], n x n) instead of in W
+// (LDS) — rows p and q of Wt are what a rotation touches, so the accesses stay coalesced.
+__device__ void jacobi_eig_lds(double *M, double *W, int n, int ld, double *rot, double *shred, double *Wt = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int e = tid; e < n * n; e += nt) W[(e / n) * ld + (e % n)] = (e / n == e % n) ? 1.0 : 0.0;
+    if (Wt)
+        for (int e = tid; e < n * n; e += nt) Wt[e] = (e / n == e % n) ? 1.0 : 0.0;
+    else
+        for (int e = tid; e < n * n; e += nt) W[(e / n) * ld + (e % n)] = (e / n == e % n) ? 1.0 : 0.0;
     __syncthreads();
     const int half = n >> 1;
     for (int sweep = 0; sweep < 40; ++sweep) {
@@ -253,10 +259,17 @@ __device__ void jacobi_eig_lds(double *M, double *W, int n, int ld, double *rot,
                 const double mp = M[i * ld + p], mq = M[i * ld + q];
                 M[i * ld + p] = c * mp - s * mq;
                 M[i * ld + q] = s * mp + c * mq;
-                const double wp = W[i * ld + p], wq = W[i * ld + q];
-                W[i * ld + p] = c * wp - s * wq;
-                W[i * ld + q] = s * wp + c * wq;
+                if (Wt) {
+                    const double wp = Wt[(size_t)p * n + i], wq = Wt[(size_t)q * n + i];
+                    Wt[(size_t)p * n + i] = c * wp - s * wq;
+                    Wt[(size_t)q * n + i] = s * wp + c * wq;
+                } else {
+                    const double wp = W[i * ld + p], wq = W[i * ld + q];
+                    W[i * ld + p] = c * wp - s * wq;
+                    W[i * ld + q] = s * wp + c * wq;
+                }
             }
+            if (Wt) __threadfence_block();
             __syncthreads();
         }
     }
@@ -286,7 +299,8 @@ __device__ __forceinline__ double gsym(const double *__restrict__ G, int ldg, in
 // scratch per matrix: 4 * P * l doubles (Q, Z, R, Y).
 __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__ G, int ldg, int P, int k, int l, int npow,
                                                              double *__restrict__ scratch, double *__restrict__ V,
-                                                             double *__restrict__ lam, int *__restrict__ iters_out) {
+                                                             double *__restrict__ lam, int *__restrict__ iters_out,
+                                                             int max_it, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     double *Gb = G + (size_t)b * ldg * ldg;
@@ -300,6 +314,41 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
     int *order = reinterpret_cast<int *>(vec + 2 * l);  // l ints
     double *qstage = vec + 2 * l + (l + 1) / 2 + 1;      // PLD_KC x PLD_QS (subspace path only)
 
+    if (P <= l && l > PLD_LMAX) {
+        if (status && status[b]) return;  // the short subspace pass already converged this matrix
+        // ---- direct, mid-size (PLD_LMAX < P <= PLD_DIRECT_MAX): Jacobi on C itself with C in LDS (l x (l + 1) doubles
+        // fill it) and the eigenvectors transposed in global scratch.  A few ms per matrix, against tens of Rayleigh-
+        // Ritz steps of the subspace iteration when the spectrum of a 2nd-order product block decays slowly.
+        double *Wt = scratch + (size_t)b * l * l;
+        double *rot2 = T + l * ld, *shred2 = rot2 + 2 * l, *vec2 = shred2 + nt;
+        int *order2 = reinterpret_cast<int *>(vec2 + 2 * l);
+        for (int e = tid; e < l * l; e += nt) {
+            const int i = e / l, j = e % l;
+            T[i * ld + j] = (i < P && j < P) ? gsym(Gb, ldg, i, j) : 0.0;
+        }
+        __syncthreads();
+        jacobi_eig_lds(T, nullptr, l, ld, rot2, shred2, Wt);
+        if (tid < l && tid >= P) T[tid * ld + tid] = -1.0;  // pad eigenvalue sorts last
+        __syncthreads();
+        // order by eigenvalue, l may exceed 64: rank by counting, one thread per entry
+        for (int a = tid; a < l; a += nt) {
+            const double v = T[a * ld + a];
+            int rank = 0;
+            for (int j = 0; j < l; ++j) {
+                const double u = T[j * ld + j];
+                rank += (u > v || (u == v && j < a)) ? 1 : 0;
+            }
+            order2[rank] = a;
+        }
+        __syncthreads();
+        for (int e = tid; e < P * k; e += nt) {
+            const int a = e / P, i = e - a * P;  // i fastest: rows of Wt are read contiguously
+            Vb[(size_t)i * k + a] = Wt[(size_t)order2[a] * l + i];
+        }
+        if (tid < k) lamb[tid] = T[order2[tid] * ld + order2[tid]];
+        if (tid == 0 && iters_out) iters_out[b] = 0;
+        return;
+    }
     if (P <= l) {
         // ---- direct: Jacobi on C itself (l = P rounded up to even; the pad row/col is zero)
         for (int e = tid; e < l * l; e += nt) {
@@ -520,7 +569,8 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
     __syncthreads();
     svqb(Q, R);
     int it = 0;
-    for (; it < 400; ++it) {
+    bool converged = false;
+    for (; it < max_it; ++it) {
         cq_mfma(Q, Z);  // Z = C Q
         // T = Q^T Z (symmetrised)
         for (int e = tid; e < l * l; e += nt) {
@@ -563,7 +613,10 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         const double th0 = fabs(T[order[0] * ld + order[0]]);
         if (tid < k) lamb[tid] = T[order[tid] * ld + order[tid]];  // T is reused by the orthonormalisation below
         __syncthreads();
-        if (res <= 1e-13 * th0 * sqrt((double)k)) break;
+        if (res <= 1e-13 * th0 * sqrt((double)k)) {
+            converged = true;
+            break;
+        }
         // next basis: orthonormalised C^npow R (npow - 1 more products between two Rayleigh-Ritz steps)
         double *src = Y, *dst = Z;
         for (int pw = 1; pw < npow; ++pw) {
@@ -582,43 +635,62 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         Vb[e] = R[(size_t)i * l + a];
     }
     if (tid == 0 && iters_out) iters_out[b] = it;
+    if (tid == 0 && status) status[b] = converged ? 1 : 0;
 }
 
-// U = A V diag(lam)^-1/2 into X[:, col0 : col0 + k]
+// U = A V diag(lam)^-1/2 into X[:, col0 : col0 + k] on the fp64 matrix cores.  One workgroup = 64 rows of A (4 waves x
+// 16 rows); A is streamed once through a 64 x 64 LDS tile (512-B row segments), V through a 64 x 16 k_tiles tile;
+// v_mfma_f64_16x16x4: A operand [row = lane & 15][kk = lane >> 4], B operand [kk = lane >> 4][col = lane & 15],
+// D [row = (lane >> 4) + 4 r][col = lane & 15].  k <= 64 components (4 column tiles).
+constexpr int PRJ_TS = 65;  // LDS row stride of the A tile (doubles): odd => the 16 rows of an operand hit 16 banks pairs
 __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restrict__ A, const double *__restrict__ V,
                                                            const double *__restrict__ lam, int N, int P, int k, int ldx,
                                                            int col0, double *__restrict__ X) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (n >= N) return;
-    const double *row = A + ((size_t)b * N + n) * P;
+    __shared__ double At[64 * PRJ_TS];
+    __shared__ double Vt[64 * 64];
+    const int b = blockIdx.y, n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double *Ab = A + (size_t)b * N * P;
     const double *Vb = V + (size_t)b * P * k;
-    for (int a0 = 0; a0 < k; a0 += 4) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        for (int p = lane; p < P; p += 64) {
-            const double r = row[p];
-            const double *v = Vb + (size_t)p * k + a0;
-            s0 = fma(r, v[0], s0);
-            if (a0 + 1 < k) s1 = fma(r, v[1], s1);
-            if (a0 + 2 < k) s2 = fma(r, v[2], s2);
-            if (a0 + 3 < k) s3 = fma(r, v[3], s3);
+    const int kt = (k + 15) >> 4;
+    pld_d4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            At[r * PRJ_TS + c] = (n0 + r < N && p0 + c < P) ? Ab[(size_t)(n0 + r) * P + p0 + c] : 0.0;
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            s0 += __shfl_down(s0, off);
-            s1 += __shfl_down(s1, off);
-            s2 += __shfl_down(s2, off);
-            s3 += __shfl_down(s3, off);
+        for (int e = tid; e < 64 * 16 * kt; e += 256) {
+            const int r = e / (16 * kt), c = e - r * (16 * kt);
+            Vt[r * 64 + c] = (p0 + r < P && c < k) ? Vb[(size_t)(p0 + r) * k + c] : 0.0;
         }
-        if (lane == 0) {
-            double *x = X + ((size_t)b * N + n) * ldx + col0 + a0;
-            const double *lb = lam + (size_t)b * k + a0;
-            x[0] = s0 / sqrt(fmax(lb[0], 1e-300));
-            if (a0 + 1 < k) x[1] = s1 / sqrt(fmax(lb[1], 1e-300));
-            if (a0 + 2 < k) x[2] = s2 / sqrt(fmax(lb[2], 1e-300));
-            if (a0 + 3 < k) x[3] = s3 / sqrt(fmax(lb[3], 1e-300));
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < 64; kk += 4) {
+            const double av = At[(wave * 16 + (lane & 15)) * PRJ_TS + kk + (lane >> 4)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < kt) {
+                    const double bv = Vt[(kk + (lane >> 4)) * 64 + c * 16 + (lane & 15)];
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
+                }
         }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < kt) {
+            const int a = c * 16 + (lane & 15);
+            if (a < k) {
+                const double sc = sqrt(fmax(lam[(size_t)b * k + a], 1e-300));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wave * 16 + (lane >> 4) + 4 * r;
+                    if (n < N) X[((size_t)b * N + n) * ldx + col0 + a] = acc[c][r] / sc;
+                }
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
@@ -633,37 +705,59 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         return LK_ENOMEM;
     }
     gram_plain_launch(A, d_off, B, P, G, stream);
-    int l;
-    if (P <= PLD_LMAX) {
-        l = (P + 1) & ~1;
-    } else {
-        l = std::min(PLD_LMAX, (k + 16 + 1) & ~1);
-    }
-    double *scr = nullptr;
-    if (P > l) {
-        scr = (double *)ws.alloc((size_t)B * 4 * P * l * 8);
-        if (!scr) {
-            set_error("PLD workspace exhausted (subspace)");
-            return LK_ENOMEM;
-        }
-    }
-    double *V = (double *)ws.alloc((size_t)B * P * k * 8), *lam = (double *)ws.alloc((size_t)B * k * 8);
-    if (!V || !lam) {
-        set_error("PLD workspace exhausted (V)");
-        return LK_ENOMEM;
-    }
-    const int ld = l + 1;
-    const size_t lds = ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1 + (P > l ? PLD_KC * PLD_QS : 0)) * 8 + 64;
+    static const int direct_max = getenv("LK_PLD_DIRECT_MAX") ? atoi(getenv("LK_PLD_DIRECT_MAX")) : PLD_DIRECT_MAX;
+    static const int npow = getenv("LK_PLD_POWER") ? std::max(1, atoi(getenv("LK_PLD_POWER"))) : 3;
     static bool attr_set = false;
     if (!attr_set) {
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    static const int npow = getenv("LK_PLD_POWER") ? std::max(1, atoi(getenv("LK_PLD_POWER"))) : 3;
-    hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                       (int *)nullptr);
-    hipLaunchKernelGGL(pld_project_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, A, V, lam, N, P, k, ldx, col0, X);
+    double *V = (double *)ws.alloc((size_t)B * P * k * 8), *lam = (double *)ws.alloc((size_t)B * k * 8);
+    if (!V || !lam) {
+        set_error("PLD workspace exhausted (V)");
+        return LK_ENOMEM;
+    }
+    // Mid-size blocks (PLD_LMAX < P <= PLD_DIRECT_MAX) get two passes: a SHORT subspace iteration (a pixel block with a
+    // few dominant stars converges in ~5 Rayleigh-Ritz steps), then the direct Jacobi on C itself for the matrices that
+    // did not converge (2nd-order product blocks decay slowly: ~45 steps of the iteration vs one ~15 ms Jacobi).
+    const bool two_pass = P > PLD_LMAX && P <= std::min(direct_max, PLD_DIRECT_MAX);
+    int *status = nullptr;
+    if (two_pass) {
+        status = (int *)ws.alloc((size_t)B * 4);
+        if (!status) {
+            set_error("PLD workspace exhausted (status)");
+            return LK_ENOMEM;
+        }
+    }
+    if (P > PLD_LMAX) {  // subspace iteration
+        const int l = std::min(PLD_LMAX, (k + 16 + 1) & ~1), ld = l + 1;
+        double *scr = (double *)ws.alloc((size_t)B * 4 * P * l * 8);
+        if (!scr) {
+            set_error("PLD workspace exhausted (subspace)");
+            return LK_ENOMEM;
+        }
+        const size_t lds = ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1 + PLD_KC * PLD_QS) * 8 + 64;
+        hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
+                           (int *)nullptr, two_pass ? 8 : 400, status);
+    }
+    if (P <= PLD_LMAX || two_pass) {  // direct Jacobi on C
+        const int l = (P + 1) & ~1, ld = l + 1;
+        double *scr = nullptr;
+        if (two_pass) {
+            scr = (double *)ws.alloc((size_t)B * l * l * 8);
+            if (!scr) {
+                set_error("PLD workspace exhausted (eigenvectors)");
+                return LK_ENOMEM;
+            }
+        }
+        const int nt_eig = two_pass ? 512 : 1024;
+        const size_t lds = two_pass ? ((size_t)l * ld + 2 * l + nt_eig + 2 * l + (l + 1) / 2 + 1) * 8 + 64
+                                    : ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1) * 8 + 64;
+        hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(nt_eig), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
+                           (int *)nullptr, 400, status);
+    }
+    hipLaunchKernelGGL(pld_project_kernel, dim3((N + 63) / 64, B), dim3(256), 0, stream, A, V, lam, N, P, k, ldx, col0, X);
     return LK_OK;
 }
 
@@ -672,7 +766,7 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
                       int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,
                       double *prior_sigma, hipStream_t stream) {
     LK_REQUIRE(B >= 1 && N >= 2, "need B >= 1 cutouts with N >= 2 cadences");
-    LK_REQUIRE(pca_components >= 1, "pca_components must be >= 1 on the HIP path");
+    LK_REQUIRE(pca_components >= 1 && pca_components <= 48, "pca_components must be between 1 and 48 on the HIP path");
     LK_REQUIRE(pld_order >= 0 && pld_order <= 4, "pld_order outside 0..4");
     LK_REQUIRE(Pb >= 1 && bkg_pix, "at least one background pixel is required");
     LK_REQUIRE(spline_degree >= 0 && spline_degree <= 7, "spline_degree outside 0..7");
