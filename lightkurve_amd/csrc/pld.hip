@@ -90,33 +90,47 @@ __global__ __launch_bounds__(256) void pld_center_kernel(double *__restrict__ A,
         for (int n = ry; n < N; n += 8) Ab[(size_t)n * P + c] -= mean;
 }
 
-// all `order`-fold products (combinations with replacement, lexicographic) of the k columns of U (ldu = ldx)
-__global__ void pld_products_kernel(const double *__restrict__ X, int ldx, int col0, int k, int order, int N, int Pc,
-                                    double *__restrict__ out) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x;
-    const double *u = X + ((size_t)b * N + n) * ldx + col0;
-    double *o = out + ((size_t)b * N + n) * Pc;
-    // thread t handles combos t, t + blockDim, ...: unrank the combination index
-    for (int idx = threadIdx.x; idx < Pc; idx += blockDim.x) {
-        int rem = idx, lo = 0;
-        double prod = 1.0;
-        for (int pos = 0; pos < order; ++pos) {
-            // choose the smallest a >= lo such that the number of combos starting with a' < a is <= rem
-            for (int a = lo; a < k; ++a) {
-                // combos of the remaining (order - pos - 1) slots from values >= a: C(k - a + r - 1, r)
-                const int r = order - pos - 1;
-                long long cnt = 1;
-                for (int i = 1; i <= r; ++i) cnt = cnt * (k - a + i - 1) / i;
-                if (rem < cnt) {
-                    prod *= u[a];
-                    lo = a;
-                    break;
-                }
-                rem -= (int)cnt;
-            }
+// all `order`-fold products (combinations with replacement, lexicographic: itertools order, as the reference's
+// multichoose loop) of the k columns of U = X[:, col0 : col0 + k].  comb[idx * order + pos] = column of factor pos of
+// product idx (built once per (k, order) on the host).  Two kernels: the column means of the products (nothing is
+// written), then the CENTRED products — the PCA input — in one pass over A.
+__global__ __launch_bounds__(256) void pld_products_mean_kernel(const double *__restrict__ X, int ldx, int col0, int order,
+                                                                 int N, int Pc, const uint8_t *__restrict__ comb,
+                                                                 double *__restrict__ mean) {
+    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Pc) return;
+    int a[4] = {0, 0, 0, 0};
+    for (int pos = 0; pos < order; ++pos) a[pos] = comb[idx * order + pos];
+    const double *u = X + (size_t)b * N * ldx + col0;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const double *r = u + (size_t)n * ldx;
+        double prod = r[a[0]];
+        for (int pos = 1; pos < order; ++pos) prod *= r[a[pos]];
+        s += prod;
+    }
+    mean[(size_t)b * Pc + idx] = s / (double)N;
+}
+
+__global__ __launch_bounds__(256) void pld_products_kernel(const double *__restrict__ X, int ldx, int col0, int k, int order,
+                                                            int N, int Pc, const uint8_t *__restrict__ comb,
+                                                            const double *__restrict__ mean, double *__restrict__ out) {
+    __shared__ double us[4][64];
+    const int b = blockIdx.y, n0 = blockIdx.x * 4;
+    for (int e = threadIdx.x; e < 4 * k; e += 256) {
+        const int r = e / k, c = e - r * k;
+        us[r][c] = n0 + r < N ? X[((size_t)b * N + n0 + r) * ldx + col0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Pc; idx += 256) {
+        int a[4] = {0, 0, 0, 0};
+        for (int pos = 0; pos < order; ++pos) a[pos] = comb[idx * order + pos];
+        const double m = mean[(size_t)b * Pc + idx];
+        for (int r = 0; r < 4 && n0 + r < N; ++r) {
+            double prod = us[r][a[0]];
+            for (int pos = 1; pos < order; ++pos) prod *= us[r][a[pos]];
+            out[((size_t)b * N + n0 + r) * Pc + idx] = prod - m;
         }
-        o[idx] = prod;
     }
 }
 
@@ -696,8 +710,8 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
 // ------------------------------------------------------------------------------------------------ launcher
 // PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
 static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
-                     int col0, hipStream_t stream, Arena &ws) {
-    hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
+                     int col0, hipStream_t stream, Arena &ws, bool centred = false) {
+    if (!centred) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
     const int KB = (P + 63) / 64, ldg = KB * 64;
     double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
     if (!G) {
@@ -803,8 +817,33 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
         for (int o = 2; o <= pld_order; ++o) {
             h->ws.used = mark;  // the previous block's Gram / subspace scratch is dead once its kernels are enqueued
             const int Pc = ncombos(k1, o), ko = std::min(pca_components, Pc);
-            hipLaunchKernelGGL(pld_products_kernel, dim3(N, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc, A);
-            rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws);
+            // combination table (itertools.combinations_with_replacement order)
+            std::vector<uint8_t> comb((size_t)Pc * o);
+            {
+                std::vector<int> cur((size_t)o, 0);
+                for (int idx = 0; idx < Pc; ++idx) {
+                    for (int pos = 0; pos < o; ++pos) comb[(size_t)idx * o + pos] = (uint8_t)cur[pos];
+                    int pos = o - 1;
+                    while (pos >= 0 && cur[pos] == k1 - 1) --pos;
+                    if (pos >= 0) {
+                        const int v = cur[pos] + 1;
+                        for (int q = pos; q < o; ++q) cur[q] = v;
+                    }
+                }
+            }
+            uint8_t *d_comb = (uint8_t *)h->ws.alloc(comb.size());
+            double *d_mean = (double *)h->ws.alloc((size_t)B * Pc * 8);
+            if (!d_comb || !d_mean) {
+                set_error("PLD workspace exhausted (products)");
+                return LK_ENOMEM;
+            }
+            LK_HIP_CHECK(hipMemcpyAsync(d_comb, comb.data(), comb.size(), hipMemcpyHostToDevice, stream));
+            LK_HIP_CHECK(hipStreamSynchronize(stream));  // comb dies at the end of this iteration
+            hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(256), 0, stream, X, K, col1, o, N,
+                               Pc, d_comb, d_mean);
+            hipLaunchKernelGGL(pld_products_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc,
+                               d_comb, d_mean, A);
+            rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws, true);
             if (rc) return rc;
             col += ko;
         }
