@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--freqs", type=int, default=100000, help="trial frequencies (M)")
     ap.add_argument("--chunks", type=int, default=4, help="target chunks per step (comm/compute overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ls", choices=["ls", "bls", "pld", "flatten", "lschi2", "pgsmooth", "fold"])
+    ap.add_argument("--workload", default="ls", choices=["ls", "bls", "pld", "flatten", "lschi2", "pgsmooth", "fold", "regress"])
+    ap.add_argument("--regressors", type=int, default=135, help="regress: design-matrix columns K")
     ap.add_argument("--nterms", type=int, default=2, help="lschi2: Fourier terms")
     ap.add_argument("--cutouts", type=int, default=500, help="PLD: cutouts per GPU")
     ap.add_argument("--pld-cadences", type=int, default=3500)
@@ -203,6 +204,22 @@ def cpu_baseline_pgsmooth(args):
             "sample": "1 periodogram x %d frequencies, logmedian filter_width 0.01, numpy restatement of the reference loop" % M}
 
 
+def cpu_baseline_regress(args):
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(0)
+    n, K, nb = args.pld_cadences, args.regressors, 4
+    t0 = None
+    Xs = [rng.standard_normal((n, K)) for _ in range(nb)]
+    ys = [X @ rng.standard_normal(K) * 1e-3 + 1 + 1e-3 * rng.standard_normal(n) for X in Xs]
+    t0 = time.perf_counter()
+    for X, y in zip(Xs, ys):
+        O.regression_correct(X, y, np.full(n, 1e-3), prior_mu=np.zeros(K), prior_sigma=np.full(K, 10.0))
+    dt = time.perf_counter() - t0
+    return {"value": nb / dt, "unit": "fits/sec", "cores": effective_cores(), "kind": "port",
+            "sample": "%d fits, N=%d, K=%d, 5 sigma-clip iterations, numpy port of RegressionCorrector.correct "
+                      "(BLAS/LAPACK may thread)" % (nb, n, K)}
+
+
 def cpu_baseline_fold(args):
     from lightkurve_amd import synth
     from oracle import np_oracle as O
@@ -226,7 +243,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = {"ls": cpu_baseline_ls, "bls": cpu_baseline_bls, "pld": cpu_baseline_pld,
                     "flatten": cpu_baseline_flatten, "lschi2": cpu_baseline_lschi2, "pgsmooth": cpu_baseline_pgsmooth,
-                    "fold": cpu_baseline_fold}[args.workload](args)
+                    "fold": cpu_baseline_fold, "regress": cpu_baseline_regress}[args.workload](args)
 
     import torch
     import torch.distributed as dist
@@ -389,6 +406,41 @@ def main():
         pairs_per_step = float(off[-1])
         metric, unit = "flatten cadences/sec (window 401, niters 3)", "cadences/sec"
         workload = "flatten: %d light curves x %d cadences, window 401, polyorder 2, niters 3 per GPU" % (B, N)
+    elif args.workload == "regress":
+        Bc, Nc, K = args.cutouts, args.pld_cadences, args.regressors
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        d_X = torch.randn((Bc * Nc, K), dtype=torch.float64, device=dev, generator=g)
+        d_coef = torch.randn((Bc, K), dtype=torch.float64, device=dev, generator=g) * 1e-3
+        d_y = (d_X.view(Bc, Nc, K) @ d_coef.unsqueeze(-1)).reshape(-1) + 1.0 + \
+            1e-3 * torch.randn(Bc * Nc, dtype=torch.float64, device=dev, generator=g)
+        d_err = torch.full((Bc * Nc,), 1e-3, dtype=torch.float64, device=dev)
+        d_mu = torch.zeros(K, dtype=torch.float64, device=dev)
+        d_ps = torch.full((K,), 10.0, dtype=torch.float64, device=dev)
+        d_w = torch.empty((Bc, K), dtype=torch.float64, device=dev)
+        d_model = torch.empty(Bc * Nc, dtype=torch.float64, device=dev)
+        d_out = torch.empty(Bc * Nc, dtype=torch.uint8, device=dev)
+        offp = np.arange(Bc + 1, dtype=np.int64) * Nc
+        lib = _capi.load_library()
+        import ctypes
+        vp = ctypes.c_void_p
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps + args.warmup)]
+
+        def step(k):
+            e0, e1 = ev[k]
+            e0.record()
+            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), K,
+                                                  vp(d_X.data_ptr()), vp(d_y.data_ptr()), vp(d_err.data_ptr()), None,
+                                                  vp(d_mu.data_ptr()), vp(d_ps.data_ptr()), 5.0, 5, vp(d_w.data_ptr()),
+                                                  vp(d_model.data_ptr()), vp(d_out.data_ptr()), vp(stream)))
+            e1.record()
+
+        off = offp
+        units_per_step = Bc
+        pairs_per_step = float(Bc) * 5 * 2.0 * Nc * (K + 1) ** 2   # Gram flop over the 5 clip iterations
+        metric, unit = "RegressionCorrector fits/sec (N=%d, K=%d, 5 sigma-clip iterations)" % (Nc, K), "fits/sec"
+        workload = "configs[4] regression stage: %d fits, N=%d cadences, K=%d regressors per GPU" % (Bc, Nc, K)
+        B, N = Bc, Nc
     elif args.workload == "lschi2":
         t, y, dy, off = synth.ls_batch(1, B, N, first_index=rank * B)
         for b in range(B):
@@ -613,6 +665,14 @@ def main():
                                "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "flatten_kernel", "kernel_ms_per_step": kern_ms,
                                "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
+        elif args.workload == "regress":
+            ach = pairs_per_step / (kern_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
+                               "note": "algorithmic 2*N*(K+1)^2 flop per Gram build x 5 sigma-clip iterations (SURVEY.md "
+                                       "8(d)); the step also runs 5 LU solves, 5 model products and 5 sigma-clips per fit; "
+                                       "X (N*K*8 B per fit) is re-read each iteration"}
         elif args.workload == "lschi2":
             fl = 2.0 * (4 + 4 * (2 * args.nterms - 1) + 6 * args.nterms) * pairs_per_step
             out["roofline"] = {"bound": "valu", "achieved": fl / (kern_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
