@@ -93,3 +93,39 @@ def test_invalid_period_duration():
         _capi.bls_batch(t, np.zeros(200), np.ones(200), [0, 200], [0.3, 1.0], [0.5])
     with pytest.raises(ValueError, match="period"):
         _capi.bls_batch(t, np.zeros(200), np.ones(200), [0, 200], [1.0, np.nan], [0.1])
+
+
+@pytest.mark.parametrize("use_like", [True, False])
+def test_stress_regimes_bit_exact(use_like):
+    """The skip-ahead scan must never change a result: regimes that stress its bound — pure noise (best barely above
+    the crowd), very deep and very shallow transits, quantised flux (exact ties), constant flux (every objective equal),
+    zero-weight cadences, wildly different weights — all seven outputs == the C oracle."""
+    rng = np.random.default_rng(42)
+    n = 3000
+    t = np.sort(rng.uniform(0, 27.0, n))
+    sig = 5e-4
+    cases = {}
+    cases["noise"] = (rng.normal(0, sig, n), np.full(n, sig ** -2))
+    y = rng.normal(0, sig, n)
+    y[((t - 0.3) % 2.75) < 0.12] -= 2e-2
+    cases["deep"] = (y, np.full(n, sig ** -2))
+    y = rng.normal(0, sig, n)
+    y[((t - 1.1) % 4.1) < 0.2] -= 3e-4
+    cases["shallow"] = (y, np.full(n, sig ** -2))
+    cases["quantised"] = (np.round(rng.normal(0, sig, n) / 2.5e-4) * 2.5e-4, np.full(n, 1.0))
+    cases["constant"] = (np.zeros(n), np.full(n, 1.0))
+    w = np.full(n, sig ** -2)
+    w[rng.random(n) < 0.2] = 0.0
+    cases["zero_weights"] = (rng.normal(0, sig, n), w)
+    cases["wild_weights"] = (rng.normal(0, sig, n), 10.0 ** rng.uniform(2, 9, n))
+    period = np.concatenate([np.linspace(0.55, 8.9, 150), [2.75, 4.1]])
+    duration = np.linspace(0.02, 0.5, 41)
+    ys, ws = zip(*cases.values())
+    tt, off = synth.pack_ragged([t] * len(cases))
+    yy, _ = synth.pack_ragged([y - np.median(y) for y in ys])
+    ww, _ = synth.pack_ragged(list(ws))
+    res = _capi.bls_batch(tt, yy, ww, off, period, duration, 10, use_like)
+    for b, name in enumerate(cases):
+        ref = O.bls(t, ys[b] - np.median(ys[b]), ws[b], period, duration, 10, use_like)
+        for field, r in zip(_capi.BLS_FIELDS, ref):
+            assert np.array_equal(res[field][b], r, equal_nan=True), (name, field)
