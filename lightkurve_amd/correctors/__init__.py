@@ -3,3 +3,4 @@ from .designmatrix import DesignMatrix, DesignMatrixCollection  # noqa: F401
 from .pldcorrector import PixelCube, PLDCorrector, pld_correct_batch  # noqa: F401
 from .regressioncorrector import RegressionCorrector  # noqa: F401
 from .metrics import overfit_metric_lombscargle  # noqa: F401
+from .cbvcorrector import CBVCorrector  # noqa: F401

@@ -192,6 +192,38 @@ def gen_fold():
     save("fold", **out)
 
 
+def gen_cbv():
+    """CBVCorrector.correct_gaussian_prior (cbvcorrector.py:221-292) with hand-made basis vectors: the same collection
+    ([CBVs, Constant]) and prior widths CBVCorrector builds (:639-778), fitted by the reference RegressionCorrector."""
+    from lightkurve.correctors import RegressionCorrector, DesignMatrix, DesignMatrixCollection
+    import pandas as pd
+    rng = np.random.default_rng(17)
+    n, nv = 1800, 12
+    t = np.linspace(0, 27, n)
+    raw = np.column_stack([np.sin(2 * np.pi * (j + 1) * t / 54.0 + j) + 0.3 * rng.standard_normal(n).cumsum() / np.sqrt(n)
+                           for j in range(nv)])
+    cbvs, _ = np.linalg.qr(raw - raw.mean(0))
+    flux = 1000.0 * (1 + cbvs[:, :8] @ rng.normal(0, 0.02, 8)) + rng.normal(0, 0.8, n)
+    err = np.full(n, 0.8) * rng.uniform(0.9, 1.1, n)
+    cm = np.ones(n, bool)
+    cm[900:960] = False
+    lc = lk.LightCurve(time=t, flux=flux, flux_err=err)
+    out = dict(time=t, flux=flux, flux_err=err, cbvs=cbvs, cadence_mask=cm)
+    for tag, alpha in (("weak", 1e-20), ("ridge", 0.5), ("none", 0.0)):
+        sigma = None if alpha == 0.0 else np.median(err) / np.sqrt(np.abs(alpha))
+        mats = [DesignMatrix(pd.DataFrame(cbvs[:, :8], columns=["VECTOR_%d" % i for i in range(1, 9)]), name="SingleScale"),
+                DesignMatrix(np.ones(n), columns=["Constant"], name="Constant")]
+        for dm in mats:
+            dm.prior_sigma = np.ones(dm.shape[1]) * (np.inf if sigma is None else sigma)
+        rc = RegressionCorrector(lc)
+        clc = rc.correct(DesignMatrixCollection(mats), cadence_mask=cm)
+        out["alpha_" + tag] = alpha
+        out["coefficients_" + tag] = rc.coefficients
+        out["corrected_" + tag] = clc.flux.value
+        out["outlier_" + tag] = rc.outlier_mask
+    save("cbv_ridge", **out)
+
+
 def gen_bls():
     t, y, e, truth = synth.bls_target(3, 0, 2500, cadence_days=10.0 / 1440.0)
     lc = lk.LightCurve(time=t + 1325.5, flux=y, flux_err=e)
@@ -351,6 +383,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "metrics", "fold", "bls", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "metrics", "fold", "cbv", "bls", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

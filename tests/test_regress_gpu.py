@@ -127,3 +127,19 @@ def test_regressioncorrector_api_like_reference(golden):
     clc = rc.correct(DesignMatrix(g["X"], name="X", prior_mu=g["prior_mu"], prior_sigma=g["prior_sigma"]),
                      cadence_mask=g["cadence_mask"])
     assert np.array_equal(rc.outlier_mask, g["outlier_mask"]) and np.allclose(clc.flux, g["corrected"], atol=1e-11)
+
+
+def test_cbv_gaussian_prior_golden(golden):
+    """Row A14: CBVCorrector.correct_gaussian_prior = [CBVs, Constant] with one ridge width on every column, fitted by
+    the regression kernels; golden from the reference RegressionCorrector on the same collection (1e-9 relative)."""
+    from lightkurve_amd.correctors.cbvcorrector import CBVCorrector
+    from lightkurve_amd.lightcurve import LightCurve
+    g = golden("cbv_ridge")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    for tag in ("weak", "ridge", "none"):
+        cor = CBVCorrector(lc, g["cbvs"])
+        out = cor.correct_gaussian_prior(cbv_indices=np.arange(1, 9), alpha=float(g["alpha_" + tag]),
+                                         cadence_mask=g["cadence_mask"])
+        assert np.array_equal(cor.outlier_mask, g["outlier_" + tag])
+        assert np.max(np.abs(out.flux - g["corrected_" + tag])) <= 1e-9 * np.max(np.abs(g["corrected_" + tag]))
+        assert np.allclose(cor.coefficients, g["coefficients_" + tag], rtol=1e-7, atol=1e-9 * np.abs(g["coefficients_" + tag]).max())
