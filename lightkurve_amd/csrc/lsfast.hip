@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double
     // k1 = ka + A kb, advances by e^{2 pi i c A / N} each time
     int last_f = -1;
     double2 w = make_double2(1.0, 0.0), step = w;
-    const int twl = 31 - __clz(tw);  // tw is a power of two
+    const int twl = tw > 0 ? 31 - __clz(tw) : 0;  // tw is a power of two (negative: row-tiled layout, see below)
     auto store = [&](int f, int k1, double2 v, int) {
         const int c = c0 + f;
         if (f != last_f) {  // first output of this thread: k1 = ka
@@ -540,7 +540,12 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double
         }
         // gout: separate buffer in the tiled layout [c / tw][k1][c % tw] (a workgroup's output is one contiguous
         // run and step 2 reads 16 B x tw x RT runs); otherwise in place in the natural layout
-        if (gout)
+        if (gout && tw < 0) {
+            // row-tiled layout [k1 / H][c][k1 % H], H = -tw: the H rows one step-2 workgroup transforms are one
+            // contiguous N2 * H * 16-B chunk; this kernel's stores come in runs of CT * H * 16 B
+            const int hl = 31 - __clz(-tw);
+            gout[((size_t)blockIdx.y << (m1 + m2)) + (((((size_t)(k1 >> hl)) << m2) + c) << hl) + (k1 & (-tw - 1))] = cmul(v, w);
+        } else if (gout)
             gout[((size_t)blockIdx.y << (m1 + m2)) + ((((size_t)(c >> twl) << m1) + k1) << twl) + (c & (tw - 1))] = cmul(v, w);
         else
             G[(size_t)k1 * N2 + c] = cmul(v, w);
@@ -568,6 +573,167 @@ __global__ __launch_bounds__(256) void fft_rows_reg_kernel(const double2 *__rest
         if (k < nkeep) S[k] = v;
     };
     block_fft<LA, LB, 0>(RT, lds2, load, store);
+}
+
+// ------------------------------------------------------------------------------------------------ three-phase FFT
+// Block transform of NF sequences of length n = A*B*C (A = 2^LA, ...) in THREE register phases with two LDS exchanges.
+// A thread never holds more than max(A, B, C) <= 16 points, so the kernels built on it need ~100 VGPRs instead of
+// ~220-290 and 4-5 waves per SIMD stay resident: loads of one wave overlap the butterflies of the others (the
+// two-phase kernels above run 1-2 waves per SIMD and alternate between waiting on HBM and computing).
+//   input index  e = a*B*C + b*C + c,   output index  k = ka + A*kb + A*B*kc
+//   phase 1  thread t = b*C + c        A-point FFT over a, times W_n^{t ka}            -> LDS [ka][t]       (stride S1)
+//   phase 2  thread (ka, c)            B-point FFT over b, times W_{BC}^{c kb}         -> LDS [c][ka + A kb] (stride S3)
+//   phase 3  thread t3 = ka + A*kb     C-point FFT over c                               -> store(f, t3 + A*B*kc, ., kc)
+// load(f, e) / store(f, k, value, kc) as in block_fft.  Threads per sequence T = max(BC, AC, AB); tile: NF * FFT3_TILE
+// double2.  MODE as in block_fft (thread order of the phase-1 loads).
+template <int LA, int LB, int LC>
+struct Fft3 {
+    static constexpr int A = 1 << LA, B = 1 << LB, C = 1 << LC, n = A * B * C;
+    static constexpr int T = (B * C > A * C ? (B * C > A * B ? B * C : A * B) : (A * C > A * B ? A * C : A * B));
+    static constexpr int S1 = B * C + 8, S3 = A * B + 2;  // strides chosen so 16-lane groups of 16-B accesses tile the banks
+    static constexpr int TILE = (A * S1 > C * S3 ? A * S1 : C * S3);
+};
+
+template <int LA, int LB, int LC, int MODE, class Load, class Store>
+__device__ __forceinline__ void block_fft3(int NF, double2 *tile, Load load, Store store, int tw = 1) {
+    using F = Fft3<LA, LB, LC>;
+    constexpr int A = F::A, B = F::B, C = F::C, n = F::n, T = F::T, S1 = F::S1, S3 = F::S3;
+    const int tid = threadIdx.x;
+    int f, t;
+    if (MODE == 1) {
+        f = tid % NF;
+        t = tid / NF;
+    } else if (MODE == 2) {
+        const int jl = tid % tw, rest = tid / tw;
+        f = rest % NF;
+        t = jl + tw * (rest / NF);
+    } else {
+        f = tid / T;
+        t = tid % T;
+    }
+    const bool live = tid < NF * T;
+    double2 *my = tile + (size_t)f * F::TILE;
+    // ---- phase 1
+    if (live && t < B * C) {
+        double2 v[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) v[a] = load(f, a * (B * C) + t);
+        reg_fft<LA>(v);
+        double s1, c1;
+        sincospi(2.0 * (double)t / (double)n, &s1, &c1);
+        const double2 step = make_double2(c1, s1);
+        double2 w = make_double2(1.0, 0.0);
+#pragma unroll
+        for (int ka = 0; ka < A; ++ka) {
+            my[ka * S1 + t] = cmul(v[brev_c(ka, LA)], w);
+            w = cmul(w, step);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2
+    double2 u[B];
+    const int ka2 = t / C, c2 = t % C;
+    if (live && t < A * C) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) u[b] = my[ka2 * S1 + b * C + c2];
+        reg_fft<LB>(u);
+    }
+    __syncthreads();  // every read of the [ka][t] layout is done before the tile is overwritten
+    if (live && t < A * C) {
+        double s1, c1;
+        sincospi(2.0 * (double)c2 / (double)(B * C), &s1, &c1);
+        const double2 step = make_double2(c1, s1);
+        double2 w = make_double2(1.0, 0.0);
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) {
+            my[c2 * S3 + ka2 + A * kb] = cmul(u[brev_c(kb, LB)], w);
+            w = cmul(w, step);
+        }
+    }
+    __syncthreads();
+    // ---- phase 3
+    if (live && t < A * B) {
+        double2 z[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[c] = my[c * S3 + t];
+        reg_fft<LC>(z);
+#pragma unroll
+        for (int kc = 0; kc < C; ++kc) store(f, t + A * B * kc, z[brev_c(kc, LC)], kc);
+    }
+}
+
+// step 2 fused with the closed form, three-phase version: thread (f, t3) ends with the outputs k2 = t3 + A*B*kc of row
+// r0 + f and keeps those below M / N1 (kc < KC) for the three grids
+template <int LA, int LB, int LC, int KC>
+__global__ __launch_bounds__(512) void fft_rows_power3_kernel(const double2 *__restrict__ grids, int m1, int RT,
+                                                               const int64_t *__restrict__ n_off,
+                                                               const FastStats *__restrict__ stats, int b0, double f0,
+                                                               double df, int64_t M, int fit_mean, int norm,
+                                                               const double *__restrict__ scale,
+                                                               double *__restrict__ power, int tw) {
+    extern __shared__ __attribute__((aligned(16))) double2 lds2[];
+    using F = Fft3<LA, LB, LC>;
+    constexpr int m2 = LA + LB + LC;
+    const int twl = tw > 0 ? 31 - __clz(tw) : 0;
+    const int lb = blockIdx.y, r0 = blockIdx.x * RT;
+    double2 keep[3][KC];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int q = 0; q < KC; ++q) keep[g][q] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        if (g == 1 && !fit_mean) continue;
+        const double2 *G = grids + ((size_t)(lb * 3 + g) << (m1 + m2));
+        auto store = [&](int, int, double2 v, int kc) {
+            if (kc < KC) keep[g][kc < KC ? kc : 0] = v;
+        };
+        if (tw < 0) {  // row-tiled layout (RT == -tw): this workgroup's rows are one contiguous chunk, f fastest
+            const double2 *Gt = G + (((size_t)blockIdx.x << m2) * (size_t)RT);
+            auto load = [&](int f, int c) -> double2 { return Gt[(size_t)c * RT + f]; };
+            block_fft3<LA, LB, LC, 1>(RT, lds2, load, store);
+        } else {
+            auto load = [&](int f, int c) -> double2 {
+                return G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))];
+            };
+            block_fft3<LA, LB, LC, 2>(RT, lds2, load, store, tw);
+        }
+        __syncthreads();
+    }
+    // the (f, t) mapping of block_fft3 (MODE 1 for the row-tiled layout, MODE 2 otherwise)
+    const int tid = threadIdx.x;
+    if (tid >= RT * F::T) return;
+    int f, t3;
+    if (tw < 0) {
+        f = tid % RT;
+        t3 = tid / RT;
+    } else {
+        const int jl = tid % tw, rest = tid / tw;
+        f = rest % RT;
+        t3 = jl + tw * (rest / RT);
+    }
+    if (t3 >= F::A * F::B) return;
+    const int b = b0 + lb;
+    const FastStats st = stats[b];
+    const double nn = (double)(n_off[b + 1] - n_off[b]);
+    const double sc = scale ? scale[b] : 1.0;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const long long k = (long long)(r0 + f) + ((long long)(t3 + F::A * F::B * kc) << m1);
+        if (k >= M) continue;
+        double2 a = keep[0][kc], bq = keep[1][kc], c2 = keep[2][kc];
+        if (st.t0 != 0.0) {
+            const double twopi = 6.283185307179586;
+            double s, c;
+            sincos(twopi * st.t0 * (f0 + df * (double)k), &s, &c);
+            a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+            bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
+            sincos(twopi * st.t0 * (2.0 * f0 + 2.0 * df * (double)k), &s, &c);
+            c2 = make_double2(c2.x * c - c2.y * s, c2.x * s + c2.y * c);
+        }
+        power[(size_t)b * (size_t)M + k] = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY,
+                                                          0.5 * st.wsum, nn, sc);
+    }
 }
 
 // step 2 fused with the closed form: one workgroup transforms rows r0..r0+RT-1 of the THREE grids of a target in
@@ -779,8 +945,61 @@ static bool rows_power_available(int m1, int m2, int64_t M) {
     return m2 >= 4 && m2 <= 10 && (k2need + Aa - 1) / Aa <= 8;
 }
 
+template <int LA, int LB, int LC, int KC>
+static void launch_rows_power3_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, int tw, hipStream_t stream) {
+    using F = Fft3<LA, LB, LC>;
+    const int N1 = 1 << m1;
+    static const int rt_env = getenv("LK_FFT3_RT") ? atoi(getenv("LK_FFT3_RT")) : 4;  // 4 rows: 37 KB LDS, 4 workgroups per CU
+    int RT = std::max(1, std::min(N1, 512 / F::T));
+    if (rt_env > 0) RT = std::max(1, std::min(RT, rt_env));
+    while (RT > 1 && (N1 % RT)) --RT;
+    if (tw < 0) RT = -tw;  // the row-tiled intermediate fixes the rows per workgroup
+    const int nt = ((RT * F::T + 63) / 64) * 64;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_power3_kernel<LA, LB, LC, KC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((fft_rows_power3_kernel<LA, LB, LC, KC>), dim3(N1 / RT, ntargets), dim3(nt),
+                       (size_t)RT * F::TILE * 16, stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M,
+                       a.fit_mean, a.norm, a.scale, a.power, tw);
+}
+
+// three-phase step 2 where an instantiation exists (needs the tiled intermediate layout, tw >= 1, T % tw == 0)
+static bool launch_rows_power3(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
+                               hipStream_t stream) {
+    // measured on configs[1]: +2 % on one box, -1.3 % on another vs the two-phase kernel at 2 waves/SIMD — step 2 is
+    // limited by how fast HBM serves its 64-B x RT runs, not by occupancy — so the three-phase kernel is opt-in
+    if (!(getenv("LK_FFT3") && atoi(getenv("LK_FFT3")) == 1)) return false;
+    const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
+#define LK_RP3(la, lb, lc)                                                              \
+    {                                                                                   \
+        const int ab = 1 << ((la) + (lb));                                              \
+        const int kc = (int)((k2need + ab - 1) / ab);                                   \
+        if (kc <= 2) {                                                                  \
+            launch_rows_power3_t<la, lb, lc, 2>(m1, ntargets, grids, a, tw, stream);    \
+            return true;                                                                \
+        }                                                                               \
+        if (kc <= 4 && (1 << (lc)) >= 4) {                                              \
+            launch_rows_power3_t<la, lb, lc, 4>(m1, ntargets, grids, a, tw, stream);    \
+            return true;                                                                \
+        }                                                                               \
+        return false;                                                                   \
+    }
+    switch (m2) {
+        case 8: LK_RP3(3, 3, 2)
+        case 9: LK_RP3(3, 3, 3)
+        case 10: LK_RP3(4, 3, 3)
+        default: return false;
+    }
+#undef LK_RP3
+}
+
 static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
                               hipStream_t stream) {
+    if (launch_rows_power3(m1, m2, ntargets, grids, a, tw, stream)) return true;
+    if (tw < 0) return false;  // the two-phase kernel below reads the column-tiled layout only
     const int LA = (m2 + 1) / 2, Aa = 1 << LA;
     const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
     const int kb = (int)((k2need + Aa - 1) / Aa);
@@ -886,7 +1105,21 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     }
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10 && !getenv("LK_FFT_RADIX2");
     const bool fused = reg_path && !getenv("LK_FFT_UNFUSED") && rows_power_available(m1, m2, M);
-    const int tw = tile_width(m1, m2);
+    int tw = tile_width(m1, m2);
+    {
+        // row-tiled intermediate (negative tw = -rows per tile): step-2 workgroups would stream contiguous chunks, but
+        // step 1's stores shrink to CT * H * 16-B runs — measured slower (18.5 ms at H = 8, 15.5 at H = 4 vs 15.0), so
+        // it stays an experiment behind LK_FFT_LAYOUT=1 (LK_FFT_RTILE sets H).
+        const long long k2need = (M + ((long long)1 << m1) - 1) >> m1;
+        const int la3 = m2 == 10 ? 4 : 3, lb3 = 3, lc3 = m2 - la3 - lb3;
+        const bool three = fused && m2 >= 8 && m2 <= 10 && getenv("LK_FFT3") && atoi(getenv("LK_FFT3")) == 1 &&
+                           (k2need + (1 << (la3 + lb3)) - 1) / (1 << (la3 + lb3)) <= (lc3 >= 2 ? 4 : 2);
+        const int h8 = getenv("LK_FFT_RTILE") ? atoi(getenv("LK_FFT_RTILE")) : 8;
+        const int T3 = 1 << std::max(std::max(lb3 + lc3, la3 + lc3), la3 + lb3);
+        if (three && getenv("LK_FFT_LAYOUT") && atoi(getenv("LK_FFT_LAYOUT")) == 1 && (h8 == 2 || h8 == 4 || h8 == 8) &&
+            h8 * T3 <= 512 && (1 << m1) % h8 == 0)
+            tw = -h8;
+    }
     double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16) : nullptr;
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
@@ -913,7 +1146,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             if (fused) {
                 // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
                 launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
-                launch_rows_power(m1, m2, nb, d_grids2, fa, tw, stream);
+                LK_REQUIRE(launch_rows_power(m1, m2, nb, d_grids2, fa, tw, stream), "no step-2 kernel for this layout");
                 continue;
             }
             launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, nullptr, 1, stream);
