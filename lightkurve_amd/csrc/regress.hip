@@ -62,21 +62,28 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
     const bool live_i0 = i0 + wi * 32 < Ka, live_i1 = i0 + wi * 32 + 16 < Ka;
     const bool live_j0 = j0 + wj * 32 < Ka, live_j1 = j0 + wj * 32 + 16 < Ka;
 
+    __shared__ double sw[GR_RC];  // the stage's 32 cadence weights (0 = masked), computed once per cadence
     for (int n0 = 0; n0 < n; n0 += GR_RC) {
+        if (tid < GR_RC) {
+            const int nn = n0 + tid;
+            double w = 0.0;
+            if (nn < n) {
+                const int64_t g = lo + nn;
+                if ((!cmask || cmask[g]) && !(outl && outl[g])) {
+                    const double s = err ? err[g] : 1.0;
+                    w = 1.0 / (s * s);
+                }
+            }
+            sw[tid] = w;
+        }
+        __syncthreads();
         // stage: 32 cadences x 64 columns for each operand; thread -> (row = tid/8 .. , 8 columns)
         for (int e = tid; e < GR_RC * GR_BLK; e += 256) {
             const int r = e >> 6, c = e & 63;
             const int nn = n0 + r;
             double va = 0.0, vb = 0.0;
             if (nn < n) {
-                const int64_t g = lo + nn;
-                const bool use = (!cmask || cmask[g]) && !(outl && outl[g]);
-                double w = 0.0;
-                if (use) {
-                    const double s = err ? err[g] : 1.0;
-                    w = 1.0 / (s * s);
-                }
-                va = aug(X, y, K, nn, i0 + c) * w;   // X / err^2 exactly as the reference forms it (:166)
+                va = aug(X, y, K, nn, i0 + c) * sw[r];   // X / err^2 exactly as the reference forms it (:166)
                 vb = aug(X, y, K, nn, j0 + c);
             }
             sa[r][c] = va;
