@@ -134,8 +134,8 @@ __device__ int block_compact(int n, Pred pred, int *out, int *sh) {
     return total;
 }
 
-constexpr int FIR_TILE = 2048;  // outputs per LDS tile of the interior correlation
-constexpr int FIR_LDS = 4096;   // doubles of LDS for a tile's inputs (window <= FIR_LDS - FIR_TILE + 1)
+// LDS plan (dynamic): sh[max(nt, 264)] 64-bit words | shi[nt] ints | fir[FIR_LDS + 2] doubles.  FIR_LDS = doubles of LDS
+// for a tile's inputs, FIR_TILE = FIR_LDS / 2 outputs per tile (window <= FIR_LDS - FIR_TILE + 1 takes the tiled path).
 
 struct FlattenScratch {  // per-target slab offsets are computed from N by the launcher
     double *tm, *fm, *tr;
@@ -147,10 +147,14 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     const double *__restrict__ t, const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
     const int64_t *__restrict__ n_off, int window, int polyorder, double break_tol, int niters, double sigma,
     const double *__restrict__ coeffs, const double *__restrict__ edge, char *__restrict__ scratch,
-    const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask) {
-    __shared__ unsigned long long sh[1024];
-    __shared__ int shi[1024];
-    __shared__ __attribute__((aligned(16))) double fir[FIR_LDS + 2];
+    const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask,
+    int FIR_LDS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
+    unsigned long long *sh = dyn_lds;
+    const int sh_words = max((int)blockDim.x, 264);
+    double *fir = reinterpret_cast<double *>(sh + sh_words);           // 16-B aligned: sh_words is even
+    int *shi = reinterpret_cast<int *>(fir + FIR_LDS + 2);
+    const int FIR_TILE = FIR_LDS / 2;
     const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int64_t lo = n_off[target];
     const int N = (int)(n_off[target + 1] - lo);
@@ -424,8 +428,18 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
     static const int flat_nt = getenv("LK_FLAT_NT") ? atoi(getenv("LK_FLAT_NT")) : 512;  // 512 threads x 3 workgroups per CU overlap the barrier-bound phases best
-    hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), 0, stream, t, flux, user_mask, d_off, window, polyorder,
-                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask);
+    static const int fir_lds_env = getenv("LK_FLAT_FIR") ? atoi(getenv("LK_FLAT_FIR")) : 4096;
+    int fir_lds = std::max(512, fir_lds_env & ~1);
+    while (fir_lds < 16384 && window > fir_lds / 2 + 1) fir_lds *= 2;  // keep the tiled FIR path for long windows
+    const size_t lds = (size_t)std::max(flat_nt, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)flat_nt * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
+                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
