@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(double2 *__restrict__ gri
 __global__ __launch_bounds__(256) void fft_rows_kernel(const double2 *__restrict__ grids, int m1, int m2, int RT,
                                                         int nkeep, double2 *__restrict__ spec) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
-    const int N1 = 1 << m1, N2 = 1 << m2;
+    const int N2 = 1 << m2;
     double2 *x = lds2, *tw = lds2 + (size_t)RT * N2;
     const double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
     double2 *S = spec + (size_t)blockIdx.y * nkeep;
