@@ -15,6 +15,7 @@
 // answer wherever the spectrum has a gap.  PCA bases are only defined up to rotation inside a block and the
 // regression is invariant to it, so parity is stated on the corrected flux.
 // The order-1 block skips the reference's redundant re-PCA of an already orthonormal basis (same subspace).
+#include <type_traits>
 #include <vector>
 
 #include "block_select.hpp"
@@ -445,13 +446,17 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
     // tiles of C and streams each of its C elements exactly once per product.
     const int wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
     const int na = (l + 15) >> 4, ntile = (P + 15) >> 4;
-    auto cq_mfma = [&](const double *src, double *dst) {
+    // NA (16-column tiles of the basis, l <= 16 NA) is a compile-time constant: with a run-time bound the compiler keeps
+    // all 4 x 4 accumulator tiles (128 VGPRs = the whole budget of a 1024-thread workgroup) and spills hundreds of
+    // registers around every MFMA
+    auto cq_impl = [&](auto na_c, const double *src, double *dst) {
+        constexpr int NA = decltype(na_c)::value;
         for (int tbase = 0; tbase < ntile; tbase += 4 * nwv) {
-            pld_d4 acc[4][4];
+            pld_d4 acc[4][NA];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int ai = 0; ai < 4; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
+                for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
             for (int k0 = 0; k0 < P; k0 += PLD_KC) {
                 __syncthreads();
                 for (int e = tid; e < PLD_KC * 16 * na; e += nt) {
@@ -468,30 +473,35 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
                         const int ncol = (tbase + wave + t * nwv) * 16 + (lane & 15);
                         bv[t] = (krow < P && ncol < P) ? Gb[(size_t)krow * ldg + ncol] : 0.0;
                     }
-                    double av[4];
+                    double av[NA];
 #pragma unroll
-                    for (int ai = 0; ai < 4; ++ai)
-                        av[ai] = ai < na ? qstage[(kk + (lane >> 4)) * PLD_QS + ai * 16 + (lane & 15)] : 0.0;
+                    for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + (lane >> 4)) * PLD_QS + ai * 16 + (lane & 15)];
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int ai = 0; ai < 4; ++ai)
-                            if (ai < na) acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv[t], acc[t][ai], 0, 0, 0);
+                        for (int ai = 0; ai < NA; ++ai)
+                            acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv[t], acc[t][ai], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int n = (tbase + wave + t * nwv) * 16 + (lane & 15);
 #pragma unroll
-                for (int ai = 0; ai < 4; ++ai)
+                for (int ai = 0; ai < NA; ++ai)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int a = ai * 16 + (lane >> 4) + 4 * r;
-                        if (ai < na && n < P && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
+                        if (n < P && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
                     }
             }
         }
         __syncthreads();
+    };
+    auto cq_mfma = [&](const double *src, double *dst) {
+        if (na <= 2)
+            cq_impl(std::integral_constant<int, 2>{}, src, dst);
+        else
+            cq_impl(std::integral_constant<int, 4>{}, src, dst);
     };
 
     // ---- Cholesky-QR of the P x l matrix Yin -> Qout (two passes).  The columns handed in are images C^q r of Ritz
