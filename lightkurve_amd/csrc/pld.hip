@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
 // ------------------------------------------------------------------------------------------------ launcher
 // PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
 static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
-                     int col0, hipStream_t stream, Arena &ws, bool centred = false) {
+                     int col0, hipStream_t stream, Arena &ws, bool centred = false, bool products = false) {
     if (!centred) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
     const int KB = (P + 63) / 64, ldg = KB * 64;
     double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
@@ -754,7 +754,10 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
             return LK_ENOMEM;
         }
     }
-    if (P > PLD_LMAX) {  // subspace iteration
+    // product blocks are known to need the Jacobi: skip their short subspace pass (status stays all zero)
+    const bool direct_only = two_pass && products;
+    if (direct_only) LK_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)B * 4, stream));
+    if (P > PLD_LMAX && !direct_only) {  // subspace iteration
         const int l = std::min(PLD_LMAX, (k + 16 + 1) & ~1), ld = l + 1;
         double *scr = (double *)ws.alloc((size_t)B * 4 * P * l * 8);
         if (!scr) {
@@ -853,7 +856,7 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
                                Pc, d_comb, d_mean);
             hipLaunchKernelGGL(pld_products_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc,
                                d_comb, d_mean, A);
-            rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws, true);
+            rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws, true, true);
             if (rc) return rc;
             col += ko;
         }
