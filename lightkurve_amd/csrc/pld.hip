@@ -7,11 +7,13 @@
 //   order 1: pixel flux / SAP flux;  order n: all n-fold products of the order-1 components;  background pixels.
 //
 // PCA = Gram + eigen: C = A^T A on the fp64 matrix cores (gram_mfma_kernel, the "MFMA A^T A" of config[4]), the
-// top-k eigenpairs of C by blocked subspace iteration with Rayleigh-Ritz and SVQB orthonormalisation (small
-// l x l eigenproblems by parallel cyclic Jacobi in LDS; for P <= 64 the Jacobi runs on C itself), then
-// U = A V diag(lambda)^-1/2 written straight into X.  The reference uses fbpca (randomised range finder, 10 power
-// iterations, 2 oversampling columns, unseeded RNG => not reproducible); the oracle uses an exact SVD; the
-// subspace iteration here converges the residual ||C r - theta r|| to 1e-13 theta_max, i.e. to the exact
+// top-k eigenpairs of C by blocked subspace iteration with Rayleigh-Ritz — C Q on the matrix cores too, three power
+// steps per Ritz step, column-scaled Cholesky-QR between them (SVQB as the fallback and for the random start; small
+// l x l eigenproblems by parallel cyclic Jacobi in LDS) — or, for blocks of at most 138 columns whose iteration does
+// not converge in eight steps, by a direct Jacobi on C held in LDS; for P <= 64 the Jacobi always runs on C itself.
+// Then U = A V diag(lambda)^-1/2 (pld_project_kernel, MFMA) written straight into X.  The reference uses fbpca
+// (randomised range finder, 10 power iterations, 2 oversampling columns, unseeded RNG => not reproducible); the oracle
+// uses an exact SVD; the iteration here converges the residual ||C r - theta r|| to 1e-13 theta_max, i.e. to the exact
 // answer wherever the spectrum has a gap.  PCA bases are only defined up to rotation inside a block and the
 // regression is invariant to it, so parity is stated on the corrected flux.
 // The order-1 block skips the reference's redundant re-PCA of an already orthonormal basis (same subspace).
