@@ -7,16 +7,19 @@
 // BIT-IDENTICAL to the reference (tests/test_bls_gpu.py compares with ==).
 //
 // One 256-thread workgroup per (target, period); everything lives in LDS:
-//   pass A  each thread walks a contiguous slice of the cadences, computes the cycle number k = floor(t/P)
-//           and phase r = fmod(t, P) exactly (fma remainder with +-1 correction) and marks where a new
-//           "round" starts (k changes or r decreases).  Inside a round the bin index is non-decreasing, so
-//           every bin is touched by ONE contiguous run of cadences.
-//   pass B  rounds are processed in order (one barrier each).  A round is split evenly over the threads; a
-//           thread owns the runs that START in its slice and adds them to the LDS bin one cadence at a time
-//           (bin += y*ivar, the reference's order).  No two threads ever touch the same bin in a round.
-//   wrap    pad + sequential inclusive prefix sum (two lanes, one per array; sequential = same rounding).
-//   scan    lanes stride over start bins, durations outermost; IEEE divisions; each lane keeps its first best
-//           (strict >), the block reduction breaks ties by (duration index, start bin) = the reference's
+//   pass A  round boundaries.  A "round" is a maximal run of cadences whose bin index does not decrease, so every
+//           bin is touched by ONE contiguous run of cadences per round.  Time-sorted targets (flagged by the prep
+//           kernel): rounds are the cycles k = floor(t/P), found by one binary search each; otherwise two sweeps with
+//           the exact (k, r) = (trunc(t/P), fmod(t, P)) by fma remainder with +-1 correction.
+//   pass B  ordered histogram.  Bins are split into NW contiguous ranges, one per wave; a wave walks the rounds in
+//           order over its own bins (no workgroup barrier).  Per 64-cadence chunk the leader lane of each equal-bin run
+//           folds the run's members (parked in LDS) into the bin one cadence at a time: the reference's order.
+//   wrap    pad + sequential inclusive prefix sums (lane 0: y, lane 1: ivar; sequential = same rounding).
+//   scan    a thread owns a start bin and walks the durations in ascending length.  From each evaluation a rigorous
+//           bound on how fast the objective can grow with the window tells how many longer durations can be SKIPPED
+//           (they are strictly below the best seen so far); candidates that are reached pass a division-free
+//           conservative filter and only survivors run the reference's exact arithmetic (IEEE divisions), which alone
+//           decides the result.  Ties are broken by (caller's duration index, start bin) = the reference's
 //           duration-major / phase-minor "first wins" order.  The winner recomputes the reported statistics.
 // blockIdx -> (target, period) is XCD-aware (all periods of a target on one XCD; its t / y*ivar / ivar arrays,
 // 24 B per cadence, stay in that XCD's L2).
@@ -407,14 +410,17 @@ __global__ __launch_bounds__(1024) void bls_kernel(
     __syncthreads();
 
     // ---- scan
-    // Wave w takes durations w, w+4, ...; its lanes stride over the start bins.  Every candidate first goes
-    // through a DIVISION-FREE conservative filter against the best objective seen so far by anyone in the
-    // workgroup (s_thr): with a = y_out sum, b = ivar_in, c = y_in sum, e = ivar_out and Nn = a*b - c*e,
-    //     likelihood  0.5*b*(a/e - c/b)^2 > thr  <=>  0.5*Nn^2 > thr*b*e^2
-    //     snr         (a/e - c/b)/sqrt(1/b+1/e) > thr  <=>  Nn >= 0 and Nn^2 > thr^2*b*e*(b+e)
-    // evaluated with an absolute slack eN >= every rounding the exact chain can commit, so a rejected candidate
-    // is STRICTLY below the threshold and can never be the winner (ties always reach the exact path).  Survivors
-    // (a handful per workgroup) run the reference's exact arithmetic, which alone decides the result.
+    // A thread owns start bins n = tid, tid + NT, ... and walks the durations in ascending length.  With a = y_out sum,
+    // b = ivar_in, c = y_in sum, e = ivar_out and Nn = a*b - c*e = S*b - E*c (S, E the totals):
+    //     likelihood  0.5*b*(a/e - c/b)^2 = 0.5*Nn^2 / (b*e^2)        snr  (a/e - c/b)/sqrt(1/b+1/e) = Nn / sqrt(b*e*E)
+    // (1) skip-ahead: growing the window by one bin changes Nn by at most gmax, only raises b, lowers e by at most wmax,
+    //     so from one evaluation the largest m with "every window up to m bins longer is STRICTLY below thr" follows
+    //     in closed form (1e-4 safety factors, absolute slack far above the prefix-sum rounding); the walk jumps there.
+    // (2) candidates that are reached go through a division-free conservative filter with an absolute slack eN >= every
+    //     rounding the exact chain can commit, so a rejected candidate is STRICTLY below the threshold and can never be
+    //     the winner (ties always reach the exact path).
+    // (3) survivors (a handful per workgroup) run the reference's exact arithmetic, which alone decides the result.
+    // thr = the best objective seen so far by anyone in the workgroup (s_thr), warm-started from a coarse lattice.
     double best = -INFINITY;
     int bk = -1, bn = -1;
     if (!(ablate & 4)) {
