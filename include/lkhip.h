@@ -84,6 +84,18 @@ int lk_ls_chi2_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const d
                          int fit_mean, int center_data, int normalization, const double *scale, double *power,
                          void *stream);
 
+/* ---- Lomb-Scargle ls_method="fastchi2" with nterms Fourier terms (periodogram.py:948-967): astropy
+ * lombscargle_fastchi2 (fastchi2_impl.py:60-137) — the multi-term fit of lk_ls_chi2_batch with every trig sum taken
+ * from the extirpolated FFT grids (3 nterms grids per target), regular frequency grid only.  Agrees with the
+ * reference's 'fastchi2' output to ~1e-9 where the fit is well posed.  nterms = 1 is lk_ls_fast_batch. */
+int lk_ls_fastchi2_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                         double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
+                         const double *scale, int oversampling, double *power);
+int lk_ls_fastchi2_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                             const double *dy, double f0, double df, int64_t M, int nterms, int fit_mean,
+                             int center_data, int normalization, const double *scale, int oversampling, double *power,
+                             void *stream);
+
 /* ---- LightCurve.fold (src/lightkurve/lightcurve.py:1089-1214 over astropy TimeSeries.fold, timeseries/sampled.py:
  * 230-233) for B ragged targets: phase = ((t - epoch_time) + epoch_phase + (P - wrap)) % P - (P - wrap) (numpy `%`),
  * divided by P if normalize_phase (epoch_phase and wrap_phase are then in phase units), followed by a STABLE sort by

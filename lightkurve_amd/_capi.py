@@ -44,6 +44,12 @@ SIGNATURES = [
     ("lk_ls_chi2_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_ls_fastchi2_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int, _c_dp]),
+    ("lk_ls_fastchi2_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
     ("lk_ls_fast_batch", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int, _c_dp]),
@@ -224,9 +230,11 @@ def ls_power_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, freq_ptr, f0
 
 
 def ls_fast_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True, normalization="psd",
-                  scale=None, oversampling=5, device=0):
+                  scale=None, oversampling=5, device=0, nterms=1):
     """The reference's default ``ls_method="fast"`` (extirpolation + FFT) for B ragged targets on the regular grid
-    ``f0 + df*arange(M)`` -> float64[B, M]."""
+    ``f0 + df*arange(M)`` -> float64[B, M].  ``nterms`` > 1: its multi-term sibling ``"fastchi2"``."""
+    if not 1 <= int(nterms) <= MAX_NTERMS:
+        raise ValueError("nterms must be between 1 and %d on the HIP path (got %r)" % (MAX_NTERMS, nterms))
     h = Handle.get(device)
     t, y = _f64(t), _f64(y)
     n_off = _offsets(n_off, t.size)
@@ -236,9 +244,9 @@ def ls_fast_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, cent
     B, M = n_off.size - 1, int(M)
     scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
     power = np.empty((B, M), dtype=np.float64)
-    _check(_lib.lk_ls_fast_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), float(f0), float(df), M,
-                                 int(bool(fit_mean)), int(bool(center_data)), NORM[normalization], _ptr(scale),
-                                 int(oversampling), _ptr(power)))
+    _check(_lib.lk_ls_fastchi2_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), float(f0), float(df), M,
+                                     int(nterms), int(bool(fit_mean)), int(bool(center_data)), NORM[normalization],
+                                     _ptr(scale), int(oversampling), _ptr(power)))
     return power
 
 

@@ -38,6 +38,9 @@ def lombscargle_batch(lcs, frequency, normalization="amplitude", freq_unit=None,
         grid = exact_grid(f_day)
         kw = dict(normalization=plans[0]["norm"], scale=[p["scale"] for p in plans], device=device)
         nt = plans[0]["nterms"]
+        if nt > 1 and plans[0]["ls_method"] == "fastchi2":
+            return _capi.ls_fast_batch(t, y, off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=len(f_day),
+                                       nterms=nt, **kw)
         if nt > 1:
             if grid is not None:
                 return _capi.ls_power_batch(t, y, off, f0=grid[0], df=grid[1], M=len(f_day), nterms=nt, **kw)

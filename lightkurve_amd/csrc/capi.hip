@@ -289,9 +289,19 @@ int lk_ls_fast_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const d
                              oversampling, power, static_cast<hipStream_t>(stream));
 }
 
-int lk_ls_fast_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
-                     double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
-                     const double *scale, int oversampling, double *power) {
+int lk_ls_fastchi2_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                             const double *dy, double f0, double df, int64_t M, int nterms, int fit_mean,
+                             int center_data, int normalization, const double *scale, int oversampling, double *power,
+                             void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::lsfastchi2_launch(h, B, n_off_host, t, y, dy, f0, df, M, nterms, fit_mean, center_data, normalization,
+                                 scale, oversampling, power, static_cast<hipStream_t>(stream));
+}
+
+int lk_ls_fastchi2_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                         double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
+                         const double *scale, int oversampling, double *power) {
     LK_REQUIRE(h != nullptr, "handle is NULL");
     LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
     LK_REQUIRE(M >= 0, "M must be >= 0");
@@ -311,11 +321,18 @@ int lk_ls_fast_batch(lk_handle *h, int B, const int64_t *n_off, const double *t,
     LK_HIP_CHECK(hipMemcpy(dyv, y, nb, hipMemcpyHostToDevice));
     if (dy) LK_HIP_CHECK(hipMemcpy(ddy, dy, nb, hipMemcpyHostToDevice));
     if (scale) LK_HIP_CHECK(hipMemcpy(dscale, scale, sb, hipMemcpyHostToDevice));
-    rc = lk::lsfast_launch(h, B, n_off, dt, dyv, ddy, f0, df, M, fit_mean, center_data, normalization, dscale,
-                           oversampling, dpow, nullptr);
+    rc = lk::lsfastchi2_launch(h, B, n_off, dt, dyv, ddy, f0, df, M, nterms, fit_mean, center_data, normalization, dscale,
+                               oversampling, dpow, nullptr);
     if (rc) return rc;
     LK_HIP_CHECK(hipMemcpy(power, dpow, pb, hipMemcpyDeviceToHost));
     return LK_OK;
+}
+
+int lk_ls_fast_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
+                     double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
+                     const double *scale, int oversampling, double *power) {
+    return lk_ls_fastchi2_batch(h, B, n_off, t, y, dy, f0, df, M, 1, fit_mean, center_data, normalization, scale,
+                                oversampling, power);
 }
 
 // ------------------------------------------------------------------------------------------------ argmax

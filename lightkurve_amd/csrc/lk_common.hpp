@@ -48,6 +48,9 @@ struct Arena {
     void release();
 };
 
+int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+                      double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
+                      const double *scale, int oversampling, double *power, hipStream_t stream);
 }  // namespace lk
 
 namespace lk {
@@ -62,6 +65,9 @@ struct HostStage {
     int copy(void *dst, const void *src, size_t bytes, hipStream_t stream);
     void release();
 };
+int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+                      double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
+                      const double *scale, int oversampling, double *power, hipStream_t stream);
 }  // namespace lk
 
 struct lk_handle {
@@ -110,4 +116,7 @@ int pg_boxsmooth_launch(lk_handle *h, int B, int64_t M, const double *power, con
 int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
                   double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
                   const double *scale, int oversampling, double *power, hipStream_t stream);
+int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+                      double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
+                      const double *scale, int oversampling, double *power, hipStream_t stream);
 }  // namespace lk

@@ -325,105 +325,6 @@ __global__ __launch_bounds__(256) void ls_any_kernel(const CadAny *__restrict__ 
 // The sums here are the EXACT direct sums (what 'chi2' computes); harmonics come from the fundamental by the
 // Chebyshev recurrence c_m = 2 c_1 c_{m-1} - c_{m-2} (2 FMA each).  Per (cadence, frequency) pair:
 // 4 (phasor) + 4 (2 nterms - 1) (harmonics) + 6 nterms (accumulates) FMAs.
-template <int NT>
-struct Chi2Sums {
-    double Sw[2 * NT], Cw[2 * NT], Sy[NT], Cy[NT];
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int m = 0; m < 2 * NT; ++m) Sw[m] = Cw[m] = 0.0;
-#pragma unroll
-        for (int m = 0; m < NT; ++m) Sy[m] = Cy[m] = 0.0;
-    }
-    // fold one cadence: (a, b) = (cos, sin) of the fundamental phase, w = weight, wy = w (y - ybar)
-    __device__ __forceinline__ void add(double a, double b, double w, double wy) {
-        const double two_a = a + a;
-        double cm = 1.0, sm = 0.0, c = a, s2 = b;
-#pragma unroll
-        for (int m = 0; m < 2 * NT; ++m) {
-            Sw[m] = fma(w, s2, Sw[m]);
-            Cw[m] = fma(w, c, Cw[m]);
-            if (m < NT) {
-                Sy[m] = fma(wy, s2, Sy[m]);
-                Cy[m] = fma(wy, c, Cy[m]);
-            }
-            const double cn = fma(two_a, c, -cm), sn = fma(two_a, s2, -sm);
-            cm = c;
-            sm = s2;
-            c = cn;
-            s2 = sn;
-        }
-    }
-    // (X^T y)^T (X^T X)^-1 (X^T y) with weights normalised to sum 1 (yws = sum w (y - ybar))
-    __device__ __forceinline__ double solve(double yws, int fit_mean) const {
-        constexpr int D = 2 * NT + 1;
-        auto CW = [&](int m) { return m == 0 ? 1.0 : Cw[m - 1]; };
-        auto SW = [&](int m) { return m == 0 ? 0.0 : Sw[m - 1]; };
-        // basis order: 0 = bias (cos 0), 2i-1 = sin i, 2i = cos i
-        double A[D][D], bv[D];
-#pragma unroll
-        for (int r = 0; r < D; ++r) {
-            const int mr = (r + 1) >> 1;
-            const bool rs = (r & 1) != 0;  // sine?
-            bv[r] = r == 0 ? yws : (rs ? Sy[mr - 1] : Cy[mr - 1]);
-#pragma unroll
-            for (int c = 0; c <= r; ++c) {
-                const int mc = (c + 1) >> 1;
-                const bool cs = (c & 1) != 0;
-                const int dm = mr - mc, sm = mr + mc;  // mr >= mc because r >= c
-                double v;
-                if (rs && cs)
-                    v = 0.5 * (CW(dm) - CW(sm));
-                else if (!rs && !cs)
-                    v = 0.5 * (CW(dm) + CW(sm));
-                else if (rs && !cs)  // sin(mr) cos(mc): 0.5 (sign(mr - mc) Sw[|mr - mc|] + Sw[mr + mc])
-                    v = 0.5 * ((dm > 0 ? SW(dm) : 0.0) + SW(sm));
-                else  // cos(mr) sin(mc): 0.5 (sign(mc - mr) Sw[|mc - mr|] + Sw[mr + mc])
-                    v = 0.5 * ((dm > 0 ? -SW(dm) : 0.0) + SW(sm));
-                A[r][c] = v;
-            }
-        }
-        if (!fit_mean) {  // drop the bias: identity row/column leaves the rest of the solve untouched
-            A[0][0] = 1.0;
-            bv[0] = 0.0;
-#pragma unroll
-            for (int r = 1; r < D; ++r) A[r][0] = 0.0;
-        }
-        // Cholesky A = L L^T (lower, in place), z = L^-1 b, power = |z|^2
-        double p = 0.0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            double d = A[j][j];
-#pragma unroll
-            for (int m = 0; m < j; ++m) d = fma(-A[j][m], A[j][m], d);
-            const double inv = 1.0 / sqrt(d);
-            double z = bv[j];
-#pragma unroll
-            for (int m = 0; m < j; ++m) z = fma(-A[j][m], bv[m], z);
-            z *= inv;
-            bv[j] = z;
-            p = fma(z, z, p);
-#pragma unroll
-            for (int r = j + 1; r < D; ++r) {
-                double v = A[r][j];
-#pragma unroll
-                for (int m = 0; m < j; ++m) v = fma(-A[r][m], A[j][m], v);
-                A[r][j] = v * inv;
-            }
-        }
-        return p;
-    }
-};
-
-__device__ __forceinline__ double chi2_normalise(double p, int norm, double YY, double psd_factor, double nN,
-                                                 double scale) {
-    switch (norm) {
-        case LK_NORM_STANDARD: return p / YY;
-        case LK_NORM_PSD: return p * psd_factor;
-        case LK_NORM_LK_AMPLITUDE: return sqrt(p * psd_factor) * sqrt(4.0 / nN);
-        default: return p * psd_factor * scale;
-    }
-}
-
 constexpr int LS_CHI2_F = 4;  // frequencies per lane of the multi-term grid kernel (6 nterms sums each)
 
 template <int NT>

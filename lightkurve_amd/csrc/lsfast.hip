@@ -25,6 +25,7 @@ namespace lk {
 
 struct FastStats {
     double wsum, ybar, YY, t0;
+    double yws, pad;  // sum w (y - ybar) (the bias entry of X^T y in the multi-term solve)
 };
 
 // per target: weights, mean about y[0], YY, t0 = min t; w[i] (normalised) and wy[i] = w (y - ybar)
@@ -110,7 +111,10 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
         wy_out[lo + i] = w * yc;
     }
     const double YY = bsum(acc);
-    if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0};
+    acc = 0.0;
+    for (int64_t i = tid; i < n; i += 256) acc += wy_out[lo + i];  // each thread re-reads what it wrote
+    const double yws = bsum(acc);
+    if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0, yws, 0.0};
 }
 
 // astropy extirpolate (M = 4) of one complex sample h at position x into grid[0..nfft)
@@ -821,6 +825,67 @@ __global__ __launch_bounds__(256) void fft_rows_power_kernel(const double2 *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fastchi2
+// astropy lombscargle_fastchi2 (fastchi2_impl.py:60-137): the multi-term fit of chi2_impl with every trig sum taken
+// from the extirpolated FFT grids (trig_sum with freq_factor = m).  3 nterms grids per target:
+//   g <  nterms : w (y - ybar) at harmonic g + 1              g >= nterms : w at harmonic g - nterms + 1 (up to 2 nterms)
+__global__ __launch_bounds__(256) void lsf_scatter_multi_kernel(const double *__restrict__ t, const double *__restrict__ w,
+                                                                 const double *__restrict__ wy,
+                                                                 const int64_t *__restrict__ n_off,
+                                                                 const FastStats *__restrict__ stats, int b0, double f0,
+                                                                 double df, int nfft, int nterms,
+                                                                 double2 *__restrict__ grids) {
+    const int b = b0 + blockIdx.y;
+    const int64_t lo = n_off[b];
+    const int n = (int)(n_off[b + 1] - lo);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double tt = t[lo + i] - stats[b].t0;
+    double2 *g0 = grids + (size_t)blockIdx.y * 3 * nterms * nfft;
+    const double wi = w[lo + i], wyi = wy[lo + i];
+    const double twopi = 6.283185307179586;
+    for (int fac = 1; fac <= 2 * nterms; ++fac) {
+        const double dff = df * (double)fac, f0f = f0 * (double)fac;
+        double c = 1.0, s = 0.0;
+        if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
+        const double tn = fmod(tt * (double)nfft * dff, (double)nfft);
+        extirpolate4(g0 + (size_t)(nterms + fac - 1) * nfft, nfft, tn, wi * c, wi * s);
+        if (fac <= nterms) extirpolate4(g0 + (size_t)(fac - 1) * nfft, nfft, tn, wyi * c, wyi * s);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void lsf_chi2_power_kernel(const double2 *__restrict__ spec,
+                                                              const int64_t *__restrict__ n_off,
+                                                              const FastStats *__restrict__ stats, int b0, double f0,
+                                                              double df, int64_t M, int fit_mean, int norm,
+                                                              const double *__restrict__ scale,
+                                                              double *__restrict__ power) {
+    const int b = b0 + blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const FastStats st = stats[b];
+    const double2 *s0 = spec + (size_t)blockIdx.y * 3 * NT * M;
+    Chi2Sums<NT> sums;
+    const double twopi = 6.283185307179586;
+#pragma unroll
+    for (int m = 1; m <= 2 * NT; ++m) {
+        double cph = 1.0, sph = 0.0;
+        if (st.t0 != 0.0) sincos(twopi * st.t0 * (double)m * (f0 + df * (double)j), &sph, &cph);  // utils.py:151-153
+        const double2 a = s0[(size_t)(NT + m - 1) * M + j];
+        sums.Cw[m - 1] = a.x * cph - a.y * sph;
+        sums.Sw[m - 1] = a.x * sph + a.y * cph;
+        if (m <= NT) {
+            const double2 y = s0[(size_t)(m - 1) * M + j];
+            sums.Cy[m - 1] = y.x * cph - y.y * sph;
+            sums.Sy[m - 1] = y.x * sph + y.y * cph;
+        }
+    }
+    const double n = (double)(n_off[b + 1] - n_off[b]);
+    power[(size_t)b * (size_t)M + j] =
+        chi2_normalise(sums.solve_lu(st.yws, fit_mean), norm, st.YY, 0.5 * st.wsum, n, scale ? scale[b] : 1.0);
+}
+
 // closed form from the three spectra (C = real, S = imag of the unnormalised inverse transform)
 __global__ __launch_bounds__(256) void lsf_power_kernel(const double2 *__restrict__ spec,
                                                          const int64_t *__restrict__ n_off,
@@ -1158,6 +1223,90 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         }
         hipLaunchKernelGGL(lsf_power_kernel, dim3((unsigned)((M + 255) / 256), nb), dim3(256), 0, stream, d_spec,
                            d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power);
+    }
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fastchi2 launcher
+int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
+                      double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
+                      const double *scale, int oversampling, double *power, hipStream_t stream) {
+    LK_REQUIRE(nterms >= 1 && nterms <= LK_MAX_NTERMS, "nterms must be between 1 and %d (got %d)", LK_MAX_NTERMS, nterms);
+    if (nterms == 1)
+        return lsfast_launch(h, B, n_off_host, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
+                             oversampling, power, stream);
+    LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    LK_REQUIRE(M >= 0, "M must be >= 0");
+    if (B == 0 || M == 0) return LK_OK;
+    LK_REQUIRE(t && y && power, "t, y, power must be non-NULL");
+    LK_REQUIRE(f0 >= 0.0, "Frequencies must be positive");
+    LK_REQUIRE(df > 0.0, "Frequency steps must be positive");
+    LK_REQUIRE(oversampling >= 1, "oversampling must be >= 1");
+    LK_REQUIRE(normalization >= LK_NORM_STANDARD && normalization <= LK_NORM_LK_PSD, "unknown normalization %d",
+               normalization);
+    LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");
+    int64_t nmax = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t n = n_off_host[b + 1] - n_off_host[b];
+        LK_REQUIRE(n >= 1 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
+        nmax = std::max(nmax, n);
+    }
+    const int m = ilog2_ceil((long long)oversampling * (long long)M);
+    LK_REQUIRE(m >= 2 && m <= 26, "FFT grid of 2^%d points is outside the supported range", m);
+    const int nfft = 1 << m, m1 = (m + 1) / 2, m2 = m / 2;
+    const int N1 = 1 << m1, N2 = 1 << m2;
+    const int NG = 3 * nterms;
+    const size_t ntot = (size_t)n_off_host[B];
+    const size_t per_target = (size_t)NG * nfft * 16;
+    const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)2 << 30) / per_target));
+    h->ws.reset();
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
+                           (size_t)Bc * per_target + (size_t)Bc * NG * M * 16 + 16384);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
+    double *d_w = (double *)h->ws.alloc(ntot * 8), *d_wy = (double *)h->ws.alloc(ntot * 8);
+    double2 *d_grids = (double2 *)h->ws.alloc((size_t)Bc * per_target);
+    double2 *d_spec = (double2 *)h->ws.alloc((size_t)Bc * NG * M * 16);
+    rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
+                       d_w, d_wy, d_stats, df, nfft, m2, (int *)nullptr);
+    const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+        attr_set = true;
+    }
+    const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
+    const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int nb = std::min(Bc, B - b0);
+        LK_HIP_CHECK(hipMemsetAsync(d_grids, 0, (size_t)nb * per_target, stream));
+        hipLaunchKernelGGL(lsf_scatter_multi_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, d_w,
+                           d_wy, d_off, d_stats, b0, f0, df, nfft, nterms, d_grids);
+        if (reg_path) {
+            launch_cols_reg(m1, m2, nb * NG, d_grids, nullptr, nullptr, 1, stream);
+            launch_rows_reg(m1, m2, nb * NG, d_grids, (int)M, d_spec, stream);
+        } else {
+            hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * NG), dim3(256), ldsA, stream, d_grids, m1, m2, CT);
+            hipLaunchKernelGGL(fft_rows_kernel, dim3(N1 / RT, nb * NG), dim3(256), ldsB, stream, d_grids, m1, m2, RT,
+                               (int)M, d_spec);
+        }
+        const dim3 pg((unsigned)((M + 255) / 256), nb);
+#define LK_FC2(NT)                                                                                                    \
+    hipLaunchKernelGGL(lsf_chi2_power_kernel<NT>, pg, dim3(256), 0, stream, d_spec, d_off, d_stats, b0, f0, df, M,    \
+                       fit_mean, normalization, scale, power)
+        switch (nterms) {
+            case 2: LK_FC2(2); break;
+            case 3: LK_FC2(3); break;
+            default: LK_FC2(4); break;
+        }
+#undef LK_FC2
     }
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;

@@ -329,17 +329,22 @@ class LombScarglePeriodogram(Periodogram):
         default output to 1e-9; like the reference it needs a regular frequency grid and otherwise switches to
         ``"slow"``.  Every other name (``"slow"``, ``"cython"``, ``"chi2"``, ``"scipy"``, ``"auto"``, ``"hip"``) runs
         the exact fp64 direct-sum kernels (== the reference's exact methods to 1e-9).  ``nterms`` > 1 (with
-        ``ls_method`` ``"chi2"`` or ``"fastchi2"``, as in the reference) runs the multi-term least-squares kernels,
-        which reproduce the reference's ``"chi2"`` output to 1e-9 (``"fastchi2"`` is its FFT approximation)."""
+        ``ls_method`` ``"chi2"`` or ``"fastchi2"``, as in the reference) runs the multi-term kernels: exact sums for
+        ``"chi2"``, extirpolated FFT sums for ``"fastchi2"`` — each reproduces the reference's output of that name."""
         plan = _ls_plan(lc, minimum_frequency, maximum_frequency, minimum_period, maximum_period, frequency, period,
                         nterms, nyquist_factor, oversample_factor, freq_unit, normalization, ls_method, **kwargs)
         n = len(plan["trel"])
         grid = exact_grid(plan["f_day"])
         common = dict(dy=plan["dy"], fit_mean=plan["fit_mean"], center_data=plan["center_data"],
                       normalization=plan["norm"], scale=[plan["scale"]], device=device)
-        if plan["nterms"] > 1:
-            # multi-term least-squares periodogram ('chi2' arithmetic with exact sums; 'fastchi2' is the reference's
-            # extirpolated approximation of the same quantity): reference periodogram.py:948-967
+        if plan["nterms"] > 1 and plan["ls_method"] == "fastchi2":
+            # the reference's FFT-based multi-term method, same arithmetic (extirpolated trig sums): periodogram.py:948-967
+            fd = plan["f_day"]
+            f0, dfq = (float(fd[0]), float(fd[1] - fd[0])) if len(fd) > 1 else (float(fd[0]), float(fd[0]))
+            power = _capi.ls_fast_batch(plan["trel"], plan["flux"], [0, n], f0=f0, df=dfq, M=len(fd),
+                                        nterms=plan["nterms"], **common)[0]
+        elif plan["nterms"] > 1:
+            # multi-term least-squares periodogram with exact sums ('chi2'): reference periodogram.py:948-967
             if grid is not None:
                 power = _capi.ls_power_batch(plan["trel"], plan["flux"], [0, n], f0=grid[0], df=grid[1],
                                              M=len(plan["f_day"]), nterms=plan["nterms"], **common)[0]

@@ -31,8 +31,11 @@ def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit
 
 
 def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True, fit_mean=True,
-                         normalization="standard", use_fft=True, trig_sum_kwds=None, **unused):
-    """Signature of astropy's lombscargle_fast (fast_impl.py:6): the f0/df/Nf form 'fast*' methods receive."""
+                         normalization="standard", use_fft=True, trig_sum_kwds=None, nterms=1, **unused):
+    """Signature of astropy's lombscargle_fast / lombscargle_fastchi2 (fast_impl.py:6, fastchi2_impl.py:8): the
+    f0/df/Nf form every 'fast*' method receives; ``nterms`` > 1 arrives only under the name 'fastchi2'."""
+    if not 1 <= nterms <= _capi.MAX_NTERMS:
+        raise ValueError("the HIP kernels are instantiated for 1 <= nterms <= %d" % _capi.MAX_NTERMS)
     if normalization not in ("standard", "psd"):
         raise ValueError("normalization='{}' not recognized".format(normalization))
     if f0 < 0:
@@ -45,7 +48,7 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
     t = np.asarray(t, dtype=np.float64)
     return _capi.ls_fast_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
                                center_data=center_data, normalization=normalization,
-                               oversampling=int(kw.get("oversampling", 5)))[0]
+                               oversampling=int(kw.get("oversampling", 5)), nterms=nterms)[0]
 
 
 def bls_fast_hip(t, y, ivar, period, duration, oversample, use_likelihood):
@@ -66,7 +69,9 @@ def install():
     # the reference's DEFAULT method: lc.to_periodogram() reaches the GPU with no change on the caller's side
     ls_main.METHODS.setdefault("fast_cpu", ls_main.METHODS["fast"])
     ls_main.METHODS["fast"] = lombscargle_fast_hip
+    ls_main.METHODS.setdefault("fastchi2_cpu", ls_main.METHODS["fastchi2"])
+    ls_main.METHODS["fastchi2"] = lombscargle_fast_hip
     bls_methods._bls_fast_reference = getattr(bls_methods, "_bls_fast_reference", bls_methods.bls_fast)
     bls_methods.bls_fast = bls_fast_hip
     return ["lombscargle:METHODS['hip']", "lombscargle:METHODS['chi2']", "lombscargle:METHODS['fast']",
-            "bls:methods.bls_fast"]
+            "lombscargle:METHODS['fastchi2']", "bls:methods.bls_fast"]

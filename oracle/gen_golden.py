@@ -102,8 +102,11 @@ def gen_ls_multiterm():
     for nt in (2, 3, 4):
         pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method="chi2", nterms=nt)
         out["amp_chi2_%d" % nt] = np.asarray(pg.power.value)
-    pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method="fastchi2", nterms=2)
-    out["amp_fastchi2_2"] = np.asarray(pg.power.value)
+    for nt in (2, 3):
+        pg = lc.to_periodogram(frequency=f, normalization="amplitude", ls_method="fastchi2", nterms=nt)
+        out["amp_fastchi2_%d" % nt] = np.asarray(pg.power.value)
+    pg = lc.to_periodogram(frequency=f * 1e6 / 86400.0, normalization="psd", ls_method="fastchi2", nterms=2)
+    out["psd_fastchi2_2"] = np.asarray(pg.power.value)
     pg = lc.to_periodogram(frequency=f * 1e6 / 86400.0, normalization="psd", ls_method="chi2", nterms=2)
     out["frequency_uhz"] = f * 1e6 / 86400.0
     out["psd_chi2_2"] = np.asarray(pg.power.value)
@@ -122,6 +125,7 @@ def gen_ls_multiterm():
         ls = LombScargle(t - t[0], y, dy, nterms=2, fit_mean=fm, center_data=True)
         out["astropy_standard_fm%d" % fm] = ls.power(f, method="chi2", normalization="standard")
         out["astropy_psd_fm%d" % fm] = ls.power(f, method="chi2", normalization="psd")
+        out["astropy_fastchi2_standard_fm%d" % fm] = ls.power(f, method="fastchi2", normalization="standard")
     save("ls_multiterm", **out)
 
 

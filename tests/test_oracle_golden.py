@@ -99,8 +99,17 @@ def test_ls_multiterm_chi2(golden):
         for norm in ("standard", "psd"):
             p = O.ls_power_chi2(t, g["flux"], g["dy"], g["frequency"], nterms=2, fit_mean=bool(fm), normalization=norm)
             check(p, g["astropy_%s_fm%d" % (norm, fm)], ok)
-    # 'fastchi2' is an approximation of 'chi2' (extirpolation): close, not equal
+    # 'fastchi2' is an approximation of 'chi2' (extirpolation): close, not equal — and it has its own restatement
     assert relmax(g["amp_fastchi2_2"][ok], g["amp_chi2_2"][ok]) < 2e-2
+    f = g["frequency"]
+    df = f[1] - f[0]
+    for nt in (2, 3):
+        a = O.ls_power_fastchi2(t, g["flux"], None, f[0], df, len(f), nterms=nt, normalization="lk_amplitude")
+        check(a, g["amp_fastchi2_%d" % nt], ok)
+    for fm in (1, 0):
+        a = O.ls_power_fastchi2(t, g["flux"], g["dy"], f[0], df, len(f), nterms=2, fit_mean=bool(fm),
+                                normalization="standard")
+        check(a, g["astropy_fastchi2_standard_fm%d" % fm], ok)
 
 
 def test_ls_constant_flux_zero_power(golden):

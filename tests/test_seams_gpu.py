@@ -30,7 +30,7 @@ def test_astropy_seams_under_conda():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_RESULT ")][-1]
     res = json.loads(line[len("SEAMS_RESULT "):])
-    assert len(res["installed"]) == 4
+    assert len(res["installed"]) == 5
     for k, v in res["ls_relerr"].items():
         assert v < 1e-9, (k, v)
     assert res["bls_bit_exact"]["likelihood"] and res["bls_bit_exact"]["snr"]
