@@ -129,3 +129,43 @@ def test_stress_regimes_bit_exact(use_like):
         ref = O.bls(t, ys[b] - np.median(ys[b]), ws[b], period, duration, 10, use_like)
         for field, r in zip(_capi.BLS_FIELDS, ref):
             assert np.array_equal(res[field][b], r, equal_nan=True), (name, field)
+
+
+def test_randomised_configurations_bit_exact():
+    """Seeded fuzz over the whole parameter space of run_bls (cadence count, baseline, period and duration grids,
+    oversample, objective, weights, transit shapes): every output of every configuration == the C oracle."""
+    rng = np.random.default_rng(20260925)
+    n_cfg = 48
+    for c in range(n_cfg):
+        n = int(rng.integers(20, 2500))
+        span = float(rng.uniform(3.0, 90.0))
+        t = np.sort(rng.uniform(0, span, n))
+        if c % 5 == 0:
+            t = np.round(t / 0.02) * 0.02                   # many exactly equal phases / bin edges
+            t = np.sort(t)
+        sig = 10.0 ** rng.uniform(-5, -2)
+        y = rng.normal(0, sig, n)
+        P0 = rng.uniform(0.4, span / 2.5)
+        y[((t - rng.uniform(0, P0)) % P0) < rng.uniform(0.02, 0.3)] -= rng.uniform(0.2, 30.0) * sig
+        if c % 7 == 3:
+            y = np.round(y / sig) * sig                     # quantised: ties between candidates
+        ivar = np.full(n, sig ** -2) if c % 3 else 1.0 / (sig * rng.uniform(0.3, 3.0, n)) ** 2
+        if c % 11 == 5:
+            ivar[rng.random(n) < 0.3] = 0.0
+        nd = int(rng.integers(1, 25))
+        dmin = rng.uniform(0.01, 0.08)
+        duration = np.sort(rng.uniform(dmin, dmin * rng.uniform(1.5, 12.0), nd))
+        if c % 4 == 1:
+            duration = rng.permutation(duration)            # caller's order is the tie-break order
+        pmin = duration.max() * rng.uniform(1.05, 3.0)
+        period = rng.uniform(pmin, max(pmin * 1.5, span / 1.5), int(rng.integers(1, 40)))
+        oversample = int(rng.integers(1, 13))
+        use_like = bool(c % 2)
+        yy = y - np.median(y)
+        nbins = np.ceil(period.max() / (duration.min() / oversample)) + oversample
+        if nbins > 8000:
+            continue
+        res = _capi.bls_batch(t, yy, ivar, [0, n], period, duration, oversample, use_like)
+        ref = O.bls(t, yy, ivar, period, duration, oversample, use_like)
+        for field, r in zip(_capi.BLS_FIELDS, ref):
+            assert np.array_equal(res[field][0], r, equal_nan=True), (c, field, n, oversample, use_like)
