@@ -127,6 +127,22 @@ class Periodogram(object):
         import copy
         return copy.deepcopy(self)
 
+    def bin(self, binsize=10, method="mean"):
+        """Bin the spectrum by an integer factor (reference periodogram.py:140-181): mean or nanmedian of consecutive
+        groups of ``binsize`` points; the trailing remainder is dropped.  Pure reshaping — no kernel involved."""
+        if binsize < 1:
+            raise ValueError("binsize must be larger than or equal to 1")
+        method = validate_method(method, ["mean", "median"])
+        m = int(len(self.power) / binsize)
+        f = self.frequency[: m * binsize].reshape((m, binsize))
+        pw = self.power[: m * binsize].reshape((m, binsize))
+        out = self.copy()
+        if method == "mean":
+            out.frequency, out.power = f.mean(1), pw.mean(1)
+        else:
+            out.frequency, out.power = np.nanmedian(f, axis=1), np.nanmedian(pw, axis=1)
+        return out
+
     def smooth(self, method="boxkernel", filter_width=0.1, device=0):
         """Smoothed copy of the power spectrum (reference periodogram.py:182-284): ``'boxkernel'`` convolves with a
         box of ``filter_width`` (frequency units; needs an evenly spaced grid), ``'logmedian'`` is a moving median
@@ -304,7 +320,7 @@ def _ls_plan(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=
     else:
         norm, scale = "lk_amplitude", 1.0
         power_unit = "flux"
-    return dict(lc=lc, trel=time - time[0], flux=flux, dy=dy, frequency=frequency, f_day=f_day, norm=norm, scale=scale,
+    return dict(lc=lc, trel=time - time[0], t0=time[0], flux=flux, dy=dy, frequency=frequency, f_day=f_day, norm=norm, scale=scale,
                 nyquist=nyquist, freq_unit=freq_unit, power_unit=power_unit, default_view=default_view,
                 ls_method=ls_method, nterms=nterms, fit_mean=fit_mean, center_data=center_data,
                 normalization=normalization)
@@ -312,6 +328,9 @@ def _ls_plan(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=
 
 class LombScarglePeriodogram(Periodogram):
     """Lomb-Scargle periodogram computed by the exact HIP kernels (reference periodogram.py:589-1018)."""
+
+    def model(self, time, frequency=None, device=0):
+        return _ls_model(self, time, frequency, device)
 
     def __init__(self, *args, **kwargs):
         self._LS_inputs = kwargs.pop("ls_obj", None)
@@ -365,9 +384,42 @@ class LombScarglePeriodogram(Periodogram):
         return LombScarglePeriodogram(
             frequency=plan["frequency"], power=power, nyquist=plan["nyquist"], targetid=lcc.meta.get("TARGETID"),
             label=lcc.meta.get("LABEL"), default_view=plan["default_view"],
-            ls_obj=dict(trel=plan["trel"], flux=plan["flux"], dy=plan["dy"]), nterms=plan["nterms"],
+            ls_obj=dict(trel=plan["trel"], flux=plan["flux"], dy=plan["dy"], t0=float(plan["t0"]),
+                        fit_mean=plan["fit_mean"], center_data=plan["center_data"]), nterms=plan["nterms"],
             ls_method=plan["ls_method"], meta=lcc.meta, frequency_unit=plan["freq_unit"],
             power_unit=plan["power_unit"])
+
+
+def _ls_model(self, time, frequency=None, device=0):
+    """Best-fit truncated Fourier series at one frequency, evaluated at ``time`` (reference periodogram.py:991-1018 ->
+    astropy LombScargle.model -> mle.periodic_fit, implementations/mle.py:58-114): weighted least squares of
+    [1,] sin(2 pi m f t), cos(2 pi m f t), m <= nterms, on the light curve the periodogram came from (one
+    Gram + solve on the GPU regression path), plus the weighted mean that was removed; normalised like the reference."""
+    from .lightcurve import LightCurve
+    if self._LS_inputs is None:
+        raise ValueError("No Lomb Scargle inputs are attached to this periodogram.")
+    if frequency is None:
+        frequency = self.frequency_at_max_power
+    f_day = float(frequency) / _freq_unit_factor(self.frequency_unit)
+    trel, y, dy = self._LS_inputs["trel"], self._LS_inputs["flux"], self._LS_inputs["dy"]
+    t0 = self._LS_inputs.get("t0", 0.0)
+    fit_mean, center = self._LS_inputs.get("fit_mean", True), self._LS_inputs.get("center_data", True)
+
+    def design(t):
+        cols = [np.ones_like(t)] if fit_mean else []
+        for m in range(1, self.nterms + 1):
+            cols += [np.sin(2 * np.pi * m * f_day * t), np.cos(2 * np.pi * m * f_day * t)]
+        return np.column_stack(cols)
+
+    w = np.ones_like(y) if dy is None else dy ** -2.0
+    y_mean = np.dot(y, w) / w.sum() if center else 0.0
+    res = _capi.regress_batch(design(trel), y - y_mean, [0, len(y)], err=dy, sigma=1e300, niters=1, device=device)
+    theta = res["coefficients"][0]
+    tfit = np.asarray(time, dtype=np.float64) - t0
+    lc = LightCurve(time=np.asarray(time, dtype=np.float64), flux=y_mean + design(tfit).dot(theta),
+                    meta={"FREQUENCY": frequency, "LABEL": "LS Model",
+                          "TARGETID": "{} LS Model".format(self.targetid)})
+    return lc.normalize()
 
 
 def _bls_plan(lc, **kwargs):

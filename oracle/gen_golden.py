@@ -228,6 +228,28 @@ def gen_cbv():
     save("cbv_ridge", **out)
 
 
+def gen_pg_misc():
+    """Periodogram.bin (periodogram.py:140-181) and LombScarglePeriodogram.model (:991-1018)."""
+    t, y, e, truth = synth.ls_target(1, 6, 1200)
+    lc = lk.LightCurve(time=t + 2000.0, flux=y, flux_err=e)
+    pg = lc.to_periodogram(ls_method="slow", oversample_factor=3)
+    out = dict(time=lc.time.value, flux=y, flux_err=e, frequency=pg.frequency.value, power=pg.power.value)
+    for meth in ("mean", "median"):
+        b = pg.bin(binsize=7, method=meth)
+        out["bin_freq_" + meth] = b.frequency.value
+        out["bin_power_" + meth] = b.power.value
+    tfit = np.linspace(lc.time.value[0] - 0.5, lc.time.value[-1] + 0.5, 777)
+    out["tfit"] = tfit
+    out["model_default"] = pg.model(lc.time).flux.value                      # at the frequency of max power
+    out["model_tfit_f"] = pg.model(tfit * u.day if False else lc.time.__class__(tfit, format=lc.time.format, scale=lc.time.scale),
+                                   frequency=pg.frequency_at_max_power * 0.5).flux.value
+    out["model_frequency"] = float(pg.frequency_at_max_power.value * 0.5)
+    pg2 = lc.to_periodogram(ls_method="chi2", nterms=2, oversample_factor=3)
+    out["model_nterms2"] = pg2.model(lc.time).flux.value
+    out["model_nterms2_frequency"] = float(pg2.frequency_at_max_power.value)
+    save("pg_misc", **out)
+
+
 def gen_bls():
     t, y, e, truth = synth.bls_target(3, 0, 2500, cadence_days=10.0 / 1440.0)
     lc = lk.LightCurve(time=t + 1325.5, flux=y, flux_err=e)
@@ -387,6 +409,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "metrics", "fold", "cbv", "bls", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "metrics", "fold", "cbv", "bls", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

@@ -144,3 +144,25 @@ def test_empty_and_degenerate_batches():
         _capi.ls_power_batch(np.arange(4.0), np.ones(4), [0, 2, 2, 4], f0=1.0, df=1.0, M=5)     # empty light curve
     with pytest.raises(ValueError):
         _capi.pg_logmedian_batch(np.ones((1, 4)), [0], [9], [0, 0, 0, 0], [0, 0, 0, 0])         # window outside the grid
+
+
+def test_periodogram_bin_and_ls_model(golden):
+    """Result-type helpers (row A15): Periodogram.bin and LombScarglePeriodogram.model against lightkurve's own outputs;
+    the model's least-squares fit runs on the GPU regression path.  Tolerance 1e-9 relative."""
+    from lightkurve_amd.lightcurve import LightCurve
+    from lightkurve_amd.periodogram import Periodogram
+    g = golden("pg_misc")
+    pg = Periodogram(g["frequency"], g["power"])
+    for meth in ("mean", "median"):
+        b = pg.bin(binsize=7, method=meth)
+        assert np.allclose(b.frequency, g["bin_freq_" + meth], rtol=1e-13, atol=0)
+        assert np.allclose(b.power, g["bin_power_" + meth], rtol=1e-13, atol=0)
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    pgl = lc.to_periodogram(ls_method="slow", oversample_factor=3)
+    m = pgl.model(lc.time)
+    assert np.max(np.abs(m.flux - g["model_default"])) < 1e-9
+    m = pgl.model(g["tfit"], frequency=float(g["model_frequency"]))
+    assert np.max(np.abs(m.flux - g["model_tfit_f"])) < 1e-9
+    pg2 = lc.to_periodogram(ls_method="chi2", nterms=2, oversample_factor=3)
+    assert abs(pg2.frequency_at_max_power - float(g["model_nterms2_frequency"])) < 1e-12
+    assert np.max(np.abs(pg2.model(lc.time).flux - g["model_nterms2"])) < 1e-9
