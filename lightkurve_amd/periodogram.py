@@ -540,3 +540,36 @@ class BoxLeastSquaresPeriodogram(Periodogram):
     @property
     def depth_at_max_power(self):
         return self.depth[np.nanargmax(self.power)]
+
+    def get_transit_model(self, period=None, duration=None, transit_time=None):
+        """Box model of the transits (reference periodogram.py:1229-1269 -> astropy BoxLeastSquares.model,
+        bls/core.py:332-387): the ivar-weighted mean flux inside / outside the transit windows.  Element-wise host
+        arithmetic on the light curve the periodogram came from — no search involved."""
+        from .lightcurve import LightCurve
+        if period is None:
+            period = self.period_at_max_power
+            log.warning("No period specified. Using period at max power")
+        if duration is None:
+            duration = self.duration_at_max_power
+            log.warning("No duration specified. Using duration at max power")
+        if transit_time is None:
+            transit_time = self.transit_time_at_max_power
+            log.warning("No transit time specified. Using transit time at max power")
+        t0 = float(self.time[0])                         # astropy works on times relative to the first cadence
+        t = np.asarray(self.time, dtype=np.float64) - t0
+        tt = float(transit_time) - t0
+        y, ivar = np.asarray(self.flux, dtype=np.float64), self._BLS_inputs["ivar"]
+        hp = 0.5 * period
+        m_in = np.abs((t - tt + hp) % period - hp) < 0.5 * duration
+        m_out = ~m_in
+        with np.errstate(invalid="ignore", divide="ignore"):
+            y_in = np.sum(y[m_in] * ivar[m_in]) / np.sum(ivar[m_in])
+            y_out = np.sum(y[m_out] * ivar[m_out]) / np.sum(ivar[m_out])
+        model = y_out + np.zeros_like(t)
+        model[m_in] = y_in
+        return LightCurve(time=self.time, flux=model, label="Transit Model Flux")
+
+    def get_transit_mask(self, period=None, duration=None, transit_time=None):
+        """True where the box model is in transit (reference periodogram.py:1271-1292)."""
+        model = self.get_transit_model(period=period, duration=duration, transit_time=transit_time)
+        return model.flux != np.median(model.flux)

@@ -286,6 +286,25 @@ def gen_bls():
          duration=pg.duration.value, transit_time=pg.transit_time.value)
 
 
+def gen_bls_model():
+    """BoxLeastSquaresPeriodogram.get_transit_model / get_transit_mask (periodogram.py:1229-1292)."""
+    t, y, e, truth = synth.bls_target(3, 21, 2500, cadence_days=10.0 / 1440.0)
+    y = y.copy()
+    y[[10, 400]] = np.nan
+    lc = lk.LightCurve(time=t + 2000.0, flux=y, flux_err=e)
+    period = np.linspace(0.8, 9.0, 400)
+    pg = lc.to_periodogram(method="bls", period=period, duration=[0.05, 0.1, 0.2, 0.3])
+    out = dict(time=lc.time.value, flux=y, flux_err=e, period=period)
+    out["model_default"] = pg.get_transit_model().flux.value
+    out["mask_default"] = np.asarray(pg.get_transit_mask())
+    out["model_custom"] = pg.get_transit_model(period=truth["period"], duration=0.17,
+                                               transit_time=lc.time.value[0] + 1.234).flux.value
+    out["custom_period"] = truth["period"]
+    out["custom_transit_time"] = lc.time.value[0] + 1.234
+    out["period_at_max_power"] = float(pg.period_at_max_power.value)
+    save("bls_model", **out)
+
+
 def gen_flatten():
     rng = np.random.default_rng(11)
     t, y, e, truth = synth.ls_target(4, 0, 3000)
@@ -409,6 +428,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "metrics", "fold", "cbv", "bls", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "metrics", "fold", "cbv", "bls", "bls_model", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

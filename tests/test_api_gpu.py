@@ -166,3 +166,16 @@ def test_periodogram_bin_and_ls_model(golden):
     pg2 = lc.to_periodogram(ls_method="chi2", nterms=2, oversample_factor=3)
     assert abs(pg2.frequency_at_max_power - float(g["model_nterms2_frequency"])) < 1e-12
     assert np.max(np.abs(pg2.model(lc.time).flux - g["model_nterms2"])) < 1e-9
+
+
+def test_bls_transit_model_and_mask(golden):
+    """get_transit_model / get_transit_mask on the GPU periodogram == lightkurve's (which asks astropy's BLS object)."""
+    from lightkurve_amd.lightcurve import LightCurve
+    g = golden("bls_model")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    pg = lc.to_periodogram(method="bls", period=g["period"], duration=[0.05, 0.1, 0.2, 0.3])
+    assert pg.period_at_max_power == float(g["period_at_max_power"])
+    assert np.max(np.abs(pg.get_transit_model().flux - g["model_default"])) < 1e-12
+    assert np.array_equal(pg.get_transit_mask(), g["mask_default"])
+    m = pg.get_transit_model(period=float(g["custom_period"]), duration=0.17, transit_time=float(g["custom_transit_time"]))
+    assert np.max(np.abs(m.flux - g["model_custom"])) < 1e-12
