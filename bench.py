@@ -1,18 +1,22 @@
 #!/usr/bin/env python
-"""bench.py — headline benchmark: batched exact Lomb-Scargle on MI355X (BASELINE.json configs[1]).
+"""bench.py — headline benchmark: batched Lomb-Scargle on MI355X (BASELINE.json configs[1]).
 
     python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" = one pass of the hot path over one batch: B targets x M trial frequencies through
-liblkhip.so's lk_ls_power_batch_dev + lk_argmax_batch_dev, inputs already resident in HBM.
-Prints ONE JSON line on rank 0 (metric frequencies*targets/sec, whole job over all ranks), carrying
-`roofline` (dominant kernel ls_grid_kernel: algorithmic 16 flop per (cadence, frequency) pair over the
-HIP-event kernel time, against the fp64 vector peak) and `cpu_baseline` (the reference's default 'fast'
-algorithm, numpy port, timed on this box's host cores on a bounded sample).
+A "step" = one pass of the hot path over one batch: B targets x M trial frequencies through liblkhip.so's
+lk_ls_fast_batch_dev (headline: the reference's DEFAULT method ls_method="fast", extirpolation + FFT) and, with the
+default --ls-method both, lk_ls_power_batch_dev (the exact direct sums, reported as `other_method`), each followed
+by lk_argmax_batch_dev; inputs already resident in HBM.  Prints ONE JSON line on rank 0 (metric
+frequencies*targets/sec, whole job over all ranks) carrying `roofline` (fast: algorithmic HBM bytes over the HIP-event
+time against 8 TB/s, with the PMC traffic from profiles/traffic.json; exact: 16 flop per (cadence, frequency) pair
+against the fp64 vector peak) and `cpu_baseline` (the reference's default algorithm run through astropy itself on this
+box's usable cores, on a bounded sample; numpy port if astropy is absent).
 
-Weak scaling: every rank owns B targets (targets are independent; no data-path collective is needed to
-compute).  With N>1 the per-shard power spectra are all-gathered over RCCL (north_star), chunked so the
-collective of chunk k overlaps the kernels of chunk k+1.
+Weak scaling: every rank owns B targets (targets are independent; no data-path collective is needed to compute).
+With N>1 the per-target (max power, argmax) are all-gathered over RCCL each step (--gather summary, default), or the
+full spectra chunk by chunk so the collective of chunk k overlaps the kernels of chunk k+1 (--gather spectra).
+
+Other workloads, same protocol and JSON shape: --workload bls | pld | regress | flatten | fold | lschi2 | pgsmooth.
 """
 import argparse
 import json
