@@ -63,33 +63,41 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
     const bool live_j0 = j0 + wj * 32 < Ka, live_j1 = j0 + wj * 32 + 16 < Ka;
 
     __shared__ double sw[GR_RC];  // the stage's 32 cadence weights (0 = masked), computed once per cadence
-    for (int n0 = 0; n0 < n; n0 += GR_RC) {
+    // Software pipeline: the global loads of stage s + 1 (8 + 8 values per thread, and the stage's weights on the first
+    // 32 threads) are issued before the MFMAs of stage s and land in registers while the matrix cores work.
+    double ra[8], rb[8], wv = 0.0;
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            const int nn = n0 + r;
+            ra[q] = nn < n ? aug(X, y, K, nn, i0 + c) : 0.0;
+            rb[q] = nn < n ? aug(X, y, K, nn, j0 + c) : 0.0;
+        }
         if (tid < GR_RC) {
             const int nn = n0 + tid;
-            double w = 0.0;
+            wv = 0.0;
             if (nn < n) {
                 const int64_t g = lo + nn;
                 if ((!cmask || cmask[g]) && !(outl && outl[g])) {
                     const double s = err ? err[g] : 1.0;
-                    w = 1.0 / (s * s);
+                    wv = 1.0 / (s * s);
                 }
             }
-            sw[tid] = w;
+        }
+    };
+    fetch(0);
+    for (int n0 = 0; n0 < n; n0 += GR_RC) {
+        if (tid < GR_RC) sw[tid] = wv;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+            sa[r][c] = ra[q] * sw[r];   // X / err^2 exactly as the reference forms it (:166)
+            sb[r][c] = rb[q];
         }
         __syncthreads();
-        // stage: 32 cadences x 64 columns for each operand; thread -> (row = tid/8 .. , 8 columns)
-        for (int e = tid; e < GR_RC * GR_BLK; e += 256) {
-            const int r = e >> 6, c = e & 63;
-            const int nn = n0 + r;
-            double va = 0.0, vb = 0.0;
-            if (nn < n) {
-                va = aug(X, y, K, nn, i0 + c) * sw[r];   // X / err^2 exactly as the reference forms it (:166)
-                vb = aug(X, y, K, nn, j0 + c);
-            }
-            sa[r][c] = va;
-            sb[r][c] = vb;
-        }
-        __syncthreads();
+        if (n0 + GR_RC < n) fetch(n0 + GR_RC);
 #pragma unroll
         for (int kk = 0; kk < GR_RC; kk += 4) {
             const int kr = kk + (lane >> 4), cc = lane & 15;
