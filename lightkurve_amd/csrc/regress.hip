@@ -12,6 +12,8 @@
 //                      std, <=5 passes) and outlier |= clipped.   (reference quirk, SURVEY App. B.5: the clip
 //                      statistics include cadences outside cadence_mask and earlier outliers.)
 // Final: model = X w - median(X w).
+#include <cstdlib>
+
 #include "block_select.hpp"
 #include "lk_common.hpp"
 
@@ -220,6 +222,113 @@ __global__ __launch_bounds__(256) void solve_kernel(const double *__restrict__ G
     for (int i = tid; i < K; i += 256) w[(size_t)target * K + i] = s_col[i];
 }
 
+// The same solve for K <= ~138 with the whole augmented system in LDS: no global round trips between the phases of a
+// column, the pivot found by a wave reduction + one 4-entry LDS exchange (2 barriers instead of 9), and a column-oriented
+// back substitution (1 barrier per unknown instead of 9).  Same pivot rule; the update order per element is unchanged.
+__global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict__ G, int K, int Kp,
+                                                         const double *__restrict__ prior_mu,
+                                                         const double *__restrict__ prior_sigma,
+                                                         double *__restrict__ w) {
+    extern __shared__ __attribute__((aligned(16))) double s_A[];  // K x (K + 1) augmented system | K multipliers | pivots
+    const int target = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *Gt = G + (size_t)target * Kp * Kp;
+    const int Ka = K + 1;
+    double *A = s_A, *x = s_A + (size_t)K * Ka;
+    double *s_pv = x + K;
+    int *s_pi = reinterpret_cast<int *>(s_pv + 4);
+    for (int i = wave; i < K; i += 4)  // one wave per row: coalesced for the upper part, strided for the mirrored part
+        for (int j = lane; j < Ka; j += 64) {
+            double v;
+            if (j < K) {
+                v = (j >= i || (j / GR_BLK) == (i / GR_BLK)) ? Gt[(size_t)i * Kp + j] : Gt[(size_t)j * Kp + i];
+                if (i == j && prior_sigma) {
+                    const double sg = prior_sigma[(size_t)target * K + i];
+                    v += 1.0 / (sg * sg);
+                }
+            } else {
+                v = Gt[(size_t)i * Kp + K];
+                if (prior_sigma) {
+                    const double sg = prior_sigma[(size_t)target * K + i];
+                    v += prior_mu[(size_t)target * K + i] / (sg * sg);
+                }
+            }
+            A[i * Ka + j] = v;
+        }
+    __syncthreads();
+    for (int j = 0; j < K; ++j) {
+        // pivot: largest |A[i][j]|, i >= j, first one wins (LAPACK idamax)
+        double best = -1.0;
+        int bi = j;
+        for (int i = j + tid; i < K; i += 256) {
+            const double v = fabs(A[i * Ka + j]);
+            if (v > best) {
+                best = v;
+                bi = i;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v2 = __shfl_xor(best, o);
+            const int i2 = __shfl_xor(bi, o);
+            if (v2 > best || (v2 == best && i2 < bi)) {
+                best = v2;
+                bi = i2;
+            }
+        }
+        if (lane == 0) {
+            s_pv[wave] = best;
+            s_pi[wave] = bi;
+        }
+        __syncthreads();
+        int p = s_pi[0];
+        double pb = s_pv[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (s_pv[q] > pb || (s_pv[q] == pb && s_pi[q] < p)) {
+                pb = s_pv[q];
+                p = s_pi[q];
+            }
+        // multipliers straight from the un-swapped rows (row p plays the role of row j and vice versa), then the swap
+        const double piv = A[p * Ka + j];
+        for (int i = j + 1 + tid; i < K; i += 256) x[i] = A[(i == p ? j : i) * Ka + j] / piv;
+        __syncthreads();
+        if (p != j) {
+            for (int c = tid; c < Ka; c += 256) {
+                const double t0 = A[j * Ka + c];
+                A[j * Ka + c] = A[p * Ka + c];
+                A[p * Ka + c] = t0;
+            }
+            __syncthreads();
+        }
+        // trailing update: wave w takes rows j+1+w, j+5+w, ...; lanes over the columns
+        double pr[3];  // Ka - j - 1 <= 143 < 192 columns for every K the LDS plan admits
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = j + 1 + lane + 64 * u;
+            pr[u] = c < Ka ? A[j * Ka + c] : 0.0;
+        }
+        for (int i = j + 1 + wave; i < K; i += 4) {
+            const double m = x[i];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int c = j + 1 + lane + 64 * u;
+                if (c < Ka) A[i * Ka + c] = fma(-m, pr[u], A[i * Ka + c]);
+            }
+        }
+        __syncthreads();
+    }
+    // back substitution, column oriented: x_i = b_i / U_ii, then b_r -= U_ri x_i for r < i (the right-hand side lives in
+    // column K); one barrier per unknown.  (Sum order differs from the dot-product form of the global kernel: results
+    // agree to rounding.)
+    for (int i = K - 1; i >= 0; --i) {
+        const double xi = A[i * Ka + K] / A[i * Ka + i];
+        __syncthreads();
+        if (tid == 0) x[i] = xi;
+        for (int r = tid; r < i; r += 256) A[r * Ka + K] = fma(-A[r * Ka + i], xi, A[r * Ka + K]);
+        __syncthreads();
+    }
+    for (int i = tid; i < K; i += 256) w[(size_t)target * K + i] = x[i];
+}
+
 // model[n] = sum_k X[n][k] w[k]; one wavefront per cadence row, lanes over k (coalesced), wave reduction.
 __global__ __launch_bounds__(256) void model_kernel(const double *__restrict__ X, const double *__restrict__ w,
                                                      const int64_t *__restrict__ n_off, int K,
@@ -355,7 +464,19 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     for (int it = 0; it < niters; ++it) {
         hipLaunchKernelGGL(gram_mfma_kernel, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K, KB,
                            d_G);
-        hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(256), 0, stream, d_G, K, Kp, prior_mu, prior_sigma, d_A, w);
+        const size_t solve_lds = ((size_t)K * (K + 1) + K + 4 + 2) * 8;
+        static const bool lds_solve_ok = !(getenv("LK_SOLVE_LDS") && atoi(getenv("LK_SOLVE_LDS")) == 0);
+        if (lds_solve_ok && solve_lds <= 160 * 1024) {
+            static bool solve_attr = false;
+            if (!solve_attr) {
+                LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_lds_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                solve_attr = true;
+            }
+            hipLaunchKernelGGL(solve_lds_kernel, dim3(B), dim3(256), solve_lds, stream, d_G, K, Kp, prior_mu, prior_sigma, w);
+        } else {
+            hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(256), 0, stream, d_G, K, Kp, prior_mu, prior_sigma, d_A, w);
+        }
         hipLaunchKernelGGL(model_kernel, dim3(64, B), dim3(256), (size_t)K * 8, stream, X, w, d_off, K, model);
         hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, model, d_off, clip_sigma, 5, d_flag, outl);
     }
