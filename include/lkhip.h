@@ -14,6 +14,12 @@
  *                           src/lightkurve/lightcurve.py:996-1063.
  *   lk_regress_batch*    <- RegressionCorrector._fit_coefficients + the sigma-clip loop of .correct,
  *                           src/lightkurve/correctors/regressioncorrector.py:127-189, 243-279.
+ *   lk_ls_fast_batch*    <- astropy lombscargle_fast (the DEFAULT ls_method="fast", periodogram.py:650): fast_impl.py.
+ *   lk_ls_chi2_batch* / lk_ls_fastchi2_batch* <- astropy lombscargle_chi2 / lombscargle_fastchi2 (nterms > 1,
+ *                           periodogram.py:948-967).
+ *   lk_pld_design_batch* <- PLDCorrector.create_design_matrix, src/lightkurve/correctors/pldcorrector.py:125-287.
+ *   lk_fold_batch*       <- LightCurve.fold, src/lightkurve/lightcurve.py:1089-1214 (astropy TimeSeries.fold + sort).
+ *   lk_pg_logmedian_batch* / lk_pg_boxsmooth_batch* <- Periodogram.smooth, periodogram.py:182-284.
  *
  * Conventions
  *   - Every function returns an int status: LK_OK, LK_EINVAL (-> ValueError), LK_ENOMEM (-> MemoryError),
