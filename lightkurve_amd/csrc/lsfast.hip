@@ -929,15 +929,16 @@ static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_us
                           hipStream_t stream) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N2 = 1 << m2;
-    const int CT = std::max(1, std::min(N2, std::min(4096 / n, 256 / std::max(A, Bq))));
+    static const int ct_pts = getenv("LK_FFT_CT_PTS") ? atoi(getenv("LK_FFT_CT_PTS")) : 4096;  // points per column tile
+    const int CT = std::max(1, std::min(N2, std::min(ct_pts / n, 256 / std::max(A, Bq))));
     const int nt = ((CT * std::max(A, Bq) + 63) / 64) * 64;
     static const bool split = getenv("LK_FFT_SPLIT") ? atoi(getenv("LK_FFT_SPLIT")) != 0 : false;  // measured 4 % slower (spills at 2 waves/SIMD)
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     if (split) {
@@ -953,7 +954,8 @@ static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_us
 // width of the tiled intermediate layout: the column kernel's CT, capped by the row kernel's Bq (both powers of 2)
 static int tile_width(int m1, int m2) {
     const int la1 = (m1 + 1) / 2, lb1 = m1 / 2, n1 = 1 << m1;
-    const int ct = std::max(1, std::min(1 << m2, std::min(4096 / n1, 256 / std::max(1 << la1, 1 << lb1))));
+    static const int ct_pts = getenv("LK_FFT_CT_PTS") ? atoi(getenv("LK_FFT_CT_PTS")) : 4096;
+    const int ct = std::max(1, std::min(1 << m2, std::min(ct_pts / n1, 256 / std::max(1 << la1, 1 << lb1))));
     const int bq2 = 1 << (m2 / 2);
     return std::min(ct, bq2);
 }
