@@ -50,24 +50,32 @@ int pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_kno
 // ------------------------------------------------------------------------------------------------ elementwise
 // out[b][n][p] = (double)( pix[b][n][p] / div[b][n] ) with the division in float32 like numpy's float32 / float32;
 // div = SAP flux (PLD pixels) or the float32 row sum of the background pixels (normalize) or 1.
-__global__ void pld_ratio_kernel(const float *__restrict__ pix, const float *__restrict__ lc, int mode, int N, int P,
-                                 double *__restrict__ out) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * blockDim.y + threadIdx.y;
-    if (n >= N) return;
-    const float *row = pix + ((size_t)b * N + n) * P;
-    float d = 1.0f;
-    if (mode == 1) d = lc[(size_t)b * N + n];
-    if (mode == 2) {
-        double s = 0.0;
-        for (int p = 0; p < P; ++p) {
-            const float v = row[p];
-            if (v == v) s += (double)v;
+__global__ __launch_bounds__(256) void pld_ratio_kernel(const float *__restrict__ pix, const float *__restrict__ lc,
+                                                         int mode, int N, int P, double *__restrict__ out) {
+    constexpr int ROWS = 32;  // cadences per workgroup: 32 x P contiguous floats in, 32 x P contiguous doubles out
+    __shared__ float div[ROWS];
+    const int b = blockIdx.y, n0 = blockIdx.x * ROWS, tid = threadIdx.x;
+    const int nr = min(ROWS, N - n0);
+    if (tid < nr) {
+        float d = 1.0f;
+        if (mode == 1) d = lc[(size_t)b * N + n0 + tid];
+        if (mode == 2) {
+            const float *row = pix + ((size_t)b * N + n0 + tid) * P;
+            double sm = 0.0;
+            for (int p = 0; p < P; ++p) {
+                const float v = row[p];
+                if (v == v) sm += (double)v;
+            }
+            d = (float)sm;  // np.nansum over float32 pixels (rounded once instead of pairwise: <= 1 ulp(f32) apart)
         }
-        d = (float)s;  // np.nansum over float32 pixels (rounded once instead of pairwise: <= 1 ulp(f32) apart)
+        div[tid] = d;
     }
-    for (int p = threadIdx.x; p < P; p += blockDim.x)
-        out[((size_t)b * N + n) * P + p] = (double)(mode == 0 ? row[p] : row[p] / d);
+    __syncthreads();
+    const size_t base = ((size_t)b * N + n0) * P;
+    for (int e = tid; e < nr * P; e += 256) {
+        const float v = pix[base + e];
+        out[base + e] = (double)(mode == 0 ? v : v / div[e / P]);
+    }
 }
 
 // column means of A_b (N x P) subtracted in place; one workgroup per (column tile, b)
@@ -824,7 +832,7 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     const size_t mark = h->ws.used;
     if (k1 > 0) {
         LK_REQUIRE(pld_pix != nullptr, "pld_pix is NULL");
-        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 3) / 4, B), dim3(64, 4), 0, stream, pld_pix, lc_flux, 1, N, P, A);
+        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, pld_pix, lc_flux, 1, N, P, A);
         rc = pca_block(h, A, B, N, P, k1, d_off, X, K, col, stream, h->ws);
         if (rc) return rc;
         const int col1 = col;
@@ -865,7 +873,7 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     }
     const int n_pld_cols = col;
     h->ws.used = mark;
-    hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 3) / 4, B), dim3(64, 4), 0, stream, bkg_pix, lc_flux,
+    hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, lc_flux,
                        normalize_bkg ? 2 : 0, N, Pb, A);
     const int kb = std::min(pca_components, Pb);
     rc = pca_block(h, A, B, N, Pb, kb, d_off, X, K, col, stream, h->ws);
