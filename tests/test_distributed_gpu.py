@@ -1,44 +1,19 @@
 """GPU: the product's sharded batch entry points under a real RCCL process group.  A 1-GPU box can only form a
 world of one rank, which still exercises the whole wiring: sharded_map -> HIP kernels through the C ABI ->
 ragged all-gather on the device over backend "nccl" (= RCCL).  The world-size-2 logic is covered on CPU with gloo
-(tests/test_distributed_cpu.py)."""
+(tests/test_distributed_cpu.py).  Runs in a fresh interpreter (tests/rccl_worker.py): torch has to be imported before
+liblkhip.so, as in bench.py."""
 import os
-import socket
+import subprocess
+import sys
 
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def test_batch_entry_points_under_rccl_world1():
-    import torch
-    import torch.distributed as dist
-    from lightkurve_amd import batch, synth
-    from lightkurve_amd.lightcurve import LightCurve
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        lcs = []
-        for i, n in enumerate((900, 300, 1500)):
-            t, y, e, _ = synth.ls_target(5, i, n)
-            lcs.append(LightCurve(time=t, flux=y, flux_err=e))
-        f = synth.ls_frequency_grid(400, fmax=50.0)
-        full = batch.lombscargle_batch(lcs, f)                       # gathered over RCCL
-        local = batch.lombscargle_batch(lcs, f, gather=False)        # this rank's block only
-        # (the spreader accumulates with LDS atomics: two runs agree to rounding, not bit for bit)
-        assert full.shape == (3, 400) and np.allclose(full, local, rtol=1e-11, atol=0)
-        for b, lc in enumerate(lcs):
-            single = lc.to_periodogram(frequency=f)
-            assert np.max(np.abs(full[b] - np.asarray(single.power))) <= 1e-11 * np.max(full[b])
-        exact = batch.lombscargle_batch(lcs, f, ls_method="chi2", nterms=2)
-        assert exact.shape == (3, 400) and np.all(np.isfinite(exact))
-    finally:
-        dist.destroy_process_group()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_worker.py")
+    p = subprocess.run([sys.executable, worker], capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"RCCL_WORKER_OK" in p.stdout
