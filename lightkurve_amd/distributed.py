@@ -65,6 +65,10 @@ def all_gather_rows(local, bounds, group=None):
         raise ValueError("bounds must have world_size + 1 entries")
     is_np = isinstance(local, np.ndarray)
     backend = dist.get_backend(group)
+    if backend == "nccl" and not torch.cuda.is_available():
+        raise RuntimeError("torch sees no GPU: in a process that uses torch.distributed with RCCL, `import torch` must come "
+                           "before the first lightkurve_amd compute call (torch bundles its own ROCm runtime; "
+                           "liblkhip.so loads /opt/rocm's)")
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     x = torch.from_numpy(np.ascontiguousarray(local)).to(dev) if is_np else local.contiguous()
     if x.shape[0] != counts[rank]:
