@@ -28,8 +28,19 @@
  *   - `*_batch` takes HOST pointers (caller-owned numpy buffers; copied in/out inside the call).
  *     `*_batch_dev` takes DEVICE pointers (already resident in HBM) and enqueues on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream) without synchronising.
+ *     Some `_dev` launchers synchronise `stream` internally where the host needs a device result to size
+ *     the next launch (fold, flatten, BLS, Periodogram.smooth, PLD); treat "no sync" as not guaranteed.
  *   - One lk_handle drives one GPU (one process per GPU); it owns its scratch workspace and is not
- *     thread-safe.  Multi-GPU = one handle per rank, targets sharded by the caller (no data-path collective).
+ *     thread-safe.  ALL calls on one handle must use ONE stream (or be separated by a stream/device
+ *     synchronisation): every launcher carves its kernel scratch from the handle's single arena, so two calls
+ *     in flight on different streams would overwrite each other's live scratch.  Use one handle per stream /
+ *     per thread if you need concurrency on one GPU.
+ *     Multi-GPU = one handle per rank, targets sharded by the caller (no data-path collective).
+ *   - Deviations from the ABI sketched in SURVEY.md §8(b), on purpose: lk_init takes ONE device id (one handle
+ *     = one GPU = one process, the torch.distributed model; the sketch's device list would put multi-GPU fan-out
+ *     inside the call); there is no `precision` argument (everything is fp64: the parity tolerance of 1e-9
+ *     against the reference leaves no room for fp32/mixed variants); (max, argmax) come from lk_argmax_batch*
+ *     or the fused lk_ls_fast_peaks_batch* rather than from extra outputs of lk_ls_power_batch.
  */
 #ifndef LKHIP_H
 #define LKHIP_H

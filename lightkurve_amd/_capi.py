@@ -382,6 +382,8 @@ def regress_batch(X, y, n_off, err=None, cadence_mask=None, prior_mu=None, prior
     B = n_off.size - 1
     err = None if err is None else _f64(np.broadcast_to(err, (ntot,)))
     cm = None if cadence_mask is None else np.ascontiguousarray(cadence_mask, dtype=np.uint8)
+    if cm is not None and cm.shape != (ntot,):
+        raise ValueError("cadence_mask must have one entry per row of X (got shape %s, need (%d,))" % (cm.shape, ntot))
     if (prior_mu is None) != (prior_sigma is None):
         raise ValueError("Please specify both `prior_mu` and `prior_sigma`")
     if prior_mu is not None:
@@ -416,6 +418,8 @@ def savgol_trend_batch(t, flux, n_off, mask=None, window_length=101, polyorder=2
     if flux.shape != t.shape:
         raise ValueError("t and flux must have the same length")
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    if m is not None and m.shape != t.shape:
+        raise ValueError("mask must have one entry per cadence (got shape %s, need %s)" % (m.shape, t.shape))
     bt = float("nan") if break_tolerance is None else float(break_tolerance)
     trend = np.empty(t.size, dtype=np.float64)
     fm = np.empty(t.size, dtype=np.uint8) if return_fit_mask else None
@@ -442,6 +446,8 @@ def pld_design_batch(pld_pix, bkg_pix, lc_flux, time, knots, pld_order, pca_comp
     P = 0
     if pld_pix is not None and np.size(pld_pix):
         pld_pix = np.ascontiguousarray(pld_pix, dtype=np.float32)
+        if pld_pix.ndim != 3 or pld_pix.shape[:2] != (B, N):
+            raise ValueError("pld_pix must be (B, N, P) with the B, N of bkg_pix (got %s)" % (pld_pix.shape,))
         P = pld_pix.shape[2]
     else:
         pld_pix = None

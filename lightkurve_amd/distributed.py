@@ -46,18 +46,23 @@ def shard_bounds(n_items, world, costs=None):
 
 
 def _dist():
-    import torch.distributed as dist
-    return dist
+    """torch.distributed, or None in an interpreter without torch (the conda + astropy environment the seams live
+    in): no torch means no process group, and every caller treats that as "one rank"."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    return dist if dist.is_available() else None
 
 
 def all_gather_rows(local, bounds, group=None):
     """All-gather row blocks of unequal height: rank r contributes ``local`` of shape (bounds[r+1]-bounds[r], ...);
     every rank gets the (bounds[-1], ...) concatenation.  torch.Tensor in -> torch.Tensor out (same device);
     numpy in -> numpy out (staged through the backend's device).  One padded all_gather_into_tensor call."""
-    import torch
     dist = _dist()
-    if not (dist.is_available() and dist.is_initialized()):
+    if dist is None or not dist.is_initialized():
         return local
+    import torch
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     counts = np.diff(np.asarray(bounds, dtype=np.int64))
@@ -88,7 +93,7 @@ def sharded_map(items, fn, costs=None, gather=True, group=None):
     (optionally) all-gather the rows so every rank returns the full (len(items), ...) result in input order.
     Without an initialised process group this is just ``fn(items)``."""
     dist = _dist()
-    if not (dist.is_available() and dist.is_initialized()):
+    if dist is None or not dist.is_initialized():
         return fn(list(items))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bounds = shard_bounds(len(items), world, costs)

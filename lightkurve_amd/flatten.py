@@ -28,6 +28,11 @@ def flatten_trend_batch(lcs, window_length=101, polyorder=2, break_tolerance=5, 
     f = np.concatenate([np.asarray(lc.flux, dtype=np.float64) for lc in lcs]) if ts else np.zeros(0)
     m = None
     if masks is not None:
+        if len(masks) != len(lcs):
+            raise ValueError("masks must hold one entry (array or None) per light curve")
+        for i, mk in enumerate(masks):
+            if mk is not None and np.shape(mk) != (len(ts[i]),):
+                raise ValueError("mask %d has shape %s, its light curve has %d cadences" % (i, np.shape(mk), len(ts[i])))
         m = np.concatenate([np.zeros(len(ts[i]), bool) if mk is None else np.asarray(mk, dtype=bool)
                             for i, mk in enumerate(masks)])
     trend = _capi.savgol_trend_batch(t, f, off, mask=m, window_length=window_length, polyorder=polyorder,

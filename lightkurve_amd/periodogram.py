@@ -300,6 +300,11 @@ def _ls_plan(lc, minimum_frequency=None, maximum_frequency=None, minimum_period=
             "Please refer to the `astropy.timeseries.periodogram.LombScargle` documentation.".format(ls_method),
             LightkurveWarning)
         nterms = 1
+    if ls_method == "auto":
+        # astropy resolves 'auto' itself (lombscargle/implementations/main.py:79-108 validate_method): a regular grid
+        # of more than 200 frequencies goes to the extirpolation + FFT method, anything else to an exact method
+        # (nterms is 1 here: the guard above reset it for every name outside chi2/fastchi2)
+        ls_method = "fast" if (len(frequency) > 200 and is_regular(frequency)) else "cython"
     if nterms > _capi.MAX_NTERMS:
         raise NotImplementedError("the HIP multi-term kernels are instantiated for nterms <= %d (got %d)"
                                   % (_capi.MAX_NTERMS, nterms))
