@@ -1,27 +1,40 @@
 #!/usr/bin/env python
-"""bench.py — headline benchmark: batched Lomb-Scargle on MI355X (BASELINE.json configs[1]).
+"""bench.py — headline benchmark of the hot path on MI355X: batched Lomb-Scargle (BASELINE.json configs[1]) + the BLS
+transit search (configs[3]) + the accuracy columns of the metric, in ONE JSON line.
 
-    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
 
-A "step" = one pass of the hot path over one batch: B targets x M trial frequencies through liblkhip.so's
-lk_ls_fast_batch_dev (headline: the reference's DEFAULT method ls_method="fast", extirpolation + FFT) and, with the
-default --ls-method both, lk_ls_power_batch_dev (the exact direct sums, reported as `other_method`), each followed
-by lk_argmax_batch_dev; inputs already resident in HBM.  Prints ONE JSON line on rank 0 (metric
-frequencies*targets/sec, whole job over all ranks) carrying `roofline` (fast: algorithmic HBM bytes over the HIP-event
-time against 8 TB/s, with the PMC traffic from profiles/traffic.json; exact: 16 flop per (cadence, frequency) pair
-against the fp64 vector peak) and `cpu_baseline` (the reference's default algorithm run through astropy itself on this
-box's usable cores, on a bounded sample; numpy port if astropy is absent).
+N > 1: the driver launches one rank per GPU (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`);
+run by hand without WORLD_SIZE in the environment, `--gpus N` re-executes itself under torch.distributed.run with N
+ranks on 127.0.0.1.  `--dry` forms the same process group on CPU (gloo) and exercises launch + barrier + max-over-ranks
+without touching a GPU (tests/test_distributed_cpu.py).
 
-Weak scaling: every rank owns B targets (targets are independent; no data-path collective is needed to compute).
-With N>1 the per-target (max power, argmax) are all-gathered over RCCL each step (--gather summary, default), or the
-full spectra chunk by chunk so the collective of chunk k overlaps the kernels of chunk k+1 (--gather spectra).
+A "step" = one pass of the hot path over one batch of targets, inputs already resident in HBM:
+  * headline (`value`): B targets x M trial frequencies through lk_ls_fast_peaks_batch_dev — the reference's DEFAULT
+    method ls_method="fast" (extirpolation + FFT) followed by the per-target (max power, argmax);
+  * `other_method`: the exact direct-sum kernel (lk_ls_power_batch_dev + lk_argmax_batch_dev), same protocol;
+  * `bls`: configs[3] (B targets x 50 000 periods x 200 durations) through lk_bls_batch_dev, 1 warm-up + <= 2 steps;
+  * `accuracy` (N = 1): astropy ITSELF (conda interpreter, oracle/astropy_baseline.py suite) run on the first targets
+    of the very same batches, arrays handed over as files: max-power relative error and argmax equality for 'fast'
+    (vs astropy 'fast') and exact (vs astropy 'cython') at full N / M, BLS best-period index equality on the full
+    period grid.  The same runs are the `cpu_baseline`s (the reference's CPU path on this box's usable cores).
+  * `host_to_host`: the same LS step through the HOST-pointer entry point (lk_ls_fast_peaks_batch: pinned,
+    double-buffered staging), PCIe included — reported beside `value`, never as `value`.
+
+Scaling: weak by default (every rank owns --targets targets); `--total-targets T` fixes the job (configs[2]: 10 000
+targets over 8 GPUs) and reports "scaling": "strong".  Targets are independent: no data-path collective; with N > 1 the
+per-target (max power, argmax) are all-gathered over RCCL each step (--gather summary), or the full spectra
+(--gather spectra, chunked so the collective of chunk k overlaps the kernels of chunk k+1), everything device-resident.
 
 Other workloads, same protocol and JSON shape: --workload bls | pld | regress | flatten | fold | lschi2 | pgsmooth.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,18 +44,22 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 MFMA dense peak (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
+CONDA = "/opt/conda/bin/python3.9"
+SYS_STDCXX = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--targets", type=int, default=1000, help="targets per GPU (B)")
+    ap.add_argument("--targets", type=int, default=1000, help="targets per GPU (B), weak scaling")
+    ap.add_argument("--total-targets", type=int, default=0,
+                    help="strong scaling: total targets of the job, sharded over the ranks (configs[2]: 10000)")
     ap.add_argument("--cadences", type=int, default=20000, help="cadences per target (N)")
     ap.add_argument("--freqs", type=int, default=100000, help="trial frequencies (M)")
     ap.add_argument("--chunks", type=int, default=4, help="target chunks per step (comm/compute overlap)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the astropy runs (cpu_baseline AND accuracy)")
     ap.add_argument("--workload", default="ls", choices=["ls", "bls", "pld", "flatten", "lschi2", "pgsmooth", "fold", "regress"])
     ap.add_argument("--regressors", type=int, default=135, help="regress: design-matrix columns K")
     ap.add_argument("--nterms", type=int, default=2, help="lschi2: Fourier terms")
@@ -55,7 +72,14 @@ def parse():
                     help="N>1: what is all-gathered over RCCL each step: per-target (max power, argmax), the full spectra, or nothing")
     ap.add_argument("--periods", type=int, default=50000)
     ap.add_argument("--durations", type=int, default=200)
-    return ap.parse_args()
+    ap.add_argument("--no-bls", action="store_true", help="workload ls: skip the BLS block of the metric")
+    ap.add_argument("--bls-targets", type=int, default=1000, help="workload ls: targets per GPU of the BLS block")
+    ap.add_argument("--no-host", action="store_true", help="workload ls: skip the host-to-host measurement")
+    ap.add_argument("--acc-fast", type=int, default=256, help="targets checked against astropy 'fast' (also the cpu_baseline sample)")
+    ap.add_argument("--acc-exact", type=int, default=16, help="targets checked against astropy 'cython' (74 s of one core each)")
+    ap.add_argument("--acc-bls", type=int, default=32, help="targets checked against astropy run_bls on the full period grid")
+    ap.add_argument("--dry", action="store_true", help="CPU only: form the process group (gloo), barrier, max over ranks; no GPU work")
+    return ap.parse_args(argv)
 
 
 def effective_cores(cap=64):
@@ -77,74 +101,119 @@ def effective_cores(cap=64):
     return max(1, min(n, cap))
 
 
-CONDA = "/opt/conda/bin/python3.9"
-SYS_STDCXX = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+# ------------------------------------------------------------------------------------------------ self-launch
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: re-execute under it with N ranks on 127.0.0.1."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
-def _astropy_baseline(argv):
-    """Run oracle/astropy_baseline.py under the conda interpreter that ships astropy (the reference's real
-    numerical dependency).  Returns its JSON dict, or None if that interpreter / astropy is not there."""
-    import subprocess
+def dry_run(args, rank, world):
+    """The launch / rendezvous / barrier / max-over-ranks skeleton of the real run on CPU (gloo), no GPU work."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    from lightkurve_amd.distributed import shard_bounds
+    total = args.total_targets or args.targets * world
+    bounds = shard_bounds(total, world) if args.total_targets else np.arange(world + 1) * args.targets
+    mine = int(bounds[rank + 1] - bounds[rank])
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(mine)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, total_seen = float(mx[0]), int(sm[1])
+    else:
+        total_seen = mine
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry": True, "n_gpus": world, "value": 0.0,
+                          "targets_total": total_seen, "scaling": "strong" if args.total_targets else "weak",
+                          "ms_per_step": 1e3 * dt, "steps": args.steps, "warmup": args.warmup}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ reference runs
+def reference_suite(args, want_ls, want_bls):
+    """Run astropy itself (the reference's numerical dependency) on the first targets of the bench batches, before
+    torch/HIP is initialised: returns the suite's result dict (rates + per-target maxima), or None when the conda
+    interpreter / astropy is not there.  Inputs travel as .npz files so both sides see identical arrays."""
+    from lightkurve_amd import synth
     if not os.path.exists(CONDA):
         return None
-    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "oracle", "shims") + os.pathsep + ROOT)
-    if os.path.exists(SYS_STDCXX):
-        env["LD_PRELOAD"] = SYS_STDCXX
+    cores = effective_cores()
+    work = tempfile.mkdtemp(prefix="lk_bench_")
+    spec = {}
     try:
-        p = subprocess.run([CONDA, "-W", "ignore", os.path.join(ROOT, "oracle", "astropy_baseline.py")] +
-                           [str(a) for a in argv], env=env, capture_output=True, timeout=900)
-        for line in p.stdout.decode().splitlines():
-            if line.startswith("BASELINE "):
-                return json.loads(line[9:])
-    except Exception:
-        pass
-    return None
+        if want_ls:
+            n = max(args.acc_fast, args.acc_exact)
+            n = min(n, args.targets)
+            t, y, dy, off = synth.ls_batch(1, n, args.cadences, first_index=0)
+            for b in range(n):
+                t[off[b]:off[b + 1]] -= t[off[b]]
+            df = 360.0 / args.freqs
+            np.savez(os.path.join(work, "ls.npz"), t=t, y=y, off=off, f0=df, df=df, M=args.freqs)
+            spec["ls"] = {"n_fast": min(args.acc_fast, n), "n_exact": min(args.acc_exact, n)}
+        if want_bls and args.acc_bls > 0:
+            n = min(args.acc_bls, args.bls_targets if args.workload == "ls" else args.targets)
+            t, y, e, off = synth.bls_batch(3, n, args.cadences, first_index=0)
+            period, duration = synth.bls_grid(args.periods, args.durations)
+            np.savez(os.path.join(work, "bls.npz"), t=t, y=y, e=e, off=off, period=period, duration=duration)
+            spec["bls"] = {"n": n}
+        json.dump(spec, open(os.path.join(work, "suite.json"), "w"))
+        env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "oracle", "shims") + os.pathsep + ROOT)
+        if os.path.exists(SYS_STDCXX):
+            env["LD_PRELOAD"] = SYS_STDCXX
+        p = subprocess.run([CONDA, "-W", "ignore", os.path.join(ROOT, "oracle", "astropy_baseline.py"), "suite", work,
+                            str(cores)], env=env, capture_output=True, timeout=1500)
+        rpath = os.path.join(work, "result.json")
+        if p.returncode != 0 or not os.path.exists(rpath):
+            sys.stderr.write("astropy suite failed: %s\n" % p.stderr.decode()[-800:])
+            return None
+        res = json.load(open(rpath))
+        res["cores"] = cores
+        return res
+    except Exception as e:   # the baseline is reported, never required
+        sys.stderr.write("astropy suite failed: %r\n" % (e,))
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
-def cpu_baseline_ls(args):
-    """The reference's DEFAULT CPU path on this box's host cores, on a bounded sample of the same workload,
-    before torch/HIP is initialised.  Preferred: astropy itself (LombScargle.power(method='fast') exactly as
-    lightkurve calls it, periodogram.py:961-964) under the conda interpreter, one process per core (kind
-    "reference").  Fallback: the numpy port of the same algorithm from oracle/ (kind "port")."""
+def port_baseline_ls(args):
+    """Fallback when astropy is absent: the numpy port of the reference default (oracle.np_oracle.ls_power_fast)."""
     import multiprocessing as mp
     from oracle import cpu_baseline as cb
     cores = effective_cores()
-    exact_pairs_per_s = cb.ls_exact_rate(args.cadences)
-    extra = {"exact_port_1core": {"value": exact_pairs_per_s / args.cadences, "unit": "frequencies*targets/sec",
-                                  "note": "C oracle (the exact direct-sum arithmetic the GPU kernel performs), 1 core"}}
-    n_targets = cores * 16
-    r = _astropy_baseline(["ls", n_targets, args.cadences, args.freqs, cores, "fast"])
-    if r is not None:
-        out = {"value": r["units_per_s"], "unit": "frequencies*targets/sec", "cores": cores, "kind": "reference",
-               "sample": "astropy %s LombScargle.power(method='fast') as lightkurve calls it (periodogram.py:961-964), "
-                         "%d targets x %d freqs, N=%d, %d processes, %.1f s" % (r["astropy"], n_targets, args.freqs,
-                                                                              args.cadences, cores, r["seconds"])}
-        out.update(extra)
-        return out
     n_targets = cores * 2
     jobs = [(1, i, args.cadences, args.freqs) for i in range(n_targets)]
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        pool.map(cb.ls_fast_one, jobs[:cores])          # warm (imports, FFT plans)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        pool.map(cb.ls_fast_one, jobs[:cores])
         t0 = time.perf_counter()
         pool.map(cb.ls_fast_one, jobs)
         dt = time.perf_counter() - t0
-    out = {"value": n_targets * args.freqs / dt, "unit": "frequencies*targets/sec", "cores": cores, "kind": "port",
-           "sample": "%d targets x %d freqs, N=%d, numpy port of the reference default ls_method='fast' "
-                     "(Press-Rybicki FFT), %d processes" % (n_targets, args.freqs, args.cadences, cores)}
-    out.update(extra)
-    return out
+    return {"value": n_targets * args.freqs / dt, "unit": "frequencies*targets/sec", "cores": cores, "kind": "port",
+            "sample": "%d targets x %d freqs, N=%d, numpy port of the reference default ls_method='fast' "
+                      "(Press-Rybicki FFT), %d processes" % (n_targets, args.freqs, args.cadences, cores)}
 
 
-def cpu_baseline_bls(args):
+def port_baseline_bls(args):
     from oracle import cpu_baseline as cb
-    cores = effective_cores()
-    r = _astropy_baseline(["bls", cores * 4, args.cadences, 480, args.durations, cores])
-    if r is not None:
-        return {"value": r["units_per_s"], "unit": "periods*targets/sec", "cores": cores, "kind": "reference",
-                "sample": "astropy %s BoxLeastSquares.power (compiled run_bls) as lightkurve calls it "
-                          "(periodogram.py:1161-1169), %d targets x 480 periods x %d durations, N=%d, %d processes, "
-                          "%.1f s" % (r["astropy"], cores * 4, args.durations, args.cadences, cores, r["seconds"])}
     rate = cb.bls_rate(args.cadences, args.durations)
     return {"value": rate, "unit": "periods*targets/sec", "cores": 1, "kind": "port",
             "sample": "C oracle (restated astropy run_bls), 1 target x 24 periods x %d durations, N=%d, 1 core"
@@ -212,7 +281,6 @@ def cpu_baseline_regress(args):
     from oracle import np_oracle as O
     rng = np.random.default_rng(0)
     n, K, nb = args.pld_cadences, args.regressors, 4
-    t0 = None
     Xs = [rng.standard_normal((n, K)) for _ in range(nb)]
     ys = [X @ rng.standard_normal(K) * 1e-3 + 1 + 1e-3 * rng.standard_normal(n) for X in Xs]
     t0 = time.perf_counter()
@@ -237,21 +305,73 @@ def cpu_baseline_fold(args):
             "sample": "32 light curves x %d cadences, numpy mod + stable argsort + two gathers" % args.cadences}
 
 
+def load_traffic():
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath))
+    except Exception:
+        return {}
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry:
+        sys.exit(dry_run(args, rank, world))
 
-    cpu_base = None
+    # ---- the reference's CPU path (cpu_baseline + accuracy reference): rank 0 at N = 1 only, before torch/HIP exist
+    ref, cpu_base, cpu_base_bls = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_base = {"ls": cpu_baseline_ls, "bls": cpu_baseline_bls, "pld": cpu_baseline_pld,
-                    "flatten": cpu_baseline_flatten, "lschi2": cpu_baseline_lschi2, "pgsmooth": cpu_baseline_pgsmooth,
-                    "fold": cpu_baseline_fold, "regress": cpu_baseline_regress}[args.workload](args)
+        if args.workload == "ls":
+            ref = reference_suite(args, True, not args.no_bls)
+            if ref is None:
+                cpu_base = port_baseline_ls(args)
+                cpu_base_bls = None if args.no_bls else port_baseline_bls(args)
+        elif args.workload == "bls":
+            ref = reference_suite(args, False, True)
+            if ref is None:
+                cpu_base = port_baseline_bls(args)
+        else:
+            cpu_base = {"pld": cpu_baseline_pld, "flatten": cpu_baseline_flatten, "lschi2": cpu_baseline_lschi2,
+                        "pgsmooth": cpu_baseline_pgsmooth, "fold": cpu_baseline_fold,
+                        "regress": cpu_baseline_regress}[args.workload](args)
+        if ref is not None:
+            if "ls_fast" in ref:
+                r = ref["ls_fast"]
+                cpu_base = {"value": r["units_per_s"], "unit": "frequencies*targets/sec", "cores": ref["cores"],
+                            "kind": "reference",
+                            "sample": "astropy %s LombScargle.power(method='fast') as lightkurve calls it "
+                                      "(periodogram.py:961-964), %d targets x %d freqs, N=%d, %d processes, %.1f s"
+                                      % (ref["astropy"], r["n_targets"], args.freqs, args.cadences, ref["procs"], r["seconds"])}
+                if "ls_cython" in ref:
+                    rc = ref["ls_cython"]
+                    cpu_base["exact_cython"] = {
+                        "value": rc["units_per_s"], "unit": "frequencies*targets/sec", "cores": ref["cores"],
+                        "sample": "astropy LombScargle.power(method='cython') (the exact method), %d targets x %d freqs, "
+                                  "N=%d, %d processes, %.1f s" % (rc["n_targets"], args.freqs, args.cadences, ref["procs"],
+                                                                  rc["seconds"])}
+            if "bls" in ref:
+                r = ref["bls"]
+                cb = {"value": r["units_per_s"], "unit": "periods*targets/sec", "cores": ref["cores"], "kind": "reference",
+                      "sample": "astropy %s BoxLeastSquares.power (compiled run_bls) as lightkurve calls it "
+                                "(periodogram.py:1161-1169), %d targets x %d periods x %d durations, N=%d, %d processes, "
+                                "%.1f s" % (ref["astropy"], r["n_targets"], args.periods, args.durations, args.cadences,
+                                            ref["procs"], r["seconds"])}
+                if args.workload == "bls":
+                    cpu_base = cb
+                else:
+                    cpu_base_bls = cb
 
+    import ctypes
     import torch
     import torch.distributed as dist
     from lightkurve_amd import _capi, synth
+    from lightkurve_amd.distributed import shard_bounds
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -263,11 +383,12 @@ def main():
     if dist_on:
         # RCCL prints a version banner on STDOUT when the first communicator is created; this script's stdout is one
         # JSON line, so file descriptor 1 points at stderr until the communicator exists
+        import datetime
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -275,13 +396,107 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
     handle = _capi.Handle.get(local_rank)
+    lib = _capi.load_library()
     stream = torch.cuda.current_stream().cuda_stream
+    vp = ctypes.c_void_p
+    i64p = ctypes.POINTER(ctypes.c_int64)
 
-    B, N, M = args.targets, args.cadences, args.freqs
-    out = {}
+    def sync():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(step_fn, warmup, steps):
+        """W untimed + K timed steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, mean HIP-event
+        ms of the kernel region per step).  step_fn(e0, e1) records e0/e1 around the library calls on `stream`."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(warmup + steps)]
+        for k in range(warmup):
+            step_fn(*evs[k])
+        sync()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step_fn(*evs[k])
+        sync()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        kms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs[warmup:]]))
+        return dt, kms
+
+    # ---- how many targets this rank owns
+    strong = args.total_targets > 0
+    if strong:
+        bounds = shard_bounds(args.total_targets, world)
+        first, B = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+        total_targets = args.total_targets
+    else:
+        first, B = rank * args.targets, args.targets
+        total_targets = args.targets * world
+    N, M = args.cadences, args.freqs
+    traffic_all = load_traffic()
+    out, extra = {}, {}
+    roofline = None
+
+    # ================================================================================================ BLS block
+    def run_bls(Bb, first_index, steps, warmup):
+        t, y, dy, off = synth.bls_batch(3, Bb, N, first_index=first_index)
+        ivar = 1.0 / dy ** 2
+        for b in range(Bb):
+            s = slice(off[b], off[b + 1])
+            t[s] -= t[s].min()
+            y[s] -= np.median(y[s])
+        period, duration = synth.bls_grid(args.periods, args.durations)
+        nP = len(period)
+        d_t, d_y, d_w = (torch.from_numpy(a).to(dev) for a in (t, y, ivar))
+        d_per = torch.from_numpy(period).to(dev)
+        d_out = torch.empty((7, Bb, nP), dtype=torch.float64, device=dev)
+        d_max = torch.empty(Bb, dtype=torch.float64, device=dev)
+        d_arg = torch.empty(Bb, dtype=torch.int64, device=dev)
+
+        def step(e0, e1):
+            e0.record()
+            _capi.bls_batch_dev(handle, Bb, off, d_t.data_ptr(), d_y.data_ptr(), d_w.data_ptr(), period,
+                                d_per.data_ptr(), duration, 10, True, d_out.data_ptr(), stream)
+            e1.record()
+            _capi.argmax_batch_dev(handle, Bb, nP, d_out.data_ptr(), d_max.data_ptr(), d_arg.data_ptr(), stream)
+
+        dt, kms = timed(step, warmup, steps)
+        nb = np.ceil(period / (duration.min() / 10)) + 10
+        durb = np.unique(np.round(duration / (duration.min() / 10)))
+        cand = float(np.sum(np.maximum(nb[:, None] - durb[None, :] + 1, 0))) * Bb   # (start bin, duration) candidates
+        ach = 12.0 * cand / (kms * 1e-3) / 1e12
+        res = {
+            "metric": "BLS periods*targets/sec", "unit": "periods*targets/sec",
+            "units_per_step": Bb * nP, "dt": dt, "steps": steps, "warmup": warmup, "kernel_ms": kms,
+            "workload": "configs[3]: %d targets x %d cadences, %d periods x %d durations BLS per GPU" % (Bb, N, nP, len(duration)),
+            "roofline": {"bound": "valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("bls"), "kernel": "bls_kernel",
+                         "kernel_ms_per_step": kms,
+                         "note": "algorithmic 12 flop per (start bin, duration) candidate (SURVEY.md 8(d)); the bit-exact "
+                                 "kernel skips most candidates with a rigorous growth bound, so this is an equivalent rate; "
+                                 "everything lives in LDS, HBM traffic is the 7 outputs"},
+            "argmax": d_arg.cpu().numpy(), "max_power": d_max.cpu().numpy(),
+            "period_at_max": period[np.clip(d_arg.cpu().numpy(), 0, nP - 1)],
+        }
+        del d_out
+        return res
+
+    def bls_accuracy(res, refb):
+        n = min(len(refb["argmax"]), len(res["argmax"]))
+        a_ref, a_gpu = np.asarray(refb["argmax"][:n]), res["argmax"][:n]
+        p_ref, p_gpu = np.asarray(refb["max_power"][:n]), res["max_power"][:n]
+        return {"targets_checked": n, "reference": "astropy %s BoxLeastSquares.power on the full %d-period grid"
+                % (ref["astropy"], args.periods),
+                "best_period_index_equal": "%d/%d" % (int(np.sum(a_ref == a_gpu)), n),
+                "max_power_bit_identical": "%d/%d" % (int(np.sum(p_ref == p_gpu)), n),
+                "max_power_relerr_max": float(np.max(np.abs(p_gpu - p_ref) / np.abs(p_ref)))}
+
     if args.workload == "ls":
-        # ---- synthetic inputs, rank r owns targets [r*B, (r+1)*B)
-        t, y, dy, off = synth.ls_batch(1, B, N, first_index=rank * B)
+        # ---- synthetic inputs (SURVEY.md 8(d)); rank r owns targets [first, first + B)
+        t, y, dy, off = synth.ls_batch(1, B, N, first_index=first)
         for b in range(B):
             t[off[b]:off[b + 1]] -= t[off[b]]
         df = 360.0 / M
@@ -291,54 +506,210 @@ def main():
         d_arg = torch.empty(B, dtype=torch.int64, device=dev)
         gather_spec = dist_on and args.gather == "spectra"
         gather_sum = dist_on and args.gather == "summary"
+        # gathers need equal shard sizes per rank (weak scaling always; strong: pad to the largest shard)
+        Bmax = B
+        if dist_on and strong:
+            Bmax = int(np.max(np.diff(shard_bounds(args.total_targets, world))))
         nch = max(1, min(args.chunks, B)) if gather_spec else 1
-        bounds = np.linspace(0, B, nch + 1).astype(int)
-        d_all = [torch.empty((world, bounds[c + 1] - bounds[c], M), dtype=torch.float64, device=dev)
+        cb = np.linspace(0, Bmax, nch + 1).astype(int)
+        d_all = [torch.empty((world, cb[c + 1] - cb[c], M), dtype=torch.float64, device=dev)
                  for c in range(nch)] if gather_spec else None
-        d_sum = torch.empty((B, 2), dtype=torch.float64, device=dev)
-        d_sum_all = torch.empty((world, B, 2), dtype=torch.float64, device=dev) if gather_sum else None
+        d_powpad = torch.zeros((Bmax, M), dtype=torch.float64, device=dev) if (gather_spec and Bmax != B) else None
+        d_sum = torch.zeros((Bmax, 2), dtype=torch.float64, device=dev)
+        d_sum_all = torch.empty((world, Bmax, 2), dtype=torch.float64, device=dev) if gather_sum else None
         headline = "fast" if args.ls_method in ("both", "fast") else "exact"
-        nev = 2 * (args.steps + args.warmup)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
 
-        def ls_step(k, method):
-            works = []
-            e0, e1 = ev[k]
-            for c in range(nch):
-                b0, b1 = int(bounds[c]), int(bounds[c + 1])
-                offc = off[b0:b1 + 1] - off[b0]
-                if c == 0:
-                    e0.record()
-                if method == "fast":
-                    _capi.ls_fast_batch_dev(handle, b1 - b0, offc, d_t.data_ptr() + 8 * int(off[b0]),
-                                            d_y.data_ptr() + 8 * int(off[b0]), 0, df, df, M, True, True,
-                                            "lk_amplitude", 0, 5, d_pow.data_ptr() + 8 * b0 * M, stream)
-                else:
-                    _capi.ls_power_batch_dev(handle, b1 - b0, offc, d_t.data_ptr() + 8 * int(off[b0]),
-                                             d_y.data_ptr() + 8 * int(off[b0]), 0, 0, df, df, M, True, True,
-                                             "lk_amplitude", 0, d_pow.data_ptr() + 8 * b0 * M, stream)
-                if c == nch - 1:
-                    e1.record()
-                if gather_spec:
-                    works.append(dist.all_gather_into_tensor(d_all[c], d_pow[b0:b1], async_op=True))
-            _capi.argmax_batch_dev(handle, B, M, d_pow.data_ptr(), d_max.data_ptr(), d_arg.data_ptr(), stream)
-            if gather_sum:   # every rank ends with every target's (max power, argmax): 16 B per target over xGMI
-                d_sum[:, 0] = d_max
-                d_sum[:, 1] = d_arg.to(torch.float64)
-                dist.all_gather_into_tensor(d_sum_all.view(world * B, 2), d_sum)
-            for w in works:
-                w.wait()
+        def make_step(method):
+            def step(e0, e1):
+                works = []
+                for c in range(nch):
+                    b0, b1 = min(int(cb[c]), B), min(int(cb[c + 1]), B)
+                    if c == 0:
+                        e0.record()
+                    if b1 > b0:
+                        offc = off[b0:b1 + 1] - off[b0]
+                        tp, yp = d_t.data_ptr() + 8 * int(off[b0]), d_y.data_ptr() + 8 * int(off[b0])
+                        pp = d_pow.data_ptr() + 8 * b0 * M
+                        if method == "fast":
+                            _capi.ls_fast_peaks_batch_dev(handle, b1 - b0, offc, tp, yp, 0, df, df, M, True, True,
+                                                          "lk_amplitude", 0, 5, pp, d_max.data_ptr() + 8 * b0,
+                                                          d_arg.data_ptr() + 8 * b0, stream)
+                        else:
+                            _capi.ls_power_batch_dev(handle, b1 - b0, offc, tp, yp, 0, 0, df, df, M, True, True,
+                                                     "lk_amplitude", 0, pp, stream)
+                            _capi.argmax_batch_dev(handle, b1 - b0, M, pp, d_max.data_ptr() + 8 * b0,
+                                                   d_arg.data_ptr() + 8 * b0, stream)
+                    if c == nch - 1:
+                        e1.record()
+                    if gather_spec:
+                        src = d_pow
+                        if d_powpad is not None:
+                            d_powpad[:B] = d_pow
+                            src = d_powpad
+                        works.append(dist.all_gather_into_tensor(d_all[c], src[int(cb[c]):int(cb[c + 1])], async_op=True))
+                if gather_sum:   # every rank ends with every target's (max power, argmax): 16 B per target over xGMI
+                    d_sum[:B, 0] = d_max
+                    d_sum[:B, 1] = d_arg.to(torch.float64)
+                    dist.all_gather_into_tensor(d_sum_all.view(world * Bmax, 2), d_sum)
+                for w in works:
+                    w.wait()
+            return step
 
-        def step(k):
-            ls_step(k, headline)
-
-        units_per_step = B * M
-        pairs_per_step = float(sum(int(off[b + 1] - off[b]) for b in range(B))) * M
+        results = {}
+        order = [headline] + ([("exact" if headline == "fast" else "fast")] if args.ls_method == "both" else [])
+        peaks = {}
+        for method in order:
+            results[method] = timed(make_step(method), args.warmup, args.steps)
+            peaks[method] = (d_max.cpu().numpy().copy(), d_arg.cpu().numpy().copy())
+        units_per_step = total_targets * M
+        pairs_local = float(off[-1]) * M
         names = {"exact": "exact GLS, direct fp64 trig sums", "fast": "ls_method='fast' (reference default): extirpolation + FFT"}
-        metric = "frequencies*targets/sec (Lomb-Scargle, %s)" % names[headline]
+        metric = "frequencies*targets/sec (Lomb-Scargle, %s)%s" % (names[headline], "" if args.no_bls else
+                                                                   " + BLS periods*targets/sec; max-power rel-err")
         unit = "frequencies*targets/sec"
-        workload = ("configs[1]: %d TESS-like %d-cadence targets x %d freqs Lomb-Scargle per GPU, ls_method=%s"
-                    % (B, N, M, headline))
+        workload = ("configs[%d]: %d TESS-like %d-cadence targets x %d freqs Lomb-Scargle %s, ls_method=%s"
+                    % (2 if strong else 1, total_targets if strong else B, N, M,
+                       "in total over %d GPU(s)" % world if strong else "per GPU", headline))
+
+        def ls_roofline(method, kms):
+            if method == "fast":
+                nfft = 1 << int(np.ceil(np.log2(5 * M)))
+                n2 = 1 << (int(np.log2(nfft)) // 2)
+                fused_spread = os.environ.get("LK_LSF_SPREAD_FUSED", "1") != "0"
+                used = 0.0   # grid rows that can hold samples: written by the stand-alone spreader and read by FFT step 1
+                if not fused_spread:
+                    for b in range(B):
+                        span = (t[off[b + 1] - 1] - t[off[b]]) * nfft * df
+                        used += 2 * min(nfft, (int((span + 4) / n2) + 1) * n2) + min(nfft, (int((2 * span + 4) / n2) + 1) * n2)
+                algo = B * (3 * nfft * 16.0 * 2 + 8.0 * M) + used * 16.0 * 2 + 40.0 * float(off[-1])
+                r01 = B * (3 * nfft * 16.0 * 2 + 3 * M * 16.0 * 2 + 8.0 * M) + 16.0 * float(off[-1])
+                tr = traffic_all.get("ls_fast")
+                rl = {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+                      "kernel": "lsf_cols kernel (FFT step 1%s) + fft_rows_power_kernel (FFT step 2 + closed form): whole step"
+                                % (" with the extirpolation fused in" if fused_spread else ", after lsf_spread_owner_kernel"),
+                      "kernel_ms_per_step": kms, "algorithmic_bytes_per_step": algo,
+                      "note": "algorithmic bytes per target: 3 complex fp64 grids of Nfft=%d written by FFT step 1 and read by "
+                              "step 2 (2 x 16 B x Nfft each)%s, 40 B/cadence (t, y in; w, w*y written by the prep kernel and "
+                              "read by the spreader), 8 B/frequency out.  The three spectra never touch HBM (fused closed "
+                              "form) and are not counted." % (nfft, "" if fused_spread else
+                                                              ", the sample-bearing rows written by the spreader and read by step 1"),
+                      "frac_r01_formula": r01 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if tr:
+                    rl["hbm_utilisation"] = float(tr) * (B / 1000.0) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    rl["traffic_note"] = ("PMC FETCH_SIZE + WRITE_SIZE per 1000-target step from profiles/ (separate rocprofv3 "
+                                          "--pmc passes of this command), scaled to this batch; not re-measured in this run")
+                return rl
+            flops = 16.0 * pairs_local
+            ach = flops / (kms * 1e-3) / 1e12
+            algo_bytes = 16.0 * float(off[-1]) + 8.0 * B * M
+            return {"bound": "valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("ls"),
+                    "kernel": "ls_grid_kernel<16> (+ls_prep_kernel)", "kernel_ms_per_step": kms,
+                    "note": "fp64 direct trig sums: 16 flop (8 v_fma_f64) per (cadence, frequency) pair; arithmetic "
+                            "intensity ~3e4 flop/B so the fp64 VECTOR pipe binds (peak == fp64 MFMA dense peak), not HBM",
+                    "hbm": {"achieved": algo_bytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_step": algo_bytes}}
+
+        dt, kern_ms = results[headline]
+        roofline = ls_roofline(headline, kern_ms)
+        extra["config_ls_method"] = headline
+        if len(order) > 1:
+            other = order[1]
+            dt2, kms2 = results[other]
+            extra["other_method"] = {"ls_method": other, "value": units_per_step * args.steps / dt2, "unit": unit,
+                                     "ms_per_step": 1e3 * dt2 / args.steps, "roofline": ls_roofline(other, kms2),
+                                     "note": "same workload, same timing protocol; 'exact' = the direct-sum kernel "
+                                             "(matches the reference's slow/cython/chi2 to 1e-9), 'fast' = the reference's "
+                                             "default algorithm (matches lightkurve's default output to 1e-9)"}
+
+        # ---- accuracy vs astropy itself on the first targets of this very batch (N = 1 only)
+        if ref is not None and rank == 0:
+            acc = {}
+            for method, key in (("fast", "ls_fast"), ("exact", "ls_cython")):
+                if method in peaks and key in ref:
+                    n = min(len(ref[key]["max_power"]), B)
+                    r_max, r_arg = np.asarray(ref[key]["max_power"][:n]), np.asarray(ref[key]["argmax"][:n])
+                    g_max, g_arg = peaks[method][0][:n], peaks[method][1][:n]
+                    rel = np.abs(g_max - r_max) / np.abs(r_max)
+                    acc["ls_" + method] = {
+                        "reference": "astropy %s LombScargle.power(method='%s'), lightkurve amplitude normalisation, "
+                                     "N=%d, M=%d" % (ref["astropy"], "fast" if method == "fast" else "cython", N, M),
+                        "targets_checked": int(n), "max_power_relerr_max": float(np.max(rel)),
+                        "max_power_relerr_median": float(np.median(rel)),
+                        "argmax_equal": "%d/%d" % (int(np.sum(g_arg == r_arg)), n)}
+            extra["accuracy"] = acc
+
+        # ---- host-to-host: the same step through the host-pointer entry point (PCIe included)
+        if not args.no_host:
+            try:
+                h_pow = _capi.pinned_empty((B, M))
+                h_t, h_y = _capi.pinned_empty(t.shape), _capi.pinned_empty(y.shape)
+                h_t[:], h_y[:] = t, y
+                hs = {}
+                for label, kw in (("spectra_pinned", dict(out=h_pow, want_power=True)),
+                                  ("peaks_only_pinned", dict(want_power=False))):
+                    _capi.ls_fast_peaks_batch(h_t, h_y, off, f0=df, df=df, M=M, normalization="lk_amplitude",
+                                              device=local_rank, **kw)
+                    sync()
+                    t0 = time.perf_counter()
+                    reps = max(1, min(args.steps, 3))
+                    for _ in range(reps):
+                        r = _capi.ls_fast_peaks_batch(h_t, h_y, off, f0=df, df=df, M=M, normalization="lk_amplitude",
+                                                      device=local_rank, **kw)
+                    sync()
+                    hdt = (time.perf_counter() - t0) / reps
+                    if dist_on:
+                        tt = torch.tensor([hdt], dtype=torch.float64, device=dev)
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        hdt = float(tt.item())
+                    hs[label] = {"value": units_per_step / hdt, "ms_per_step": 1e3 * hdt}
+                    if label == "peaks_only_pinned" and "fast" in peaks:
+                        hs[label]["peaks_match_device_path"] = bool(np.array_equal(r[2], peaks["fast"][1]))
+                # pageable numpy buffers (what a caller that never heard of lk_host_alloc passes)
+                p_pow = np.empty((min(B, 256), M))
+                nb = p_pow.shape[0]
+                _capi.ls_fast_peaks_batch(t[:off[nb]], y[:off[nb]], off[:nb + 1], f0=df, df=df, M=M,
+                                          normalization="lk_amplitude", device=local_rank, out=p_pow, want_power=True)
+                t0 = time.perf_counter()
+                _capi.ls_fast_peaks_batch(t[:off[nb]], y[:off[nb]], off[:nb + 1], f0=df, df=df, M=M,
+                                          normalization="lk_amplitude", device=local_rank, out=p_pow, want_power=True)
+                hdt = time.perf_counter() - t0
+                hs["spectra_pageable"] = {"value": nb * M * world / hdt, "ms_per_step": 1e3 * hdt, "targets": nb}
+                hs["unit"] = unit
+                hs["note"] = ("lk_ls_fast_peaks_batch (HOST pointers): chunked, double-buffered staging; H2D of chunk k+1 "
+                              "and D2H of chunk k-1 overlap the kernels of chunk k.  *_pinned: caller buffers from "
+                              "lk_host_alloc (direct async DMA); pageable: plain numpy arrays")
+                extra["host_to_host"] = hs
+                extra["value_host_to_host"] = hs["spectra_pinned"]["value"]
+                del h_pow
+            except Exception as e:   # reported, never fatal for the headline
+                extra["host_to_host"] = {"error": repr(e)}
+
+        # ---- BLS block of the metric
+        if not args.no_bls:
+            del d_pow
+            torch.cuda.empty_cache()
+            bsteps = max(1, min(args.steps, 2))
+            bres = run_bls(args.bls_targets, rank * args.bls_targets, bsteps, 1)
+            bval = bres["units_per_step"] * world * bsteps / bres["dt"]
+            blk = {"metric": bres["metric"], "value": bval, "unit": bres["unit"], "steps": bsteps, "warmup": 1,
+                   "ms_per_step": 1e3 * bres["dt"] / bsteps, "scaling": "weak",
+                   "config": {"workload": bres["workload"]}, "roofline": bres["roofline"]}
+            if cpu_base_bls is not None:
+                blk["cpu_baseline"] = cpu_base_bls
+                blk["speedup_vs_cpu_baseline"] = bval / cpu_base_bls["value"]
+            if ref is not None and "bls" in ref and rank == 0:
+                blk["accuracy"] = bls_accuracy(bres, ref["bls"])
+            extra["bls"] = blk
+    elif args.workload == "bls":
+        bres = run_bls(B, first, args.steps, args.warmup)
+        dt, kern_ms = bres["dt"], bres["kernel_ms"]
+        units_per_step = total_targets * args.periods
+        metric, unit, workload, roofline = bres["metric"], bres["unit"], bres["workload"], bres["roofline"]
+        if ref is not None and "bls" in ref and rank == 0:
+            extra["accuracy"] = bls_accuracy(bres, ref["bls"])
     elif args.workload == "pld":
         Bc, Nc, npix = args.cutouts, args.pld_cadences, 11
         P = npix * npix
@@ -350,8 +721,8 @@ def main():
         lce = np.sqrt((epx.astype(np.float64) ** 2).sum(axis=2))
         deg, nkn = 5, Nc // 50
         n_inner = nkn - deg - 1
-        knots = np.stack([np.concatenate([[t.min()], np.percentile(t, np.linspace(0, 100, n_inner + 2)[1:-1]), [t.max()]])
-                          for t in tt])
+        knots = np.stack([np.concatenate([[t_.min()], np.percentile(t_, np.linspace(0, 100, n_inner + 2)[1:-1]), [t_.max()]])
+                          for t_ in tt])
         K = _capi.pld_design_width(P, P, 3, 16, nkn)
         d_pix, d_lcf, d_t, d_kn = (torch.from_numpy(a).to(dev) for a in (pix, lcf, tt, knots))
         d_y, d_err = torch.from_numpy(lcf.astype(np.float64).ravel()).to(dev), torch.from_numpy(lce.ravel()).to(dev)
@@ -362,54 +733,55 @@ def main():
         d_model = torch.empty(Bc * Nc, dtype=torch.float64, device=dev)
         d_out = torch.empty(Bc * Nc, dtype=torch.uint8, device=dev)
         offp = np.arange(Bc + 1, dtype=np.int64) * Nc
-        lib = _capi.load_library()
-        import ctypes
-        vp = ctypes.c_void_p
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps + args.warmup)]
 
-        def step(k):
-            e0, e1 = ev[k]
+        def step(e0, e1):
             e0.record()
             _capi._check(lib.lk_pld_design_batch_dev(handle._h, Bc, Nc, P, P, vp(d_pix.data_ptr()), vp(d_pix.data_ptr()),
                                                      vp(d_lcf.data_ptr()), vp(d_t.data_ptr()), vp(d_kn.data_ptr()),
                                                      n_inner, 3, 16, nkn, deg, 1, K, vp(d_X.data_ptr()),
                                                      vp(d_ps.data_ptr()), vp(stream)))
-            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), K,
+            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(i64p), K,
                                                   vp(d_X.data_ptr()), vp(d_y.data_ptr()), vp(d_err.data_ptr()), None,
                                                   vp(d_mu.data_ptr()), vp(d_ps.data_ptr()), 5.0, 5, vp(d_w.data_ptr()),
                                                   vp(d_model.data_ptr()), vp(d_out.data_ptr()), vp(stream)))
             e1.record()
 
-        units_per_step = Bc
+        dt, kern_ms = timed(step, args.warmup, args.steps)
+        units_per_step = Bc * world
         gram_cols = [P, 136, 816, P]
-        pairs_per_step = float(Bc) * (2.0 * Nc * sum(c * c for c in gram_cols) + 5 * 2.0 * Nc * (K + 1) ** 2)  # MFMA flop
+        flop = float(Bc) * (2.0 * Nc * sum(c * c for c in gram_cols) + 5 * 2.0 * Nc * (K + 1) ** 2)  # MFMA flop
         metric, unit = "PLD cutouts/sec (design matrix + regression)", "cutouts/sec"
         workload = ("configs[4]: %d K2-like 11x11-pixel cutouts x %d cadences, 3rd-order design matrix (K=%d), "
                     "MFMA Gram per GPU" % (Bc, Nc, K))
+        ach = flop / (kern_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("pld"),
+                    "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
+                    "note": "algorithmic 2*N*P^2 flop per PCA Gram (P = 121, 136, 816, 121) + 5 x 2*N*(K+1)^2 "
+                            "for the regression, over the WHOLE step time (eigen-solver, projections, LU, "
+                            "clipping included), against the fp64 MFMA dense peak"}
         B, N = Bc, Nc
     elif args.workload == "flatten":
-        t, y, dy, off = synth.ls_batch(6, B, N, first_index=rank * B)
+        t, y, dy, off = synth.ls_batch(6, B, N, first_index=first)
         d_t, d_y = torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev)
         d_tr = torch.empty_like(d_y)
-        lib = _capi.load_library()
-        import ctypes
-        vp = ctypes.c_void_p
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps + args.warmup)]
 
-        def step(k):
-            e0, e1 = ev[k]
+        def step(e0, e1):
             e0.record()
-            _capi._check(lib.lk_savgol_trend_batch_dev(handle._h, B, off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+            _capi._check(lib.lk_savgol_trend_batch_dev(handle._h, B, off.ctypes.data_as(i64p),
                                                        vp(d_t.data_ptr()), vp(d_y.data_ptr()), None, 401, 2, 5.0, 3, 3.0,
                                                        vp(d_tr.data_ptr()), None, vp(stream)))
             e1.record()
 
-        units_per_step = int(off[-1])
-        pairs_per_step = float(off[-1])
+        dt, kern_ms = timed(step, args.warmup, args.steps)
+        units_per_step = int(off[-1]) * world
         metric, unit = "flatten cadences/sec (window 401, niters 3)", "cadences/sec"
         workload = "flatten: %d light curves x %d cadences, window 401, polyorder 2, niters 3 per GPU" % (B, N)
+        algo = 24.0 * float(off[-1])
+        roofline = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic_all.get("flatten"), "kernel": "flatten_kernel", "kernel_ms_per_step": kern_ms,
+                    "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
     elif args.workload == "regress":
         Bc, Nc, K = args.cutouts, args.pld_cadences, args.regressors
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -424,62 +796,61 @@ def main():
         d_model = torch.empty(Bc * Nc, dtype=torch.float64, device=dev)
         d_out = torch.empty(Bc * Nc, dtype=torch.uint8, device=dev)
         offp = np.arange(Bc + 1, dtype=np.int64) * Nc
-        lib = _capi.load_library()
-        import ctypes
-        vp = ctypes.c_void_p
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps + args.warmup)]
 
-        def step(k):
-            e0, e1 = ev[k]
+        def step(e0, e1):
             e0.record()
-            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), K,
+            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(i64p), K,
                                                   vp(d_X.data_ptr()), vp(d_y.data_ptr()), vp(d_err.data_ptr()), None,
                                                   vp(d_mu.data_ptr()), vp(d_ps.data_ptr()), 5.0, 5, vp(d_w.data_ptr()),
                                                   vp(d_model.data_ptr()), vp(d_out.data_ptr()), vp(stream)))
             e1.record()
 
-        off = offp
-        units_per_step = Bc
-        pairs_per_step = float(Bc) * 5 * 2.0 * Nc * (K + 1) ** 2   # Gram flop over the 5 clip iterations
+        dt, kern_ms = timed(step, args.warmup, args.steps)
+        units_per_step = Bc * world
+        flop = float(Bc) * 5 * 2.0 * Nc * (K + 1) ** 2   # Gram flop over the 5 clip iterations
         metric, unit = "RegressionCorrector fits/sec (N=%d, K=%d, 5 sigma-clip iterations)" % (Nc, K), "fits/sec"
         workload = "configs[4] regression stage: %d fits, N=%d cadences, K=%d regressors per GPU" % (Bc, Nc, K)
+        ach = flop / (kern_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                    "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
+                    "note": "algorithmic 2*N*(K+1)^2 flop per Gram build x 5 sigma-clip iterations (SURVEY.md "
+                            "8(d)); the step also runs 5 LU solves, 5 model products and 5 sigma-clips per fit; "
+                            "X (N*K*8 B per fit) is re-read each iteration"}
         B, N = Bc, Nc
     elif args.workload == "lschi2":
-        t, y, dy, off = synth.ls_batch(1, B, N, first_index=rank * B)
+        t, y, dy, off = synth.ls_batch(1, B, N, first_index=first)
         for b in range(B):
             t[off[b]:off[b + 1]] -= t[off[b]]
         d_t, d_y = torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev)
         d_p = torch.empty((B, M), dtype=torch.float64, device=dev)
         df = 360.0 / M
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps + args.warmup)]
 
-        def step(k):
-            e0, e1 = ev[k]
+        def step(e0, e1):
             e0.record()
             _capi.ls_power_batch_dev(handle, B, off, d_t.data_ptr(), d_y.data_ptr(), 0, 0, df, df, M, True, True,
                                      "lk_amplitude", 0, d_p.data_ptr(), stream, nterms=args.nterms)
             e1.record()
 
-        units_per_step = B * M
-        pairs_per_step = float(off[-1]) * M
+        dt, kern_ms = timed(step, args.warmup, args.steps)
+        units_per_step = B * M * world
         metric, unit = "frequencies*targets/sec (Lomb-Scargle, nterms=%d, exact chi2)" % args.nterms, "frequencies*targets/sec"
         workload = "%d targets x %d cadences x %d frequencies, nterms=%d multi-term Lomb-Scargle per GPU" % (B, N, M, args.nterms)
+        fl = 2.0 * (4 + 4 * (2 * args.nterms - 1) + 6 * args.nterms) * float(off[-1]) * M
+        roofline = {"bound": "valu", "achieved": fl / (kern_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": fl / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                    "traffic": None, "kernel": "ls_chi2_grid_kernel<%d>" % args.nterms, "kernel_ms_per_step": kern_ms,
+                    "note": "4 + 4(2n-1) + 6n FMAs per (cadence, frequency) pair (phasor recurrence, Chebyshev "
+                            "harmonics, 6n accumulates), n = nterms"}
     elif args.workload == "pgsmooth":
         from lightkurve_amd.periodogram import _logmedian_windows
         f = (360.0 / M) * (1 + np.arange(M))
         tabs = [np.ascontiguousarray(a, dtype=np.int32) for a in _logmedian_windows(f, 0.01)]
         d_p = torch.rand((B, M), dtype=torch.float64, device=dev)
         d_o = torch.empty_like(d_p)
-        lib = _capi.load_library()
-        import ctypes
-        vp, i32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps + args.warmup)]
+        i32p = ctypes.POINTER(ctypes.c_int32)
 
-        def step(k):
-            e0, e1 = ev[k]
+        def step(e0, e1):
             e0.record()
             _capi._check(lib.lk_pg_logmedian_batch_dev(handle._h, B, M, vp(d_p.data_ptr()), int(tabs[0].size),
                                                        tabs[0].ctypes.data_as(i32p), tabs[1].ctypes.data_as(i32p),
@@ -487,232 +858,71 @@ def main():
                                                        (8.0 / 9.0) ** 3, vp(d_o.data_ptr()), vp(stream)))
             e1.record()
 
-        off = np.array([0, B * M])
-        units_per_step = B * M
-        pairs_per_step = float(B) * float(np.sum(tabs[1] - tabs[0]))   # window memberships = values the medians look at
+        dt, kern_ms = timed(step, args.warmup, args.steps)
+        units_per_step = B * M * world
+        members = float(B) * float(np.sum(tabs[1] - tabs[0]))   # window memberships = values the medians look at
         metric, unit = "frequencies*targets/sec (Periodogram.smooth logmedian, filter_width 0.01)", "frequencies*targets/sec"
         workload = "%d periodograms x %d frequencies, logmedian smoothing (%d windows) per GPU" % (B, M, tabs[0].size)
-    elif args.workload == "fold":
-        t, y, dy, off = synth.ls_batch(6, B, N, first_index=rank * B)
+        algo = 16.0 * B * M
+        roofline = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "pg_window_median_kernel (+pg_window_average_kernel)", "kernel_ms_per_step": kern_ms,
+                    "note": "algorithmic 16 B per frequency (power in, smoothed out); every value sits in ~4 "
+                            "overlapping windows and each window median is an 8-pass radix select over its "
+                            "members (%.3g member reads per step, served by L2)" % members}
+    else:   # fold
+        t, y, dy, off = synth.ls_batch(6, B, N, first_index=first)
         d_t, d_y, d_e = (torch.from_numpy(a).to(dev) for a in (t, y, dy))
         d_ph, d_fy, d_fe = torch.empty_like(d_t), torch.empty_like(d_t), torch.empty_like(d_t)
         d_ord = torch.empty(len(t), dtype=torch.int64, device=dev)
         period = np.linspace(0.7, 9.0, B)
         epoch = np.array([t[off[b]] for b in range(B)])
         wrap = period / 2
-        lib = _capi.load_library()
-        import ctypes
-        vp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
+        dp = ctypes.POINTER(ctypes.c_double)
         cin = (vp * 2)(d_y.data_ptr(), d_e.data_ptr())
         cout = (vp * 2)(d_fy.data_ptr(), d_fe.data_ptr())
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps + args.warmup)]
 
-        def step(k):
-            e0, e1 = ev[k]
+        def step(e0, e1):
             e0.record()
-            _capi._check(lib.lk_fold_batch_dev(handle._h, B, off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+            _capi._check(lib.lk_fold_batch_dev(handle._h, B, off.ctypes.data_as(i64p),
                                                vp(d_t.data_ptr()), period.ctypes.data_as(dp), epoch.ctypes.data_as(dp), 0.0,
                                                wrap.ctypes.data_as(dp), 0, 2, cin, cout, vp(d_ph.data_ptr()),
                                                vp(d_ord.data_ptr()), vp(stream)))
             e1.record()
 
-        units_per_step = int(off[-1])
-        pairs_per_step = float(off[-1])
+        dt, kern_ms = timed(step, args.warmup, args.steps)
+        units_per_step = int(off[-1]) * world
         metric, unit = "fold cadences/sec (phase + stable sort + 2 gathered columns)", "cadences/sec"
         workload = "fold: %d light curves x %d cadences per GPU" % (B, N)
-    else:
-        t, y, dy, off = synth.bls_batch(3, B, N, first_index=rank * B)
-        ivar = 1.0 / dy ** 2
-        for b in range(B):
-            s = slice(off[b], off[b + 1])
-            t[s] -= t[s].min()
-            y[s] -= np.median(y[s])
-        period, duration = synth.bls_grid(args.periods, args.durations)
-        d_t, d_y, d_w = (torch.from_numpy(a).to(dev) for a in (t, y, ivar))
-        d_per = torch.from_numpy(period).to(dev)
-        d_out = torch.empty((7, B, len(period)), dtype=torch.float64, device=dev)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps + args.warmup)]
-
-        def step(k):
-            e0, e1 = ev[k]
-            e0.record()
-            _capi.bls_batch_dev(handle, B, off, d_t.data_ptr(), d_y.data_ptr(), d_w.data_ptr(), period,
-                                d_per.data_ptr(), duration, 10, True, d_out.data_ptr(), stream)
-            e1.record()
-
-        units_per_step = B * len(period)
-        nb = np.ceil(period / (duration.min() / 10)) + 10
-        durb = np.unique(np.round(duration / (duration.min() / 10)))
-        cand = float(np.sum(np.maximum(nb[:, None] - durb[None, :] + 1, 0)))
-        pairs_per_step = cand * B     # (start bin, duration) candidates
-        metric, unit = "BLS periods*targets/sec", "periods*targets/sec"
-        workload = ("configs[3]: %d targets x %d cadences, %d periods x %d durations BLS per GPU"
-                    % (B, N, len(period), len(duration)))
-
-    def sync():
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for k in range(args.warmup):
-        step(k)
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kern_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.warmup, args.warmup + args.steps)]))
-    second = None
-    if args.workload == "ls" and args.ls_method == "both":
-        # the other Lomb-Scargle method, measured the same way (W warmup + K timed steps, barrier + sync, max over ranks)
-        other = "exact" if headline == "fast" else "fast"
-        k0 = args.warmup + args.steps
-        for k in range(k0, k0 + args.warmup):
-            ls_step(k, other)
-        sync()
-        t1 = time.perf_counter()
-        for k in range(k0 + args.warmup, k0 + args.warmup + args.steps):
-            ls_step(k, other)
-        sync()
-        dt2 = time.perf_counter() - t1
-        if dist_on:
-            tt = torch.tensor([dt2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt2 = float(tt.item())
-        kms2 = float(np.mean([ev[k][0].elapsed_time(ev[k][1])
-                              for k in range(k0 + args.warmup, k0 + args.warmup + args.steps)]))
-        second = (other, dt2, kms2)
+        algo = 72.0 * float(off[-1])
+        roofline = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "fold_kernel (+2 fold_gather_kernel)", "kernel_ms_per_step": kern_ms,
+                    "note": "algorithmic 72 B per cadence (t in, phase + order out, two columns in and out + "
+                            "the order read per gather); the sort itself runs in LDS tiles / an L2-resident slab"}
 
     if rank == 0:
-        value = units_per_step * world * args.steps / dt
+        value = units_per_step * args.steps / dt
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "targets_per_gpu": B, "cadences": N,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "targets_per_gpu": B if not strong else None,
+                       "targets_total": total_targets, "cadences": N,
                        "parallelism": "targets sharded over %d rank(s), no data-path collective%s"
                                       % (world, ("; RCCL all-gather of %s each step" % (
                                           "the per-target (max power, argmax)" if args.gather == "summary" else
                                           "the full spectra, overlapped with compute"))
                                          if world > 1 and args.workload == "ls" and args.gather != "none" else "")},
+            "roofline": roofline,
         }
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath))
-                if args.workload != "ls":
-                    traffic = traffic.get(args.workload)
-            except Exception:
-                traffic = None
-        def ls_roofline(method, kms):
-            if method == "fast":
-                nfft = 1 << int(np.ceil(np.log2(5 * M)))
-                m2 = int(np.log2(nfft)) // 2
-                n2 = 1 << m2
-                # rows of the Nfft = N1 x N2 grid that can hold samples (what the spreader writes and step 1 reads)
-                used = 0.0
-                for b in range(B):
-                    span = (t[off[b + 1] - 1] - t[off[b]]) * nfft * df
-                    used += 2 * min(nfft, (int((span + 4) / n2) + 1) * n2) + min(nfft, (int((2 * span + 4) / n2) + 1) * n2)
-                algo = (B * (3 * nfft * 16.0 * 2 + 3 * M * 16.0 * 2 + 8.0 * M) + used * 16.0 * 2 + 16.0 * float(off[-1]))
-                return {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (traffic or {}).get("ls_fast")
-                        if isinstance(traffic, dict) else None,
-                        "kernel": "fft_cols_reg_kernel + fft_rows_reg_kernel (+ spreader, epilogue): whole step",
-                        "kernel_ms_per_step": kms, "algorithmic_bytes_per_step": algo,
-                        "note": "algorithmic bytes per target: 3 complex grids of Nfft=%d written by FFT step 1 and read by "
-                                "step 2 (2 x 16 B x Nfft each), the sample-bearing rows written by the spreader and read by "
-                                "step 1, 3 spectra of M written + read, 16 B/cadence in, 8 B/frequency out" % nfft}
-            flops = 16.0 * pairs_per_step
-            ach = flops / (kms * 1e-3) / 1e12
-            algo_bytes = 16.0 * float(off[-1]) + 8.0 * B * M
-            return {"bound": "valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": (traffic or {}).get("ls") if isinstance(traffic, dict)
-                    else traffic, "kernel": "ls_grid_kernel<16> (+ls_prep_kernel)", "kernel_ms_per_step": kms,
-                    "note": "fp64 direct trig sums: 16 flop (8 v_fma_f64) per (cadence, frequency) pair; arithmetic "
-                            "intensity ~3e4 flop/B so the fp64 VECTOR pipe binds (peak == fp64 MFMA dense peak), not HBM",
-                    "hbm": {"achieved": algo_bytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "algorithmic_bytes_per_step": algo_bytes}}
-
-        if args.workload == "ls":
-            out["roofline"] = ls_roofline(headline, kern_ms)
-            out["config"]["ls_method"] = headline
-            if second is not None:
-                other, dt2, kms2 = second
-                out["other_method"] = {"ls_method": other, "value": units_per_step * world * args.steps / dt2,
-                                       "unit": unit, "ms_per_step": 1e3 * dt2 / args.steps,
-                                       "roofline": ls_roofline(other, kms2),
-                                       "note": "same workload, same timing protocol; 'exact' = the direct-sum kernel "
-                                               "(matches the reference's slow/cython/chi2 to 1e-9), 'fast' = the reference's "
-                                               "default algorithm (matches lightkurve's default output to 1e-9)"}
-        elif args.workload == "pld":
-            ach = pairs_per_step / (kern_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                               "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
-                               "note": "algorithmic 2*N*P^2 flop per PCA Gram (P = 121, 136, 816, 121) + 5 x 2*N*(K+1)^2 "
-                                       "for the regression, over the WHOLE step time (eigen-solver, projections, LU, "
-                                       "clipping included), against the fp64 MFMA dense peak"}
-        elif args.workload == "flatten":
-            algo = 24.0 * pairs_per_step
-            out["roofline"] = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "flatten_kernel", "kernel_ms_per_step": kern_ms,
-                               "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
-        elif args.workload == "regress":
-            ach = pairs_per_step / (kern_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
-                               "note": "algorithmic 2*N*(K+1)^2 flop per Gram build x 5 sigma-clip iterations (SURVEY.md "
-                                       "8(d)); the step also runs 5 LU solves, 5 model products and 5 sigma-clips per fit; "
-                                       "X (N*K*8 B per fit) is re-read each iteration"}
-        elif args.workload == "lschi2":
-            fl = 2.0 * (4 + 4 * (2 * args.nterms - 1) + 6 * args.nterms) * pairs_per_step
-            out["roofline"] = {"bound": "valu", "achieved": fl / (kern_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": fl / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                               "traffic": None, "kernel": "ls_chi2_grid_kernel<%d>" % args.nterms,
-                               "kernel_ms_per_step": kern_ms,
-                               "note": "4 + 4(2n-1) + 6n FMAs per (cadence, frequency) pair (phasor recurrence, Chebyshev "
-                                       "harmonics, 6n accumulates), n = nterms"}
-        elif args.workload == "pgsmooth":
-            algo = 16.0 * units_per_step
-            out["roofline"] = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "pg_window_median_kernel (+pg_window_average_kernel)", "kernel_ms_per_step": kern_ms,
-                               "note": "algorithmic 16 B per frequency (power in, smoothed out); every value sits in ~4 "
-                                       "overlapping windows and each window median is an 8-pass radix select over its "
-                                       "members (%.3g member reads per step, served by L2)" % pairs_per_step}
-        elif args.workload == "fold":
-            algo = 72.0 * pairs_per_step
-            out["roofline"] = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "fold_kernel (+2 fold_gather_kernel)", "kernel_ms_per_step": kern_ms,
-                               "note": "algorithmic 72 B per cadence (t in, phase + order out, two columns in and out + "
-                                       "the order read per gather); the sort itself runs in LDS tiles / an L2-resident slab"}
-        else:
-            out["roofline"] = {
-                "bound": "valu", "achieved": 12.0 * pairs_per_step / (kern_ms * 1e-3) / 1e12,
-                "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": 12.0 * pairs_per_step / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                "traffic": traffic, "kernel": "bls_kernel", "kernel_ms_per_step": kern_ms,
-                "note": "algorithmic 12 flop per (start bin, duration) candidate (SURVEY.md §8(d)); the bit-exact "
-                        "kernel skips 80-95 % of the candidates with a rigorous growth bound, so this is an equivalent rate",
-            }
+        if "config_ls_method" in extra:
+            out["config"]["ls_method"] = extra.pop("config_ls_method")
+        out.update(extra)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
             out["speedup_vs_cpu_baseline"] = value / cpu_base["value"]
-        print(json.dumps(out))
+        print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)))
     if dist_on:
         dist.destroy_process_group()
 

@@ -45,6 +45,7 @@
 #ifndef LKHIP_H
 #define LKHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -161,6 +162,29 @@ int lk_ls_fast_batch(lk_handle *h, int B, const int64_t *n_off, const double *t,
 int lk_ls_fast_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
                          const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
                          int normalization, const double *scale, int oversampling, double *power, void *stream);
+
+/* The same method followed by Periodogram.max_power / frequency_at_max_power (periodogram.py:127-140): per target
+ * nanmax and nanargmax of the power row (first maximum wins; all-NaN row -> (nan, -1)).
+ *
+ * lk_ls_fast_peaks_batch (HOST pointers) is software-pipelined over chunks of targets: the H2D copy of chunk k+1,
+ * the kernels of chunk k and the D2H copy of chunk k-1 run on three streams over double-buffered device memory.
+ * Caller buffers that are pinned (lk_host_alloc, hipHostMalloc, hipHostRegister) are DMA'd directly; pageable
+ * buffers go through the HIP runtime's staging.  power may be NULL (peaks only — the B x M spectra never cross PCIe);
+ * max_power / argmax may both be NULL (spectra only: this is what lk_ls_fast_batch does).
+ * lk_ls_fast_peaks_batch_dev: device pointers, power required, max_power / argmax nullable together. */
+int lk_ls_fast_peaks_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y,
+                           const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                           int normalization, const double *scale, int oversampling, double *power,
+                           double *max_power, int64_t *argmax);
+int lk_ls_fast_peaks_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                               const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                               int normalization, const double *scale, int oversampling, double *power,
+                               double *max_power, int64_t *argmax, void *stream);
+
+/* Pinned (page-locked) host memory for the host-pointer entry points: numpy arrays built over it are copied by DMA
+ * without a staging pass.  Any host pointer is accepted everywhere; pinned ones are simply faster. */
+int lk_host_alloc(void **ptr, size_t bytes);
+int lk_host_free(void *ptr);
 
 /* ---- nanmax / nanargmax over each row of a B x M float64 matrix (first maximum wins) ---------------- */
 int lk_argmax_batch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out);

@@ -56,6 +56,14 @@ SIGNATURES = [
     ("lk_ls_fast_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
+    ("lk_ls_fast_peaks_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int, _c_dp, _c_dp, _c_ip]),
+    ("lk_ls_fast_peaks_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    ("lk_host_alloc", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    ("lk_host_free", ctypes.c_int, [_vp]),
     ("lk_fold_batch", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, _c_dp, ctypes.c_int, ctypes.c_int,
       ctypes.POINTER(_c_dp), ctypes.POINTER(_c_dp), _c_dp, _c_ip]),
@@ -257,6 +265,62 @@ def ls_fast_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, f0, df, M, fi
                                      _vp(dy_ptr or None), float(f0), float(df), int(M), int(bool(fit_mean)),
                                      int(bool(center_data)), NORM[normalization], _vp(scale_ptr or None),
                                      int(oversampling), _vp(power_ptr), _vp(stream or None)))
+
+
+def ls_fast_peaks_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, dy_ptr, f0, df, M, fit_mean, center_data,
+                            normalization, scale_ptr, oversampling, power_ptr, max_ptr, arg_ptr, stream=0):
+    """lk_ls_fast_peaks_batch_dev: ls_method='fast' + per-target (nanmax, nanargmax), all device pointers."""
+    n_off_host = np.ascontiguousarray(n_off_host, dtype=np.int64)
+    _check(_lib.lk_ls_fast_peaks_batch_dev(handle._h, int(B), _ptr(n_off_host, _c_ip), _vp(t_ptr), _vp(y_ptr),
+                                           _vp(dy_ptr or None), float(f0), float(df), int(M), int(bool(fit_mean)),
+                                           int(bool(center_data)), NORM[normalization], _vp(scale_ptr or None),
+                                           int(oversampling), _vp(power_ptr), _vp(max_ptr or None), _vp(arg_ptr or None),
+                                           _vp(stream or None)))
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array over page-locked host memory (lk_host_alloc): the host-pointer entry points DMA such buffers
+    directly instead of staging them.  Freed when the array (and every view of it) is garbage collected."""
+    import weakref
+    load_library()
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    ptr = _vp()
+    _check(_lib.lk_host_alloc(ctypes.byref(ptr), max(nbytes, 1)))
+    buf = (ctypes.c_char * max(nbytes, 1)).from_address(ptr.value)
+    weakref.finalize(buf, _lib.lk_host_free, _vp(ptr.value))
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+
+def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True,
+                        normalization="psd", scale=None, oversampling=5, device=0, out=None, want_power=True,
+                        want_peaks=True):
+    """ls_method='fast' for B ragged targets through the pipelined host-pointer entry point.
+    Returns (power[B, M] or None, max_power[B] or None, argmax[B] or None).  ``out``: preallocated float64[B, M]
+    (e.g. from ``pinned_empty``) to receive the spectra; ``want_power=False`` keeps the spectra on the device and
+    returns only the per-target peaks (Periodogram.max_power / nanargmax)."""
+    h = Handle.get(device)
+    t, y = _f64(t), _f64(y)
+    n_off = _offsets(n_off, t.size)
+    if y.shape != t.shape:
+        raise ValueError("t and y must have the same length")
+    dy = None if dy is None else _f64(np.broadcast_to(dy, t.shape))
+    B, M = n_off.size - 1, int(M)
+    scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
+    power = None
+    if want_power:
+        power = out if out is not None else np.empty((B, M), dtype=np.float64)
+        if power.shape != (B, M) or power.dtype != np.float64 or not power.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape (B, M)")
+    if not want_power and not want_peaks:
+        raise ValueError("nothing requested")
+    mx = np.empty(B, dtype=np.float64) if want_peaks else None
+    am = np.empty(B, dtype=np.int64) if want_peaks else None
+    _check(_lib.lk_ls_fast_peaks_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), float(f0), float(df), M,
+                                       int(bool(fit_mean)), int(bool(center_data)), NORM[normalization], _ptr(scale),
+                                       int(oversampling), _ptr(power), _ptr(mx), _ptr(am, _c_ip)))
+    return power, mx, am
 
 
 # --------------------------------------------------------------------------------------------- Periodogram.smooth

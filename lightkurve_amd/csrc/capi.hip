@@ -117,6 +117,13 @@ void lk_destroy(lk_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     h->stage.release();
+    for (hipStream_t st : {h->s_in, h->s_comp, h->s_out, h->s_aux})
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t *arr : {h->ev_in, h->ev_comp, h->ev_out})
+        for (int i = 0; i < 2; ++i)
+            if (arr[i]) (void)hipEventDestroy(arr[i]);
+    for (int i = 0; i < 4; ++i)
+        if (h->ev_aux[i]) (void)hipEventDestroy(h->ev_aux[i]);
     h->ws.release();
     h->staging.release();
     delete h;
@@ -331,8 +338,9 @@ int lk_ls_fastchi2_batch(lk_handle *h, int B, const int64_t *n_off, const double
 int lk_ls_fast_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
                      double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
                      const double *scale, int oversampling, double *power) {
-    return lk_ls_fastchi2_batch(h, B, n_off, t, y, dy, f0, df, M, 1, fit_mean, center_data, normalization, scale,
-                                oversampling, power);
+    // chunked, double-buffered staging (lk_ls_fast_peaks_batch below); the multi-term path keeps the simple one
+    return lk_ls_fast_peaks_batch(h, B, n_off, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
+                                  oversampling, power, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ argmax
@@ -536,6 +544,157 @@ int lk_pld_design_batch(lk_handle *h, int B, int N, int P, int Pb, const float *
     LK_HIP_CHECK(hipMemcpy(X, dX, xb, hipMemcpyDeviceToHost));
     LK_HIP_CHECK(hipMemcpy(prior_sigma, ds, sb, hipMemcpyDeviceToHost));
     return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pinned host memory
+int lk_host_alloc(void **ptr, size_t bytes) {
+    LK_REQUIRE(ptr != nullptr, "ptr is NULL");
+    *ptr = nullptr;
+    LK_HIP_CHECK(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return LK_OK;
+}
+
+int lk_host_free(void *ptr) {
+    if (ptr) LK_HIP_CHECK(hipHostFree(ptr));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LS 'fast' + peaks
+int lk_ls_fast_peaks_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
+                               const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                               int normalization, const double *scale, int oversampling, double *power,
+                               double *max_power, int64_t *argmax, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(power != nullptr, "power must be non-NULL for the device flavour (the spectra stay in HBM anyway)");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    int rc = lk::lsfast_launch(h, B, n_off_host, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
+                               oversampling, power, static_cast<hipStream_t>(stream));
+    if (rc || B == 0 || M == 0 || (!max_power && !argmax)) return rc;
+    LK_REQUIRE(max_power && argmax, "max_power and argmax must both be given (or both NULL)");
+    return lk::argmax_launch(h, B, M, power, max_power, argmax, static_cast<hipStream_t>(stream));
+}
+
+extern "C++" {
+static int pipeline_init(lk_handle *h) {
+    if (h->s_in) return LK_OK;
+    LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_comp, hipStreamNonBlocking));
+    LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
+        LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_comp[i], hipEventDisableTiming));
+        LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_out[i], hipEventDisableTiming));
+    }
+    return LK_OK;
+}
+}  // extern "C++"
+
+// Host-pointer flavour, software-pipelined over chunks of targets: the H2D copy of chunk k+1 (stream s_in), the
+// kernels of chunk k (s_comp) and the D2H copy of chunk k-1 (s_out) overlap; both device buffers are double
+// buffered and ordered by events.  Caller buffers that are pinned (lk_host_alloc / hipHostMalloc / hipHostRegister)
+// are DMA'd directly and the whole loop is asynchronous; pageable buffers go through the runtime's own staging
+// (the host blocks inside each copy, the kernels of the next chunk are already queued).  power may be NULL
+// (peaks only: the 8 B x B x M of spectra never cross PCIe); max_power / argmax may both be NULL.
+int lk_ls_fast_peaks_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y,
+                           const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                           int normalization, const double *scale, int oversampling, double *power,
+                           double *max_power, int64_t *argmax) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    LK_REQUIRE(M >= 0, "M must be >= 0");
+    if (B == 0 || M == 0) return LK_OK;
+    LK_REQUIRE(t && y, "t, y must be non-NULL");
+    LK_REQUIRE(power || (max_power && argmax), "nothing to compute: power, max_power and argmax are all NULL");
+    LK_REQUIRE((max_power == nullptr) == (argmax == nullptr), "max_power and argmax must both be given (or both NULL)");
+    LK_REQUIRE(n_off[0] == 0, "n_off[0] must be 0");
+    for (int b = 0; b < B; ++b) LK_REQUIRE(n_off[b + 1] >= n_off[b], "n_off must be non-decreasing");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    int rc = pipeline_init(h);
+    if (rc) return rc;
+    // chunk = as many targets as give ~64 MiB of spectra (large enough to amortise launches, small enough to pipeline)
+    size_t chunk_mb = 64;
+    if (const char *e = getenv("LK_HOST_CHUNK_MB")) chunk_mb = (size_t)std::max(1, atoi(e));
+    const int C = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, (chunk_mb << 20) / ((size_t)M * 8)));
+    const int nchunks = (B + C - 1) / C;
+    size_t in_max = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        const int b0 = k * C, b1 = std::min(B, b0 + C);
+        in_max = std::max(in_max, (size_t)(n_off[b1] - n_off[b0]));
+    }
+    const int narr = dy ? 3 : 2;
+    const size_t in_bytes = in_max * 8, pow_bytes = (size_t)C * (size_t)M * 8;
+    h->staging.reset();
+    rc = h->staging.reserve(2 * narr * (in_bytes + 256) + 2 * (pow_bytes + 256) + 3 * ((size_t)B * 8 + 256) + 4096);
+    if (rc) return rc;
+    double *d_in[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    double *d_pow[2];
+    for (int s = 0; s < 2; ++s) {
+        for (int a = 0; a < narr; ++a) d_in[s][a] = (double *)h->staging.alloc(in_bytes);
+        d_pow[s] = (double *)h->staging.alloc(pow_bytes);
+    }
+    double *d_scale = scale ? (double *)h->staging.alloc((size_t)B * 8) : nullptr;
+    double *d_max = max_power ? (double *)h->staging.alloc((size_t)B * 8) : nullptr;
+    int64_t *d_arg = argmax ? (int64_t *)h->staging.alloc((size_t)B * 8) : nullptr;
+    if (scale) LK_HIP_CHECK(hipMemcpyAsync(d_scale, scale, (size_t)B * 8, hipMemcpyHostToDevice, h->s_in));
+    std::vector<int64_t> offc((size_t)C + 1);
+
+    auto enqueue_in = [&](int k) -> int {
+        const int s = k & 1, b0 = k * C, b1 = std::min(B, b0 + C);
+        const size_t lo = (size_t)n_off[b0], nbytes = (size_t)(n_off[b1] - n_off[b0]) * 8;
+        if (k >= 2) LK_HIP_CHECK(hipStreamWaitEvent(h->s_in, h->ev_comp[s], 0));  // kernels of chunk k-2 are done with d_in[s]
+        if (nbytes) {
+            LK_HIP_CHECK(hipMemcpyAsync(d_in[s][0], t + lo, nbytes, hipMemcpyHostToDevice, h->s_in));
+            LK_HIP_CHECK(hipMemcpyAsync(d_in[s][1], y + lo, nbytes, hipMemcpyHostToDevice, h->s_in));
+            if (dy) LK_HIP_CHECK(hipMemcpyAsync(d_in[s][2], dy + lo, nbytes, hipMemcpyHostToDevice, h->s_in));
+        }
+        LK_HIP_CHECK(hipEventRecord(h->ev_in[s], h->s_in));
+        return LK_OK;
+    };
+    auto enqueue_comp = [&](int k) -> int {
+        const int s = k & 1, b0 = k * C, b1 = std::min(B, b0 + C), nb = b1 - b0;
+        LK_HIP_CHECK(hipStreamWaitEvent(h->s_comp, h->ev_in[s], 0));
+        if (k >= 2 && power) LK_HIP_CHECK(hipStreamWaitEvent(h->s_comp, h->ev_out[s], 0));  // D2H of chunk k-2 has left d_pow[s]
+        for (int b = 0; b <= nb; ++b) offc[b] = n_off[b0 + b] - n_off[b0];
+        int r = lk::lsfast_launch(h, nb, offc.data(), d_in[s][0], d_in[s][1], dy ? d_in[s][2] : nullptr, f0, df, M,
+                                  fit_mean, center_data, normalization, d_scale ? d_scale + b0 : nullptr, oversampling,
+                                  d_pow[s], h->s_comp);
+        if (r) return r;
+        if (d_max) {
+            r = lk::argmax_launch(h, nb, M, d_pow[s], d_max + b0, d_arg + b0, h->s_comp);
+            if (r) return r;
+        }
+        LK_HIP_CHECK(hipEventRecord(h->ev_comp[s], h->s_comp));
+        return LK_OK;
+    };
+    auto enqueue_out = [&](int k) -> int {
+        if (!power) return LK_OK;
+        const int s = k & 1, b0 = k * C, b1 = std::min(B, b0 + C);
+        LK_HIP_CHECK(hipStreamWaitEvent(h->s_out, h->ev_comp[s], 0));
+        LK_HIP_CHECK(hipMemcpyAsync(power + (size_t)b0 * (size_t)M, d_pow[s], (size_t)(b1 - b0) * (size_t)M * 8,
+                                    hipMemcpyDeviceToHost, h->s_out));
+        LK_HIP_CHECK(hipEventRecord(h->ev_out[s], h->s_out));
+        return LK_OK;
+    };
+    // the pipeline: chunk k+1 is copied in and its kernels are queued BEFORE the copy-out of chunk k is issued, so a
+    // blocking (pageable) copy-out never leaves the GPU without queued work
+    if ((rc = enqueue_in(0)) || (rc = enqueue_comp(0))) goto fail;
+    for (int k = 0; k < nchunks; ++k) {
+        if (k + 1 < nchunks && ((rc = enqueue_in(k + 1)) || (rc = enqueue_comp(k + 1)))) goto fail;
+        if ((rc = enqueue_out(k))) goto fail;
+    }
+    if (d_max) {
+        LK_HIP_CHECK(hipMemcpyAsync(max_power, d_max, (size_t)B * 8, hipMemcpyDeviceToHost, h->s_comp));
+        LK_HIP_CHECK(hipMemcpyAsync(argmax, d_arg, (size_t)B * 8, hipMemcpyDeviceToHost, h->s_comp));
+    }
+    LK_HIP_CHECK(hipStreamSynchronize(h->s_in));
+    LK_HIP_CHECK(hipStreamSynchronize(h->s_comp));
+    LK_HIP_CHECK(hipStreamSynchronize(h->s_out));
+    return LK_OK;
+fail:
+    (void)hipStreamSynchronize(h->s_in);
+    (void)hipStreamSynchronize(h->s_comp);
+    (void)hipStreamSynchronize(h->s_out);
+    return rc;
 }
 
 }  // extern "C"

@@ -76,6 +76,12 @@ struct lk_handle {
     lk::HostStage stage;
     lk::Arena ws;        // kernel scratch (prepped per-cadence records, per-target stats)
     lk::Arena staging;   // device mirrors of host buffers for the *_batch (host pointer) entry points
+    // host-pointer pipeline (lk_ls_fast_peaks_batch): copy-in, compute and copy-out streams + the events that order
+    // the two halves of the double buffers; created on first use
+    hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    hipStream_t s_aux = nullptr;   // second compute stream of the LS 'fast' chunk pipeline (lsfast.hip)
+    hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // launchers implemented in the .hip files (device pointers, enqueue on stream, no sync)

@@ -1,10 +1,24 @@
-"""CPU baseline from the reference's REAL numerical dependency (bench infrastructure; runs under the conda
-interpreter that has astropy):  astropy.timeseries.LombScargle(...).power(frequency, method=...) exactly as
-lightkurve calls it (src/lightkurve/periodogram.py:961-964), or BoxLeastSquares(...).power(...) (:1161-1169),
-one process per core over a bounded sample of the bench workload.  Prints one JSON line.
+"""CPU baseline + accuracy reference from the reference's REAL numerical dependency (TEST/BENCH INFRASTRUCTURE; runs
+under the conda interpreter that has astropy; never imported by the product path).
 
-    LD_PRELOAD=<system libstdc++> PYTHONPATH=oracle/shims:. /opt/conda/bin/python3.9 -W ignore \\
-        oracle/astropy_baseline.py ls <n_targets> <N> <M> <procs> [method]
+    astropy.timeseries.LombScargle(time, flux, normalization="psd").power(frequency, method=...) exactly as lightkurve
+    calls it (src/lightkurve/periodogram.py:961-964) followed by its amplitude normalisation (:974-975), and
+    BoxLeastSquares(time, flux, dy).power(period, duration) (:1161-1169), one process per core.
+
+Two modes:
+
+    astropy_baseline.py ls  <n_targets> <N> <M> <procs> [method]         (rate only, inputs from lightkurve_amd.synth)
+    astropy_baseline.py bls <n_targets> <N> <n_periods> <n_dur> <procs>
+    astropy_baseline.py suite <workdir> <procs>
+
+``suite`` is what bench.py uses: the INPUT ARRAYS of the sampled bench targets are handed over as files
+(<workdir>/ls.npz: t, y, off, f0, df, M;  <workdir>/bls.npz: t, y, e, off, period, duration) so both sides
+provably see identical numbers, every job is timed (-> cpu_baseline rates), and the per-target results the
+BASELINE metric's accuracy columns need are written to <workdir>/result.json: max power and argmax for LS
+('fast' = the reference default; 'cython' = the exact method), and for BLS the argmax of power (best-period
+index), the max power and the period/duration/depth at the maximum.
+
+    LD_PRELOAD=<system libstdc++> PYTHONPATH=oracle/shims:. /opt/conda/bin/python3.9 -W ignore oracle/astropy_baseline.py ...
 """
 import json
 import multiprocessing as mp
@@ -16,6 +30,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+_G = {}   # arrays shared with the fork()ed workers
 
 
 def _ls_one(job):
@@ -39,8 +55,83 @@ def _bls_one(job):
     return float(np.max(r.power))
 
 
+def _suite_ls(job):
+    """(max amplitude power, nanargmax) of target b with astropy method `method` on the bench grid."""
+    from astropy.timeseries import LombScargle
+    b, method = job
+    d = _G["ls"]
+    s = slice(int(d["off"][b]), int(d["off"][b + 1]))
+    t, y = d["t"][s], d["y"][s]
+    f = float(d["f0"]) + float(d["df"]) * np.arange(int(d["M"]))
+    with np.errstate(all="ignore"):
+        p = LombScargle(t, y, normalization="psd").power(f, method=method)
+        p = np.sqrt(p) * np.sqrt(4.0 / len(t))
+    return float(np.nanmax(p)), int(np.nanargmax(p))
+
+
+def _suite_bls(b):
+    from astropy.timeseries import BoxLeastSquares
+    d = _G["bls"]
+    s = slice(int(d["off"][b]), int(d["off"][b + 1]))
+    r = BoxLeastSquares(d["t"][s], d["y"][s], d["e"][s]).power(d["period"], d["duration"])
+    k = int(np.argmax(r.power))
+    return (k, float(r.power[k]), float(r.period[k]), float(r.duration[k]), float(r.depth[k]),
+            float(r.transit_time[k]))
+
+
+def _warm(_):
+    """Imports + one tiny call of each astropy kernel in every worker (not timed)."""
+    from astropy.timeseries import BoxLeastSquares, LombScargle
+    t = np.linspace(0, 10, 200)
+    y = np.sin(t)
+    for m in ("fast", "cython"):
+        LombScargle(t, y, normalization="psd").power(0.05 + 0.01 * np.arange(300), method=m)
+    BoxLeastSquares(t, y, np.ones_like(t)).power(np.linspace(1, 3, 5), 0.2)
+    time.sleep(0.05)
+    return 0
+
+
+def _timed_map(pool, fn, jobs, procs):
+    pool.map(_warm, range(4 * procs), chunksize=1)
+    t0 = time.perf_counter()
+    out = pool.map(fn, jobs, chunksize=1)
+    return out, time.perf_counter() - t0
+
+
+def suite(workdir, procs):
+    import astropy
+    spec = json.load(open(os.path.join(workdir, "suite.json")))
+    res = {"astropy": astropy.__version__, "procs": procs}
+    if "ls" in spec:
+        _G["ls"] = dict(np.load(os.path.join(workdir, "ls.npz")))
+    if "bls" in spec:
+        _G["bls"] = dict(np.load(os.path.join(workdir, "bls.npz")))
+    with mp.get_context("fork").Pool(procs) as pool:
+        if "ls" in spec:
+            M = int(_G["ls"]["M"])
+            for method, n in (("fast", spec["ls"].get("n_fast", 0)), ("cython", spec["ls"].get("n_exact", 0))):
+                if n <= 0:
+                    continue
+                out, dt = _timed_map(pool, _suite_ls, [(b, method) for b in range(n)], procs)
+                res["ls_" + method] = {"n_targets": n, "seconds": dt, "units_per_s": n * M / dt,
+                                       "max_power": [o[0] for o in out], "argmax": [o[1] for o in out]}
+        if "bls" in spec and spec["bls"].get("n", 0) > 0:
+            n = spec["bls"]["n"]
+            out, dt = _timed_map(pool, _suite_bls, list(range(n)), procs)
+            res["bls"] = {"n_targets": n, "seconds": dt, "units_per_s": n * len(_G["bls"]["period"]) / dt,
+                          "argmax": [o[0] for o in out], "max_power": [o[1] for o in out],
+                          "period": [o[2] for o in out], "duration": [o[3] for o in out],
+                          "depth": [o[4] for o in out], "transit_time": [o[5] for o in out]}
+    json.dump(res, open(os.path.join(workdir, "result.json"), "w"))
+    print("BASELINE " + json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items()
+                                                                             if not isinstance(vv, list)})
+                                    for k, v in res.items()}))
+
+
 def main():
     kind = sys.argv[1]
+    if kind == "suite":
+        return suite(sys.argv[2], int(sys.argv[3]))
     if kind == "ls":
         n_targets, n, m, procs = (int(a) for a in sys.argv[2:6])
         method = sys.argv[6] if len(sys.argv) > 6 else "fast"

@@ -74,3 +74,20 @@ def test_sharded_map_gloo_world2(tmp_path):
     assert np.array_equal(r0["part"], ref[b[0]:b[1]]) and np.array_equal(r1["part"], ref[b[1]:b[2]])
     assert r0["seen"].tolist() == [b[1] - b[0]] * 2 and r1["seen"].tolist() == [b[2] - b[1]] * 2   # local work only
     assert 0 < b[1] < len(ns)
+
+
+def test_bench_gpus_flag_self_launches_ranks():
+    """`python bench.py --gpus 2` without WORLD_SIZE must really form a 2-rank group (the flag was dead).
+    --dry runs the launch / rendezvous / barrier / max-over-ranks skeleton on gloo without GPU work."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--total-targets", "11"],
+                       env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["dry"] is True
+    assert res["targets_total"] == 11 and res["scaling"] == "strong"      # 6 + 5 targets seen by the two ranks
