@@ -71,6 +71,9 @@ const char *lk_last_error(void);
 int lk_device_count(int *count);
 int lk_init(int device_id, lk_handle **out);
 void lk_destroy(lk_handle *h);
+/* Block until every kernel / copy issued through this handle's GPU has finished (hipDeviceSynchronize): for callers
+ * of the *_dev entry points that do not hold a HIP runtime of their own. */
+int lk_synchronize(lk_handle *h);
 /* bytes of device scratch currently held by the handle */
 int64_t lk_workspace_bytes(const lk_handle *h);
 

@@ -32,6 +32,7 @@ SIGNATURES = [
     ("lk_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     ("lk_destroy", None, [_vp]),
     ("lk_workspace_bytes", ctypes.c_int64, [_vp]),
+    ("lk_synchronize", ctypes.c_int, [_vp]),
     ("lk_ls_power_batch", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
       ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
@@ -168,6 +169,9 @@ class Handle:
         if self._h:
             _lib.lk_destroy(self._h)
             self._h = _vp()
+
+    def synchronize(self):
+        _check(_lib.lk_synchronize(self._h))
 
     def workspace_bytes(self):
         return int(_lib.lk_workspace_bytes(self._h))

@@ -160,4 +160,178 @@ __device__ double block_median(int n, long long count, Val val, Keep keep, unsig
     return (a + b) * 0.5;
 }
 
+// ------------------------------------------------------------------------------------------------ wave-level helpers
+// Workgroup sum with two barriers: 64-lane butterfly (DPP/shuffles), one LDS word per wave, lane-serial combine.
+// Fixed order, so deterministic; `sh` needs blockDim.x / 64 (+1) 64-bit words.
+__device__ __forceinline__ double block_sum_fast(double x, double *shd) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();  // shd may still be read by the previous user
+    if ((tid & 63) == 0) shd[tid >> 6] = x;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < nw; ++w) r += shd[w];
+    return r;
+}
+
+__device__ __forceinline__ long long block_count_fast(long long x, long long *shl) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((tid & 63) == 0) shl[tid >> 6] = x;
+    __syncthreads();
+    long long r = 0;
+    for (int w = 0; w < nw; ++w) r += shl[w];
+    return r;
+}
+
+// Exclusive prefix sum of one int per thread across the workgroup (two barriers).  total (same in all threads) via *tot.
+__device__ __forceinline__ int block_exscan_int(int x, int *shi, int *tot) {
+    const int tid = threadIdx.x, lane = tid & 63, nw = (blockDim.x + 63) >> 6;
+    int inc = x;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    __syncthreads();
+    if (lane == 63) shi[tid >> 6] = inc;
+    __syncthreads();
+    int base = 0, all = 0;
+    for (int w = 0; w < nw; ++w) {
+        const int c = shi[w];
+        if (w < (tid >> 6)) base += c;
+        all += c;
+    }
+    *tot = all;
+    return base + inc - x;
+}
+
+// ------------------------------------------------------------------------------------------------ sampled selection
+// k-th smallest of the kept values in about ONE pass over the data instead of the eight of block_select_kth
+// (Floyd-Rivest style): a strided sample of <= SEL_SAMPLE kept values is sorted in LDS, two pivots lo <= hi bracket
+// the wanted rank, one pass counts the values below lo / equal to lo / equal to hi and collects the ones strictly
+// between into `cand` (LDS, `cap` doubles); the answer is then found inside the candidates.  If the bracket misses
+// or overflows — heavy-tailed sample luck, adversarial order — the full radix select runs instead, so the result is
+// ALWAYS the exact order statistic.  count = number of kept values (> k).  Also serves rank k + 1 (for the median of
+// an even count) from the same pass: *next receives it when want_next.
+constexpr int SEL_SAMPLE = 1024;
+
+template <class Val, class Keep>
+__device__ double block_select_sampled(int n, long long count, long long k, Val val, Keep keep, unsigned long long *sh,
+                                       double *cand, int cap, bool want_next, double *next) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int *ictl = reinterpret_cast<int *>(sh + 200);  // [0] ncand, [1] sample size   (sh[0..199] are used by the callees)
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(cand);
+    auto fallback = [&]() -> double {
+        const double a = block_select_kth(n, k, val, keep, sh);
+        if (want_next) *next = (k + 1 < count) ? block_select_kth(n, k + 1, val, keep, sh) : a;
+        return a;
+    };
+    auto lds_val = [&](int i) { return cand[i]; };
+    auto lds_all = [&](int) { return true; };
+    if (cap < 2 * SEL_SAMPLE) return fallback();
+    if (count <= (long long)cap) {
+        // everything fits: collect once, select in LDS
+        if (tid == 0) ictl[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += nt)
+            if (keep(i)) cand[atomicAdd(&ictl[0], 1)] = val(i);
+        __syncthreads();
+        const int nc = ictl[0];
+        const double a = block_select_kth(nc, k, lds_val, lds_all, sh);
+        if (want_next) *next = (k + 1 < nc) ? block_select_kth(nc, k + 1, lds_val, lds_all, sh) : a;
+        return a;
+    }
+    // ---- strided sample -> keys[0..S), padded with +inf keys to a power of two, bitonic sort
+    const int S = SEL_SAMPLE;
+    for (int j = tid; j < S; j += nt) {
+        const int i = (int)(((long long)j * n) / S);
+        keys[j] = keep(i) ? f64_sortable(val(i)) : ~0ull;
+    }
+    __syncthreads();
+    for (int size = 2; size <= S; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int p = tid; p < S / 2; p += nt) {
+                const int lo_i = ((p / stride) * 2 * stride) + (p % stride), hi_i = lo_i + stride;
+                const bool up = (lo_i & size) == 0;
+                const unsigned long long a = keys[lo_i], b = keys[hi_i];
+                if ((a > b) == up) {
+                    keys[lo_i] = b;
+                    keys[hi_i] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // sample size = number of non-padding keys (the padding sorts to the end)
+    {
+        int c = 0;
+        for (int j = tid; j < S; j += nt) c += keys[j] != ~0ull ? 1 : 0;
+        const long long s_all = block_count_fast(c, reinterpret_cast<long long *>(sh));
+        if (s_all < 64) return fallback();  // (uniform: every thread sees the same s_all)
+        const double pos = ((double)k + 0.5) * (double)s_all / (double)count;
+        const int delta = (int)(1.5 * sqrt((double)s_all)) + 6;
+        const int r_lo = (int)pos - delta, r_hi = (int)pos + delta;
+        // pivots (registers, same in every thread): -inf / +inf when the bracket runs off the sample
+        const double lo = r_lo < 0 ? -INFINITY : f64_from_sortable(keys[r_lo]);
+        const double hi = r_hi >= (int)s_all ? INFINITY : f64_from_sortable(keys[r_hi]);
+        __syncthreads();  // the sample (aliasing cand) is dead from here on
+        if (tid == 0) ictl[0] = 0;
+        __syncthreads();
+        long long c_less = 0, c_eqlo = 0, c_eqhi = 0;
+        for (int i = tid; i < n; i += nt)
+            if (keep(i)) {
+                const double v = val(i);
+                if (v < lo)
+                    ++c_less;
+                else if (v == lo)
+                    ++c_eqlo;
+                else if (v < hi) {
+                    const int slot = atomicAdd(&ictl[0], 1);
+                    if (slot < cap) cand[slot] = v;
+                } else if (v == hi)
+                    ++c_eqhi;
+            }
+        const long long n_less = block_count_fast(c_less, reinterpret_cast<long long *>(sh));
+        const long long n_eqlo = block_count_fast(c_eqlo, reinterpret_cast<long long *>(sh));
+        const long long n_eqhi = block_count_fast(c_eqhi, reinterpret_cast<long long *>(sh));
+        __syncthreads();
+        const int nc = ictl[0];
+        if (nc > cap) return fallback();
+        // rank r (0-based among all kept) -> value, or "miss"
+        bool miss = false;
+        auto at_rank = [&](long long r) -> double {
+            long long q = r - n_less;
+            if (q < 0) {
+                miss = true;
+                return 0.0;
+            }
+            if (q < n_eqlo) return lo;
+            q -= n_eqlo;
+            if (q < nc) return block_select_kth(nc, q, lds_val, lds_all, sh);
+            q -= nc;
+            if (q < n_eqhi) return hi;
+            miss = true;
+            return 0.0;
+        };
+        // (every branch above depends only on workgroup-uniform values, so the barriers inside block_select_kth are safe)
+        const double a = at_rank(k);
+        double b = a;
+        if (!miss && want_next && k + 1 < count) b = at_rank(k + 1);
+        if (miss) return fallback();
+        if (want_next) *next = b;
+        return a;
+    }
+}
+
+// numpy.median of the kept values through block_select_sampled; NaN if none kept.
+template <class Val, class Keep>
+__device__ double block_median_sampled(int n, long long count, Val val, Keep keep, unsigned long long *sh, double *cand,
+                                       int cap) {
+    if (count <= 0) return __longlong_as_double(0x7ff8000000000000ll);
+    const long long k = (count - 1) / 2;
+    double nxt = 0.0;
+    const double a = block_select_sampled(n, count, k, val, keep, sh, cand, cap, (count & 1) == 0, &nxt);
+    return (count & 1) ? a : (a + nxt) * 0.5;
+}
+
 }  // namespace lk

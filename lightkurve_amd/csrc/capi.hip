@@ -124,9 +124,17 @@ void lk_destroy(lk_handle *h) {
             if (arr[i]) (void)hipEventDestroy(arr[i]);
     for (int i = 0; i < 4; ++i)
         if (h->ev_aux[i]) (void)hipEventDestroy(h->ev_aux[i]);
+    if (h->h_plan) (void)hipHostFree(h->h_plan);
     h->ws.release();
     h->staging.release();
     delete h;
+}
+
+int lk_synchronize(lk_handle *h) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipDeviceSynchronize());
+    return LK_OK;
 }
 
 int64_t lk_workspace_bytes(const lk_handle *h) { return h ? (int64_t)(h->ws.cap + h->staging.cap) : 0; }

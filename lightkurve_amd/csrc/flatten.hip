@@ -109,7 +109,8 @@ int savgol_design_host(int window, int polyorder, double *coeffs, double *edge) 
 }
 
 // ------------------------------------------------------------------------------------------------ device helpers
-// order-preserving compaction of {i < n : pred(i)} into out[]; returns the count (same in every thread)
+// order-preserving compaction of {i < n : pred(i)} into out[]; returns the count (same in every thread).
+// Every thread owns one contiguous chunk; the chunk counts are scanned with wave shuffles (two barriers in all).
 template <class Pred>
 __device__ int block_compact(int n, Pred pred, int *out, int *sh) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -117,31 +118,17 @@ __device__ int block_compact(int n, Pred pred, int *out, int *sh) {
     const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     int c = 0;
     for (int i = lo; i < hi; ++i) c += pred(i) ? 1 : 0;
-    sh[tid] = c;
-    __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan
-        const int v = tid >= off ? sh[tid - off] : 0;
-        __syncthreads();
-        sh[tid] += v;
-        __syncthreads();
-    }
-    const int total = sh[nt - 1];
-    int w = sh[tid] - c;
-    __syncthreads();
+    int total;
+    int w = block_exscan_int(c, sh, &total);
     for (int i = lo; i < hi; ++i)
         if (pred(i)) out[w++] = i;
     __syncthreads();
     return total;
 }
 
-// LDS plan (dynamic): sh[max(nt, 264)] 64-bit words | shi[nt] ints | fir[FIR_LDS + 2] doubles.  FIR_LDS = doubles of LDS
-// for a tile's inputs, FIR_TILE = FIR_LDS / 2 outputs per tile (window <= FIR_LDS - FIR_TILE + 1 takes the tiled path).
-
-struct FlattenScratch {  // per-target slab offsets are computed from N by the launcher
-    double *tm, *fm, *tr;
-    int *idx, *idx2, *segs;
-    uint8_t *mask, *mask1;
-};
+// LDS plan (dynamic): sh[max(nt, 264)] 64-bit words | fir[FIR_LDS + 2] doubles | shi[nt] ints.  FIR_LDS = doubles of LDS
+// for a tile's inputs, FIR_TILE = FIR_LDS / 2 outputs per tile (window <= FIR_LDS - FIR_TILE + 1 takes the tiled path);
+// outside the FIR the same FIR_LDS doubles hold the candidates of the sampled order statistics (block_select.hpp).
 
 __global__ __launch_bounds__(1024) void flatten_kernel(
     const double *__restrict__ t, const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
@@ -154,6 +141,8 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     const int sh_words = max((int)blockDim.x, 264);
     double *fir = reinterpret_cast<double *>(sh + sh_words);           // 16-B aligned: sh_words is even
     int *shi = reinterpret_cast<int *>(fir + FIR_LDS + 2);
+    double *shd = reinterpret_cast<double *>(sh);
+    long long *shl = reinterpret_cast<long long *>(sh);
     const int FIR_TILE = FIR_LDS / 2;
     const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int64_t lo = n_off[target];
@@ -185,21 +174,26 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         auto notnan = [&](int i) { return !isnan(flux[i]); };
         long long c = 0;
         double part = 0.0;
-        for (int i = tid; i < N; i += nt)
-            if (notnan(i)) {
+        for (int i = tid; i < N; i += nt) {
+            const double f = flux[i];
+            if (!isnan(f)) {
                 ++c;
-                part += flux[i];
+                part += f;
             }
-        const long long cnt = block_count_dyn(c, reinterpret_cast<long long *>(sh));
-        const double mean = block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)cnt;
+        }
+        const long long cnt = block_count_fast(c, shl);
+        const double mean = block_sum_fast(part, shd) / (double)cnt;
         part = 0.0;
-        for (int i = tid; i < N; i += nt)
-            if (notnan(i)) {
-                const double d = flux[i] - mean;
+        for (int i = tid; i < N; i += nt) {
+            const double f = flux[i];
+            if (!isnan(f)) {
+                const double d = f - mean;
                 part = fma(d, d, part);
             }
-        const double sd = sqrt(block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)cnt);
-        const double med = block_median(N, cnt, val, notnan, sh);
+        }
+        const double sd = sqrt(block_sum_fast(part, shd) / (double)cnt);
+        __syncthreads();
+        const double med = block_median_sampled(N, cnt, val, notnan, sh, fir, FIR_LDS);
         for (int i = tid; i < N; i += nt) {
             const double f = flux[i];
             bool m = isfinite(f) && (fabs(f - med) <= sd * sigma);
@@ -210,6 +204,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     }
 
     for (int it = 0; it < niters; ++it) {
+        const bool last = it == niters - 1;
         const int nm = block_compact(N, [&](int i) { return mask[i] != 0; }, idx, shi);
         for (int i = tid; i < nm; i += nt) {
             tm[i] = t[idx[i]];
@@ -228,8 +223,9 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             auto dkeep = [&](int i) { return !isnan(tm[i + 1] - tm[i]); };
             long long c = 0;
             for (int i = tid; i < nm - 1; i += nt) c += dkeep(i) ? 1 : 0;
-            const long long cnt = block_count_dyn(c, reinterpret_cast<long long *>(sh));
-            dmed = block_median(nm - 1, cnt, dval, dkeep, sh);
+            const long long cnt = block_count_fast(c, shl);
+            __syncthreads();
+            dmed = block_median_sampled(nm - 1, cnt, dval, dkeep, sh, fir, FIR_LDS);
         }
         const double thr = break_tol * dmed;  // NaN break_tol => every comparison false => no cuts
         const int nseg = block_compact(
@@ -241,7 +237,8 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             if (window > len || (double)len < break_tol) {
                 auto val = [&](int i) { return fm[l + i]; };
                 auto keep = [&](int i) { return true; };  // masked flux is finite
-                const double med = block_median(len, (long long)len, val, keep, sh);
+                __syncthreads();
+                const double med = block_median_sampled(len, (long long)len, val, keep, sh, fir, FIR_LDS);
                 for (int i = l + tid; i < h; i += nt) tr[i] = med;
             } else {
                 // interior: correlate with the taps (window fully inside the segment).  Tiles of FIR_TILE outputs:
@@ -304,64 +301,66 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         {
             double part = 0.0;
             for (int i = tid; i < nm; i += nt) part += fm[i] - tr[i];
-            const double mean = block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)nm;
+            const double mean = block_sum_fast(part, shd) / (double)nm;
             part = 0.0;
             for (int i = tid; i < nm; i += nt) {
                 const double d = (fm[i] - tr[i]) - mean;
                 part = fma(d, d, part);
             }
-            const double sd = sqrt(block_sum_dyn(part, reinterpret_cast<double *>(sh)) / (double)nm);
+            const double sd = sqrt(block_sum_fast(part, shd) / (double)nm);
             const double lim = sd * sigma + 1e-14;
-            for (int i = tid; i < nm; i += nt) mask1[i] = (fabs(fm[i] - tr[i]) < lim) ? 1 : 0;
+            // mask1, and mask[mask] &= mask1 (:1060-1063) in the same sweep
+            for (int i = tid; i < nm; i += nt) {
+                const bool keepit = fabs(fm[i] - tr[i]) < lim;
+                mask1[i] = keepit ? 1 : 0;
+                if (!keepit) mask[idx[i]] = 0;
+            }
             __syncthreads();
         }
-        // ---- linear interpolation / extrapolation of the kept trend onto every cadence   (:1053-1058)
+        // ---- linear interpolation / extrapolation of the kept trend onto every cadence   (:1053-1058).  The reference
+        // recomputes it in every iteration and keeps the last one; only the last one is computed here.
+        if (!last) continue;
         const int n2 = block_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
         if (n2 < 2) {
             for (int i = tid; i < N; i += nt) trend[i] = qnan;
         } else {
-            // every cs-th knot time also goes to LDS: the binary search runs there and finishes with log2(cs)
-            // global steps (the all-global search was a chain of ~15 dependent L2 round trips per cadence)
-            const int cs = (n2 + FIR_LDS - 1) / FIR_LDS, nc = (n2 + cs - 1) / cs;
             for (int j = tid; j < n2; j += nt) {
-                const double x = tm[idx2[j]];
-                xk[j] = x;
+                xk[j] = tm[idx2[j]];
                 yk[j] = tr[idx2[j]];
-                if (j % cs == 0) fir[j / cs] = x;
             }
+            // After the update above mask[c] == 1 exactly for the knot cadences, in knot order.  np.searchsorted(x, xn,
+            // 'left') = number of knots with x < xn = number of knot cadences before cadence k (times are sorted), less
+            // any that share k's time.  Each wave owns a contiguous strip of cadences and carries a running knot count:
+            // no search, no barrier inside the sweep.
+            const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+            const int strip = ((N + nw - 1) / nw + 63) & ~63;
+            const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
+            int c = 0;
+            for (int k = k_lo + lane; k < k_hi; k += 64) c += mask[k] ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
             __syncthreads();
-            for (int k = tid; k < N; k += nt) {
-                const double xn = t[k];
-                // np.searchsorted(x, xn, side='left') clipped to [1, n2-1]: first knot with x >= xn
-                int a = 0, b = nc;  // coarse: first coarse knot >= xn
-                while (a < b) {
-                    const int mid = (a + b) >> 1;
-                    if (fir[mid] < xn)
-                        a = mid + 1;
-                    else
-                        b = mid;
+            if (lane == 0) shi[wv] = c;
+            __syncthreads();  // also orders the xk / yk stores above before the loads below
+            int base = 0;
+            for (int w = 0; w < wv; ++w) base += shi[w];
+            for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+                const int k = k0 + lane;
+                const bool in = k < k_hi;
+                const bool kf = in && mask[k] != 0;
+                const unsigned long long bal = __ballot(kf);
+                if (in) {
+                    const double xn = t[k];
+                    int j = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    while (j > 0 && xk[j - 1] >= xn) --j;  // equal times: not "< xn"
+                    const int hi_i = min(max(j, 1), n2 - 1), lo_i = hi_i - 1;
+                    const double x0 = xk[lo_i], x1 = xk[hi_i];
+                    const double y0 = yk[lo_i], y1 = yk[hi_i];
+                    const double slope = (y1 - y0) / (x1 - x0);
+                    trend[k] = isnan(xn) ? qnan : slope * (xn - x0) + y0;
                 }
-                // the answer lies in ((a-1) cs, a cs]  (coarse knot a-1 is < xn, coarse knot a is >= xn or absent)
-                int lo_s = a == 0 ? 0 : (a - 1) * cs + 1, hi_s = min(a * cs, n2);
-                if (a == 0) hi_s = 0;
-                while (lo_s < hi_s) {
-                    const int mid = (lo_s + hi_s) >> 1;
-                    if (xk[mid] < xn)
-                        lo_s = mid + 1;
-                    else
-                        hi_s = mid;
-                }
-                const int hi_i = min(max(lo_s, 1), n2 - 1), lo_i = hi_i - 1;
-                const double x0 = xk[lo_i], x1 = xk[hi_i];
-                const double y0 = yk[lo_i], y1 = yk[hi_i];
-                const double slope = (y1 - y0) / (x1 - x0);
-                trend[k] = isnan(xn) ? qnan : slope * (xn - x0) + y0;
+                base += __popcll(bal);
             }
-            __syncthreads();  // fir[] is reused by the next iteration's tiles
         }
-        // ---- mask[mask] &= mask1   (:1060-1063)
-        for (int i = tid; i < nm; i += nt)
-            if (!mask1[i]) mask[idx[i]] = 0;
         __syncthreads();
     }
     if (final_mask)

@@ -82,6 +82,7 @@ struct lk_handle {
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     hipStream_t s_aux = nullptr;   // second compute stream of the LS 'fast' chunk pipeline (lsfast.hip)
     hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    int *h_plan = nullptr;         // 64 B of pinned host memory: device -> host plan words (lsfast.hip)
 };
 
 // launchers implemented in the .hip files (device pointers, enqueue on stream, no sync)

@@ -561,6 +561,98 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double
         block_fft<LA, LB, 1>(CT, lds2, load, store);
 }
 
+// step 1 for grids whose samples sit in the first rows only (time span x df << 1, the normal case: lightkurve's
+// default grid has span x df = 1/5, 2/5 on the 2f grid).  With only P = 2^LP non-zero inputs an N1-point column
+// transform is Q = N1 / P transforms of length P of the pre-twiddled input,
+//     X[Q q + s] = sum_{n < P} (x[n] W_N1^{n s}) W_P^{n q},          s < Q, q < P,
+// so the LDS exchange tile is P points per column instead of N1: PRUNED_CT = 16 columns fit where the full transform
+// holds 4.  That is what this kernel is for — 16-column tiles make the intermediate's [c / 16][k1][c % 16] layout
+// deliver 256-B runs per row to this kernel's loads and RT x 256-B runs to the row kernel (4 x the run length of the
+// full-length kernel above), and the workgroups are small enough for 2 waves per SIMD.  The input column is loaded
+// once and kept in registers over the Q passes.  perm != 0 stores pass s as one contiguous block (row index
+// k1' = s P + q; the row kernel undoes the permutation), perm == 0 keeps the natural row order k1 = Q q + s.
+constexpr int PRUNED_CT = 16;
+
+template <int LP>
+__global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols_pruned_kernel(
+    const double2 *__restrict__ grids, int m1, int m2, const int *__restrict__ rows_used, double2 *__restrict__ gout,
+    int perm) {
+    extern __shared__ __attribute__((aligned(16))) double2 lds2[];
+    constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, P = 1 << LP, LDT = Bq + 1, FST = A * LDT + 1;
+    constexpr int CT = PRUNED_CT;
+    const int N1 = 1 << m1, N2 = 1 << m2, Q = N1 >> LP;
+    const double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
+    double2 *O = gout + ((size_t)blockIdx.y << (m1 + m2)) + ((size_t)blockIdx.x << m1) * CT;  // this column tile
+    const int c0 = blockIdx.x * CT;
+    const int ru = rows_used[(blockIdx.y / 3) * 4 + (blockIdx.y % 3)];
+    const int tid = threadIdx.x;
+    const int f = tid % CT, jk = tid / CT;  // column of the tile; j (phase 1) or ka (phase 2)
+    const bool p1 = jk < Bq, p2 = jk < A;
+    const double invN1 = 1.0 / (double)N1, invN = 1.0 / (double)((size_t)1 << (m1 + m2));
+    double2 xin[A];
+    if (p1) {
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            const int r = i * Bq + jk;
+            xin[i] = r < ru ? G[(size_t)r * N2 + c0 + f] : make_double2(0.0, 0.0);
+        }
+    }
+    for (int s = 0; s < Q; ++s) {
+        if (p1) {
+            double2 v[A];
+            if (s == 0) {
+#pragma unroll
+                for (int i = 0; i < A; ++i) v[i] = xin[i];
+            } else {
+                // W_N1^{(i Bq + j) s} = e^{2 pi i j s / N1} (e^{2 pi i Bq s / N1})^i
+                double sn, cs;
+                sincospi(2.0 * (double)(jk * s) * invN1, &sn, &cs);
+                double2 w = make_double2(cs, sn);
+                sincospi(2.0 * (double)(Bq * s) * invN1, &sn, &cs);
+                const double2 st = make_double2(cs, sn);
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    v[i] = cmul(xin[i], w);
+                    w = cmul(w, st);
+                }
+            }
+            reg_fft<LA>(v);
+            double sn, cs;
+            sincospi(2.0 * (double)jk / (double)P, &sn, &cs);  // intra-transform twiddle e^{2 pi i j ka / P}, by running product
+            const double2 tw_j = make_double2(cs, sn);
+            double2 w = make_double2(1.0, 0.0);
+            double2 *row = lds2 + (size_t)f * FST + jk;
+#pragma unroll
+            for (int ka = 0; ka < A; ++ka) {
+                row[ka * LDT] = cmul(v[brev_c(ka, LA)], w);
+                w = cmul(w, tw_j);
+            }
+        }
+        __syncthreads();
+        if (p2) {
+            const double2 *row = lds2 + (size_t)f * FST + (size_t)jk * LDT;
+            double2 u[Bq];
+#pragma unroll
+            for (int j = 0; j < Bq; ++j) u[j] = row[j];
+            reg_fft<LB>(u);
+            // inter-step twiddle e^{2 pi i c k1 / N}, k1 = Q (ka + A kb) + s: advances by e^{2 pi i c Q A / N} per kb
+            double sn, cs;
+            sincospi(2.0 * (double)((long long)(c0 + f) * Q * A) * invN, &sn, &cs);
+            const double2 stepc = make_double2(cs, sn);
+            sincospi(2.0 * (double)((long long)(c0 + f) * (Q * jk + s)) * invN, &sn, &cs);
+            double2 w = make_double2(cs, sn);
+#pragma unroll
+            for (int kb = 0; kb < Bq; ++kb) {
+                const int q = jk + A * kb;
+                const int k1p = perm ? s * P + q : Q * q + s;
+                O[(size_t)k1p * CT + f] = cmul(u[brev_c(kb, LB)], w);
+                w = cmul(w, stepc);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // step 2 (register version): RT rows r0..r0+RT-1, outputs k = k1 + N1 k2 < nkeep kept
 template <int LA, int LB>
 __global__ __launch_bounds__(256) void fft_rows_reg_kernel(const double2 *__restrict__ grids, int m1, int RT, int nkeep,
@@ -749,7 +841,7 @@ __global__ __launch_bounds__(256) void fft_rows_power_kernel(const double2 *__re
                                                               const FastStats *__restrict__ stats, int b0, double f0,
                                                               double df, int64_t M, int fit_mean, int norm,
                                                               const double *__restrict__ scale,
-                                                              double *__restrict__ power, int tw) {
+                                                              double *__restrict__ power, int tw, int lp) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int m2 = LA + LB, A = 1 << LA;
     const int N2 = 1 << m2;
@@ -806,9 +898,12 @@ __global__ __launch_bounds__(256) void fft_rows_power_kernel(const double2 *__re
     const FastStats st = stats[b];
     const double nn = (double)(n_off[b + 1] - n_off[b]);
     const double sc = scale ? scale[b] : 1.0;
+    // row r0 + f of the intermediate is k1 itself, or (lp > 0: fft_cols_pruned_kernel with perm) row s P + q of k1 = Q q + s
+    const int rp = r0 + f;
+    const int k1 = lp ? (((rp & ((1 << lp) - 1)) << (m1 - lp)) + (rp >> lp)) : rp;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        const long long k = (long long)(r0 + f) + ((long long)(ka + A * kb) << m1);
+        const long long k = (long long)k1 + ((long long)(ka + A * kb) << m1);
         if (k >= M) continue;
         double2 a = keep0[kb], bq = keep1[kb], c2 = keep2[kb];
         if (st.t0 != 0.0) {
@@ -989,7 +1084,7 @@ struct FusedArgs {
 
 template <int LA, int LB, int KB>
 static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
-                                hipStream_t stream) {
+                                hipStream_t stream, int lp = 0) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N1 = 1 << m1;
     const int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
@@ -1002,7 +1097,7 @@ static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, cons
     }
     hipLaunchKernelGGL((fft_rows_power_kernel<LA, LB, KB>), dim3(N1 / RT, ntargets), dim3(nt), (size_t)RT * FST * 16,
                        stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm, a.scale,
-                       a.power, tw);
+                       a.power, tw, lp);
 }
 
 // returns false if the (m2, outputs-per-thread) combination has no fused instantiation
@@ -1064,8 +1159,8 @@ static bool launch_rows_power3(int m1, int m2, int ntargets, const double2 *grid
 }
 
 static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
-                              hipStream_t stream) {
-    if (launch_rows_power3(m1, m2, ntargets, grids, a, tw, stream)) return true;
+                              hipStream_t stream, int lp = 0) {
+    if (lp == 0 && launch_rows_power3(m1, m2, ntargets, grids, a, tw, stream)) return true;
     if (tw < 0) return false;  // the two-phase kernel below reads the column-tiled layout only
     const int LA = (m2 + 1) / 2, Aa = 1 << LA;
     const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
@@ -1073,9 +1168,9 @@ static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids
     if (kb > 8) return false;
 #define LK_RP(la, lb)                                                                  \
     if (kb <= 4)                                                                       \
-        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, tw, stream);            \
+        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, tw, stream, lp);        \
     else                                                                               \
-        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, tw, stream);            \
+        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, tw, stream, lp);        \
     return true;
     switch (m2) {
         case 4: LK_RP(2, 2)
@@ -1116,6 +1211,55 @@ static void launch_rows_reg(int m1, int m2, int ngrids, const double2 *grids, in
     }
 }
 
+// per call: the largest rows_used over all targets and grids, and the number of targets that are not "ordered"
+__global__ __launch_bounds__(256) void lsf_plan_kernel(const int *__restrict__ rows_used, int B, int *__restrict__ plan) {
+    int mx = 0, unordered = 0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        mx = max(mx, max(rows_used[b * 4], max(rows_used[b * 4 + 1], rows_used[b * 4 + 2])));
+        unordered += rows_used[b * 4 + 3] ? 0 : 1;
+    }
+    __shared__ int smx[256], sun[256];
+    smx[threadIdx.x] = mx;
+    sun[threadIdx.x] = unordered;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            smx[threadIdx.x] = max(smx[threadIdx.x], smx[threadIdx.x + s]);
+            sun[threadIdx.x] += sun[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        plan[0] = smx[0];
+        plan[1] = sun[0];
+    }
+}
+
+template <int LP>
+static void launch_cols_pruned_t(int m1, int m2, int ngrids, const double2 *grids, const int *rows_used, double2 *gout,
+                                 int perm, hipStream_t stream) {
+    constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, LDT = Bq + 1, FST = A * LDT + 1;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_pruned_kernel<LP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((fft_cols_pruned_kernel<LP>), dim3((1 << m2) / PRUNED_CT, ngrids), dim3(PRUNED_CT * A),
+                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout, perm);
+}
+
+static bool launch_cols_pruned(int lp, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
+                               double2 *gout, int perm, hipStream_t stream) {
+    switch (lp) {
+        case 5: launch_cols_pruned_t<5>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
+        case 6: launch_cols_pruned_t<6>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
+        case 7: launch_cols_pruned_t<7>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
+        case 8: launch_cols_pruned_t<8>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
+        default: return false;
+    }
+}
+
 static int ilog2_ceil(long long v) {
     int m = 0;
     while (((long long)1 << m) < v) ++m;
@@ -1153,7 +1297,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
-                           (size_t)Bc * 3 * nfft * 16 * 2 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 + 16384);
+                           (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
@@ -1190,37 +1334,87 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16) : nullptr;
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
+    int *d_plan = (int *)h->ws.alloc(64);
     hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
                        d_w, d_wy, d_stats, df, nfft, m2, d_rows);
+    // ---- plan: the pruned column kernel applies when every grid of every target keeps its samples in the first
+    // P <= 256 rows (P < N1) and the row kernel can read 16-column tiles.  The decision needs one device word, so
+    // the call synchronises `stream` once here (20-30 us against a >= 1 ms step).
+    const bool pruned_env = getenv("LK_LSF_PRUNED") ? atoi(getenv("LK_LSF_PRUNED")) != 0 : true;
+    const int perm_env = getenv("LK_LSF_PERM") ? atoi(getenv("LK_LSF_PERM")) : 0;
+    const bool streams_env = getenv("LK_LSF_STREAMS") ? atoi(getenv("LK_LSF_STREAMS")) != 0 : true;
+    int lp = 0;
+    if (fused && pruned_env && tw > 0 && m2 >= 8 && m2 <= 10 && N2 >= PRUNED_CT) {
+        if (!h->h_plan) LK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h->h_plan), 64, hipHostMallocDefault));
+        hipLaunchKernelGGL(lsf_plan_kernel, dim3(1), dim3(256), 0, stream, d_rows, B, d_plan);
+        LK_HIP_CHECK(hipMemcpyAsync(h->h_plan, d_plan, 8, hipMemcpyDeviceToHost, stream));
+        LK_HIP_CHECK(hipStreamSynchronize(stream));
+        const int max_rows = h->h_plan[0];
+        const int want = std::max(5, ilog2_ceil(std::max(1, max_rows)));
+        if (want <= 8 && want < m1) lp = want;
+    }
+    // ---- two streams: the spreader of chunk k+1 (LDS atomics, latency bound) runs on h->s_aux under the FFT kernels
+    // of chunk k (HBM / VALU bound) on the caller's stream; the spread grids are double buffered, events order the
+    // hand-overs.  All s_aux work is consumed through events by `stream`, so the caller still sees one stream.
+    const bool two_streams = fused && streams_env && B > Bc;
+    double2 *d_gridsB = nullptr;
+    if (two_streams) {
+        d_gridsB = (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16);
+        LK_REQUIRE(d_gridsB != nullptr, "workspace exhausted");
+        if (!h->s_aux) {
+            LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+            for (int i = 0; i < 4; ++i) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
+        }
+        // s_aux may start once the prep kernel's outputs exist
+        LK_HIP_CHECK(hipEventRecord(h->ev_aux[0], stream));
+        LK_HIP_CHECK(hipStreamWaitEvent(h->s_aux, h->ev_aux[0], 0));
+    }
+    hipEvent_t *ev_spread = &h->ev_aux[0], *ev_cols = &h->ev_aux[2];  // [2] each, indexed by the grid buffer
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
-    for (int b0 = 0; b0 < B; b0 += Bc) {
+    int chunk = 0;
+    for (int b0 = 0; b0 < B; b0 += Bc, ++chunk) {
         const int nb = std::min(Bc, B - b0);
+        const int buf = two_streams ? (chunk & 1) : 0;
+        double2 *gr = buf ? d_gridsB : d_grids;
+        hipStream_t ss = two_streams ? h->s_aux : stream;  // the spreader's stream
+        if (two_streams && chunk >= 2) LK_HIP_CHECK(hipStreamWaitEvent(ss, ev_cols[buf], 0));  // chunk-2's step 1 has read gr
         if (reg_path) {
-            hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, stream, d_grids, m1, m2,
+            hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, ss, gr, m1, m2,
                                d_rows + (size_t)b0 * 4);
         } else {
-            LK_HIP_CHECK(hipMemsetAsync(d_grids, 0, (size_t)nb * 3 * nfft * 16, stream));
+            LK_HIP_CHECK(hipMemsetAsync(gr, 0, (size_t)nb * 3 * nfft * 16, ss));
         }
-        hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, d_w,
-                           d_wy, d_off, d_stats, b0, f0, df, nfft, fit_mean, d_grids,
+        hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, ss, t, d_w,
+                           d_wy, d_off, d_stats, b0, f0, df, nfft, fit_mean, gr,
                            reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr);
         if (reg_path)
             hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)((nfft + SPREAD_W - 1) / SPREAD_W), nb, 3),
-                               dim3(256), 0, stream, t, d_w, d_wy, d_off, d_stats, b0, f0, df, nfft, m2, fit_mean,
-                               d_grids, d_rows + (size_t)b0 * 4);
+                               dim3(256), 0, ss, t, d_w, d_wy, d_off, d_stats, b0, f0, df, nfft, m2, fit_mean,
+                               gr, d_rows + (size_t)b0 * 4);
+        if (two_streams) {
+            LK_HIP_CHECK(hipEventRecord(ev_spread[buf], ss));
+            LK_HIP_CHECK(hipStreamWaitEvent(stream, ev_spread[buf], 0));
+        }
         if (reg_path) {
             const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power};
             if (fused) {
                 // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
-                launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
-                LK_REQUIRE(launch_rows_power(m1, m2, nb, d_grids2, fa, tw, stream), "no step-2 kernel for this layout");
+                if (lp) {
+                    LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, perm_env, stream),
+                               "no pruned column kernel for 2^%d rows", lp);
+                } else {
+                    launch_cols_reg(m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
+                }
+                if (two_streams) LK_HIP_CHECK(hipEventRecord(ev_cols[buf], stream));
+                LK_REQUIRE(launch_rows_power(m1, m2, nb, d_grids2, fa, lp ? PRUNED_CT : tw, stream, (lp && perm_env) ? lp : 0),
+                           "no step-2 kernel for this layout");
                 continue;
             }
-            launch_cols_reg(m1, m2, nb * 3, d_grids, d_rows + (size_t)b0 * 4, nullptr, 1, stream);
-            launch_rows_reg(m1, m2, nb * 3, d_grids, (int)M, d_spec, stream);
+            launch_cols_reg(m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, nullptr, 1, stream);
+            launch_rows_reg(m1, m2, nb * 3, gr, (int)M, d_spec, stream);
         } else {
-            hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * 3), dim3(256), ldsA, stream, d_grids, m1, m2, CT);
-            hipLaunchKernelGGL(fft_rows_kernel, dim3(N1 / RT, nb * 3), dim3(256), ldsB, stream, d_grids, m1, m2, RT,
+            hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * 3), dim3(256), ldsA, stream, gr, m1, m2, CT);
+            hipLaunchKernelGGL(fft_rows_kernel, dim3(N1 / RT, nb * 3), dim3(256), ldsB, stream, gr, m1, m2, RT,
                                (int)M, d_spec);
         }
         hipLaunchKernelGGL(lsf_power_kernel, dim3((unsigned)((M + 255) / 256), nb), dim3(256), 0, stream, d_spec,
