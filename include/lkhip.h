@@ -221,6 +221,17 @@ int lk_regress_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, 
                          const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
                          uint8_t *outlier, void *stream);
 
+/* The same fit with propagate_errors=True (regressioncorrector.py:183-185): w_cov (B x K x K, nullable) receives
+ * inv(X^T S^-1 X + diag(1/prior_sigma^2)) of the LAST iteration's fit — RegressionCorrector.coefficients_err. */
+int lk_regress_cov_batch(lk_handle *h, int B, const int64_t *n_off, int K, const double *X, const double *y,
+                         const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                         const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                         uint8_t *outlier, double *w_cov);
+int lk_regress_cov_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
+                             const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                             const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                             uint8_t *outlier, double *w_cov, void *stream);
+
 /* ---- LightCurve.flatten trend: masked, gap-segmented Savitzky-Golay + sigma-clip loop + linear re-interpolation
  * t (non-decreasing per target), flux (may hold NaN); mask: 1 = EXCLUDE the cadence from the fit (lightkurve's
  * `mask=` semantics) or NULL; window (odd), polyorder, break_tol (NaN = no gap splitting), niters, sigma as in

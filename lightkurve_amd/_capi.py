@@ -94,6 +94,12 @@ SIGNATURES = [
     ("lk_regress_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_int, _vp,
       _vp, _vp, _vp]),
+    ("lk_regress_cov_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_u8p, _c_dp, _c_dp, ctypes.c_double,
+      ctypes.c_int, _c_dp, _c_dp, _c_u8p, _c_dp]),
+    ("lk_regress_cov_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_int, _vp,
+      _vp, _vp, _vp, _vp]),
     ("lk_savgol_trend_batch", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
       ctypes.c_double, _c_dp, _c_u8p]),
@@ -435,9 +441,10 @@ def bls_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, ivar_ptr, period_host, pe
 
 # --------------------------------------------------------------------------------------------- regression
 def regress_batch(X, y, n_off, err=None, cadence_mask=None, prior_mu=None, prior_sigma=None, sigma=5.0, niters=5,
-                  device=0):
+                  device=0, return_cov=False):
     """RegressionCorrector.correct numerics for B ragged targets sharing K columns.
-    X: (sum N, K); returns dict(coefficients[B,K], model[sum N] (median-subtracted), outlier_mask[sum N] bool)."""
+    X: (sum N, K); returns dict(coefficients[B,K], model[sum N] (median-subtracted), outlier_mask[sum N] bool);
+    ``return_cov``: also coefficients_cov[B,K,K] = inverse normal matrix of the last fit (propagate_errors=True)."""
     h = Handle.get(device)
     X = np.ascontiguousarray(X, dtype=np.float64)
     if X.ndim != 2:
@@ -460,10 +467,14 @@ def regress_batch(X, y, n_off, err=None, cadence_mask=None, prior_mu=None, prior
     w = np.empty((B, K), dtype=np.float64)
     model = np.empty(ntot, dtype=np.float64)
     outl = np.empty(ntot, dtype=np.uint8)
-    _check(_lib.lk_regress_batch(h._h, B, _ptr(n_off, _c_ip), K, _ptr(X), _ptr(y), _ptr(err), _ptr(cm, _c_u8p),
-                                 _ptr(prior_mu), _ptr(prior_sigma), float(sigma), int(niters), _ptr(w), _ptr(model),
-                                 _ptr(outl, _c_u8p)))
-    return dict(coefficients=w, model=model, outlier_mask=outl.astype(bool))
+    cov = np.empty((B, K, K), dtype=np.float64) if return_cov else None
+    _check(_lib.lk_regress_cov_batch(h._h, B, _ptr(n_off, _c_ip), K, _ptr(X), _ptr(y), _ptr(err), _ptr(cm, _c_u8p),
+                                     _ptr(prior_mu), _ptr(prior_sigma), float(sigma), int(niters), _ptr(w), _ptr(model),
+                                     _ptr(outl, _c_u8p), _ptr(cov)))
+    res = dict(coefficients=w, model=model, outlier_mask=outl.astype(bool))
+    if return_cov:
+        res["coefficients_cov"] = cov
+    return res
 
 
 # --------------------------------------------------------------------------------------------- flatten

@@ -419,20 +419,36 @@ int lk_bls_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, con
 }
 
 // ------------------------------------------------------------------------------------------------ regression
+int lk_regress_cov_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
+                             const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                             const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                             uint8_t *outlier, double *w_cov, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::regress_launch(h, B, n_off_host, K, X, y, err, cadence_mask, prior_mu, prior_sigma, clip_sigma,
+                              niters, w, model, outlier, static_cast<hipStream_t>(stream), w_cov);
+}
+
 int lk_regress_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
                          const double *err, const uint8_t *cadence_mask, const double *prior_mu,
                          const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
                          uint8_t *outlier, void *stream) {
-    LK_REQUIRE(h != nullptr, "handle is NULL");
-    LK_HIP_CHECK(hipSetDevice(h->device));
-    return lk::regress_launch(h, B, n_off_host, K, X, y, err, cadence_mask, prior_mu, prior_sigma, clip_sigma,
-                              niters, w, model, outlier, static_cast<hipStream_t>(stream));
+    return lk_regress_cov_batch_dev(h, B, n_off_host, K, X, y, err, cadence_mask, prior_mu, prior_sigma, clip_sigma,
+                                    niters, w, model, outlier, nullptr, stream);
 }
 
 int lk_regress_batch(lk_handle *h, int B, const int64_t *n_off, int K, const double *X, const double *y,
                      const double *err, const uint8_t *cadence_mask, const double *prior_mu,
                      const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
                      uint8_t *outlier) {
+    return lk_regress_cov_batch(h, B, n_off, K, X, y, err, cadence_mask, prior_mu, prior_sigma, clip_sigma, niters, w,
+                                model, outlier, nullptr);
+}
+
+int lk_regress_cov_batch(lk_handle *h, int B, const int64_t *n_off, int K, const double *X, const double *y,
+                         const double *err, const uint8_t *cadence_mask, const double *prior_mu,
+                         const double *prior_sigma, double clip_sigma, int niters, double *w, double *model,
+                         uint8_t *outlier, double *w_cov) {
     LK_REQUIRE(h != nullptr, "handle is NULL");
     LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
     if (B == 0) return LK_OK;
@@ -442,7 +458,8 @@ int lk_regress_batch(lk_handle *h, int B, const int64_t *n_off, int K, const dou
     const size_t ntot = (size_t)n_off[B];
     const size_t xb = ntot * (size_t)K * 8, nb = ntot * 8, kb = (size_t)B * K * 8;
     h->staging.reset();
-    int rc = h->staging.reserve(xb + 3 * (nb + 256) + 2 * (ntot + 256) + 3 * (kb + 256) + 4096);
+    const size_t cb = w_cov ? (size_t)B * K * K * 8 : 0;
+    int rc = h->staging.reserve(xb + 3 * (nb + 256) + 2 * (ntot + 256) + 3 * (kb + 256) + cb + 4096);
     if (rc) return rc;
     double *dX = (double *)h->staging.alloc(xb), *dy = (double *)h->staging.alloc(nb);
     double *derr = err ? (double *)h->staging.alloc(nb) : nullptr;
@@ -452,6 +469,7 @@ int lk_regress_batch(lk_handle *h, int B, const int64_t *n_off, int K, const dou
     double *dmu = prior_mu ? (double *)h->staging.alloc(kb) : nullptr;
     double *dsg = prior_sigma ? (double *)h->staging.alloc(kb) : nullptr;
     double *dw = (double *)h->staging.alloc(kb);
+    double *dcov = w_cov ? (double *)h->staging.alloc(cb) : nullptr;
     LK_HIP_CHECK(hipMemcpy(dX, X, xb, hipMemcpyHostToDevice));
     LK_HIP_CHECK(hipMemcpy(dy, y, nb, hipMemcpyHostToDevice));
     if (err) LK_HIP_CHECK(hipMemcpy(derr, err, nb, hipMemcpyHostToDevice));
@@ -459,8 +477,9 @@ int lk_regress_batch(lk_handle *h, int B, const int64_t *n_off, int K, const dou
     if (prior_mu) LK_HIP_CHECK(hipMemcpy(dmu, prior_mu, kb, hipMemcpyHostToDevice));
     if (prior_sigma) LK_HIP_CHECK(hipMemcpy(dsg, prior_sigma, kb, hipMemcpyHostToDevice));
     rc = lk::regress_launch(h, B, n_off, K, dX, dy, derr, dcm, dmu, dsg, clip_sigma, niters, dw, dmodel, dout,
-                            nullptr);
+                            nullptr, dcov);
     if (rc) return rc;
+    if (w_cov) LK_HIP_CHECK(hipMemcpy(w_cov, dcov, cb, hipMemcpyDeviceToHost));
     LK_HIP_CHECK(hipMemcpy(w, dw, kb, hipMemcpyDeviceToHost));
     LK_HIP_CHECK(hipMemcpy(model, dmodel, nb, hipMemcpyDeviceToHost));
     LK_HIP_CHECK(hipMemcpy(outlier, dout, ntot, hipMemcpyDeviceToHost));

@@ -100,7 +100,8 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
                int nD, int oversample, int use_likelihood, double *out7, hipStream_t stream);
 int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
                    const double *err, const uint8_t *cmask, const double *prior_mu, const double *prior_sigma,
-                   double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream);
+                   double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream,
+                   double *w_cov = nullptr);
 int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
                    const uint8_t *user_mask, int window, int polyorder, double break_tol, int niters, double sigma,
                    double *trend, uint8_t *final_mask, hipStream_t stream);

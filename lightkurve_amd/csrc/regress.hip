@@ -424,6 +424,88 @@ __global__ __launch_bounds__(1024) void demedian_kernel(const int64_t *__restric
     for (int i = tid; i < n; i += 1024) model[i] -= med;
 }
 
+// (X^T S^-1 X + diag(1 / prior_sigma^2))^-1, the coefficient covariance RegressionCorrector keeps when
+// propagate_errors=True (regressioncorrector.py:183-185, np.linalg.inv): Gauss-Jordan with partial pivoting on [A | I]
+// in global scratch (K x 2K doubles per target), one 256-thread workgroup per target.
+__global__ __launch_bounds__(256) void invert_kernel(const double *__restrict__ G, int K, int Kp,
+                                                      const double *__restrict__ prior_sigma,
+                                                      double *__restrict__ Awork, double *__restrict__ inv) {
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    __shared__ double s_col[1024];  // column j of every row (K <= 1023)
+    const int target = blockIdx.x, tid = threadIdx.x;
+    const double *Gt = G + (size_t)target * Kp * Kp;
+    const int W = 2 * K;
+    double *A = Awork + (size_t)target * K * W;
+    for (int e = tid; e < K * W; e += 256) {
+        const int i = e / W, j = e - i * W;
+        double v;
+        if (j < K) {
+            v = (j >= i || (j / GR_BLK) == (i / GR_BLK)) ? Gt[(size_t)i * Kp + j] : Gt[(size_t)j * Kp + i];
+            if (i == j && prior_sigma) {
+                const double sg = prior_sigma[(size_t)target * K + i];
+                v += 1.0 / (sg * sg);
+            }
+        } else {
+            v = (j - K == i) ? 1.0 : 0.0;
+        }
+        A[e] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < K; ++j) {
+        double best = -1.0;
+        int bi = j;
+        for (int i = j + tid; i < K; i += 256) {
+            const double v = fabs(A[(size_t)i * W + j]);
+            if (v > best) {
+                best = v;
+                bi = i;
+            }
+        }
+        s_val[tid] = best;
+        s_idx[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                const double v2 = s_val[tid + s];
+                const int i2 = s_idx[tid + s];
+                if (v2 > s_val[tid] || (v2 == s_val[tid] && i2 < s_idx[tid])) {
+                    s_val[tid] = v2;
+                    s_idx[tid] = i2;
+                }
+            }
+            __syncthreads();
+        }
+        const int p = s_idx[0];
+        __syncthreads();
+        if (p != j) {
+            for (int c = tid; c < W; c += 256) {
+                const double t0 = A[(size_t)j * W + c];
+                A[(size_t)j * W + c] = A[(size_t)p * W + c];
+                A[(size_t)p * W + c] = t0;
+            }
+        }
+        __syncthreads();
+        const double piv = A[(size_t)j * W + j];
+        for (int i = tid; i < K; i += 256) s_col[i] = A[(size_t)i * W + j];
+        __syncthreads();
+        // scale the pivot row (columns right of j; column j itself is never read again)
+        for (int c = j + 1 + tid; c < W; c += 256) A[(size_t)j * W + c] /= piv;
+        __syncthreads();
+        // eliminate column j from every other row
+        const int nc = W - j - 1;
+        for (int e = tid; e < K * nc; e += 256) {
+            const int i = e / nc, c = j + 1 + e % nc;
+            if (i != j) A[(size_t)i * W + c] = fma(-s_col[i], A[(size_t)j * W + c], A[(size_t)i * W + c]);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < K * K; e += 256) {
+        const int i = e / K, c = e - i * K;
+        inv[(size_t)target * K * K + e] = A[(size_t)i * W + K + c];
+    }
+}
+
 // plain Gram matrices G_b = A_b^T A_b of B row-major (N_b x K) blocks (no weights, no masks), for PCA (pld.hip)
 int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, double *G, hipStream_t stream) {
     const int KB = (K + GR_BLK - 1) / GR_BLK;
@@ -434,7 +516,8 @@ int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, doubl
 
 int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
                    const double *err, const uint8_t *cmask, const double *prior_mu, const double *prior_sigma,
-                   double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream) {
+                   double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream,
+                   double *w_cov) {
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
     if (B == 0) return LK_OK;
     LK_REQUIRE(K >= 1 && K <= 1023, "K=%d outside the supported range 1..1023", K);
@@ -449,11 +532,12 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     const size_t ntot = (size_t)n_off_host[B];
     const int KB = (K + 1 + GR_BLK - 1) / GR_BLK, Kp = KB * GR_BLK;
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * Kp * Kp * 8 + (size_t)B * K * (K + 1) * 8 + ntot + 4096);
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * Kp * Kp * 8 + (size_t)B * K * (K + 1) * 8 * (w_cov ? 2 : 1) +
+                           ntot + 4096);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     double *d_G = (double *)h->ws.alloc((size_t)B * Kp * Kp * 8);
-    double *d_A = (double *)h->ws.alloc((size_t)B * K * (K + 1) * 8);
+    double *d_A = (double *)h->ws.alloc((size_t)B * K * (K + 1) * 8 * (w_cov ? 2 : 1));  // K x 2K per target for the inverse
     uint8_t *d_flag = (uint8_t *)h->ws.alloc(ntot);
     {
         const int rcs = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
@@ -481,6 +565,8 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
         hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, model, d_off, clip_sigma, 5, d_flag, outl);
     }
     hipLaunchKernelGGL(demedian_kernel, dim3(B), dim3(1024), 0, stream, d_off, model);
+    // d_G still holds the normal matrix of the LAST iteration's fit: its inverse is the coefficient covariance
+    if (w_cov) hipLaunchKernelGGL(invert_kernel, dim3(B), dim3(256), 0, stream, d_G, K, Kp, prior_sigma, d_A, w_cov);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

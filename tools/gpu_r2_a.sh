@@ -32,5 +32,5 @@ echo "== default bench (with astropy accuracy)"; timeout 1500 python bench.py > 
 echo "== PLD MFMA counters"
 rocprofv3 --list-avail 2>/dev/null | grep -i -E "MFMA|VALU_BUSY|SQ_BUSY_CY" | head -40 > $O/avail_mfma.txt
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 -d $OLDPWD/$O/pld_pmc -o pld -- python $OLDPWD/bench.py --workload pld --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/pld_pmc.log 2>&1); echo "pld pmc rc=$?"
-ls $O/pld_pmc 2>/dev/null | head
+DB=$(find $O/pld_pmc -name "*results.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" "PLD bench (--steps 2 --warmup 1): MFMA counters" > $O/pld_pmc_summary.txt 2>&1 && rm -rf $O/pld_pmc && tail -25 $O/pld_pmc_summary.txt
 echo done
