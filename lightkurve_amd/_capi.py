@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblkhip.so")
+LIB_PATH = os.environ.get("LK_LIB_PATH") or os.path.join(_HERE, "liblkhip.so")   # LK_LIB_PATH: A/B builds of the library
 
 LK_OK, LK_EINVAL, LK_ENOMEM, LK_EHIP = 0, 1, 2, 3
 NORM = {"standard": 0, "psd": 1, "lk_amplitude": 2, "lk_psd": 3}

@@ -6,7 +6,8 @@ import copy as _copy
 
 import numpy as np
 
-__all__ = ["DesignMatrix", "DesignMatrixCollection"]
+__all__ = ["DesignMatrix", "DesignMatrixCollection", "SparseDesignMatrix", "SparseDesignMatrixCollection",
+           "create_sparse_spline_matrix"]
 
 
 class DesignMatrix(object):
@@ -14,6 +15,8 @@ class DesignMatrix(object):
         if isinstance(df, dict):
             columns = list(df.keys()) if columns is None else columns
             values = np.column_stack([np.asarray(v, dtype=np.float64) for v in df.values()])
+        elif hasattr(df, "toarray"):     # scipy.sparse matrix: densified (K <= ~500 columns on this path)
+            values = np.asarray(df.toarray(), dtype=np.float64)
         else:
             values = np.asarray(getattr(df, "values", df), dtype=np.float64)
             if values.ndim == 1:
@@ -106,3 +109,54 @@ class DesignMatrixCollection(object):
 
     def __repr__(self):
         return "DesignMatrixCollection:\n" + "".join("\t{}\n".format(m.__repr__()) for m in self.matrices)
+
+
+class SparseDesignMatrix(DesignMatrix):
+    """Reference: src/lightkurve/correctors/sparsedesignmatrix.py.  The HIP regression path is dense (the Gram matrix is
+    formed on the fp64 matrix cores; only the spline block of a PLD matrix is genuinely sparse, degree + 1 non-zeros per
+    row), so a sparse matrix is accepted and densified at construction; names, priors and collection semantics are the
+    reference's."""
+
+    def __repr__(self):
+        return "{} SparseDesignMatrix {}".format(self.name, self.shape)
+
+
+class SparseDesignMatrixCollection(DesignMatrixCollection):
+    def __repr__(self):
+        return "SparseDesignMatrixCollection:\n" + "".join("\t{}\n".format(m.__repr__()) for m in self.matrices)
+
+
+def _spline_basis_vector(x, degree, i, knots):
+    """Cox-de Boor recursion exactly as the reference writes it (designmatrix.py:853-893): degree-0 pieces are CLOSED on
+    both ends (a sample that sits on a knot belongs to both neighbouring pieces), zero-width denominators give 0."""
+    if degree == 0:
+        B = np.zeros(len(x))
+        B[(x >= knots[i]) & (x <= knots[i + 1])] = 1
+        return B
+    da = knots[degree + i] - knots[i]
+    db = knots[i + degree + 1] - knots[i + 1]
+    alpha1 = (x - knots[i]) / da if da != 0 else np.zeros(len(x))
+    alpha2 = (knots[i + degree + 1] - x) / db if db != 0 else np.zeros(len(x))
+    return _spline_basis_vector(x, degree - 1, i, knots) * alpha1 + _spline_basis_vector(x, degree - 1, i + 1, knots) * alpha2
+
+
+def create_sparse_spline_matrix(x, n_knots=20, knots=None, degree=3, name="spline"):
+    """The spline block of ``PLDCorrector.create_design_matrix(sparse=True)`` (reference designmatrix.py:896-949): knots at
+    the mid-points between the samples that end each of ``n_knots - degree`` equal chunks of the sorted ``x``, boundary
+    knots repeated ``degree`` times, all-zero basis vectors dropped.  A different basis from the patsy splines of the dense
+    path (designmatrix.py:952-997), so ``sparse=True`` and ``sparse=False`` differ in the reference too.  Host-side
+    construction of an N x ~n_knots block, like the knot selection of the dense path."""
+    x = np.asarray(x, np.float64)
+    if not isinstance(n_knots, (int, np.integer)):
+        raise ValueError("`n_knots` must be an integer.")
+    if n_knots - degree <= 0:
+        raise ValueError("n_knots must be greater than degree.")
+    if knots is None:
+        ends = np.asarray([s_[-1] for s_ in np.array_split(np.argsort(x), n_knots - degree)[:-1]])
+        knots = [np.mean([x[k], x[k + 1]]) for k in ends]
+    knots = np.append(np.append(x.min(), knots), x.max())
+    knots = np.unique(knots)
+    knots_wbounds = np.append(np.append([x.min()] * (degree - 1), knots), [x.max()] * degree)
+    cols = [_spline_basis_vector(x, degree, idx, knots_wbounds) for idx in np.arange(-1, len(knots_wbounds) - degree - 1)]
+    cols = [c for c in cols if c.sum() != 0]
+    return SparseDesignMatrix(np.column_stack(cols), name=name)

@@ -11,7 +11,8 @@ import numpy as np
 
 from .. import _capi
 from ..lightcurve import LightCurve
-from .designmatrix import DesignMatrix, DesignMatrixCollection
+from .designmatrix import (DesignMatrix, DesignMatrixCollection, SparseDesignMatrixCollection,
+                           create_sparse_spline_matrix)
 from .regressioncorrector import RegressionCorrector
 
 log = logging.getLogger(__name__)
@@ -154,8 +155,6 @@ class PLDCorrector(RegressionCorrector):
                              background_aperture_mask="background", spline_n_knots=None, spline_degree=3,
                              normalize_background_pixels=None, sparse=False, device=0):
         """DesignMatrixCollection [pixel_series | background | spline] built on the GPU (one cutout = a batch of 1)."""
-        if sparse:
-            raise NotImplementedError("sparse design matrices are densified on the HIP path; pass sparse=False")
         if pca_components is None or pca_components < 1:
             raise NotImplementedError("pca_components must be >= 1 on the HIP path")
         if pld_aperture_mask is None:
@@ -182,6 +181,13 @@ class PLDCorrector(RegressionCorrector):
         if npld > 0:
             mats.append(DesignMatrix(X[:, :npld], name="pixel_series", prior_sigma=ps[:npld]))
         mats.append(DesignMatrix(X[:, npld:npld + kb], name="background", prior_sigma=ps[npld:npld + kb]))
+        if sparse:
+            # reference :194-199, 226-230: the sparse collection carries a DIFFERENT spline basis
+            # (create_sparse_spline_matrix); pixel and background blocks are the same PCA'd matrices
+            sp = create_sparse_spline_matrix(self.lc.time, n_knots=spline_n_knots, degree=spline_degree).append_constant()
+            sp.prior_sigma = np.ones(sp.shape[1]) * ps[-1]
+            mats.append(sp)
+            return SparseDesignMatrixCollection(mats)
         mats.append(DesignMatrix(X[:, npld + kb:], name="spline", prior_sigma=ps[npld + kb:],
                                  columns=["knot{}".format(i + 1) for i in range(spline_n_knots)] + ["offset"]))
         return DesignMatrixCollection(mats)

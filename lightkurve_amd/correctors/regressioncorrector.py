@@ -38,8 +38,6 @@ class RegressionCorrector(object):
                 device=0):
         """Fit and subtract the best linear combination of the regressors (Gaussian priors, iterative 5-sigma
         clipping).  The whole loop (Gram on the fp64 matrix cores, solve, residuals, clipping) runs on the GPU."""
-        if propagate_errors:
-            raise NotImplementedError("propagate_errors=True (coefficient covariance sampling) is not on the HIP path")
         if not isinstance(design_matrix_collection, DesignMatrixCollection):
             if not isinstance(design_matrix_collection, DesignMatrix):
                 raise ValueError("design_matrix_collection must be a DesignMatrix or DesignMatrixCollection")
@@ -55,11 +53,25 @@ class RegressionCorrector(object):
         res = _capi.regress_batch(
             self.dmc.X, self.lc.flux, [0, n], err=err, cadence_mask=self.cadence_mask,
             prior_mu=self.dmc.prior_mu if has_prior else None,
-            prior_sigma=self.dmc.prior_sigma if has_prior else None, sigma=sigma, niters=niters, device=device)
+            prior_sigma=self.dmc.prior_sigma if has_prior else None, sigma=sigma, niters=niters, device=device,
+            return_cov=bool(propagate_errors))
         self.coefficients = res["coefficients"][0]
-        self.coefficients_err = np.zeros(len(self.coefficients)) * np.nan
         self.outlier_mask = res["outlier_mask"]
-        self.model_lc = LightCurve(time=self.lc.time, flux=res["model"], flux_err=np.zeros(n), meta=self.lc.meta)
+        if propagate_errors:
+            # reference :183-185 keeps inv(X^T S^-1 X + diag(1/sigma_p^2)) of the last fit (computed on the GPU here) and
+            # :280-298 turns it into a model uncertainty by drawing 100 coefficient vectors from N(w, cov) with the
+            # global numpy RNG: same draws, same percentiles (host glue over K x K and N x 100 arrays, as in the reference)
+            self.coefficients_err = res["coefficients_cov"][0]
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                samples = np.asarray([self.dmc.X.dot(np.random.multivariate_normal(self.coefficients, self.coefficients_err))
+                                      for _ in range(100)]).T
+            model_err = np.abs(np.percentile(samples, [16, 84], axis=1) - np.median(samples, axis=1)[:, None].T).mean(axis=0)
+        else:
+            self.coefficients_err = np.zeros(len(self.coefficients)) * np.nan
+            model_err = np.zeros(n)
+        self.model_lc = LightCurve(time=self.lc.time, flux=res["model"], flux_err=model_err, meta=self.lc.meta)
         self.corrected_lc = self.lc.copy()
         self.corrected_lc.flux = self.lc.flux - self.model_lc.flux
         self.corrected_lc.flux_err = (self.lc.flux_err ** 2 + self.model_lc.flux_err ** 2) ** 0.5

@@ -99,6 +99,13 @@ __device__ double block_select_kth(int n, long long k, Val val, Keep keep, unsig
     return r;
 }
 
+// Out-of-line copy for the rarely taken fallback of block_select_sampled: kept out of the caller's register allocation
+// (inlined, its eight passes cost the hot path ~0.15 ms per call in spills although they never ran).
+template <class Val, class Keep>
+__device__ __noinline__ double block_select_kth_cold(int n, long long k, Val val, Keep keep, unsigned long long *sh) {
+    return block_select_kth(n, k, val, keep, sh);
+}
+
 // deterministic workgroup sum (fixed tree order)
 __device__ __forceinline__ double block_sum_dyn(double x, double *shd) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -160,6 +167,27 @@ __device__ double block_median(int n, long long count, Val val, Keep keep, unsig
     return (a + b) * 0.5;
 }
 
+// ------------------------------------------------------------------------------------------------ strided passes
+// for i = tid, tid + nt, ... < n: proc(i, load(i)) with U loads in flight per thread.  A plain `for (i = tid; i < n;
+// i += nt)` loop over global memory waits one full memory latency per element (the compiler cannot hoist loads over
+// the byte stores / LDS atomics in the bodies here); issuing U loads before the first use turns n / nt latencies into
+// n / (nt U).
+template <int U, class L, class P>
+__device__ __forceinline__ void strided_pass(int n, L load, P proc) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int i = tid;
+#ifndef LK_SP_PLAIN
+    for (; i + (U - 1) * nt < n; i += U * nt) {
+        decltype(load(0)) v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load(i + u * nt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) proc(i + u * nt, v[u]);
+    }
+#endif
+    for (; i < n; i += nt) proc(i, load(i));
+}
+
 // ------------------------------------------------------------------------------------------------ wave-level helpers
 // Workgroup sum with two barriers: 64-lane butterfly (DPP/shuffles), one LDS word per wave, lane-serial combine.
 // Fixed order, so deterministic; `sh` needs blockDim.x / 64 (+1) 64-bit words.
@@ -206,49 +234,74 @@ __device__ __forceinline__ int block_exscan_int(int x, int *shi, int *tot) {
     return base + inc - x;
 }
 
-// ------------------------------------------------------------------------------------------------ sampled selection
-// k-th smallest of the kept values in about ONE pass over the data instead of the eight of block_select_kth
-// (Floyd-Rivest style): a strided sample of <= SEL_SAMPLE kept values is sorted in LDS, two pivots lo <= hi bracket
-// the wanted rank, one pass counts the values below lo / equal to lo / equal to hi and collects the ones strictly
-// between into `cand` (LDS, `cap` doubles); the answer is then found inside the candidates.  If the bracket misses
-// or overflows — heavy-tailed sample luck, adversarial order — the full radix select runs instead, so the result is
-// ALWAYS the exact order statistic.  count = number of kept values (> k).  Also serves rank k + 1 (for the median of
-// an even count) from the same pass: *next receives it when want_next.
-constexpr int SEL_SAMPLE = 1024;
+// ascending bitonic sort of S = 2^m 64-bit keys in LDS.  Every thread keeps E = S / blockDim.x consecutive keys in
+// registers: compare-exchanges at distance < E are register moves, at distance < 64 E lane shuffles inside the wave
+// (no barrier), and only the few stages at distance >= 64 E go through LDS (two barriers each) — 6 LDS stages instead
+// of 66 barriers for 2048 keys on 512 threads.  Falls back to the plain one-barrier-per-stage LDS network when S is not
+// E x blockDim.x with E in {1, 2, 4, 8}.
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int lane_delta) {
+    const int lo = __shfl_xor((int)(unsigned int)(v & 0xffffffffull), lane_delta);
+    const int hi = __shfl_xor((int)(unsigned int)(v >> 32), lane_delta);
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
+}
 
-template <class Val, class Keep>
-__device__ double block_select_sampled(int n, long long count, long long k, Val val, Keep keep, unsigned long long *sh,
-                                       double *cand, int cap, bool want_next, double *next) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    int *ictl = reinterpret_cast<int *>(sh + 200);  // [0] ncand, [1] sample size   (sh[0..199] are used by the callees)
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(cand);
-    auto fallback = [&]() -> double {
-        const double a = block_select_kth(n, k, val, keep, sh);
-        if (want_next) *next = (k + 1 < count) ? block_select_kth(n, k + 1, val, keep, sh) : a;
-        return a;
-    };
-    auto lds_val = [&](int i) { return cand[i]; };
-    auto lds_all = [&](int) { return true; };
-    if (cap < 2 * SEL_SAMPLE) return fallback();
-    if (count <= (long long)cap) {
-        // everything fits: collect once, select in LDS
-        if (tid == 0) ictl[0] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += nt)
-            if (keep(i)) cand[atomicAdd(&ictl[0], 1)] = val(i);
-        __syncthreads();
-        const int nc = ictl[0];
-        const double a = block_select_kth(nc, k, lds_val, lds_all, sh);
-        if (want_next) *next = (k + 1 < nc) ? block_select_kth(nc, k + 1, lds_val, lds_all, sh) : a;
-        return a;
-    }
-    // ---- strided sample -> keys[0..S), padded with +inf keys to a power of two, bitonic sort
-    const int S = SEL_SAMPLE;
-    for (int j = tid; j < S; j += nt) {
-        const int i = (int)(((long long)j * n) / S);
-        keys[j] = keep(i) ? f64_sortable(val(i)) : ~0ull;
-    }
+template <int E>
+__device__ __forceinline__ void lds_bitonic_sort_regs(unsigned long long *keys, int S) {
+    const int tid = threadIdx.x;
+    unsigned long long r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = keys[tid * E + e];
+    for (int size = 2; size <= S; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64 * E) {  // partner in another wave: through LDS
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) keys[tid * E + e] = r[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    const unsigned long long p = keys[i ^ stride];
+                    const bool keep_min = ((i & stride) == 0) == ((i & size) == 0);
+                    r[e] = keep_min ? (r[e] < p ? r[e] : p) : (r[e] > p ? r[e] : p);
+                }
+            } else if (stride >= E) {  // partner in another lane of this wave
+                const int ld = stride / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = tid * E + e;
+                    const unsigned long long p = shfl_xor_u64(r[e], ld);
+                    const bool keep_min = ((i & stride) == 0) == ((i & size) == 0);
+                    r[e] = keep_min ? (r[e] < p ? r[e] : p) : (r[e] > p ? r[e] : p);
+                }
+            } else {  // partner in this thread's registers (stride in {1, 2, 4})
+                unsigned long long q[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    unsigned long long p = r[e];
+                    if (stride == 1) p = r[(e ^ 1) & (E - 1)];
+                    if (stride == 2) p = r[(e ^ 2) & (E - 1)];
+                    if (stride == 4) p = r[(e ^ 4) & (E - 1)];
+                    const int i = tid * E + e;
+                    const bool keep_min = ((i & stride) == 0) == ((i & size) == 0);
+                    q[e] = keep_min ? (r[e] < p ? r[e] : p) : (r[e] > p ? r[e] : p);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) r[e] = q[e];
+            }
+        }
     __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[tid * E + e] = r[e];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lds_bitonic_sort(unsigned long long *keys, int S) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if ((nt & 63) == 0 && S == nt) return lds_bitonic_sort_regs<1>(keys, S);
+    if ((nt & 63) == 0 && S == 2 * nt) return lds_bitonic_sort_regs<2>(keys, S);
+    if ((nt & 63) == 0 && S == 4 * nt) return lds_bitonic_sort_regs<4>(keys, S);
+    if ((nt & 63) == 0 && S == 8 * nt) return lds_bitonic_sort_regs<8>(keys, S);
     for (int size = 2; size <= S; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int p = tid; p < S / 2; p += nt) {
@@ -262,6 +315,71 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
             }
             __syncthreads();
         }
+}
+
+// ------------------------------------------------------------------------------------------------ sampled selection
+// k-th smallest of the kept values in about ONE pass over the data instead of the eight of block_select_kth
+// (Floyd-Rivest style): a strided sample of <= SEL_SAMPLE kept values is sorted in LDS, two pivots lo <= hi bracket
+// the wanted rank, one pass counts the values below lo / equal to lo / equal to hi and collects the ones strictly
+// between into `cand` (LDS, `cap` doubles); the answer is then found inside the candidates.  If the bracket misses
+// or overflows — heavy-tailed sample luck, adversarial order — the full radix select runs instead, so the result is
+// ALWAYS the exact order statistic.  count = number of kept values (> k).  Also serves rank k + 1 (for the median of
+// an even count) from the same pass: *next receives it when want_next.
+constexpr int SEL_SAMPLE = 1024;
+
+template <class Val, class Keep>
+__device__ double block_select_sampled(int n, long long count, long long k, Val val, Keep keep, unsigned long long *sh,
+                                       double *cand, int cap, bool want_next, double *next, int dbg = -1) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int *ictl = reinterpret_cast<int *>(sh + 200);  // [0] ncand, [1] sample size   (sh[0..199] are used by the callees)
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(cand);
+    auto fallback = [&]() -> double {
+        const double a = block_select_kth_cold(n, k, val, keep, sh);
+        if (want_next) *next = (k + 1 < count) ? block_select_kth_cold(n, k + 1, val, keep, sh) : a;
+        return a;
+    };
+    auto lds_val = [&](int i) { return cand[i]; };
+    auto lds_all = [&](int) { return true; };
+    // ranks q (and q + 1 if want_next) among the nc candidates sitting in cand[]: sort them in place (as sortable keys,
+    // padded with +max keys to a power of two) when the padded size fits, else two radix selects
+    auto sorted_ranks = [&](int nc, long long q) -> double {
+        int S2 = 2;
+        while (S2 < nc) S2 <<= 1;
+        if (S2 > cap) {
+            const double a = block_select_kth(nc, q, lds_val, lds_all, sh);
+            if (want_next) *next = (q + 1 < nc) ? block_select_kth(nc, q + 1, lds_val, lds_all, sh) : a;
+            return a;
+        }
+        for (int i = tid; i < S2; i += nt) keys[i] = i < nc ? f64_sortable(cand[i]) : ~0ull;
+        __syncthreads();
+        lds_bitonic_sort(keys, S2);
+        const double a = f64_from_sortable(keys[q]);
+        if (want_next) *next = (q + 1 < nc) ? f64_from_sortable(keys[q + 1]) : a;
+        __syncthreads();
+        return a;
+    };
+    if (cap < 2 * SEL_SAMPLE) return fallback();
+    if (count <= (long long)cap) {
+        // everything fits: collect once, select in LDS
+        if (tid == 0) ictl[0] = 0;
+        __syncthreads();
+        strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
+            if (keep(i)) cand[atomicAdd(&ictl[0], 1)] = v;
+        });
+        __syncthreads();
+        const int nc = ictl[0];
+        return sorted_ranks(nc, k);
+    }
+    // ---- strided sample -> keys[0..S), padded with +inf keys to a power of two, bitonic sort
+    const int S = SEL_SAMPLE;
+    for (int j = tid; j < S; j += nt) {
+        const int i = (int)(((long long)j * n) / S);
+        keys[j] = keep(i) ? f64_sortable(val(i)) : ~0ull;
+    }
+    __syncthreads();
+    if (dbg == 0) return 0.0;  // (profiling aid: stop after the sample gather / sample sort / collect pass / counts)
+    lds_bitonic_sort(keys, S);
+    if (dbg == 1) return 0.0;
     // sample size = number of non-padding keys (the padding sorts to the end)
     {
         int c = 0;
@@ -269,7 +387,10 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         const long long s_all = block_count_fast(c, reinterpret_cast<long long *>(sh));
         if (s_all < 64) return fallback();  // (uniform: every thread sees the same s_all)
         const double pos = ((double)k + 0.5) * (double)s_all / (double)count;
-        const int delta = (int)(1.5 * sqrt((double)s_all)) + 6;
+        // half-width of the bracket in sample ranks: 3.4 sigma of the rank scatter of a random sample, narrowed (never
+        // below 2.6 sigma) when that keeps the expected number of candidates under ~1800, i.e. inside a 2048-key sort
+        const double sq = sqrt((double)s_all);
+        const int delta = (int)fmin(1.5 * sq + 6.0, fmax(1.2 * sq + 4.0, 1800.0 * (double)s_all / (2.0 * (double)count)));
         const int r_lo = (int)pos - delta, r_hi = (int)pos + delta;
         // pivots (registers, same in every thread): -inf / +inf when the bracket runs off the sample
         const double lo = r_lo < 0 ? -INFINITY : f64_from_sortable(keys[r_lo]);
@@ -278,9 +399,8 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         if (tid == 0) ictl[0] = 0;
         __syncthreads();
         long long c_less = 0, c_eqlo = 0, c_eqhi = 0;
-        for (int i = tid; i < n; i += nt)
+        strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
             if (keep(i)) {
-                const double v = val(i);
                 if (v < lo)
                     ++c_less;
                 else if (v == lo)
@@ -291,12 +411,25 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
                 } else if (v == hi)
                     ++c_eqhi;
             }
+        });
+        if (dbg == 2) return 0.0;
         const long long n_less = block_count_fast(c_less, reinterpret_cast<long long *>(sh));
         const long long n_eqlo = block_count_fast(c_eqlo, reinterpret_cast<long long *>(sh));
         const long long n_eqhi = block_count_fast(c_eqhi, reinterpret_cast<long long *>(sh));
         __syncthreads();
         const int nc = ictl[0];
         if (nc > cap) return fallback();
+        if (dbg == 3) return 0.0;
+        // the candidates, sorted once (keys[] aliases cand[]): rank lookups are then plain LDS reads
+        int S2 = 2;
+        while (S2 < nc) S2 <<= 1;
+        const bool sorted = S2 <= cap;
+        if (sorted) {
+            for (int i = tid; i < S2; i += nt) keys[i] = i < nc ? f64_sortable(cand[i]) : ~0ull;
+            __syncthreads();
+            lds_bitonic_sort(keys, S2);
+        }
+        if (dbg == 4) return 0.0;
         // rank r (0-based among all kept) -> value, or "miss"
         bool miss = false;
         auto at_rank = [&](long long r) -> double {
@@ -307,7 +440,7 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
             }
             if (q < n_eqlo) return lo;
             q -= n_eqlo;
-            if (q < nc) return block_select_kth(nc, q, lds_val, lds_all, sh);
+            if (q < nc) return sorted ? f64_from_sortable(keys[q]) : block_select_kth(nc, q, lds_val, lds_all, sh);
             q -= nc;
             if (q < n_eqhi) return hi;
             miss = true;
@@ -315,8 +448,17 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         };
         // (every branch above depends only on workgroup-uniform values, so the barriers inside block_select_kth are safe)
         const double a = at_rank(k);
+        if (dbg == 5) return 0.0;
         double b = a;
         if (!miss && want_next && k + 1 < count) b = at_rank(k + 1);
+        if (dbg == 6) return 0.0;
+        __syncthreads();  // every thread has read its ranks before cand[] / keys[] are reused by the caller
+        if (dbg == 7) return 0.0;
+#ifdef LK_SEL_DEBUG
+        if (tid == 0 && (blockIdx.x < 2 || miss))
+            printf("[sel] blk %d n %d count %lld k %lld s_all %lld delta %d lo %.17g hi %.17g less %lld eqlo %lld nc %d eqhi %lld miss %d a %.17g\n",
+                   blockIdx.x, n, count, k, s_all, delta, lo, hi, n_less, n_eqlo, nc, n_eqhi, (int)miss, a);
+#endif
         if (miss) return fallback();
         if (want_next) *next = b;
         return a;
@@ -326,11 +468,11 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
 // numpy.median of the kept values through block_select_sampled; NaN if none kept.
 template <class Val, class Keep>
 __device__ double block_median_sampled(int n, long long count, Val val, Keep keep, unsigned long long *sh, double *cand,
-                                       int cap) {
+                                       int cap, int dbg = -1) {
     if (count <= 0) return __longlong_as_double(0x7ff8000000000000ll);
     const long long k = (count - 1) / 2;
     double nxt = 0.0;
-    const double a = block_select_sampled(n, count, k, val, keep, sh, cand, cap, (count & 1) == 0, &nxt);
+    const double a = block_select_sampled(n, count, k, val, keep, sh, cand, cap, (count & 1) == 0, &nxt, dbg);
     return (count & 1) ? a : (a + nxt) * 0.5;
 }
 

@@ -126,24 +126,68 @@ __device__ int block_compact(int n, Pred pred, int *out, int *sh) {
     return total;
 }
 
+// The same compaction with coalesced accesses: every wave owns one contiguous strip of the index range and walks it 64
+// entries at a time (four groups in flight), positions from ballot prefixes; two barriers.
+template <class Pred>
+__device__ int strip_compact(int n, Pred pred, int *out, int *sh) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+    const int strip = ((n + nw - 1) / nw + 63) & ~63;
+    const int k_lo = min(wv * strip, n), k_hi = min(k_lo + strip, n);
+    int c = 0;
+    for (int k = k_lo + lane; k < k_hi; k += 64) c += pred(k) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __syncthreads();
+    if (lane == 0) sh[wv] = c;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < nw; ++w) {
+        if (w < wv) base += sh[w];
+        total += sh[w];
+    }
+    for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
+        bool m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane;
+            m[u] = k < k_hi && pred(k);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long bal = __ballot(m[u]);
+            if (m[u]) out[base + __popcll(bal & ((1ull << lane) - 1ull))] = k0 + 64 * u + lane;
+            base += __popcll(bal);
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
 // LDS plan (dynamic): sh[max(nt, 264)] 64-bit words | fir[FIR_LDS + 2] doubles | shi[nt] ints.  FIR_LDS = doubles of LDS
-// for a tile's inputs, FIR_TILE = FIR_LDS / 2 outputs per tile (window <= FIR_LDS - FIR_TILE + 1 takes the tiled path);
-// outside the FIR the same FIR_LDS doubles hold the candidates of the sampled order statistics (block_select.hpp).
+// for a FIR tile's inputs (8 interleaved sub-arrays, see the FIR below); outside the FIR the same doubles hold the
+// candidates of the sampled order statistics (block_select.hpp).
 
 __global__ __launch_bounds__(1024) void flatten_kernel(
     const double *__restrict__ t, const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
     const int64_t *__restrict__ n_off, int window, int polyorder, double break_tol, int niters, double sigma,
     const double *__restrict__ coeffs, const double *__restrict__ edge, char *__restrict__ scratch,
     const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask,
-    int FIR_LDS) {
+    int FIR_LDS, int stop_at) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
+    // Phase profiling aid: LK_FLAT_STOP=<16 * iteration + phase> makes every workgroup return when it reaches that
+    // point (phase numbers as in the lap() calls below), so kernel time differences between successive stop points
+    // give the cost of each phase.  Workgroup-uniform, no timers, no atomics; -1 (default) never stops.
+    int lap_iter = 0;
+#define lap(phase)                                                \
+    do {                                                          \
+        if (stop_at == 16 * lap_iter + (phase)) return;           \
+    } while (0)
     unsigned long long *sh = dyn_lds;
     const int sh_words = max((int)blockDim.x, 264);
     double *fir = reinterpret_cast<double *>(sh + sh_words);           // 16-B aligned: sh_words is even
     int *shi = reinterpret_cast<int *>(fir + FIR_LDS + 2);
     double *shd = reinterpret_cast<double *>(sh);
     long long *shl = reinterpret_cast<long long *>(sh);
-    const int FIR_TILE = FIR_LDS / 2;
     const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int64_t lo = n_off[target];
     const int N = (int)(n_off[target + 1] - lo);
@@ -174,43 +218,86 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         auto notnan = [&](int i) { return !isnan(flux[i]); };
         long long c = 0;
         double part = 0.0;
-        for (int i = tid; i < N; i += nt) {
-            const double f = flux[i];
+        strided_pass<8>(N, val, [&](int, double f) {
             if (!isnan(f)) {
                 ++c;
                 part += f;
             }
-        }
+        });
         const long long cnt = block_count_fast(c, shl);
         const double mean = block_sum_fast(part, shd) / (double)cnt;
         part = 0.0;
-        for (int i = tid; i < N; i += nt) {
-            const double f = flux[i];
+        strided_pass<8>(N, val, [&](int, double f) {
             if (!isnan(f)) {
                 const double d = f - mean;
                 part = fma(d, d, part);
             }
-        }
+        });
         const double sd = sqrt(block_sum_fast(part, shd) / (double)cnt);
         __syncthreads();
-        const double med = block_median_sampled(N, cnt, val, notnan, sh, fir, FIR_LDS);
-        for (int i = tid; i < N; i += nt) {
-            const double f = flux[i];
+        lap(0);
+        const double med = block_median_sampled(N, cnt, val, notnan, sh, fir, FIR_LDS, (stop_at >= 100 && stop_at < 200) ? stop_at - 100 : -1);
+        if (stop_at >= 100 && stop_at < 200) return;
+        lap(1);
+        strided_pass<8>(N, val, [&](int i, double f) {
             bool m = isfinite(f) && (fabs(f - med) <= sd * sigma);
             if (user_mask && user_mask[i]) m = false;
             mask[i] = m ? 1 : 0;
-        }
+        });
         __syncthreads();
+        lap(2);
     }
 
     for (int it = 0; it < niters; ++it) {
         const bool last = it == niters - 1;
-        const int nm = block_compact(N, [&](int i) { return mask[i] != 0; }, idx, shi);
-        for (int i = tid; i < nm; i += nt) {
-            tm[i] = t[idx[i]];
-            fm[i] = flux[idx[i]];
+        lap_iter = it;
+        // ---- compaction of the kept cadences, fused with the gather of their times and fluxes: every wave owns one
+        // contiguous strip of cadences (coalesced byte / double loads), counts its survivors, and after one exchange of
+        // the wave totals writes idx / tm / fm at ballot-prefix positions — order preserving, two barriers.
+        int nm;
+        {
+            const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+            const int strip = ((N + nw - 1) / nw + 63) & ~63;
+            const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
+            int c = 0;
+            for (int k = k_lo + lane; k < k_hi; k += 64) c += mask[k] ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            __syncthreads();
+            if (lane == 0) shi[wv] = c;
+            __syncthreads();
+            int base = 0, total = 0;
+            for (int w = 0; w < nw; ++w) {
+                if (w < wv) base += shi[w];
+                total += shi[w];
+            }
+            nm = total;
+            lap(3);
+            for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
+                bool m[4];
+                double tv[4], fv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // four 64-cadence groups in flight
+                    const int k = k0 + 64 * u + lane;
+                    const bool in = k < k_hi;
+                    m[u] = in && mask[k] != 0;
+                    tv[u] = in ? t[k] : 0.0;
+                    fv[u] = in ? flux[k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long bal = __ballot(m[u]);
+                    if (m[u]) {
+                        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                        idx[pos] = k0 + 64 * u + lane;
+                        tm[pos] = tv[u];
+                        fm[pos] = fv[u];
+                    }
+                    base += __popcll(bal);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        lap(4);
         if (nm == 0) {
             for (int i = tid; i < N; i += nt) trend[i] = qnan;
             __syncthreads();
@@ -222,14 +309,18 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             auto dval = [&](int i) { return tm[i + 1] - tm[i]; };
             auto dkeep = [&](int i) { return !isnan(tm[i + 1] - tm[i]); };
             long long c = 0;
-            for (int i = tid; i < nm - 1; i += nt) c += dkeep(i) ? 1 : 0;
+            strided_pass<8>(nm - 1, dval, [&](int, double d) { c += isnan(d) ? 0 : 1; });
             const long long cnt = block_count_fast(c, shl);
             __syncthreads();
-            dmed = block_median_sampled(nm - 1, cnt, dval, dkeep, sh, fir, FIR_LDS);
+            lap(5);
+            dmed = block_median_sampled(nm - 1, cnt, dval, dkeep, sh, fir, FIR_LDS, stop_at >= 200 ? stop_at - 200 : -1);
+            if (stop_at >= 200) return;
+            lap(6);
         }
         const double thr = break_tol * dmed;  // NaN break_tol => every comparison false => no cuts
-        const int nseg = block_compact(
+        const int nseg = strip_compact(
             nm, [&](int i) { return i == 0 || (tm[i] - tm[i - 1]) > thr; }, segs, shi);
+        lap(7);
         // ---- per segment: median for short ones, Savitzky-Golay otherwise   (:1030-1046)
         for (int sg = 0; sg < nseg; ++sg) {
             const int l = segs[sg], h = (sg + 1 < nseg) ? segs[sg + 1] : nm;
@@ -241,39 +332,56 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                 const double med = block_median_sampled(len, (long long)len, val, keep, sh, fir, FIR_LDS);
                 for (int i = l + tid; i < h; i += nt) tr[i] = med;
             } else {
-                // interior: correlate with the taps (window fully inside the segment).  Tiles of FIR_TILE outputs:
-                // the FIR_TILE + window - 1 inputs are staged in LDS once (coalesced), every thread then produces two
-                // neighbouring outputs from 16-B LDS reads — 4 FMAs per read, so the fp64 pipe is the limit, not L1.
+                // interior: correlate with the taps (window fully inside the segment)
                 const int o_lo = l + half, o_hi = h - half;  // outputs [o_lo, o_hi)
-                if (window + FIR_TILE - 1 <= FIR_LDS) {
-                    for (int o0 = o_lo; o0 < o_hi; o0 += FIR_TILE) {
-                        const int no = min(FIR_TILE, o_hi - o0), ni = no + window - 1;
+                // Tiles of TO outputs; the tile's TO + window - 1 inputs are staged in LDS once (coalesced) as FP = 8
+                // interleaved sub-arrays (element e at [e % 8][e / 8], sub-array stride S = 4 mod 32: the staging stores
+                // and the reads below are both bank-conflict free).  A thread produces 8 NEIGHBOURING outputs from a
+                // sliding 8-value register window: per tap one 8-B LDS read (the value entering the window — lanes read
+                // consecutive addresses of one sub-array) and 8 FMAs, so the fp64 pipe is the limit, not the LDS (the
+                // 2-outputs-per-16-B-read version this replaces kept the LDS port 100 % busy at 21 % of the FMA peak).
+                // Every output accumulates its taps in the order of scipy's correlate1d, as before.
+                constexpr int FP = 8;
+                const int S = (((FIR_LDS / FP) - 4) / 32) * 32 + 4;
+                const int TO = S >= 36 ? ((FP * S - FP - (window - 1)) / FP) * FP : 0;
+                if (TO >= FP) {
+                    for (int o0 = o_lo; o0 < o_hi; o0 += TO) {
+                        const int no = min(TO, o_hi - o0), ni = no + window - 1;
                         __syncthreads();
-                        for (int i = tid; i < ni; i += nt) fir[i] = fm[o0 - half + i];
-                        if (tid < 2) fir[ni + tid] = 0.0;  // the pair reads run one past an odd end
+                        for (int e = tid; e < ni + FP; e += nt)   // FP look-ahead slots past the end, zero filled
+                            fir[(e % FP) * S + e / FP] = e < ni ? fm[o0 - half + e] : 0.0;
                         __syncthreads();
-                        for (int q = tid; 2 * q < no; q += nt) {
-                            const double2 *xp = reinterpret_cast<const double2 *>(fir + 2 * q);
-                            double a0 = 0.0, a1 = 0.0;
-                            double2 cur = xp[0];
-                            // out[2q] = sum_j c[j] x[2q+j], out[2q+1] = sum_j c[j] x[2q+1+j]
-                            int j = 0;
-                            for (; j + 1 < window; j += 2) {
-                                const double2 nxt = xp[(j >> 1) + 1];
-                                const double c0 = coeffs[j], c1 = coeffs[j + 1];
-                                a0 = fma(c0, cur.x, a0);
-                                a0 = fma(c1, cur.y, a0);
-                                a1 = fma(c0, cur.y, a1);
-                                a1 = fma(c1, nxt.x, a1);
-                                cur = nxt;
+                        for (int q = tid; FP * q < no; q += nt) {
+                            double win[FP], acc[FP];
+#pragma unroll
+                            for (int r = 0; r < FP; ++r) {
+                                win[r] = fir[r * S + q];  // x[8 q + r]
+                                acc[r] = 0.0;
                             }
-                            if (j < window) {  // odd window: last tap
-                                const double c0 = coeffs[j];
-                                a0 = fma(c0, cur.x, a0);
-                                a1 = fma(c0, cur.y, a1);
+                            int jb = 0;
+                            for (; jb + FP <= window; jb += FP) {
+                                const int nxt = q + 1 + jb / FP;
+#pragma unroll
+                                for (int jj = 0; jj < FP; ++jj) {
+                                    const double cj = coeffs[jb + jj];
+#pragma unroll
+                                    for (int r = 0; r < FP; ++r) acc[r] = fma(cj, win[(jj + r) & (FP - 1)], acc[r]);
+                                    win[jj] = fir[jj * S + nxt];  // x[8 q + jb + jj + 8] replaces x[8 q + jb + jj]
+                                }
                             }
-                            tr[o0 + 2 * q] = a0;
-                            if (2 * q + 1 < no) tr[o0 + 2 * q + 1] = a1;
+                            const int nxt = q + 1 + jb / FP;
+#pragma unroll
+                            for (int jj = 0; jj < FP - 1; ++jj) {  // the window % 8 last taps
+                                if (jb + jj < window) {
+                                    const double cj = coeffs[jb + jj];
+#pragma unroll
+                                    for (int r = 0; r < FP; ++r) acc[r] = fma(cj, win[(jj + r) & (FP - 1)], acc[r]);
+                                    win[jj] = fir[jj * S + nxt];
+                                }
+                            }
+#pragma unroll
+                            for (int r = 0; r < FP; ++r)
+                                if (FP * q + r < no) tr[o0 + FP * q + r] = acc[r];
                         }
                     }
                 } else {
@@ -284,14 +392,28 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                         tr[i] = acc;
                     }
                 }
-                // edges: polynomial refit of the first / last `window` samples (mode='interp')
-                // (the device copy of the operators is transposed, [side][tap][row]: lanes read neighbouring rows)
+                // edges: polynomial refit of the first / last `window` samples (mode='interp').  The two windows are
+                // staged in LDS; thread (side, r) streams row r of the operator (stored transposed, [side][tap][row]:
+                // lanes read neighbouring rows) with 8 loads in flight — the plain tap loop was a chain of ~400
+                // dependent L2 round trips and had become the longest part of the segment.
+                __syncthreads();
+                for (int e = tid; e < 2 * window; e += nt)
+                    fir[e] = e < window ? fm[l + e] : fm[h - window + (e - window)];
+                __syncthreads();
                 for (int e = tid; e < 2 * half; e += nt) {
                     const int side = e >= half, r = e - side * half;
-                    const double *x = side ? fm + (h - window) : fm + l;
+                    const double *x = fir + side * window;
                     const double *E = edge + (size_t)side * half * window + r;
                     double acc = 0.0;
-                    for (int j = 0; j < window; ++j) acc = fma(E[(size_t)j * half], x[j], acc);
+                    int j = 0;
+                    for (; j + 8 <= window; j += 8) {
+                        double ev[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ev[u] = E[(size_t)(j + u) * half];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = fma(ev[u], x[j + u], acc);
+                    }
+                    for (; j < window; ++j) acc = fma(E[(size_t)j * half], x[j], acc);
                     tr[side ? (h - half + r) : (l + r)] = acc;
                 }
             }
@@ -299,35 +421,38 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         }
         // ---- clip: |flux - trend| < sigma * nanstd(flux - trend) + 1e-14   (:1049-1052)
         {
+            lap(8);
+            auto resid = [&](int i) { return fm[i] - tr[i]; };
             double part = 0.0;
-            for (int i = tid; i < nm; i += nt) part += fm[i] - tr[i];
+            strided_pass<8>(nm, resid, [&](int, double r) { part += r; });
             const double mean = block_sum_fast(part, shd) / (double)nm;
             part = 0.0;
-            for (int i = tid; i < nm; i += nt) {
-                const double d = (fm[i] - tr[i]) - mean;
+            strided_pass<8>(nm, resid, [&](int, double r) {
+                const double d = r - mean;
                 part = fma(d, d, part);
-            }
+            });
             const double sd = sqrt(block_sum_fast(part, shd) / (double)nm);
             const double lim = sd * sigma + 1e-14;
             // mask1, and mask[mask] &= mask1 (:1060-1063) in the same sweep
-            for (int i = tid; i < nm; i += nt) {
-                const bool keepit = fabs(fm[i] - tr[i]) < lim;
+            strided_pass<8>(nm, resid, [&](int i, double r) {
+                const bool keepit = fabs(r) < lim;
                 mask1[i] = keepit ? 1 : 0;
                 if (!keepit) mask[idx[i]] = 0;
-            }
+            });
             __syncthreads();
+            lap(9);
         }
         // ---- linear interpolation / extrapolation of the kept trend onto every cadence   (:1053-1058).  The reference
         // recomputes it in every iteration and keeps the last one; only the last one is computed here.
         if (!last) continue;
-        const int n2 = block_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
+        const int n2 = strip_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
         if (n2 < 2) {
             for (int i = tid; i < N; i += nt) trend[i] = qnan;
         } else {
-            for (int j = tid; j < n2; j += nt) {
-                xk[j] = tm[idx2[j]];
-                yk[j] = tr[idx2[j]];
-            }
+            strided_pass<8>(n2, [&](int j) { return idx2[j]; }, [&](int j, int c) {
+                xk[j] = tm[c];
+                yk[j] = tr[c];
+            });
             // After the update above mask[c] == 1 exactly for the knot cadences, in knot order.  np.searchsorted(x, xn,
             // 'left') = number of knots with x < xn = number of knot cadences before cadence k (times are sorted), less
             // any that share k's time.  Each wave owns a contiguous strip of cadences and carries a running knot count:
@@ -343,28 +468,59 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             __syncthreads();  // also orders the xk / yk stores above before the loads below
             int base = 0;
             for (int w = 0; w < wv; ++w) base += shi[w];
-            for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
-                const int k = k0 + lane;
-                const bool in = k < k_hi;
-                const bool kf = in && mask[k] != 0;
-                const unsigned long long bal = __ballot(kf);
-                if (in) {
-                    const double xn = t[k];
-                    int j = base + __popcll(bal & ((1ull << lane) - 1ull));
-                    while (j > 0 && xk[j - 1] >= xn) --j;  // equal times: not "< xn"
-                    const int hi_i = min(max(j, 1), n2 - 1), lo_i = hi_i - 1;
-                    const double x0 = xk[lo_i], x1 = xk[hi_i];
-                    const double y0 = yk[lo_i], y1 = yk[hi_i];
-                    const double slope = (y1 - y0) / (x1 - x0);
-                    trend[k] = isnan(xn) ? qnan : slope * (xn - x0) + y0;
+            for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
+                // four 64-cadence groups in flight: every stage of the dependent chain (mask/time -> knot index ->
+                // knot abscissae -> knot ordinates) is issued for all four before the next stage starts
+                bool in[4], kf[4];
+                double xn[4];
+                int j[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 64 * u + lane;
+                    in[u] = k < k_hi;
+                    kf[u] = in[u] && mask[k] != 0;
+                    xn[u] = in[u] ? t[k] : 0.0;
                 }
-                base += __popcll(bal);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long bal = __ballot(kf[u]);
+                    j[u] = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    base += __popcll(bal);
+                }
+                double xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xb[u] = (in[u] && j[u] > 0) ? xk[j[u] - 1] : -INFINITY;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (in[u] && xb[u] >= xn[u]) {  // equal times: those knots are not "< xn" (rare)
+                        --j[u];
+                        while (j[u] > 0 && xk[j[u] - 1] >= xn[u]) --j[u];
+                    }
+                }
+                double x0[4], x1[4], y0[4], y1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int hi_i = min(max(j[u], 1), n2 - 1), lo_i = hi_i - 1;
+                    x0[u] = xk[lo_i];
+                    x1[u] = xk[hi_i];
+                    y0[u] = yk[lo_i];
+                    y1[u] = yk[hi_i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (in[u]) {
+                        const double slope = (y1[u] - y0[u]) / (x1[u] - x0[u]);
+                        trend[k0 + 64 * u + lane] = isnan(xn[u]) ? qnan : slope * (xn[u] - x0[u]) + y0[u];
+                    }
+                }
             }
         }
         __syncthreads();
+        lap(10);
     }
     if (final_mask)
         for (int i = tid; i < N; i += nt) final_mask[i] = mask[i];
+#undef lap
 }
 
 int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
@@ -418,7 +574,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         soff[b + 1] = soff[b] + ((5 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + 4096);
+    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + 8192);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     int64_t *d_soff = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
@@ -427,7 +583,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
     static const int flat_nt = getenv("LK_FLAT_NT") ? atoi(getenv("LK_FLAT_NT")) : 512;  // 512 threads x 3 workgroups per CU overlap the barrier-bound phases best
-    static const int fir_lds_env = getenv("LK_FLAT_FIR") ? atoi(getenv("LK_FLAT_FIR")) : 4096;
+    static const int fir_lds_env = getenv("LK_FLAT_FIR") ? atoi(getenv("LK_FLAT_FIR")) : 4896;  // 8 x 612: 4096-output tiles at window 401
     int fir_lds = std::max(512, fir_lds_env & ~1);
     while (fir_lds < 16384 && window > fir_lds / 2 + 1) fir_lds *= 2;  // keep the tiled FIR path for long windows
     const size_t lds = (size_t)std::max(flat_nt, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)flat_nt * 4;
@@ -437,8 +593,9 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see the kernel
     hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
-                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds);
+                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

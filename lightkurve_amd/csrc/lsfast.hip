@@ -23,6 +23,8 @@
 
 namespace lk {
 
+constexpr int SPREAD_W_C = 1024;  // cells owned by one workgroup of lsf_spread_owner_kernel
+
 struct FastStats {
     double wsum, ybar, YY, t0;
     double yws, pad;  // sum w (y - ybar) (the bias entry of X^T y in the multi-term solve)
@@ -34,7 +36,8 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
                                                         const int64_t *__restrict__ n_off, int center,
                                                         double *__restrict__ w_out, double *__restrict__ wy_out,
                                                         FastStats *__restrict__ stats, double df, int nfft, int m2,
-                                                        int *__restrict__ rows_used) {
+                                                        int *__restrict__ rows_used, int *__restrict__ spread_tab,
+                                                        int ntab) {
     __shared__ double sh[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
@@ -90,6 +93,34 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
         const int any_unsorted = __syncthreads_or(unsorted);
         const bool nowrap = (t1 - t0) * (double)nfft * df * 2.0 < (double)nfft - 8.0;
         if (tid == 0) rows_used[b * 4 + 3] = (!any_unsorted && nowrap) ? 1 : 0;
+    }
+    if (spread_tab) {
+        // Search tables for the owner-computes spreader (ordered targets: grid positions grow with the cadence index).
+        // Per grid g and 1024-cell block k:  lo_tab[k] = first cadence with position >= k W - 4,  hi_tab[k] = first
+        // cadence with position >= k W + 3 — what the spreader used to find with two block-wide binary searches per
+        // workgroup.  Every cadence fills the thresholds that fall between its predecessor's position and its own.
+        int *tab = spread_tab + (size_t)b * 6 * ntab;
+        const double W = (double)SPREAD_W_C;
+        for (int g = 0; g < 3; ++g) {
+            const double dff = df * (g == 2 ? 2.0 : 1.0);
+            int *lo_tab = tab + (size_t)(2 * g) * ntab, *hi_tab = lo_tab + ntab;
+            for (int64_t i = tid; i < n; i += 256) {
+                const double p = fmod((t[lo + i] - t0) * (double)nfft * dff, (double)nfft);
+                const double pp = i > 0 ? fmod((t[lo + i - 1] - t0) * (double)nfft * dff, (double)nfft) : -1e300;
+                // thresholds x_k = k W - 4 with pp < x_k <= p
+                long long k0 = i > 0 ? (long long)floor((pp + 4.0) / W) + 1 : 0, k1 = (long long)floor((p + 4.0) / W);
+                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) lo_tab[k] = (int)i;
+                k0 = i > 0 ? (long long)floor((pp - 3.0) / W) + 1 : 0;
+                k1 = (long long)floor((p - 3.0) / W);
+                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) hi_tab[k] = (int)i;
+            }
+            // thresholds beyond the last cadence
+            const double pl = fmod((t[lo + n - 1] - t0) * (double)nfft * dff, (double)nfft);
+            for (int k = tid; k < ntab; k += 256) {
+                if ((double)k * W - 4.0 > pl) lo_tab[k] = (int)n;
+                if ((double)k * W + 3.0 > pl) hi_tab[k] = (int)n;
+            }
+        }
     }
     const double y0 = y[lo];
     double ybar = 0.0;
@@ -179,7 +210,7 @@ __global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restri
 // so workgroup (x, target, g) owns cells [x W, (x+1) W) of grid g, finds the cadences whose 4-point stencils reach
 // them by two block-wide probes, accumulates in LDS (ds_add_f64) and writes its cells once with plain, coalesced
 // stores — zeros included, so no memset and no global atomics.  g: 0 = w*y at f, 1 = w at f, 2 = w at 2 f.
-constexpr int SPREAD_W = 1024;
+constexpr int SPREAD_W = SPREAD_W_C;
 
 __global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__restrict__ t, const double *__restrict__ w,
                                                                 const double *__restrict__ wy,
@@ -187,7 +218,8 @@ __global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__r
                                                                 const FastStats *__restrict__ stats, int b0, double f0,
                                                                 double df, int nfft, int m2, int fit_mean,
                                                                 double2 *__restrict__ grids,
-                                                                const int *__restrict__ rows_used) {
+                                                                const int *__restrict__ rows_used,
+                                                                const int *__restrict__ spread_tab, int ntab) {
     __shared__ double2 acc[SPREAD_W];
     const int lb = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
     if (!rows_used[lb * 4 + 3]) return;
@@ -227,7 +259,15 @@ __global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__r
         const int cnt2 = __syncthreads_count(i2 < hi_i && pos(i2) < x);
         return lo_i + cnt2;
     };
-    const int i_lo = lower((double)c_lo - 4.0), i_hi = lower((double)c_hi + 3.0);
+    int i_lo, i_hi;
+    if (spread_tab) {  // precomputed by lsf_prep_kernel: no searching
+        const int *tab = spread_tab + ((size_t)b * 6 + 2 * g) * ntab;
+        i_lo = tab[blockIdx.x];
+        i_hi = tab[ntab + min((int)blockIdx.x + 1, ntab - 1)];
+    } else {
+        i_lo = lower((double)c_lo - 4.0);
+        i_hi = lower((double)c_hi + 3.0);
+    }
     for (int c = tid; c < SPREAD_W; c += 256) acc[c] = make_double2(0.0, 0.0);
     __syncthreads();
     const double twopi = 6.283185307179586;
@@ -836,7 +876,7 @@ __global__ __launch_bounds__(512) void fft_rows_power3_kernel(const double2 *__r
 // turn (the LDS tile is reused), each phase-2 thread keeps the <= KB outputs it owns that fall below M, and the
 // power is computed in registers: the three spectra never go to memory.
 template <int LA, int LB, int KB>
-__global__ __launch_bounds__(256) void fft_rows_power_kernel(const double2 *__restrict__ grids, int m1, int RT,
+__global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__restrict__ grids, int m1, int RT,
                                                               const int64_t *__restrict__ n_off,
                                                               const FastStats *__restrict__ stats, int b0, double f0,
                                                               double df, int64_t M, int fit_mean, int norm,
@@ -1087,12 +1127,20 @@ static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, cons
                                 hipStream_t stream, int lp = 0) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N1 = 1 << m1;
-    const int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
+    int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
+    // LK_FFT_RT=16: twice the rows per workgroup (twice the contiguous run per column tile the loads see) at the price
+    // of one workgroup per CU (140 KB of LDS at N2 = 512)
+    if (const char *e = getenv("LK_FFT_RT")) {
+        const int want = atoi(e);
+        if (want >= 1 && want <= N1 && (N1 % want) == 0 && want * std::max(A, Bq) <= 512 &&
+            (size_t)want * FST * 16 <= 160 * 1024)
+            RT = want;
+    }
     const int nt = ((RT * std::max(A, Bq) + 63) / 64) * 64;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_power_kernel<LA, LB, KB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     hipLaunchKernelGGL((fft_rows_power_kernel<LA, LB, KB>), dim3(N1 / RT, ntargets), dim3(nt), (size_t)RT * FST * 16,
@@ -1297,7 +1345,8 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
-                           (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 + 16384);
+                           (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
+                           (size_t)B * 6 * ((nfft + 1023) / 1024 + 2) * 4 + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
@@ -1335,8 +1384,11 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     int *d_plan = (int *)h->ws.alloc(64);
+    const bool tab_env = getenv("LK_LSF_TABLES") ? atoi(getenv("LK_LSF_TABLES")) != 0 : true;
+    const int ntab = (nfft + SPREAD_W - 1) / SPREAD_W + 2;
+    int *d_tab = (reg_path && tab_env) ? (int *)h->ws.alloc((size_t)B * 6 * ntab * 4) : nullptr;
     hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
-                       d_w, d_wy, d_stats, df, nfft, m2, d_rows);
+                       d_w, d_wy, d_stats, df, nfft, m2, d_rows, d_tab, ntab);
     // ---- plan: the pruned column kernel applies when every grid of every target keeps its samples in the first
     // P <= 256 rows (P < N1) and the row kernel can read 16-column tiles.  The decision needs one device word, so
     // the call synchronises `stream` once here (20-30 us against a >= 1 ms step).
@@ -1390,7 +1442,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         if (reg_path)
             hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)((nfft + SPREAD_W - 1) / SPREAD_W), nb, 3),
                                dim3(256), 0, ss, t, d_w, d_wy, d_off, d_stats, b0, f0, df, nfft, m2, fit_mean,
-                               gr, d_rows + (size_t)b0 * 4);
+                               gr, d_rows + (size_t)b0 * 4, d_tab, ntab);
         if (two_streams) {
             LK_HIP_CHECK(hipEventRecord(ev_spread[buf], ss));
             LK_HIP_CHECK(hipStreamWaitEvent(stream, ev_spread[buf], 0));
@@ -1468,7 +1520,7 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
     rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
-                       d_w, d_wy, d_stats, df, nfft, m2, (int *)nullptr);
+                       d_w, d_wy, d_stats, df, nfft, m2, (int *)nullptr, (int *)nullptr, 0);
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
     static bool attr_set = false;
     if (!attr_set) {

@@ -574,6 +574,75 @@ class BoxLeastSquaresPeriodogram(Periodogram):
         model[m_in] = y_in
         return LightCurve(time=self.time, flux=model, label="Transit Model Flux")
 
+    def compute_stats(self, period=None, duration=None, transit_time=None):
+        """Vetting statistics of one box model (reference periodogram.py:1194-1229 -> astropy
+        BoxLeastSquares.compute_stats, bls/core.py:389-570).  Same keys and values as astropy's dict (plain floats /
+        ndarrays instead of Quantities; ``transit_times`` absolute like ``self.time``).  Element-wise host arithmetic over
+        the one light curve the periodogram came from, as in the reference — no search involved."""
+        if period is None:
+            period = self.period_at_max_power
+            log.warning("No period specified. Using period at max power")
+        if duration is None:
+            duration = self.duration_at_max_power
+            log.warning("No duration specified. Using duration at max power")
+        if transit_time is None:
+            transit_time = self.transit_time_at_max_power
+            log.warning("No transit time specified. Using transit time at max power")
+        period, duration = float(period), float(duration)
+        if not (period > 0 and duration > 0):
+            raise ValueError("period and duration must be positive")
+        if duration >= period:
+            raise ValueError("The maximum transit duration must be shorter than the minimum period")
+        t0 = float(self.time[0])                         # astropy works on times relative to the first cadence
+        t = np.asarray(self.time, dtype=np.float64) - t0
+        tt = float(transit_time) - t0
+        y = np.asarray(self.flux, dtype=np.float64)
+        ivar = np.asarray(self._BLS_inputs["ivar"], dtype=np.float64)
+
+        def _compute_depth(m, y_out=None, var_out=None):
+            if np.any(m) and (var_out is None or np.isfinite(var_out)):
+                var_m = 1.0 / np.sum(ivar[m])
+                y_m = np.sum(y[m] * ivar[m]) * var_m
+                if y_out is None:
+                    return y_m, var_m
+                return y_out - y_m, np.sqrt(var_m + var_out)
+            return 0.0, np.inf
+
+        hp = 0.5 * period
+        m_in = np.abs((t - tt + hp) % period - hp) < 0.5 * duration
+        m_out = ~m_in
+        m_odd = np.abs((t - tt) % (2 * period) - period) < 0.5 * duration
+        m_even = np.abs((t - tt + period) % (2 * period) - period) < 0.5 * duration
+        y_out, var_out = _compute_depth(m_out)
+        depth = _compute_depth(m_in, y_out, var_out)
+        depth_odd = _compute_depth(m_odd, y_out, var_out)
+        depth_even = _compute_depth(m_even, y_out, var_out)
+        y_in = y_out - depth[0]
+        m_phase = np.abs((t - tt) % period - hp) < 0.5 * duration
+        depth_phase = _compute_depth(m_phase, *_compute_depth((~m_phase) & m_out))
+        m_half = np.abs((t - tt + 0.25 * period) % (0.5 * period) - 0.25 * period) < 0.5 * duration
+        depth_half = _compute_depth(m_half, *_compute_depth(~m_half))
+        transit_id = np.round((t[m_in] - tt) / period).astype(int)
+        transit_times = period * np.arange(transit_id.min(), transit_id.max() + 1) + tt
+        unique_ids, unique_counts = np.unique(transit_id, return_counts=True)
+        unique_ids -= np.min(transit_id)
+        transit_id -= np.min(transit_id)
+        counts = np.zeros(np.max(transit_id) + 1, dtype=int)
+        counts[unique_ids] = unique_counts
+        ll = -0.5 * ivar[m_in] * ((y[m_in] - y_in) ** 2 - (y[m_in] - y_out) ** 2)
+        lls = np.zeros(len(counts))
+        for i in unique_ids:
+            lls[i] = np.sum(ll[transit_id == i])
+        full_ll = -0.5 * np.sum(ivar[m_in] * (y[m_in] - y_in) ** 2)
+        full_ll -= 0.5 * np.sum(ivar[m_out] * (y[m_out] - y_out) ** 2)
+        A = np.vstack((np.sin(2 * np.pi * t / period), np.cos(2 * np.pi * t / period), np.ones_like(t))).T
+        w = np.linalg.solve(np.dot(A.T, A * ivar[:, None]), np.dot(A.T, y * ivar))
+        sin_ll = -0.5 * np.sum((y - np.dot(A, w)) ** 2 * ivar)
+        return dict(transit_times=transit_times + t0, per_transit_count=counts, per_transit_log_likelihood=lls,
+                    depth=depth, depth_phased=depth_phase, depth_half=depth_half, depth_odd=depth_odd,
+                    depth_even=depth_even, harmonic_amplitude=np.sqrt(np.sum(w[:2] ** 2)),
+                    harmonic_delta_log_likelihood=sin_ll - full_ll)
+
     def get_transit_mask(self, period=None, duration=None, transit_time=None):
         """True where the box model is in transit (reference periodogram.py:1271-1292)."""
         model = self.get_transit_model(period=period, duration=duration, transit_time=transit_time)

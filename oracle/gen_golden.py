@@ -302,6 +302,17 @@ def gen_bls_model():
     out["custom_period"] = truth["period"]
     out["custom_transit_time"] = lc.time.value[0] + 1.234
     out["period_at_max_power"] = float(pg.period_at_max_power.value)
+    # compute_stats (periodogram.py:1194-1229 -> astropy bls/core.py:389-570), default and custom parameters
+    for tag, kw in (("default", {}), ("custom", dict(period=truth["period"], duration=0.17,
+                                                      transit_time=lc.time.value[0] + 1.234))):
+        st = pg.compute_stats(**kw)
+        for k, v in st.items():
+            if k == "transit_times":
+                v = v.value if hasattr(v, "value") else v
+                v = getattr(v, "jd", v)
+            if isinstance(v, tuple):
+                v = np.array([getattr(x, "value", x) for x in v], dtype=float)
+            out["stats_%s_%s" % (tag, k)] = np.asarray(getattr(v, "value", v))
     save("bls_model", **out)
 
 
@@ -358,6 +369,13 @@ def gen_regression():
     save("regress_k8", time=t, flux=y, flux_err=err, X=X, cadence_mask=cm, prior_mu=pmu, prior_sigma=psig,
          coefficients=rc.coefficients, corrected=clc.flux.value, model=rc.model_lc.flux.value,
          outlier_mask=rc.outlier_mask)
+    # propagate_errors=True (:183-185, 280-298): coefficient covariance and the sampled model error under a fixed seed
+    rcp = RegressionCorrector(lc)
+    np.random.seed(20260925)
+    clcp = rcp.correct(dm, cadence_mask=cm, sigma=5, niters=5, propagate_errors=True)
+    save("regress_cov", time=t, flux=y, flux_err=err, X=X, cadence_mask=cm, prior_mu=pmu, prior_sigma=psig,
+         coefficients=rcp.coefficients, coefficients_err=np.asarray(rcp.coefficients_err),
+         model_err=rcp.model_lc.flux_err.value, corrected_err=clcp.flux_err.value, seed=20260925)
     # reference test KAT (tests/correctors/test_regressioncorrector.py:13-48)
     lc2 = lk.LightCurve(flux=[5, 10], flux_err=[1, 1], time=[1, 2])
     out = {}
@@ -389,7 +407,8 @@ def _pld_dump(name, tpf, aperture_mask, **correct_kw):
                threshold_mask=np.asarray(tpf.create_threshold_mask(3), bool),
                lc_flux=np.asarray(pld.lc.flux.value, float), lc_flux_err=np.asarray(pld.lc.flux_err.value, float),
                corrected=np.asarray(clc.flux.value, float), corrected_err=np.asarray(clc.flux_err.value, float),
-               outlier_mask=np.asarray(pld.outlier_mask, bool), X=np.asarray(dmc.X, float),
+               outlier_mask=np.asarray(pld.outlier_mask, bool),
+               X=np.asarray(dmc.X.toarray() if hasattr(dmc.X, "toarray") else dmc.X, float),
                prior_sigma=np.asarray(dmc.prior_sigma, float), prior_mu=np.asarray(dmc.prior_mu, float),
                block_names=np.array([m.name for m in dmc.matrices]),
                block_widths=np.array([m.shape[1] for m in dmc.matrices]),
@@ -410,6 +429,10 @@ def gen_pld():
     # (1) the 3rd-order pixel-product path; never exercised by the reference's offline tests
     _pld_dump("pld_k2sin_order3", tpf, None, pld_order=3, pca_components=16, pld_aperture_mask="all",
               normalize_background_pixels=True)
+    # (1b) the same correction through the SPARSE design-matrix branch (pldcorrector.py:194-199; regressioncorrector.py
+    #      :170-176): different spline basis (create_sparse_spline_matrix), scipy.sparse normal equations
+    _pld_dump("pld_k2sin_order3_sparse", tpf, None, pld_order=3, pca_components=16, pld_aperture_mask="all",
+              normalize_background_pixels=True, sparse=True)
     # (2) what the reference's own offline tests run (tests/test_synthetic_data.py:162-201): no MISSION keyword
     #     => order 1, 3 PCA terms, pld_aperture_mask 'empty': background(3) + spline(10+1)
     _pld_dump("pld_k2sin_default", tpf, None)

@@ -179,3 +179,20 @@ def test_bls_transit_model_and_mask(golden):
     assert np.array_equal(pg.get_transit_mask(), g["mask_default"])
     m = pg.get_transit_model(period=float(g["custom_period"]), duration=0.17, transit_time=float(g["custom_transit_time"]))
     assert np.max(np.abs(m.flux - g["model_custom"])) < 1e-12
+
+
+def test_bls_compute_stats_vs_reference(golden):
+    """BoxLeastSquaresPeriodogram.compute_stats (periodogram.py:1194-1229 -> astropy compute_stats) on the GPU periodogram:
+    every entry of astropy's dict, default (at max power) and custom parameters; 1e-10 relative."""
+    from lightkurve_amd.lightcurve import LightCurve
+    g = golden("bls_model")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    pg = lc.to_periodogram(method="bls", period=g["period"], duration=[0.05, 0.1, 0.2, 0.3])
+    for tag, kw in (("default", {}), ("custom", dict(period=float(g["custom_period"]), duration=0.17,
+                                                      transit_time=float(g["custom_transit_time"])))):
+        st = pg.compute_stats(**kw)
+        for k, v in st.items():
+            ref = g["stats_%s_%s" % (tag, k)]
+            v = np.asarray(v, dtype=float)
+            assert v.shape == ref.shape, (tag, k)
+            assert np.allclose(v, ref, rtol=1e-10, atol=1e-12), (tag, k, v, ref)

@@ -143,3 +143,44 @@ def test_cbv_gaussian_prior_golden(golden):
         assert np.array_equal(cor.outlier_mask, g["outlier_" + tag])
         assert np.max(np.abs(out.flux - g["corrected_" + tag])) <= 1e-9 * np.max(np.abs(g["corrected_" + tag]))
         assert np.allclose(cor.coefficients, g["coefficients_" + tag], rtol=1e-7, atol=1e-9 * np.abs(g["coefficients_" + tag]).max())
+
+
+def test_propagate_errors_covariance_vs_reference_golden(golden):
+    """propagate_errors=True: the coefficient covariance (inverse normal matrix of the last fit, Gauss-Jordan on the GPU)
+    against the reference's np.linalg.inv (1e-9 of each entry's scale) and, through the mirror class with the same numpy
+    seed, the sampled model uncertainty (the draws go through numpy's SVD of our covariance: 1e-6 relative)."""
+    from lightkurve_amd import LightCurve
+    from lightkurve_amd.correctors import DesignMatrix, RegressionCorrector
+    g = golden("regress_cov")
+    n = len(g["flux"])
+    r = _capi.regress_batch(g["X"], g["flux"], [0, n], err=g["flux_err"], cadence_mask=g["cadence_mask"],
+                            prior_mu=g["prior_mu"], prior_sigma=g["prior_sigma"], return_cov=True)
+    cov, ref = r["coefficients_cov"][0], g["coefficients_err"]
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    assert np.max(np.abs(cov - ref) / scale) < 1e-9
+    assert np.allclose(cov, cov.T, rtol=0, atol=1e-12 * np.max(np.abs(cov)))
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    dm = DesignMatrix(g["X"], name="X", prior_mu=g["prior_mu"], prior_sigma=g["prior_sigma"])
+    rc = RegressionCorrector(lc)
+    np.random.seed(int(g["seed"]))
+    clc = rc.correct(dm, cadence_mask=g["cadence_mask"], propagate_errors=True)
+    assert np.allclose(rc.model_lc.flux_err, g["model_err"], rtol=1e-6, atol=0)
+    assert np.allclose(clc.flux_err, g["corrected_err"], rtol=1e-8, atol=0)
+
+
+def test_covariance_batch_k135_vs_oracle():
+    rng = np.random.default_rng(7)
+    Xs, ys, es, cms = [], [], [], []
+    for n in (900, 1400):
+        X, y, err, cm = make_problem(rng, n, 135, 10, smooth=False)
+        Xs.append(X), ys.append(y), es.append(err), cms.append(cm)
+    off = np.concatenate([[0], np.cumsum([len(y) for y in ys])])
+    ps = np.full((2, 135), 10.0)
+    r = _capi.regress_batch(np.vstack(Xs), np.concatenate(ys), off, err=np.concatenate(es),
+                            cadence_mask=np.concatenate(cms), prior_mu=np.zeros((2, 135)), prior_sigma=ps, return_cov=True)
+    for b in range(2):
+        o = O.regression_correct(Xs[b], ys[b], es[b], cadence_mask=cms[b], prior_mu=np.zeros(135), prior_sigma=ps[b])
+        assert np.array_equal(r["outlier_mask"][off[b]:off[b + 1]], o["outlier_mask"])
+        ref = o["coefficients_cov"]
+        scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+        assert np.max(np.abs(r["coefficients_cov"][b] - ref) / scale) < 1e-8
