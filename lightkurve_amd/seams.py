@@ -1,21 +1,46 @@
-"""Install the HIP kernels behind the reference's own seams when astropy is importable.
+"""Install the HIP kernels behind the reference's own seams, so that an UNMODIFIED lightkurve —
+``lc.to_periodogram()``, ``lc.to_periodogram(method="bls")``, ``lc.flatten()``, ``RegressionCorrector.correct``,
+``PLDCorrector.correct`` — returns its own LightCurve / Periodogram objects with the arithmetic done in liblkhip.so.
 
-* S1: register ``'hip'`` (exact) in astropy's Lomb-Scargle ``METHODS`` and replace ``'fast'`` (the default of
-  lightkurve's ``lc.to_periodogram()``, src/lightkurve/periodogram.py:650, 961-964) by the GPU FFT path; the CPU
-  original stays reachable as ``'fast_cpu'``.
-* S2: replace ``astropy.timeseries.periodograms.bls.methods.bls_fast`` (reached from periodogram.py:1169).
+* S1  astropy Lomb-Scargle method registry (reached from src/lightkurve/periodogram.py:961-964): ``'fast'`` (lightkurve's
+      default, :650), ``'fastchi2'``, ``'chi2'`` are replaced, ``'hip'`` (exact direct sums) is added; astropy's own
+      implementations stay reachable as ``'fast_cpu'``, ``'fastchi2_cpu'``, ``'chi2_cpu'`` and are called for what the
+      kernels do not cover (``nterms`` > 4, a ``'fast'`` call with ``use_fft=False``).
+* S2  ``astropy.timeseries.periodograms.bls.methods.bls_fast`` (reached from periodogram.py:1169).
+* S3  ``lightkurve.lightcurve.LightCurve.flatten`` (lightcurve.py:943-1078): the mask / segmentation / savgol / clip /
+      interpolation loop (:996-1063) is ONE call of lk_savgol_trend_batch; the object handling around it stays lightkurve's.
+      Calls the kernel does not cover (extra ``savgol_filter`` keyword arguments, unsorted time) go to the original method.
+* S4  ``RegressionCorrector._fit_coefficients`` (regressioncorrector.py:127-189; the sigma-clip loop around it stays the
+      reference's) and — faster, ``full_loop=True`` — ``RegressionCorrector.correct`` itself (:191-309, all iterations in one
+      lk_regress_cov_batch call); ``PLDCorrector.create_design_matrix`` (pldcorrector.py:125-287) builds its PCA blocks with
+      lk_pld_design_batch.  Sparse collections are densified; ``pca_components=0`` goes to the original method.
 
-astropy is NOT available in the product interpreter of this image; the seams are exercised on the GPU box by
-``tests/test_seams_gpu.py`` under the conda interpreter that ships astropy 4.3.1.  Nothing here falls back to CPU.
+``backend`` is the module that provides the compute entry points (default: ``lightkurve_amd._capi``, i.e. the GPU).  The
+tests pass a stand-in to check the wiring against a real lightkurve on a machine without a GPU (tests/test_seams_cpu.py);
+nothing in the package itself ever substitutes a CPU implementation.
+
+astropy / lightkurve are NOT importable in the product interpreter of this image; on the GPU box the seams are exercised
+under the conda interpreter that ships astropy 4.3.1 (tests/test_seams_gpu.py).
 """
 import numpy as np
 
 from . import _capi
 
+_BACKEND = _capi
+_ORIG = {}
 
+
+def _be():
+    return _BACKEND
+
+
+# ------------------------------------------------------------------------------------------------ S1
 def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit_mean=True, center_data=True,
                     nterms=1, **unused):
     """Signature of astropy's METHODS entries (lombscargle/implementations/main.py:182-217)."""
+    if nterms > _capi.MAX_NTERMS and "chi2" in _ORIG:     # beyond the instantiated kernels: astropy's own chi2
+        return _ORIG["chi2"](t, y, dy, frequency=frequency, normalization=normalization, fit_mean=fit_mean,
+                             center_data=center_data, nterms=nterms)
     if not 1 <= nterms <= _capi.MAX_NTERMS:
         raise ValueError("the HIP kernels are instantiated for 1 <= nterms <= %d" % _capi.MAX_NTERMS)
     if normalization not in ("standard", "psd"):
@@ -26,14 +51,21 @@ def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit
     grid = exact_grid(frequency)
     kw = dict(dy=dy, fit_mean=fit_mean, center_data=center_data, normalization=normalization, nterms=nterms)
     if grid is not None:
-        return _capi.ls_power_batch(t, y, [0, len(t)], f0=grid[0], df=grid[1], M=len(frequency), **kw)[0]
-    return _capi.ls_power_batch(t, y, [0, len(t)], frequency=frequency, **kw)[0]
+        return _be().ls_power_batch(t, y, [0, len(t)], f0=grid[0], df=grid[1], M=len(frequency), **kw)[0]
+    return _be().ls_power_batch(t, y, [0, len(t)], frequency=frequency, **kw)[0]
 
 
 def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True, fit_mean=True,
                          normalization="standard", use_fft=True, trig_sum_kwds=None, nterms=1, **unused):
     """Signature of astropy's lombscargle_fast / lombscargle_fastchi2 (fast_impl.py:6, fastchi2_impl.py:8): the
     f0/df/Nf form every 'fast*' method receives; ``nterms`` > 1 arrives only under the name 'fastchi2'."""
+    kw = dict(trig_sum_kwds or {})
+    unsupported = nterms > _capi.MAX_NTERMS or not use_fft or int(kw.get("Mfft", 4)) != 4
+    if unsupported and ("fastchi2" if nterms > 1 else "fast") in _ORIG:
+        name = "fastchi2" if nterms > 1 else "fast"
+        extra = dict(nterms=nterms) if nterms > 1 else {}
+        return _ORIG[name](t, y, dy, f0=f0, df=df, Nf=Nf, center_data=center_data, fit_mean=fit_mean,
+                           normalization=normalization, use_fft=use_fft, trig_sum_kwds=trig_sum_kwds, **extra)
     if not 1 <= nterms <= _capi.MAX_NTERMS:
         raise ValueError("the HIP kernels are instantiated for 1 <= nterms <= %d" % _capi.MAX_NTERMS)
     if normalization not in ("standard", "psd"):
@@ -44,34 +76,275 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
         raise ValueError("Frequency steps must be positive")
     if Nf <= 0:
         raise ValueError("Number of frequencies must be positive")
-    kw = dict(trig_sum_kwds or {})
     t = np.asarray(t, dtype=np.float64)
-    return _capi.ls_fast_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
+    return _be().ls_fast_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
                                center_data=center_data, normalization=normalization,
                                oversampling=int(kw.get("oversampling", 5)), nterms=nterms)[0]
 
 
+# ------------------------------------------------------------------------------------------------ S2
 def bls_fast_hip(t, y, ivar, period, duration, oversample, use_likelihood):
     """Signature of astropy's methods.bls_fast (bls/methods.py:55-95)."""
-    res = _capi.bls_batch(t, y, ivar, [0, len(t)], period, duration, oversample, use_likelihood)
+    res = _be().bls_batch(t, y, ivar, [0, len(t)], period, duration, oversample, use_likelihood)
     return tuple(res[k][0] for k in _capi.BLS_FIELDS)
 
 
-def install():
-    """Patch astropy in place; returns the list of seams installed."""
+# ------------------------------------------------------------------------------------------------ S3
+def flatten_trend_hip(time, flux, window_length=101, polyorder=2, break_tolerance=5, niters=3, sigma=3, mask=None):
+    """The trend the loop of LightCurve.flatten (lightcurve.py:996-1063) ends with, for plain arrays.
+    ``mask``: True = cadence excluded from the fit (lightkurve's ``mask=`` semantics)."""
+    t = np.ascontiguousarray(time, dtype=np.float64)
+    f = np.ascontiguousarray(flux, dtype=np.float64)
+    return _be().savgol_trend_batch(t, f, [0, len(t)], mask=mask, window_length=window_length, polyorder=polyorder,
+                                    break_tolerance=break_tolerance, niters=niters, sigma=sigma)
+
+
+def _plain(x):
+    """ndarray of a Quantity / masked Quantity / ndarray (masked entries -> NaN)."""
+    x = getattr(x, "unmasked", x)
+    return np.asarray(getattr(x, "value", x), dtype=np.float64)
+
+
+def _make_flatten(lk_lightcurve_mod):
+    orig = lk_lightcurve_mod.LightCurve.flatten
+    Quantity = lk_lightcurve_mod.Quantity
+
+    def flatten(self, window_length=101, polyorder=2, return_trend=False, break_tolerance=5, niters=3, sigma=3,
+                mask=None, **kwargs):
+        time = _plain(self.time.value)
+        if kwargs or (len(time) > 1 and np.any(np.diff(time) < 0)) or window_length % 2 != 1 or niters < 1:
+            return orig(self, window_length=window_length, polyorder=polyorder, return_trend=return_trend,
+                        break_tolerance=break_tolerance, niters=niters, sigma=sigma, mask=mask, **kwargs)
+        if polyorder >= window_length:
+            polyorder = window_length - 1
+            lk_lightcurve_mod.log.warning("polyorder must be smaller than window_length, "
+                                          "using polyorder={}.".format(polyorder))
+        flux = self.flux
+        fl = _plain(flux)
+        if hasattr(flux, "mask"):                                  # astropy >= 5: masked entries are excluded cadences
+            fl = np.where(np.asarray(flux.mask, dtype=bool), np.nan, fl)
+        trend = flatten_trend_hip(time, fl, window_length=window_length, polyorder=polyorder,
+                                  break_tolerance=break_tolerance, niters=niters, sigma=sigma,
+                                  mask=None if mask is None else np.asarray(mask, dtype=bool))
+        trend_signal = Quantity(trend, self.flux.unit)
+        import warnings
+        flatten_lc = self.copy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            flatten_lc.flux = flatten_lc.flux / trend_signal
+            flatten_lc.flux_err = flatten_lc.flux_err / trend_signal
+        flatten_lc.meta["NORMALIZED"] = True
+        if return_trend:
+            trend_lc = self.copy()
+            trend_lc.flux = trend_signal
+            return flatten_lc, trend_lc
+        return flatten_lc
+
+    flatten.__doc__ = orig.__doc__
+    return flatten
+
+
+# ------------------------------------------------------------------------------------------------ S4
+def _dense(X):
+    return np.ascontiguousarray(X.toarray() if hasattr(X, "toarray") else X, dtype=np.float64)
+
+
+def _regress(self, cadence_mask, prior_mu, prior_sigma, sigma, niters, want_cov):
+    """One lk_regress_cov_batch call over this corrector's light curve and design-matrix collection."""
+    X = _dense(self.dmc.X)
+    n = X.shape[0]
+    flux = _plain(self.lc.flux)
+    ferr = _plain(self.lc.flux_err)
+    err = None if np.all(~np.isfinite(ferr)) else ferr
+    has_prior = prior_sigma is not None
+    return _be().regress_batch(X, flux, [0, n], err=err, cadence_mask=np.asarray(cadence_mask, dtype=bool),
+                               prior_mu=np.asarray(prior_mu, dtype=np.float64) if has_prior else None,
+                               prior_sigma=np.asarray(prior_sigma, dtype=np.float64) if has_prior else None,
+                               sigma=sigma, niters=niters, return_cov=want_cov)
+
+
+def _fit_coefficients_hip(self, cadence_mask=None, prior_mu=None, prior_sigma=None, propagate_errors=False):
+    """RegressionCorrector._fit_coefficients (regressioncorrector.py:127-189): one weighted ridge fit on the GPU."""
+    if (prior_mu is None) != (prior_sigma is None):
+        raise ValueError("Please specify both `prior_mu` and `prior_sigma`")
+    if cadence_mask is None:
+        cadence_mask = np.ones(len(self.lc.flux), bool)
+    res = _regress(self, cadence_mask, prior_mu, prior_sigma, sigma=5.0, niters=1, want_cov=bool(propagate_errors))
+    w = res["coefficients"][0]
+    w_err = res["coefficients_cov"][0] if propagate_errors else np.zeros(len(w)) * np.nan
+    return w, w_err
+
+
+def _make_correct(lk_regcorr_mod):
+    LightCurve = lk_regcorr_mod.LightCurve
+    u = lk_regcorr_mod.u
+    DMC = lk_regcorr_mod.DesignMatrixCollection
+    DM = lk_regcorr_mod.DesignMatrix
+    SDM = lk_regcorr_mod.SparseDesignMatrix
+    SDMC = lk_regcorr_mod.SparseDesignMatrixCollection
+    orig = lk_regcorr_mod.RegressionCorrector.correct
+
+    def correct(self, design_matrix_collection, cadence_mask=None, sigma=5, niters=5, propagate_errors=False):
+        if not isinstance(design_matrix_collection, DMC):
+            if isinstance(design_matrix_collection, SDM):
+                design_matrix_collection = SDMC([design_matrix_collection])
+            elif isinstance(design_matrix_collection, DM):
+                design_matrix_collection = DMC([design_matrix_collection])
+        design_matrix_collection.validate()
+        self.design_matrix_collection = design_matrix_collection
+        n = len(self.lc.time)
+        self.cadence_mask = np.ones(n, bool) if cadence_mask is None else cadence_mask
+        res = _regress(self, self.cadence_mask, self.dmc.prior_mu, self.dmc.prior_sigma, sigma, niters,
+                       bool(propagate_errors))                    # the whole clip loop, :243-279, in one call
+        self.coefficients = res["coefficients"][0]
+        self.outlier_mask = res["outlier_mask"]
+        model_flux = res["model"]                                 # X.w - median(X.w)
+        if propagate_errors:                                      # :280-298, the reference's own sampling on our covariance
+            import warnings
+            self.coefficients_err = res["coefficients_cov"][0]
+            X = _dense(self.dmc.X)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                samples = np.asarray([X.dot(np.random.multivariate_normal(self.coefficients, self.coefficients_err))
+                                      for _ in range(100)]).T
+            model_err = np.abs(np.percentile(samples, [16, 84], axis=1) - np.median(samples, axis=1)[:, None].T).mean(axis=0)
+        else:
+            self.coefficients_err = np.zeros(len(self.coefficients)) * np.nan
+            model_err = np.zeros(n)
+        unit = self.lc.flux.unit
+        self.model_lc = LightCurve(time=self.lc.time, flux=u.Quantity(model_flux, unit=unit),
+                                   flux_err=u.Quantity(model_err, unit=unit))
+        self.corrected_lc = self.lc.copy()
+        self.corrected_lc.flux = self.lc.flux - self.model_lc.flux
+        self.corrected_lc.flux_err = (self.lc.flux_err ** 2 + self.model_lc.flux_err ** 2) ** 0.5
+        self.diagnostic_lightcurves = self._create_diagnostic_lightcurves()
+        return self.corrected_lc
+
+    correct.__doc__ = orig.__doc__
+    return correct
+
+
+def _make_create_design_matrix(lk_pld_mod):
+    import pandas as pd
+    orig = lk_pld_mod.PLDCorrector.create_design_matrix
+    DM = lk_pld_mod.DesignMatrix
+    DMC = lk_pld_mod.DesignMatrixCollection
+    from .correctors.pldcorrector import _finite_columns, _percentile_knots
+
+    def create_design_matrix(self, pld_order=3, pca_components=16, pld_aperture_mask=None,
+                             background_aperture_mask="background", spline_n_knots=None, spline_degree=3,
+                             normalize_background_pixels=None, sparse=False):
+        if sparse or not pca_components or pca_components < 1:
+            return orig(self, pld_order=pld_order, pca_components=pca_components, pld_aperture_mask=pld_aperture_mask,
+                        background_aperture_mask=background_aperture_mask, spline_n_knots=spline_n_knots,
+                        spline_degree=spline_degree, normalize_background_pixels=normalize_background_pixels,
+                        sparse=sparse)
+        if pld_aperture_mask is None:
+            pld_aperture_mask = "empty"
+        self.pld_aperture_mask = self.tpf._parse_aperture_mask(pld_aperture_mask)
+        self.background_aperture_mask = self.tpf._parse_aperture_mask(background_aperture_mask)
+        n = len(self.lc)
+        if spline_n_knots is None:
+            spline_n_knots = int(n / 50)
+        if normalize_background_pixels is None:
+            normalize_background_pixels = False
+        cube = np.asarray(self.tpf.flux.value, dtype=np.float32)
+        pld_pix = _finite_columns(cube[:, self.pld_aperture_mask].reshape(n, -1))
+        bkg_pix = _finite_columns(cube[:, self.background_aperture_mask].reshape(n, -1))
+        time = np.asarray(self.lc.time.value, dtype=np.float64)
+        lcf = np.asarray(self.lc.flux.value).astype(np.float32)
+        knots = _percentile_knots(time, spline_n_knots, spline_degree)
+        X, ps = _be().pld_design_batch(pld_pix[None] if pld_pix.shape[1] else None, bkg_pix[None], lcf[None], time[None],
+                                       knots[None], pld_order, pca_components, spline_degree, normalize_background_pixels)
+        X, ps = X[0], ps[0]
+        nsp = spline_n_knots + 1
+        kb = min(pca_components, bkg_pix.shape[1])
+        npld = X.shape[1] - nsp - kb
+        mats = []
+        if npld > 0:
+            mats.append(DM(pd.DataFrame(X[:, :npld]), name="pixel_series", prior_sigma=ps[:npld]))
+        mats.append(DM(pd.DataFrame(X[:, npld:npld + kb]), name="background", prior_sigma=ps[npld:npld + kb]))
+        cols = ["knot{}".format(i + 1) for i in range(spline_n_knots)] + ["offset"]
+        mats.append(DM(pd.DataFrame(X[:, npld + kb:], columns=cols), name="spline", prior_sigma=ps[npld + kb:]))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return DMC(mats)
+
+    create_design_matrix.__doc__ = orig.__doc__
+    return create_design_matrix
+
+
+# ------------------------------------------------------------------------------------------------ install / uninstall
+def install(backend=None, lightkurve=True, full_loop=True):
+    """Patch astropy (S1, S2) and, if it is importable and ``lightkurve`` is true, lightkurve (S3, S4) in place; returns
+    the list of seams installed.  ``full_loop``: replace ``RegressionCorrector.correct`` (all clip iterations in one
+    GPU call) in addition to ``_fit_coefficients``."""
+    global _BACKEND
+    _BACKEND = backend if backend is not None else _capi
     from astropy.timeseries.periodograms.bls import methods as bls_methods
     from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main
+    for name in ("fast", "fastchi2", "chi2"):
+        _ORIG.setdefault(name, ls_main.METHODS.get(name + "_cpu", ls_main.METHODS[name]))
+        ls_main.METHODS.setdefault(name + "_cpu", _ORIG[name])
     ls_main.METHODS["hip"] = lombscargle_hip
     # multi-term fits (lightkurve nterms > 1 requires the name 'chi2' or 'fastchi2', periodogram.py:948-958):
     # 'chi2' receives the raw frequency array like 'hip' does, so it can be replaced one-to-one
-    ls_main.METHODS.setdefault("chi2_cpu", ls_main.METHODS["chi2"])
     ls_main.METHODS["chi2"] = lombscargle_hip
     # the reference's DEFAULT method: lc.to_periodogram() reaches the GPU with no change on the caller's side
-    ls_main.METHODS.setdefault("fast_cpu", ls_main.METHODS["fast"])
     ls_main.METHODS["fast"] = lombscargle_fast_hip
-    ls_main.METHODS.setdefault("fastchi2_cpu", ls_main.METHODS["fastchi2"])
     ls_main.METHODS["fastchi2"] = lombscargle_fast_hip
     bls_methods._bls_fast_reference = getattr(bls_methods, "_bls_fast_reference", bls_methods.bls_fast)
     bls_methods.bls_fast = bls_fast_hip
-    return ["lombscargle:METHODS['hip']", "lombscargle:METHODS['chi2']", "lombscargle:METHODS['fast']",
+    done = ["lombscargle:METHODS['hip']", "lombscargle:METHODS['chi2']", "lombscargle:METHODS['fast']",
             "lombscargle:METHODS['fastchi2']", "bls:methods.bls_fast"]
+    if not lightkurve:
+        return done
+    try:
+        import lightkurve.lightcurve as lk_lc
+        import lightkurve.correctors.regressioncorrector as lk_rc
+        import lightkurve.correctors.pldcorrector as lk_pld
+    except ImportError:
+        return done
+    _ORIG.setdefault("flatten", lk_lc.LightCurve.flatten)
+    _ORIG.setdefault("_fit_coefficients", lk_rc.RegressionCorrector._fit_coefficients)
+    _ORIG.setdefault("correct", lk_rc.RegressionCorrector.correct)
+    _ORIG.setdefault("create_design_matrix", lk_pld.PLDCorrector.create_design_matrix)
+    lk_lc.LightCurve.flatten = _make_flatten(lk_lc)
+    done.append("lightkurve:LightCurve.flatten")
+    lk_rc.RegressionCorrector._fit_coefficients = _fit_coefficients_hip
+    done.append("lightkurve:RegressionCorrector._fit_coefficients")
+    if full_loop:
+        lk_rc.RegressionCorrector.correct = _make_correct(lk_rc)
+        done.append("lightkurve:RegressionCorrector.correct")
+    lk_pld.PLDCorrector.create_design_matrix = _make_create_design_matrix(lk_pld)
+    done.append("lightkurve:PLDCorrector.create_design_matrix")
+    return done
+
+
+def uninstall():
+    """Undo ``install()`` (restores astropy's and lightkurve's own functions)."""
+    global _BACKEND
+    _BACKEND = _capi
+    from astropy.timeseries.periodograms.bls import methods as bls_methods
+    from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main
+    for name in ("fast", "fastchi2", "chi2"):
+        if name in _ORIG:
+            ls_main.METHODS[name] = _ORIG[name]
+    ls_main.METHODS.pop("hip", None)
+    if hasattr(bls_methods, "_bls_fast_reference"):
+        bls_methods.bls_fast = bls_methods._bls_fast_reference
+    try:
+        import lightkurve.lightcurve as lk_lc
+        import lightkurve.correctors.regressioncorrector as lk_rc
+        import lightkurve.correctors.pldcorrector as lk_pld
+    except ImportError:
+        return
+    if "flatten" in _ORIG:
+        lk_lc.LightCurve.flatten = _ORIG["flatten"]
+    if "_fit_coefficients" in _ORIG:
+        lk_rc.RegressionCorrector._fit_coefficients = _ORIG["_fit_coefficients"]
+    if "correct" in _ORIG:
+        lk_rc.RegressionCorrector.correct = _ORIG["correct"]
+    if "create_design_matrix" in _ORIG:
+        lk_pld.PLDCorrector.create_design_matrix = _ORIG["create_design_matrix"]

@@ -228,6 +228,42 @@ def gen_cbv():
     save("cbv_ridge", **out)
 
 
+def gen_cbv_goodness():
+    """CBVCorrector.correct (cbvcorrector.py:397-500): bounded Brent over the ridge penalty with the over-fitting metric as
+    the objective (target_under_score <= 0 skips the under-fitting metric, which needs MAST downloads), on a corrector
+    built with do_not_load_cbvs=True and the basis vectors passed as ext_dm (what the reference's own offline test does,
+    tests/correctors/test_cbvcorrector.py:350).  Also the objective on a fixed alpha grid, each with its own numpy seed."""
+    from lightkurve.correctors import CBVCorrector, DesignMatrix
+    import pandas as pd
+    rng = np.random.default_rng(23)
+    n, nv = 1500, 8
+    t = np.linspace(0, 27, n) + 1500.0
+    raw = np.column_stack([np.sin(2 * np.pi * (j + 1) * (t - 1500) / 40.0 + 0.7 * j) + 0.5 * rng.standard_normal(n).cumsum() / np.sqrt(n)
+                           for j in range(nv)])
+    cbvs, _ = np.linalg.qr(raw - raw.mean(0))
+    flux = 2000.0 * (1 + cbvs @ rng.normal(0, 0.01, nv)) + 3.0 * np.sin(2 * np.pi * (t - 1500) / 2.3) + rng.normal(0, 1.5, n)
+    err = np.full(n, 1.5) * rng.uniform(0.9, 1.1, n)
+    lc = lk.TessLightCurve(time=t, flux=flux, flux_err=err, cadenceno=np.arange(n), flux_unit=u.Unit("electron / second"))
+    dm = DesignMatrix(pd.DataFrame(cbvs, columns=["VECTOR_%d" % i for i in range(1, nv + 1)]), name="SingleScale")
+    out = dict(time=t, flux=flux, flux_err=err, cbvs=cbvs)
+    cor = CBVCorrector(lc, do_not_load_cbvs=True)
+    alphas = np.array([1e-4, 1e-2, 1.0, 1e2, 1e4])
+    over, corrected = [], []
+    for i, a in enumerate(alphas):
+        cor.correct_gaussian_prior(cbv_type=None, cbv_indices=None, alpha=a, ext_dm=dm)
+        np.random.seed(100 + i)
+        over.append(cor.over_fitting_metric(n_samples=3))
+        corrected.append(cor.corrected_lc.flux.value.copy())
+    out.update(scan_alpha=alphas, scan_over=np.array(over), scan_corrected=np.array(corrected))
+    np.random.seed(777)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        clc = cor.correct(cbv_type=None, cbv_indices=None, ext_dm=dm, alpha_bounds=[1e-4, 1e4], target_over_score=0.8,
+                          target_under_score=-1)
+    out.update(opt_alpha=cor.alpha, opt_over=cor.over_fitting_score, opt_corrected=clc.flux.value, opt_seed=777)
+    save("cbv_goodness", **out)
+
+
 def gen_pg_misc():
     """Periodogram.bin (periodogram.py:140-181) and LombScarglePeriodogram.model (:991-1018)."""
     t, y, e, truth = synth.ls_target(1, 6, 1200)
@@ -451,6 +487,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "metrics", "fold", "cbv", "bls", "bls_model", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE: a stand-in for ``lightkurve_amd._capi`` whose entry points are answered by the CPU oracle.
+
+``lightkurve_amd.seams.install(backend=...)`` takes it so that the WIRING of the seams (signatures, array plumbing, the
+lightkurve objects that come back) can be exercised against a real lightkurve on a machine without a GPU
+(tests/test_seams_cpu.py).  It is never imported by the package; the numerics of the real backend are checked on the GPU
+box (tests/test_seams_gpu.py and the parity tests)."""
+import numpy as np
+
+from oracle import np_oracle as O
+
+BLS_FIELDS = ("power", "depth", "depth_err", "duration", "transit_time", "depth_snr", "log_likelihood")
+CALLS = []     # (entry point name) of every call, so the tests can assert the seams were really taken
+
+
+def _split(a, n_off):
+    return [np.asarray(a)[n_off[b]:n_off[b + 1]] for b in range(len(n_off) - 1)]
+
+
+def ls_power_batch(t, y, n_off, dy=None, frequency=None, f0=0.0, df=0.0, M=None, fit_mean=True, center_data=True,
+                   normalization="psd", scale=None, device=0, nterms=1):
+    CALLS.append("ls_power_batch")
+    f = np.asarray(frequency, float) if frequency is not None else f0 + df * np.arange(int(M))
+    out = []
+    for b, (tt, yy) in enumerate(zip(_split(t, n_off), _split(y, n_off))):
+        d = None if dy is None else _split(np.broadcast_to(dy, np.shape(t)), n_off)[b]
+        if nterms > 1:
+            out.append(O.ls_power_chi2(tt, yy, d, f, nterms=nterms, fit_mean=fit_mean, center_data=center_data,
+                                       normalization=normalization))
+        else:
+            out.append(O.ls_power(tt, yy, d, f, fit_mean=fit_mean, center_data=center_data, normalization=normalization))
+    return np.array(out)
+
+
+def ls_fast_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True, normalization="psd",
+                  scale=None, oversampling=5, device=0, nterms=1):
+    CALLS.append("ls_fast_batch")
+    out = []
+    for b, (tt, yy) in enumerate(zip(_split(t, n_off), _split(y, n_off))):
+        d = None if dy is None else _split(np.broadcast_to(dy, np.shape(t)), n_off)[b]
+        if nterms > 1 or not fit_mean:
+            out.append(O.ls_power_fastchi2(tt, yy, d, f0, df, int(M), nterms=nterms, fit_mean=fit_mean,
+                                           center_data=center_data, normalization=normalization))
+        else:
+            out.append(O.ls_power_fast(tt, yy, d, f0, df, int(M), normalization=normalization))
+    return np.array(out)
+
+
+def bls_batch(t, y, ivar, n_off, period, duration, oversample=10, use_likelihood=True, device=0):
+    CALLS.append("bls_batch")
+    res = [O.bls(tt, yy, ww, period, duration, oversample, use_likelihood)
+           for tt, yy, ww in zip(_split(t, n_off), _split(y, n_off), _split(ivar, n_off))]
+    return {k: np.array([r[i] for r in res]) for i, k in enumerate(BLS_FIELDS)}
+
+
+def savgol_trend_batch(t, flux, n_off, mask=None, window_length=101, polyorder=2, break_tolerance=5, niters=3, sigma=3,
+                       return_fit_mask=False, device=0):
+    CALLS.append("savgol_trend_batch")
+    trends, masks = [], []
+    for b, (tt, ff) in enumerate(zip(_split(t, n_off), _split(flux, n_off))):
+        m = None if mask is None else _split(mask, n_off)[b]
+        tr, fm = O.flatten_trend(tt, ff, window_length, polyorder, break_tolerance, niters, sigma, mask=m)
+        trends.append(tr)
+        masks.append(fm)
+    tr = np.concatenate(trends)
+    return (tr, np.concatenate(masks)) if return_fit_mask else tr
+
+
+def regress_batch(X, y, n_off, err=None, cadence_mask=None, prior_mu=None, prior_sigma=None, sigma=5.0, niters=5,
+                  device=0, return_cov=False):
+    CALLS.append("regress_batch")
+    X, y = np.asarray(X, float), np.asarray(y, float)
+    B = len(n_off) - 1
+    K = X.shape[1]
+    w, model, outl, cov = [], [], [], []
+    for b in range(B):
+        s = slice(n_off[b], n_off[b + 1])
+        mu = None if prior_mu is None else np.broadcast_to(np.asarray(prior_mu, float), (B, K))[b]
+        sg = None if prior_sigma is None else np.broadcast_to(np.asarray(prior_sigma, float), (B, K))[b]
+        r = O.regression_correct(X[s], y[s], None if err is None else np.broadcast_to(err, y.shape)[s],
+                                 cadence_mask=None if cadence_mask is None else np.asarray(cadence_mask, bool)[s],
+                                 prior_mu=mu, prior_sigma=sg, sigma=sigma, niters=niters)
+        w.append(r["coefficients"]), model.append(r["model"]), outl.append(r["outlier_mask"]), cov.append(r["coefficients_cov"])
+    res = dict(coefficients=np.array(w), model=np.concatenate(model), outlier_mask=np.concatenate(outl))
+    if return_cov:
+        res["coefficients_cov"] = np.array(cov)
+    return res
+
+
+def pld_design_batch(pld_pix, bkg_pix, lc_flux, time, knots, pld_order, pca_components, spline_degree, normalize_bkg=True,
+                     device=0):
+    CALLS.append("pld_design_batch")
+    Xs, pss = [], []
+    for b in range(len(bkg_pix)):
+        P = 0 if pld_pix is None else pld_pix[b].shape[1]
+        Pb = bkg_pix[b].shape[1]
+        parts = ([pld_pix[b]] if P else []) + [bkg_pix[b]]
+        cube = np.concatenate(parts, axis=1)[:, None, :]
+        pm = np.zeros((1, P + Pb), bool)
+        pm[0, :P] = True
+        n_knots = knots.shape[1] - 2 + int(spline_degree) + 1
+        X, mu, ps, widths = O.pld_design_matrix(time[b], cube, lc_flux[b], pm, ~pm, pld_order=pld_order,
+                                                pca_components=pca_components, spline_n_knots=n_knots,
+                                                spline_degree=spline_degree, normalize_background_pixels=normalize_bkg)
+        Xs.append(X)
+        pss.append(ps)
+    return np.array(Xs), np.array(pss)

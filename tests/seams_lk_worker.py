@@ -1,0 +1,158 @@
+"""TEST INFRASTRUCTURE, runs under the conda interpreter with the REAL lightkurve (PYTHONPATH=<shims>:/root/reference/src):
+installs all four seams into lightkurve/astropy and checks that an unmodified lightkurve returns the same objects as
+without them.
+
+    seams_lk_worker.py compare <backend>     backend = "oracle" (CPU stand-in, wiring check) or "hip" (the GPU library)
+    seams_lk_worker.py reftests <backend> <reference test files ...>     run the reference's own tests with the seams active
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def backend(name):
+    if name == "oracle":
+        import oracle_backend
+        return oracle_backend
+    return None          # the real thing: lightkurve_amd._capi
+
+
+def val(x):
+    x = getattr(x, "unmasked", x)
+    return np.asarray(getattr(x, "value", x), dtype=float)
+
+
+def relerr(a, b):
+    a, b = val(a), val(b)
+    ok = np.isfinite(b)
+    assert np.array_equal(ok, np.isfinite(a)), "NaN pattern differs"
+    return float(np.max(np.abs(a[ok] - b[ok])) / max(np.max(np.abs(b[ok])), 1e-300))
+
+
+def run_all(lk):
+    """Every seam through lightkurve's public API; returns {name: object}."""
+    from lightkurve.correctors import DesignMatrix, PLDCorrector, RegressionCorrector
+    from lightkurve_amd import synth
+    import pandas as pd
+    out = {}
+    t, y, e, _ = synth.ls_target(1, 5, 2500, cadence_days=10.0 / 1440.0)
+    lc = lk.LightCurve(time=t + 2000.0, flux=y, flux_err=e)
+    out["ls_default"] = lc.to_periodogram()                                        # S1, default method 'fast'
+    out["ls_psd"] = lc.to_periodogram(normalization="psd", freq_unit="microhertz")
+    out["ls_slow_period_grid"] = lc.to_periodogram(period=np.linspace(0.5, 5, 300), ls_method="slow")
+    out["ls_chi2_nterms2"] = lc.to_periodogram(nterms=2, ls_method="chi2", oversample_factor=2)
+    out["ls_chi2_nterms5"] = lc.to_periodogram(nterms=5, ls_method="chi2", oversample_factor=1)   # beyond the kernels
+    tb, yb, eb, _ = synth.bls_target(3, 9, 2500, cadence_days=10.0 / 1440.0)
+    lcb = lk.LightCurve(time=tb + 2000.0, flux=yb, flux_err=eb)
+    out["bls"] = lcb.to_periodogram(method="bls", period=np.linspace(0.7, 8, 500), duration=[0.05, 0.1, 0.2])   # S2
+    yf = y * (1 + 0.01 * np.sin(2 * np.pi * t / 7.0))
+    yf[100] = np.nan
+    lcf = lk.LightCurve(time=t + 2000.0, flux=yf, flux_err=e)
+    flat, trend = lcf.flatten(window_length=101, return_trend=True)               # S3
+    out["flatten"], out["flatten_trend"] = flat, trend
+    m = np.zeros(len(t), bool)
+    m[500:560] = True
+    out["flatten_mask"] = lcf.flatten(window_length=51, mask=m, niters=2, sigma=4)
+    rng = np.random.default_rng(3)
+    n = len(t)
+    X = np.column_stack([np.sin(2 * np.pi * t / p) for p in (1.3, 2.9, 7.7)] + [t / t[-1], np.ones(n)])
+    yr = 1 + X[:, :4] @ np.array([3e-3, -2e-3, 1e-3, 4e-3]) + 3e-4 * rng.standard_normal(n)
+    yr[rng.integers(0, n, 12)] += 0.02
+    lcr = lk.LightCurve(time=t + 2000.0, flux=yr, flux_err=np.full(n, 3e-4))
+    cm = np.ones(n, bool)
+    cm[300:340] = False
+    rc = RegressionCorrector(lcr)
+    out["regress"] = rc.correct(DesignMatrix(pd.DataFrame(X), name="X", prior_sigma=np.array([np.inf, 0.01, 0.1, 1.0, np.inf])),
+                                cadence_mask=cm)                                   # S4
+    out["regress_coefficients"] = rc.coefficients
+    out["regress_outliers"] = rc.outlier_mask
+    out["regress_diag"] = rc.diagnostic_lightcurves["X"]
+    ref_data = "/root/reference/tests/data/synthetic/synthetic-k2-sinusoid.targ.fits.gz"
+    if os.path.exists(ref_data):
+        tpf = lk.read(ref_data)
+        pld = PLDCorrector(tpf)
+        out["pld"] = pld.correct(pld_order=2, pca_components=8, pld_aperture_mask="all")   # S4: design matrix + regression
+        out["pld_outliers"] = pld.outlier_mask
+        out["pld_blocks"] = [mm.name for mm in pld.design_matrix_collection.matrices]
+    return out
+
+
+def compare(bname):
+    import lightkurve as lk
+    from lightkurve_amd import seams
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = run_all(lk)
+        installed = seams.install(backend=backend(bname))
+        try:
+            np.random.seed(0)
+            got = run_all(lk)
+        finally:
+            seams.uninstall()
+        again = run_all(lk)                                  # uninstall really restores the reference path
+    res = {"installed": installed, "errors": {}, "types": {}}
+    tol = {"pld": 1e-6}
+    for k, r in ref.items():
+        g = got[k]
+        assert type(g) is type(r), (k, type(g), type(r))
+        res["types"][k] = type(g).__name__
+        if k.startswith("ls_") or k == "bls":
+            assert g.frequency.unit == r.frequency.unit and g.power.unit == r.power.unit, k
+            assert np.array_equal(val(g.frequency), val(r.frequency)), k
+            res["errors"][k] = relerr(g.power, r.power)
+            assert g.default_view == r.default_view
+            if k == "bls":
+                for attr in ("duration", "depth", "snr", "transit_time"):
+                    a, b = getattr(g, attr), getattr(r, attr)
+                    assert np.array_equal(val(a), val(b)), (k, attr)          # bit-exact BLS through the seam
+                assert val(g.period_at_max_power) == val(r.period_at_max_power)
+                st_g, st_r = g.compute_stats(), r.compute_stats()             # _BLS_object still works
+                assert np.allclose(val(st_g["depth"][0]), val(st_r["depth"][0]))
+            else:
+                assert val(g.frequency_at_max_power) == val(r.frequency_at_max_power), k
+                assert g._LS_object is not None
+        elif hasattr(r, "flux"):
+            assert g.flux.unit == r.flux.unit, k
+            assert np.array_equal(val(g.time.value), val(r.time.value)), k
+            res["errors"][k] = relerr(g.flux, r.flux)
+            res["errors"][k + "_err"] = relerr(g.flux_err, r.flux_err) if np.any(np.isfinite(val(r.flux_err))) else 0.0
+            assert dict(g.meta).get("NORMALIZED") == dict(r.meta).get("NORMALIZED"), k
+        elif k.endswith("outliers"):
+            assert np.array_equal(np.asarray(g), np.asarray(r)), k
+        elif k == "pld_blocks":
+            assert g == r
+        else:
+            res["errors"][k] = float(np.max(np.abs(np.asarray(g) - np.asarray(r))) / np.max(np.abs(np.asarray(r))))
+    for k, v in res["errors"].items():
+        assert v < tol.get(k.replace("_err", ""), 1e-8), (k, v)
+    # after uninstall the reference path is bit-for-bit back
+    for k in ("ls_default", "bls"):
+        assert np.array_equal(val(again[k].power), val(ref[k].power)), k
+    assert np.array_equal(val(again["flatten"].flux), val(ref["flatten"].flux), equal_nan=True)
+    if bname == "oracle":
+        import oracle_backend
+        res["calls"] = sorted(set(oracle_backend.CALLS))
+    print("SEAMS_LK_RESULT " + json.dumps(res))
+
+
+def reftests(bname, files):
+    import pytest
+    from lightkurve_amd import seams
+    seams.install(backend=backend(bname))
+    rc = pytest.main(list(files) + ["-q", "-x", "-p", "no:cacheprovider", "-W", "ignore"])
+    print("SEAMS_LK_REFTESTS rc=%d" % int(rc))
+    sys.exit(int(rc))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "compare":
+        compare(sys.argv[2])
+    else:
+        reftests(sys.argv[2], sys.argv[3:])

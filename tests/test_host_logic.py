@@ -167,3 +167,46 @@ def test_cbv_collection_layout():
         cor._collection(None, None)
     with pytest.raises(ValueError):
         CBVCorrector(lc, cbvs[:10])
+
+
+def test_minimize_scalar_bounded_matches_scipy():
+    """The restated bounded Brent driver of CBVCorrector.correct visits scipy's abscissae (scipy is importable here)."""
+    scipy_opt = pytest.importorskip("scipy.optimize")
+    from lightkurve_amd.correctors.cbvcorrector import minimize_scalar_bounded
+    for f, bounds in ((lambda x: (x - 2.0) ** 2 + 0.3 * np.sin(5 * x), (0.0, 5.0)),
+                      (lambda x: -np.exp(-(np.log10(x) - 1.0) ** 2), (1e-4, 1e4)),
+                      (lambda x: abs(x - 1e3) ** 0.5, (1e-4, 1e4))):
+        seen_a, seen_b = [], []
+        ra = minimize_scalar_bounded(lambda x: (seen_a.append(x), f(x))[1], bounds, maxiter=100)
+        rb = scipy_opt.minimize_scalar(lambda x: (seen_b.append(x), f(x))[1], method="Bounded", bounds=bounds,
+                                       options={"maxiter": 100})
+        assert seen_a == seen_b
+        assert ra["x"] == rb.x and ra["fun"] == rb.fun and ra["nfev"] == rb.nfev
+
+
+def test_underfit_metric_neighbors_properties():
+    """Residual-correlation goodness (reference metrics.py:141-257) with hand-made neighbours: a target that shares a
+    systematic with its neighbours scores low, white noise scores ~0.95 (the calibration point of the reference)."""
+    from lightkurve_amd.correctors.metrics import underfit_metric_neighbors
+    from lightkurve_amd.lightcurve import LightCurve
+    rng = np.random.default_rng(3)
+    n = 3000
+    t = np.linspace(0, 27, n)
+    common = np.sin(2 * np.pi * t / 3.0)
+    neigh = 1e-3 * (common[:, None] + 0.2 * rng.standard_normal((n, 30)))
+    bad = LightCurve(time=t, flux=1.0 + 1e-3 * common + 2e-4 * rng.standard_normal(n), flux_err=np.full(n, 2e-4))
+    good = LightCurve(time=t, flux=1.0 + 2e-4 * rng.standard_normal(n), flux_err=np.full(n, 2e-4))
+    m_bad, m_good = underfit_metric_neighbors(bad, neigh), underfit_metric_neighbors(good, neigh)
+    assert m_bad < 0.1 and 0.85 < m_good <= 1.0
+    noise = 1e-3 * rng.standard_normal((n, 40))
+    assert abs(underfit_metric_neighbors(good, noise) - 0.95) < 0.05
+
+
+def test_sparse_spline_matrix_matches_reference_golden(golden):
+    """create_sparse_spline_matrix (reference designmatrix.py:896-949, the spline block of PLDCorrector(sparse=True))."""
+    from lightkurve_amd.correctors import create_sparse_spline_matrix
+    g = golden("pld_k2sin_order3_sparse")
+    w = int(g["block_widths"][-1])
+    sp = create_sparse_spline_matrix(g["time"], n_knots=10, degree=5).append_constant()
+    assert sp.shape == (len(g["time"]), w)
+    assert np.array_equal(sp.X, g["X"][:, -w:])

@@ -35,3 +35,39 @@ def test_reference_sanity_cases():
     lc_flat.flux_err += 0.5
     lc_sine.flux_err += 0.5
     assert overfit_metric_lombscargle(lc_flat, lc_sine) > 0.5
+
+
+def test_cbv_goodness_scan_and_brent_vs_reference(golden):
+    """CBVCorrector.correct (reference cbvcorrector.py:397-500, 781-854): the over-fitting objective on a grid of ridge
+    penalties (scalar path with the reference's seeds: 1e-7; batched path == the scalar loop under one seed: 1e-9) and the
+    bounded Brent optimisation (same numpy seed: alpha within 1e-3 relative — the search compares objective values that
+    agree to ~1e-8 —, corrected flux within 1e-6 of the flux scale, final score within 1e-6)."""
+    from lightkurve_amd.correctors import CBVCorrector
+    g = golden("cbv_goodness")
+    lc = LightCurve(time=g["time"], flux=g["flux"], flux_err=g["flux_err"])
+    cor = CBVCorrector(lc, g["cbvs"])
+    alphas = g["scan_alpha"]
+    scalar = []
+    for i, a in enumerate(alphas):
+        clc = cor.correct_gaussian_prior(cbv_indices="ALL", alpha=float(a))
+        assert np.max(np.abs(clc.flux - g["scan_corrected"][i])) < 1e-6 * np.median(g["flux"])
+        np.random.seed(100 + i)
+        scalar.append(cor.over_fitting_metric(n_samples=3))
+    assert np.max(np.abs(np.array(scalar) - g["scan_over"])) < 1e-7
+    # batched scan == a loop of scalar evaluations consuming one random stream in the same order
+    np.random.seed(4242)
+    loop = []
+    for a in alphas:
+        cor.correct_gaussian_prior(cbv_indices="ALL", alpha=float(a))
+        loop.append(cor.over_fitting_metric(n_samples=2))
+    np.random.seed(4242)
+    scan = cor.goodness_scan(alphas, cbv_indices="ALL", n_samples=2)
+    assert np.max(np.abs(scan["over_fitting"] - np.array(loop))) < 1e-9
+    assert np.max(np.abs(scan["corrected_flux"] - g["scan_corrected"])) < 1e-6 * np.median(g["flux"])
+    # the optimisation itself
+    np.random.seed(int(g["opt_seed"]))
+    clc = cor.correct(cbv_indices="ALL", alpha_bounds=[1e-4, 1e4], target_over_score=0.8, target_under_score=-1)
+    assert abs(cor.alpha - float(g["opt_alpha"])) < 1e-3 * float(g["opt_alpha"])
+    assert abs(cor.over_fitting_score - float(g["opt_over"])) < 1e-6
+    assert cor.under_fitting_score == -1.0
+    assert np.max(np.abs(clc.flux - g["opt_corrected"])) < 1e-6 * np.median(g["flux"])
