@@ -575,19 +575,18 @@ def main():
             if method == "fast":
                 nfft = 1 << int(np.ceil(np.log2(5 * M)))
                 n2 = 1 << (int(np.log2(nfft)) // 2)
-                fused_spread = os.environ.get("LK_LSF_SPREAD_FUSED", "1") != "0"
-                used = 0.0   # grid rows that can hold samples: written by the stand-alone spreader and read by FFT step 1
-                if not fused_spread:
-                    for b in range(B):
-                        span = (t[off[b + 1] - 1] - t[off[b]]) * nfft * df
-                        used += 2 * min(nfft, (int((span + 4) / n2) + 1) * n2) + min(nfft, (int((2 * span + 4) / n2) + 1) * n2)
+                fused_spread = False   # the extirpolation is its own kernel (lsf_spread_owner_kernel), its output is real traffic
+                used = 0.0   # grid rows that can hold samples: written by the spreader and read by FFT step 1
+                for b in range(B):
+                    span = (t[off[b + 1] - 1] - t[off[b]]) * nfft * df
+                    used += 2 * min(nfft, (int((span + 4) / n2) + 1) * n2) + min(nfft, (int((2 * span + 4) / n2) + 1) * n2)
                 algo = B * (3 * nfft * 16.0 * 2 + 8.0 * M) + used * 16.0 * 2 + 40.0 * float(off[-1])
                 r01 = B * (3 * nfft * 16.0 * 2 + 3 * M * 16.0 * 2 + 8.0 * M) + 16.0 * float(off[-1])
                 tr = traffic_all.get("ls_fast")
                 rl = {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
-                      "kernel": "lsf_cols kernel (FFT step 1%s) + fft_rows_power_kernel (FFT step 2 + closed form): whole step"
-                                % (" with the extirpolation fused in" if fused_spread else ", after lsf_spread_owner_kernel"),
+                      "kernel": "lsf_spread_owner_kernel + fft_cols_pruned_kernel (FFT step 1) + fft_rows_power_kernel (FFT step 2 "
+                                "+ closed form): whole step",
                       "kernel_ms_per_step": kms, "algorithmic_bytes_per_step": algo,
                       "note": "algorithmic bytes per target: 3 complex fp64 grids of Nfft=%d written by FFT step 1 and read by "
                               "step 2 (2 x 16 B x Nfft each)%s, 40 B/cadence (t, y in; w, w*y written by the prep kernel and "

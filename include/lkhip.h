@@ -155,6 +155,15 @@ int lk_pg_boxsmooth_batch(lk_handle *h, int B, int64_t M, const double *power, c
 int lk_pg_boxsmooth_batch_dev(lk_handle *h, int B, int64_t M, const double *power, const double *taps, int nk,
                               double *out, void *stream);
 
+/* ---- seismology 2-D autocorrelation (src/lightkurve/seismology/numax_estimators.py:15-205 over seismology/utils.py:
+ * 106-158): for n_win windows of W samples starting at win_start[k] (HOST array) of each of B periodograms on one grid,
+ * the autocorrelation C[lag] = sum_i p[i] p[i + lag], lag < W, of the window minus its nanmean, and the mean collapsed
+ * correlation metric[k] = (sum_lag |C[lag]| - 1) / W.  acf2d: B x n_win x W (window-major); metric: B x n_win. */
+int lk_pg_acf2d_batch(lk_handle *h, int B, int64_t M, const double *power, int n_win, const int32_t *win_start, int W,
+                      double *acf2d, double *metric);
+int lk_pg_acf2d_batch_dev(lk_handle *h, int B, int64_t M, const double *power, int n_win, const int32_t *win_start,
+                          int W, double *acf2d, double *metric, void *stream);
+
 /* ---- Lomb-Scargle, lightkurve's DEFAULT method ls_method="fast" (periodogram.py:650): Press & Rybicki extirpolation
  * + FFT evaluation of the trig sums (astropy fast_impl.py / utils.py trig_sum, extirpolate), regular grid only.
  * Agrees with the reference's 'fast' output to ~1e-10 (and, like it, is ~1e-3 of the peak from the exact methods).

@@ -80,6 +80,10 @@ SIGNATURES = [
     ("lk_pg_boxsmooth_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, _c_dp, ctypes.c_int, _c_dp]),
     ("lk_pg_boxsmooth_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, ctypes.c_int64, _vp, _c_dp, ctypes.c_int, _vp, _vp]),
+    ("lk_pg_acf2d_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, ctypes.c_int, _c_i32p, ctypes.c_int, _c_dp, _c_dp]),
+    ("lk_pg_acf2d_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _c_i32p, ctypes.c_int, _vp, _vp, _vp]),
     ("lk_argmax_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, _c_dp, _c_ip]),
     ("lk_argmax_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("lk_bls_batch", ctypes.c_int,
@@ -359,6 +363,22 @@ def pg_boxsmooth_batch(power, kernel, device=0):
     out = np.empty_like(power)
     _check(_lib.lk_pg_boxsmooth_batch(h._h, B, M, _ptr(power), _ptr(taps), int(taps.size), _ptr(out)))
     return out
+
+
+def pg_acf2d_batch(power, win_start, W, device=0):
+    """Windowed autocorrelations of B periodograms on one grid (power float64[B, M]): for every window start the ACF of
+    the W mean-subtracted samples and the mean collapsed correlation.  Returns (acf2d[B, n_win, W], metric[B, n_win])."""
+    h = Handle.get(device)
+    power = np.ascontiguousarray(np.atleast_2d(power), dtype=np.float64)
+    B, M = power.shape
+    ws = np.ascontiguousarray(win_start, dtype=np.int32).ravel()
+    W = int(W)
+    if ws.size and (ws.min() < 0 or int(ws.max()) + W > M):
+        raise ValueError("a window reaches outside the spectrum")
+    acf = np.empty((B, ws.size, W), dtype=np.float64)
+    met = np.empty((B, ws.size), dtype=np.float64)
+    _check(_lib.lk_pg_acf2d_batch(h._h, B, M, _ptr(power), int(ws.size), _ptr(ws, _c_i32p), W, _ptr(acf), _ptr(met)))
+    return acf, met
 
 
 def argmax_batch(x, device=0):

@@ -294,6 +294,33 @@ int lk_pg_boxsmooth_batch(lk_handle *h, int B, int64_t M, const double *power, c
     });
 }
 
+int lk_pg_acf2d_batch_dev(lk_handle *h, int B, int64_t M, const double *power, int n_win, const int32_t *win_start,
+                          int W, double *acf2d, double *metric, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::pg_acf2d_launch(h, B, M, power, n_win, win_start, W, acf2d, metric, static_cast<hipStream_t>(stream));
+}
+
+int lk_pg_acf2d_batch(lk_handle *h, int B, int64_t M, const double *power, int n_win, const int32_t *win_start, int W,
+                      double *acf2d, double *metric) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && M >= 1 && n_win >= 0 && W >= 1, "bad shapes");
+    if (B == 0 || n_win == 0) return LK_OK;
+    LK_REQUIRE(power && acf2d && metric, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t pb = (size_t)B * (size_t)M * 8, ab = (size_t)B * n_win * (size_t)W * 8, mb = (size_t)B * n_win * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(pb + ab + mb + 3 * 256 + 4096);
+    if (rc) return rc;
+    double *dp = (double *)h->staging.alloc(pb), *da = (double *)h->staging.alloc(ab), *dm = (double *)h->staging.alloc(mb);
+    LK_HIP_CHECK(hipMemcpy(dp, power, pb, hipMemcpyHostToDevice));
+    rc = lk::pg_acf2d_launch(h, B, M, dp, n_win, win_start, W, da, dm, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(acf2d, da, ab, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(metric, dm, mb, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ LS 'fast'
 int lk_ls_fast_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y,
                          const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,

@@ -121,6 +121,8 @@ int pg_logmedian_launch(lk_handle *h, int B, int64_t M, const double *power, int
                         hipStream_t stream);
 int pg_boxsmooth_launch(lk_handle *h, int B, int64_t M, const double *power, const double *taps_host, int nk,
                         double *out, hipStream_t stream);
+int pg_acf2d_launch(lk_handle *h, int B, int64_t M, const double *power, int n_win, const int *win_start_host, int W,
+                    double *acf2d, double *metric, hipStream_t stream);
 int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
                   double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
                   const double *scale, int oversampling, double *power, hipStream_t stream);

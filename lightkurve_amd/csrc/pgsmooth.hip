@@ -149,4 +149,116 @@ int pg_boxsmooth_launch(lk_handle *h, int B, int64_t M, const double *power, con
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ seismology 2-D ACF
+// estimate_numax_acf2d (reference src/lightkurve/seismology/numax_estimators.py:15-205) slides a window of W = 2 spread
+// samples over the spectrum and, for every central frequency, takes the full autocorrelation of the mean-subtracted
+// window (seismology/utils.py:106-158: p_sel -= nanmean(p_sel); C = np.correlate(p_sel, p_sel, "full")[W - 1:]) and the
+// "mean collapsed correlation" (sum |C| - 1) / W.  One workgroup per (window, periodogram): the window lives in LDS, a
+// thread owns four consecutive lags and slides a four-value register window over the samples (one broadcast read and one
+// new sample per four FMAs).  W^2 / 2 MACs per window, everything on chip; HBM traffic is W in and W out per window.
+__global__ __launch_bounds__(256) void pg_acf2d_kernel(const double *__restrict__ power, int64_t M,
+                                                        const int *__restrict__ win_start, int n_win, int W,
+                                                        double *__restrict__ acf2d, double *__restrict__ metric) {
+    extern __shared__ __attribute__((aligned(16))) double acf_lds[];  // W + 8 samples | 8 doubles of reduction scratch
+    double *p = acf_lds, *red = acf_lds + W + 8;
+    const int w = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const double *src = power + (size_t)b * (size_t)M + win_start[w];
+    double s = 0.0;
+    long long c = 0;
+    for (int i = tid; i < W; i += 256) {
+        const double v = src[i];
+        p[i] = v;
+        if (!isnan(v)) {
+            s += v;
+            ++c;
+        }
+    }
+    if (tid < 8) p[W + tid] = 0.0;  // the register window runs up to three samples past the end
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = s;
+        red[4 + (tid >> 6)] = (double)c;
+    }
+    __syncthreads();
+    const double mean = (red[0] + red[1] + red[2] + red[3]) / (red[4] + red[5] + red[6] + red[7]);
+    __syncthreads();
+    for (int i = tid; i < W; i += 256) p[i] -= mean;  // NaN samples stay NaN (and poison every lag, as in numpy)
+    __syncthreads();
+    double *out = acf2d + ((size_t)b * n_win + w) * (size_t)W;
+    double msum = 0.0;
+    // lags l0 .. l0 + 3; groups are dealt from both ends (short and long lags alternate) to balance the triangle
+    const int ngrp = (W + 3) / 4;
+    for (int g = tid; g < ngrp; g += 256) {
+        const int gg = (g & 1) ? (ngrp - 1 - (g >> 1)) : (g >> 1);
+        const int l0 = 4 * gg;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        double q0 = p[l0], q1 = p[l0 + 1], q2 = p[l0 + 2], q3 = p[l0 + 3];
+        // C[l] = sum_{i < W - l} p[i] p[i + l]; terms past the window's end multiply the zero pad
+        const int n_i = W - l0;
+        int i = 0;
+        for (; i < n_i - 3; ++i) {  // all four lags have a partner inside the window
+            const double x = p[i];
+            a0 = fma(x, q0, a0);
+            a1 = fma(x, q1, a1);
+            a2 = fma(x, q2, a2);
+            a3 = fma(x, q3, a3);
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = p[i + l0 + 4];
+        }
+        for (; i < n_i; ++i) {  // last three samples: lag l0 + r only pairs samples i < W - l0 - r (no 0 * NaN terms)
+            const double x = p[i];
+            a0 = fma(x, q0, a0);
+            if (i < n_i - 1) a1 = fma(x, q1, a1);
+            if (i < n_i - 2) a2 = fma(x, q2, a2);
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = 0.0;
+        }
+        if (l0 < W) { out[l0] = a0; msum += fabs(a0); }
+        if (l0 + 1 < W) { out[l0 + 1] = a1; msum += fabs(a1); }
+        if (l0 + 2 < W) { out[l0 + 2] = a2; msum += fabs(a2); }
+        if (l0 + 3 < W) { out[l0 + 3] = a3; msum += fabs(a3); }
+    }
+    for (int o = 32; o > 0; o >>= 1) msum += __shfl_xor(msum, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = msum;
+    __syncthreads();
+    if (tid == 0) metric[(size_t)b * n_win + w] = ((red[0] + red[1] + red[2] + red[3]) - 1.0) / (double)W;
+}
+
+int pg_acf2d_launch(lk_handle *h, int B, int64_t M, const double *power, int n_win, const int *win_start_host, int W,
+                    double *acf2d, double *metric, hipStream_t stream) {
+    LK_REQUIRE(B >= 0 && M >= 1 && n_win >= 0, "need B >= 0, M >= 1, n_win >= 0");
+    if (B == 0 || n_win == 0) return LK_OK;
+    LK_REQUIRE(power && win_start_host && acf2d && metric, "NULL buffer");
+    LK_REQUIRE(W >= 1 && W <= 16384, "window of %d samples outside 1..16384", W);
+    LK_REQUIRE(B <= 65535, "at most 65535 periodograms per call");
+    for (int k = 0; k < n_win; ++k)
+        LK_REQUIRE(win_start_host[k] >= 0 && (int64_t)win_start_host[k] + W <= M, "window %d = [%d, %d) outside [0, M)", k,
+                   win_start_host[k], win_start_host[k] + W);
+    h->ws.reset();
+    int rc = h->ws.reserve((size_t)n_win * 4 + 4096);
+    if (rc) return rc;
+    int *d_start = (int *)h->ws.alloc((size_t)n_win * 4);
+    LK_HIP_CHECK(hipMemcpyAsync(d_start, win_start_host, (size_t)n_win * 4, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));
+    static bool attr = false;
+    if (!attr) {
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_acf2d_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(pg_acf2d_kernel, dim3((unsigned)n_win, (unsigned)B), dim3(256), (size_t)(W + 16) * 8, stream, power,
+                       M, d_start, n_win, W, acf2d, metric);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 }  // namespace lk

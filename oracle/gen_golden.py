@@ -154,6 +154,30 @@ def gen_pg_smooth():
     save("pg_smooth", **out)
 
 
+def gen_acf2d():
+    """estimate_numax_acf2d (seismology/numax_estimators.py:15-205) on a synthetic solar-like SNR spectrum: the 2-D ACF,
+    the mean collapsed correlation, its Gaussian smoothing and numax; plus utils.autocorrelate on one window."""
+    from lightkurve.periodogram import SNRPeriodogram
+    from lightkurve.seismology import utils as sutils
+    from lightkurve.seismology.numax_estimators import estimate_numax_acf2d
+    rng = np.random.default_rng(31)
+    out = {}
+    for tag, fmax, numax_true, dnu, M in (("rg", 280.0, 120.0, 9.5, 4200), ("ms", 4200.0, 2100.0, 100.0, 9000)):
+        f = np.linspace(1.0, fmax, M)
+        env = np.exp(-0.5 * ((f - numax_true) / (0.12 * numax_true)) ** 2)
+        comb = sum(np.exp(-0.5 * ((f - (numax_true + k * dnu)) / (0.012 * dnu + 0.3 * (f[1] - f[0]))) ** 2) for k in range(-8, 9))
+        snr = (1 + 25 * env * comb) * rng.chisquare(2, M) / 2
+        pg = SNRPeriodogram(f * u.microhertz, u.Quantity(snr, None))
+        res = estimate_numax_acf2d(pg)
+        d = res.diagnostics
+        out.update({tag + "_frequency": f, tag + "_power": snr, tag + "_numax": float(res.value),
+                    tag + "_numaxs": np.asarray(d["numaxs"]), tag + "_acf2d": np.asarray(d["acf2d"]),
+                    tag + "_window_width": float(d["window_width"]), tag + "_metric": np.asarray(d["metric"]),
+                    tag + "_metric_smooth": np.asarray(d["metric_smooth"])})
+        out[tag + "_acf_single"] = sutils.autocorrelate(pg, numax_true, window_width=float(d["window_width"]))
+    save("acf2d", **out)
+
+
 def gen_metrics():
     """overfit_metric_lombscargle (correctors/metrics.py:24-138) with the global numpy RNG seeded before each call."""
     from lightkurve.correctors.metrics import overfit_metric_lombscargle
@@ -487,6 +511,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "acf2d", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

@@ -14,7 +14,7 @@ def main():
     from astropy.timeseries import BoxLeastSquares, LombScargle
     from astropy.timeseries.periodograms.bls import methods as bls_methods
     from lightkurve_amd import seams, synth
-    installed = seams.install()
+    installed = seams.install(lightkurve=False)
     out = {"installed": installed}
     # S1: astropy LombScargle.power(method='hip') vs astropy's exact methods, both normalisations, dy on/off
     t, y, e, _ = synth.ls_target(1, 3, 2500)
@@ -66,6 +66,49 @@ def main():
                                for k in ("power", "depth", "depth_err", "duration", "depth_snr", "log_likelihood"))
         exact[objective + "_tt"] = float(np.max(np.abs(np.asarray(got.transit_time) - np.asarray(ref.transit_time))))
     out["bls_bit_exact"] = exact
+    # S3: the flatten seam's array-level function vs lightkurve's loop restated over LIVE scipy (savgol_filter of the conda
+    # scipy, linear interp1d with extrapolation): trend to 1e-10 relative, same NaN pattern
+    import scipy.signal
+    from oracle import np_oracle as O
+    O.savgol_filter = lambda x, w, p: scipy.signal.savgol_filter(x, w, p)
+    t, y, e, _ = synth.ls_target(6, 2, 6000)
+    y = y * (1 + 0.01 * np.sin(2 * np.pi * t / 5.0))
+    y[[7, 3000]] = np.nan
+    m = np.zeros(len(t), bool)
+    m[1000:1100] = True
+    s3 = {}
+    for tag, kw in (("w101", dict(window_length=101)), ("w401_mask", dict(window_length=401, mask=m, niters=2, sigma=4)),
+                    ("w51_nobreak", dict(window_length=51, break_tolerance=None))):
+        got = seams.flatten_trend_hip(t, y, **kw)
+        ref, _fm = O.flatten_trend(t, y, kw.get("window_length", 101), 2, kw.get("break_tolerance", 5), kw.get("niters", 3),
+                                   kw.get("sigma", 3), mask=kw.get("mask"))
+        ok = np.isfinite(ref)
+        assert np.array_equal(ok, np.isfinite(got)), tag
+        s3[tag] = float(np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok])))
+    out["flatten_relerr"] = s3
+    # S4: RegressionCorrector._fit_coefficients' arithmetic (one weighted ridge fit + covariance) vs numpy.linalg
+    rng = np.random.default_rng(11)
+    n, k = 3000, 40
+    X = np.column_stack([rng.standard_normal((n, k - 1)), np.ones(n)])
+    w_true = rng.normal(0, 1e-3, k)
+    err = rng.uniform(0.5, 2, n) * 2e-4
+    yy = 1 + X @ w_true + err * rng.standard_normal(n)
+    cm = rng.random(n) > 0.1
+    ps = np.where(np.arange(k) % 3 == 0, np.inf, 0.05)
+
+    class _Fake:          # what _fit_coefficients_hip reads from a RegressionCorrector
+        pass
+    fake = _Fake()
+    fake.lc = _Fake()
+    fake.lc.flux, fake.lc.flux_err = yy, err
+    fake.dmc = _Fake()
+    fake.dmc.X = X
+    w, cov = seams._fit_coefficients_hip(fake, cadence_mask=cm, prior_mu=np.zeros(k), prior_sigma=ps, propagate_errors=True)
+    A = X[cm].T @ (X[cm] / err[cm, None] ** 2) + np.diag(1 / ps ** 2)
+    wr = np.linalg.solve(A, X[cm].T @ (yy[cm] / err[cm] ** 2))
+    cr = np.linalg.inv(A)
+    out["fit_relerr"] = {"w": float(np.max(np.abs(w - wr)) / np.max(np.abs(wr))),
+                         "cov": float(np.max(np.abs(cov - cr) / np.sqrt(np.outer(np.diag(cr), np.diag(cr)))))}
     print("SEAMS_RESULT " + json.dumps(out))
 
 

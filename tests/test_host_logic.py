@@ -210,3 +210,18 @@ def test_sparse_spline_matrix_matches_reference_golden(golden):
     sp = create_sparse_spline_matrix(g["time"], n_knots=10, degree=5).append_constant()
     assert sp.shape == (len(g["time"]), w)
     assert np.array_equal(sp.X, g["X"][:, -w:])
+
+
+def test_acf2d_host_side_smoothing_and_plan(golden):
+    """Host half of estimate_numax_acf2d: default numaxs / window / spacing, window index arithmetic and the Gaussian
+    smoothing of the metric (astropy convolve, boundary='extend'), against the reference's diagnostics."""
+    from lightkurve_amd import seismology
+    from lightkurve_amd.periodogram import Periodogram
+    g = golden("acf2d")
+    for tag in ("rg", "ms"):
+        pg = Periodogram(g[tag + "_frequency"], g[tag + "_power"], frequency_unit="uHz")
+        numaxs, ww, starts, W = seismology._plan(pg, None, None, None)
+        assert np.array_equal(numaxs, g[tag + "_numaxs"]) and ww == float(g[tag + "_window_width"])
+        assert W == g[tag + "_acf2d"].shape[0] and starts.min() >= 0 and starts.max() + W <= len(g[tag + "_power"])
+        sm = seismology._gaussian_smooth_extend(g[tag + "_metric"], np.sqrt(len(numaxs)))
+        assert np.allclose(sm, g[tag + "_metric_smooth"], rtol=1e-12, atol=0)

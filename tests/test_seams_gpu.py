@@ -35,3 +35,6 @@ def test_astropy_seams_under_conda():
         assert v < 1e-9, (k, v)
     assert res["bls_bit_exact"]["likelihood"] and res["bls_bit_exact"]["snr"]
     assert res["bls_bit_exact"]["likelihood_tt"] < 1e-9
+    for k, v in res["flatten_relerr"].items():          # S3 vs live scipy
+        assert v < 1e-10, (k, v)
+    assert res["fit_relerr"]["w"] < 1e-9 and res["fit_relerr"]["cov"] < 1e-9      # S4 vs numpy.linalg
