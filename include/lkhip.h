@@ -198,6 +198,46 @@ int lk_ls_fast_peaks_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, c
 int lk_host_alloc(void **ptr, size_t bytes);
 int lk_host_free(void *ptr);
 
+/* ---- batch ingest: the steps before the hot path, for B ragged light curves -------------------
+ * lk_ingest_batch: LightCurve.remove_nans (src/lightkurve/lightcurve.py:1300-1327) + LightCurve.normalize (:1216-1292).
+ * Cadences whose flux is NaN are dropped (order kept), the batch is repacked contiguously: new_off (B + 1, HOST, written
+ * before the call returns: the call synchronises) addresses t_out / flux_out / flux_err_out (capacity: the input sizes);
+ * median_out[b] = nanmedian(flux_b) (nullable); normalize != 0 divides flux and flux_err by it.  flux_err / flux_err_out
+ * nullable (NaN errors are written when flux_err is NULL and flux_err_out is not). */
+int lk_ingest_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *flux, const double *flux_err,
+                    int normalize, double *t_out, double *flux_out, double *flux_err_out, int64_t *new_off,
+                    double *median_out);
+int lk_ingest_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
+                        const double *flux_err, int normalize, double *t_out, double *flux_out, double *flux_err_out,
+                        int64_t *new_off_host, double *median_out, void *stream);
+/* LightCurve.remove_outliers (:1430-1556): astropy.stats.sigma_clip(y, sigma, maxiters, cenfunc=median, stdfunc=std).mask
+ * for B ragged arrays: outlier[i] = 1 where the value is clipped or not finite. */
+int lk_sigma_clip_batch(lk_handle *h, int B, const int64_t *n_off, const double *y, double sigma, int maxiters,
+                        uint8_t *outlier);
+int lk_sigma_clip_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *y, double sigma, int maxiters,
+                            uint8_t *outlier, void *stream);
+/* LightCurve.create_transit_mask (:2967-3037): target b has planets [planet_off[b], planet_off[b+1]) of the HOST arrays
+ * period / duration / transit_time [d]; mask[i] = 1 where |((t - t0 + P/2) % P) - P/2| < duration/2 for any of them. */
+int lk_transit_mask_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const int32_t *planet_off,
+                          const double *period, const double *duration, const double *transit_time, uint8_t *mask);
+int lk_transit_mask_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const int32_t *planet_off,
+                              const double *period, const double *duration, const double *transit_time, uint8_t *mask,
+                              void *stream);
+/* LightCurve.bin (:1558-1763) over astropy aggregate_downsample (astropy@4.3.1 timeseries/downsample.py:12-125), times
+ * sorted.  Target b gets bins [bin_off[b], bin_off[b+1]) of the outputs; its bins start at time_bin_start[b] [d] and their
+ * edges, in seconds relative to it, are edges_sec[0 .. n_bins_b] (HOST; numpy's cumsum of the bin size, shared by all
+ * targets, n_edges entries).  A cadence at relative time r belongs to bin k when edges[k] < r <= edges[k+1] (r == 0: bin 0)
+ * and r < edges[n_bins_b].  flux_out = nanmean; flux_err_out = sqrt(nansum(err^2) / #finite) where has_err[b] (the light
+ * curve has at least one finite error), else nanstd of the flux in the bin; empty bins are NaN;
+ * t_out = time_bin_start + (edges[k] + bin_size_sec / 2) / 86400. */
+int lk_bin_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *flux, const double *flux_err,
+                 const int64_t *bin_off, const double *time_bin_start, const double *edges_sec, int64_t n_edges,
+                 double bin_size_sec, const uint8_t *has_err, double *t_out, double *flux_out, double *flux_err_out);
+int lk_bin_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
+                     const double *flux_err, const int64_t *bin_off, const double *time_bin_start, const double *edges_sec,
+                     int64_t n_edges, double bin_size_sec, const uint8_t *has_err, double *t_out, double *flux_out,
+                     double *flux_err_out, void *stream);
+
 /* ---- nanmax / nanargmax over each row of a B x M float64 matrix (first maximum wins) ---------------- */
 int lk_argmax_batch(lk_handle *h, int B, int64_t M, const double *x, double *max_out, int64_t *argmax_out);
 int lk_argmax_batch_dev(lk_handle *h, int B, int64_t M, const double *x, double *max_out,

@@ -9,5 +9,6 @@ does not load the library; the first compute call does, and fails loudly if it i
 __version__ = "0.1.0"
 
 from .lightcurve import FoldedLightCurve, LightCurve  # noqa: F401
+from .ingest import LightCurveBatch  # noqa: F401
 from .periodogram import (BoxLeastSquaresPeriodogram, LightkurveWarning, LombScarglePeriodogram,  # noqa: F401
                           Periodogram)

@@ -84,6 +84,20 @@ SIGNATURES = [
      [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, ctypes.c_int, _c_i32p, ctypes.c_int, _c_dp, _c_dp]),
     ("lk_pg_acf2d_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _c_i32p, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_sigma_clip_batch", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _c_dp, ctypes.c_double, ctypes.c_int, _c_u8p]),
+    ("lk_sigma_clip_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, ctypes.c_double, ctypes.c_int, _vp, _vp]),
+    ("lk_ingest_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_ip, _c_dp]),
+    ("lk_ingest_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _c_ip, _vp, _vp]),
+    ("lk_transit_mask_batch", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _c_dp, _c_i32p, _c_dp, _c_dp, _c_dp, _c_u8p]),
+    ("lk_transit_mask_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, _c_i32p, _c_dp, _c_dp, _c_dp, _vp, _vp]),
+    ("lk_bin_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, _c_ip, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_double, _c_u8p, _c_dp,
+      _c_dp, _c_dp]),
+    ("lk_bin_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _c_ip, _c_dp, _c_dp, ctypes.c_int64, ctypes.c_double, _c_u8p, _vp, _vp, _vp,
+      _vp]),
     ("lk_argmax_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _c_dp, _c_dp, _c_ip]),
     ("lk_argmax_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("lk_bls_batch", ctypes.c_int,
@@ -563,3 +577,93 @@ def pld_design_batch(pld_pix, bkg_pix, lc_flux, time, knots, pld_order, pca_comp
                                     _ptr(time), _ptr(knots), n_inner, int(pld_order), int(pca_components), n_knots,
                                     int(spline_degree), int(bool(normalize_bkg)), K, _ptr(X), _ptr(ps)))
     return X, ps
+
+
+# --------------------------------------------------------------------------------------------- batch ingest (N4)
+def sigma_clip_batch(y, n_off, sigma=5.0, maxiters=5, device=0):
+    """astropy.stats.sigma_clip(y_b, sigma, maxiters).mask for B ragged arrays -> bool[sum N] (True = clipped / non-finite)."""
+    h = Handle.get(device)
+    y = _f64(y)
+    n_off = _offsets(n_off, y.size)
+    out = np.zeros(y.size, dtype=np.uint8)
+    _check(_lib.lk_sigma_clip_batch(h._h, n_off.size - 1, _ptr(n_off, _c_ip), _ptr(y), float(sigma), int(maxiters),
+                                    _ptr(out, _c_u8p)))
+    return out.astype(bool)
+
+
+def ingest_batch(t, flux, n_off, flux_err=None, normalize=True, device=0):
+    """remove_nans (+ normalize) for B ragged light curves.  Returns (t, flux, flux_err or None, new_off, median[B])."""
+    h = Handle.get(device)
+    t, flux = _f64(t), _f64(flux)
+    n_off = _offsets(n_off, t.size)
+    if flux.shape != t.shape:
+        raise ValueError("t and flux must have the same length")
+    err = None if flux_err is None else _f64(np.broadcast_to(flux_err, t.shape))
+    B = n_off.size - 1
+    to, fo = np.empty_like(t), np.empty_like(t)
+    eo = np.empty_like(t) if err is not None else None
+    new_off = np.zeros(B + 1, dtype=np.int64)
+    med = np.empty(B, dtype=np.float64)
+    _check(_lib.lk_ingest_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(flux), _ptr(err), int(bool(normalize)), _ptr(to),
+                                _ptr(fo), _ptr(eo), _ptr(new_off, _c_ip), _ptr(med)))
+    k = int(new_off[-1])
+    return to[:k], fo[:k], (eo[:k] if eo is not None else None), new_off, med
+
+
+def transit_mask_batch(t, n_off, period, duration, transit_time, planet_off=None, device=0):
+    """create_transit_mask for B ragged light curves.  ``period`` / ``duration`` / ``transit_time``: flat arrays over all
+    planets, ``planet_off[B + 1]`` says which belong to which target (default: every target gets all of them)."""
+    h = Handle.get(device)
+    t = _f64(t)
+    n_off = _offsets(n_off, t.size)
+    B = n_off.size - 1
+    period, duration, transit_time = (_f64(np.atleast_1d(a)) for a in (period, duration, transit_time))
+    if not (period.shape == duration.shape == transit_time.shape):
+        raise ValueError("period, duration, and transit_time must have the same number of values.")
+    if planet_off is None:
+        k = period.size
+        period, duration, transit_time = (np.tile(a, B) for a in (period, duration, transit_time))
+        planet_off = np.arange(B + 1, dtype=np.int32) * k
+    planet_off = np.ascontiguousarray(planet_off, dtype=np.int32)
+    if planet_off.shape != (B + 1,) or planet_off[0] != 0 or planet_off[-1] != period.size:
+        raise ValueError("planet_off must be B + 1 prefix offsets over the planet arrays")
+    mask = np.zeros(t.size, dtype=np.uint8)
+    _check(_lib.lk_transit_mask_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(planet_off, _c_i32p), _ptr(period),
+                                      _ptr(duration), _ptr(transit_time), _ptr(mask, _c_u8p)))
+    return mask.astype(bool)
+
+
+def bin_batch(t, flux, n_off, flux_err=None, time_bin_size=0.5, time_bin_start=None, device=0):
+    """LightCurve.bin(time_bin_size=...) for B ragged, time-sorted light curves.
+    Returns (t_binned, flux_binned, flux_err_binned, bin_off[B + 1])."""
+    h = Handle.get(device)
+    t, flux = _f64(t), _f64(flux)
+    n_off = _offsets(n_off, t.size)
+    B = n_off.size - 1
+    err = None if flux_err is None else _f64(np.broadcast_to(flux_err, t.shape))
+    size_sec = float(time_bin_size) * 86400.0
+    if not size_sec > 0:
+        raise ValueError("time_bin_size must be positive")
+    start = np.empty(B, dtype=np.float64)
+    nb = np.zeros(B, dtype=np.int64)
+    has_err = np.zeros(B, dtype=np.uint8)
+    for b in range(B):
+        lo, hi = int(n_off[b]), int(n_off[b + 1])
+        if hi == lo:
+            start[b] = 0.0
+            continue
+        tb = t[lo:hi]
+        if np.any(np.diff(tb) < 0):
+            raise ValueError("bin needs the light curve sorted by time")
+        s0 = tb[0] if time_bin_start is None else np.broadcast_to(np.asarray(time_bin_start, float), (B,))[b]
+        start[b] = s0
+        nb[b] = max(0, int(np.ceil((tb[-1] - s0) * 86400.0 / size_sec)))     # downsample.py:75-76
+        has_err[b] = 1 if (err is not None and np.any(np.isfinite(err[lo:hi]))) else 0
+    bin_off = np.zeros(B + 1, dtype=np.int64)
+    bin_off[1:] = np.cumsum(nb)
+    edges = np.cumsum(np.hstack([0.0, np.repeat(size_sec, int(nb.max()) if B else 0)]))   # downsample.py:82
+    nbt = int(bin_off[-1])
+    to, fo, eo = (np.empty(nbt, dtype=np.float64) for _ in range(3))
+    _check(_lib.lk_bin_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(flux), _ptr(err), _ptr(bin_off, _c_ip), _ptr(start),
+                             _ptr(edges), int(edges.size), size_sec, _ptr(has_err, _c_u8p), _ptr(to), _ptr(fo), _ptr(eo)))
+    return to, fo, eo, bin_off

@@ -108,6 +108,63 @@ class PixelCube(object):
         return lc
 
 
+    def pixel_periodograms(self, frequency=None, corrector="remove_outliers", sigma=5.0, normalization="amplitude",
+                           ls_method="fast", device=0, **kwargs):
+        """One Lomb-Scargle periodogram per pixel — the loop of ``TargetPixelFile.plot_pixels(periodogram=True)``
+        (reference src/lightkurve/targetpixelfile.py:1958-1974: per pixel a one-pixel aperture light curve,
+        ``corrector_func`` (default ``remove_outliers``), ``to_periodogram(**kwargs)``) — as batched GPU calls: ONE sigma
+        clip over all pixels and ONE periodogram launch per group of pixels that share a frequency grid (all of them when
+        ``frequency`` is given; otherwise each pixel's default grid depends on which of its cadences survived the clip).
+        Returns a list (row-major over the pixels) of ``LombScarglePeriodogram`` objects, ``None`` where a pixel has no
+        usable cadence — the reference's ``pixel_list``."""
+        from .. import _capi as capi
+        from ..batch import lombscargle_batch
+        from ..periodogram import LombScarglePeriodogram, _ls_plan
+        n, nr, nc = self.shape
+        flux = np.asarray(self.flux, dtype=np.float64).reshape(n, nr * nc)
+        ferr = np.asarray(self.flux_err, dtype=np.float64).reshape(n, nr * nc)
+        npx = nr * nc
+        y = np.ascontiguousarray(flux.T).ravel()                       # pixel-major ragged batch, n cadences each
+        off = np.arange(npx + 1, dtype=np.int64) * n
+        if corrector == "remove_outliers":
+            bad = capi.sigma_clip_batch(y, off, sigma=sigma, device=device).reshape(npx, n)
+        elif corrector is None:
+            bad = np.zeros((npx, n), bool)
+        else:
+            raise ValueError("corrector must be 'remove_outliers' or None on the batched path")
+        lcs, idx = [], []
+        for j in range(npx):
+            keep = ~bad[j]
+            if not np.any(keep & np.isfinite(flux[:, j])):
+                continue
+            lcs.append(LightCurve(time=self.time[keep], flux=flux[keep, j], flux_err=ferr[keep, j], meta=dict(self.meta)))
+            idx.append(j)
+        out = [None] * npx
+        # group the pixels by frequency grid (one launch per group)
+        groups = {}
+        plans = {}
+        for lc, j in zip(lcs, idx):
+            try:
+                plan = _ls_plan(lc, frequency=frequency, normalization=normalization, ls_method=ls_method, **kwargs)
+            except IndexError:          # the reference appends None for a light curve too short for a grid
+                continue
+            plans[j] = plan
+            groups.setdefault(plan["frequency"].tobytes(), []).append(j)
+        by_pix = dict(zip(idx, lcs))
+        for key, members in groups.items():
+            p0 = plans[members[0]]
+            power = lombscargle_batch([by_pix[j] for j in members], p0["frequency"], normalization=normalization,
+                                      freq_unit=p0["freq_unit"], ls_method=ls_method, device=device, gather=False,
+                                      oversample_factor=kwargs.get("oversample_factor"), nterms=kwargs.get("nterms", 1))
+            for row, j in zip(power, members):
+                pl = plans[j]
+                out[j] = LombScarglePeriodogram(frequency=pl["frequency"], power=row, nyquist=pl["nyquist"],
+                                                default_view=pl["default_view"], ls_method=pl["ls_method"],
+                                                nterms=pl["nterms"], meta=pl["lc"].meta,
+                                                frequency_unit=pl["freq_unit"], power_unit=pl["power_unit"])
+        return out
+
+
 def _percentile_knots(time, n_knots, degree):
     """[min, interior knots, max] of patsy's bs(x, df=n_knots, degree, include_intercept=True)."""
     order = degree + 1

@@ -751,4 +751,141 @@ fail:
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------ sigma clip
+int lk_sigma_clip_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *y, double sigma, int maxiters,
+                            uint8_t *outlier, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::sigma_clip_launch(h, B, n_off_host, y, sigma, maxiters, outlier, static_cast<hipStream_t>(stream));
+}
+
+int lk_sigma_clip_batch(lk_handle *h, int B, const int64_t *n_off, const double *y, double sigma, int maxiters,
+                        uint8_t *outlier) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    if (B == 0 || n_off[B] == 0) return LK_OK;
+    LK_REQUIRE(y && outlier, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B];
+    h->staging.reset();
+    int rc = h->staging.reserve(ntot * 9 + 2 * 256 + 4096);
+    if (rc) return rc;
+    double *dy = (double *)h->staging.alloc(ntot * 8);
+    uint8_t *dm = (uint8_t *)h->staging.alloc(ntot);
+    LK_HIP_CHECK(hipMemcpy(dy, y, ntot * 8, hipMemcpyHostToDevice));
+    rc = lk::sigma_clip_launch(h, B, n_off, dy, sigma, maxiters, dm, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(outlier, dm, ntot, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batch ingest (N4)
+int lk_ingest_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
+                        const double *flux_err, int normalize, double *t_out, double *flux_out, double *flux_err_out,
+                        int64_t *new_off_host, double *median_out, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::ingest_launch(h, B, n_off_host, t, flux, flux_err, normalize, t_out, flux_out, flux_err_out, new_off_host,
+                             median_out, static_cast<hipStream_t>(stream));
+}
+
+int lk_ingest_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *flux, const double *flux_err,
+                    int normalize, double *t_out, double *flux_out, double *flux_err_out, int64_t *new_off,
+                    double *median_out) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr && new_off != nullptr, "bad batch description");
+    if (B == 0) {
+        new_off[0] = 0;
+        return LK_OK;
+    }
+    LK_REQUIRE(t && flux && t_out && flux_out, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B], nb = ntot * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(6 * (nb + 256) + (size_t)B * 8 + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(nb), *df = (double *)h->staging.alloc(nb);
+    double *de = flux_err ? (double *)h->staging.alloc(nb) : nullptr;
+    double *dto = (double *)h->staging.alloc(nb), *dfo = (double *)h->staging.alloc(nb);
+    double *deo = flux_err_out ? (double *)h->staging.alloc(nb) : nullptr;
+    double *dmed = median_out ? (double *)h->staging.alloc((size_t)B * 8) : nullptr;
+    LK_HIP_CHECK(hipMemcpy(dt, t, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(df, flux, nb, hipMemcpyHostToDevice));
+    if (flux_err) LK_HIP_CHECK(hipMemcpy(de, flux_err, nb, hipMemcpyHostToDevice));
+    rc = lk::ingest_launch(h, B, n_off, dt, df, de, normalize, dto, dfo, deo, new_off, dmed, nullptr);
+    if (rc) return rc;
+    const size_t kb = (size_t)new_off[B] * 8;
+    LK_HIP_CHECK(hipMemcpy(t_out, dto, kb, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(flux_out, dfo, kb, hipMemcpyDeviceToHost));
+    if (flux_err_out) LK_HIP_CHECK(hipMemcpy(flux_err_out, deo, kb, hipMemcpyDeviceToHost));
+    if (median_out) LK_HIP_CHECK(hipMemcpy(median_out, dmed, (size_t)B * 8, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
+int lk_transit_mask_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const int32_t *planet_off,
+                              const double *period, const double *duration, const double *transit_time, uint8_t *mask,
+                              void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::transit_mask_launch(h, B, n_off_host, t, planet_off, period, duration, transit_time, mask,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int lk_transit_mask_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const int32_t *planet_off,
+                          const double *period, const double *duration, const double *transit_time, uint8_t *mask) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr, "bad batch description");
+    if (B == 0 || n_off[B] == 0) return LK_OK;
+    LK_REQUIRE(t && mask, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B];
+    h->staging.reset();
+    int rc = h->staging.reserve(ntot * 9 + 2 * 256 + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(ntot * 8);
+    uint8_t *dm = (uint8_t *)h->staging.alloc(ntot);
+    LK_HIP_CHECK(hipMemcpy(dt, t, ntot * 8, hipMemcpyHostToDevice));
+    rc = lk::transit_mask_launch(h, B, n_off, dt, planet_off, period, duration, transit_time, dm, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(mask, dm, ntot, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
+int lk_bin_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
+                     const double *flux_err, const int64_t *bin_off, const double *time_bin_start, const double *edges_sec,
+                     int64_t n_edges, double bin_size_sec, const uint8_t *has_err, double *t_out, double *flux_out,
+                     double *flux_err_out, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::bin_launch(h, B, n_off_host, t, flux, flux_err, bin_off, time_bin_start, edges_sec, n_edges, bin_size_sec,
+                          has_err, t_out, flux_out, flux_err_out, static_cast<hipStream_t>(stream));
+}
+
+int lk_bin_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *flux, const double *flux_err,
+                 const int64_t *bin_off, const double *time_bin_start, const double *edges_sec, int64_t n_edges,
+                 double bin_size_sec, const uint8_t *has_err, double *t_out, double *flux_out, double *flux_err_out) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && n_off != nullptr && bin_off != nullptr, "bad batch description");
+    if (B == 0 || bin_off[B] == 0) return LK_OK;
+    LK_REQUIRE(t && flux && t_out && flux_out && flux_err_out, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ntot = (size_t)n_off[B], nb = ntot * 8, ob = (size_t)bin_off[B] * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(3 * (nb + 256) + 3 * (ob + 256) + 4096);
+    if (rc) return rc;
+    double *dt = (double *)h->staging.alloc(nb), *df = (double *)h->staging.alloc(nb);
+    double *de = flux_err ? (double *)h->staging.alloc(nb) : nullptr;
+    double *dto = (double *)h->staging.alloc(ob), *dfo = (double *)h->staging.alloc(ob), *deo = (double *)h->staging.alloc(ob);
+    LK_HIP_CHECK(hipMemcpy(dt, t, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(df, flux, nb, hipMemcpyHostToDevice));
+    if (flux_err) LK_HIP_CHECK(hipMemcpy(de, flux_err, nb, hipMemcpyHostToDevice));
+    rc = lk::bin_launch(h, B, n_off, dt, df, de, bin_off, time_bin_start, edges_sec, n_edges, bin_size_sec, has_err, dto, dfo,
+                        deo, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(t_out, dto, ob, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(flux_out, dfo, ob, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(flux_err_out, deo, ob, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 }  // extern "C"

@@ -121,6 +121,18 @@ int pg_logmedian_launch(lk_handle *h, int B, int64_t M, const double *power, int
                         hipStream_t stream);
 int pg_boxsmooth_launch(lk_handle *h, int B, int64_t M, const double *power, const double *taps_host, int nk,
                         double *out, hipStream_t stream);
+int sigma_clip_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *y, double sigma, int maxiters,
+                      uint8_t *outlier, hipStream_t stream);
+int ingest_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux, const double *err,
+                  int normalize, double *t_out, double *f_out, double *e_out, int64_t *new_off_host, double *median_out,
+                  hipStream_t stream);
+int transit_mask_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const int *p_off_host,
+                        const double *period_host, const double *duration_host, const double *transit_time_host,
+                        uint8_t *mask, hipStream_t stream);
+int bin_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux, const double *err,
+               const int64_t *bin_off_host, const double *start_host, const double *edges_host, int64_t n_edges,
+               double bin_size_sec, const uint8_t *has_err_host, double *t_out, double *f_out, double *e_out,
+               hipStream_t stream);
 int pg_acf2d_launch(lk_handle *h, int B, int64_t M, const double *power, int n_win, const int *win_start_host, int W,
                     double *acf2d, double *metric, hipStream_t stream);
 int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,

@@ -514,6 +514,32 @@ int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, doubl
     return KB * GR_BLK;  // leading dimension of each G_b
 }
 
+// astropy.stats.sigma_clip(y, sigma, maxiters, cenfunc=median, stdfunc=std).mask for B ragged arrays — what
+// LightCurve.remove_outliers (src/lightkurve/lightcurve.py:1430-1556) keeps its cadences by: 1 = clipped or non-finite.
+int sigma_clip_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *y, double sigma, int maxiters,
+                      uint8_t *outlier, hipStream_t stream) {
+    LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    if (B == 0 || n_off_host[B] == 0) return LK_OK;
+    LK_REQUIRE(y && outlier, "NULL buffer");
+    LK_REQUIRE(maxiters >= 0, "maxiters must be >= 0");
+    const size_t ntot = (size_t)n_off_host[B];
+    h->ws.reset();
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + ntot * 9 + 3 * 256 + 4096);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    double *d_zero = (double *)h->ws.alloc(ntot * 8);
+    uint8_t *d_flag = (uint8_t *)h->ws.alloc(ntot);
+    {
+        const int rcs = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
+        if (rcs) return rcs;
+    }
+    LK_HIP_CHECK(hipMemsetAsync(d_zero, 0, ntot * 8, stream));
+    LK_HIP_CHECK(hipMemsetAsync(outlier, 0, ntot, stream));
+    hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, d_zero, d_off, sigma, maxiters, d_flag, outlier);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
                    const double *err, const uint8_t *cmask, const double *prior_mu, const double *prior_sigma,
                    double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream,

@@ -1,0 +1,108 @@
+"""Ragged batch container for light curves + the device-side ingest steps.
+
+A pipeline over a ``LightCurveCollection`` (reference src/lightkurve/collections.py:145) calls ``remove_nans`` /
+``normalize`` / ``bin`` / ``create_transit_mask`` / ``fold`` per light curve in Python, each building astropy Time / Quantity
+/ Table objects; with the kernels at milliseconds per thousand targets that object construction is the wall.
+``LightCurveBatch`` keeps B light curves as three concatenated float64 arrays plus prefix offsets — the layout every
+``lk_*_batch`` entry point takes — and runs those steps for the whole batch in one launch each.
+
+    batch = LightCurveBatch.from_lightcurves(lcs)          # anything with .time / .flux / .flux_err
+    batch = batch.remove_nans().normalize()                # lk_ingest_batch
+    mask  = batch.create_transit_mask(period, transit_time, duration)     # lk_transit_mask_batch
+    power = batch.to_periodogram_power(frequency)          # lombscargle_batch over the same arrays
+"""
+import numpy as np
+
+from . import _capi
+from .lightcurve import LightCurve
+
+__all__ = ["LightCurveBatch"]
+
+
+def _values(x):
+    """float64 ndarray of an ndarray / astropy Quantity / Time / masked column."""
+    x = getattr(x, "unmasked", x)
+    x = getattr(x, "value", x)
+    return np.asarray(x, dtype=np.float64)
+
+
+class LightCurveBatch(object):
+    def __init__(self, time, flux, flux_err, n_off, meta=None):
+        self.time = np.ascontiguousarray(time, dtype=np.float64)
+        self.flux = np.ascontiguousarray(flux, dtype=np.float64)
+        self.flux_err = np.ascontiguousarray(flux_err, dtype=np.float64)
+        self.n_off = np.ascontiguousarray(n_off, dtype=np.int64)
+        if not (self.time.shape == self.flux.shape == self.flux_err.shape) or self.time.ndim != 1:
+            raise ValueError("time, flux, flux_err must be 1-D arrays of one length")
+        if self.n_off[0] != 0 or self.n_off[-1] != self.time.size or np.any(np.diff(self.n_off) < 0):
+            raise ValueError("n_off must be non-decreasing prefix offsets over the arrays")
+        self.meta = list(meta) if meta is not None else [{} for _ in range(len(self))]
+
+    @classmethod
+    def from_lightcurves(cls, lcs):
+        """From an iterable of light curves (this package's or lightkurve's own: Time / Quantity columns are read through
+        ``.value``)."""
+        ts, fs, es, meta = [], [], [], []
+        for lc in lcs:
+            t = _values(lc.time)
+            f = _values(lc.flux)
+            e = getattr(lc, "flux_err", None)
+            e = np.full(len(t), np.nan) if e is None else np.broadcast_to(_values(e), t.shape)
+            ts.append(t), fs.append(f), es.append(e), meta.append(dict(getattr(lc, "meta", {}) or {}))
+        off = np.zeros(len(ts) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(t) for t in ts])
+        cat = lambda a: np.concatenate(a) if a else np.zeros(0)
+        return cls(cat(ts), cat(fs), cat(es), off, meta)
+
+    def __len__(self):
+        return len(self.n_off) - 1
+
+    def __getitem__(self, b):
+        s = slice(int(self.n_off[b]), int(self.n_off[b + 1]))
+        return LightCurve(time=self.time[s], flux=self.flux[s], flux_err=self.flux_err[s], meta=self.meta[b])
+
+    def to_lightcurves(self):
+        return [self[b] for b in range(len(self))]
+
+    # ---------------------------------------------------------------- device-side steps
+    def _ingest(self, normalize, device):
+        t, f, e, off, med = _capi.ingest_batch(self.time, self.flux, self.n_off, flux_err=self.flux_err,
+                                               normalize=normalize, device=device)
+        out = LightCurveBatch(t, f, e, off, [dict(m) for m in self.meta])
+        out.median_flux = med
+        return out
+
+    def remove_nans(self, device=0):
+        """Every light curve without the cadences whose flux is NaN (reference lightcurve.py:1300-1327)."""
+        return self._ingest(False, device)
+
+    def normalize(self, device=0):
+        """flux and flux_err divided by nanmedian(flux) per light curve (reference :1216-1292); NaN-flux cadences are dropped
+        first — what pipelines do anyway (``lc.remove_nans().normalize()``, e.g. correctors/metrics.py:60) — because the
+        packed layout has no place for them."""
+        out = self._ingest(True, device)
+        for m in out.meta:
+            m["NORMALIZED"] = True
+        return out
+
+    def create_transit_mask(self, period, transit_time, duration, planet_off=None, device=0):
+        """Boolean array over all cadences of the batch, True in transit (reference :2967-3037).  Scalars / 1-D arrays
+        apply to every light curve; with ``planet_off`` each light curve gets its own planets."""
+        return _capi.transit_mask_batch(self.time, self.n_off, period, duration, transit_time, planet_off=planet_off,
+                                        device=device)
+
+    def bin(self, time_bin_size=0.5, time_bin_start=None, device=0):
+        """Equal-width time bins (reference :1558-1763 with ``time_bin_size`` in days): nanmean flux, rms flux_err."""
+        t, f, e, boff = _capi.bin_batch(self.time, self.flux, self.n_off, flux_err=self.flux_err,
+                                        time_bin_size=time_bin_size, time_bin_start=time_bin_start, device=device)
+        return LightCurveBatch(t, f, e, boff, [dict(m) for m in self.meta])
+
+    def to_periodogram_power(self, frequency, normalization="amplitude", ls_method="fast", device=0, **kw):
+        """Lomb-Scargle power of every light curve on one shared grid (``batch.lombscargle_batch``) -> float64[B, M]."""
+        from .batch import lombscargle_batch
+        return lombscargle_batch(self.to_lightcurves(), frequency, normalization=normalization, ls_method=ls_method,
+                                 device=device, **kw)
+
+    def flatten_trend(self, device=0, **kw):
+        """The trend ``LightCurve.flatten`` divides by, for every light curve -> concatenated array in batch layout."""
+        return _capi.savgol_trend_batch(self.time, self.flux, self.n_off, device=device, **kw)

@@ -85,6 +85,27 @@ class LightCurve(object):
         lc.meta["NORMALIZED"] = True
         return lc
 
+    def remove_outliers(self, sigma=5.0, return_mask=False, maxiters=5, device=0):
+        """Light curve without the cadences astropy.stats.sigma_clip flags (median centre, std width, ``maxiters``
+        rounds; NaN flux counts as an outlier) — reference :1430-1556, the default ``corrector_func`` of
+        ``TargetPixelFile.plot_pixels``; the clip runs on the GPU (lk_sigma_clip_batch)."""
+        from . import _capi
+        mask = _capi.sigma_clip_batch(self.flux, [0, len(self)], sigma=sigma, maxiters=maxiters, device=device)
+        return (self[~mask], mask) if return_mask else self[~mask]
+
+    def bin(self, time_bin_size=0.5, time_bin_start=None, device=0):
+        """Equal-width time bins (reference :1558-1763, the ``time_bin_size`` [d] form): nanmean of the flux, rms of the
+        errors (nanstd of the flux when there are none); one GPU call (lk_bin_batch).  Empty bins hold NaN."""
+        from . import _capi
+        t, f, e, _off = _capi.bin_batch(self.time, self.flux, [0, len(self)], flux_err=self.flux_err,
+                                        time_bin_size=time_bin_size, time_bin_start=time_bin_start, device=device)
+        return LightCurve(time=t, flux=f, flux_err=e, meta=self.meta)
+
+    def create_transit_mask(self, period, transit_time, duration, device=0):
+        """True for the cadences inside any of the transits (reference :2967-3037); lk_transit_mask_batch."""
+        from . import _capi
+        return _capi.transit_mask_batch(self.time, [0, len(self)], period, duration, transit_time, device=device)
+
     def __sub__(self, other):
         """lc - scalar shifts the flux (reference LightCurve.__add__/__sub__ :610-660, scalar case)."""
         new = self.copy()

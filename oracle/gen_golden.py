@@ -178,6 +178,76 @@ def gen_acf2d():
     save("acf2d", **out)
 
 
+def gen_ingest():
+    """remove_nans + normalize (lightcurve.py:1300-1327, 1216-1292), create_transit_mask (:2967-3037) and bin (:1558-1763)
+    on ragged synthetic light curves with NaNs, gaps and missing errors."""
+    rng = np.random.default_rng(41)
+    out = {"n": 4}
+    for b in range(4):
+        t, y, e, _ = synth.bls_target(3, 40 + b, 1500 + 400 * b, cadence_days=(10.0 + 5 * b) / 1440.0)
+        y = y.copy() * (1.0 + 0.2 * b)
+        y[rng.integers(0, len(y), 15)] = np.nan
+        if b == 2:
+            e = np.full(len(t), np.nan)            # no errors at all: bin() falls back to nanstd
+        elif b == 3:
+            e = e.copy()
+            e[rng.integers(0, len(e), 30)] = np.nan
+        lc = lk.LightCurve(time=t + 2000.0, flux=y, flux_err=e)
+        clean = lc.remove_nans().normalize()
+        per, dur = np.array([2.3, 5.1 + b]), np.array([0.2, 0.35])
+        tt = np.array([2000.7, 2001.9])
+        mask = lc.create_transit_mask(period=per, transit_time=tt, duration=dur)
+        # LightCurve.bin itself cannot run here: it forwards time_bin_end=, which needs astropy >= 5 (the oracle interpreter
+        # has 4.3.1).  Its body (:1715-1752) is replayed instead: aggregate_downsample of the light curve (nanmean), then of
+        # the errors with lightkurve's own rmse (or of the flux with nanstd when there are no finite errors), time = bin
+        # start + half a bin.  The binning rule pinned here is therefore astropy 4.3.1's (timeseries/downsample.py:12-125).
+        from astropy.timeseries import TimeSeries, aggregate_downsample
+        from lightkurve.lightcurve import rmse
+        size = (0.25 + 0.1 * b) * u.day
+        ts = aggregate_downsample(lc, time_bin_size=size, time_bin_start=lc.time[0])
+        if np.any(np.isfinite(lc.flux_err)):
+            ts_err = aggregate_downsample(TimeSeries(data=dict(time=lc.time.copy(), flux_err=lc.flux_err)), time_bin_size=size,
+                                          time_bin_start=lc.time[0], aggregate_func=rmse)
+            berr = ts_err["flux_err"]
+        else:
+            ts_err = aggregate_downsample(TimeSeries(data=dict(time=lc.time.copy(), flux=lc.flux)), time_bin_size=size,
+                                          time_bin_start=lc.time[0], aggregate_func=np.nanstd)
+            berr = ts_err["flux"]
+
+        class _B:
+            pass
+        binned = _B()
+        binned.time = (ts.time_bin_start + ts.time_bin_size / 2.0)
+        binned.flux, binned.flux_err = ts["flux"], berr
+        out.update({"time_%d" % b: lc.time.value, "flux_%d" % b: y, "err_%d" % b: e,
+                    "clean_time_%d" % b: clean.time.value, "clean_flux_%d" % b: clean.flux.value,
+                    "clean_err_%d" % b: clean.flux_err.value, "mask_%d" % b: np.asarray(mask),
+                    "period_%d" % b: per, "duration_%d" % b: dur, "transit_time_%d" % b: tt,
+                    "bin_size_%d" % b: 0.25 + 0.1 * b, "bin_time_%d" % b: np.asarray(binned.time.value, dtype=float),
+                    "bin_flux_%d" % b: np.ma.filled(np.ma.asarray(binned.flux.value), np.nan),
+                    "bin_err_%d" % b: np.ma.filled(np.ma.asarray(binned.flux_err.value), np.nan)})
+    save("ingest", **out)
+
+
+def gen_pixel_pg():
+    """The per-pixel periodograms of TargetPixelFile.plot_pixels(periodogram=True) (targetpixelfile.py:1958-1974): one-pixel
+    aperture light curve -> remove_outliers() -> to_periodogram(), for a few pixels of the synthetic K2 cutout."""
+    tpf = lk.read("/root/reference/tests/data/synthetic/synthetic-k2-sinusoid.targ.fits.gz")
+    out = dict(time=tpf.time.value, flux=np.asarray(tpf.flux.value, dtype=np.float32),
+               flux_err=np.asarray(tpf.flux_err.value, dtype=np.float32))
+    pix = [0, 10, 24, 30, 48]
+    for j in pix:
+        m = np.zeros(tpf.shape[1:], bool)
+        m[np.unravel_index(j, tpf.shape[1:])] = True
+        lc = tpf.to_lightcurve(aperture_mask=m).remove_outliers()
+        pg = lc.to_periodogram()
+        out["freq_%d" % j], out["power_%d" % j], out["n_%d" % j] = pg.frequency.value, pg.power.value, len(lc)
+        pg2 = lc.to_periodogram(frequency=np.linspace(0.1, 20, 1500))
+        out["power_grid_%d" % j] = pg2.power.value
+    out["pixels"] = np.array(pix)
+    save("pixel_pg", **out)
+
+
 def gen_metrics():
     """overfit_metric_lombscargle (correctors/metrics.py:24-138) with the global numpy RNG seeded before each call."""
     from lightkurve.correctors.metrics import overfit_metric_lombscargle
@@ -511,6 +581,6 @@ def gen_pld():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "acf2d", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "acf2d", "ingest", "pixel_pg", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

@@ -309,3 +309,20 @@ def test_pld_corrected_flux(golden, name):
     assert r["X"].shape == g["X"].shape and np.allclose(r["prior_sigma"], g["prior_sigma"], rtol=1e-6)
     assert np.array_equal(r["outlier_mask"], g["outlier_mask"])
     assert np.max(np.abs(r["corrected"] - g["corrected"])) / np.median(g["corrected"]) < 1e-6
+
+
+def test_ingest_oracle_vs_reference(golden):
+    """remove_nans + normalize, create_transit_mask and bin restatements against lightkurve / astropy outputs."""
+    g = golden("ingest")
+    for b in range(int(g["n"])):
+        t, f, e = g["time_%d" % b], g["flux_%d" % b], g["err_%d" % b]
+        ct, cf, ce, _med = O.remove_nans_normalize(t, f, e)
+        assert np.array_equal(ct, g["clean_time_%d" % b])
+        assert np.allclose(cf, g["clean_flux_%d" % b], rtol=1e-15, atol=0)
+        assert np.allclose(ce, g["clean_err_%d" % b], rtol=1e-15, atol=0, equal_nan=True)
+        m = O.transit_mask(t, g["period_%d" % b], g["duration_%d" % b], g["transit_time_%d" % b])
+        assert np.array_equal(m, g["mask_%d" % b])
+        bt, bf, be = O.bin_lightcurve(t, f, e, float(g["bin_size_%d" % b]))
+        assert np.allclose(bt, g["bin_time_%d" % b], rtol=0, atol=1e-9)
+        assert np.allclose(bf, g["bin_flux_%d" % b], rtol=1e-13, atol=0, equal_nan=True)
+        assert np.allclose(be, g["bin_err_%d" % b], rtol=1e-12, atol=0, equal_nan=True)
