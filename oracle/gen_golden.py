@@ -240,6 +240,10 @@ def gen_pixel_pg():
         m = np.zeros(tpf.shape[1:], bool)
         m[np.unravel_index(j, tpf.shape[1:])] = True
         lc = tpf.to_lightcurve(aperture_mask=m).remove_outliers()
+        # FITS cubes are float32; under numpy < 2 (this interpreter: 1.26) astropy's `y - np.dot(w, y)` then stays float32
+        # (legacy value-based casting), under numpy >= 2 it is float64.  The fixture pins the float64 arithmetic.
+        lc = lk.LightCurve(time=lc.time, flux=np.asarray(lc.flux.value, dtype=np.float64),
+                           flux_err=np.asarray(lc.flux_err.value, dtype=np.float64))
         pg = lc.to_periodogram()
         out["freq_%d" % j], out["power_%d" % j], out["n_%d" % j] = pg.frequency.value, pg.power.value, len(lc)
         pg2 = lc.to_periodogram(frequency=np.linspace(0.1, 20, 1500))
