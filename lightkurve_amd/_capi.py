@@ -151,6 +151,7 @@ def load_library(path=None):
         raise OSError(
             "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "
             "make -C lightkurve_amd/csrc).  lightkurve_amd has no CPU fallback." % path)
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(path)
     for name, restype, argtypes in SIGNATURES:
         fn = getattr(lib, name)
@@ -158,6 +159,30 @@ def load_library(path=None):
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's); if
+    liblkhip.so pulls in /opt/rocm's copy first and torch is imported LATER, torch ends up on a second runtime and sees
+    no GPU (round 1's import-order trap).  So when torch is installed but not imported yet, its bundled runtime is
+    loaded first with RTLD_GLOBAL: liblkhip.so's DT_NEEDED libamdhip64.so.7 then resolves to that already-loaded
+    object, and a later `import torch` reuses it — the situation bench.py (torch first) has always been in.
+    LK_NO_TORCH_HIP=1 disables this (e.g. to force /opt/rocm's runtime)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("LK_NO_TORCH_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            cand = os.path.join(libdir, name)
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:      # never fatal: fall back to the plain load
+        pass
 
 
 def _check(rc):

@@ -8,7 +8,7 @@ from . import _capi
 from .distributed import sharded_map
 from .periodogram import _bls_plan, _ls_plan, exact_grid
 
-__all__ = ["lombscargle_batch", "bls_batch", "periodogram_peaks"]
+__all__ = ["lombscargle_batch", "lombscargle_peaks_batch", "bls_batch", "periodogram_peaks"]
 
 
 def _pack(arrs):
@@ -50,6 +50,33 @@ def lombscargle_batch(lcs, frequency, normalization="amplitude", freq_unit=None,
         if grid is not None:
             return _capi.ls_power_batch(t, y, off, f0=grid[0], df=grid[1], M=len(f_day), **kw)
         return _capi.ls_power_batch(t, y, off, frequency=f_day, **kw)
+
+    return sharded_map(list(lcs), compute, costs=[len(lc) for lc in lcs], gather=gather)
+
+
+def lombscargle_peaks_batch(lcs, frequency, normalization="amplitude", freq_unit=None, oversample_factor=None, device=0,
+                            gather=True):
+    """(max power, argmax) of the default-method (``ls_method="fast"``) periodogram of every light curve on one shared
+    regular grid -> float64[len(lcs), 2] (column 1 holds the index).  The spectra never leave the GPU
+    (lk_ls_fast_peaks_batch with power = NULL) and with a process group only 16 B per target cross xGMI: this is the
+    collective to use when ``Periodogram.max_power`` / ``frequency_at_max_power`` is what the pipeline keeps
+    (reference periodogram.py:127-140) — ``lombscargle_batch(gather=True)`` makes every rank hold all B x M powers."""
+    frequency = np.asarray(frequency, dtype=np.float64)
+
+    def compute(local):
+        if not local:
+            return np.zeros((0, 2))
+        plans = [_ls_plan(lc, frequency=frequency, normalization=normalization, freq_unit=freq_unit,
+                          oversample_factor=oversample_factor, ls_method="fast") for lc in local]
+        if plans[0]["ls_method"] != "fast":
+            raise ValueError("lombscargle_peaks_batch needs a regular frequency grid (the reference switches to 'slow')")
+        t, off = _pack([p["trel"] for p in plans])
+        y, _ = _pack([p["flux"] for p in plans])
+        f_day = plans[0]["f_day"]
+        _pw, mx, am = _capi.ls_fast_peaks_batch(t, y, off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=len(f_day),
+                                                normalization=plans[0]["norm"], scale=[p["scale"] for p in plans],
+                                                device=device, want_power=False)
+        return np.column_stack([mx, am.astype(np.float64)])
 
     return sharded_map(list(lcs), compute, costs=[len(lc) for lc in lcs], gather=gather)
 

@@ -143,6 +143,7 @@ int fold_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t,
                 int ncols, const double *const *cols_in, double *const *cols_out, double *phase, int64_t *order,
                 hipStream_t stream) {
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    LK_REQUIRE(B <= 65535, "at most 65535 targets per call on this path (got %d): split the batch", B);
     if (B == 0) return LK_OK;
     LK_REQUIRE(t && period_host && epoch_time_host && wrap_phase_host && phase && order, "NULL buffer");
     LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");

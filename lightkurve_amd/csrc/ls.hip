@@ -448,6 +448,7 @@ int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
                    int normalization, const double *scale, double *power, hipStream_t stream) {
     LK_REQUIRE(nterms >= 1 && nterms <= LK_MAX_NTERMS, "nterms must be between 1 and %d (got %d)", LK_MAX_NTERMS, nterms);
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    LK_REQUIRE(freq == nullptr || B <= 65535, "at most 65535 targets per call with an explicit frequency array (got %d)", B);
     LK_REQUIRE(M >= 0, "M must be >= 0");
     if (B == 0 || M == 0) return LK_OK;
     LK_REQUIRE(t && y && power, "t, y, power must be non-NULL");

@@ -1501,7 +1501,8 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
         nmax = std::max(nmax, n);
     }
     const int m = ilog2_ceil((long long)oversampling * (long long)M);
-    LK_REQUIRE(m >= 2 && m <= 26, "FFT grid of 2^%d points is outside the supported range", m);
+    LK_REQUIRE(m >= 2 && m <= 24, "FFT grid of 2^%d points is outside the supported range (2^2 .. 2^24: the in-LDS column\n"
+               "transform of longer grids does not fit 160 KB)", m);
     const int nfft = 1 << m, m1 = (m + 1) / 2, m2 = m / 2;
     const int N1 = 1 << m1, N2 = 1 << m2;
     const int NG = 3 * nterms;

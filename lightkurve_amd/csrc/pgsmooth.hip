@@ -98,6 +98,7 @@ int pg_logmedian_launch(lk_handle *h, int B, int64_t M, const double *power, int
     LK_REQUIRE(power && out && klo_host && khi_host, "NULL buffer");
     LK_REQUIRE(K == 0 || (win_lo_host && win_hi_host), "NULL window table");
     LK_REQUIRE(M < ((int64_t)1 << 31), "M too large");
+    LK_REQUIRE(B <= 65535, "at most 65535 periodograms per call (got %d)", B);
     for (int k = 0; k < K; ++k)
         LK_REQUIRE(win_lo_host[k] >= 0 && win_lo_host[k] <= win_hi_host[k] && win_hi_host[k] <= M,
                    "window %d = [%d, %d) outside [0, M]", k, win_lo_host[k], win_hi_host[k]);
@@ -132,6 +133,7 @@ int pg_boxsmooth_launch(lk_handle *h, int B, int64_t M, const double *power, con
     if (B == 0) return LK_OK;
     LK_REQUIRE(power && out && taps_host, "NULL buffer");
     LK_REQUIRE(nk >= 1 && nk % 2 == 1, "the kernel must have an odd number of taps");
+    LK_REQUIRE(B <= 65535, "at most 65535 periodograms per call (got %d)", B);
     double ksum = 0.0;
     for (int i = 0; i < nk; ++i) ksum += taps_host[i];
     LK_REQUIRE(ksum > 1e-8, "The kernel can't be normalized, because its sum is close to zero.");

@@ -547,6 +547,7 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
     if (B == 0) return LK_OK;
     LK_REQUIRE(K >= 1 && K <= 1023, "K=%d outside the supported range 1..1023", K);
+    LK_REQUIRE(B <= 65535, "at most 65535 targets per call on this path (got %d): split the batch", B);
     LK_REQUIRE(X && y && w && model && outl, "NULL buffer");
     LK_REQUIRE((prior_mu == nullptr) == (prior_sigma == nullptr), "Please specify both `prior_mu` and `prior_sigma`");
     LK_REQUIRE(niters >= 1, "niters must be >= 1");

@@ -91,3 +91,23 @@ def test_bench_gpus_flag_self_launches_ranks():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["dry"] is True
     assert res["targets_total"] == 11 and res["scaling"] == "strong"      # 6 + 5 targets seen by the two ranks
+
+
+def test_batch_entry_points_work_without_torch():
+    """sharded_map / all_gather_rows imported torch.distributed unconditionally, so the batch entry points raised
+    ModuleNotFoundError in the interpreter the seams live in (conda + astropy, no torch).  With torch blocked they must
+    behave as a world of one rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.modules['torch'] = None; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from lightkurve_amd import distributed as D\n"
+        "import lightkurve_amd.batch, lightkurve_amd.correctors.metrics\n"
+        "out = D.sharded_map([1, 2, 3], lambda xs: np.array([[x, 2 * x] for x in xs]), costs=[1, 1, 1])\n"
+        "assert out.tolist() == [[1, 2], [2, 4], [3, 6]]\n"
+        "assert D.all_gather_rows(out, [0, 3]) is out\n"
+        "print('NO_TORCH_OK')\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=120)
+    assert p.returncode == 0 and b"NO_TORCH_OK" in p.stdout, p.stderr.decode()[-1500:]

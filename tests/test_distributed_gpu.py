@@ -17,3 +17,13 @@ def test_batch_entry_points_under_rccl_world1():
     p = subprocess.run([sys.executable, worker], capture_output=True, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     assert b"RCCL_WORKER_OK" in p.stdout
+
+
+def test_library_before_torch_keeps_torch_on_the_gpu():
+    """Round 1's import-order trap: liblkhip.so loaded before torch left torch without a device.  _capi now loads
+    torch's bundled HIP runtime first (one runtime per process), so either order works."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "import_order_worker.py")], capture_output=True,
+                       timeout=600)
+    assert p.returncode == 0 and b"IMPORT_ORDER_OK" in p.stdout, p.stderr.decode()[-1500:]
