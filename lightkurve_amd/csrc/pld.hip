@@ -216,9 +216,14 @@ __global__ void pld_spline_kernel(const double *__restrict__ time, const double 
 // diag(M) <- eigenvalues.  All threads of the workgroup participate.  rot: n/2 x 4 doubles of LDS scratch.
 // Wt != nullptr: the eigenvectors are kept TRANSPOSED in global memory (Wt[p * n + i] = W[i][p], n x n) instead of in W
 // (LDS) — rows p and q of Wt are what a rotation touches, so the accesses stay coalesced.
-__device__ void jacobi_eig_lds(double *M, double *W, int n, int ld, double *rot, double *shred, double *Wt = nullptr) {
+// M, W, rot, shred are OFFSETS (in doubles) into the workgroup's dynamic LDS: a non-inlined function that took them as
+// plain pointers would address LDS through flat loads and stores.
+template <bool WT>
+static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld, int orot, int oshred, double *Wt = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    double *M = lds_dyn + oM, *W = lds_dyn + oW, *rot = lds_dyn + orot, *shred = lds_dyn + oshred;
     const int tid = threadIdx.x, nt = blockDim.x;
-    if (Wt)
+    if (WT)
         for (int e = tid; e < n * n; e += nt) Wt[e] = (e / n == e % n) ? 1.0 : 0.0;
     else
         for (int e = tid; e < n * n; e += nt) W[(e / n) * ld + (e % n)] = (e / n == e % n) ? 1.0 : 0.0;
@@ -284,7 +289,7 @@ __device__ void jacobi_eig_lds(double *M, double *W, int n, int ld, double *rot,
                 const double mp = M[i * ld + p], mq = M[i * ld + q];
                 M[i * ld + p] = c * mp - s * mq;
                 M[i * ld + q] = s * mp + c * mq;
-                if (Wt) {
+                if (WT) {
                     const double wp = Wt[(size_t)p * n + i], wq = Wt[(size_t)q * n + i];
                     Wt[(size_t)p * n + i] = c * wp - s * wq;
                     Wt[(size_t)q * n + i] = s * wp + c * wq;
@@ -294,7 +299,7 @@ __device__ void jacobi_eig_lds(double *M, double *W, int n, int ld, double *rot,
                     W[i * ld + q] = s * wp + c * wq;
                 }
             }
-            if (Wt) __threadfence_block();
+            if (WT) __threadfence_block();
             __syncthreads();
         }
     }
@@ -320,24 +325,355 @@ __device__ __forceinline__ double gsym(const double *__restrict__ G, int ldg, in
     return (j >= i || (j >> 6) == (i >> 6)) ? G[(size_t)i * ldg + j] : G[(size_t)j * ldg + i];
 }
 
+// ------------------------------------------------------------------------------------------------ top-k eigenpairs
+// The pieces of the subspace iteration are separate NON-inlined device functions: inlined into one kernel body (the
+// first version) the compiler carried ~200 spilled registers through the hot loops.  EigCtx travels by value.
+// The LDS regions are OFFSETS (in doubles) into the dynamic LDS block, turned back into pointers inside each function:
+// a pointer argument would lose its address space and every LDS access would become a flat load/store.
+struct EigCtx {
+    int T, W, rot, shred, vec, qstage;  // LDS: two l x ld matrices, rotation table, reduction scratch, 2 l scalars, stage
+    int order;                          // LDS: l ints (offset in doubles)
+    double *Gb;                         // this matrix (global, leading dimension ldg)
+    int ldg, P, k, l, ld;
+};
+#define LK_EIG_LDS extern __shared__ __attribute__((aligned(16))) double lds_dyn[]
+// likewise the global operands: as plain pointer arguments they would be read with flat loads
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) const double cgdouble;
+typedef __attribute__((address_space(1))) const pld_d4 cgd4;
+
+// Every dense step runs on the fp64 matrix cores (v_mfma_f64_16x16x4: A operand [row = lane & 15][k = lane >> 4],
+// B operand [k = lane >> 4][col = lane & 15], D [row = (lane >> 4) + 4 r][col = lane & 15]).  The first version used one
+// thread per output entry with a P-long serial fma chain for the skinny products (X^T Y, X M): at 1024 threads and 4
+// waves per SIMD those loops were latency-bound and cost as much as the products with C.
+
+// out (LDS, l x ld) = X^T Yv for two P x l row-major matrices.  Wave = (16 x 16 output tile, slice of the P rows); the
+// slices are summed through LDS (qstage doubles as the buffer of partial tiles).
+static __device__ __noinline__ void eig_xty(EigCtx c, const double *X_, const double *Yv_, int oout) {
+    LK_EIG_LDS;
+    cgdouble *X = (cgdouble *)X_, *Yv = (cgdouble *)Yv_;
+    double *out = lds_dyn + oout;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
+    const int lq = lane >> 4, lr = lane & 15, l = c.l, P = c.P, na = (l + 15) >> 4;
+    const int tiles = na * na, parts = max(1, nwv / tiles);
+    double *pbuf = lds_dyn + c.qstage;
+    if (wave < tiles * parts) {
+        const int tile = wave % tiles, part = wave / tiles;
+        const int acol = (tile / na) * 16 + lr, ccol = (tile % na) * 16 + lr;
+        const int steps = (P + 3) >> 2, per = (steps + parts - 1) / parts;
+        const int s0 = part * per, s1 = min(steps, s0 + per);
+        pld_d4 acc = pld_d4{0.0, 0.0, 0.0, 0.0};
+        const bool aok = acol < l, cok = ccol < l;
+        int st = s0;
+        for (; st + 4 <= s1; st += 4) {  // four steps of loads in flight
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = (st + u) * 4 + lq;
+                av[u] = (i < P && aok) ? X[(size_t)i * l + acol] : 0.0;
+                bv[u] = (i < P && cok) ? Yv[(size_t)i * l + ccol] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+        for (; st < s1; ++st) {
+            const int i = st * 4 + lq;
+            const double av = (i < P && aok) ? X[(size_t)i * l + acol] : 0.0;
+            const double bv = (i < P && cok) ? Yv[(size_t)i * l + ccol] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pbuf[(part * tiles + tile) * 256 + (lq + 4 * r) * 16 + lr] = acc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < l * l; e += nt) {
+        const int a = e / l, cc = e % l;
+        const int idx = ((a >> 4) * na + (cc >> 4)) * 256 + (a & 15) * 16 + (cc & 15);
+        double sm = 0.0;
+        for (int pt = 0; pt < parts; ++pt) sm += pbuf[pt * tiles * 256 + idx];
+        out[a * c.ld + cc] = sm;
+    }
+    __syncthreads();
+}
+
+// out = X Mm (P x l times the l x l matrix Mm in LDS, leading dimension ld), optionally out2 = X2 Mm in the same pass.
+// A wave owns 16-row strips; the single-matrix form loads a whole strip of X before it stores, so out may alias X.  With
+// theta != nullptr the return value is this thread's share of sum_{c < k} || out2[:, c] - theta[c] out[:, c] ||^2.
+template <int NA, bool TWO>
+static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double *out_, const double *X2_, double *out2_,
+                                             int oMm, int otheta) {
+    LK_EIG_LDS;
+    cgdouble *X = (cgdouble *)X_, *X2 = (cgdouble *)X2_;
+    gdouble *out = (gdouble *)out_, *out2 = (gdouble *)out2_;
+    const double *Mm = lds_dyn + oMm, *theta = otheta >= 0 ? lds_dyn + otheta : nullptr;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
+    const int lq = lane >> 4, lr = lane & 15, l = c.l, P = c.P, ld = c.ld;
+    double part = 0.0;
+    const int nstrip = (P + 15) >> 4;
+    for (int strip = wave; strip < nstrip; strip += nwv) {
+        const int irow = strip * 16 + lr;
+        pld_d4 acc[NA], acc2[TWO ? NA : 1];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) acc[t] = pld_d4{0.0, 0.0, 0.0, 0.0};
+        if (TWO) {
+#pragma unroll
+            for (int t = 0; t < NA; ++t) acc2[t] = pld_d4{0.0, 0.0, 0.0, 0.0};
+        }
+        double av[4 * NA];
+#pragma unroll
+        for (int ks = 0; ks < 4 * NA; ++ks) {
+            const int a = ks * 4 + lq;
+            av[ks] = (irow < P && a < l) ? X[(size_t)irow * l + a] : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4 * NA; ++ks) {
+            const int a = ks * 4 + lq;
+            double av2 = 0.0;
+            if (TWO) av2 = (irow < P && a < l) ? X2[(size_t)irow * l + a] : 0.0;
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                const int col = t * 16 + lr;
+                const double bv = (a < l && col < l) ? Mm[a * ld + col] : 0.0;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv, acc[t], 0, 0, 0);
+                if (TWO) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2, bv, acc2[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int col = t * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = strip * 16 + lq + 4 * r;
+                if (i < P && col < l) {
+                    out[(size_t)i * l + col] = acc[t][r];
+                    if (TWO) {
+                        out2[(size_t)i * l + col] = acc2[t][r];
+                        if (theta && col < c.k) {
+                            const double d = acc2[t][r] - theta[col] * acc[t][r];
+                            part = fma(d, d, part);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return part;
+}
+
+// dst = C src (P x l, row-major): dst^T (l x P) = src^T (l x P) C (P x P).  The A operand (src^T) comes from an LDS stage
+// of PLD_KC rows of src; the B operand straight from global: a wave owns 64 consecutive columns of C and a lane loads
+// FOUR of them per row (32 B, so one load instruction covers 4 rows x 512 contiguous bytes) — component j of the load
+// feeds MFMA tile j, whose column (lane & 15) is therefore column 64 w + 4 (lane & 15) + j of C.  Loads run two steps
+// ahead of the matrix cores.  Every element of C is streamed exactly once per product.
+template <int NA>
+static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double *dst_) {
+    cgdouble *src = (cgdouble *)src_;
+    gdouble *dst = (gdouble *)dst_;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
+    const int lq = lane >> 4, lr = lane & 15, l = c.l, P = c.P, ldg = c.ldg, na = (l + 15) >> 4;
+    LK_EIG_LDS;
+    double *qstage = lds_dyn + c.qstage;
+    const int ngrp = (P + 63) >> 6, nsteps = (P + 3) >> 2;
+    for (int gbase = 0; gbase < ngrp; gbase += nwv) {
+        const int grp = gbase + wave;
+        const bool active = grp < ngrp;
+        const int n0 = grp * 64 + 4 * lr;
+        cgdouble *cp = (cgdouble *)c.Gb + n0;
+        bool colok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) colok[j] = active && n0 + j < P;
+        auto load_b = [&](int st) -> pld_d4 {
+            const int krow = st * 4 + lq;
+            return (active && krow < P) ? *(cgd4 *)(cp + (size_t)krow * ldg) : pld_d4{0.0, 0.0, 0.0, 0.0};
+        };
+        pld_d4 acc[4][NA];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
+        pld_d4 b0 = load_b(0), b1 = load_b(1);
+        for (int k0 = 0; k0 < P; k0 += PLD_KC) {
+            __syncthreads();
+            for (int e = tid; e < PLD_KC * 16 * na; e += nt) {
+                const int kk = e / (16 * na), a = e - kk * (16 * na);
+                qstage[kk * PLD_QS + a] = (k0 + kk < P && a < l) ? src[(size_t)(k0 + kk) * l + a] : 0.0;
+            }
+            __syncthreads();
+            const int s_lo = k0 >> 2, s_hi = min(nsteps, (k0 + PLD_KC) >> 2);
+            for (int st = s_lo; st < s_hi; st += 2) {  // PLD_KC is a multiple of 8: step st + 1 stays inside the stage
+                const pld_d4 c0 = b0, c1 = b1;
+                b0 = load_b(st + 2);
+                b1 = load_b(st + 3);
+                const int kk = st * 4 - k0;
+                double av[NA];
+#pragma unroll
+                for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + lq) * PLD_QS + ai * 16 + lr];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double bv = colok[t] ? c0[t] : 0.0;
+#pragma unroll
+                    for (int ai = 0; ai < NA; ++ai)
+                        acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv, acc[t][ai], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + 4 + lq) * PLD_QS + ai * 16 + lr];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double bv = colok[t] ? c1[t] : 0.0;
+#pragma unroll
+                    for (int ai = 0; ai < NA; ++ai)
+                        acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv, acc[t][ai], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + t;
+#pragma unroll
+            for (int ai = 0; ai < NA; ++ai)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = ai * 16 + lq + 4 * r;
+                    if (colok[t] && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
+                }
+        }
+    }
+    __syncthreads();
+}
+
+// SVQB orthonormalisation of the P x l matrix Yv (in place): unit-scale columns, eig of the l x l Gram, Yv S Phi^-1/2
+template <int NA>
+static __device__ __noinline__ void eig_svqb(EigCtx c, double *Yv) {
+    LK_EIG_LDS;
+    const int tid = threadIdx.x, nt = blockDim.x, l = c.l, ld = c.ld;
+    double *T = lds_dyn + c.T, *W = lds_dyn + c.W, *vec = lds_dyn + c.vec;
+    for (int pass = 0; pass < 2; ++pass) {
+        eig_xty(c, Yv, Yv, c.T);
+        if (tid < l) vec[tid] = T[tid * ld + tid] > 0.0 ? 1.0 / sqrt(T[tid * ld + tid]) : 0.0;
+        __syncthreads();
+        for (int e = tid; e < l * l; e += nt) {
+            const int a = e / l, cc = e % l;
+            if (cc >= a) {
+                const double v = 0.5 * (T[a * ld + cc] + T[cc * ld + a]) * vec[a] * vec[cc];
+                W[a * ld + cc] = v;
+                W[cc * ld + a] = v;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < l * l; e += nt) T[(e / l) * ld + (e % l)] = W[(e / l) * ld + (e % l)];
+        __syncthreads();
+        jacobi_eig_lds<false>(c.T, c.W, l, ld, c.rot, c.shred);
+        double mx = 0.0;
+        for (int a = 0; a < l; ++a) mx = fmax(mx, T[a * ld + a]);
+        if (tid < l) {
+            const double ph = fmax(T[tid * ld + tid], 1e-15 * mx);
+            vec[l + tid] = 1.0 / sqrt(ph);
+        }
+        __syncthreads();
+        // Mm = diag(vec) W diag(vec2) into T, then Yv <- Yv Mm in place
+        for (int e = tid; e < l * l; e += nt) {
+            const int a = e / l, cc = e % l;
+            T[a * ld + cc] = vec[a] * W[a * ld + cc] * vec[l + cc];
+        }
+        __syncthreads();
+        eig_xm<NA, false>(c, Yv, Yv, nullptr, nullptr, c.T, -1);
+    }
+}
+
+// Cholesky-QR of the P x l matrix Yin -> Qout (two passes; Qout may be Yin).  The columns handed in are images C^q r of
+// Ritz vectors, i.e. nearly orthogonal with wildly different norms: after scaling them to unit length the Gram matrix is
+// close to the identity and its Cholesky factor is benign.  Returns false (in every thread) on a breakdown (pivot <=
+// 1e-12), in which case the caller falls back to SVQB.
+template <int NA>
+static __device__ __noinline__ bool eig_cholqr(EigCtx c, const double *Yin, double *Qout) {
+    LK_EIG_LDS;
+    const int tid = threadIdx.x, nt = blockDim.x, l = c.l, ld = c.ld;
+    double *T = lds_dyn + c.T, *W = lds_dyn + c.W, *vec = lds_dyn + c.vec;
+    int *order = reinterpret_cast<int *>(lds_dyn + c.order);
+    const double *cur = Yin;
+    for (int pass = 0; pass < 2; ++pass) {
+        eig_xty(c, cur, cur, c.W);
+        if (tid < l) vec[tid] = W[tid * ld + tid] > 0.0 ? 1.0 / sqrt(W[tid * ld + tid]) : 0.0;
+        __syncthreads();
+        for (int e = tid; e < l * l; e += nt) {
+            const int a = e / l, cc = e % l;
+            if (cc >= a) {
+                const double v = 0.5 * (W[a * ld + cc] + W[cc * ld + a]) * vec[a] * vec[cc];
+                T[a * ld + cc] = v;
+                T[cc * ld + a] = v;
+            }
+        }
+        __syncthreads();
+        // T = L L^T in place (lower), then W = L^-1, both on one wave (l <= 64: lane = row)
+        if (tid < 64) {
+            int ok = 1;
+            for (int j = 0; j < l; ++j) {
+                const double d = T[j * ld + j];
+                if (!(d > 1e-12)) {
+                    ok = 0;
+                    break;
+                }
+                const double rs = 1.0 / sqrt(d);
+                __builtin_amdgcn_wave_barrier();
+                if (tid >= j && tid < l) T[tid * ld + j] *= rs;  // column j of L (diagonal included: sqrt(d))
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (tid > j && tid < l) {
+                    const double lij = T[tid * ld + j];
+                    for (int cc = j + 1; cc <= tid; ++cc) T[tid * ld + cc] -= lij * T[cc * ld + j];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (tid == 0) order[0] = ok;
+            if (ok && tid < l) {
+                // COLUMN cc of L^-1 solves L x = e_cc: lane = column, forward substitution down the rows
+                const int cc = tid;
+                for (int i = 0; i < l; ++i) {
+                    double x = (i == cc) ? 1.0 : 0.0;
+                    for (int m = cc; m < i; ++m) x -= T[i * ld + m] * W[m * ld + cc];
+                    W[i * ld + cc] = i < cc ? 0.0 : x / T[i * ld + i];
+                }
+            }
+        }
+        __syncthreads();
+        const bool ok = order[0] != 0;
+        __syncthreads();
+        if (!ok) return false;
+        // Mm[a][cc] = vec[a] Linv[cc][a] (a <= cc): out = cur diag(vec) L^-T
+        for (int e = tid; e < l * l; e += nt) {
+            const int a = e / l, cc = e % l;
+            T[a * ld + cc] = a <= cc ? vec[a] * W[cc * ld + a] : 0.0;
+        }
+        __syncthreads();
+        eig_xm<NA, false>(c, cur, Qout, nullptr, nullptr, c.T, -1);
+        cur = Qout;
+    }
+    return true;
+}
+
 // Top-k eigenpairs of the P x P Gram matrix of matrix b -> V (P x k, row-major), lam (k).  One workgroup per matrix.
-// scratch per matrix: 4 * P * l doubles (Q, Z, R, Y).
+// scratch per matrix: 4 * P * l doubles (Q, Z, R, Y).  NA = number of 16-column tiles of the basis (l <= 16 NA): a
+// compile-time constant, because with a run-time bound the compiler keeps all 4 x 4 accumulator tiles of the product
+// with C (128 VGPRs = the whole budget of a 1024-thread workgroup) and spills around every MFMA.
+template <int NA>
 __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__ G, int ldg, int P, int k, int l, int npow,
                                                              double *__restrict__ scratch, double *__restrict__ V,
-                                                             double *__restrict__ lam, int *__restrict__ iters_out,
-                                                             int max_it, int *__restrict__ status) {
+                                                             double *__restrict__ lam, long long *__restrict__ iters_out,
+                                                             int max_it, int *__restrict__ status, int cheb_on) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     double *Gb = G + (size_t)b * ldg * ldg;
     double *Vb = V + (size_t)b * P * k, *lamb = lam + (size_t)b * k;
     const int ld = l + 1;                      // odd leading dimension: conflict-free column walks
-    double *T = lds;                           // l x ld
-    double *W = T + l * ld;                    // l x ld
-    double *rot = W + l * ld;                  // (l/2) x 4
-    double *shred = rot + 2 * l;               // nt doubles
-    double *vec = shred + nt;                  // 2 * l  (norms / theta)
-    int *order = reinterpret_cast<int *>(vec + 2 * l);  // l ints
-    double *qstage = vec + 2 * l + (l + 1) / 2 + 1;      // PLD_KC x PLD_QS (subspace path only)
+    const int oT = 0, oW = l * ld, orot = 2 * l * ld, oshred = orot + 2 * l, ovec = oshred + nt, oorder = ovec + 2 * l,
+              oqstage = oorder + (l + 1) / 2 + 1;
+    double *T = lds + oT;                      // l x ld
+    double *W = lds + oW;                      // l x ld
+    double *shred = lds + oshred;              // nt doubles (after the (l/2) x 4 rotation table)
+    double *vec = lds + ovec;                  // 2 * l  (norms / theta)
+    int *order = reinterpret_cast<int *>(lds + oorder);  // l ints; then qstage: PLD_KC x PLD_QS (subspace path only)
 
     if (P <= l && l > PLD_LMAX) {
         if (status && status[b]) return;  // the short subspace pass already converged this matrix
@@ -345,14 +681,15 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         // fill it) and the eigenvectors transposed in global scratch.  A few ms per matrix, against tens of Rayleigh-
         // Ritz steps of the subspace iteration when the spectrum of a 2nd-order product block decays slowly.
         double *Wt = scratch + (size_t)b * l * l;
-        double *rot2 = T + l * ld, *shred2 = rot2 + 2 * l, *vec2 = shred2 + nt;
+        const int orot2 = l * ld, oshred2 = orot2 + 2 * l;
+        double *vec2 = lds + oshred2 + nt;
         int *order2 = reinterpret_cast<int *>(vec2 + 2 * l);
         for (int e = tid; e < l * l; e += nt) {
             const int i = e / l, j = e % l;
             T[i * ld + j] = (i < P && j < P) ? gsym(Gb, ldg, i, j) : 0.0;
         }
         __syncthreads();
-        jacobi_eig_lds(T, nullptr, l, ld, rot2, shred2, Wt);
+        jacobi_eig_lds<true>(oT, oT, l, ld, orot2, oshred2, Wt);
         if (tid < l && tid >= P) T[tid * ld + tid] = -1.0;  // pad eigenvalue sorts last
         __syncthreads();
         // order by eigenvalue, l may exceed 64: rank by counting, one thread per entry
@@ -371,7 +708,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
             Vb[(size_t)i * k + a] = Wt[(size_t)order2[a] * l + i];
         }
         if (tid < k) lamb[tid] = T[order2[tid] * ld + order2[tid]];
-        if (tid == 0 && iters_out) iters_out[b] = 0;
+        if (tid == 0 && iters_out) iters_out[(size_t)b * 8] = 0;
         return;
     }
     if (P <= l) {
@@ -381,7 +718,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
             T[i * ld + j] = (i < P && j < P) ? gsym(Gb, ldg, i, j) : 0.0;
         }
         __syncthreads();
-        jacobi_eig_lds(T, W, l, ld, rot, shred);
+        jacobi_eig_lds<false>(oT, oW, l, ld, orot, oshred);
         if (tid < l && tid >= P) T[tid * ld + tid] = -1.0;  // pad eigenvalue sorts last
         __syncthreads();
         sort_desc_lds(T, l, ld, order);
@@ -390,208 +727,26 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
             Vb[e] = W[i * ld + order[a]];
         }
         if (tid < k) lamb[tid] = T[order[tid] * ld + order[tid]];
-        if (tid == 0 && iters_out) iters_out[b] = 0;
+        if (tid == 0 && iters_out) iters_out[(size_t)b * 8] = 0;
         return;
     }
 
+    // ---- subspace iteration with Rayleigh-Ritz steps
     double *Q = scratch + (size_t)b * 4 * P * l, *Z = Q + (size_t)P * l, *R = Z + (size_t)P * l, *Y = R + (size_t)P * l;
-    // SVQB orthonormalisation of the P x l matrix Y (in place): unit-scale columns, eig of the l x l Gram, Y S Phi^-1/2
-    auto svqb = [&](double *Y, double *tmp) {
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int a = tid; a < l; a += nt) vec[a] = 0.0;
-            __syncthreads();
-            // G = Y^T Y (thread per (a, b) entry)
-            for (int e = tid; e < l * l; e += nt) {
-                const int a = e / l, c = e % l;
-                double s = 0.0;
-                if (c >= a)
-                    for (int i = 0; i < P; ++i) s = fma(Y[(size_t)i * l + a], Y[(size_t)i * l + c], s);
-                T[a * ld + c] = s;
-            }
-            __syncthreads();
-            for (int e = tid; e < l * l; e += nt) {
-                const int a = e / l, c = e % l;
-                if (c < a) T[a * ld + c] = T[c * ld + a];
-            }
-            __syncthreads();
-            if (tid < l) vec[tid] = T[tid * ld + tid] > 0.0 ? 1.0 / sqrt(T[tid * ld + tid]) : 0.0;
-            __syncthreads();
-            for (int e = tid; e < l * l; e += nt) {
-                const int a = e / l, c = e % l;
-                T[a * ld + c] *= vec[a] * vec[c];
-            }
-            __syncthreads();
-            jacobi_eig_lds(T, W, l, ld, rot, shred);
-            double mx = 0.0;
-            for (int a = 0; a < l; ++a) mx = fmax(mx, T[a * ld + a]);
-            if (tid < l) {
-                const double ph = fmax(T[tid * ld + tid], 1e-15 * mx);
-                vec[l + tid] = 1.0 / sqrt(ph);
-            }
-            __syncthreads();
-            // tmp = Y diag(vec) W diag(vec2); then copy back
-            for (int e = tid; e < P * l; e += nt) {
-                const int i = e / l, c = e % l;
-                double s = 0.0;
-                for (int a = 0; a < l; ++a) s = fma(Y[(size_t)i * l + a] * vec[a], W[a * ld + c], s);
-                tmp[e] = s * vec[l + c];
-            }
-            __syncthreads();
-            for (int e = tid; e < P * l; e += nt) Y[e] = tmp[e];
-            __syncthreads();
+    const EigCtx ctx{oT, oW, orot, oshred, ovec, oqstage, oorder, Gb, ldg, P, k, l, ld};
+    long long tprof[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = iters_out ? (long long)wall_clock64() : 0;
+    auto lap = [&](int slot) {  // debug (LK_PLD_ITERS=1): per-phase 100 MHz ticks
+        if (iters_out) {
+            const long long now = (long long)wall_clock64();
+            tprof[slot] += now - tlast;
+            tlast = now;
         }
     };
-
-    // ---- the Gram kernel wrote the upper 64x64 blocks only: mirror them so the products below read plain rows
+    // the Gram kernel wrote the upper 64x64 blocks only: mirror them so the products below read plain rows
     for (int e = tid; e < P * P; e += nt) {
         const int i = e / P, j = e - i * P;
         if ((j >> 6) < (i >> 6)) Gb[(size_t)i * ldg + j] = Gb[(size_t)j * ldg + i];
     }
-    __syncthreads();
-
-    // ---- dst = C src (P x l, row-major) on the fp64 matrix cores: dst^T (l x P) = src^T (l x P) C (P x P).
-    // v_mfma_f64_16x16x4: A[row = lane & 15][k = lane >> 4] = src[k0 + k][a0 + row] from an LDS stage of PLD_KC rows,
-    // B[k = lane >> 4][col = lane & 15] = C[k0 + k][n0 + col] straight from global (4 x 128-B row segments per load),
-    // D[row = (lane >> 4) + 4 r][col = lane & 15] -> dst[n0 + col][a0 + row].  A wave owns up to four 16-column
-    // tiles of C and streams each of its C elements exactly once per product.
-    const int wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
-    const int na = (l + 15) >> 4, ntile = (P + 15) >> 4;
-    // NA (16-column tiles of the basis, l <= 16 NA) is a compile-time constant: with a run-time bound the compiler keeps
-    // all 4 x 4 accumulator tiles (128 VGPRs = the whole budget of a 1024-thread workgroup) and spills hundreds of
-    // registers around every MFMA
-    auto cq_impl = [&](auto na_c, const double *src, double *dst) {
-        constexpr int NA = decltype(na_c)::value;
-        for (int tbase = 0; tbase < ntile; tbase += 4 * nwv) {
-            pld_d4 acc[4][NA];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < P; k0 += PLD_KC) {
-                __syncthreads();
-                for (int e = tid; e < PLD_KC * 16 * na; e += nt) {
-                    const int kk = e / (16 * na), a = e - kk * (16 * na);
-                    qstage[kk * PLD_QS + a] = (k0 + kk < P && a < l) ? src[(size_t)(k0 + kk) * l + a] : 0.0;
-                }
-                __syncthreads();
-                const int kend = min(PLD_KC, P - k0);
-                for (int kk = 0; kk < kend; kk += 4) {
-                    const int krow = k0 + kk + (lane >> 4);
-                    double bv[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int ncol = (tbase + wave + t * nwv) * 16 + (lane & 15);
-                        bv[t] = (krow < P && ncol < P) ? Gb[(size_t)krow * ldg + ncol] : 0.0;
-                    }
-                    double av[NA];
-#pragma unroll
-                    for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + (lane >> 4)) * PLD_QS + ai * 16 + (lane & 15)];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int ai = 0; ai < NA; ++ai)
-                            acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv[t], acc[t][ai], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int n = (tbase + wave + t * nwv) * 16 + (lane & 15);
-#pragma unroll
-                for (int ai = 0; ai < NA; ++ai)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int a = ai * 16 + (lane >> 4) + 4 * r;
-                        if (n < P && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
-                    }
-            }
-        }
-        __syncthreads();
-    };
-    auto cq_mfma = [&](const double *src, double *dst) {
-        if (na <= 2)
-            cq_impl(std::integral_constant<int, 2>{}, src, dst);
-        else
-            cq_impl(std::integral_constant<int, 4>{}, src, dst);
-    };
-
-    // ---- Cholesky-QR of the P x l matrix Yin -> Qout (two passes).  The columns handed in are images C^q r of Ritz
-    // vectors, i.e. nearly orthogonal with wildly different norms: after scaling them to unit length the Gram matrix is
-    // close to the identity and its Cholesky factor is benign.  Returns false (in every thread) on a breakdown
-    // (pivot <= 1e-12), in which case the caller falls back to SVQB.
-    auto cholqr = [&](const double *Yin, double *Qout, double *tmp) -> bool {
-        const double *cur = Yin;
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int e = tid; e < l * l; e += nt) {
-                const int a = e / l, c = e % l;
-                double sm = 0.0;
-                if (c >= a)
-                    for (int i = 0; i < P; ++i) sm = fma(cur[(size_t)i * l + a], cur[(size_t)i * l + c], sm);
-                T[a * ld + c] = sm;
-            }
-            __syncthreads();
-            if (tid < l) vec[tid] = T[tid * ld + tid] > 0.0 ? 1.0 / sqrt(T[tid * ld + tid]) : 0.0;
-            __syncthreads();
-            for (int e = tid; e < l * l; e += nt) {
-                const int a = e / l, c = e % l;
-                if (c >= a) {
-                    const double v = T[a * ld + c] * vec[a] * vec[c];
-                    T[a * ld + c] = v;
-                    T[c * ld + a] = v;
-                }
-            }
-            __syncthreads();
-            // T = L L^T in place (lower), then W = L^-1, both on one wave (l <= 64: lane = row)
-            if (tid < 64) {
-                int ok = 1;
-                for (int j = 0; j < l; ++j) {
-                    const double d = T[j * ld + j];
-                    if (!(d > 1e-12)) {
-                        ok = 0;
-                        break;
-                    }
-                    const double rs = 1.0 / sqrt(d);
-                    __builtin_amdgcn_wave_barrier();
-                    if (tid >= j && tid < l) T[tid * ld + j] *= rs;  // column j of L (diagonal included: sqrt(d))
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (tid > j && tid < l) {
-                        const double lij = T[tid * ld + j];
-                        for (int c = j + 1; c <= tid; ++c) T[tid * ld + c] -= lij * T[c * ld + j];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (tid == 0) order[0] = ok;
-                if (ok && tid < l) {
-                    // row `tid` of W = L^-1 is not independent of the others, but COLUMN c of L^-1 solves L x = e_c:
-                    // lane = column c, forward substitution down the rows
-                    const int c = tid;
-                    for (int i = 0; i < l; ++i) {
-                        double x = (i == c) ? 1.0 : 0.0;
-                        for (int m = c; m < i; ++m) x -= T[i * ld + m] * W[m * ld + c];
-                        W[i * ld + c] = i < c ? 0.0 : x / T[i * ld + i];
-                    }
-                }
-            }
-            __syncthreads();
-            const bool ok = order[0] != 0;
-            __syncthreads();
-            if (!ok) return false;
-            // out[i][c] = sum_{a <= c} cur[i][a] vec[a] Linv[c][a]
-            for (int e = tid; e < P * l; e += nt) {
-                const int i = e / l, c = e % l;
-                double sm = 0.0;
-                for (int a2 = 0; a2 <= c; ++a2) sm = fma(cur[(size_t)i * l + a2] * vec[a2], W[c * ld + a2], sm);
-                tmp[e] = sm;
-            }
-            __syncthreads();
-            for (int e = tid; e < P * l; e += nt) Qout[e] = tmp[e];
-            __syncthreads();
-            cur = Qout;
-        }
-        return true;
-    };
-
     // deterministic pseudo-random start
     for (int e = tid; e < P * l; e += nt) {
         unsigned int x = (unsigned int)(e + 1) * 2654435761u;
@@ -601,74 +756,92 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         Q[e] = (double)(x & 0xffffffu) / 8388608.0 - 1.0;
     }
     __syncthreads();
-    svqb(Q, R);
+    eig_svqb<NA>(ctx, Q);
+    lap(0);
     int it = 0;
     bool converged = false;
+    double *theta = vec + l;  // sorted Ritz values of the current step
     for (; it < max_it; ++it) {
-        cq_mfma(Q, Z);  // Z = C Q
-        // T = Q^T Z (symmetrised)
-        for (int e = tid; e < l * l; e += nt) {
-            const int a = e / l, c = e % l;
-            double s = 0.0;
-            for (int i = 0; i < P; ++i) s = fma(Q[(size_t)i * l + a], Z[(size_t)i * l + c], s);
-            W[a * ld + c] = s;
-        }
-        __syncthreads();
+        eig_cq<NA>(ctx, Q, Z);  // Z = C Q
+        lap(1);
+        eig_xty(ctx, Q, Z, oW);  // T = Q^T Z (symmetrised)
         for (int e = tid; e < l * l; e += nt) {
             const int a = e / l, c = e % l;
             T[a * ld + c] = 0.5 * (W[a * ld + c] + W[c * ld + a]);
         }
         __syncthreads();
-        jacobi_eig_lds(T, W, l, ld, rot, shred);
+        lap(2);
+        jacobi_eig_lds<false>(oT, oW, l, ld, orot, oshred);
         sort_desc_lds(T, l, ld, order);
-        // R = Q W (Ritz vectors, sorted by Ritz value), Y = Z W = C R
-        for (int e = tid; e < P * l; e += nt) {
-            const int i = e / l, c = e % l;
-            const int oc = order[c];
-            double s = 0.0, y = 0.0;
-            for (int a = 0; a < l; ++a) {
-                const double w = W[a * ld + oc];
-                s = fma(Q[(size_t)i * l + a], w, s);
-                y = fma(Z[(size_t)i * l + a], w, y);
-            }
-            R[e] = s;
-            Y[e] = y;
+        lap(3);
+        // R = Q W (Ritz vectors, sorted by Ritz value), Y = Z W = C R, and the residual || C r - theta r || of the k
+        // wanted pairs, in one pass over Q and Z
+        if (tid < l) theta[tid] = T[order[tid] * ld + order[tid]];
+        __syncthreads();
+        for (int e = tid; e < l * l; e += nt) {
+            const int a = e / l, c = e % l;
+            T[a * ld + c] = W[a * ld + order[c]];
         }
         __syncthreads();
-        // residual of the k wanted pairs: || C r - theta r ||
-        double part = 0.0;
-        for (int e = tid; e < P * k; e += nt) {
-            const int i = e / k, c = e % k;
-            const double th = T[order[c] * ld + order[c]];
-            const double d = Y[(size_t)i * l + c] - th * R[(size_t)i * l + c];
-            part = fma(d, d, part);
-        }
+        const double part = eig_xm<NA, true>(ctx, Q, R, Z, Y, oT, ovec + l);
         const double res = sqrt(block_sum_dyn(part, shred));
-        const double th0 = fabs(T[order[0] * ld + order[0]]);
-        if (tid < k) lamb[tid] = T[order[tid] * ld + order[tid]];  // T is reused by the orthonormalisation below
+        const double th0 = fabs(theta[0]), th_k = theta[k - 1], th_cut = theta[l - 1];
+        if (tid < k) lamb[tid] = theta[tid];
         __syncthreads();
+        lap(4);
         if (res <= 1e-13 * th0 * sqrt((double)k)) {
             converged = true;
             break;
         }
-        // next basis: orthonormalised C^npow R (npow - 1 more products between two Rayleigh-Ritz steps)
+        // next basis: orthonormalised p(C) R with npow - 1 more products between two Rayleigh-Ritz steps.
+        //  * flat spectrum (the wanted Ritz values sit close to the first unwanted one: product blocks): p = the Chebyshev
+        //    polynomial of degree npow that is bounded by 1 on the unwanted interval [0, theta_cut] and grows fastest
+        //    outside it — for theta_k / theta_cut = 1.2 a degree-3 step damps the unwanted part 6.8x instead of the
+        //    1.7x of C^3, so the slowly converging blocks need a fraction of the Rayleigh-Ritz steps;
+        //  * steep spectrum: p = C^npow (the Chebyshev factors between the columns would differ by > 1e8 and only
+        //    invite a Cholesky breakdown; these blocks converge in a handful of steps anyway).
+        const bool cheb = (cheb_on & 1) && npow >= 2 && th_cut > 0.0 && th_k < 1.5 * th_cut && th0 < 30.0 * th_cut;
         double *src = Y, *dst = Z;
-        for (int pw = 1; pw < npow; ++pw) {
-            cq_mfma(src, dst);
-            double *t2 = src;
-            src = dst;
-            dst = t2;
+        if (cheb) {
+            // x = (C - c) / e with c = e = theta_cut / 2:  X0 = R, X1 = (C R - c R) / e, X_{j+1} = (2/e)(C X_j - c X_j) - X_{j-1}
+            const double cc = 0.5 * th_cut, ie = 1.0 / cc;
+            for (int e = tid; e < P * l; e += nt) Y[e] = (Y[e] - cc * R[e]) * ie;
+            __syncthreads();
+            double *prev = R, *cur = Y, *free1 = Z, *free2 = Q;
+            for (int pw = 1; pw < npow; ++pw) {
+                double *nxt = free1;
+                eig_cq<NA>(ctx, cur, nxt);
+                for (int e = tid; e < P * l; e += nt) nxt[e] = 2.0 * ie * (nxt[e] - cc * cur[e]) - prev[e];
+                __syncthreads();
+                free1 = free2;
+                free2 = prev;
+                prev = cur;
+                cur = nxt;
+            }
+            src = cur;
+        } else {
+            for (int pw = 1; pw < npow; ++pw) {
+                eig_cq<NA>(ctx, src, dst);
+                double *t2 = src;
+                src = dst;
+                dst = t2;
+            }
         }
-        if (!cholqr(src, Q, dst)) {  // breakdown: one plain step from the (orthonormal) Ritz vectors, SVQB
-            cq_mfma(R, Q);
-            svqb(Q, Z);
+        lap(5);
+        if (!eig_cholqr<NA>(ctx, src, Q)) {  // breakdown: one plain step from the (orthonormal) Ritz vectors, SVQB
+            eig_cq<NA>(ctx, R, Q);
+            eig_svqb<NA>(ctx, Q);
         }
+        lap(6);
     }
     for (int e = tid; e < P * k; e += nt) {
         const int i = e / k, a = e % k;
         Vb[e] = R[(size_t)i * l + a];
     }
-    if (tid == 0 && iters_out) iters_out[b] = it;
+    if (tid == 0 && iters_out) {  // debug (LK_PLD_ITERS=1): step count and per-phase 100 MHz ticks of this workgroup
+        iters_out[(size_t)b * 8] = it;
+        for (int s2 = 0; s2 < 7; ++s2) iters_out[(size_t)b * 8 + 1 + s2] = tprof[s2];
+    }
     if (tid == 0 && status) status[b] = converged ? 1 : 0;
 }
 
@@ -741,9 +914,13 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
     gram_plain_launch(A, d_off, B, P, G, stream);
     static const int direct_max = getenv("LK_PLD_DIRECT_MAX") ? atoi(getenv("LK_PLD_DIRECT_MAX")) : PLD_DIRECT_MAX;
     static const int npow = getenv("LK_PLD_POWER") ? std::max(1, atoi(getenv("LK_PLD_POWER"))) : 3;
+    static const int cheb_on = getenv("LK_PLD_CHEB") ? (atoi(getenv("LK_PLD_CHEB")) & 1) : 1;  // Chebyshev-filtered steps for flat spectra
+    static const bool dbg_iters = getenv("LK_PLD_ITERS") && atoi(getenv("LK_PLD_ITERS")) != 0;   // print Rayleigh-Ritz step counts
     static bool attr_set = false;
     if (!attr_set) {
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel),
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel<4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -775,8 +952,29 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
             return LK_ENOMEM;
         }
         const size_t lds = ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1 + PLD_KC * PLD_QS) * 8 + 64;
-        hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                           (int *)nullptr, two_pass ? 8 : 400, status);
+        long long *d_it = dbg_iters ? (long long *)ws.alloc((size_t)B * 64) : nullptr;
+        if (l <= 32)
+            hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
+                               d_it, two_pass ? 8 : 400, status, cheb_on);
+        else
+            hipLaunchKernelGGL(pld_topk_eig_kernel<4>, dim3(B), dim3(1024), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
+                               d_it, two_pass ? 8 : 400, status, cheb_on);
+        if (d_it) {
+            std::vector<long long> hit((size_t)B * 8);
+            LK_HIP_CHECK(hipMemcpyAsync(hit.data(), d_it, (size_t)B * 64, hipMemcpyDeviceToHost, stream));
+            LK_HIP_CHECK(hipStreamSynchronize(stream));
+            long long sum = 0, mx = 0;
+            double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int b2 = 0; b2 < B; ++b2) {
+                sum += hit[(size_t)b2 * 8];
+                mx = std::max(mx, hit[(size_t)b2 * 8]);
+                for (int s2 = 0; s2 < 7; ++s2) ph[s2] += (double)hit[(size_t)b2 * 8 + 1 + s2] / B * 0.01;  // 100 MHz ticks -> us
+            }
+            fprintf(stderr,
+                    "[pld eig] P=%d k=%d l=%d opt=%d: Rayleigh-Ritz steps mean %.1f max %lld over %d matrices; per matrix us: "
+                    "init %.0f | C*Q %.0f | Q^T Z %.0f | Jacobi %.0f | Ritz+resid %.0f | power products %.0f | CholQR %.0f\n",
+                    P, k, l, cheb_on, (double)sum / B, mx, B, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+        }
     }
     if (P <= PLD_LMAX || two_pass) {  // direct Jacobi on C
         const int l = (P + 1) & ~1, ld = l + 1;
@@ -791,8 +989,8 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         const int nt_eig = two_pass ? 512 : 1024;
         const size_t lds = two_pass ? ((size_t)l * ld + 2 * l + nt_eig + 2 * l + (l + 1) / 2 + 1) * 8 + 64
                                     : ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1) * 8 + 64;
-        hipLaunchKernelGGL(pld_topk_eig_kernel, dim3(B), dim3(nt_eig), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                           (int *)nullptr, 400, status);
+        hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_eig), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
+                           (long long *)nullptr, 400, status, cheb_on);
     }
     hipLaunchKernelGGL(pld_project_kernel, dim3((N + 63) / 64, B), dim3(256), 0, stream, A, V, lam, N, P, k, ldx, col0, X);
     return LK_OK;
