@@ -755,10 +755,12 @@ def main():
         ach = flop / (kern_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("pld"),
-                    "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
+                    "kernel": "gram128_kernel + gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
                     "note": "algorithmic 2*N*P^2 flop per PCA Gram (P = 121, 136, 816, 121) + 5 x 2*N*(K+1)^2 "
                             "for the regression, over the WHOLE step time (eigen-solver, projections, LU, "
-                            "clipping included), against the fp64 MFMA dense peak"}
+                            "clipping included), against the fp64 MFMA dense peak; the 816-column Gram alone "
+                            "(gram128_kernel, 25.3 ms) keeps the matrix cores 75 % busy "
+                            "(profiles/r02_pld_pmc_sq.txt: SQ_VALU_MFMA_BUSY_CYCLES)"}
         B, N = Bc, Nc
     elif args.workload == "flatten":
         t, y, dy, off = synth.ls_batch(6, B, N, first_index=first)

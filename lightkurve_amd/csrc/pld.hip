@@ -6,11 +6,15 @@
 // where every PLD/background block is the PCA (top-k left singular vectors of the column-centred matrix) of
 //   order 1: pixel flux / SAP flux;  order n: all n-fold products of the order-1 components;  background pixels.
 //
-// PCA = Gram + eigen: C = A^T A on the fp64 matrix cores (gram_mfma_kernel, the "MFMA A^T A" of config[4]), the
-// top-k eigenpairs of C by blocked subspace iteration with Rayleigh-Ritz — C Q on the matrix cores too, three power
-// steps per Ritz step, column-scaled Cholesky-QR between them (SVQB as the fallback and for the random start; small
-// l x l eigenproblems by parallel cyclic Jacobi in LDS) — or, for blocks of at most 138 columns whose iteration does
-// not converge in eight steps, by a direct Jacobi on C held in LDS; for P <= 64 the Jacobi always runs on C itself.
+// PCA = Gram + eigen: C = A^T A on the fp64 matrix cores (gram_mfma_kernel for narrow blocks; gram128_kernel — 128 x 128
+// output blocks, 4 x 4 MFMA tiles per wave, 76 % of the fp64 MFMA peak — for the wide product blocks: the "MFMA A^T A"
+// of config[4]), the top-k eigenpairs of C by blocked subspace iteration with Rayleigh-Ritz.  Every dense step of the
+// iteration is MFMA work in one workgroup per matrix: C Q (32-byte row loads two steps ahead of the matrix cores), the
+// skinny products Q^T Z and X M, Ritz vectors + residual in one pass; three products with C per Ritz step (eight for the
+// mid-size product blocks, whose flat spectrum tolerates it), column-scaled Cholesky-QR between steps (SVQB as the
+// fallback and for the random start; small l x l eigenproblems by parallel cyclic Jacobi in LDS).  Pixel blocks of at
+// most 138 columns whose iteration does not converge in eight steps fall through to a direct Jacobi on C held in LDS;
+// for P <= 64 the Jacobi always runs on C itself.
 // Then U = A V diag(lambda)^-1/2 (pld_project_kernel, MFMA) written straight into X.  The reference uses fbpca
 // (randomised range finder, 10 power iterations, 2 oversampling columns, unseeded RNG => not reproducible); the oracle
 // uses an exact SVD; the iteration here converges the residual ||C r - theta r|| to 1e-13 theta_max, i.e. to the exact
@@ -105,22 +109,40 @@ __global__ __launch_bounds__(256) void pld_center_kernel(double *__restrict__ A,
 // multichoose loop) of the k columns of U = X[:, col0 : col0 + k].  comb[idx * order + pos] = column of factor pos of
 // product idx (built once per (k, order) on the host).  Two kernels: the column means of the products (nothing is
 // written), then the CENTRED products — the PCA input — in one pass over A.
-__global__ __launch_bounds__(256) void pld_products_mean_kernel(const double *__restrict__ X, int ldx, int col0, int order,
-                                                                 int N, int Pc, const uint8_t *__restrict__ comb,
-                                                                 double *__restrict__ mean) {
-    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Pc) return;
+constexpr int PM_ROWS = 128;  // rows of U staged per step of the products-mean kernel
+__global__ __launch_bounds__(1024) void pld_products_mean_kernel(const double *__restrict__ X, int ldx, int col0, int k,
+                                                                  int order, int N, int Pc,
+                                                                  const uint8_t *__restrict__ comb,
+                                                                  double *__restrict__ mean) {
+    // workgroup = 256 products x 4 row phases; the rows of U go through LDS in chunks, the four phase sums are added in
+    // a fixed order (the one-thread-per-product version walked all N rows serially with strided global loads)
+    __shared__ double us[PM_ROWS * 49];  // k <= 48 components, row stride k | 1
+    __shared__ double red[4][256];
+    const int b = blockIdx.y, t = threadIdx.x & 255, g = threadIdx.x >> 8, idx = blockIdx.x * 256 + t;
+    const int ks = k | 1;  // odd row stride
     int a[4] = {0, 0, 0, 0};
-    for (int pos = 0; pos < order; ++pos) a[pos] = comb[idx * order + pos];
+    if (idx < Pc)
+        for (int pos = 0; pos < order; ++pos) a[pos] = comb[idx * order + pos];
     const double *u = X + (size_t)b * N * ldx + col0;
     double s = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const double *r = u + (size_t)n * ldx;
-        double prod = r[a[0]];
-        for (int pos = 1; pos < order; ++pos) prod *= r[a[pos]];
-        s += prod;
+    for (int r0 = 0; r0 < N; r0 += PM_ROWS) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < PM_ROWS * k; e += 1024) {
+            const int r = e / k, c = e - r * k;
+            us[r * ks + c] = r0 + r < N ? u[(size_t)(r0 + r) * ldx + c] : 0.0;
+        }
+        __syncthreads();
+        const int rend = min(PM_ROWS, N - r0);
+        for (int r = g; r < rend; r += 4) {
+            const double *rr = us + r * ks;
+            double prod = rr[a[0]];
+            for (int pos = 1; pos < order; ++pos) prod *= rr[a[pos]];
+            s += prod;
+        }
     }
-    mean[(size_t)b * Pc + idx] = s / (double)N;
+    red[g][t] = s;
+    __syncthreads();
+    if (g == 0 && idx < Pc) mean[(size_t)b * Pc + idx] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / (double)N;
 }
 
 __global__ __launch_bounds__(256) void pld_products_kernel(const double *__restrict__ X, int ldx, int col0, int k, int order,
@@ -464,7 +486,8 @@ static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double 
 // dst = C src (P x l, row-major): dst^T (l x P) = src^T (l x P) C (P x P).  The A operand (src^T) comes from an LDS stage
 // of PLD_KC rows of src; the B operand straight from global: a wave owns 64 consecutive columns of C and a lane loads
 // FOUR of them per row (32 B, so one load instruction covers 4 rows x 512 contiguous bytes) — component j of the load
-// feeds MFMA tile j, whose column (lane & 15) is therefore column 64 w + 4 (lane & 15) + j of C.  Loads run two steps
+// feeds MFMA tile j, whose column (lane & 15) is therefore column 64 w + 4 (lane & 15) + j of C (two and 32 w + 2 (lane &
+// 15) + j for the wide basis).  Loads run two steps
 // ahead of the matrix cores.  Every element of C is streamed exactly once per product.
 template <int NA>
 static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double *dst_) {
@@ -474,25 +497,30 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
     const int lq = lane >> 4, lr = lane & 15, l = c.l, P = c.P, ldg = c.ldg, na = (l + 15) >> 4;
     LK_EIG_LDS;
     double *qstage = lds_dyn + c.qstage;
-    const int ngrp = (P + 63) >> 6, nsteps = (P + 3) >> 2;
+    // NT tiles (= NT consecutive columns per lane) per wave: 4 while the 4 x NA accumulator tiles fit the register budget
+    // of a 1024-thread workgroup, 2 for the wide basis (NA = 4: 4 x 4 tiles would be all 128 VGPRs)
+    constexpr int NT = NA <= 2 ? 4 : 2;
+    typedef double bvec __attribute__((ext_vector_type(NT)));
+    typedef __attribute__((address_space(1))) const bvec cgbvec;
+    const int ngrp = (P + 16 * NT - 1) / (16 * NT), nsteps = (P + 3) >> 2;
     for (int gbase = 0; gbase < ngrp; gbase += nwv) {
         const int grp = gbase + wave;
         const bool active = grp < ngrp;
-        const int n0 = grp * 64 + 4 * lr;
+        const int n0 = grp * (16 * NT) + NT * lr;
         cgdouble *cp = (cgdouble *)c.Gb + n0;
-        bool colok[4];
+        bool colok[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) colok[j] = active && n0 + j < P;
-        auto load_b = [&](int st) -> pld_d4 {
+        for (int j = 0; j < NT; ++j) colok[j] = active && n0 + j < P;
+        auto load_b = [&](int st) -> bvec {
             const int krow = st * 4 + lq;
-            return (active && krow < P) ? *(cgd4 *)(cp + (size_t)krow * ldg) : pld_d4{0.0, 0.0, 0.0, 0.0};
+            return (active && krow < P) ? *(cgbvec *)(cp + (size_t)krow * ldg) : bvec(0.0);
         };
-        pld_d4 acc[4][NA];
+        pld_d4 acc[NT][NA];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
-        pld_d4 b0 = load_b(0), b1 = load_b(1);
+        bvec b0 = load_b(0), b1 = load_b(1);
         for (int k0 = 0; k0 < P; k0 += PLD_KC) {
             __syncthreads();
             for (int e = tid; e < PLD_KC * 16 * na; e += nt) {
@@ -502,7 +530,7 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
             __syncthreads();
             const int s_lo = k0 >> 2, s_hi = min(nsteps, (k0 + PLD_KC) >> 2);
             for (int st = s_lo; st < s_hi; st += 2) {  // PLD_KC is a multiple of 8: step st + 1 stays inside the stage
-                const pld_d4 c0 = b0, c1 = b1;
+                const bvec c0 = b0, c1 = b1;
                 b0 = load_b(st + 2);
                 b1 = load_b(st + 3);
                 const int kk = st * 4 - k0;
@@ -510,7 +538,7 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
 #pragma unroll
                 for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + lq) * PLD_QS + ai * 16 + lr];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     const double bv = colok[t] ? c0[t] : 0.0;
 #pragma unroll
                     for (int ai = 0; ai < NA; ++ai)
@@ -519,7 +547,7 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
 #pragma unroll
                 for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + 4 + lq) * PLD_QS + ai * 16 + lr];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     const double bv = colok[t] ? c1[t] : 0.0;
 #pragma unroll
                     for (int ai = 0; ai < NA; ++ai)
@@ -528,7 +556,7 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
             }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const int n = n0 + t;
 #pragma unroll
             for (int ai = 0; ai < NA; ++ai)
@@ -845,59 +873,73 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
     if (tid == 0 && status) status[b] = converged ? 1 : 0;
 }
 
-// U = A V diag(lam)^-1/2 into X[:, col0 : col0 + k] on the fp64 matrix cores.  One workgroup = 64 rows of A (4 waves x
-// 16 rows); A is streamed once through a 64 x 64 LDS tile (512-B row segments), V through a 64 x 16 k_tiles tile;
-// v_mfma_f64_16x16x4: A operand [row = lane & 15][kk = lane >> 4], B operand [kk = lane >> 4][col = lane & 15],
-// D [row = (lane >> 4) + 4 r][col = lane & 15].  k <= 64 components (4 column tiles).
-constexpr int PRJ_TS = 65;  // LDS row stride of the A tile (doubles): odd => the 16 rows of an operand hit 16 banks pairs
+// U = A V diag(lam)^-1/2 into X[:, col0 : col0 + k] on the fp64 matrix cores.  One WAVE = 16 rows of A against all of V
+// (k <= 64 components = 4 column tiles), no LDS and no barriers: the first version staged 64 x 64 tiles of A and V through
+// LDS with two workgroup barriers around 16 MFMAs per wave and ran 15x off the HBM time of A.  v_mfma_f64_16x16x4:
+// A operand [row = lane & 15][kk = lane >> 4], B operand [kk = lane >> 4][col = lane & 15], D [row = (lane >> 4) + 4 r]
+// [col = lane & 15].  The summation index of an MFMA step is free to permute: lane group q = lane >> 4 owns columns
+// p0 + 4 q .. + 3 of A (one 32-byte load when P % 4 == 0 — the four groups cover a 128-byte line of each row) and feeds
+// component j at step j, with the matching row p0 + 4 q + j of V as the B operand (4 x 128-byte rows, from L1/L2).
+template <int KT, bool VEC4>  // KT = 16-column tiles of V (k <= 16 KT); VEC4: P % 4 == 0, rows of A are 32-byte aligned
 __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restrict__ A, const double *__restrict__ V,
                                                            const double *__restrict__ lam, int N, int P, int k, int ldx,
                                                            int col0, double *__restrict__ X) {
-    __shared__ double At[64 * PRJ_TS];
-    __shared__ double Vt[64 * 64];
-    const int b = blockIdx.y, n0 = blockIdx.x * 64;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const double *Ab = A + (size_t)b * N * P;
+    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    if (n0 >= N) return;
+    const int lq = lane >> 4, lr = lane & 15, row = n0 + lr;
+    const double *Ar = A + ((size_t)b * N + min(row, N - 1)) * P;
     const double *Vb = V + (size_t)b * P * k;
-    const int kt = (k + 15) >> 4;
-    pld_d4 acc[4];
+    // loads are UNCONDITIONAL on clamped addresses and masked afterwards: guarded loads end up behind branches and are
+    // no longer issued back to back
+    auto load_a = [&](int p0) -> pld_d4 {
+        const int p = p0 + 4 * lq;
+        pld_d4 v;
+        if (VEC4) {
+            v = *reinterpret_cast<const pld_d4 *>(Ar + min(p, P - 4));
+            if (!(row < N && p < P)) v = pld_d4{0.0, 0.0, 0.0, 0.0};
+        } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = pld_d4{0.0, 0.0, 0.0, 0.0};
-    for (int p0 = 0; p0 < P; p0 += 64) {
-        __syncthreads();
-        for (int e = tid; e < 64 * 64; e += 256) {
-            const int r = e >> 6, c = e & 63;
-            At[r * PRJ_TS + c] = (n0 + r < N && p0 + c < P) ? Ab[(size_t)(n0 + r) * P + p0 + c] : 0.0;
-        }
-        for (int e = tid; e < 64 * 16 * kt; e += 256) {
-            const int r = e / (16 * kt), c = e - r * (16 * kt);
-            Vt[r * 64 + c] = (p0 + r < P && c < k) ? Vb[(size_t)(p0 + r) * k + c] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < 64; kk += 4) {
-            const double av = At[(wave * 16 + (lane & 15)) * PRJ_TS + kk + (lane >> 4)];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < kt) {
-                    const double bv = Vt[(kk + (lane >> 4)) * 64 + c * 16 + (lane & 15)];
-                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[c], 0, 0, 0);
-                }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (c < kt) {
-            const int a = c * 16 + (lane & 15);
-            if (a < k) {
-                const double sc = sqrt(fmax(lam[(size_t)b * k + a], 1e-300));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wave * 16 + (lane >> 4) + 4 * r;
-                    if (n < N) X[((size_t)b * N + n) * ldx + col0 + a] = acc[c][r] / sc;
-                }
+            for (int j = 0; j < 4; ++j) {
+                const double x = Ar[min(p + j, P - 1)];
+                v[j] = (row < N && p + j < P) ? x : 0.0;
             }
         }
+        return v;
+    };
+    pld_d4 acc[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) acc[c] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < P; p0 += 64) {  // 64 columns per trip: four 32-byte loads of A and 16 kt loads of V in flight
+        pld_d4 a4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] = load_a(p0 + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + 16 * u + 4 * lq + j;
+#pragma unroll
+                for (int c = 0; c < KT; ++c) {
+                    const int col = c * 16 + lr;
+                    const double vraw = Vb[(size_t)min(p, P - 1) * k + min(col, k - 1)];
+                    const double bv = (p < P && col < k) ? vraw : 0.0;
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[u][j], bv, acc[c], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        const int a = c * 16 + lr;
+        if (a < k) {
+            const double sc = sqrt(fmax(lam[(size_t)b * k + a], 1e-300));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + lq + 4 * r;
+                if (n < N) X[((size_t)b * N + n) * ldx + col0 + a] = acc[c][r] / sc;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
@@ -913,7 +955,12 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
     }
     gram_plain_launch(A, d_off, B, P, G, stream);
     static const int direct_max = getenv("LK_PLD_DIRECT_MAX") ? atoi(getenv("LK_PLD_DIRECT_MAX")) : PLD_DIRECT_MAX;
-    static const int npow = getenv("LK_PLD_POWER") ? std::max(1, atoi(getenv("LK_PLD_POWER"))) : 3;
+    static const int npow_std = getenv("LK_PLD_POWER") ? std::max(1, atoi(getenv("LK_PLD_POWER"))) : 3;
+    // mid-size product blocks: a product with the 136 x 136 C is cheap next to the l x l Jacobi and the Cholesky-QR of a
+    // Rayleigh-Ritz step, and their flat spectrum keeps C^8 R well conditioned — 8 products per step need 5 steps where 3
+    // need 12.  (Pixel blocks must NOT do this: their steep spectrum makes C^5 R numerically rank-deficient, the Cholesky
+    // breaks down and the iteration stalls.)
+    static const int npow_prod = getenv("LK_PLD_POWER_PROD") ? std::max(1, atoi(getenv("LK_PLD_POWER_PROD"))) : 8;
     static const int cheb_on = getenv("LK_PLD_CHEB") ? (atoi(getenv("LK_PLD_CHEB")) & 1) : 1;  // Chebyshev-filtered steps for flat spectra
     static const bool dbg_iters = getenv("LK_PLD_ITERS") && atoi(getenv("LK_PLD_ITERS")) != 0;   // print Rayleigh-Ritz step counts
     static bool attr_set = false;
@@ -932,7 +979,14 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
     // Mid-size blocks (PLD_LMAX < P <= PLD_DIRECT_MAX) get two passes: a SHORT subspace iteration (a pixel block with a
     // few dominant stars converges in ~5 Rayleigh-Ritz steps), then the direct Jacobi on C itself for the matrices that
     // did not converge (2nd-order product blocks decay slowly: ~45 steps of the iteration vs one ~15 ms Jacobi).
-    const bool two_pass = P > PLD_LMAX && P <= std::min(direct_max, PLD_DIRECT_MAX);
+    // mid-size product blocks (2nd-order: 136 columns): subspace iteration with 8 products per Rayleigh-Ritz step (5 steps,
+    // 4.4 ms per matrix) instead of the direct Jacobi on C (135 rotation rounds x ~10 sweeps, 16 ms per matrix).
+    // LK_PLD_PROD_DIRECT=1 restores the Jacobi; LK_PLD_PROD_L overrides the basis width (default k + 16).
+    static const bool prod_direct = getenv("LK_PLD_PROD_DIRECT") && atoi(getenv("LK_PLD_PROD_DIRECT")) != 0;
+    static const int prod_l = getenv("LK_PLD_PROD_L") ? atoi(getenv("LK_PLD_PROD_L")) : 0;
+    const bool wide_sub = products && !prod_direct && P > PLD_LMAX && P <= PLD_DIRECT_MAX;
+    const bool two_pass = !wide_sub && P > PLD_LMAX && P <= std::min(direct_max, PLD_DIRECT_MAX);
+    const int npow = wide_sub ? npow_prod : npow_std;
     int *status = nullptr;
     if (two_pass) {
         status = (int *)ws.alloc((size_t)B * 4);
@@ -945,7 +999,7 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
     const bool direct_only = two_pass && products;
     if (direct_only) LK_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)B * 4, stream));
     if (P > PLD_LMAX && !direct_only) {  // subspace iteration
-        const int l = std::min(PLD_LMAX, (k + 16 + 1) & ~1), ld = l + 1;
+        const int l = (wide_sub && prod_l > 0) ? std::min(PLD_LMAX, prod_l & ~1) : std::min(PLD_LMAX, (k + 16 + 1) & ~1), ld = l + 1;
         double *scr = (double *)ws.alloc((size_t)B * 4 * P * l * 8);
         if (!scr) {
             set_error("PLD workspace exhausted (subspace)");
@@ -992,7 +1046,22 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_eig), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
                            (long long *)nullptr, 400, status, cheb_on);
     }
-    hipLaunchKernelGGL(pld_project_kernel, dim3((N + 63) / 64, B), dim3(256), 0, stream, A, V, lam, N, P, k, ldx, col0, X);
+    {
+        const dim3 grid((N + 63) / 64, B), blk(256);
+        const int kt = (k + 15) / 16;
+        const bool v4 = (P & 3) == 0 && P >= 4;
+#define LK_PROJ(KT, V4) hipLaunchKernelGGL((pld_project_kernel<KT, V4>), grid, blk, 0, stream, A, V, lam, N, P, k, ldx, col0, X)
+        if (kt <= 1) {
+            if (v4) LK_PROJ(1, true); else LK_PROJ(1, false);
+        } else if (kt == 2) {
+            if (v4) LK_PROJ(2, true); else LK_PROJ(2, false);
+        } else if (kt == 3) {
+            if (v4) LK_PROJ(3, true); else LK_PROJ(3, false);
+        } else {
+            if (v4) LK_PROJ(4, true); else LK_PROJ(4, false);
+        }
+#undef LK_PROJ
+    }
     return LK_OK;
 }
 
@@ -1060,8 +1129,8 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
             }
             LK_HIP_CHECK(hipMemcpyAsync(d_comb, comb.data(), comb.size(), hipMemcpyHostToDevice, stream));
             LK_HIP_CHECK(hipStreamSynchronize(stream));  // comb dies at the end of this iteration
-            hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(256), 0, stream, X, K, col1, o, N,
-                               Pc, d_comb, d_mean);
+            hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(1024), 0, stream, X, K, col1, k1, o,
+                               N, Pc, d_comb, d_mean);
             hipLaunchKernelGGL(pld_products_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc,
                                d_comb, d_mean, A);
             rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws, true, true);

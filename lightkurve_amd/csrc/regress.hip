@@ -506,9 +506,141 @@ __global__ __launch_bounds__(256) void invert_kernel(const double *__restrict__ 
     }
 }
 
+// Plain Gram matrix G = A^T A of a wide block (PCA of the PLD product blocks, K in the hundreds): 128 x 128 output blocks,
+// each wave a 64 x 64 sub-block = 4 x 4 MFMA tiles, 16 cadences per LDS stage.  Against the 64 x 64 kernel above (2 x 2
+// tiles per wave, three barriers around 32 MFMAs) a stage here is two barriers around 64 MFMAs per wave with 8 LDS
+// fragment reads per 16 MFMAs, which is what the matrix cores need to stay fed.  Only the blocks on or above the
+// diagonal are computed; on a diagonal block the strictly-lower wave idles and both operands come from one tile.
+// Output layout as gram_mfma_kernel's: G[row * ldg + col] for every 64 x 64 block on or above the diagonal.
+constexpr int G2_BLK = 128, G2_RC = 16, G2_LD = 144;  // LD == 16 mod 32 doubles: conflict-free ds_read_b64 fragments
+typedef double double2_t __attribute__((ext_vector_type(2)));
+template <bool VEC2>  // VEC2: K even, so every row of A is 16-byte aligned and a thread moves pairs of columns
+__global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__ A, const int64_t *__restrict__ n_off, int K,
+                                                       int KB2, int ldg, double *__restrict__ G) {
+    __shared__ __attribute__((aligned(16))) double sa[G2_RC][G2_LD];
+    __shared__ __attribute__((aligned(16))) double sb[G2_RC][G2_LD];
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (8 private L2s) by their linear index, so the
+    // index is re-read such that consecutive VIRTUAL indices — the blocks of one matrix, which walk the same cadences of
+    // the same column panels at the same time — land on one XCD and share its L2.
+    const int nb = gridDim.x, total = nb * gridDim.y, lin = blockIdx.x + nb * blockIdx.y, chunk = total >> 3;
+    const int virt = lin < chunk * 8 ? (lin & 7) * chunk + (lin >> 3) : lin;
+    int bi = 0, bj = virt % nb;
+    while (bj >= KB2 - bi) {
+        bj -= KB2 - bi;
+        ++bi;
+    }
+    bj += bi;
+    const int target = virt / nb;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    A += lo * K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = bi * G2_BLK, j0 = bj * G2_BLK;
+    const bool diag = bi == bj;
+    const bool idle = diag && wi > wj;  // strictly-lower 64 x 64 sub-block of a diagonal block
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // stage = 16 cadences x 128 columns per operand = 4 pairs (VEC2) or 8 single values per thread and operand.  Loads
+    // are unconditional on clamped addresses and masked afterwards (guarded loads compile to one branch per load).
+    double2_t ra[4], rb[4];
+    auto fetch = [&](int n0) {
+        if (VEC2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q, r = e >> 6, c = (e & 63) * 2;
+                const int nn = n0 + r;
+                const size_t rowo = (size_t)min(nn, n - 1) * K;
+                const double2_t va = *reinterpret_cast<const double2_t *>(A + rowo + min(i0 + c, K - 2));
+                const double2_t vb = *reinterpret_cast<const double2_t *>(A + rowo + min(j0 + c, K - 2));
+                ra[q] = (nn < n && i0 + c < K) ? va : (double2_t){0.0, 0.0};
+                rb[q] = (nn < n && j0 + c < K) ? vb : (double2_t){0.0, 0.0};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = tid + 256 * (2 * q + h), r = e >> 7, c = e & 127;
+                    const int nn = n0 + r;
+                    const size_t rowo = (size_t)min(nn, n - 1) * K;
+                    const double va = A[rowo + min(i0 + c, K - 1)], vb = A[rowo + min(j0 + c, K - 1)];
+                    ra[q][h] = (nn < n && i0 + c < K) ? va : 0.0;
+                    rb[q][h] = (nn < n && j0 + c < K) ? vb : 0.0;
+                }
+        }
+    };
+    fetch(0);
+    for (int n0 = 0; n0 < n; n0 += G2_RC) {
+        __syncthreads();  // the previous stage's fragments have been read
+        if (VEC2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q, r = e >> 6, c = (e & 63) * 2;
+                *reinterpret_cast<double2_t *>(&sa[r][c]) = ra[q];
+                *reinterpret_cast<double2_t *>(&sb[r][c]) = rb[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = tid + 256 * (2 * q + h), r = e >> 7, c = e & 127;
+                    sa[r][c] = ra[q][h];
+                    sb[r][c] = rb[q][h];
+                }
+        }
+        __syncthreads();
+        fetch(n0 + G2_RC);  // in flight while the matrix cores work (past the end: clamped, masked, unused)
+        if (!idle) {
+#pragma unroll
+            for (int kk = 0; kk < G2_RC; kk += 4) {
+                const int kr = kk + (lane >> 4), cc = lane & 15;
+                double av[4], bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    av[t] = sa[kr][wi * 64 + t * 16 + cc];
+                    bv[t] = sb[kr][wj * 64 + t * 16 + cc];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    if (idle) return;
+    double *Gt = G + (size_t)target * ldg * ldg;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi * 64 + a * 16 + (lane >> 4) + 4 * r;
+                const int col = j0 + wj * 64 + b * 16 + (lane & 15);
+                if (row < ldg && col < ldg) Gt[(size_t)row * ldg + col] = acc[a][b][r];
+            }
+}
+
 // plain Gram matrices G_b = A_b^T A_b of B row-major (N_b x K) blocks (no weights, no masks), for PCA (pld.hip)
 int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, double *G, hipStream_t stream) {
     const int KB = (K + GR_BLK - 1) / GR_BLK;
+    static const int wide_min = getenv("LK_GRAM_WIDE_MIN") ? atoi(getenv("LK_GRAM_WIDE_MIN")) : 192;
+    if (K >= wide_min) {
+        const int KB2 = (K + G2_BLK - 1) / G2_BLK;
+        if (K % 2 == 0)
+            hipLaunchKernelGGL(gram128_kernel<true>, dim3(KB2 * (KB2 + 1) / 2, B), dim3(256), 0, stream, A, d_off, K, KB2,
+                               KB * GR_BLK, G);
+        else
+            hipLaunchKernelGGL(gram128_kernel<false>, dim3(KB2 * (KB2 + 1) / 2, B), dim3(256), 0, stream, A, d_off, K, KB2,
+                               KB * GR_BLK, G);
+        return KB * GR_BLK;
+    }
     hipLaunchKernelGGL(gram_mfma_kernel, dim3(KB * (KB + 1) / 2, B), dim3(256), 0, stream, A, (const double *)nullptr,
                        (const double *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, d_off, K, KB, G);
     return KB * GR_BLK;  // leading dimension of each G_b
