@@ -48,7 +48,9 @@ static bool solve_small(std::vector<long double> &M, std::vector<long double> &b
 // coeffs[w]: FIR taps (scipy savgol_coeffs(w, p): min-norm solution of sum_j c_j x_j^i = delta_i0 with
 // x = h..-h; symmetric for deriv=0).  edge[2][half][w]: rows of E for outputs 0..half-1 from the first w samples
 // and outputs w-half..w-1 from the last w samples.  Abscissae are scaled to [-1, 1] for conditioning.
-static bool savgol_design(int w, int p, std::vector<double> &coeffs, std::vector<double> &edge) {
+static bool savgol_design(int w, int p, std::vector<double> &coeffs, std::vector<double> &edge,
+                          long double *tap_poly = nullptr,  // tap_poly[a]: c_j = sum_a tap_poly[a] ((half - j) / half)^a
+                          std::vector<double> *edge_minv = nullptr) {  // (p+1)^2: inverse moment matrix of the edge fit
     const int half = w / 2, np1 = p + 1;
     std::vector<long double> z(w);
     const long double hs = half > 0 ? (long double)half : 1.0L;
@@ -65,6 +67,8 @@ static bool savgol_design(int w, int p, std::vector<double> &coeffs, std::vector
         std::vector<long double> Mc = M;
         if (!solve_small(Mc, rhs, np1)) return false;
     }
+    if (tap_poly)
+        for (int a = 0; a < np1; ++a) tap_poly[a] = rhs[a];
     coeffs.assign(w, 0.0);
     for (int j = 0; j < w; ++j) {
         long double s = 0.0L;
@@ -81,6 +85,15 @@ static bool savgol_design(int w, int p, std::vector<double> &coeffs, std::vector
             for (int j = 0; j < w; ++j) s += powl(u[j], a + b);
             M[a * np1 + b] = s;
         }
+    if (edge_minv) {
+        edge_minv->assign((size_t)np1 * np1, 0.0);
+        for (int b = 0; b < np1; ++b) {
+            std::vector<long double> Mc = M, g(np1, 0.0L);
+            g[b] = 1.0L;
+            if (!solve_small(Mc, g, np1)) return false;
+            for (int a = 0; a < np1; ++a) (*edge_minv)[(size_t)a * np1 + b] = (double)g[a];
+        }
+    }
     edge.assign((size_t)2 * half * w, 0.0);
     for (int side = 0; side < 2; ++side)
         for (int r = 0; r < half; ++r) {
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     const int64_t *__restrict__ n_off, int window, int polyorder, double break_tol, int niters, double sigma,
     const double *__restrict__ coeffs, const double *__restrict__ edge, char *__restrict__ scratch,
     const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask,
-    int FIR_LDS, int stop_at) {
+    int FIR_LDS, int stop_at, double quad_a, double quad_b, const double *__restrict__ edge_minv) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
     // Phase profiling aid: LK_FLAT_STOP=<16 * iteration + phase> makes every workgroup return when it reaches that
     // point (phase numbers as in the lap() calls below), so kernel time differences between successive stop points
@@ -344,7 +357,83 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                 constexpr int FP = 8;
                 const int S = (((FIR_LDS / FP) - 4) / 32) * 32 + 4;
                 const int TO = S >= 36 ? ((FP * S - FP - (window - 1)) / FP) * FP : 0;
-                if (TO >= FP) {
+                // polyorder <= 3: the taps are a quadratic in the offset, c_k = a + b k^2, so an output is
+                // a S0 + b S2 with the window moments S0 = sum y, S2 = sum k^2 y — O(1) per output from three prefix sums
+                // (y, u y, u^2 y; u = position relative to the tile centre) instead of `window` FMAs.  A tile spans at
+                // most 4 windows, which keeps the cancellation in S2 = W2 - 2 v W1 + v^2 W0 to a few bits: the result is
+                // within ~1e-14 of the tap-by-tap sum (tests state 1e-10).  Used for long windows only (quad_b != 0).
+                const int QCAP = FIR_LDS / 3;
+                const int QNI = min(QCAP, 4 * window), QTO = QNI - (window - 1);
+                if (quad_b != 0.0 && QTO >= 64) {
+                    double *p0 = fir, *p1 = fir + QCAP, *p2 = fir + 2 * QCAP;
+                    const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+                    for (int o0 = o_lo; o0 < o_hi; o0 += QTO) {
+                        const int no = min(QTO, o_hi - o0), ni = no + window - 1;
+                        const double uc = 0.5 * (double)(ni - 1);
+                        const double *x = fm + (o0 - half);
+                        const int CH = (ni + nt - 1) / nt;
+                        const int e0 = min(ni, tid * CH), e1 = min(ni, e0 + CH);
+                        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                        for (int e = e0; e < e1; ++e) {
+                            const double yv = x[e], u = (double)e - uc;
+                            s0 += yv;
+                            s1 = fma(u, yv, s1);
+                            s2 = fma(u * u, yv, s2);
+                        }
+                        double i0 = s0, i1 = s1, i2 = s2;  // inclusive scan over the wave, then over the waves
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const double a0 = __shfl_up(i0, off), a1 = __shfl_up(i1, off), a2 = __shfl_up(i2, off);
+                            if (lane >= off) {
+                                i0 += a0;
+                                i1 += a1;
+                                i2 += a2;
+                            }
+                        }
+                        __syncthreads();  // shd and the prefix arrays of the previous tile are free
+                        if (lane == 63) {
+                            shd[wv * 3 + 0] = i0;
+                            shd[wv * 3 + 1] = i1;
+                            shd[wv * 3 + 2] = i2;
+                        }
+                        __syncthreads();
+                        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+                        for (int w2 = 0; w2 < wv && w2 < nwv; ++w2) {
+                            r0 += shd[w2 * 3 + 0];
+                            r1 += shd[w2 * 3 + 1];
+                            r2 += shd[w2 * 3 + 2];
+                        }
+                        {
+                            const double x0 = __shfl_up(i0, 1), x1 = __shfl_up(i1, 1), x2 = __shfl_up(i2, 1);
+                            if (lane > 0) {
+                                r0 += x0;
+                                r1 += x1;
+                                r2 += x2;
+                            }
+                        }
+                        for (int e = e0; e < e1; ++e) {
+                            const double yv = x[e], u = (double)e - uc;
+                            r0 += yv;
+                            r1 = fma(u, yv, r1);
+                            r2 = fma(u * u, yv, r2);
+                            p0[e] = r0;
+                            p1[e] = r1;
+                            p2[e] = r2;
+                        }
+                        __syncthreads();
+                        for (int q = tid; q < no; q += nt) {
+                            const int hi = q + window - 1;
+                            double w0 = p0[hi], w1 = p1[hi], w2 = p2[hi];
+                            if (q > 0) {
+                                w0 -= p0[q - 1];
+                                w1 -= p1[q - 1];
+                                w2 -= p2[q - 1];
+                            }
+                            const double v = (double)(q + half) - uc;
+                            const double m2 = fma(v, fma(v, w0, -2.0 * w1), w2);  // sum (u - v)^2 y
+                            tr[o0 + q] = fma(quad_b, m2, quad_a * w0);
+                        }
+                    }
+                } else if (TO >= FP) {
                     for (int o0 = o_lo; o0 < o_hi; o0 += TO) {
                         const int no = min(TO, o_hi - o0), ni = no + window - 1;
                         __syncthreads();
@@ -400,6 +489,43 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                 for (int e = tid; e < 2 * window; e += nt)
                     fir[e] = e < window ? fm[l + e] : fm[h - window + (e - window)];
                 __syncthreads();
+                const int np1 = polyorder + 1;
+                if (edge_minv && 2 * window + 2 * np1 <= FIR_LDS) {
+                    // The edge outputs are the least-squares polynomial of the side's `window` samples evaluated at the
+                    // output's position: p + 1 moments sum_j u_j^b x_j per side (one wave per moment), beta = M^-1 m,
+                    // then a Horner evaluation per output — O(window p) per segment instead of the half x window
+                    // operator rows (401 dependent FMAs per output on L2-resident rows: after the moment-form interior
+                    // this was most of the segment).  Abscissae scaled to [-1, 1] as on the host; polyorder <= 5.
+                    const double c0 = 0.5 * (double)(window - 1), sc = c0 > 0.0 ? c0 : 1.0;
+                    double *mom = fir + 2 * window;
+                    const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+                    for (int pair = wv; pair < 2 * np1; pair += nwv) {
+                        const int side = pair / np1, b = pair - side * np1;
+                        const double *x = fir + side * window;
+                        double sm = 0.0;
+                        for (int j = lane; j < window; j += 64) {
+                            const double u = ((double)j - c0) / sc;
+                            double ub = 1.0;
+                            for (int q = 0; q < b; ++q) ub *= u;
+                            sm = fma(ub, x[j], sm);
+                        }
+                        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                        if (lane == 0) mom[pair] = sm;
+                    }
+                    __syncthreads();
+                    for (int e = tid; e < 2 * half; e += nt) {
+                        const int side = e >= half, r = e - side * half;
+                        const int pos = side ? (window - half + r) : r;
+                        const double u = ((double)pos - c0) / sc;
+                        double acc = 0.0;
+                        for (int a = np1 - 1; a >= 0; --a) {
+                            double beta = 0.0;
+                            for (int b = 0; b < np1; ++b) beta = fma(edge_minv[a * np1 + b], mom[side * np1 + b], beta);
+                            acc = fma(acc, u, beta);
+                        }
+                        tr[side ? (h - half + r) : (l + r)] = acc;
+                    }
+                } else {
                 for (int e = tid; e < 2 * half; e += nt) {
                     const int side = e >= half, r = e - side * half;
                     const double *x = fir + side * window;
@@ -415,6 +541,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                     }
                     for (; j < window; ++j) acc = fma(E[(size_t)j * half], x[j], acc);
                     tr[side ? (h - half + r) : (l + r)] = acc;
+                }
                 }
             }
             __syncthreads();
@@ -539,7 +666,8 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     // double on the host and kept resident; it is a few ms of host work that would otherwise dominate small batches
     struct Design {
         int device, window, polyorder;
-        double *d_c, *d_e;
+        double *d_c, *d_e, *d_minv;  // d_minv: inverse moment matrix of the edge fit (polyorder <= 5), else nullptr
+        double quad_a, quad_b;  // taps = quad_a + quad_b k^2 (polyorder <= 3), else 0, 0
     };
     static std::vector<Design> cache;
     const Design *des = nullptr;
@@ -547,9 +675,28 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         if (d.device == h->device && d.window == window && d.polyorder == polyorder) des = &d;
     if (!des) {
         std::vector<double> coeffs, edge;
-        LK_REQUIRE(savgol_design(window, polyorder, coeffs, edge),
+        long double tap_poly[16] = {0};
+        std::vector<double> minv;
+        LK_REQUIRE(savgol_design(window, polyorder, coeffs, edge, tap_poly, &minv),
                    "singular Savitzky-Golay design (window %d, order %d)", window, polyorder);
-        Design d{h->device, window, polyorder, nullptr, nullptr};
+        Design d{h->device, window, polyorder, nullptr, nullptr, nullptr, 0.0, 0.0};
+        if (polyorder <= 5 && window >= 3) {
+            LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.d_minv), minv.size() * 8));
+            LK_HIP_CHECK(hipMemcpy(d.d_minv, minv.data(), minv.size() * 8, hipMemcpyHostToDevice));
+        }
+        if (polyorder >= 2 && polyorder <= 3 && window >= 3) {
+            const int half = window / 2;
+            const long double a = tap_poly[0], b = tap_poly[2] / ((long double)half * (long double)half);
+            long double worst = 0.0L;  // the odd terms vanish by symmetry; check the quadratic against the taps anyway
+            for (int j = 0; j < window; ++j) {
+                const long double k = (long double)(half - j);
+                worst = std::max(worst, fabsl(a + b * k * k - (long double)coeffs[j]));
+            }
+            if (worst <= 1e-15L * fabsl(a)) {
+                d.quad_a = (double)a;
+                d.quad_b = (double)b;
+            }
+        }
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.d_c), coeffs.size() * 8));
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d.d_e), edge.size() * 8 + 8));
         LK_HIP_CHECK(hipMemcpy(d.d_c, coeffs.data(), coeffs.size() * 8, hipMemcpyHostToDevice));
@@ -566,6 +713,12 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         des = &cache.back();
     }
     double *d_c = des->d_c, *d_e = des->d_e;
+    // moment form of the Savitzky-Golay interior for long windows (see the kernel); LK_FLAT_QUAD_MIN=0 disables it
+    static const int quad_min = getenv("LK_FLAT_QUAD_MIN") ? atoi(getenv("LK_FLAT_QUAD_MIN")) : 201;
+    const bool use_quad = quad_min > 0 && window >= quad_min && des->quad_b != 0.0;
+    const double quad_a = use_quad ? des->quad_a : 0.0, quad_b = use_quad ? des->quad_b : 0.0;
+    static const bool edge_moments = !(getenv("LK_FLAT_EDGE_OPS") && atoi(getenv("LK_FLAT_EDGE_OPS")) != 0);
+    const double *d_minv = edge_moments ? des->d_minv : nullptr;
     std::vector<int64_t> soff((size_t)B + 1, 0);
     for (int b = 0; b < B; ++b) {
         const int64_t n = n_off_host[b + 1] - n_off_host[b];
@@ -595,7 +748,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     }
     const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see the kernel
     hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
-                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at);
+                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
