@@ -329,7 +329,9 @@ constexpr int SEL_SAMPLE = 1024;
 
 template <class Val, class Keep>
 __device__ double block_select_sampled(int n, long long count, long long k, Val val, Keep keep, unsigned long long *sh,
-                                       double *cand, int cap, bool want_next, double *next, int dbg = -1) {
+                                       double *cand, int cap, bool want_next, double *next, int dbg = -1,
+                                       double *spacing = nullptr) {  // *spacing: mean gap between values around rank k (0 = unknown)
+    if (spacing) *spacing = 0.0;
     const int tid = threadIdx.x, nt = blockDim.x;
     int *ictl = reinterpret_cast<int *>(sh + 200);  // [0] ncand, [1] sample size   (sh[0..199] are used by the callees)
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(cand);
@@ -419,6 +421,7 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         __syncthreads();
         const int nc = ictl[0];
         if (nc > cap) return fallback();
+        if (spacing && nc > 0 && isfinite(lo) && isfinite(hi)) *spacing = (hi - lo) / (double)nc;
         if (dbg == 3) return 0.0;
         // the candidates, sorted once (keys[] aliases cand[]): rank lookups are then plain LDS reads
         int S2 = 2;
@@ -468,12 +471,62 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
 // numpy.median of the kept values through block_select_sampled; NaN if none kept.
 template <class Val, class Keep>
 __device__ double block_median_sampled(int n, long long count, Val val, Keep keep, unsigned long long *sh, double *cand,
-                                       int cap, int dbg = -1) {
+                                       int cap, int dbg = -1, double *spacing = nullptr) {
+    if (spacing) *spacing = 0.0;
     if (count <= 0) return __longlong_as_double(0x7ff8000000000000ll);
     const long long k = (count - 1) / 2;
     double nxt = 0.0;
-    const double a = block_select_sampled(n, count, k, val, keep, sh, cand, cap, (count & 1) == 0, &nxt, dbg);
+    const double a = block_select_sampled(n, count, k, val, keep, sh, cand, cap, (count & 1) == 0, &nxt, dbg, spacing);
     return (count & 1) ? a : (a + nxt) * 0.5;
+}
+
+// numpy.median of the kept values when a good GUESS is at hand (the median of nearly the same set, e.g. the previous
+// clipping iteration's): ONE pass counts the values below guess - width and collects those inside [guess - width, guess +
+// width]; if the two middle ranks fall among the collected values they are sorted (a few hundred keys) and the answer is
+// exact.  Otherwise *ok = false (every thread) and the caller runs block_median_sampled.  No sample, no 2048-key sort.
+template <class Val, class Keep>
+__device__ double block_median_near(int n, long long count, Val val, Keep keep, double guess, double width,
+                                    unsigned long long *sh, double *cand, int cap, bool *ok) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    *ok = false;
+    if (count <= 0 || !(width > 0.0) || !isfinite(guess)) return 0.0;
+    int *ictl = reinterpret_cast<int *>(sh + 200);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(cand);
+    const long long k = (count - 1) / 2;
+    const bool want_next = (count & 1) == 0;
+    const double lo = guess - width, hi = guess + width;
+    __syncthreads();
+    if (tid == 0) ictl[0] = 0;
+    __syncthreads();
+    long long c_less = 0;
+    strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
+        if (keep(i)) {
+            if (v < lo)
+                ++c_less;
+            else if (v <= hi) {
+                const int slot = atomicAdd(&ictl[0], 1);
+                if (slot < cap) cand[slot] = v;
+            }
+        }
+    });
+    const long long n_less = block_count_fast(c_less, reinterpret_cast<long long *>(sh));
+    __syncthreads();
+    const int nc = ictl[0];
+    const long long q = k - n_less;
+    int S2 = 2;
+    while (S2 < nc) S2 <<= 1;
+    if (S2 < nt && (nt & (nt - 1)) == 0) S2 = nt;  // the one-key-per-thread register sort
+    const bool good = nc <= cap && S2 <= cap && q >= 0 && q + (want_next ? 1 : 0) < (long long)nc;
+    __syncthreads();
+    if (!good) return 0.0;
+    for (int i = tid; i < S2; i += nt) keys[i] = i < nc ? f64_sortable(cand[i]) : ~0ull;
+    __syncthreads();
+    lds_bitonic_sort(keys, S2);
+    const double a = f64_from_sortable(keys[q]);
+    const double b = want_next ? f64_from_sortable(keys[q + 1]) : a;
+    __syncthreads();
+    *ok = true;
+    return want_next ? (a + b) * 0.5 : a;
 }
 
 }  // namespace lk

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     const int64_t *__restrict__ n_off, int window, int polyorder, double break_tol, int niters, double sigma,
     const double *__restrict__ coeffs, const double *__restrict__ edge, char *__restrict__ scratch,
     const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask,
-    int FIR_LDS, int stop_at, double quad_a, double quad_b, const double *__restrict__ edge_minv) {
+    int FIR_LDS, int stop_at, double quad_a, double quad_b, const double *__restrict__ edge_minv, int near_on) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
     // Phase profiling aid: LK_FLAT_STOP=<16 * iteration + phase> makes every workgroup return when it reaches that
     // point (phase numbers as in the lap() calls below), so kernel time differences between successive stop points
@@ -261,6 +261,8 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         lap(2);
     }
 
+    double dmed_prev = qnan, dspacing = 0.0;  // previous iteration's median dt and the mean gap between dt values around it
+    int nm_prev = 0;
     for (int it = 0; it < niters; ++it) {
         const bool last = it == niters - 1;
         lap_iter = it;
@@ -326,8 +328,20 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             const long long cnt = block_count_fast(c, shl);
             __syncthreads();
             lap(5);
-            dmed = block_median_sampled(nm - 1, cnt, dval, dkeep, sh, fir, FIR_LDS, stop_at >= 200 ? stop_at - 200 : -1);
+            // Later iterations: the dt's are the previous iteration's minus the few clipped cadences (each removes two
+            // gaps and adds their sum), so the median moved by at most ~3 ranks per clipped cadence — look for it within
+            // that many mean gaps of the previous median first (one pass, a few hundred candidates), exact when it hits.
+            bool near_ok = false;
+            if (it > 0 && near_on && dspacing > 0.0 && nm_prev >= nm) {
+                const double width = dspacing * (3.0 * (double)(nm_prev - nm) + 96.0);
+                dmed = block_median_near(nm - 1, cnt, dval, dkeep, dmed_prev, width, sh, fir, FIR_LDS, &near_ok);
+            }
+            if (!near_ok)
+                dmed = block_median_sampled(nm - 1, cnt, dval, dkeep, sh, fir, FIR_LDS, stop_at >= 200 ? stop_at - 200 : -1,
+                                            &dspacing);
             if (stop_at >= 200) return;
+            dmed_prev = dmed;
+            nm_prev = nm;
             lap(6);
         }
         const double thr = break_tol * dmed;  // NaN break_tol => every comparison false => no cuts
@@ -719,6 +733,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     const double quad_a = use_quad ? des->quad_a : 0.0, quad_b = use_quad ? des->quad_b : 0.0;
     static const bool edge_moments = !(getenv("LK_FLAT_EDGE_OPS") && atoi(getenv("LK_FLAT_EDGE_OPS")) != 0);
     const double *d_minv = edge_moments ? des->d_minv : nullptr;
+    static const int near_on = getenv("LK_FLAT_NEAR") ? atoi(getenv("LK_FLAT_NEAR")) : 1;  // guided dt median in iterations >= 1
     std::vector<int64_t> soff((size_t)B + 1, 0);
     for (int b = 0; b < B; ++b) {
         const int64_t n = n_off_host[b + 1] - n_off_host[b];
@@ -748,7 +763,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     }
     const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see the kernel
     hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
-                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv);
+                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
