@@ -73,6 +73,24 @@ def test_batch_of_cutouts_vs_oracle():
         assert np.max(np.abs(corrected[i] - r["corrected"])) / np.median(r["corrected"]) < 1e-6, i
 
 
+@pytest.mark.parametrize("order,comps,npix", [(2, 24, 11), (3, 20, 9), (2, 40, 11)])
+def test_wide_bases_vs_oracle(order, comps, npix):
+    """More than 16 PCA components: the 40- to 56-wide subspace (4 column tiles per wave in the eigen-solver, 2 to 3 in
+    the projection), product blocks of 300 / 1540 / 820 columns through the 128 x 128 Gram kernel."""
+    from lightkurve_amd import synth
+    cubes = []
+    for i in range(2):
+        t, flux, err, truth = synth.pld_cutout(4, 10 + i, n=700, npix=npix)
+        cubes.append(PixelCube(t, flux, err, mission="K2"))
+    corrected, outl = pld_correct_batch(cubes, pld_order=order, pca_components=comps)
+    allm = np.ones((npix, npix), bool)
+    for i, c in enumerate(cubes):
+        r = O.pld_correct(c.time, c.flux, c.flux_err, allm, allm, allm, pld_order=order, pca_components=comps,
+                          spline_degree=5)
+        assert np.array_equal(outl[i], r["outlier_mask"]), i
+        assert np.max(np.abs(corrected[i] - r["corrected"])) / np.median(r["corrected"]) < 1e-6, i
+
+
 def test_golden_sparse_design_matrix_branch(golden):
     """PLDCorrector.correct(sparse=True) (reference pldcorrector.py:194-199, regressioncorrector.py:170-176): the sparse
     collection carries a different spline basis (create_sparse_spline_matrix); densified and fitted on the GPU."""
