@@ -122,9 +122,19 @@ __global__ __launch_bounds__(1024) void bls_kernel(
     const double *__restrict__ tm, const double2 *__restrict__ yw,
     const int64_t *__restrict__ n_off, const BlsStats *__restrict__ stats, const double *__restrict__ period,
     const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur,
-    double bin_duration, int oversample, int obj_flag, double *__restrict__ out7, int ablate) {
+    double bin_duration, int oversample, int obj_flag, double *__restrict__ out7, int ablate,
+    unsigned long long *__restrict__ prof) {  // prof: LK_BLS_PROF=1 debug only (per-phase 100 MHz ticks, summed by atomics)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS is dynamic: keeps the base 16-B aligned
 
+    unsigned long long t_last = prof ? wall_clock64() : 0ull;
+#define BLS_LAP(slot_)                                                        \
+    do {                                                                      \
+        if (prof && threadIdx.x == 0) {                                       \
+            const unsigned long long now_ = wall_clock64();                   \
+            atomicAdd(&prof[slot_], now_ - t_last);                           \
+            t_last = now_;                                                    \
+        }                                                                     \
+    } while (0)
     const unsigned bid = blockIdx.x;
     const unsigned xcd = bid & 7u, slot = bid >> 3;
     const int target = (int)((slot / (unsigned)np_group) * 8u + xcd);
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         __syncthreads();
     }
 
+    BLS_LAP(0);  // setup + round boundaries
     // ---- pass B: ordered histogram
     if (ablate & 1) {
     } else if (serial) {
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         __syncthreads();
     }
 
+    BLS_LAP(1);  // histogram (incl. the segment searches)
     // ---- wrap pad (reference: for n=1..oversample: mean[n_bins-oversample+n-1] = mean[n], in that order),
     //      then sequential inclusive prefix sums (y on wave 0, ivar on wave 1)
     if (n_bins - oversample > oversample) {  // source [1, os] and destination [n_bins-os, n_bins-1] are disjoint
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         }
     }
     __syncthreads();
+    BLS_LAP(2);  // wrap pad + gmax / wmax reductions
     // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  bins[0] is always
     // (0, 0), so starting at i = 0 with acc = 0 is the same chain.
     if (wave == 0 && lane < 2 && !(ablate & 2)) {
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
         }
     }
     __syncthreads();
+    BLS_LAP(3);  // prefix chains
 
     // ---- scan
     // A thread owns start bins n = tid, tid + NT, ... and walks the durations in ascending length.  With a = y_out sum,
@@ -528,6 +542,7 @@ __global__ __launch_bounds__(1024) void bls_kernel(
     }
     s_best[tid] = BlsBest{best, bk, bn};
     __syncthreads();
+    BLS_LAP(4);  // scan
     for (int s = NT >> 1; s > 0; s >>= 1) {
         if (tid < s) {
             const BlsBest o = s_best[tid + s], m = s_best[tid];
@@ -569,6 +584,9 @@ __global__ __launch_bounds__(1024) void bls_kernel(
             o[6 * stride] = log_like;
         }
     }
+    BLS_LAP(5);  // final reduction + outputs
+    if (prof && threadIdx.x == 0) atomicAdd(&prof[7], 1ull);
+#undef BLS_LAP
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
@@ -673,6 +691,14 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     // groups: cut whenever the LDS need drops below 3/4 of the group's head (keeps occupancy close to the need)
     int ablate = 0;
     if (const char *e = getenv("LK_BLS_ABLATE")) ablate = atoi(e);  // profiling only: skips phases, results wrong
+    // LK_BLS_PROF=1 (debug): per-phase wall time of the workgroups (thread 0's clock), printed per LDS group; with W
+    // workgroups resident per CU a group's share of the step is (sum of the phases) x workgroups / (W x 256 CUs)
+    unsigned long long *d_prof = nullptr;
+    const bool prof_on = getenv("LK_BLS_PROF") && atoi(getenv("LK_BLS_PROF")) != 0;
+    if (prof_on) {
+        LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_prof), 64));
+        LK_HIP_CHECK(hipMemset(d_prof, 0, 64));
+    }
     size_t g0 = 0;
     while (g0 < (size_t)nP) {
         const int head_bins = nbins_of(order[g0]);
@@ -688,9 +714,22 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
         hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off,
                            d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration,
-                           oversample, use_likelihood ? 1 : 0, out7, ablate);
+                           oversample, use_likelihood ? 1 : 0, out7, ablate, d_prof);
+        if (prof_on) {
+            unsigned long long hp[8];
+            LK_HIP_CHECK(hipStreamSynchronize(stream));
+            LK_HIP_CHECK(hipMemcpy(hp, d_prof, 64, hipMemcpyDeviceToHost));
+            LK_HIP_CHECK(hipMemset(d_prof, 0, 64));
+            const double nb = (double)std::max<unsigned long long>(hp[7], 1);
+            fprintf(stderr,
+                    "[bls prof] group head_bins %5d periods %6d nt %4d lds %6zu workgroups %9llu | us per workgroup: setup %.1f  "
+                    "hist %.1f  pad+red %.1f  prefix %.1f  scan %.1f  out %.1f\n",
+                    head_bins, npg, nt, lds, hp[7], hp[0] / nb * 0.01, hp[1] / nb * 0.01, hp[2] / nb * 0.01, hp[3] / nb * 0.01,
+                    hp[4] / nb * 0.01, hp[5] / nb * 0.01);
+        }
         g0 = g1;
     }
+    if (d_prof) LK_HIP_CHECK(hipFree(d_prof));
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
