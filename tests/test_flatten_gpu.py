@@ -64,11 +64,18 @@ def test_ragged_batch_vs_oracle():
         mk = np.zeros(n, bool)
         mk[n // 2:n // 2 + n // 40] = i % 2 == 0
         masks.append(mk)
-    for w, p, bt, ni, sg in [(101, 2, 5, 3, 3), (31, 3, 2, 4, 2.5)]:
+    # (401, 2), (257, 3): moment-form interior + moment-form edges; (101, 4), (61, 5): tap-by-tap interior, moment-form edges;
+    # (75, 6): operator rows for the edges (polyorder > 5); five iterations exercise the guided dt median repeatedly
+    for w, p, bt, ni, sg in [(101, 2, 5, 3, 3), (31, 3, 2, 4, 2.5), (401, 2, 5, 3, 3), (257, 3, 3, 5, 2.5), (101, 4, 5, 3, 3),
+                             (61, 5, 5, 3, 3), (75, 6, 5, 2, 3)]:
         trends = flatten_trend_batch(lcs, window_length=w, polyorder=p, break_tolerance=bt, niters=ni, sigma=sg, masks=masks)
         for lc, mk, tr in zip(lcs, masks, trends):
             ref, _ = O.flatten_trend(lc.time, lc.flux, w, p, bt, ni, sg, mask=mk)
-            assert np.allclose(tr, ref, rtol=RTOL, atol=0, equal_nan=True), (len(lc), w)
+            # polyorder >= 4: scipy's savgol_coeffs (and the oracle's) solve an ill-conditioned Vandermonde system in
+            # double, so the REFERENCE taps carry a conditioning error of 1e-9 (p = 4, 5) to 1e-7 (p = 6) of the trend; the
+            # kernel's taps are the exact solution (long double design) rounded once.  Measured: 8.2e-10, 1.0e-10, 1.5e-7.
+            rtol = RTOL if p <= 3 else (5e-9 if p <= 5 else 1e-6)
+            assert np.allclose(tr, ref, rtol=rtol, atol=0, equal_nan=True), (len(lc), w, p)
 
 
 def test_flatten_errors():
