@@ -616,13 +616,16 @@ constexpr int PRUNED_CT = 16;
 template <int LP>
 __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols_pruned_kernel(
     const double2 *__restrict__ grids, int m1, int m2, const int *__restrict__ rows_used, double2 *__restrict__ gout,
-    int perm) {
+    int perm, int tpad) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, P = 1 << LP, LDT = Bq + 1, FST = A * LDT + 1;
     constexpr int CT = PRUNED_CT;
     const int N1 = 1 << m1, N2 = 1 << m2, Q = N1 >> LP;
     const double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
-    double2 *O = gout + ((size_t)blockIdx.y << (m1 + m2)) + ((size_t)blockIdx.x << m1) * CT;  // this column tile
+    // tpad elements of padding after every column tile of the intermediate: without it the 32 tiles of a row start
+    // exactly N1 * 256 B = 256 KB apart and step 2's reads of one row all fall on the same HBM channel
+    const size_t tstride = ((size_t)CT << m1) + (size_t)tpad, gstride = (size_t)(N2 / CT) * tstride;
+    double2 *O = gout + (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * tstride;  // this column tile
     const int c0 = blockIdx.x * CT;
     const int ru = rows_used[(blockIdx.y / 3) * 4 + (blockIdx.y % 3)];
     const int tid = threadIdx.x;
@@ -881,19 +884,21 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
                                                               const FastStats *__restrict__ stats, int b0, double f0,
                                                               double df, int64_t M, int fit_mean, int norm,
                                                               const double *__restrict__ scale,
-                                                              double *__restrict__ power, int tw, int lp) {
+                                                              double *__restrict__ power, int tw, int lp, int tpad) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int m2 = LA + LB, A = 1 << LA;
     const int N2 = 1 << m2;
     const int twl = tw ? 31 - __clz(tw) : 0;
+    // padded column-tile stride of the intermediate (see fft_cols_pruned_kernel); tpad = 0: the plain power-of-two layout
+    const size_t tstride = tw ? (((size_t)tw << m1) + (size_t)tpad) : 0, gstride = tw ? (size_t)(N2 >> twl) * tstride : ((size_t)1 << (m1 + m2));
     const int lb = blockIdx.y, r0 = blockIdx.x * RT;
     double2 keep0[KB], keep1[KB], keep2[KB];
 #pragma unroll
     for (int q = 0; q < KB; ++q) keep0[q] = keep1[q] = keep2[q] = make_double2(0.0, 0.0);
     {
-        const double2 *G = grids + ((size_t)(lb * 3 + 0) << (m1 + m2));
+        const double2 *G = grids + (size_t)(lb * 3 + 0) * gstride;
         auto load = [&](int f, int c) -> double2 {
-            return tw ? G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
+            return tw ? G[(size_t)(c >> twl) * tstride + ((size_t)(r0 + f) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
         };
         auto store = [&](int, int, double2 v, int kb) {
             if (kb < KB) keep0[kb < KB ? kb : 0] = v;
@@ -905,9 +910,9 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
     }
     __syncthreads();
     if (fit_mean) {
-        const double2 *G = grids + ((size_t)(lb * 3 + 1) << (m1 + m2));
+        const double2 *G = grids + (size_t)(lb * 3 + 1) * gstride;
         auto load = [&](int f, int c) -> double2 {
-            return tw ? G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
+            return tw ? G[(size_t)(c >> twl) * tstride + ((size_t)(r0 + f) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
         };
         auto store = [&](int, int, double2 v, int kb) {
             if (kb < KB) keep1[kb < KB ? kb : 0] = v;
@@ -919,9 +924,9 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
     }
     __syncthreads();
     {
-        const double2 *G = grids + ((size_t)(lb * 3 + 2) << (m1 + m2));
+        const double2 *G = grids + (size_t)(lb * 3 + 2) * gstride;
         auto load = [&](int f, int c) -> double2 {
-            return tw ? G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
+            return tw ? G[(size_t)(c >> twl) * tstride + ((size_t)(r0 + f) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
         };
         auto store = [&](int, int, double2 v, int kb) {
             if (kb < KB) keep2[kb < KB ? kb : 0] = v;
@@ -941,22 +946,34 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
     // row r0 + f of the intermediate is k1 itself, or (lp > 0: fft_cols_pruned_kernel with perm) row s P + q of k1 = Q q + s
     const int rp = r0 + f;
     const int k1 = lp ? (((rp & ((1 << lp) - 1)) << (m1 - lp)) + (rp >> lp)) : rp;
+    // e^{2 pi i t0 f} for this thread's outputs k = k1 + N1 (ka + A kb): one sincos for kb = 0 and one for the step between
+    // consecutive kb (a rotation by 2 pi t0 df N1 A), the 2f phase by the double-angle formulas (its argument is exactly
+    // twice the 1f one) — 2 sincos per thread instead of 2 per output; the products drift by < 1e-15 over KB <= 8 steps.
+    const double twopi = 6.283185307179586;
+    double ph_c = 1.0, ph_s = 0.0, st_c = 1.0, st_s = 0.0;
+    if (st.t0 != 0.0) {
+        const long long kfirst = (long long)k1 + ((long long)ka << m1);
+        sincos(twopi * st.t0 * (f0 + df * (double)kfirst), &ph_s, &ph_c);
+        sincos(twopi * st.t0 * (df * (double)((long long)A << m1)), &st_s, &st_c);
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const long long k = (long long)k1 + ((long long)(ka + A * kb) << m1);
-        if (k >= M) continue;
-        double2 a = keep0[kb], bq = keep1[kb], c2 = keep2[kb];
-        if (st.t0 != 0.0) {
-            const double twopi = 6.283185307179586;
-            double s, c;
-            sincos(twopi * st.t0 * (f0 + df * (double)k), &s, &c);
-            a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
-            bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
-            sincos(twopi * st.t0 * (2.0 * f0 + 2.0 * df * (double)k), &s, &c);
-            c2 = make_double2(c2.x * c - c2.y * s, c2.x * s + c2.y * c);
+        if (k < M) {
+            double2 a = keep0[kb], bq = keep1[kb], c2 = keep2[kb];
+            if (st.t0 != 0.0) {
+                const double c = ph_c, s = ph_s;
+                a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+                bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
+                const double cc = c * c - s * s, ss = 2.0 * s * c;
+                c2 = make_double2(c2.x * cc - c2.y * ss, c2.x * ss + c2.y * cc);
+            }
+            power[(size_t)b * (size_t)M + k] = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY,
+                                                              0.5 * st.wsum, nn, sc);
         }
-        power[(size_t)b * (size_t)M + k] = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY,
-                                                          0.5 * st.wsum, nn, sc);
+        const double nc = ph_c * st_c - ph_s * st_s, ns = ph_s * st_c + ph_c * st_s;
+        ph_c = nc;
+        ph_s = ns;
     }
 }
 
@@ -1124,7 +1141,7 @@ struct FusedArgs {
 
 template <int LA, int LB, int KB>
 static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
-                                hipStream_t stream, int lp = 0) {
+                                hipStream_t stream, int lp = 0, int tpad = 0) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N1 = 1 << m1;
     int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
@@ -1145,7 +1162,7 @@ static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, cons
     }
     hipLaunchKernelGGL((fft_rows_power_kernel<LA, LB, KB>), dim3(N1 / RT, ntargets), dim3(nt), (size_t)RT * FST * 16,
                        stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm, a.scale,
-                       a.power, tw, lp);
+                       a.power, tw, lp, tpad);
 }
 
 // returns false if the (m2, outputs-per-thread) combination has no fused instantiation
@@ -1207,7 +1224,7 @@ static bool launch_rows_power3(int m1, int m2, int ntargets, const double2 *grid
 }
 
 static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
-                              hipStream_t stream, int lp = 0) {
+                              hipStream_t stream, int lp = 0, int tpad = 0) {
     if (lp == 0 && launch_rows_power3(m1, m2, ntargets, grids, a, tw, stream)) return true;
     if (tw < 0) return false;  // the two-phase kernel below reads the column-tiled layout only
     const int LA = (m2 + 1) / 2, Aa = 1 << LA;
@@ -1216,9 +1233,9 @@ static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids
     if (kb > 8) return false;
 #define LK_RP(la, lb)                                                                  \
     if (kb <= 4)                                                                       \
-        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, tw, stream, lp);        \
+        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, tw, stream, lp, tpad);  \
     else                                                                               \
-        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, tw, stream, lp);        \
+        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, tw, stream, lp, tpad);  \
     return true;
     switch (m2) {
         case 4: LK_RP(2, 2)
@@ -1285,7 +1302,7 @@ __global__ __launch_bounds__(256) void lsf_plan_kernel(const int *__restrict__ r
 
 template <int LP>
 static void launch_cols_pruned_t(int m1, int m2, int ngrids, const double2 *grids, const int *rows_used, double2 *gout,
-                                 int perm, hipStream_t stream) {
+                                 int perm, int tpad, hipStream_t stream) {
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, LDT = Bq + 1, FST = A * LDT + 1;
     static bool attr = false;
     if (!attr) {
@@ -1294,16 +1311,16 @@ static void launch_cols_pruned_t(int m1, int m2, int ngrids, const double2 *grid
         attr = true;
     }
     hipLaunchKernelGGL((fft_cols_pruned_kernel<LP>), dim3((1 << m2) / PRUNED_CT, ngrids), dim3(PRUNED_CT * A),
-                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout, perm);
+                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout, perm, tpad);
 }
 
 static bool launch_cols_pruned(int lp, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
-                               double2 *gout, int perm, hipStream_t stream) {
+                               double2 *gout, int perm, int tpad, hipStream_t stream) {
     switch (lp) {
-        case 5: launch_cols_pruned_t<5>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
-        case 6: launch_cols_pruned_t<6>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
-        case 7: launch_cols_pruned_t<7>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
-        case 8: launch_cols_pruned_t<8>(m1, m2, ngrids, grids, rows_used, gout, perm, stream); return true;
+        case 5: launch_cols_pruned_t<5>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
+        case 6: launch_cols_pruned_t<6>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
+        case 7: launch_cols_pruned_t<7>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
+        case 8: launch_cols_pruned_t<8>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
         default: return false;
     }
 }
@@ -1344,9 +1361,12 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     if (const char *e = getenv("LK_FAST_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(e)) << 20;  // tuning knob
     const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     h->ws.reset();
+    // padding after each 16-column tile of the FFT intermediate (pruned path only), in 16-byte elements
+    static const int tpad_env = getenv("LK_LSF_TILE_PAD") ? std::max(0, atoi(getenv("LK_LSF_TILE_PAD"))) : 0;
+    const size_t pad_elems = ((size_t)(nfft >> m1) / PRUNED_CT + 1) * (size_t)tpad_env;
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
-                           (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
-                           (size_t)B * 6 * ((nfft + 1023) / 1024 + 2) * 4 + 16384);
+                           (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * pad_elems * 16 + (size_t)Bc * 3 * M * 16 +
+                           (size_t)B * 16 + (size_t)B * 6 * ((nfft + 1023) / 1024 + 2) * 4 + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
@@ -1380,7 +1400,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             h8 * T3 <= 512 && (1 << m1) % h8 == 0)
             tw = -h8;
     }
-    double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16) : nullptr;
+    double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * (nfft + pad_elems) * 16) : nullptr;
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     int *d_plan = (int *)h->ws.alloc(64);
@@ -1452,13 +1472,13 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             if (fused) {
                 // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
                 if (lp) {
-                    LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, perm_env, stream),
+                    LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, perm_env, tpad_env, stream),
                                "no pruned column kernel for 2^%d rows", lp);
                 } else {
                     launch_cols_reg(m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
                 }
                 if (two_streams) LK_HIP_CHECK(hipEventRecord(ev_cols[buf], stream));
-                LK_REQUIRE(launch_rows_power(m1, m2, nb, d_grids2, fa, lp ? PRUNED_CT : tw, stream, (lp && perm_env) ? lp : 0),
+                LK_REQUIRE(launch_rows_power(m1, m2, nb, d_grids2, fa, lp ? PRUNED_CT : tw, stream, (lp && perm_env) ? lp : 0, lp ? tpad_env : 0),
                            "no step-2 kernel for this layout");
                 continue;
             }
