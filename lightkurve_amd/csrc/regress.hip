@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
                                                          const uint8_t *__restrict__ cmask,
                                                          const uint8_t *__restrict__ outl,
                                                          const int64_t *__restrict__ n_off, int K, int KB,
-                                                         double *__restrict__ G) {
+                                                         double *__restrict__ G, const int *__restrict__ done = nullptr) {
+    if (done && done[blockIdx.y]) return;  // this target's clip loop has converged (see regress_launch): G is final
     __shared__ double sa[GR_RC][GR_LD];  // weighted left tile  (rows: cadence, cols: 64 output rows)
     __shared__ double sb[GR_RC][GR_LD];  // right tile          (cols: 64 output cols)
     // upper-triangular block pair from the linear block index
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
 __global__ __launch_bounds__(256) void solve_kernel(const double *__restrict__ G, int K, int Kp,
                                                      const double *__restrict__ prior_mu,
                                                      const double *__restrict__ prior_sigma,
-                                                     double *__restrict__ Awork, double *__restrict__ w) {
+                                                     double *__restrict__ Awork, double *__restrict__ w,
+                                                     const int *__restrict__ done = nullptr) {
+    if (done && done[blockIdx.x]) return;
     __shared__ double s_val[256];
     __shared__ int s_idx[256];
     __shared__ double s_col[1024];  // pivot-column multipliers (K <= 1024)
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(256) void solve_kernel(const double *__restrict__ G
 __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict__ G, int K, int Kp,
                                                          const double *__restrict__ prior_mu,
                                                          const double *__restrict__ prior_sigma,
-                                                         double *__restrict__ w) {
+                                                         double *__restrict__ w, const int *__restrict__ done = nullptr) {
+    if (done && done[blockIdx.x]) return;
     extern __shared__ __attribute__((aligned(16))) double s_A[];  // K x (K + 1) augmented system | K multipliers | pivots
     const int target = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *Gt = G + (size_t)target * Kp * Kp;
@@ -332,7 +336,8 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
 // model[n] = sum_k X[n][k] w[k]; one wavefront per cadence row, lanes over k (coalesced), wave reduction.
 __global__ __launch_bounds__(256) void model_kernel(const double *__restrict__ X, const double *__restrict__ w,
                                                      const int64_t *__restrict__ n_off, int K,
-                                                     double *__restrict__ model) {
+                                                     double *__restrict__ model, const int *__restrict__ done = nullptr) {
+    if (done && done[blockIdx.y]) return;
     extern __shared__ __attribute__((aligned(16))) double s_w[];
     const int target = blockIdx.y;
     const int64_t lo = n_off[target];
@@ -352,7 +357,12 @@ __global__ __launch_bounds__(256) void model_kernel(const double *__restrict__ X
 // residuals over all cadences + astropy sigma_clip; outl |= clipped.  One 1024-thread workgroup per target.
 __global__ __launch_bounds__(1024) void clip_kernel(const double *__restrict__ y, const double *__restrict__ model,
                                                      const int64_t *__restrict__ n_off, double sigma, int maxiters,
-                                                     uint8_t *__restrict__ flag, uint8_t *__restrict__ outl) {
+                                                     uint8_t *__restrict__ flag, uint8_t *__restrict__ outl,
+                                                     int *__restrict__ done = nullptr) {
+    // done[target] != 0: an earlier pass of the clip loop added no outlier, so the fit mask, the fit, the residuals and
+    // this clip would all repeat exactly — the remaining passes of the reference's `for count in range(niters)` are
+    // no-ops for this target and are skipped (regressioncorrector.py:245-272 has no early exit; the fixed point is exact)
+    if (done && done[blockIdx.x]) return;
     __shared__ unsigned long long sh[1024];
     const int target = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = n_off[target];
@@ -403,10 +413,18 @@ __global__ __launch_bounds__(1024) void clip_kernel(const double *__restrict__ y
         count = newcount;
         if (!changed) break;
     }
+    int added = 0;
     for (int i = tid; i < n; i += 1024) {
         const double r = val(i);
         const bool clipped = !isfinite(r) || r < lo_b || r > hi_b;
-        if (clipped) outl[i] = 1;
+        if (clipped) {
+            added += outl[i] ? 0 : 1;
+            outl[i] = 1;
+        }
+    }
+    if (done) {
+        added = __syncthreads_or(added);
+        if (tid == 0 && !added) done[target] = 1;
     }
 }
 
@@ -692,7 +710,7 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     const int KB = (K + 1 + GR_BLK - 1) / GR_BLK, Kp = KB * GR_BLK;
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * Kp * Kp * 8 + (size_t)B * K * (K + 1) * 8 * (w_cov ? 2 : 1) +
-                           ntot + 4096);
+                           ntot + (size_t)B * 4 + 4096);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     double *d_G = (double *)h->ws.alloc((size_t)B * Kp * Kp * 8);
@@ -703,10 +721,14 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
         if (rcs) return rcs;
     }
     LK_HIP_CHECK(hipMemsetAsync(outl, 0, ntot, stream));
+    // per-target convergence flags of the clip loop (LK_REGRESS_EARLY=0 runs every pass for every target, as round 1 did)
+    static const bool early = !(getenv("LK_REGRESS_EARLY") && atoi(getenv("LK_REGRESS_EARLY")) == 0);
+    int *d_done = early ? (int *)h->ws.alloc((size_t)B * 4) : nullptr;
+    if (d_done) LK_HIP_CHECK(hipMemsetAsync(d_done, 0, (size_t)B * 4, stream));
     const int nblk = KB * (KB + 1) / 2;
     for (int it = 0; it < niters; ++it) {
         hipLaunchKernelGGL(gram_mfma_kernel, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K, KB,
-                           d_G);
+                           d_G, (const int *)d_done);
         const size_t solve_lds = ((size_t)K * (K + 1) + K + 4 + 2) * 8;
         static const bool lds_solve_ok = !(getenv("LK_SOLVE_LDS") && atoi(getenv("LK_SOLVE_LDS")) == 0);
         if (lds_solve_ok && solve_lds <= 160 * 1024) {
@@ -716,12 +738,15 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 solve_attr = true;
             }
-            hipLaunchKernelGGL(solve_lds_kernel, dim3(B), dim3(256), solve_lds, stream, d_G, K, Kp, prior_mu, prior_sigma, w);
+            hipLaunchKernelGGL(solve_lds_kernel, dim3(B), dim3(256), solve_lds, stream, d_G, K, Kp, prior_mu, prior_sigma, w,
+                               (const int *)d_done);
         } else {
-            hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(256), 0, stream, d_G, K, Kp, prior_mu, prior_sigma, d_A, w);
+            hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(256), 0, stream, d_G, K, Kp, prior_mu, prior_sigma, d_A, w,
+                               (const int *)d_done);
         }
-        hipLaunchKernelGGL(model_kernel, dim3(64, B), dim3(256), (size_t)K * 8, stream, X, w, d_off, K, model);
-        hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, model, d_off, clip_sigma, 5, d_flag, outl);
+        hipLaunchKernelGGL(model_kernel, dim3(64, B), dim3(256), (size_t)K * 8, stream, X, w, d_off, K, model,
+                           (const int *)d_done);
+        hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, model, d_off, clip_sigma, 5, d_flag, outl, d_done);
     }
     hipLaunchKernelGGL(demedian_kernel, dim3(B), dim3(1024), 0, stream, d_off, model);
     // d_G still holds the normal matrix of the LAST iteration's fit: its inverse is the coefficient covariance
