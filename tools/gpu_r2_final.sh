@@ -21,6 +21,10 @@ DB=$(find $O/flat_trace -name "*results.db" | head -1); [ -n "$DB" ] && python t
 python tools/flat_phase_profile.py 1000 2>/dev/null > $O/flat_phase.txt; tail -18 $O/flat_phase.txt
 echo "== PLD bench"
 timeout 600 python bench.py --workload pld --steps 5 --warmup 2 > $O/bench_pld.json 2> $O/bench_pld.err; python -c "import json;d=json.load(open('$O/bench_pld.json'));print('pld ms/step',d['ms_per_step'],d['value'])"
+echo "== regress bench + PLD trace"
+timeout 300 python bench.py --workload regress --steps 5 --warmup 2 > $O/bench_regress.json 2> $O/bench_regress.err; python -c "import json;d=json.load(open('$O/bench_regress.json'));print('regress ms/step',d['ms_per_step'],d['value'])"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/pld_trace -o pld -- python $OLDPWD/bench.py --workload pld --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $OLDPWD/$O/pld_trace.err)
+DB=$(find $O/pld_trace -name "*results.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" "bench.py --workload pld --steps 3 --warmup 1 (round 2 final)" > $O/pld_trace_summary.txt && rm -rf $O/pld_trace && head -12 $O/pld_trace_summary.txt
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo "== LS fast trace (default path)"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/ls_trace -o ls -- python $OLDPWD/bench.py --ls-method fast --no-bls --no-host --no-cpu-baseline --steps 5 --warmup 2 > $OLDPWD/$O/ls_trace.json 2> $OLDPWD/$O/ls_trace.err)
