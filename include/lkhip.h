@@ -216,6 +216,23 @@ int lk_sigma_clip_batch(lk_handle *h, int B, const int64_t *n_off, const double 
                         uint8_t *outlier);
 int lk_sigma_clip_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *y, double sigma, int maxiters,
                             uint8_t *outlier, void *stream);
+/* lk_fits_unpack_batch: what the reference's light-curve readers do per file through astropy — Table.read of the BINTABLE
+ * (src/lightkurve/io/generic.py:21-207), drop the rows whose TIME is NaN (:98-101), drop the cadences whose quality flag
+ * hits the bitmask (io/kepler.py:49-53, io/tess.py:45-48, utils.py:79-115) — for B files at once.  `raw`: the tables' bytes
+ * exactly as in the files (big-endian records), file b at [raw_off[b], raw_off[b+1]) with raw_off[b] a multiple of 4 and
+ * at least 3 spare bytes after its rows x record-length bytes.  desc: B x 10 int32 = {record length (<= 512), rows, byte
+ * offset and TFORM code of TIME, of the flux column, of the flux-error column (offset -1: none -> NaN), of the quality
+ * column (offset -1: none -> 0)}; codes 0 = D (float64), 1 = E (float32), 2 = J (int32), 3 = K (int64), 4 = I (int16),
+ * 5 = B (uint8).  bitmask: B x int64.  Outputs (capacity: sum of rows): float64 time / flux / flux_err (nullable),
+ * int32 quality (nullable), packed in file order; new_off (B + 1, HOST, valid when the call returns: it synchronises).
+ * Header parsing stays on the host (lightkurve_amd/fitsio.py). */
+int lk_fits_unpack_batch(lk_handle *h, int B, const uint8_t *raw, const int64_t *raw_off, const int32_t *desc,
+                         const int64_t *bitmask, double *t_out, double *flux_out, double *flux_err_out,
+                         int32_t *quality_out, int64_t *new_off);
+int lk_fits_unpack_batch_dev(lk_handle *h, int B, const uint8_t *raw, const int64_t *raw_off_host, const int32_t *desc_host,
+                             const int64_t *bitmask_host, double *t_out, double *flux_out, double *flux_err_out,
+                             int32_t *quality_out, int64_t *new_off_host, void *stream);
+
 /* LightCurve.create_transit_mask (:2967-3037): target b has planets [planet_off[b], planet_off[b+1]) of the HOST arrays
  * period / duration / transit_time [d]; mask[i] = 1 where |((t - t0 + P/2) % P) - P/2| < duration/2 for any of them. */
 int lk_transit_mask_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const int32_t *planet_off,

@@ -90,6 +90,8 @@ SIGNATURES = [
      [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_ip, _c_dp]),
     ("lk_ingest_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _c_ip, _vp, _vp]),
+    ("lk_fits_unpack_batch", ctypes.c_int, [_vp, ctypes.c_int, _c_u8p, _c_ip, _c_i32p, _c_ip, _c_dp, _c_dp, _c_dp, _c_i32p, _c_ip]),
+    ("lk_fits_unpack_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _vp, _c_ip, _c_i32p, _c_ip, _vp, _vp, _vp, _vp, _c_ip, _vp]),
     ("lk_transit_mask_batch", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _c_dp, _c_i32p, _c_dp, _c_dp, _c_dp, _c_u8p]),
     ("lk_transit_mask_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, _c_i32p, _c_dp, _c_dp, _c_dp, _vp, _vp]),
     ("lk_bin_batch", ctypes.c_int,
@@ -633,6 +635,33 @@ def ingest_batch(t, flux, n_off, flux_err=None, normalize=True, device=0):
                                 _ptr(fo), _ptr(eo), _ptr(new_off, _c_ip), _ptr(med)))
     k = int(new_off[-1])
     return to[:k], fo[:k], (eo[:k] if eo is not None else None), new_off, med
+
+
+def fits_unpack_batch(raws, descs, bitmasks, device=0):
+    """FITS binary tables -> packed (time, flux, flux_err, quality, n_off) for B files (see lightkurve_amd/fitsio.py).
+    ``raws``: list of uint8 arrays (rows x record bytes, as in the file); ``descs``: B x 10 int32 (fitsio.lightcurve_columns);
+    ``bitmasks``: B ints.  Rows with NaN time or (quality & bitmask) != 0 are dropped on the device."""
+    h = Handle.get(device)
+    B = len(raws)
+    desc = np.ascontiguousarray(descs, dtype=np.int32).reshape(B, 10)
+    mask = np.ascontiguousarray(bitmasks, dtype=np.int64).reshape(B)
+    raw_off = np.zeros(B + 1, dtype=np.int64)
+    for b, r in enumerate(raws):
+        nbytes = int(desc[b, 0]) * int(desc[b, 1])
+        if np.asarray(r).size != nbytes:
+            raise ValueError("file %d: %d bytes of table data, descriptor says %d rows x %d bytes" % (b, np.asarray(r).size, desc[b, 1], desc[b, 0]))
+        raw_off[b + 1] = raw_off[b] + ((nbytes + 3 + 15) // 16) * 16   # 3 spare bytes, then 16-byte alignment
+    raw = np.zeros(int(raw_off[-1]), dtype=np.uint8)
+    for b, r in enumerate(raws):
+        raw[raw_off[b]:raw_off[b] + np.asarray(r).size] = np.asarray(r, dtype=np.uint8).reshape(-1)
+    rows = int(desc[:, 1].sum())
+    t, f, e = (np.empty(rows, dtype=np.float64) for _ in range(3))
+    q = np.empty(rows, dtype=np.int32)
+    new_off = np.zeros(B + 1, dtype=np.int64)
+    _check(_lib.lk_fits_unpack_batch(h._h, B, _ptr(raw, _c_u8p), _ptr(raw_off, _c_ip), _ptr(desc, _c_i32p), _ptr(mask, _c_ip),
+                                     _ptr(t), _ptr(f), _ptr(e), _ptr(q, _c_i32p), _ptr(new_off, _c_ip)))
+    k = int(new_off[-1])
+    return t[:k], f[:k], e[:k], q[:k], new_off
 
 
 def transit_mask_batch(t, n_off, period, duration, transit_time, planet_off=None, device=0):

@@ -822,6 +822,48 @@ int lk_ingest_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, 
     return LK_OK;
 }
 
+int lk_fits_unpack_batch_dev(lk_handle *h, int B, const uint8_t *raw, const int64_t *raw_off_host, const int32_t *desc_host,
+                             const int64_t *bitmask_host, double *t_out, double *flux_out, double *flux_err_out,
+                             int32_t *quality_out, int64_t *new_off_host, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::fits_unpack_launch(h, B, raw, raw_off_host, desc_host, bitmask_host, t_out, flux_out, flux_err_out,
+                                  quality_out, new_off_host, static_cast<hipStream_t>(stream));
+}
+
+int lk_fits_unpack_batch(lk_handle *h, int B, const uint8_t *raw, const int64_t *raw_off, const int32_t *desc,
+                         const int64_t *bitmask, double *t_out, double *flux_out, double *flux_err_out,
+                         int32_t *quality_out, int64_t *new_off) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 0 && raw_off != nullptr && desc != nullptr && new_off != nullptr, "bad batch description");
+    if (B == 0) {
+        new_off[0] = 0;
+        return LK_OK;
+    }
+    LK_REQUIRE(raw && bitmask && t_out && flux_out, "NULL buffer");
+    LK_REQUIRE(raw_off[0] == 0, "raw_off[0] must be 0");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    size_t rows = 0;
+    for (int b = 0; b < B; ++b) rows += (size_t)std::max(0, desc[(size_t)b * 10 + 1]);
+    const size_t nraw = (size_t)raw_off[B], nb = rows * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(nraw + 3 * (nb + 256) + rows * 4 + 4096);
+    if (rc) return rc;
+    uint8_t *draw = (uint8_t *)h->staging.alloc(nraw + 16);
+    double *dto = (double *)h->staging.alloc(nb), *dfo = (double *)h->staging.alloc(nb);
+    double *deo = flux_err_out ? (double *)h->staging.alloc(nb) : nullptr;
+    int32_t *dqo = quality_out ? (int32_t *)h->staging.alloc(rows * 4) : nullptr;
+    LK_HIP_CHECK(hipMemcpy(draw, raw, nraw, hipMemcpyHostToDevice));
+    rc = lk::fits_unpack_launch(h, B, draw, raw_off, desc, bitmask, dto, dfo, deo, dqo, new_off, nullptr);
+    if (rc) return rc;
+    const size_t kept = (size_t)new_off[B];
+    LK_HIP_CHECK(hipMemcpy(t_out, dto, kept * 8, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(flux_out, dfo, kept * 8, hipMemcpyDeviceToHost));
+    if (flux_err_out) LK_HIP_CHECK(hipMemcpy(flux_err_out, deo, kept * 8, hipMemcpyDeviceToHost));
+    if (quality_out) LK_HIP_CHECK(hipMemcpy(quality_out, dqo, kept * 4, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 int lk_transit_mask_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const int32_t *planet_off,
                               const double *period, const double *duration, const double *transit_time, uint8_t *mask,
                               void *stream) {

@@ -170,6 +170,159 @@ int ingest_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ FITS table -> arrays
+// lk_fits_unpack_batch: what lightkurve's readers do per file through astropy (src/lightkurve/io/generic.py:21-207,
+// io/kepler.py:49-53, io/tess.py:45-48), for B files in three launches.  Input: the raw big-endian bytes of each file's
+// BINTABLE (row-major records of row_bytes bytes) and, per file, where TIME / flux / flux_err / quality sit in a record
+// and their TFORM type; output: (time, flux, flux_err) as float64, quality as int32, for the rows the readers keep —
+// time not NaN (generic.py:98-101) and (quality & bitmask) == 0 (utils.py:115) — packed contiguously, order preserved.
+// A workgroup stages 256 records at a time in LDS with coalesced 4-byte loads (a record is ~100 unaligned bytes, so
+// per-field global loads would touch every cache line several times), then one thread decodes one record from LDS.
+struct FitsDesc {
+    int row_bytes, n_rows, off_t, code_t, off_f, code_f, off_e, code_e, off_q, code_q;  // TFORM codes: 0 D 1 E 2 J 3 K 4 I 5 B
+};
+constexpr int FITS_ROWS = 256;
+
+__device__ __forceinline__ unsigned long long fits_be(const uint8_t *p, int nbytes) {
+    unsigned long long v = 0;
+    for (int i = 0; i < nbytes; ++i) v = (v << 8) | (unsigned long long)p[i];
+    return v;
+}
+__device__ __forceinline__ double fits_real(const uint8_t *rec, int off, int code) {
+    if (code == 0) return __longlong_as_double((long long)fits_be(rec + off, 8));
+    return (double)__uint_as_float((unsigned)fits_be(rec + off, 4));
+}
+__device__ __forceinline__ long long fits_int(const uint8_t *rec, int off, int code) {
+    if (code == 2) return (long long)(int)(unsigned)fits_be(rec + off, 4);
+    if (code == 3) return (long long)fits_be(rec + off, 8);
+    if (code == 4) return (long long)(short)(unsigned short)fits_be(rec + off, 2);
+    return (long long)rec[off];
+}
+
+// stage records [r0, r0 + nr) of one file into LDS (word loads: the file's table starts 4-byte aligned in `raw`)
+__device__ __forceinline__ void fits_stage(const uint8_t *__restrict__ tab, long long r0, int nr, int row_bytes,
+                                           uint8_t *lds_bytes) {
+    const long long b0 = r0 * row_bytes, b1 = b0 + (long long)nr * row_bytes;
+    const long long w0 = b0 >> 2, w1 = (b1 + 3) >> 2;  // words covering the byte range (reads <= 3 bytes past: in bounds, see launcher)
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(tab);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(lds_bytes);
+    for (long long w = w0 + threadIdx.x; w < w1; w += blockDim.x) dst[w - w0] = src[w];
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void fits_unpack_kernel(const uint8_t *__restrict__ raw, const int64_t *__restrict__ raw_off,
+                                                           const FitsDesc *__restrict__ desc,
+                                                           const int64_t *__restrict__ bitmask, int64_t *__restrict__ kept,
+                                                           const int64_t *__restrict__ new_off, double *__restrict__ t_out,
+                                                           double *__restrict__ f_out, double *__restrict__ e_out,
+                                                           int *__restrict__ q_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fits_lds[];
+    __shared__ int s_cnt[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const FitsDesc d = desc[b];
+    const uint8_t *tab = raw + raw_off[b];
+    const long long mask = bitmask[b];
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    long long base = PACK ? new_off[b] : 0, total = 0;
+    for (long long r0 = 0; r0 < d.n_rows; r0 += FITS_ROWS) {
+        const int nr = (int)min((long long)FITS_ROWS, (long long)d.n_rows - r0);
+        __syncthreads();
+        fits_stage(tab, r0, nr, d.row_bytes, fits_lds);
+        __syncthreads();
+        const int skew = (int)((r0 * d.row_bytes) & 3);  // the staged words start at a 4-byte boundary
+        const uint8_t *rec = fits_lds + skew + (size_t)tid * d.row_bytes;
+        double tv = qnan, fv = qnan, ev = qnan;
+        long long qv = 0;
+        bool keep = false;
+        if (tid < nr) {
+            tv = fits_real(rec, d.off_t, d.code_t);
+            if (d.off_q >= 0) qv = fits_int(rec, d.off_q, d.code_q);
+            keep = !isnan(tv) && (qv & mask) == 0;
+            if (PACK && keep) {
+                fv = fits_real(rec, d.off_f, d.code_f);
+                if (d.off_e >= 0) ev = fits_real(rec, d.off_e, d.code_e);
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) before += s_cnt[w];
+            all += s_cnt[w];
+        }
+        if (PACK && keep) {
+            const long long pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+            t_out[pos] = tv;
+            f_out[pos] = fv;
+            if (e_out) e_out[pos] = ev;
+            if (q_out) q_out[pos] = (int)qv;
+        }
+        base += all;
+        total += all;
+    }
+    if (!PACK && tid == 0) kept[b] = total;
+}
+
+int fits_unpack_launch(lk_handle *h, int B, const uint8_t *raw, const int64_t *raw_off_host, const int32_t *desc_host,
+                       const int64_t *bitmask_host, double *t_out, double *f_out, double *e_out, int32_t *q_out,
+                       int64_t *new_off_host, hipStream_t stream) {
+    LK_REQUIRE(B >= 0 && raw_off_host != nullptr && desc_host != nullptr && new_off_host != nullptr, "bad batch description");
+    if (B == 0) {
+        new_off_host[0] = 0;
+        return LK_OK;
+    }
+    LK_REQUIRE(raw && bitmask_host && t_out && f_out, "NULL buffer");
+    int max_row = 0;
+    for (int b = 0; b < B; ++b) {
+        const int32_t *d = desc_host + (size_t)b * 10;
+        LK_REQUIRE(d[0] >= 1 && d[0] <= 512 && d[1] >= 0, "file %d: record length %d outside 1..512 bytes", b, d[0]);
+        LK_REQUIRE((raw_off_host[b] & 3) == 0, "file %d: the table must start at a multiple of 4 bytes in `raw`", b);
+        LK_REQUIRE(raw_off_host[b + 1] - raw_off_host[b] >= (int64_t)d[0] * d[1] + 3,
+                   "file %d: `raw` holds fewer bytes than rows x record length (+3 bytes of padding)", b);
+        const int widths[6] = {8, 4, 4, 8, 2, 1};
+        const int offs[4] = {d[2], d[4], d[6], d[8]}, codes[4] = {d[3], d[5], d[7], d[9]};
+        for (int c = 0; c < 4; ++c) {
+            if (c >= 2 && offs[c] < 0) continue;  // flux_err / quality may be absent
+            LK_REQUIRE(codes[c] >= 0 && codes[c] <= 5 && offs[c] >= 0 && offs[c] + widths[codes[c]] <= d[0],
+                       "file %d: column %d (offset %d, type %d) does not fit the %d-byte record", b, c, offs[c], codes[c], d[0]);
+            LK_REQUIRE(c == 3 ? codes[c] >= 2 : codes[c] <= 1, "file %d: column %d has the wrong kind of TFORM", b, c);
+        }
+        max_row = std::max(max_row, d[0]);
+    }
+    h->ws.reset();
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 * 4 + (size_t)B * sizeof(FitsDesc) + 4096);
+    if (rc) return rc;
+    int64_t *d_roff = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    int64_t *d_mask = (int64_t *)h->ws.alloc((size_t)B * 8);
+    int64_t *d_kept = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    int64_t *d_new = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    FitsDesc *d_desc = (FitsDesc *)h->ws.alloc((size_t)B * sizeof(FitsDesc));
+    LK_HIP_CHECK(hipMemcpyAsync(d_roff, raw_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_mask, bitmask_host, (size_t)B * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_desc, desc_host, (size_t)B * sizeof(FitsDesc), hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));  // pageable sources may be reused by the caller
+    const size_t lds = (size_t)FITS_ROWS * max_row + 16;
+    static bool attr = false;
+    if (!attr) {
+        // (the kernel also has 16 bytes of static LDS: the dynamic part may not claim all 160 KB)
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(fits_unpack_kernel<false>, dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask, d_kept,
+                       (const int64_t *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr);
+    hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, stream, d_kept, B, d_new);
+    hipLaunchKernelGGL(fits_unpack_kernel<true>, dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask,
+                       (int64_t *)nullptr, d_new, t_out, f_out, e_out, q_out);
+    LK_HIP_CHECK(hipMemcpyAsync(new_off_host, d_new, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ create_transit_mask
 __global__ __launch_bounds__(256) void transit_mask_kernel(const double *__restrict__ t, int64_t ntot,
                                                             const int64_t *__restrict__ n_off, int B,

@@ -54,6 +54,28 @@ class LightCurveBatch(object):
         cat = lambda a: np.concatenate(a) if a else np.zeros(0)
         return cls(cat(ts), cat(fs), cat(es), off, meta)
 
+    @classmethod
+    def from_fits(cls, paths, flux_column=None, quality_bitmask="default", ext=1, device=0):
+        """Light-curve FITS files -> one batch, with the reference readers' defaults (``lk.read(path)``: PDCSAP flux and
+        the mission's default quality bitmask for Kepler / K2 / TESS products, FLUX / QUALITY otherwise; rows with NaN time
+        dropped; reference src/lightkurve/io/generic.py:21-207, io/kepler.py, io/tess.py).  The host parses the headers,
+        the GPU turns the tables' bytes into the arrays (``lk_fits_unpack_batch``).  ``batch.quality`` holds the kept
+        cadences' flags, ``batch.meta[b]`` OBJECT / MISSION / the bitmask used, like the reference's ``lc.meta``."""
+        from . import fitsio
+        raws, descs, masks, meta = [], [], [], []
+        for path in paths:
+            tab = fitsio.read_fits_table(path, ext=ext)
+            desc, bitmask, mission = fitsio.lightcurve_columns(tab, flux_column=flux_column, quality_bitmask=quality_bitmask)
+            raws.append(tab.raw), descs.append(desc), masks.append(bitmask)
+            meta.append({"FILENAME": str(path), "LABEL": tab.primary.get("OBJECT"),
+                         "MISSION": tab.primary.get("MISSION", tab.primary.get("TELESCOP")), "RA": tab.primary.get("RA_OBJ"),
+                         "DEC": tab.primary.get("DEC_OBJ"), "QUALITY_BITMASK": quality_bitmask,
+                         "BJDREFI": tab.header.get("BJDREFI"), "READER_MISSION": mission})
+        t, f, e, q, off = _capi.fits_unpack_batch(raws, descs, masks, device=device)
+        out = cls(t, f, e, off, meta)
+        out.quality = q
+        return out
+
     def __len__(self):
         return len(self.n_off) - 1
 

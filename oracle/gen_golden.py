@@ -584,7 +584,102 @@ def gen_pld():
               background_aperture_mask="all", spline_degree=3)
 
 
+def gen_fits():
+    """FITS light-curve files -> arrays through the reference's own readers (io/kepler.py, io/tess.py, io/generic.py).
+    The files are SYNTHETIC (written here with astropy.io.fits in the layout of the mission products: big-endian records,
+    E / D / J / K columns, NaN times, NaN fluxes, quality flags inside and outside the default bitmasks) and committed
+    under tests/golden/fits/ so the GPU box can unpack them; the expected arrays are what lightkurve returns for them."""
+    from astropy.io import fits
+    from lightkurve.io.kepler import read_kepler_lightcurve
+    from lightkurve.io.tess import read_tess_lightcurve
+    from lightkurve.io.generic import read_generic_lightcurve
+    fdir = os.path.join(OUT, "fits")
+    os.makedirs(fdir, exist_ok=True)
+    rng = np.random.default_rng(77)
+    out = {}
+
+    def table(n, qual_name, qual_fmt, bjdrefi, flags, flux_fmt="E", extra_first=True):
+        t = 100.0 + np.arange(n) * 0.0204 + rng.normal(0, 1e-5, n)
+        t[rng.integers(0, n, 5)] = np.nan
+        sap = (1e4 + rng.normal(0, 20, n)).astype("f4" if flux_fmt == "E" else "f8")
+        pdc = (1.02e4 + rng.normal(0, 15, n)).astype(sap.dtype)
+        pdc[rng.integers(0, n, 7)] = np.nan
+        err = np.abs(rng.normal(12, 1, n)).astype(sap.dtype)
+        q = np.zeros(n, dtype="i8")
+        idx = rng.integers(0, n, 40)
+        q[idx] = rng.choice(flags, size=40)
+        cols = [fits.Column(name="TIME", format="D", unit="BJD - %d" % bjdrefi, array=t),
+                fits.Column(name="TIMECORR", format="E", unit="d", array=np.zeros(n, "f4")),
+                fits.Column(name="CADENCENO", format="J", array=np.arange(n, dtype="i4") + 1000),
+                fits.Column(name="SAP_FLUX", format=flux_fmt, unit="e-/s", array=sap),
+                fits.Column(name="SAP_FLUX_ERR", format=flux_fmt, unit="e-/s", array=err),
+                fits.Column(name="SAP_BKG", format="E", unit="e-/s", array=np.full(n, 300, "f4")),
+                fits.Column(name="PDCSAP_FLUX", format=flux_fmt, unit="e-/s", array=pdc),
+                fits.Column(name="PDCSAP_FLUX_ERR", format=flux_fmt, unit="e-/s", array=(err * 1.1).astype(sap.dtype)),
+                fits.Column(name=qual_name, format=qual_fmt, array=q.astype("i4" if qual_fmt == "J" else ("i8" if qual_fmt == "K" else "i2"))),
+                fits.Column(name="MOM_CENTR1", format="D", unit="pixel", array=500 + rng.normal(0, 0.01, n))]
+        hdu = fits.BinTableHDU.from_columns(cols, name="LIGHTCURVE")
+        hdu.header["BJDREFI"] = bjdrefi
+        hdu.header["BJDREFF"] = 0.0
+        hdu.header["TIMESYS"] = "TDB"
+        return hdu
+
+    def write(name, telescop, hdu, extra=None):
+        pri = fits.PrimaryHDU()
+        pri.header["TELESCOP"] = telescop
+        pri.header["OBJECT"] = "SYNTH " + name
+        pri.header["MISSION"] = telescop
+        pri.header["RA_OBJ"] = 123.456
+        pri.header["DEC_OBJ"] = -12.5
+        pri.header["COMMENT"] = "synthetic file for lightkurve_amd's FITS-ingest parity test; it's not flight data"
+        for k, v in (extra or {}).items():
+            pri.header[k] = v
+        path = os.path.join(fdir, name + ".fits")
+        fits.HDUList([pri, hdu, fits.ImageHDU(np.ones((3, 3), "i4"), name="APERTURE")]).writeto(path, overwrite=True)
+        return path
+
+    def dump(tag, lc):
+        out[tag + "_time"] = np.asarray(lc.time.value, dtype=np.float64)
+        out[tag + "_flux"] = np.asarray(lc.flux.value, dtype=np.float64)
+        out[tag + "_flux_err"] = np.asarray(lc.flux_err.value, dtype=np.float64)
+        qn = "sap_quality" if "sap_quality" in lc.columns else "quality"
+        out[tag + "_quality"] = np.asarray(lc[qn].value if hasattr(lc[qn], "value") else lc[qn], dtype=np.int64)
+
+    kflags = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 1048576]
+    tflags = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+    p = write("kepler_llc", "Kepler", table(331, "SAP_QUALITY", "J", 2454833, kflags), {"KEPLERID": 1234567})
+    dump("kepler_default", read_kepler_lightcurve(p))
+    dump("kepler_hard_sap", read_kepler_lightcurve(p, flux_column="sap_flux", quality_bitmask="hard"))
+    dump("kepler_none", read_kepler_lightcurve(p, quality_bitmask="none"))
+    p = write("tess_lc", "TESS", table(257, "QUALITY", "J", 2457000, tflags), {"TICID": 7654321})
+    dump("tess_default", read_tess_lightcurve(p))
+    dump("tess_int", read_tess_lightcurve(p, quality_bitmask=2 + 8 + 128))
+    # generic table: double-precision FLUX / FLUX_ERR, 64-bit QUALITY, no quality masking in the generic reader
+    n = 120
+    t = 2000.0 + np.arange(n) * 0.02
+    t[[3, 50]] = np.nan
+    g = fits.BinTableHDU.from_columns([
+        fits.Column(name="TIME", format="D", array=t),
+        fits.Column(name="FLUX", format="D", array=1.0 + rng.normal(0, 1e-3, n)),
+        fits.Column(name="FLUX_ERR", format="D", array=np.full(n, 1e-3)),
+        fits.Column(name="CADENCENO", format="J", array=np.arange(n, dtype="i4")),
+        fits.Column(name="QUALITY", format="K", array=(rng.integers(0, 2, n) * 2 ** 40).astype("i8"))], name="LIGHTCURVE")
+    g.header["BJDREFI"] = 2457000
+    g.header["TIMESYS"] = "TDB"
+    p = write("generic_double", "HOMEBREW", g)
+    lc = read_generic_lightcurve(p)
+    out["generic_time"] = np.asarray(lc.time.value, dtype=np.float64)
+    out["generic_flux"] = np.asarray(lc.flux.value, dtype=np.float64)
+    out["generic_flux_err"] = np.asarray(lc.flux_err.value, dtype=np.float64)
+    # one of the reference's own sample files, for the CPU-side parser test (only read when /root/reference is present)
+    lc = lk.read("/root/reference/tests/data/test-lc-tess-pimen-100-cadences.fits")
+    out["pimen_time"] = np.asarray(lc.time.value, dtype=np.float64)
+    out["pimen_flux"] = np.asarray(lc.flux.value, dtype=np.float64)
+    out["pimen_flux_err"] = np.asarray(lc.flux_err.value, dtype=np.float64)
+    save("fits_ingest", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "acf2d", "ingest", "pixel_pg", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
+    which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "acf2d", "ingest", "fits", "pixel_pg", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
     for w in which:
         globals()["gen_" + w]()

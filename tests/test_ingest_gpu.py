@@ -87,3 +87,38 @@ def test_batch_feeds_the_periodogram_path():
     P = batch.to_periodogram_power(f)
     ref = lombscargle_batch([lc.remove_nans().normalize() for lc in lcs], f)
     assert np.max(np.abs(P - ref)) <= 1e-12 * np.max(ref)
+
+
+def test_fits_files_to_batch_vs_reference_readers(golden):
+    """FITS -> ragged arrays on the device (lk_fits_unpack_batch) for a mixed batch of Kepler-, TESS- and generic-layout
+    files against what lightkurve's own readers return for the same files (oracle/gen_golden.py::gen_fits)."""
+    import os
+    from lightkurve_amd.ingest import LightCurveBatch
+    g = golden("fits_ingest")
+    fdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fits")
+    paths = [os.path.join(fdir, n) for n in ("kepler_llc.fits", "tess_lc.fits", "generic_double.fits", "kepler_llc.fits")]
+    batch = LightCurveBatch.from_fits(paths)
+    tags = ["kepler_default", "tess_default", "generic", "kepler_default"]
+    assert len(batch) == 4 and batch.n_off[-1] == sum(len(g[t + "_time"]) for t in tags)
+    for b, tag in enumerate(tags):
+        lc = batch[b]
+        assert np.array_equal(lc.time, g[tag + "_time"]), tag
+        assert np.array_equal(lc.flux, g[tag + "_flux"], equal_nan=True), tag
+        assert np.array_equal(lc.flux_err, g[tag + "_flux_err"], equal_nan=True), tag
+        if tag + "_quality" in g:
+            assert np.array_equal(batch.quality[batch.n_off[b]:batch.n_off[b + 1]], g[tag + "_quality"]), tag
+    assert batch.meta[0]["MISSION"] == "Kepler" and batch.meta[1]["LABEL"] == "SYNTH tess_lc"
+    # reader options: SAP flux + 'hard' mask, no mask, an integer mask
+    for kw, tag, path in [(dict(flux_column="sap_flux", quality_bitmask="hard"), "kepler_hard_sap", paths[0]),
+                          (dict(quality_bitmask="none"), "kepler_none", paths[0]),
+                          (dict(quality_bitmask=2 + 8 + 128), "tess_int", paths[1])]:
+        one = LightCurveBatch.from_fits([path], **kw)
+        assert np.array_equal(one.time, g[tag + "_time"]) and np.array_equal(one.flux, g[tag + "_flux"], equal_nan=True)
+        assert np.array_equal(one.flux_err, g[tag + "_flux_err"], equal_nan=True)
+        assert np.array_equal(one.quality, g[tag + "_quality"])
+    # the batch goes straight on: remove_nans + normalize + periodogram of the Kepler file
+    clean = LightCurveBatch.from_fits(paths[:2]).remove_nans().normalize()
+    assert np.isfinite(clean.flux).all() and abs(np.median(clean[0].flux) - 1.0) < 1e-12
+    # many files: more workgroups than one wave of CUs, records staged through LDS in several trips
+    big = LightCurveBatch.from_fits(paths[:3] * 40)
+    assert len(big) == 120 and np.array_equal(big[117].time, g["kepler_default_time"])
