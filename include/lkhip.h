@@ -233,6 +233,23 @@ int lk_fits_unpack_batch_dev(lk_handle *h, int B, const uint8_t *raw, const int6
                              const int64_t *bitmask_host, double *t_out, double *flux_out, double *flux_err_out,
                              int32_t *quality_out, int64_t *new_off_host, void *stream);
 
+/* lk_fits_unpack_cube: one target-pixel file -> what PLDCorrector reads from a TargetPixelFile: time, quality and the
+ * float32 pixel cubes FLUX / FLUX_ERR / FLUX_BKG / ... of the cadences the reference keeps
+ * (src/lightkurve/targetpixelfile.py:332, 372, 380, 386, 398: hdu[1].data[col][quality_mask]; quality_mask =
+ * (QUALITY & bitmask) == 0, :2120-2122 for Kepler / K2; TESS additionally drops NaN times when a bitmask is set,
+ * :2794-2801 — pass keep_nan_time = 1 for Kepler files and for bitmask 0; a kept cadence without a finite TIME is
+ * returned as 0.0 like TargetPixelFile.time does, :333-335).  raw: the BINTABLE's bytes as in the file;
+ * ncols <= 4 pixel columns of npix big-endian float32 each at byte offsets col_off[]; cubes_out: ncols x n_rows x npix
+ * float32 (column c starts at c * n_rows * npix, its first *kept cadences are valid); kept: HOST scalar. */
+int lk_fits_unpack_cube(lk_handle *h, const uint8_t *raw, int row_bytes, int n_rows, int off_time, int code_time,
+                        int off_quality, int code_quality, int64_t bitmask, int keep_nan_time, int ncols,
+                        const int32_t *col_off, int npix, double *t_out, int32_t *quality_out, float *cubes_out,
+                        int64_t *kept);
+int lk_fits_unpack_cube_dev(lk_handle *h, const uint8_t *raw, int row_bytes, int n_rows, int off_time, int code_time,
+                            int off_quality, int code_quality, int64_t bitmask, int keep_nan_time, int ncols,
+                            const int32_t *col_off_host, int npix, double *t_out, int32_t *quality_out, float *cubes_out,
+                            int64_t *kept_host, void *stream);
+
 /* LightCurve.create_transit_mask (:2967-3037): target b has planets [planet_off[b], planet_off[b+1]) of the HOST arrays
  * period / duration / transit_time [d]; mask[i] = 1 where |((t - t0 + P/2) % P) - P/2| < duration/2 for any of them. */
 int lk_transit_mask_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const int32_t *planet_off,

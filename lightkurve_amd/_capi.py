@@ -92,6 +92,12 @@ SIGNATURES = [
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _c_ip, _vp, _vp]),
     ("lk_fits_unpack_batch", ctypes.c_int, [_vp, ctypes.c_int, _c_u8p, _c_ip, _c_i32p, _c_ip, _c_dp, _c_dp, _c_dp, _c_i32p, _c_ip]),
     ("lk_fits_unpack_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _vp, _c_ip, _c_i32p, _c_ip, _vp, _vp, _vp, _vp, _c_ip, _vp]),
+    ("lk_fits_unpack_cube", ctypes.c_int, [_vp, _c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int, _c_dp,
+                                            _c_i32p, ctypes.POINTER(ctypes.c_float), _c_ip]),
+    ("lk_fits_unpack_cube_dev", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int, _vp,
+                                                _vp, _vp, _c_ip, _vp]),
     ("lk_transit_mask_batch", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _c_dp, _c_i32p, _c_dp, _c_dp, _c_dp, _c_u8p]),
     ("lk_transit_mask_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, _c_i32p, _c_dp, _c_dp, _c_dp, _vp, _vp]),
     ("lk_bin_batch", ctypes.c_int,
@@ -662,6 +668,25 @@ def fits_unpack_batch(raws, descs, bitmasks, device=0):
                                      _ptr(t), _ptr(f), _ptr(e), _ptr(q, _c_i32p), _ptr(new_off, _c_ip)))
     k = int(new_off[-1])
     return t[:k], f[:k], e[:k], q[:k], new_off
+
+
+def fits_unpack_cube(raw, off_time, code_time, off_quality, code_quality, bitmask, keep_nan_time, col_offsets, npix, device=0):
+    """One target-pixel file's table -> (time[k], quality[k], cubes[ncols, k, npix] float32) for the kept cadences."""
+    h = Handle.get(device)
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    n_rows, row_bytes = raw.shape
+    cols = np.ascontiguousarray(col_offsets, dtype=np.int32)
+    ncols = cols.size
+    t = np.empty(n_rows, dtype=np.float64)
+    q = np.empty(n_rows, dtype=np.int32)
+    cubes = np.empty((ncols, n_rows, npix), dtype=np.float32)
+    kept = np.zeros(1, dtype=np.int64)
+    _check(_lib.lk_fits_unpack_cube(h._h, _ptr(raw.reshape(-1), _c_u8p), int(row_bytes), int(n_rows), int(off_time), int(code_time),
+                                    int(off_quality), int(code_quality), ctypes.c_int64(int(bitmask)), int(bool(keep_nan_time)),
+                                    int(ncols), _ptr(cols, _c_i32p), int(npix), _ptr(t), _ptr(q, _c_i32p),
+                                    cubes.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _ptr(kept, _c_ip)))
+    k = int(kept[0])
+    return t[:k], q[:k], cubes[:, :k, :]
 
 
 def transit_mask_batch(t, n_off, period, duration, transit_time, planet_off=None, device=0):

@@ -31,6 +31,31 @@ class PixelCube(object):
             raise ValueError("flux and flux_err must be (cadence, row, column) cubes matching time")
         self.meta = {"MISSION": mission, "TARGETID": targetid}
 
+    @classmethod
+    def from_fits(cls, path, quality_bitmask="default", device=0):
+        """A Kepler / K2 / TESS target-pixel file -> the arrays PLDCorrector works on, with the reference's cadence
+        selection (``KeplerTargetPixelFile`` / ``TessTargetPixelFile``: targetpixelfile.py:2120-2122, 2794-2801).  Headers
+        are parsed on the host (fitsio.py), the table's bytes are turned into time / quality / float32 cubes on the GPU
+        (``lk_fits_unpack_cube``).  Also sets ``flux_bkg`` (when the file has it), ``quality`` and ``pipeline_mask``
+        (aperture extension & 2, targetpixelfile.py:308-322)."""
+        from .. import _capi, fitsio
+        tab = fitsio.read_fits_table(path, ext=1)
+        pc = fitsio.pixel_columns(tab, quality_bitmask=quality_bitmask)
+        t, q, cubes = _capi.fits_unpack_cube(tab.raw, pc["off_time"], pc["code_time"], pc["off_quality"], pc["code_quality"],
+                                             pc["bitmask"], pc["keep_nan_time"], pc["col_offsets"], pc["npix"], device=device)
+        shape = (len(t),) + tuple(pc["shape"])
+        by_name = {n: cubes[i].reshape(shape) for i, n in enumerate(pc["columns"])}
+        flux = by_name["flux"]
+        err = by_name.get("flux_err", np.full(shape, np.nan, dtype=np.float32))
+        mission = tab.primary.get("MISSION", tab.primary.get("TELESCOP"))
+        out = cls(t, flux, err, mission=mission, targetid=tab.primary.get("KEPLERID", tab.primary.get("TICID")))
+        out.quality = q
+        out.flux_bkg = by_name.get("flux_bkg")
+        aper = fitsio.read_fits_image(path, 2)
+        out.pipeline_mask = (aper & 2) > 0 if aper is not None and aper.shape == shape[1:] else np.ones(shape[1:], dtype=bool)
+        out.meta.update({"FILENAME": str(path), "QUALITY_BITMASK": quality_bitmask, "LABEL": tab.primary.get("OBJECT")})
+        return out
+
     @property
     def shape(self):
         return self.flux.shape

@@ -864,6 +864,47 @@ int lk_fits_unpack_batch(lk_handle *h, int B, const uint8_t *raw, const int64_t 
     return LK_OK;
 }
 
+int lk_fits_unpack_cube_dev(lk_handle *h, const uint8_t *raw, int row_bytes, int n_rows, int off_time, int code_time,
+                            int off_quality, int code_quality, int64_t bitmask, int keep_nan_time, int ncols,
+                            const int32_t *col_off_host, int npix, double *t_out, int32_t *quality_out, float *cubes_out,
+                            int64_t *kept_host, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::fits_cube_launch(h, raw, row_bytes, n_rows, off_time, code_time, off_quality, code_quality, bitmask,
+                                keep_nan_time, ncols, col_off_host, npix, t_out, quality_out, cubes_out, kept_host,
+                                static_cast<hipStream_t>(stream));
+}
+
+int lk_fits_unpack_cube(lk_handle *h, const uint8_t *raw, int row_bytes, int n_rows, int off_time, int code_time,
+                        int off_quality, int code_quality, int64_t bitmask, int keep_nan_time, int ncols,
+                        const int32_t *col_off, int npix, double *t_out, int32_t *quality_out, float *cubes_out,
+                        int64_t *kept) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(raw && col_off && t_out && cubes_out && kept, "NULL buffer");
+    LK_REQUIRE(row_bytes >= 1 && n_rows >= 0 && ncols >= 1 && ncols <= 4 && npix >= 1, "bad table description");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t nraw = (size_t)row_bytes * n_rows, ncube = (size_t)ncols * n_rows * npix * 4;
+    h->staging.reset();
+    int rc = h->staging.reserve(nraw + ncube + (size_t)n_rows * 12 + 4096);
+    if (rc) return rc;
+    uint8_t *draw = (uint8_t *)h->staging.alloc(nraw + 16);
+    double *dt = (double *)h->staging.alloc((size_t)n_rows * 8 + 8);
+    int32_t *dq = quality_out ? (int32_t *)h->staging.alloc((size_t)n_rows * 4 + 8) : nullptr;
+    float *dc = (float *)h->staging.alloc(ncube + 16);
+    LK_HIP_CHECK(hipMemcpy(draw, raw, nraw, hipMemcpyHostToDevice));
+    rc = lk::fits_cube_launch(h, draw, row_bytes, n_rows, off_time, code_time, off_quality, code_quality, bitmask,
+                              keep_nan_time, ncols, col_off, npix, dt, dq, dc, kept, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipDeviceSynchronize());
+    const size_t k = (size_t)*kept;
+    LK_HIP_CHECK(hipMemcpy(t_out, dt, k * 8, hipMemcpyDeviceToHost));
+    if (quality_out) LK_HIP_CHECK(hipMemcpy(quality_out, dq, k * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < ncols; ++c)  // host layout: [column][kept cadence][pixel], columns n_rows * npix apart like the device's
+        LK_HIP_CHECK(hipMemcpy(cubes_out + (size_t)c * n_rows * npix, dc + (size_t)c * n_rows * npix, k * npix * 4,
+                               hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 int lk_transit_mask_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const int32_t *planet_off,
                               const double *period, const double *duration, const double *transit_time, uint8_t *mask,
                               void *stream) {

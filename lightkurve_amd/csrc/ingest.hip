@@ -209,13 +209,17 @@ __device__ __forceinline__ void fits_stage(const uint8_t *__restrict__ tab, long
     for (long long w = w0 + threadIdx.x; w < w1; w += blockDim.x) dst[w - w0] = src[w];
 }
 
-template <bool PACK>
+// STAGE = false: records too long for the LDS stage (target-pixel files: kilobytes per cadence) — the few scalar fields
+// are read straight from global memory.  keep_nan_time: Kepler target-pixel files keep cadences whose TIME is NaN
+// (targetpixelfile.py:2120-2122), every other reader drops them.  row_out (nullable): source row of every kept record.
+template <bool PACK, bool STAGE>
 __global__ __launch_bounds__(256) void fits_unpack_kernel(const uint8_t *__restrict__ raw, const int64_t *__restrict__ raw_off,
                                                            const FitsDesc *__restrict__ desc,
                                                            const int64_t *__restrict__ bitmask, int64_t *__restrict__ kept,
                                                            const int64_t *__restrict__ new_off, double *__restrict__ t_out,
                                                            double *__restrict__ f_out, double *__restrict__ e_out,
-                                                           int *__restrict__ q_out) {
+                                                           int *__restrict__ q_out, int keep_nan_time,
+                                                           int *__restrict__ row_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fits_lds[];
     __shared__ int s_cnt[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -227,17 +231,22 @@ __global__ __launch_bounds__(256) void fits_unpack_kernel(const uint8_t *__restr
     for (long long r0 = 0; r0 < d.n_rows; r0 += FITS_ROWS) {
         const int nr = (int)min((long long)FITS_ROWS, (long long)d.n_rows - r0);
         __syncthreads();
-        fits_stage(tab, r0, nr, d.row_bytes, fits_lds);
-        __syncthreads();
-        const int skew = (int)((r0 * d.row_bytes) & 3);  // the staged words start at a 4-byte boundary
-        const uint8_t *rec = fits_lds + skew + (size_t)tid * d.row_bytes;
+        const uint8_t *rec;
+        if (STAGE) {
+            fits_stage(tab, r0, nr, d.row_bytes, fits_lds);
+            __syncthreads();
+            const int skew = (int)((r0 * d.row_bytes) & 3);  // the staged words start at a 4-byte boundary
+            rec = fits_lds + skew + (size_t)tid * d.row_bytes;
+        } else {
+            rec = tab + (size_t)(r0 + min(tid, nr - 1)) * d.row_bytes;
+        }
         double tv = qnan, fv = qnan, ev = qnan;
         long long qv = 0;
         bool keep = false;
         if (tid < nr) {
             tv = fits_real(rec, d.off_t, d.code_t);
             if (d.off_q >= 0) qv = fits_int(rec, d.off_q, d.code_q);
-            keep = !isnan(tv) && (qv & mask) == 0;
+            keep = (keep_nan_time || !isnan(tv)) && (qv & mask) == 0;
             if (PACK && keep) {
                 fv = fits_real(rec, d.off_f, d.code_f);
                 if (d.off_e >= 0) ev = fits_real(rec, d.off_e, d.code_e);
@@ -253,10 +262,12 @@ __global__ __launch_bounds__(256) void fits_unpack_kernel(const uint8_t *__restr
         }
         if (PACK && keep) {
             const long long pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
-            t_out[pos] = tv;
+            // a kept cadence without a time reads 0, as TargetPixelFile.time makes it (targetpixelfile.py:333-335)
+            t_out[pos] = (keep_nan_time && !isfinite(tv)) ? 0.0 : tv;
             f_out[pos] = fv;
             if (e_out) e_out[pos] = ev;
             if (q_out) q_out[pos] = (int)qv;
+            if (row_out) row_out[pos] = (int)(r0 + tid);
         }
         base += all;
         total += all;
@@ -306,19 +317,91 @@ int fits_unpack_launch(lk_handle *h, int B, const uint8_t *raw, const int64_t *r
     static bool attr = false;
     if (!attr) {
         // (the kernel also has 16 bytes of static LDS: the dynamic part may not claim all 160 KB)
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<false>),
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<false, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<true>),
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<true, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(fits_unpack_kernel<false>, dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask, d_kept,
-                       (const int64_t *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr);
+    hipLaunchKernelGGL((fits_unpack_kernel<false, true>), dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask, d_kept,
+                       (const int64_t *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr, 0,
+                       (int *)nullptr);
     hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, stream, d_kept, B, d_new);
-    hipLaunchKernelGGL(fits_unpack_kernel<true>, dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask,
-                       (int64_t *)nullptr, d_new, t_out, f_out, e_out, q_out);
+    hipLaunchKernelGGL((fits_unpack_kernel<true, true>), dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask,
+                       (int64_t *)nullptr, d_new, t_out, f_out, e_out, q_out, 0, (int *)nullptr);
     LK_HIP_CHECK(hipMemcpyAsync(new_off_host, d_new, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// Target-pixel files (the input of PLDCorrector): every kept cadence's pixel vectors (FLUX, FLUX_ERR, FLUX_BKG ...: `npix`
+// big-endian float32 per column and record) -> float32 cubes [column][kept cadence][pixel].  One workgroup per kept
+// cadence; the pixels of a record are contiguous, so the loads are coalesced 4-byte words when the column is aligned.
+__global__ __launch_bounds__(128) void fits_cube_kernel(const uint8_t *__restrict__ tab, int row_bytes, const int *__restrict__ rows,
+                                                         int ncols, int off0, int off1, int off2, int off3, int npix,
+                                                         size_t col_stride, float *__restrict__ out) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const uint8_t *rec = tab + (size_t)rows[i] * row_bytes;
+    const int offs[4] = {off0, off1, off2, off3};
+    for (int c = 0; c < ncols; ++c) {
+        const uint8_t *src = rec + offs[c];
+        float *dst = out + (size_t)c * col_stride + (size_t)i * npix;
+        if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+            const unsigned int *w = reinterpret_cast<const unsigned int *>(src);
+            for (int p = tid; p < npix; p += 128) dst[p] = __uint_as_float(__builtin_bswap32(w[p]));
+        } else {
+            for (int p = tid; p < npix; p += 128) dst[p] = __uint_as_float((unsigned)fits_be(src + 4 * p, 4));
+        }
+    }
+}
+
+int fits_cube_launch(lk_handle *h, const uint8_t *raw, int row_bytes, int n_rows, int off_time, int code_time, int off_qual,
+                     int code_qual, int64_t bitmask, int keep_nan_time, int ncols, const int32_t *col_off_host, int npix,
+                     double *t_out, int32_t *q_out, float *cubes_out, int64_t *kept_host, hipStream_t stream) {
+    LK_REQUIRE(raw && t_out && cubes_out && kept_host && col_off_host, "NULL buffer");
+    LK_REQUIRE(row_bytes >= 1 && n_rows >= 0 && ncols >= 1 && ncols <= 4 && npix >= 1, "bad table description");
+    LK_REQUIRE(code_time >= 0 && code_time <= 1 && off_time >= 0 && off_time + (code_time ? 4 : 8) <= row_bytes,
+               "TIME does not fit the record");
+    LK_REQUIRE(off_qual < 0 || (code_qual >= 2 && code_qual <= 5 && off_qual + 1 <= row_bytes), "QUALITY does not fit the record");
+    for (int c = 0; c < ncols; ++c)
+        LK_REQUIRE(col_off_host[c] >= 0 && (int64_t)col_off_host[c] + 4ll * npix <= row_bytes,
+                   "pixel column %d (offset %d, %d pixels) does not fit the %d-byte record", c, col_off_host[c], npix, row_bytes);
+    if (n_rows == 0) {
+        *kept_host = 0;
+        return LK_OK;
+    }
+    h->ws.reset();
+    int rc = h->ws.reserve(64 + sizeof(FitsDesc) + (size_t)n_rows * 4 + (size_t)n_rows * 16 + 4096);
+    if (rc) return rc;
+    int64_t *d_roff = (int64_t *)h->ws.alloc(16), *d_mask = (int64_t *)h->ws.alloc(8);
+    int64_t *d_kept = (int64_t *)h->ws.alloc(16), *d_new = (int64_t *)h->ws.alloc(16);
+    FitsDesc *d_desc = (FitsDesc *)h->ws.alloc(sizeof(FitsDesc));
+    int *d_rows = (int *)h->ws.alloc((size_t)n_rows * 4);
+    double *d_dummy = (double *)h->ws.alloc((size_t)n_rows * 8);  // the scalar kernel's flux slot (TIME again), unused
+    const int64_t roff[2] = {0, (int64_t)row_bytes * n_rows};
+    const FitsDesc desc{row_bytes, n_rows, off_time, code_time, off_time, code_time, -1, 0, off_qual, code_qual};
+    LK_HIP_CHECK(hipMemcpyAsync(d_roff, roff, 16, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_mask, &bitmask, 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipMemcpyAsync(d_desc, &desc, sizeof(FitsDesc), hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));  // the sources are on this function's stack
+    hipLaunchKernelGGL((fits_unpack_kernel<false, false>), dim3(1), dim3(256), 16, stream, raw, d_roff, d_desc, d_mask, d_kept,
+                       (const int64_t *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr,
+                       keep_nan_time, (int *)nullptr);
+    hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, stream, d_kept, 1, d_new);
+    hipLaunchKernelGGL((fits_unpack_kernel<true, false>), dim3(1), dim3(256), 16, stream, raw, d_roff, d_desc, d_mask,
+                       (int64_t *)nullptr, d_new, t_out, d_dummy, (double *)nullptr, q_out, keep_nan_time, d_rows);
+    int64_t newoff[2];
+    LK_HIP_CHECK(hipMemcpyAsync(newoff, d_new, 16, hipMemcpyDeviceToHost, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t kept = newoff[1];
+    *kept_host = kept;
+    if (kept > 0) {
+        const int o[4] = {col_off_host[0], ncols > 1 ? col_off_host[1] : 0, ncols > 2 ? col_off_host[2] : 0,
+                          ncols > 3 ? col_off_host[3] : 0};
+        hipLaunchKernelGGL(fits_cube_kernel, dim3((unsigned)kept), dim3(128), 0, stream, raw, row_bytes, d_rows, ncols, o[0], o[1],
+                           o[2], o[3], npix, (size_t)n_rows * npix, cubes_out);
+    }
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

@@ -129,6 +129,9 @@ int ingest_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
 int fits_unpack_launch(lk_handle *h, int B, const uint8_t *raw, const int64_t *raw_off_host, const int32_t *desc_host,
                        const int64_t *bitmask_host, double *t_out, double *f_out, double *e_out, int32_t *q_out,
                        int64_t *new_off_host, hipStream_t stream);
+int fits_cube_launch(lk_handle *h, const uint8_t *raw, int row_bytes, int n_rows, int off_time, int code_time, int off_qual,
+                     int code_qual, int64_t bitmask, int keep_nan_time, int ncols, const int32_t *col_off_host, int npix,
+                     double *t_out, int32_t *q_out, float *cubes_out, int64_t *kept_host, hipStream_t stream);
 int transit_mask_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const int *p_off_host,
                         const double *period_host, const double *duration_host, const double *transit_time_host,
                         uint8_t *mask, hipStream_t stream);

@@ -14,7 +14,7 @@ import gzip
 
 import numpy as np
 
-__all__ = ["read_fits_table", "FitsTable", "lightcurve_columns", "QUALITY_OPTIONS"]
+__all__ = ["read_fits_table", "read_fits_image", "FitsTable", "lightcurve_columns", "pixel_columns", "QUALITY_OPTIONS"]
 
 # reference src/lightkurve/utils.py: KeplerQualityFlags.OPTIONS (:190-195), TessQualityFlags.OPTIONS (:270-275)
 QUALITY_OPTIONS = {
@@ -76,8 +76,9 @@ class FitsTable(object):
     """One BINTABLE extension: ``raw`` (uint8, n_rows x row_bytes, the file's bytes untouched), ``columns`` (lower-case
     name -> (byte offset in the row, TFORM letter, repeat)), ``header`` (extension) and ``primary`` (HDU 0)."""
 
-    def __init__(self, raw, columns, header, primary, path=None):
+    def __init__(self, raw, columns, header, primary, path=None, dims=None):
         self.raw, self.columns, self.header, self.primary, self.path = raw, columns, header, primary, path
+        self.dims = dims or {}   # lower-case name -> numpy shape of one cell (from TDIMn), vector columns only
 
     @property
     def n_rows(self):
@@ -118,7 +119,7 @@ def read_fits_table(path, ext=1):
     row_bytes, n_rows = int(hdr["NAXIS1"]), int(hdr["NAXIS2"])
     if data_pos + row_bytes * n_rows > buf.size:
         raise OSError("%s: the table is truncated (%d of %d bytes)" % (path, buf.size - data_pos, row_bytes * n_rows))
-    columns, off = {}, 0
+    columns, dims, off = {}, {}, 0
     for i in range(1, int(hdr["TFIELDS"]) + 1):
         form = str(hdr["TFORM%d" % i]).strip()
         j = 0
@@ -130,11 +131,43 @@ def read_fits_table(path, ext=1):
         name = str(hdr.get("TTYPE%d" % i, "col%d" % i)).strip().lower()
         scaled = float(hdr.get("TSCAL%d" % i, 1.0)) != 1.0 or float(hdr.get("TZERO%d" % i, 0.0)) != 0.0
         columns.setdefault(name, (off, letter, repeat, scaled))
+        tdim = hdr.get("TDIM%d" % i)
+        if tdim and name not in dims:  # '(ncol,nrow)' in Fortran order -> numpy shape (nrow, ncol)
+            dims[name] = tuple(int(x) for x in str(tdim).strip().strip("()").split(","))[::-1]
         off += nbytes
     if off != row_bytes:
         raise OSError("%s: TFORM widths add up to %d bytes, NAXIS1 says %d" % (path, off, row_bytes))
     raw = buf[data_pos:data_pos + row_bytes * n_rows].reshape(n_rows, row_bytes)
-    return FitsTable(raw, columns, hdr, primary, path=str(path))
+    return FitsTable(raw, columns, hdr, primary, path=str(path), dims=dims)
+
+
+def read_fits_image(path, ext):
+    """Image extension ``ext`` (1-based) as a native-endian ndarray, or None if the file has no such HDU / it is not an
+    image.  Used for the aperture extension of target-pixel files (a few hundred integers: decoded on the host)."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rb") as fh:
+        buf = np.frombuffer(fh.read(), dtype=np.uint8)
+    pos, hdr = 0, None
+    try:
+        for i in range(int(ext) + 1):
+            hdr, pos = _read_header(buf, pos)
+            nax = int(hdr.get("NAXIS", 0))
+            size = abs(int(hdr.get("BITPIX", 8))) // 8 if nax > 0 else 0
+            for k in range(1, nax + 1):
+                size *= int(hdr["NAXIS%d" % k])
+            size += int(hdr.get("PCOUNT", 0))
+            data_pos = pos
+            pos += (size + BLOCK - 1) // BLOCK * BLOCK
+    except OSError:
+        return None
+    if str(hdr.get("XTENSION", "IMAGE")).strip() != "IMAGE" or int(hdr.get("NAXIS", 0)) == 0:
+        return None
+    dt = {8: "u1", 16: ">i2", 32: ">i4", 64: ">i8", -32: ">f4", -64: ">f8"}[int(hdr["BITPIX"])]
+    shape = tuple(int(hdr["NAXIS%d" % k]) for k in range(int(hdr["NAXIS"]), 0, -1))
+    n = int(np.prod(shape))
+    arr = np.frombuffer(bytes(buf[data_pos:data_pos + n * np.dtype(dt).itemsize]), dtype=dt).reshape(shape)
+    return arr.astype(arr.dtype.newbyteorder("=")) * hdr.get("BSCALE", 1) + hdr.get("BZERO", 0) \
+        if ("BSCALE" in hdr or "BZERO" in hdr) else arr.astype(arr.dtype.newbyteorder("="))
 
 
 _CODES = {"D": 0, "E": 1, "J": 2, "K": 3, "I": 4, "B": 5}
@@ -190,3 +223,42 @@ def lightcurve_columns(tab, flux_column=None, quality_bitmask="default", mission
     oq, cq = field(qual_col, "JKIB")
     desc = np.array([tab.row_bytes, tab.n_rows, ot, ct, of, cf, oe, ce, oq, cq], dtype=np.int32)
     return desc, int(bitmask), mission
+
+
+def pixel_columns(tab, columns=("flux", "flux_err", "flux_bkg"), quality_bitmask="default", mission=None):
+    """Where a target-pixel file keeps TIME, QUALITY and its pixel cubes, and which cadences the reference keeps:
+    quality_mask = (QUALITY & bitmask) == 0 (targetpixelfile.py:2120-2122 Kepler / K2, :2794-2797 TESS), TESS also drops
+    NaN times unless the bitmask is 0 / 'none' (:2798-2801).  Returns a dict for ``_capi.fits_unpack_cube``."""
+    if mission is None:
+        tel = str(tab.primary.get("TELESCOP", tab.header.get("TELESCOP", ""))).strip().lower()
+        mission = "tess" if tel == "tess" else "kepler"
+    opts = QUALITY_OPTIONS[mission]
+    if isinstance(quality_bitmask, str):
+        if quality_bitmask not in opts:
+            raise ValueError("quality_bitmask='{}' is not supported, expected one of {}".format(quality_bitmask, tuple(opts)))
+        bitmask = opts[quality_bitmask]
+    else:
+        bitmask = 0 if quality_bitmask is None else int(quality_bitmask)
+    cols = tab.columns
+    for need in ("time", "quality", columns[0]):
+        if need not in cols:
+            raise KeyError("%s has no %s column" % (tab.path, need.upper()))
+    ot, lt, rt, st = cols["time"]
+    oq, lq, rq, sq = cols["quality"]
+    if lt not in "DE" or lq not in "JKIB" or rt != 1 or rq != 1 or st or sq:
+        raise NotImplementedError("TIME / QUALITY of %s have unsupported TFORMs" % tab.path)
+    use, offs, npix, shape = [], [], None, None
+    for name in columns:
+        if name not in cols:
+            continue
+        off, letter, repeat, scaled = cols[name]
+        if letter != "E" or scaled:
+            raise NotImplementedError("pixel column %s of %s is not plain float32" % (name.upper(), tab.path))
+        if npix is None:
+            npix, shape = repeat, tab.dims.get(name, (repeat,))
+        elif repeat != npix:
+            raise ValueError("pixel columns of %s have different sizes" % tab.path)
+        use.append(name), offs.append(off)
+    keep_nan_time = mission != "tess" or bitmask == 0 or quality_bitmask == "none"
+    return dict(off_time=ot, code_time=_CODES[lt], off_quality=oq, code_quality=_CODES[lq], bitmask=bitmask,
+                keep_nan_time=keep_nan_time, columns=use, col_offsets=offs, npix=npix, shape=shape, mission=mission)

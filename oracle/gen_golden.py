@@ -676,6 +676,70 @@ def gen_fits():
     out["pimen_time"] = np.asarray(lc.time.value, dtype=np.float64)
     out["pimen_flux"] = np.asarray(lc.flux.value, dtype=np.float64)
     out["pimen_flux_err"] = np.asarray(lc.flux_err.value, dtype=np.float64)
+    # ---- target-pixel files (the input of PLDCorrector): synthetic 6 x 5 cutouts in the mission layout
+    from lightkurve.targetpixelfile import KeplerTargetPixelFile, TessTargetPixelFile
+
+    def tpf_file(name, telescop, n, flags, bjdrefi):
+        ny, nx = 6, 5
+        t = 50.0 + np.arange(n) * 0.0204
+        t[[4, 40]] = np.nan
+        flux = (200 + 50 * rng.random((n, ny, nx))).astype("f4")
+        flux[7, 2, 3] = np.nan
+        err = (1 + rng.random((n, ny, nx))).astype("f4")
+        bkg = (20 + rng.random((n, ny, nx))).astype("f4")
+        q = np.zeros(n, "i4")
+        idx = rng.integers(0, n, 25)
+        q[idx] = rng.choice(flags, size=25)
+        dim = "(%d,%d)" % (nx, ny)
+        fmt = "%dE" % (nx * ny)
+        cols = [fits.Column(name="TIME", format="D", unit="BJD - %d" % bjdrefi, array=t),
+                fits.Column(name="TIMECORR", format="E", array=np.zeros(n, "f4")),
+                fits.Column(name="CADENCENO", format="J", array=np.arange(n, dtype="i4")),
+                fits.Column(name="RAW_CNTS", format="%dJ" % (nx * ny), dim=dim, array=np.ones((n, ny, nx), "i4")),
+                fits.Column(name="FLUX", format=fmt, dim=dim, unit="e-/s", array=flux),
+                fits.Column(name="FLUX_ERR", format=fmt, dim=dim, unit="e-/s", array=err),
+                fits.Column(name="FLUX_BKG", format=fmt, dim=dim, unit="e-/s", array=bkg),
+                fits.Column(name="FLUX_BKG_ERR", format=fmt, dim=dim, unit="e-/s", array=err * 0.1),
+                fits.Column(name="COSMIC_RAYS", format=fmt, dim=dim, array=np.zeros((n, ny, nx), "f4")),
+                fits.Column(name="QUALITY", format="J", array=q),
+                fits.Column(name="POS_CORR1", format="E", array=np.zeros(n, "f4")),
+                fits.Column(name="POS_CORR2", format="E", array=np.zeros(n, "f4"))]
+        hdu = fits.BinTableHDU.from_columns(cols, name="TARGETTABLES" if telescop == "Kepler" else "PIXELS")
+        hdu.header["BJDREFI"] = bjdrefi
+        hdu.header["BJDREFF"] = 0.0
+        hdu.header["TIMESYS"] = "TDB"
+        for k in ("1CRV5P", "2CRV5P", "1CRV4P", "2CRV4P"):
+            hdu.header[k] = 10
+        pri = fits.PrimaryHDU()
+        pri.header["TELESCOP"] = telescop
+        pri.header["INSTRUME"] = "Kepler Photometer" if telescop == "Kepler" else "TESS Photometer"
+        pri.header["OBJECT"] = "SYNTH TPF " + name
+        pri.header["MISSION"] = "K2" if telescop == "Kepler" else "TESS"
+        pri.header["KEPLERID" if telescop == "Kepler" else "TICID"] = 4242
+        pri.header["OBSMODE"] = "long cadence"
+        pri.header["CREATOR"] = "synthetic TargetPixelExporterPipelineModule"
+        pri.header["COMMENT"] = "synthetic file for lightkurve_amd's FITS-ingest parity test; it's not flight data"
+        aper = np.ones((ny, nx), "i4")
+        aper[1:4, 1:4] = 3
+        path = os.path.join(fdir, name + ".fits")
+        fits.HDUList([pri, hdu, fits.ImageHDU(aper, name="APERTURE")]).writeto(path, overwrite=True)
+        return path
+
+    def dump_tpf(tag, tpf):
+        out[tag + "_time"] = np.asarray(tpf.time.value, dtype=np.float64)
+        out[tag + "_flux"] = np.asarray(tpf.flux.value, dtype=np.float32)
+        out[tag + "_flux_err"] = np.asarray(tpf.flux_err.value, dtype=np.float32)
+        out[tag + "_flux_bkg"] = np.asarray(tpf.flux_bkg.value, dtype=np.float32)
+        out[tag + "_quality"] = np.asarray(tpf.quality, dtype=np.int64)
+        out[tag + "_pipeline_mask"] = np.asarray(tpf.pipeline_mask, dtype=bool)
+
+    p = tpf_file("kepler_tpf", "Kepler", 90, kflags, 2454833)
+    dump_tpf("ktpf_default", KeplerTargetPixelFile(p))
+    dump_tpf("ktpf_none", KeplerTargetPixelFile(p, quality_bitmask="none"))
+    p = tpf_file("tess_tpf", "TESS", 80, tflags, 2457000)
+    dump_tpf("ttpf_default", TessTargetPixelFile(p))
+    dump_tpf("ttpf_none", TessTargetPixelFile(p, quality_bitmask="none"))
+    dump_tpf("ttpf_hard", TessTargetPixelFile(p, quality_bitmask="hard"))
     save("fits_ingest", **out)
 
 

@@ -129,3 +129,26 @@ def test_pixel_periodograms_batch_vs_reference(golden):
     for j in g["pixels"]:
         ref = g["power_grid_%d" % j]
         assert np.max(np.abs(pgs2[int(j)].power - ref)) / np.max(ref) < 1e-9
+
+
+@pytest.mark.parametrize("fname,tag,kw", [
+    ("kepler_tpf.fits", "ktpf_default", {}),
+    ("kepler_tpf.fits", "ktpf_none", dict(quality_bitmask="none")),
+    ("tess_tpf.fits", "ttpf_default", {}),
+    ("tess_tpf.fits", "ttpf_none", dict(quality_bitmask="none")),
+    ("tess_tpf.fits", "ttpf_hard", dict(quality_bitmask="hard")),
+])
+def test_target_pixel_file_to_cube_vs_reference_classes(golden, fname, tag, kw):
+    """FITS target-pixel file -> PixelCube on the device (lk_fits_unpack_cube): time, quality, flux / flux_err / flux_bkg
+    cubes and the pipeline mask bit-identical to KeplerTargetPixelFile / TessTargetPixelFile on the same file."""
+    import os
+    g = golden("fits_ingest")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fits", fname)
+    cube = PixelCube.from_fits(path, **kw)
+    assert np.array_equal(cube.time, g[tag + "_time"], equal_nan=True)
+    assert np.array_equal(cube.quality, g[tag + "_quality"])
+    assert cube.flux.dtype == np.float32 and np.array_equal(cube.flux, g[tag + "_flux"], equal_nan=True)
+    assert np.array_equal(cube.flux_err, g[tag + "_flux_err"], equal_nan=True)
+    assert np.array_equal(cube.flux_bkg, g[tag + "_flux_bkg"], equal_nan=True)
+    assert np.array_equal(cube.pipeline_mask, g[tag + "_pipeline_mask"])
+    assert cube.meta["MISSION"] in ("K2", "TESS") and cube.meta["TARGETID"] == 4242
