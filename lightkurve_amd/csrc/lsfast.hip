@@ -733,8 +733,13 @@ struct Fft3 {
     static constexpr int TILE = (A * S1 > C * S3 ? A * S1 : C * S3);
 };
 
-template <int LA, int LB, int LC, int MODE, class Load, class Store>
-__device__ __forceinline__ void block_fft3(int NF, double2 *tile, Load load, Store store, int tw = 1) {
+// KOUT: only the outputs kc < KOUT of phase 3 are wanted (C = 8, KOUT <= 2: two direct sums instead of the 8-point FFT).
+// steps != nullptr: the two per-thread twiddle steps (W_n^t, W_{BC}^{c2}), which depend on the thread only — a caller
+// that transforms several arrays with the same thread mapping computes them once (fft3_twiddle_steps) instead of two
+// sincospi per array.
+template <int LA, int LB, int LC, int MODE, int KOUT = (1 << LC), class Load, class Store>
+__device__ __forceinline__ void block_fft3(int NF, double2 *tile, Load load, Store store, int tw = 1,
+                                           const double2 *steps = nullptr) {
     using F = Fft3<LA, LB, LC>;
     constexpr int A = F::A, B = F::B, C = F::C, n = F::n, T = F::T, S1 = F::S1, S3 = F::S3;
     const int tid = threadIdx.x;
@@ -758,9 +763,14 @@ __device__ __forceinline__ void block_fft3(int NF, double2 *tile, Load load, Sto
 #pragma unroll
         for (int a = 0; a < A; ++a) v[a] = load(f, a * (B * C) + t);
         reg_fft<LA>(v);
-        double s1, c1;
-        sincospi(2.0 * (double)t / (double)n, &s1, &c1);
-        const double2 step = make_double2(c1, s1);
+        double2 step;
+        if (steps) {
+            step = steps[0];
+        } else {
+            double s1, c1;
+            sincospi(2.0 * (double)t / (double)n, &s1, &c1);
+            step = make_double2(c1, s1);
+        }
         double2 w = make_double2(1.0, 0.0);
 #pragma unroll
         for (int ka = 0; ka < A; ++ka) {
@@ -779,9 +789,14 @@ __device__ __forceinline__ void block_fft3(int NF, double2 *tile, Load load, Sto
     }
     __syncthreads();  // every read of the [ka][t] layout is done before the tile is overwritten
     if (live && t < A * C) {
-        double s1, c1;
-        sincospi(2.0 * (double)c2 / (double)(B * C), &s1, &c1);
-        const double2 step = make_double2(c1, s1);
+        double2 step;
+        if (steps) {
+            step = steps[1];
+        } else {
+            double s1, c1;
+            sincospi(2.0 * (double)c2 / (double)(B * C), &s1, &c1);
+            step = make_double2(c1, s1);
+        }
         double2 w = make_double2(1.0, 0.0);
 #pragma unroll
         for (int kb = 0; kb < B; ++kb) {
@@ -795,10 +810,47 @@ __device__ __forceinline__ void block_fft3(int NF, double2 *tile, Load load, Sto
         double2 z[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) z[c] = my[c * S3 + t];
-        reg_fft<LC>(z);
+        if (C == 8 && KOUT <= 2) {
+            // X[0] = sum z_c;  X[1] = sum z_c W^c, W = e^{+2 pi i / 8}: (z0 - z4) + i (z2 - z6) + W (z1 - z5) + W^3 (z3 - z7)
+            const double2 x0 = make_double2(((z[0].x + z[4].x) + (z[2].x + z[6].x)) + ((z[1].x + z[5].x) + (z[3].x + z[7].x)),
+                                            ((z[0].y + z[4].y) + (z[2].y + z[6].y)) + ((z[1].y + z[5].y) + (z[3].y + z[7].y)));
+            store(f, t, x0, 0);
+            if (KOUT > 1) {
+                const double r = 0.70710678118654752440;
+                const double2 d04 = make_double2(z[0].x - z[4].x, z[0].y - z[4].y), d26 = make_double2(z[2].x - z[6].x, z[2].y - z[6].y);
+                const double2 d15 = make_double2(z[1].x - z[5].x, z[1].y - z[5].y), d37 = make_double2(z[3].x - z[7].x, z[3].y - z[7].y);
+                // W d15 = r ((x - y) + i (x + y));  W^3 d37 = r ((-x - y) + i (x - y))
+                const double2 x1 = make_double2((d04.x - d26.y) + r * ((d15.x - d15.y) - (d37.x + d37.y)),
+                                                (d04.y + d26.x) + r * ((d15.x + d15.y) + (d37.x - d37.y)));
+                store(f, t + A * B, x1, 1);
+            }
+        } else {
+            reg_fft<LC>(z);
 #pragma unroll
-        for (int kc = 0; kc < C; ++kc) store(f, t + A * B * kc, z[brev_c(kc, LC)], kc);
+            for (int kc = 0; kc < C; ++kc) store(f, t + A * B * kc, z[brev_c(kc, LC)], kc);
+        }
     }
+}
+
+// the two twiddle steps of block_fft3 for this thread (MODE 1 / 2 thread mapping as in block_fft3)
+template <int LA, int LB, int LC, int MODE>
+__device__ __forceinline__ void fft3_twiddle_steps(int NF, int tw, double2 *steps) {
+    using F = Fft3<LA, LB, LC>;
+    const int tid = threadIdx.x;
+    int t;
+    if (MODE == 1) {
+        t = tid / NF;
+    } else if (MODE == 2) {
+        const int jl = tid % tw, rest = tid / tw;
+        t = jl + tw * (rest / NF);
+    } else {
+        t = tid % F::T;
+    }
+    double s1, c1;
+    sincospi(2.0 * (double)t / (double)F::n, &s1, &c1);
+    steps[0] = make_double2(c1, s1);
+    sincospi(2.0 * (double)(t % F::C) / (double)(F::B * F::C), &s1, &c1);
+    steps[1] = make_double2(c1, s1);
 }
 
 // step 2 fused with the closed form, three-phase version: thread (f, t3) ends with the outputs k2 = t3 + A*B*kc of row
@@ -820,6 +872,11 @@ __global__ __launch_bounds__(512) void fft_rows_power3_kernel(const double2 *__r
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int q = 0; q < KC; ++q) keep[g][q] = make_double2(0.0, 0.0);
+    double2 steps[2];  // the thread's twiddle steps are the same for the three grids
+    if (tw < 0)
+        fft3_twiddle_steps<LA, LB, LC, 1>(RT, tw, steps);
+    else
+        fft3_twiddle_steps<LA, LB, LC, 2>(RT, tw, steps);
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         if (g == 1 && !fit_mean) continue;
@@ -830,12 +887,12 @@ __global__ __launch_bounds__(512) void fft_rows_power3_kernel(const double2 *__r
         if (tw < 0) {  // row-tiled layout (RT == -tw): this workgroup's rows are one contiguous chunk, f fastest
             const double2 *Gt = G + (((size_t)blockIdx.x << m2) * (size_t)RT);
             auto load = [&](int f, int c) -> double2 { return Gt[(size_t)c * RT + f]; };
-            block_fft3<LA, LB, LC, 1>(RT, lds2, load, store);
+            block_fft3<LA, LB, LC, 1, KC>(RT, lds2, load, store, 1, steps);
         } else {
             auto load = [&](int f, int c) -> double2 {
                 return G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))];
             };
-            block_fft3<LA, LB, LC, 2>(RT, lds2, load, store, tw);
+            block_fft3<LA, LB, LC, 2, KC>(RT, lds2, load, store, tw, steps);
         }
         __syncthreads();
     }
