@@ -575,12 +575,14 @@ def main():
             if method == "fast":
                 nfft = 1 << int(np.ceil(np.log2(5 * M)))
                 n2 = 1 << (int(np.log2(nfft)) // 2)
-                fused_spread = False   # the extirpolation is its own kernel (lsf_spread_owner_kernel), its output is real traffic
+                # the extirpolation is its own kernel (lsf_spread_owner_kernel) and its output is real traffic, unless the opt-in
+                # fused path is on (LK_LSF_FUSED_SPREAD=1: the spread grid is never materialised)
+                fused_spread = os.environ.get("LK_LSF_FUSED_SPREAD", "0") == "1"
                 used = 0.0   # grid rows that can hold samples: written by the spreader and read by FFT step 1
                 for b in range(B):
                     span = (t[off[b + 1] - 1] - t[off[b]]) * nfft * df
                     used += 2 * min(nfft, (int((span + 4) / n2) + 1) * n2) + min(nfft, (int((2 * span + 4) / n2) + 1) * n2)
-                algo = B * (3 * nfft * 16.0 * 2 + 8.0 * M) + used * 16.0 * 2 + 40.0 * float(off[-1])
+                algo = B * (3 * nfft * 16.0 * 2 + 8.0 * M) + (0.0 if fused_spread else used * 16.0 * 2) + 40.0 * float(off[-1])
                 r01 = B * (3 * nfft * 16.0 * 2 + 3 * M * 16.0 * 2 + 8.0 * M) + 16.0 * float(off[-1])
                 tr = traffic_all.get("ls_fast")
                 rl = {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
                                                         double *__restrict__ w_out, double *__restrict__ wy_out,
                                                         FastStats *__restrict__ stats, double df, int nfft, int m2,
                                                         int *__restrict__ rows_used, int *__restrict__ spread_tab,
-                                                        int ntab) {
+                                                        int ntab, int *__restrict__ tab16 = nullptr, int ntab16 = 0) {
     __shared__ double sh[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
@@ -120,6 +120,25 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
                 if ((double)k * W - 4.0 > pl) lo_tab[k] = (int)n;
                 if ((double)k * W + 3.0 > pl) hi_tab[k] = (int)n;
             }
+        }
+    }
+    if (tab16) {
+        // Fine table for the extirpolation fused into the pruned column kernel: per grid g and 16-cell group G,
+        // tab16[G] = first cadence with position >= 16 G - 4 (ordered targets).  A tile row then knows its cadences without
+        // any search: [tab16[G], tab16[G + 2]) covers every stencil that reaches cells [16 G, 16 G + 16).
+        int *tb = tab16 + (size_t)b * 3 * ntab16;
+        for (int g = 0; g < 3; ++g) {
+            const double dff = df * (g == 2 ? 2.0 : 1.0);
+            int *tg = tb + (size_t)g * ntab16;
+            for (int64_t i = tid; i < n; i += 256) {
+                const double p = fmod((t[lo + i] - t0) * (double)nfft * dff, (double)nfft);
+                const double pp = i > 0 ? fmod((t[lo + i - 1] - t0) * (double)nfft * dff, (double)nfft) : -1e300;
+                const long long k0 = i > 0 ? (long long)floor((pp + 4.0) / 16.0) + 1 : 0, k1 = (long long)floor((p + 4.0) / 16.0);
+                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab16 - 1); ++k) tg[k] = (int)i;
+            }
+            const double pl = fmod((t[lo + n - 1] - t0) * (double)nfft * dff, (double)nfft);
+            for (int k = tid; k < ntab16; k += 256)
+                if ((double)k * 16.0 - 4.0 > pl) tg[k] = (int)n;
         }
     }
     const double y0 = y[lo];
@@ -613,10 +632,21 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double
 // k1' = s P + q; the row kernel undoes the permutation), perm == 0 keeps the natural row order k1 = Q q + s.
 constexpr int PRUNED_CT = 16;
 
+// Arguments of the extirpolation when it is fused into the pruned column kernel (t == nullptr: not fused, the kernel
+// reads the grids lsf_spread_owner_kernel wrote).
+struct SpreadArgs {
+    const double *t, *w, *wy;
+    const int64_t *n_off;
+    const FastStats *stats;
+    const int *tab16;  // lsf_prep_kernel's per-16-cell table: first cadence with position >= 16 G - 4
+    int b0, ntab16, nfft, fit_mean;
+    double f0, df;
+};
+
 template <int LP>
 __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols_pruned_kernel(
     const double2 *__restrict__ grids, int m1, int m2, const int *__restrict__ rows_used, double2 *__restrict__ gout,
-    int perm, int tpad) {
+    int perm, int tpad, SpreadArgs sa) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, P = 1 << LP, LDT = Bq + 1, FST = A * LDT + 1;
     constexpr int CT = PRUNED_CT;
@@ -633,7 +663,80 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
     const bool p1 = jk < Bq, p2 = jk < A;
     const double invN1 = 1.0 / (double)N1, invN = 1.0 / (double)((size_t)1 << (m1 + m2));
     double2 xin[A];
-    if (p1) {
+    if (sa.t != nullptr) {
+        // ---- fused extirpolation (ordered targets: grid position grows with the cadence index).  The tile's inputs are
+        // 16 cells of each of the P live rows: thread r builds row r's 16 cells in LDS from the few cadences whose 4-point
+        // stencils reach them — found through the prep kernel's per-1024-cell tables and a short binary search — adding
+        // in cadence order (deterministic, unlike the LDS atomics of lsf_spread_owner_kernel).  The spread grid, 81 %
+        // zeros, is never written to or read from HBM: that was 13 % of the step's bytes and two launches per chunk.
+        const int lb = blockIdx.y / 3, g = blockIdx.y - 3 * lb, b = sa.b0 + lb;
+        const int64_t lo = sa.n_off[b];
+        const double *tt = sa.t + lo, *amp = (g == 0 ? sa.wy : sa.w) + lo;
+        const double t0 = sa.stats[b].t0, fac = g == 2 ? 2.0 : 1.0, dff = sa.df * fac, f0f = sa.f0 * fac;
+        const double dn = (double)sa.nfft;
+        const int *tg = sa.tab16 + ((size_t)b * 3 + g) * sa.ntab16;
+        const bool unused = g == 1 && !sa.fit_mean;
+        for (int r = tid; r < P; r += (int)blockDim.x) {
+            double2 *cells = lds2 + (size_t)r * 17;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) cells[j] = make_double2(0.0, 0.0);
+            if (r < ru && !unused) {
+                const int nA = r * N2 + c0, G16 = nA >> 4;
+                const double xhi = (double)nA + 19.0;
+                // candidates: positions in [nA - 4, nA + 28): no search, a handful of cadences, loads issued four at a time
+                const int i_lo = tg[G16], i_hi = tg[min(G16 + 2, sa.ntab16 - 1)];
+                for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
+                    double tdv[4], av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = min(i0 + u, i_hi - 1);
+                        tdv[u] = tt[i] - t0;
+                        av[u] = amp[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (i0 + u >= i_hi) break;
+                        const double td = tdv[u];
+                        double x = td * dn * dff;
+                        if (!(x < dn)) x = fmod(x, dn);  // ordered targets never wrap: the fmod of the reference is the identity
+                        if (x >= xhi) break;
+                        double c = 1.0, sn = 0.0;
+                        if (f0f > 0.0) sincos(6.283185307179586 * f0f * td, &sn, &c);
+                        const double hr = av[u] * c, hi = av[u] * sn;
+                        auto add = [&](int cell, double vr, double vi) {
+                            const int j = cell - nA;
+                            if (j >= 0 && j < CT) {
+                                double2 v = cells[j];
+                                v.x += vr;
+                                v.y += vi;
+                                cells[j] = v;
+                            }
+                        };
+                        if (x == floor(x)) {  // fmod(x, 1) == 0
+                            add((int)x, hr, hi);
+                        } else {  // astropy extirpolate, M = 4 (same arithmetic as extirpolate4 above)
+                            int ilo = (int)(x - 2.0);
+                            ilo = min(max(ilo, 0), sa.nfft - 4);
+                            const double d0 = x - (double)ilo, d1 = d0 - 1.0, d2 = d0 - 2.0, d3 = d0 - 3.0;
+                            const double prod = ((d0 * d1) * d2) * d3;
+                            const double nr = hr * prod, ni = hi * prod;
+                            const double q3 = 6.0 * d3, q2 = -2.0 * d2, q1 = 2.0 * d1, q0 = -6.0 * d0;
+                            add(ilo + 3, nr / q3, ni / q3);
+                            add(ilo + 2, nr / q2, ni / q2);
+                            add(ilo + 1, nr / q1, ni / q1);
+                            add(ilo, nr / q0, ni / q0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (p1) {
+#pragma unroll
+            for (int i = 0; i < A; ++i) xin[i] = lds2[(size_t)(i * Bq + jk) * 17 + f];
+        }
+        __syncthreads();  // the exchange tile of the passes below reuses this LDS
+    } else if (p1) {
 #pragma unroll
         for (int i = 0; i < A; ++i) {
             const int r = i * Bq + jk;
@@ -1359,8 +1462,9 @@ __global__ __launch_bounds__(256) void lsf_plan_kernel(const int *__restrict__ r
 
 template <int LP>
 static void launch_cols_pruned_t(int m1, int m2, int ngrids, const double2 *grids, const int *rows_used, double2 *gout,
-                                 int perm, int tpad, hipStream_t stream) {
+                                 int perm, int tpad, const SpreadArgs &sa, hipStream_t stream) {
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, LDT = Bq + 1, FST = A * LDT + 1;
+    static_assert(PRUNED_CT * FST >= (1 << LP) * 17, "the exchange tile must hold the fused spreader's P x 17 input cells");
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_pruned_kernel<LP>),
@@ -1368,16 +1472,16 @@ static void launch_cols_pruned_t(int m1, int m2, int ngrids, const double2 *grid
         attr = true;
     }
     hipLaunchKernelGGL((fft_cols_pruned_kernel<LP>), dim3((1 << m2) / PRUNED_CT, ngrids), dim3(PRUNED_CT * A),
-                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout, perm, tpad);
+                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout, perm, tpad, sa);
 }
 
 static bool launch_cols_pruned(int lp, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
-                               double2 *gout, int perm, int tpad, hipStream_t stream) {
+                               double2 *gout, int perm, int tpad, const SpreadArgs &sa, hipStream_t stream) {
     switch (lp) {
-        case 5: launch_cols_pruned_t<5>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
-        case 6: launch_cols_pruned_t<6>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
-        case 7: launch_cols_pruned_t<7>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
-        case 8: launch_cols_pruned_t<8>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, stream); return true;
+        case 5: launch_cols_pruned_t<5>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
+        case 6: launch_cols_pruned_t<6>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
+        case 7: launch_cols_pruned_t<7>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
+        case 8: launch_cols_pruned_t<8>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
         default: return false;
     }
 }
@@ -1423,7 +1527,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const size_t pad_elems = ((size_t)(nfft >> m1) / PRUNED_CT + 1) * (size_t)tpad_env;
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
                            (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * pad_elems * 16 + (size_t)Bc * 3 * M * 16 +
-                           (size_t)B * 16 + (size_t)B * 6 * ((nfft + 1023) / 1024 + 2) * 4 + 16384);
+                           (size_t)B * 16 + (size_t)B * 6 * ((nfft + 1023) / 1024 + 2) * 4 + (size_t)B * 3 * (nfft / 16 + 2) * 4 + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
@@ -1464,8 +1568,16 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const bool tab_env = getenv("LK_LSF_TABLES") ? atoi(getenv("LK_LSF_TABLES")) != 0 : true;
     const int ntab = (nfft + SPREAD_W - 1) / SPREAD_W + 2;
     int *d_tab = (reg_path && tab_env) ? (int *)h->ws.alloc((size_t)B * 6 * ntab * 4) : nullptr;
+    // Fused extirpolation (LK_LSF_FUSED_SPREAD=1, off by default): measured 13.55 ms against 13.49 ms per 1000 targets —
+    // the column kernel grows by 93 us per launch (sincos and four divisions per cadence visit next to the FFT's own fp64
+    // work), the separate spreader's 100 us were mostly hidden behind its neighbours, and the prep kernel pays 0.3 ms for
+    // the fine table.  It would start to pay with the phases precomputed per cadence and the Lagrange weights formed
+    // without divisions; until then the separate spreader stays.
+    static const bool fuse_env = getenv("LK_LSF_FUSED_SPREAD") && atoi(getenv("LK_LSF_FUSED_SPREAD")) == 1;
+    const int ntab16 = nfft / 16 + 2;
+    int *d_tab16 = (d_tab && fuse_env && nfft >= 4096) ? (int *)h->ws.alloc((size_t)B * 3 * ntab16 * 4) : nullptr;
     hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
-                       d_w, d_wy, d_stats, df, nfft, m2, d_rows, d_tab, ntab);
+                       d_w, d_wy, d_stats, df, nfft, m2, d_rows, d_tab, ntab, d_tab16, ntab16);
     // ---- plan: the pruned column kernel applies when every grid of every target keeps its samples in the first
     // P <= 256 rows (P < N1) and the row kernel can read 16-column tiles.  The decision needs one device word, so
     // the call synchronises `stream` once here (20-30 us against a >= 1 ms step).
@@ -1482,10 +1594,13 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         const int want = std::max(5, ilog2_ceil(std::max(1, max_rows)));
         if (want <= 8 && want < m1) lp = want;
     }
+    // ---- fused extirpolation (opt-in, see above): every target ordered (h_plan[1] = number of unordered ones), the pruned
+    // column kernel in use and the fine table built -> no spread grid at all
+    const bool fused_spread = lp != 0 && d_tab16 != nullptr && h->h_plan[1] == 0 && PRUNED_CT == 16 && N2 % PRUNED_CT == 0;
     // ---- two streams: the spreader of chunk k+1 (LDS atomics, latency bound) runs on h->s_aux under the FFT kernels
     // of chunk k (HBM / VALU bound) on the caller's stream; the spread grids are double buffered, events order the
     // hand-overs.  All s_aux work is consumed through events by `stream`, so the caller still sees one stream.
-    const bool two_streams = fused && streams_env && B > Bc;
+    const bool two_streams = fused && streams_env && B > Bc && !fused_spread;
     double2 *d_gridsB = nullptr;
     if (two_streams) {
         d_gridsB = (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16);
@@ -1507,6 +1622,15 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         double2 *gr = buf ? d_gridsB : d_grids;
         hipStream_t ss = two_streams ? h->s_aux : stream;  // the spreader's stream
         if (two_streams && chunk >= 2) LK_HIP_CHECK(hipStreamWaitEvent(ss, ev_cols[buf], 0));  // chunk-2's step 1 has read gr
+        if (fused_spread) {
+            const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power};
+            const SpreadArgs sa{t, d_w, d_wy, d_off, d_stats, d_tab16, b0, ntab16, nfft, fit_mean, f0, df};
+            LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, perm_env, tpad_env, sa, stream),
+                       "no pruned column kernel for 2^%d rows", lp);
+            LK_REQUIRE(launch_rows_power(m1, m2, nb, d_grids2, fa, PRUNED_CT, stream, perm_env ? lp : 0, tpad_env),
+                       "no step-2 kernel for this layout");
+            continue;
+        }
         if (reg_path) {
             hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, ss, gr, m1, m2,
                                d_rows + (size_t)b0 * 4);
@@ -1529,7 +1653,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             if (fused) {
                 // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
                 if (lp) {
-                    LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, perm_env, tpad_env, stream),
+                    LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, perm_env, tpad_env, SpreadArgs{}, stream),
                                "no pruned column kernel for 2^%d rows", lp);
                 } else {
                     launch_cols_reg(m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);

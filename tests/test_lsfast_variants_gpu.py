@@ -154,3 +154,26 @@ def test_peaks_dev_entry_point_matches_host_path():
         assert relmax(d_p[b], ref[b]) < 1e-12
     assert np.array_equal(d_a, np.nanargmax(ref, axis=1))
     assert np.array_equal(d_m, np.nanmax(ref, axis=1))
+
+
+def test_fused_extirpolation_opt_in_matches_default(tmp_path):
+    """LK_LSF_FUSED_SPREAD=1 (the extirpolation inside the pruned column kernel, search-free through the per-16-cell
+    table; read once per process, hence the subprocess) against the default path with the separate spreader."""
+    import subprocess
+    import sys
+    B, N, M = 5, 20000, 100000
+    t, y, dy, off = _batch(B, N)
+    df = 360.0 / M
+    ref = _capi.ls_fast_batch(t, y, off, dy=dy, f0=df, df=df, M=M, normalization="lk_amplitude")
+    inp, outp = str(tmp_path / "in.npz"), str(tmp_path / "out.npy")
+    np.savez(inp, t=t, y=y, dy=dy, off=off)
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from lightkurve_amd import _capi; d = np.load(%r); "
+            "p = _capi.ls_fast_batch(d['t'], d['y'], d['off'], dy=d['dy'], f0=%r, df=%r, M=%d, normalization='lk_amplitude'); "
+            "np.save(%r, p)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), inp, df, df, M, outp))
+    envv = dict(os.environ, LK_LSF_FUSED_SPREAD="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=envv, timeout=600)
+    fused = np.load(outp)
+    for b in range(B):
+        assert relmax(fused[b], ref[b]) < 1e-12, b
+    port = O.ls_power_fast(t[off[0]:off[1]], y[off[0]:off[1]], dy[off[0]:off[1]], df, df, M, normalization="lk_amplitude")
+    assert relmax(fused[0], port) < TOL
