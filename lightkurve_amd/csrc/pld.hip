@@ -60,19 +60,22 @@ __global__ __launch_bounds__(256) void pld_ratio_kernel(const float *__restrict_
     __shared__ float div[ROWS];
     const int b = blockIdx.y, n0 = blockIdx.x * ROWS, tid = threadIdx.x;
     const int nr = min(ROWS, N - n0);
-    if (tid < nr) {
-        float d = 1.0f;
-        if (mode == 1) d = lc[(size_t)b * N + n0 + tid];
-        if (mode == 2) {
-            const float *row = pix + ((size_t)b * N + n0 + tid) * P;
+    if (mode == 2) {
+        // np.nansum over the float32 pixels of a cadence (accumulated in double, rounded once: <= 1 ulp(f32) from numpy's
+        // pairwise float32 sum).  A wave per cadence, lanes over pixels; the per-lane partials are added in lane order.
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int r = wave; r < nr; r += 4) {
+            const float *row = pix + ((size_t)b * N + n0 + r) * P;
             double sm = 0.0;
-            for (int p = 0; p < P; ++p) {
+            for (int p = lane; p < P; p += 64) {
                 const float v = row[p];
                 if (v == v) sm += (double)v;
             }
-            d = (float)sm;  // np.nansum over float32 pixels (rounded once instead of pairwise: <= 1 ulp(f32) apart)
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            if (lane == 0) div[r] = (float)sm;
         }
-        div[tid] = d;
+    } else if (tid < nr) {
+        div[tid] = mode == 1 ? lc[(size_t)b * N + n0 + tid] : 1.0f;
     }
     __syncthreads();
     const size_t base = ((size_t)b * N + n0) * P;
@@ -145,24 +148,30 @@ __global__ __launch_bounds__(1024) void pld_products_mean_kernel(const double *_
     if (g == 0 && idx < Pc) mean[(size_t)b * Pc + idx] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / (double)N;
 }
 
+constexpr int PP_ROWS = 16;  // cadences per workgroup of the products kernel
 __global__ __launch_bounds__(256) void pld_products_kernel(const double *__restrict__ X, int ldx, int col0, int k, int order,
                                                             int N, int Pc, const uint8_t *__restrict__ comb,
                                                             const double *__restrict__ mean, double *__restrict__ out) {
-    __shared__ double us[4][64];
-    const int b = blockIdx.y, n0 = blockIdx.x * 4;
-    for (int e = threadIdx.x; e < 4 * k; e += 256) {
+    // 16 cadences per workgroup: a product's factor indices and mean are fetched once per 16 outputs (the 4-row version
+    // spent more on those fetches than on the 3.6 GB it writes: 3.2 ms against 0.6 ms of HBM time at P = 816)
+    __shared__ double us[PP_ROWS][65];
+    const int b = blockIdx.y, n0 = blockIdx.x * PP_ROWS;
+    for (int e = threadIdx.x; e < PP_ROWS * k; e += 256) {
         const int r = e / k, c = e - r * k;
         us[r][c] = n0 + r < N ? X[((size_t)b * N + n0 + r) * ldx + col0 + c] : 0.0;
     }
     __syncthreads();
+    const int nr = min(PP_ROWS, N - n0);
     for (int idx = threadIdx.x; idx < Pc; idx += 256) {
         int a[4] = {0, 0, 0, 0};
         for (int pos = 0; pos < order; ++pos) a[pos] = comb[idx * order + pos];
         const double m = mean[(size_t)b * Pc + idx];
-        for (int r = 0; r < 4 && n0 + r < N; ++r) {
+        double *o = out + ((size_t)b * N + n0) * Pc + idx;
+#pragma unroll 4
+        for (int r = 0; r < nr; ++r) {
             double prod = us[r][a[0]];
             for (int pos = 1; pos < order; ++pos) prod *= us[r][a[pos]];
-            out[((size_t)b * N + n0 + r) * Pc + idx] = prod - m;
+            o[(size_t)r * Pc] = prod - m;
         }
     }
 }
@@ -1131,7 +1140,7 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
             LK_HIP_CHECK(hipStreamSynchronize(stream));  // comb dies at the end of this iteration
             hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(1024), 0, stream, X, K, col1, k1, o,
                                N, Pc, d_comb, d_mean);
-            hipLaunchKernelGGL(pld_products_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc,
+            hipLaunchKernelGGL(pld_products_kernel, dim3((N + PP_ROWS - 1) / PP_ROWS, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc,
                                d_comb, d_mean, A);
             rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws, true, true);
             if (rc) return rc;

@@ -557,6 +557,9 @@ __global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__
     const int i0 = bi * G2_BLK, j0 = bj * G2_BLK;
     const bool diag = bi == bj;
     const bool idle = diag && wi > wj;  // strictly-lower 64 x 64 sub-block of a diagonal block
+    // 16-wide tiles of this wave that hold real columns (the last 128-block of K = 816 has 48 of 128): the others are
+    // skipped — wave-uniform, so these are scalar branches around whole MFMAs
+    const int na_live = min(4, max(0, (K - (i0 + wi * 64) + 15) >> 4)), nb_live = min(4, max(0, (K - (j0 + wj * 64) + 15) >> 4));
     double4_t acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__
         }
         __syncthreads();
         fetch(n0 + G2_RC);  // in flight while the matrix cores work (past the end: clamped, masked, unused)
-        if (!idle) {
+        if (!idle && na_live > 0 && nb_live > 0) {
 #pragma unroll
             for (int kk = 0; kk < G2_RC; kk += 4) {
                 const int kr = kk + (lane >> 4), cc = lane & 15;
@@ -627,7 +630,8 @@ __global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                        if (a < na_live && b < nb_live)
+                            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
             }
         }
     }
