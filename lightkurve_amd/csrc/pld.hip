@@ -367,6 +367,7 @@ struct EigCtx {
     int order;                          // LDS: l ints (offset in doubles)
     double *Gb;                         // this matrix (global, leading dimension ldg)
     int ldg, P, k, l, ld;
+    int kc;                             // rows of the basis per LDS stage of eig_cq (a multiple of 8)
 };
 #define LK_EIG_LDS extern __shared__ __attribute__((aligned(16))) double lds_dyn[]
 // likewise the global operands: as plain pointer arguments they would be read with flat loads
@@ -512,7 +513,7 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
     constexpr int NT = NA <= 2 ? 4 : 2;
     typedef double bvec __attribute__((ext_vector_type(NT)));
     typedef __attribute__((address_space(1))) const bvec cgbvec;
-    const int ngrp = (P + 16 * NT - 1) / (16 * NT), nsteps = (P + 3) >> 2;
+    const int ngrp = (P + 16 * NT - 1) / (16 * NT), nsteps = (P + 3) >> 2, KC = c.kc;
     for (int gbase = 0; gbase < ngrp; gbase += nwv) {
         const int grp = gbase + wave;
         const bool active = grp < ngrp;
@@ -531,14 +532,14 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
 #pragma unroll
             for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
         bvec b0 = load_b(0), b1 = load_b(1);
-        for (int k0 = 0; k0 < P; k0 += PLD_KC) {
+        for (int k0 = 0; k0 < P; k0 += KC) {
             __syncthreads();
-            for (int e = tid; e < PLD_KC * 16 * na; e += nt) {
+            for (int e = tid; e < KC * 16 * na; e += nt) {
                 const int kk = e / (16 * na), a = e - kk * (16 * na);
                 qstage[kk * PLD_QS + a] = (k0 + kk < P && a < l) ? src[(size_t)(k0 + kk) * l + a] : 0.0;
             }
             __syncthreads();
-            const int s_lo = k0 >> 2, s_hi = min(nsteps, (k0 + PLD_KC) >> 2);
+            const int s_lo = k0 >> 2, s_hi = min(nsteps, (k0 + KC) >> 2);
             for (int st = s_lo; st < s_hi; st += 2) {  // PLD_KC is a multiple of 8: step st + 1 stays inside the stage
                 const bvec c0 = b0, c1 = b1;
                 b0 = load_b(st + 2);
@@ -699,7 +700,7 @@ template <int NA>
 __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__ G, int ldg, int P, int k, int l, int npow,
                                                              double *__restrict__ scratch, double *__restrict__ V,
                                                              double *__restrict__ lam, long long *__restrict__ iters_out,
-                                                             int max_it, int *__restrict__ status, int cheb_on) {
+                                                             int max_it, int *__restrict__ status, int cheb_on, int kc) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     double *Gb = G + (size_t)b * ldg * ldg;
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
 
     // ---- subspace iteration with Rayleigh-Ritz steps
     double *Q = scratch + (size_t)b * 4 * P * l, *Z = Q + (size_t)P * l, *R = Z + (size_t)P * l, *Y = R + (size_t)P * l;
-    const EigCtx ctx{oT, oW, orot, oshred, ovec, oqstage, oorder, Gb, ldg, P, k, l, ld};
+    const EigCtx ctx{oT, oW, orot, oshred, ovec, oqstage, oorder, Gb, ldg, P, k, l, ld, kc};
     long long tprof[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = iters_out ? (long long)wall_clock64() : 0;
     auto lap = [&](int slot) {  // debug (LK_PLD_ITERS=1): per-phase 100 MHz ticks
         if (iters_out) {
@@ -1019,15 +1020,17 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         // wave, the random start) overlap the other's stream through C — 97.2 -> 86.6 ms per PLD step against one
         // 1024-thread workgroup per CU (LK_PLD_EIG_NT=1024)
         static const int nt_env = getenv("LK_PLD_EIG_NT") ? atoi(getenv("LK_PLD_EIG_NT")) : 512;
-        const int nt_sub = (nt_env == 512 || nt_env == 1024) ? nt_env : 1024;
-        const size_t lds = ((size_t)2 * l * ld + 2 * l + nt_sub + 2 * l + (l + 1) / 2 + 1 + PLD_KC * PLD_QS) * 8 + 64;
+        int nt_sub = (nt_env == 256 || nt_env == 512 || nt_env == 1024) ? nt_env : 512;
+        if (nt_sub == 256 && l > 32) nt_sub = 512;  // 16 partial tiles of eig_xty need the 64-row stage
+        const int kc = nt_sub == 256 ? 32 : PLD_KC;  // LDS stage rows: the stage also holds eig_xty's (nt / 64) x 2 KB of partial tiles
+        const size_t lds = ((size_t)2 * l * ld + 2 * l + nt_sub + 2 * l + (l + 1) / 2 + 1 + kc * PLD_QS) * 8 + 64;
         long long *d_it = dbg_iters ? (long long *)ws.alloc((size_t)B * 64) : nullptr;
         if (l <= 32)
             hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc);
         else
             hipLaunchKernelGGL(pld_topk_eig_kernel<4>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc);
         if (d_it) {
             std::vector<long long> hit((size_t)B * 8);
             LK_HIP_CHECK(hipMemcpyAsync(hit.data(), d_it, (size_t)B * 64, hipMemcpyDeviceToHost, stream));
@@ -1059,7 +1062,7 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         const size_t lds = two_pass ? ((size_t)l * ld + 2 * l + nt_eig + 2 * l + (l + 1) / 2 + 1) * 8 + 64
                                     : ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1) * 8 + 64;
         hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_eig), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                           (long long *)nullptr, 400, status, cheb_on);
+                           (long long *)nullptr, 400, status, cheb_on, PLD_KC);
     }
     {
         const dim3 grid((N + 63) / 64, B), blk(256);
