@@ -228,13 +228,16 @@ def cpu_baseline_pld(args):
     allm = np.ones((11, 11), bool)
     t0 = time.perf_counter()
     n = 2
+    kept = []
     for i in range(n):
         t, flux, err, _ = synth.pld_cutout(4, i, n=args.pld_cadences, npix=11)
-        O.pld_correct(t, flux, err, allm, allm, allm, pld_order=3, pca_components=16, spline_degree=5)
+        r = O.pld_correct(t, flux, err, allm, allm, allm, pld_order=3, pca_components=16, spline_degree=5)
+        kept.append((np.asarray(r["corrected"]), np.asarray(r["outlier_mask"])))
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "cutouts/sec", "cores": 1, "kind": "port",
             "sample": "%d cutouts 11x11 x %d cadences, order 3, 16 PCA comps, numpy port (LAPACK may thread)"
-                      % (n, args.pld_cadences)}
+                      % (n, args.pld_cadences),
+            "_results": kept}   # popped before the JSON line: the accuracy block compares the GPU path with these
 
 
 def cpu_baseline_flatten(args):
@@ -243,11 +246,11 @@ def cpu_baseline_flatten(args):
     n = 8
     lcs = [synth.ls_target(6, i, args.cadences) for i in range(n)]
     t0 = time.perf_counter()
-    for t, y, e, _ in lcs:
-        O.flatten_trend(t, y, 401, 2, 5, 3, 3)
+    kept = [O.flatten_trend(t, y, 401, 2, 5, 3, 3)[0] for t, y, e, _ in lcs]
     dt = time.perf_counter() - t0
     return {"value": n * args.cadences / dt, "unit": "cadences/sec", "cores": 1, "kind": "port",
-            "sample": "%d light curves x %d cadences, window 401, numpy port of LightCurve.flatten" % (n, args.cadences)}
+            "sample": "%d light curves x %d cadences, window 401, numpy port of LightCurve.flatten" % (n, args.cadences),
+            "_results": kept}   # popped before the JSON line: the accuracy block compares the GPU trends with these
 
 
 def cpu_baseline_lschi2(args):
@@ -749,6 +752,18 @@ def main():
 
         dt, kern_ms = timed(step, args.warmup, args.steps)
         units_per_step = Bc * world
+        if cpu_base is not None and "_results" in cpu_base:
+            # accuracy at the FULL config shape: the product path (PLDCorrector mirror: design matrix, regression, restored
+            # trend) on the cutouts the numpy/LAPACK port just corrected
+            from lightkurve_amd.correctors.pldcorrector import PixelCube, pld_correct_batch
+            kept = cpu_base.pop("_results")
+            cubes2 = [PixelCube(cubes[i][0], cubes[i][1], cubes[i][2], mission="K2") for i in range(len(kept))]
+            corr, outl = pld_correct_batch(cubes2, pld_order=3, pca_components=16)
+            relerr = [float(np.max(np.abs(corr[i] - kept[i][0])) / np.median(kept[i][0])) for i in range(len(kept))]
+            extra["accuracy"] = {"reference": "numpy/LAPACK port of PLDCorrector.correct (exact SVD), %d cutouts 11x11 x %d "
+                                              "cadences, order 3, 16 components" % (len(kept), Nc),
+                                 "corrected_flux_relerr_max": max(relerr),
+                                 "outlier_masks_equal": "%d/%d" % (sum(int(np.array_equal(outl[i], kept[i][1])) for i in range(len(kept))), len(kept))}
         gram_cols = [P, 136, 816, P]
         # MFMA flop: the four PCA Grams + ONE regression Gram (the clip loop stops at its fixed point: later passes that
         # would repeat the same fit are not executed, so they are not counted either)
@@ -780,6 +795,16 @@ def main():
 
         dt, kern_ms = timed(step, args.warmup, args.steps)
         units_per_step = int(off[-1]) * world
+        if cpu_base is not None and "_results" in cpu_base and first == 0:
+            kept = cpu_base.pop("_results")   # the port's trends of the first light curves of this batch, full config shape
+            tr = d_tr.cpu().numpy()
+            rel = []
+            for i, ref_tr in enumerate(kept[:B]):
+                mine = tr[off[i]:off[i + 1]]
+                okm = np.isfinite(ref_tr)
+                rel.append(float(np.max(np.abs(mine[okm] - ref_tr[okm]) / np.abs(ref_tr[okm]))) if np.array_equal(okm, np.isfinite(mine)) else float("inf"))
+            extra["accuracy"] = {"reference": "numpy port of LightCurve.flatten (scipy savgol semantics), %d light curves x %d "
+                                              "cadences, window 401" % (len(rel), N), "trend_relerr_max": max(rel)}
         metric, unit = "flatten cadences/sec (window 401, niters 3)", "cadences/sec"
         workload = "flatten: %d light curves x %d cadences, window 401, polyorder 2, niters 3 per GPU" % (B, N)
         algo = 24.0 * float(off[-1])
@@ -926,7 +951,7 @@ def main():
             out["config"]["ls_method"] = extra.pop("config_ls_method")
         out.update(extra)
         if cpu_base is not None:
-            out["cpu_baseline"] = cpu_base
+            out["cpu_baseline"] = {k: v for k, v in cpu_base.items() if not k.startswith("_")}
             out["speedup_vs_cpu_baseline"] = value / cpu_base["value"]
         print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)))
     if dist_on:
