@@ -263,6 +263,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
 
     double dmed_prev = qnan, dspacing = 0.0;  // previous iteration's median dt and the mean gap between dt values around it
     int nm_prev = 0;
+    int removed_any = 1;
     for (int it = 0; it < niters; ++it) {
         const bool last = it == niters - 1;
         lap_iter = it;
@@ -575,17 +576,23 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             const double sd = sqrt(block_sum_fast(part, shd) / (double)nm);
             const double lim = sd * sigma + 1e-14;
             // mask1, and mask[mask] &= mask1 (:1060-1063) in the same sweep
+            int removed = 0;
             strided_pass<8>(nm, resid, [&](int i, double r) {
                 const bool keepit = fabs(r) < lim;
                 mask1[i] = keepit ? 1 : 0;
-                if (!keepit) mask[idx[i]] = 0;
+                if (!keepit) {
+                    mask[idx[i]] = 0;
+                    removed = 1;
+                }
             });
-            __syncthreads();
+            removed_any = __syncthreads_or(removed);
             lap(9);
         }
         // ---- linear interpolation / extrapolation of the kept trend onto every cadence   (:1053-1058).  The reference
-        // recomputes it in every iteration and keeps the last one; only the last one is computed here.
-        if (!last) continue;
+        // recomputes it in every iteration and keeps the last one; only the last one is computed here — the last one
+        // being either iteration niters - 1 or the first iteration that clipped nothing (the mask, hence every later
+        // iteration, would repeat exactly).
+        if (!last && removed_any) continue;
         const int n2 = strip_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
         if (n2 < 2) {
             for (int i = tid; i < N; i += nt) trend[i] = qnan;
@@ -658,6 +665,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         }
         __syncthreads();
         lap(10);
+        if (!removed_any) break;
     }
     if (final_mask)
         for (int i = tid; i < N; i += nt) final_mask[i] = mask[i];
@@ -757,8 +765,9 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     const size_t lds = (size_t)std::max(flat_nt, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)flat_nt * 4;
     static bool attr_set = false;
     if (!attr_set) {
+        // (__syncthreads_or keeps a few bytes of static LDS: the dynamic part may not claim all 160 KB)
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
     }
     const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see the kernel
