@@ -14,7 +14,7 @@ import gzip
 
 import numpy as np
 
-__all__ = ["read_fits_table", "read_fits_image", "FitsTable", "lightcurve_columns", "pixel_columns", "QUALITY_OPTIONS"]
+__all__ = ["read", "read_fits_table", "read_fits_image", "FitsTable", "lightcurve_columns", "pixel_columns", "QUALITY_OPTIONS"]
 
 # reference src/lightkurve/utils.py: KeplerQualityFlags.OPTIONS (:190-195), TessQualityFlags.OPTIONS (:270-275)
 QUALITY_OPTIONS = {
@@ -262,3 +262,20 @@ def pixel_columns(tab, columns=("flux", "flux_err", "flux_bkg"), quality_bitmask
     keep_nan_time = mission != "tess" or bitmask == 0 or quality_bitmask == "none"
     return dict(off_time=ot, code_time=_CODES[lt], off_quality=oq, code_quality=_CODES[lq], bitmask=bitmask,
                 keep_nan_time=keep_nan_time, columns=use, col_offsets=offs, npix=npix, shape=shape, mission=mission)
+
+
+def read(path, quality_bitmask="default", flux_column=None, device=0):
+    """``lightkurve.read(path)`` for local Kepler / K2 / TESS FITS products (reference src/lightkurve/io/read.py:32-145):
+    a target-pixel file (its table's FLUX column is a pixel vector) comes back as a ``PixelCube``, a light-curve file as
+    a ``LightCurve`` — with the reference's quality masking and NaN-time handling, decoded on the GPU.  Remote paths, the
+    community readers (QLP, EVEREST, ...) and FoldedLightCurve files stay with the reference."""
+    tab = read_fits_table(path, ext=1)
+    flux = tab.columns.get("flux")
+    if flux is not None and flux[2] > 1:
+        from .correctors.pldcorrector import PixelCube
+        return PixelCube.from_fits(path, quality_bitmask=quality_bitmask, device=device)
+    from .ingest import LightCurveBatch
+    batch = LightCurveBatch.from_fits([path], flux_column=flux_column, quality_bitmask=quality_bitmask, device=device)
+    lc = batch[0]
+    lc.quality = batch.quality
+    return lc

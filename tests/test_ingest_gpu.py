@@ -122,3 +122,19 @@ def test_fits_files_to_batch_vs_reference_readers(golden):
     # many files: more workgroups than one wave of CUs, records staged through LDS in several trips
     big = LightCurveBatch.from_fits(paths[:3] * 40)
     assert len(big) == 120 and np.array_equal(big[117].time, g["kepler_default_time"])
+
+
+def test_read_dispatches_on_file_type(golden):
+    """lightkurve_amd.read(path): light-curve files -> LightCurve, target-pixel files -> PixelCube (reference io/read.py)."""
+    import os
+    import lightkurve_amd as lka
+    from lightkurve_amd.correctors.pldcorrector import PixelCube
+    g = golden("fits_ingest")
+    fdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fits")
+    lc = lka.read(os.path.join(fdir, "tess_lc.fits"))
+    assert isinstance(lc, LightCurve) and np.array_equal(lc.time, g["tess_default_time"])
+    assert np.array_equal(lc.flux, g["tess_default_flux"], equal_nan=True) and lc.meta["MISSION"] == "TESS"
+    hard = lka.read(os.path.join(fdir, "kepler_llc.fits"), quality_bitmask="hard", flux_column="sap_flux")
+    assert np.array_equal(hard.flux, g["kepler_hard_sap_flux"], equal_nan=True)
+    cube = lka.read(os.path.join(fdir, "kepler_tpf.fits"))
+    assert isinstance(cube, PixelCube) and np.array_equal(cube.flux, g["ktpf_default_flux"], equal_nan=True)
