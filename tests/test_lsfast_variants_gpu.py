@@ -156,9 +156,13 @@ def test_peaks_dev_entry_point_matches_host_path():
     assert np.array_equal(d_m, np.nanmax(ref, axis=1))
 
 
-def test_fused_extirpolation_opt_in_matches_default(tmp_path):
-    """LK_LSF_FUSED_SPREAD=1 (the extirpolation inside the pruned column kernel, search-free through the per-16-cell
-    table; read once per process, hence the subprocess) against the default path with the separate spreader."""
+@pytest.mark.parametrize("envkw", [dict(LK_LSF_FUSED_SPREAD="1"), dict(LK_LSF_ROWS_STREAM="1", LK_FAST_CHUNK_MB="64"),
+                                   dict(LK_FFT3="1")])
+def test_opt_in_variants_match_default(tmp_path, envkw):
+    """The opt-in structures of the default method — LK_LSF_FUSED_SPREAD=1 (the extirpolation inside the pruned column
+    kernel, search-free through the per-16-cell table), LK_LSF_ROWS_STREAM=1 (row transforms of chunk k on a second stream
+    under the column transforms of chunk k + 1; 64-MB chunks = 2 targets each here), LK_FFT3=1 (three-phase row kernel) —
+    against the default path.  The switches are read once per process, hence the subprocess."""
     import subprocess
     import sys
     B, N, M = 5, 20000, 100000
@@ -170,10 +174,9 @@ def test_fused_extirpolation_opt_in_matches_default(tmp_path):
     code = ("import numpy as np, sys; sys.path.insert(0, %r); from lightkurve_amd import _capi; d = np.load(%r); "
             "p = _capi.ls_fast_batch(d['t'], d['y'], d['off'], dy=d['dy'], f0=%r, df=%r, M=%d, normalization='lk_amplitude'); "
             "np.save(%r, p)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), inp, df, df, M, outp))
-    envv = dict(os.environ, LK_LSF_FUSED_SPREAD="1")
-    subprocess.run([sys.executable, "-c", code], check=True, env=envv, timeout=600)
-    fused = np.load(outp)
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **envkw), timeout=600)
+    var = np.load(outp)
     for b in range(B):
-        assert relmax(fused[b], ref[b]) < 1e-12, b
+        assert relmax(var[b], ref[b]) < 1e-12, b
     port = O.ls_power_fast(t[off[0]:off[1]], y[off[0]:off[1]], dy[off[0]:off[1]], df, df, M, normalization="lk_amplitude")
-    assert relmax(fused[0], port) < TOL
+    assert relmax(var[0], port) < TOL
