@@ -837,9 +837,11 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         //    polynomial of degree npow that is bounded by 1 on the unwanted interval [0, theta_cut] and grows fastest
         //    outside it — for theta_k / theta_cut = 1.2 a degree-3 step damps the unwanted part 6.8x instead of the
         //    1.7x of C^3, so the slowly converging blocks need a fraction of the Rayleigh-Ritz steps;
-        //  * steep spectrum: p = C^npow (the Chebyshev factors between the columns would differ by > 1e8 and only
-        //    invite a Cholesky breakdown; these blocks converge in a handful of steps anyway).
-        const bool cheb = (cheb_on & 1) && npow >= 2 && th_cut > 0.0 && th_k < 1.5 * th_cut && th0 < 30.0 * th_cut;
+        //  * steep spectrum: the same filter (option bit 1, default) — the factors between the columns differ by many
+        //    orders of magnitude, but the Cholesky-QR scales the columns to unit length first, and measured it needs 5.0
+        //    steps where p = C^npow (option bit 1 off) needs 7.2.
+        const bool cheb = npow >= 2 && th_cut > 0.0 &&
+                          (((cheb_on & 1) && th_k < 1.5 * th_cut && th0 < 30.0 * th_cut) || (cheb_on & 2));  // bit 1 (LK_PLD_CHEB=2/3): always
         double *src = Y, *dst = Z;
         if (cheb) {
             // x = (C - c) / e with c = e = theta_cut / 2:  X0 = R, X1 = (C R - c R) / e, X_{j+1} = (2/e)(C X_j - c X_j) - X_{j-1}
@@ -972,7 +974,11 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
     // need 12.  (Pixel blocks must NOT do this: their steep spectrum makes C^5 R numerically rank-deficient, the Cholesky
     // breaks down and the iteration stalls.)
     static const int npow_prod = getenv("LK_PLD_POWER_PROD") ? std::max(1, atoi(getenv("LK_PLD_POWER_PROD"))) : 8;
-    static const int cheb_on = getenv("LK_PLD_CHEB") ? (atoi(getenv("LK_PLD_CHEB")) & 1) : 1;  // Chebyshev-filtered steps for flat spectra
+    // Chebyshev-filtered steps: bit 0 = for flat spectra only (round 2's first version), bit 1 = for every spectrum.
+    // Default 3: the degree-3 filter on [0, theta_cut] needs 5.0 Rayleigh-Ritz steps where C^3 needs 7.2 on the 816-column
+    // blocks (4 instead of 5 on the pixel blocks); the feared Cholesky breakdowns on steep spectra do not occur — the
+    // columns are scaled to unit length first and SVQB stands behind — PLD step 83.7 -> 77.7 ms.  LK_PLD_CHEB=1 or 0 to compare.
+    static const int cheb_on = getenv("LK_PLD_CHEB") ? (atoi(getenv("LK_PLD_CHEB")) & 3) : 3;
     static const bool dbg_iters = getenv("LK_PLD_ITERS") && atoi(getenv("LK_PLD_ITERS")) != 0;   // print Rayleigh-Ritz step counts
     static bool attr_set = false;
     if (!attr_set) {
