@@ -19,7 +19,6 @@ optimize/_optimize.py:_minimize_scalar_bounded), which is what the reference cal
 import numpy as np
 
 from .. import _capi
-from ..lightcurve import LightCurve
 from .designmatrix import DesignMatrix, DesignMatrixCollection
 from .metrics import overfit_metric_lombscargle, overfit_metric_lombscargle_batch, underfit_metric_neighbors
 from .regressioncorrector import RegressionCorrector
