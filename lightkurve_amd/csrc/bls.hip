@@ -118,7 +118,9 @@ struct BlsBest {
     int k, n;
 };
 
-__global__ __launch_bounds__(1024) void bls_kernel(
+// amdgpu_waves_per_eu(8, 8): 57 VGPRs without a spill instead of the 66 the allocator takes by itself — the short-period
+// groups then fit 8 workgroups per CU instead of 7 (-1.4 % on configs[3])
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void bls_kernel(
     const double *__restrict__ tm, const double2 *__restrict__ yw,
     const int64_t *__restrict__ n_off, const BlsStats *__restrict__ stats, const double *__restrict__ period,
     const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur,
