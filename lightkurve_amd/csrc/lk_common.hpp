@@ -48,12 +48,6 @@ struct Arena {
     void release();
 };
 
-int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
-                      double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
-                      const double *scale, int oversampling, double *power, hipStream_t stream);
-}  // namespace lk
-
-namespace lk {
 // Ring of pinned host buffers for small asynchronous host->device copies (batch offsets): the caller's buffer is
 // captured before the entry point returns, and the device copy stays ordered on the caller's stream.
 struct HostStage {
@@ -65,9 +59,6 @@ struct HostStage {
     int copy(void *dst, const void *src, size_t bytes, hipStream_t stream);
     void release();
 };
-int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
-                      double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
-                      const double *scale, int oversampling, double *power, hipStream_t stream);
 }  // namespace lk
 
 struct lk_handle {
