@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 
     // ---- pass A: round boundaries.  Wave w sweeps cadences [w*Q, (w+1)*Q) 64 at a time (coalesced loads); the
     //      predecessor's (k, r) comes from the lane below (lane 0: carried from the previous sweep step).
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int Q = (((N + NW - 1) / NW) + 63) & ~63;
     const int w0 = min(wave * Q, N), w1 = min(w0 + Q, N);
     auto sweep = [&](int write_base) -> int {
@@ -296,14 +296,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         __syncthreads();
         // (round, 64-cadence chunk) pairs of this wave are walked as one flat sequence so the next chunk's three
         // global loads are in flight while the current one is folded into the bins
-        double2 *stage = reinterpret_cast<double2 *>(s_best) + (wave << 6);
         int rd = -1, i0 = 0, s1 = 0;  // wave-uniform cursor
         auto advance = [&]() {
             i0 += 64;
             while (i0 >= s1) {
                 if (++rd >= nrounds) return false;
-                i0 = (wave == 0) ? rstart[rd] : segs[nb1 * rd + wave - 1];
-                s1 = (wave == NW - 1) ? rstart[rd + 1] : segs[nb1 * rd + wave];
+                i0 = __builtin_amdgcn_readfirstlane((wave == 0) ? rstart[rd] : segs[nb1 * rd + wave - 1]);
+                s1 = __builtin_amdgcn_readfirstlane((wave == NW - 1) ? rstart[rd + 1] : segs[nb1 * rd + wave]);
             }
             return true;
         };
@@ -330,36 +329,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     c_yw = yw[i0 + lane];
                 }
             }
-            int ind = -1 - lane;  // inactive lanes: unique negatives, never equal to a neighbour
+            // every lane adds its cadence with LDS atomics: same-address lanes of one ds_add_f64 are applied in lane order
+            // (= cadence order) and the wave's LDS instructions run in program order, so the bin sums keep the reference's
+            // order without leader election (tools/microbench/lds_atomic_order.hip; checked again by bls_selftest_kernel)
             if (act) {
                 double k, r;
                 if (tsorted)
                     r = fma(-kcur, P, tv);
                 else
                     fold_exact(tv, P, invP, &k, &r);
-                ind = bin_of_fast(r, bin_duration, inv_bd);
+                const int ind = bin_of_fast(r, bin_duration, inv_bd);
+                atomicAdd(&bins[ind].x, vy);
+                atomicAdd(&bins[ind].y, vi);
             }
-            // lane - 1's bin by a DPP wave shift (no LDS round trip); lane 0 keeps its own value and is a leader anyway
-            const int indp = __builtin_amdgcn_update_dpp(ind, ind, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const bool leader = act && (lane == 0 || ind != indp);
-            // the leader of a run folds the run's members into its bin one by one (reference order); the members'
-            // values are parked in this wave's 64 slots of s_best (free until the final reduction)
-            const unsigned long long lead = __ballot(leader || !act);
-            stage[lane] = make_double2(vy, vi);
-            double2 v = make_double2(0.0, 0.0);
-            if (leader) {
-                const unsigned long long above = lane < 63 ? (lead >> (lane + 1)) : 0ull;
-                const int run = above ? __ffsll((long long)above) : 64 - lane;  // members incl. the leader
-                v = bins[ind];
-                v.x += vy;
-                v.y += vi;
-                for (int c = 1; c < run; ++c) {
-                    const double2 mv = stage[lane + c];
-                    v.x += mv.x;
-                    v.y += mv.y;
-                }
-            }
-            if (leader) bins[ind] = v;
         }
         __syncthreads();
     }
@@ -404,20 +386,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         // LDS read, one dependent add and one LDS write, eight bins in flight
         double acc = 0.0;
         double *comp = reinterpret_cast<double *>(bins) + lane;  // .x for lane 0, .y for lane 1 (stride 2 doubles)
-        int i = 0;
-        for (; i + 8 <= n_bins + 1; i += 8) {
-            double x[8];
+        const int total = n_bins + 1, nfull = total >> 3;
+        double x[8], nx[8];
+        if (nfull > 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = comp[2 * (i + u)];
+            for (int u = 0; u < 8; ++u) x[u] = comp[2 * u];
+        }
+        for (int it = 0; it < nfull; ++it) {  // the next eight bins load while the dependent adds of these eight run
+            double *cp = comp + (it << 4);
+            if (it + 1 < nfull) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nx[u] = cp[16 + 2 * u];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 acc = x[u] + acc;
                 x[u] = acc;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) comp[2 * (i + u)] = x[u];
+            for (int u = 0; u < 8; ++u) cp[2 * u] = x[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = nx[u];
         }
-        for (; i <= n_bins; ++i) {
+        for (int i = nfull << 3; i < total; ++i) {
             acc = comp[2 * i] + acc;
             comp[2 * i] = acc;
         }
@@ -591,6 +582,580 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #undef BLS_LAP
 }
 
+// ------------------------------------------------------------------------------------------------ team kernel
+// One workgroup ("team", NW = 1 .. 16 waves by LDS footprint) per (target, period); everything lives in LDS.
+//
+//   histogram  ONE wave walks the target's cadences in order, four 64-cadence chunks at a time, and every lane adds its
+//              cadence into the bin with an LDS floating-point atomic (ds_add_f64; y*ivar and ivar in two arrays: the
+//              8-byte stride is 1.6 x faster than an interleaved pair).  Same-address lanes of one ds_add_f64 are applied
+//              in increasing lane order and a wave's LDS instructions execute in program order (measured:
+//              tools/microbench/lds_atomic_order.hip; re-checked per handle by bls_selftest_kernel), so every bin
+//              accumulates in cadence order = the reference's order, for sorted and unsorted time alike — no rounds, no
+//              segment searches, no leader election.  Time-sorted targets: the cycle number of a cadence is the running
+//              k0 or k0 + 1, so the phase is one of two exact fused remainders; a quad that contains a longer gap, or a
+//              quotient too close to an integer for the reciprocal multiply, is redone with the general arithmetic.
+//              The other waves of the team sleep at the barrier meanwhile (other teams of the CU fill the SIMDs).
+//   prefix     sequential inclusive sums (lane 0: y, lane 1: ivar), eight bins per step with the next eight loading
+//   scan       all waves; start bins are handed out by an LDS counter (a lane whose walk ends early takes the next start
+//              bin); skip-ahead bound, conservative filter and the reference's exact arithmetic as described on top
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const int lo_ = __builtin_amdgcn_readlane(__double2loint(x), l), hi_ = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi_, lo_);
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The histogram wave handles U chunks of 64 cadences at a time (their arithmetic interleaves: the wave's dependent-issue
+// latency, not its instruction count, is what a lone wave pays) with the global loads of PFG further groups in flight.
+// <2, 2>: the 64-VGPR build for the groups that fit many teams per CU; <4, 2>: 128 VGPRs, long periods that own a CU.
+template <int U, int PFG>
+__device__ __forceinline__ void bls_team_body(
+    const double *__restrict__ tm, const double2 *__restrict__ yw, const int64_t *__restrict__ n_off,
+    const BlsStats *__restrict__ stats, const double *__restrict__ period, const int *__restrict__ pidx, int np_group,
+    int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur, double bin_duration, int oversample,
+    int obj_flag, double *__restrict__ out7, int cap, int ablate, unsigned long long *__restrict__ prof) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long t_last = prof ? wall_clock64() : 0ull;
+#define BLS_LAP(slot_)                                                        \
+    do {                                                                      \
+        if (prof && threadIdx.x == 0) {                                       \
+            const unsigned long long now_ = wall_clock64();                   \
+            atomicAdd(&prof[slot_], now_ - t_last);                           \
+            t_last = now_;                                                    \
+        }                                                                     \
+    } while (0)
+    const unsigned bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const int target = (int)((slot / (unsigned)np_group) * 8u + xcd);
+    if (target >= B) return;
+    const int p = pidx[slot % (unsigned)np_group];
+    const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x, NW = NT >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double P = period[p];
+    const double invP = 1.0 / P;
+    const int n_bins = (int)(ceil(P / bin_duration)) + oversample;
+    const int64_t lo = n_off[target];
+    const int N = (int)(n_off[target + 1] - lo);
+    tm += lo;
+    yw += lo;
+
+    // LDS: duration tables | ya[cap] | wa[cap] | s_thr | s_red[3] | s_ctr (+pad) | s_best[NW] | zm8 | zm64
+    // tables (sorted ascending by length): dur_bins[k] (k = n_dur: a sentinel no window fits), the caller's index
+    // korig[k] (tie-break order) and first_kd[L] = k | dur_bins[k] << 16 for the first k with dur_bins[k] >= L
+    int *dur_bins = reinterpret_cast<int *>(smem);
+    int *korig = dur_bins + n_dur + 1;
+    int *first_kd = korig + n_dur;
+    const int tab_ints = 2 * n_dur + 1 + max_dur + 2;
+    double *ya = reinterpret_cast<double *>(smem + (((size_t)tab_ints * 4 + 15) & ~(size_t)15));
+    double *wa = ya + cap;
+    long long *s_thr = reinterpret_cast<long long *>(wa + cap);
+    long long *s_red = s_thr + 1;                       // gmax, wmax (bit patterns), yabs (double)
+    int *s_ctr = reinterpret_cast<int *>(s_red + 3);    // next start bin of the scan
+    BlsBest *s_best = reinterpret_cast<BlsBest *>(s_red + 5);
+    double *zm8 = reinterpret_cast<double *>(s_best + NW);  // [(n_bins >> 3) + 1] max of Z over aligned blocks of 8 bins
+    double *zm64 = zm8 + (cap >> 3) + 1;                    // [(n_bins >> 6) + 1] ... of 64 bins (Z: see the scan)
+    for (int i = tid; i < tab_ints; i += NT) dur_bins[i] = dur_tab[i];
+    for (int i = tid; i <= n_bins; i += NT) {
+        ya[i] = 0.0;
+        wa[i] = 0.0;
+    }
+    if (tid == 0) {
+        *s_thr = __double_as_longlong(-INFINITY);
+        s_red[0] = s_red[1] = s_red[2] = 0;
+        *s_ctr = 0;
+    }
+    __syncthreads();
+    BLS_LAP(0);  // setup
+
+    // ---- histogram (wave 0)
+    const BlsStats st = stats[target];
+    if (wave == 0 && !(ablate & 1)) {
+        const bool tsorted = st.sorted != 0.0;
+        const double inv_bd = 1.0 / bin_duration;
+        const double guard = 1e-12 * ((double)n_bins + 2.0);  // >= 1e-12 (q + 1) for every quotient of this period
+        const double guard_hi = 1.0 - guard;
+        constexpr int GC = U * 64;  // cadences per group of U chunks
+        double kd0 = 0.0;  // wave-uniform: a cycle number not above that of any cadence still to come (sorted targets)
+        // one group: phases, bins, two atomics per cadence.  `full` (a literal at both call sites): every lane holds a
+        // cadence, so the fast path carries no masks at all.
+        auto do_group = [&](const double(&tv)[U], const double2(&v)[U], int i_base, bool full) {
+            bool act[U];
+            int ind[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) act[u] = full || (i_base + (u << 6) + lane < N);
+            bool bad = false, nxt_last = false;
+            const double kd1 = kd0 + 1.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double r1 = fma(-kd0, P, tv[u]), r2 = fma(-kd1, P, tv[u]);
+                const bool nxt = r1 >= P;
+                const double r = nxt ? r2 : r1;
+                const double q = r * inv_bd;
+                const double f = q - floor(q);
+                ind[u] = (int)q + 1;
+                bad = bad || (act[u] && !(f > guard && f < guard_hi));
+                if (full ? (u == U - 1) : true) bad = bad || (act[u] && nxt && r2 >= P);  // sorted: the last cadence decides
+                if (u == U - 1) nxt_last = nxt;
+            }
+            if (!tsorted || __ballot(bad)) {
+                // general arithmetic: exact (k, r) by fused remainder with +-1 correction, exact division wherever the
+                // reciprocal multiply is within the guard of an integer
+                double k_last = 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    double k, r;
+                    fold_exact(tv[u], P, invP, &k, &r);
+                    ind[u] = bin_of_fast(r, bin_duration, inv_bd);
+                    if (u == U - 1) k_last = k;
+                }
+                kd0 = readlane_f64(k_last, 63);  // only used after a full group
+            } else if (__ballot(nxt_last) >> 63) {
+                kd0 = kd1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (act[u]) {
+                    atomicAdd(&ya[ind[u]], v[u].x);
+                    atomicAdd(&wa[ind[u]], v[u].y);
+                }
+        };
+        const int nfull = N / GC;  // full groups: wave-uniform base pointer + lane offset, unconditional loads (a branch
+                                   // around a load would make the compiler wait for every load in flight)
+        if (nfull > 0) {
+            double tvb[PFG][U];
+            double2 vb[PFG][U];
+#pragma unroll
+            for (int s = 0; s < PFG; ++s) {
+                const int gs = min(s, nfull - 1);
+                const double *tp = tm + (size_t)gs * GC;
+                const double2 *yp = yw + (size_t)gs * GC;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    tvb[s][u] = tp[(u << 6) + lane];
+                    vb[s][u] = yp[(u << 6) + lane];
+                }
+            }
+            for (int g0 = 0; g0 < nfull; g0 += PFG) {
+#pragma unroll
+                for (int s = 0; s < PFG; ++s) {
+                    const int gd = g0 + s;
+                    if (gd < nfull) {  // wave-uniform
+                        double tv[U];
+                        double2 v[U];
+                        const int gn = min(gd + PFG, nfull - 1);  // the last group is re-loaded at the end: harmless
+                        const double *tp = tm + (size_t)gn * GC;
+                        const double2 *yp = yw + (size_t)gn * GC;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            tv[u] = tvb[s][u];
+                            v[u] = vb[s][u];
+                            tvb[s][u] = tp[(u << 6) + lane];
+                            vb[s][u] = yp[(u << 6) + lane];
+                        }
+                        do_group(tv, v, gd * GC, true);
+                    }
+                }
+            }
+        }
+        if (nfull * GC < N) {  // ragged tail: clamped loads, masked lanes
+            double tv[U];
+            double2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(nfull * GC + (u << 6) + lane, N - 1);
+                tv[u] = tm[i];
+                v[u] = yw[i];
+            }
+            do_group(tv, v, nfull * GC, false);
+        }
+    }
+    __syncthreads();
+    BLS_LAP(1);  // histogram
+    // ---- wrap pad (reference: for n=1..oversample: mean[n_bins-oversample+n-1] = mean[n], in that order)
+    if (n_bins - oversample > oversample) {  // source [1, os] and destination [n_bins-os, n_bins-1] are disjoint
+        for (int q = 1 + tid; q <= oversample; q += NT) {
+            ya[n_bins - oversample + q - 1] = ya[q];
+            wa[n_bins - oversample + q - 1] = wa[q];
+        }
+    } else if (tid == 0) {
+        for (int q = 1; q <= oversample; ++q) {
+            ya[n_bins - oversample + q - 1] = ya[q];
+            wa[n_bins - oversample + q - 1] = wa[q];
+        }
+    }
+    __syncthreads();
+    // constants of the scan's skip bound, from the per-bin sums while they are still per-bin
+    const double sum_y = st.sum_y, sum_ivar = st.sum_ivar;
+    {
+        double g = 0.0, wm = 0.0, ysum = 0.0;
+        for (int i = 1 + tid; i <= n_bins; i += NT) {
+            const double vy = ya[i], vw = wa[i];
+            g = fmax(g, fabs(sum_y * vw - sum_ivar * vy));
+            wm = fmax(wm, vw);
+            ysum += fabs(vy);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            g = fmax(g, __shfl_xor(g, o));
+            wm = fmax(wm, __shfl_xor(wm, o));
+            ysum += __shfl_xor(ysum, o);
+        }
+        if (lane == 0) {
+            atomicMax(&s_red[0], __double_as_longlong(g));
+            atomicMax(&s_red[1], __double_as_longlong(wm));
+            atomicAdd(reinterpret_cast<double *>(&s_red[2]), ysum * (1.0 + 1e-6));
+        }
+    }
+    __syncthreads();
+    BLS_LAP(2);  // wrap pad + gmax / wmax reductions
+    // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  bins[0] is always 0, so
+    // starting at i = 0 with acc = 0 is the same chain.  Lane 0: y, lane 1: ivar.
+    if (tid < 2 && !(ablate & 2)) {
+        double *comp = tid ? wa : ya;
+        double acc = 0.0;
+        // Eight bins per step on two register sets: while one set runs its dependent adds the other's loads are in
+        // flight (written out as A / B halves so the compiler's s_waitcnt placement can tell the two apart).
+        const int total = n_bins + 1, nstep = total >> 3;
+        double xa[8], xb[8];
+        auto chain8 = [&](double(&x)[8], double *cp) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc = x[u] + acc;
+                x[u] = acc;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cp[u] = x[u];
+        };
+        if (nstep > 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xa[u] = comp[u];
+        }
+        int it = 0;
+        for (; it + 2 <= nstep; it += 2) {
+            double *cp = comp + (it << 3);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xb[u] = cp[8 + u];
+            chain8(xa, cp);
+            if (it + 2 < nstep) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xa[u] = cp[16 + u];
+            }
+            chain8(xb, cp + 8);
+        }
+        if (it < nstep) chain8(xa, comp + (it << 3));
+        for (int i = nstep << 3; i < total; ++i) {
+            acc = comp[i] + acc;
+            comp[i] = acc;
+        }
+    }
+    __syncthreads();
+    // Z[i] = S * W[i] - E * Y[i] (W, Y the prefix sums just formed): the numerator of both objectives is a plain
+    // difference, Nn(n, dur) = Z[n + dur] - Z[n], so the maximum of Z over a block of bins bounds Nn for every window
+    // of a start bin that ends in that block.  Block maxima over aligned blocks of 8 and 64 bins (1.1 B per bin).
+    {
+        const int nb8 = (n_bins >> 3) + 1;
+        for (int b8 = tid; b8 < nb8; b8 += NT) {
+            double m = -INFINITY;
+            const int i0 = b8 << 3, i1 = min(i0 + 7, n_bins);
+            for (int i = i0; i <= i1; ++i) m = fmax(m, st.sum_y * wa[i] - st.sum_ivar * ya[i]);
+            zm8[b8] = m;
+        }
+        __syncthreads();
+        const int nb64 = (n_bins >> 6) + 1;
+        for (int b64 = tid; b64 < nb64; b64 += NT) {
+            double m = -INFINITY;
+            const int i0 = b64 << 3, i1 = min(i0 + 7, nb8 - 1);
+            for (int i = i0; i <= i1; ++i) m = fmax(m, zm8[i]);
+            zm64[b64] = m;
+        }
+    }
+    __syncthreads();
+    BLS_LAP(3);  // prefix chains + block maxima
+
+    // ---- scan
+    // A lane owns a start bin n and walks the durations in ascending length.  With a = y_out sum, b = ivar_in,
+    // c = y_in sum, e = ivar_out and Nn = a*b - c*e = S*b - E*c (S, E the totals):
+    //     likelihood  0.5*b*(a/e - c/b)^2 = 0.5*Nn^2 / (b*e^2)        snr  (a/e - c/b)/sqrt(1/b+1/e) = Nn / sqrt(b*e*E)
+    // (1) skip-ahead: growing the window by one bin changes Nn by at most gmax, only raises b, lowers e by at most wmax,
+    //     so from one evaluation the largest m with "every window up to m bins longer is STRICTLY below thr" follows
+    //     in closed form (1e-4 safety factors, absolute slack far above the prefix-sum rounding); the walk jumps there.
+    // (2) candidates that are reached go through a division-free conservative filter with an absolute slack eN >= every
+    //     rounding the exact chain can commit, so a rejected candidate is STRICTLY below the threshold and can never be
+    //     the winner (ties always reach the exact path).
+    // (3) survivors (a handful per team) run the reference's exact arithmetic, which alone decides the result.
+    // thr = the best objective seen so far by anyone in the team (s_thr), warm-started from a coarse lattice.
+    double best = -INFINITY;
+    int bk = -1, bn = -1;
+    if (!(ablate & 4)) {
+        const double S = sum_y, E = sum_ivar;
+        const double gmax = __longlong_as_double(s_red[0]) * (1.0 + 1e-9);  // max_i |S w_i - E y_i|
+        const double wmax = __longlong_as_double(s_red[1]);                 // max_i w_i
+        const double yabs = __longlong_as_double(s_red[2]);                 // sum_i |y_i|
+        // |Nn computed from the rounded prefix sums - Nn of the real bin sums| is below ~n_bins eps E (|S| + yabs);
+        // 1e-9 leaves four orders of magnitude
+        const double slack = 1e-9 * E * (fabs(S) + yabs);
+        const int dmin = dur_bins[0];
+        // conservative filter, then the reference's exact arithmetic; keeps the FIRST best in (caller's duration
+        // index, start bin) order
+        auto finish = [&](int n, int kc, double y_in, double ivar_in, double ivar_out, double Nn, double eN, double thr) {
+            if (Nn + eN < 0.0) return;  // certainly y_out < y_in
+            {
+                const double m = fabs(Nn) + eN;
+                double lhs, rhs;
+                if (obj_flag) {
+                    lhs = 0.5 * m * m;
+                    rhs = thr * ivar_in * ivar_out * ivar_out;
+                } else {
+                    lhs = m * m;
+                    rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
+                }
+                if (lhs * (1.0 + 1e-12) < rhs) return;  // certainly objective < thr
+            }
+            double y_out = S - y_in;
+            y_in /= ivar_in;
+            y_out /= ivar_out;
+            double obj;
+            if (obj_flag) {
+                const double arg = y_out - y_in;
+                obj = 0.5 * ivar_in * arg * arg;
+            } else {
+                const double depth = y_out - y_in;
+                const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+                obj = depth / depth_err;
+            }
+            if (y_out >= y_in &&
+                (obj > best || (obj == best && (korig[kc] < korig[bk] || (kc == bk && n < bn))))) {
+                best = obj;
+                bk = kc;
+                bn = n;
+                atomicMax(s_thr, __double_as_longlong(obj));  // obj >= 0 here: the bit pattern orders like the value
+            }
+        };
+        // ---- warm start: every 8th start bin x every 8th duration (1.6 % of the candidates) gives the walk below a
+        //      threshold close to the final best from its first step
+        if (!(ablate & 128)) {
+            const int cn = (n_bins - dmin) / 8 + 1, ck = (n_dur + 7) / 8;
+            for (int c = tid; c < cn * ck; c += NT) {
+                const int kc = (c / cn) * 8, n = (c - (c / cn) * cn) * 8;
+                const int dur = dur_bins[kc];
+                if (n + dur > n_bins) continue;
+                const double y_in = ya[n + dur] - ya[n], ivar_in = wa[n + dur] - wa[n], ivar_out = E - ivar_in;
+                if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
+                const double ab = S * ivar_in, ce = E * y_in;
+                finish(n, kc, y_in, ivar_in, ivar_out, ab - ce, (fabs(ab) + fabs(ce)) * 1e-15,
+                       fmax(best, __longlong_as_double(*s_thr)));
+            }
+            __syncthreads();
+        }
+        // objective(Nn <= ub, ivar_in >= b, ivar_out >= e) strictly below thr (1e-4 safety factor, as in the skip-ahead)
+        auto block_below = [&](double ub, double b, double e, double thr) {
+            if (obj_flag) return 0.5 * ub * ub < thr * b * e * e * (1.0 - 1e-4);
+            return ub < thr * __builtin_amdgcn_sqrt(b * e * E) * (1.0 - 1e-4);
+        };
+        int n = atomicAdd(s_ctr, 1);
+        int k = 0, dur_k = dmin;  // dur_k == dur_bins[k] (the sentinel once k == n_dur)
+        double lwy = 0.0, lww = 0.0, zn = 0.0, thr_sh = __longlong_as_double(*s_thr);
+        if (n + dmin <= n_bins) {
+            lwy = ya[n];
+            lww = wa[n];
+            zn = S * lww - E * lwy;
+        }
+        while (n + dmin <= n_bins) {  // start bins are handed out in ascending order: the first miss ends the lane
+            if (n + dur_k > n_bins) {  // durations ascend: once one overruns, every later one does too
+                n = atomicAdd(s_ctr, 1);
+                k = 0;
+                dur_k = dmin;
+                if (n + dmin <= n_bins) {
+                    lwy = ya[n];
+                    lww = wa[n];
+                    zn = S * lww - E * lwy;
+                }
+                continue;
+            }
+            const int dur = dur_k, kc = k;
+            const int j = n + dur;
+            const double hw = wa[j];
+            const double thr = fmax(best, thr_sh);  // one iteration stale: still a valid (lower) bound
+            thr_sh = __longlong_as_double(*s_thr);
+            const double ivar_in = hw - lww;
+            const double ivar_out = E - ivar_in;
+            // ---- block skip: every window of this start bin that ends inside the aligned block of 64 (then 8) bins around
+            //      j has Nn <= max(Z over the block) - Z[n], ivar_in >= this window's (ivar >= 0: windows only grow) and
+            //      ivar_out >= this one's minus the block's length x wmax.  If that bound is strictly below thr, none of
+            //      them can win: jump to the first duration that ends beyond the block.
+            if (thr > 0.0 && ivar_in >= DBL_EPSILON && !(ablate & 32)) {
+                int jend = ((j >> 6) + 1) << 6;
+                double ub = zm64[j >> 6] - zn + slack;
+                double e_lb = ivar_out - 64.0 * wmax;
+                bool skip = ub < 0.0 || (e_lb > 0.0 && block_below(ub, ivar_in, e_lb, thr));
+                if (!skip) {
+                    jend = ((j >> 3) + 1) << 3;
+                    ub = zm8[j >> 3] - zn + slack;
+                    e_lb = ivar_out - 8.0 * wmax;
+                    skip = ub < 0.0 || (e_lb > 0.0 && block_below(ub, ivar_in, e_lb, thr));
+                }
+                if (skip) {
+                    const int len = jend - n;  // first duration (in bins) that ends beyond the block
+                    if (len > max_dur) {
+                        k = n_dur;
+                        dur_k = 0xffff;  // the sentinel: this start bin is exhausted
+                    } else {
+                        const int kd = first_kd[len];
+                        k = kd & 0xffff;
+                        dur_k = (int)((unsigned)kd >> 16);
+                    }
+                    continue;
+                }
+            }
+            const double hy = ya[j];
+            dur_k = dur_bins[++k];
+            const double y_in = hy - lwy;
+            if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
+            // Nn = y_out ivar_in - y_in ivar_out = S ivar_in - E y_in in real arithmetic
+            const double ab = S * ivar_in, ce = E * y_in;
+            const double Nn = ab - ce;
+            // ---- how many more bins this window may grow before it could reach thr
+            if (thr > 0.0 && !(ablate & 64)) {
+                double mf;
+                if (obj_flag) {
+                    const double q = __builtin_amdgcn_sqrt(2.0 * thr * ivar_in) * (1.0 - 1e-4);
+                    mf = (q * ivar_out - Nn - slack) * __builtin_amdgcn_rcp(gmax + q * wmax) * (1.0 - 1e-4) - 1.0;
+                } else {
+                    const double e_lo = ivar_out - 64.0 * wmax;
+                    const double q = thr * __builtin_amdgcn_sqrt(ivar_in * e_lo * E) * (1.0 - 1e-4);
+                    mf = e_lo > 0.0 ? fmin((q - Nn - slack) * __builtin_amdgcn_rcp(gmax) * (1.0 - 1e-4) - 1.0, 64.0) : 0.0;
+                }
+                if (mf >= 1.0) {
+                    const int m = (int)fmin(mf, 1.0e6);
+                    const int kd = first_kd[min(dur + m, max_dur) + 1];  // >= kc + 1 since dur_bins[kc] < dur + m + 1
+                    k = kd & 0xffff;
+                    dur_k = (int)((unsigned)kd >> 16);
+                    continue;  // m >= 1 means this candidate itself is below thr as well
+                }
+            }
+            finish(n, kc, y_in, ivar_in, ivar_out, Nn, (fabs(ab) + fabs(ce)) * 1e-15, thr);
+        }
+    }
+    // ---- winner: (objective desc, caller's duration index asc, start bin asc) is a strict total order on distinct
+    //      candidates, so the xor butterfly leaves a wave's winner in every lane; lane 0 of each wave posts it
+    for (int o = 32; o > 0; o >>= 1) {
+        const double oo = __shfl_xor(best, o);
+        const int ok = __shfl_xor(bk, o), on = __shfl_xor(bn, o);
+        const bool take = ok >= 0 && (bk < 0 || oo > best ||
+                                      (oo == best && (korig[ok] < korig[bk] || (ok == bk && on < bn))));
+        if (take) {
+            best = oo;
+            bk = ok;
+            bn = on;
+        }
+    }
+    if (lane == 0) s_best[wave] = BlsBest{best, bk, bn};
+    __syncthreads();
+    BLS_LAP(4);  // scan
+    if (tid == 0) {
+        BlsBest w = s_best[0];
+        for (int i = 1; i < NW; ++i) {
+            const BlsBest o = s_best[i];
+            const bool take = o.k >= 0 && (w.k < 0 || o.obj > w.obj ||
+                                            (o.obj == w.obj && (korig[o.k] < korig[w.k] || (o.k == w.k && o.n < w.n))));
+            if (take) w = o;
+        }
+        const size_t stride = (size_t)B * (size_t)nP;
+        double *o = out7 + (size_t)target * (size_t)nP + (size_t)p;
+        if (w.k < 0) {
+            o[0] = -INFINITY;
+            for (int f = 1; f < 7; ++f) o[f * stride] = 0.0;
+        } else {
+            const int dur = dur_bins[w.k], n = w.n;
+            double y_in = ya[n + dur] - ya[n];
+            const double ivar_in = wa[n + dur] - wa[n];
+            double y_out = sum_y - y_in;
+            const double ivar_out = sum_ivar - ivar_in;
+            y_in /= ivar_in;
+            y_out /= ivar_out;
+            const double arg = y_out - y_in;
+            const double log_like = 0.5 * ivar_in * arg * arg;
+            const double depth = y_out - y_in;
+            const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+            const double depth_snr = depth / depth_err;
+            const double duration = dur * bin_duration;
+            const double phase = fmod(n * bin_duration + 0.5 * duration + st.min_t, P);
+            o[0] = w.obj;
+            o[1 * stride] = depth;
+            o[2 * stride] = depth_err;
+            o[3 * stride] = duration;
+            o[4 * stride] = phase;
+            o[5 * stride] = depth_snr;
+            o[6 * stride] = log_like;
+        }
+    }
+    BLS_LAP(5);  // final reduction + outputs
+    if (prof && threadIdx.x == 0) atomicAdd(&prof[7], 1ull);
+#undef BLS_LAP
+}
+
+#define BLS_TEAM_ARGS                                                                                                  \
+    const double *__restrict__ tm, const double2 *__restrict__ yw, const int64_t *__restrict__ n_off,                  \
+        const BlsStats *__restrict__ stats, const double *__restrict__ period, const int *__restrict__ pidx,           \
+        int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur, double bin_duration, \
+        int oversample, int obj_flag, double *__restrict__ out7, int cap, int ablate, unsigned long long *__restrict__ prof
+#define BLS_TEAM_PASS \
+    tm, yw, n_off, stats, period, pidx, np_group, nP, B, dur_tab, n_dur, max_dur, bin_duration, oversample, obj_flag, out7, cap, ablate, prof
+
+// 80 VGPRs: 6 waves per SIMD, for the groups whose LDS footprint admits >= 3 teams per CU
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 6))) void bls_team_kernel(BLS_TEAM_ARGS) {
+    bls_team_body<2, 2>(BLS_TEAM_PASS);
+}
+// 128 VGPRs: the long periods (one or two teams per CU, <= 16 waves): four chunks at a time, eight more in flight
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void bls_team_deep_kernel(BLS_TEAM_ARGS) {
+    bls_team_body<4, 2>(BLS_TEAM_PASS);
+}
+
+// lk_create-time check of the hardware property the atomic histogram rests on: one ds_add_f64 applies same-address
+// lanes in increasing lane order.  256 bins, 24 chunks of adversarial patterns per workgroup; out[0] counts mismatches
+// against the sequential sum done by lane 0.
+__global__ __launch_bounds__(64) void bls_selftest_kernel(int *__restrict__ bad) {
+    __shared__ double bins[256], ref[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) bins[i] = ref[i] = 0.0;
+    wave_sync();
+    unsigned long long s = 0x9e3779b97f4a7c15ull * (unsigned long long)(blockIdx.x + 1);
+    for (int c = 0; c < 24; ++c) {
+        // the same pseudo-random stream in every lane; lane l keeps draw l
+        int j = 0;
+        double v = 0.0;
+        int cur = 0;
+        for (int l = 0; l < 64; ++l) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            const unsigned r = (unsigned)(s >> 33);
+            int jj;
+            if ((c & 3) == 0) {
+                if (l == 0) cur = r & 255;
+                else if ((r & 15) < 9) cur = (cur + 1) & 255;
+                jj = cur;
+            } else if ((c & 3) == 1) jj = (int)(r % 19u);
+            else if ((c & 3) == 2) jj = (int)((r >> 5) & 1u) * 7;
+            else jj = (int)(r & 255u);
+            const double vv = ldexp(1.0 + (double)(r & 0xfffffu) * 9.5367431640625e-07, (int)((r >> 20) % 20u) - 10) *
+                              ((r >> 31) ? -1.0 : 1.0);
+            if (l == lane) {
+                j = jj;
+                v = vv;
+            }
+            if (lane == 0) ref[jj] += vv;  // sequential, lane order
+        }
+        atomicAdd(&bins[j], v);
+        wave_sync();
+    }
+    int nbad = 0;
+    for (int i = lane; i < 256; i += 64)
+        nbad += __double_as_longlong(bins[i]) != __double_as_longlong(ref[i]);
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 // ------------------------------------------------------------------------------------------------ launcher
 int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *ivar,
                const double *period_host, const double *period_dev, int64_t nP, const double *duration_host, int nD,
@@ -668,7 +1233,7 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     const size_t ntot = (size_t)n_off_host[B];
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(BlsStats) + 3 * (ntot * 8 + 256) +
-                           (size_t)nP * 4 + dur_tab.size() * 4 + 4096);
+                           (size_t)nP * 4 + dur_tab.size() * 4 + 8192);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     BlsStats *d_stats = (BlsStats *)h->ws.alloc((size_t)B * sizeof(BlsStats));
@@ -684,54 +1249,113 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
 
     hipLaunchKernelGGL(bls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, ivar, d_off, d_tm, d_yw, d_stats);
 
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (h->bls_attr_set != 1) {
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr_set = true;
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_team_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_team_deep_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        // the histogram rests on one hardware property (same-address lanes of a ds_add_f64 are applied in lane order):
+        // check it on this device once per handle and refuse to run without it
+        int *d_bad = (int *)h->ws.alloc(256);
+        LK_HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, stream));
+        hipLaunchKernelGGL(bls_selftest_kernel, dim3(64), dim3(64), 0, stream, d_bad);
+        int bad = -1;
+        LK_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
+        LK_HIP_CHECK(hipStreamSynchronize(stream));
+        if (bad != 0) {
+            lk::set_error("BLS self-test: LDS ds_add_f64 is not lane-ordered on this device (%d mismatching bins); the "
+                          "bit-exact histogram cannot run", bad);
+            return LK_EHIP;
+        }
+        h->bls_attr_set = 1;
     }
-    // groups: cut whenever the LDS need drops below 3/4 of the group's head (keeps occupancy close to the need)
     int ablate = 0;
     if (const char *e = getenv("LK_BLS_ABLATE")) ablate = atoi(e);  // profiling only: skips phases, results wrong
-    // LK_BLS_PROF=1 (debug): per-phase wall time of the workgroups (thread 0's clock), printed per LDS group; with W
-    // workgroups resident per CU a group's share of the step is (sum of the phases) x workgroups / (W x 256 CUs)
+    // LK_BLS_PROF=1 (debug): per-phase wall time of the teams (thread 0's clock) and the wall time of every launch
     unsigned long long *d_prof = nullptr;
-    const bool prof_on = getenv("LK_BLS_PROF") && atoi(getenv("LK_BLS_PROF")) != 0;
-    if (prof_on) {
+    const int prof_level = getenv("LK_BLS_PROF") ? atoi(getenv("LK_BLS_PROF")) : 0;  // 1: launch times; 2: + phases (the
+    const bool prof_on = prof_level != 0;                                            // in-kernel atomics distort short teams)
+    if (prof_level >= 2) {
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_prof), 64));
         LK_HIP_CHECK(hipMemset(d_prof, 0, 64));
+    }
+    const bool use_team = !(getenv("LK_BLS_TEAM") && atoi(getenv("LK_BLS_TEAM")) == 0);
+    int force_nw = 0;
+    if (const char *e = getenv("LK_BLS_NW")) force_nw = atoi(e);
+    const size_t tab_bytes16 = ((dur_tab.size() * 4 + 15) / 16) * 16;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (prof_on) {
+        LK_HIP_CHECK(hipEventCreate(&pe0));
+        LK_HIP_CHECK(hipEventCreate(&pe1));
     }
     size_t g0 = 0;
     while (g0 < (size_t)nP) {
         const int head_bins = nbins_of(order[g0]);
+        if (prof_on) LK_HIP_CHECK(hipEventRecord(pe0, stream));
+        // groups: cut whenever the LDS need drops below 7/8 of the group's head (occupancy stays close to the need)
         size_t g1 = g0 + 1;
-        while (g1 < (size_t)nP && nbins_of(order[g1]) * 4 >= head_bins * 3) ++g1;
+        while (g1 < (size_t)nP && nbins_of(order[g1]) * (use_team ? 8 : 4) >= head_bins * (use_team ? 7 : 3)) ++g1;
         const int npg = (int)(g1 - g0);
-        // threads per workgroup by LDS footprint: small-LDS groups fit >= 4 workgroups per CU with 4 waves each;
-        // long periods (one or two workgroups per CU) get 8 / 16 waves so the SIMDs still have waves to swap.
-        const size_t bins_bytes = (size_t)(head_bins + 1) * 16;
-        const int nt = bins_bytes <= 28 * 1024 ? 256 : (bins_bytes <= 64 * 1024 ? 512 : 1024);
-        const size_t lds = bins_bytes + lds_fixed_of(nt);
         const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)npg;
         LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
-        hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off,
-                           d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration,
-                           oversample, use_likelihood ? 1 : 0, out7, ablate, d_prof);
+        int nt;
+        size_t lds;
+        if (use_team) {
+            const int cap = (head_bins + 2) & ~1;  // doubles per component array (even: both arrays 16-B aligned)
+            const size_t lds0 = tab_bytes16 + (size_t)cap * 16 + 48 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8;
+            // waves per team: fill the 24 wave slots the 80-VGPR build leaves per CU with the teams 160 KB of LDS admit
+            const int teams = std::max(1, (int)((160 * 1024) / (lds0 + 64)));
+            int nw = 1;
+            while (nw < 16 && teams * nw * 2 <= 24) nw *= 2;
+            if (force_nw) nw = force_nw;
+            nt = 64 * nw;
+            lds = lds0 + (size_t)nw * 16;
+            const bool deep = teams * nw <= 16;  // <= 4 waves per SIMD: the 128-VGPR build fits
+            if (deep)
+                hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
+                                   period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
+                                   use_likelihood ? 1 : 0, out7, cap, ablate, d_prof);
+            else
+                hipLaunchKernelGGL(bls_team_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
+                                   period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
+                                   use_likelihood ? 1 : 0, out7, cap, ablate, d_prof);
+        } else {
+            // threads per workgroup by LDS footprint: small-LDS groups fit >= 4 workgroups per CU with 4 waves each;
+            // long periods (one or two workgroups per CU) get 8 / 16 waves so the SIMDs still have waves to swap.
+            const size_t bins_bytes = (size_t)(head_bins + 1) * 16;
+            nt = bins_bytes <= 28 * 1024 ? 256 : (bins_bytes <= 64 * 1024 ? 512 : 1024);
+            lds = bins_bytes + lds_fixed_of(nt);
+            hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off,
+                               d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration,
+                               oversample, use_likelihood ? 1 : 0, out7, ablate, d_prof);
+        }
         if (prof_on) {
             unsigned long long hp[8];
-            LK_HIP_CHECK(hipStreamSynchronize(stream));
-            LK_HIP_CHECK(hipMemcpy(hp, d_prof, 64, hipMemcpyDeviceToHost));
-            LK_HIP_CHECK(hipMemset(d_prof, 0, 64));
+            float ms = 0.f;
+            LK_HIP_CHECK(hipEventRecord(pe1, stream));
+            LK_HIP_CHECK(hipEventSynchronize(pe1));
+            LK_HIP_CHECK(hipEventElapsedTime(&ms, pe0, pe1));
+            memset(hp, 0, sizeof(hp));
+            if (d_prof) {
+                LK_HIP_CHECK(hipMemcpy(hp, d_prof, 64, hipMemcpyDeviceToHost));
+                LK_HIP_CHECK(hipMemset(d_prof, 0, 64));
+            }
             const double nb = (double)std::max<unsigned long long>(hp[7], 1);
             fprintf(stderr,
-                    "[bls prof] group head_bins %5d periods %6d nt %4d lds %6zu workgroups %9llu | us per workgroup: setup %.1f  "
-                    "hist %.1f  pad+red %.1f  prefix %.1f  scan %.1f  out %.1f\n",
-                    head_bins, npg, nt, lds, hp[7], hp[0] / nb * 0.01, hp[1] / nb * 0.01, hp[2] / nb * 0.01, hp[3] / nb * 0.01,
-                    hp[4] / nb * 0.01, hp[5] / nb * 0.01);
+                    "[bls prof] head_bins %5d periods %6d nt %4d lds %6zu | %7.2f ms = %6.2f CU-us per (target, period) | us per "
+                    "team: setup %.1f  hist %.1f  pad+red %.1f  prefix %.1f  scan %.1f  out %.1f\n",
+                    head_bins, npg, nt, lds, ms, ms * 1e3 * 256.0 / ((double)npg * B), hp[0] / nb * 0.01, hp[1] / nb * 0.01,
+                    hp[2] / nb * 0.01, hp[3] / nb * 0.01, hp[4] / nb * 0.01, hp[5] / nb * 0.01);
         }
         g0 = g1;
     }
     if (d_prof) LK_HIP_CHECK(hipFree(d_prof));
+    if (pe0) {
+        hipEventDestroy(pe0);
+        hipEventDestroy(pe1);
+    }
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

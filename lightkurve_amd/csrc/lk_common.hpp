@@ -76,6 +76,7 @@ struct lk_handle {
     hipStream_t s_rows = nullptr;  // stream of the LS 'fast' row transforms when they overlap the next chunk's column transforms
     hipEvent_t ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};  // [0..1] columns done (per intermediate buffer), [2..3] rows done
     int *h_plan = nullptr;         // 64 B of pinned host memory: device -> host plan words (lsfast.hip)
+    int bls_attr_set = 0;          // bls.hip: kernel attributes set and the LDS-atomic order self-test passed on this device
 };
 
 // launchers implemented in the .hip files (device pointers, enqueue on stream, no sync)
