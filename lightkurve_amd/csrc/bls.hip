@@ -617,7 +617,7 @@ __device__ __forceinline__ void bls_team_body(
     const double *__restrict__ tm, const double2 *__restrict__ yw, const int64_t *__restrict__ n_off,
     const BlsStats *__restrict__ stats, const double *__restrict__ period, const int *__restrict__ pidx, int np_group,
     int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur, double bin_duration, int oversample,
-    int obj_flag, double *__restrict__ out7, int cap, int ablate, unsigned long long *__restrict__ prof) {
+    int obj_flag, double *__restrict__ out7, int cap, int multi, int ablate, unsigned long long *__restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t_last = prof ? wall_clock64() : 0ull;
 #define BLS_LAP(slot_)                                                        \
@@ -628,13 +628,25 @@ __device__ __forceinline__ void bls_team_body(
             t_last = now_;                                                    \
         }                                                                     \
     } while (0)
+    // Two shapes.  multi == 0: the workgroup is ONE team of NW waves on one period (long periods).  multi != 0: the
+    // workgroup holds G = blockDim / 64 one-wave teams on G consecutive periods of the sorted grid (short periods); they
+    // share the duration tables, the barriers, and — the point — the prefix pass: lane 2g + c of wave 0 runs the chain
+    // of team g's component c, so the serial chain instructions are spent on 2 G lanes instead of 2.
+    const int wtid = threadIdx.x, lane = wtid & 63;
+    const int wwave = __builtin_amdgcn_readfirstlane(wtid >> 6);
+    const int G = multi ? ((int)blockDim.x >> 6) : 1;
+    const int NT = multi ? 64 : (int)blockDim.x, NW = NT >> 6;  // threads / waves of this team
+    const int tid = multi ? lane : wtid;
+    const int wave = multi ? 0 : wwave;                          // wave index inside the team
+    const int g = multi ? wwave : 0;                             // team index inside the workgroup
     const unsigned bid = blockIdx.x;
     const unsigned xcd = bid & 7u, slot = bid >> 3;
-    const int target = (int)((slot / (unsigned)np_group) * 8u + xcd);
+    const unsigned nq = ((unsigned)np_group + (unsigned)G - 1u) / (unsigned)G;
+    const int target = (int)((slot / nq) * 8u + xcd);
     if (target >= B) return;
-    const int p = pidx[slot % (unsigned)np_group];
-    const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x, NW = NT >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pslot_raw = (int)(slot % nq) * G + g;
+    const bool emit = pslot_raw < np_group;            // the tail workgroup of a target: surplus teams redo the last
+    const int p = pidx[min(pslot_raw, np_group - 1)];  // period in their own LDS region and write nothing
     const double P = period[p];
     const double invP = 1.0 / P;
     const int n_bins = (int)(ceil(P / bin_duration)) + oversample;
@@ -643,22 +655,24 @@ __device__ __forceinline__ void bls_team_body(
     tm += lo;
     yw += lo;
 
-    // LDS: duration tables | ya[cap] | wa[cap] | s_thr | s_red[3] | s_ctr (+pad) | s_best[NW] | zm8 | zm64
+    // LDS: duration tables | per team: ya[cap] | wa[cap] | s_thr | s_red[3] | s_ctr, s_nb | s_best[NW] | zm8 | zm64
     // tables (sorted ascending by length): dur_bins[k] (k = n_dur: a sentinel no window fits), the caller's index
     // korig[k] (tie-break order) and first_kd[L] = k | dur_bins[k] << 16 for the first k with dur_bins[k] >= L
     int *dur_bins = reinterpret_cast<int *>(smem);
     int *korig = dur_bins + n_dur + 1;
     int *first_kd = korig + n_dur;
     const int tab_ints = 2 * n_dur + 1 + max_dur + 2;
-    double *ya = reinterpret_cast<double *>(smem + (((size_t)tab_ints * 4 + 15) & ~(size_t)15));
+    const size_t region = ((size_t)cap * 16 + 48 + (size_t)NW * 16 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8 + 15) & ~(size_t)15;
+    char *region0 = smem + (((size_t)tab_ints * 4 + 15) & ~(size_t)15);
+    double *ya = reinterpret_cast<double *>(region0 + (size_t)g * region);
     double *wa = ya + cap;
     long long *s_thr = reinterpret_cast<long long *>(wa + cap);
     long long *s_red = s_thr + 1;                       // gmax, wmax (bit patterns), yabs (double)
-    int *s_ctr = reinterpret_cast<int *>(s_red + 3);    // next start bin of the scan
+    int *s_ctr = reinterpret_cast<int *>(s_red + 3);    // next start bin of the scan; s_ctr[1] = n_bins (for the chain lanes)
     BlsBest *s_best = reinterpret_cast<BlsBest *>(s_red + 5);
     double *zm8 = reinterpret_cast<double *>(s_best + NW);  // [(n_bins >> 3) + 1] max of Z over aligned blocks of 8 bins
     double *zm64 = zm8 + (cap >> 3) + 1;                    // [(n_bins >> 6) + 1] ... of 64 bins (Z: see the scan)
-    for (int i = tid; i < tab_ints; i += NT) dur_bins[i] = dur_tab[i];
+    for (int i = wtid; i < tab_ints; i += (int)blockDim.x) dur_bins[i] = dur_tab[i];
     for (int i = tid; i <= n_bins; i += NT) {
         ya[i] = 0.0;
         wa[i] = 0.0;
@@ -666,7 +680,8 @@ __device__ __forceinline__ void bls_team_body(
     if (tid == 0) {
         *s_thr = __double_as_longlong(-INFINITY);
         s_red[0] = s_red[1] = s_red[2] = 0;
-        *s_ctr = 0;
+        s_ctr[0] = 0;
+        s_ctr[1] = n_bins;
     }
     __syncthreads();
     BLS_LAP(0);  // setup
@@ -813,39 +828,131 @@ __device__ __forceinline__ void bls_team_body(
     BLS_LAP(2);  // wrap pad + gmax / wmax reductions
     // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  bins[0] is always 0, so
     // starting at i = 0 with acc = 0 is the same chain.  Lane 0: y, lane 1: ivar.
-    if (tid < 2 && !(ablate & 2)) {
-        double *comp = tid ? wa : ya;
+    if (!multi && NW >= 2 && !(ablate & 2)) {
+        // One team, two chains.  A lone wave can issue an LDS instruction only every ~20 cycles (measured: a lane that
+        // loads, adds and stores bin by bin runs at ~25 cycles per bin however the loop is pipelined; moving the operands
+        // in with v_readlane costs the same in VALU issue).  So the serial pass does the minimum:
+        // pass 1  lane c of wave 0 (0: y, 1: ivar) only LOADS (two bins per ds_read2_b64) and adds, keeping the running
+        //         sum at every 32nd bin (`carries`): half an LDS instruction and one dependent add per bin;
+        // pass 2  every thread re-runs one 32-bin block from its exact carry-in, all blocks in parallel, and writes the
+        //         prefix sums in place.  Same operands in the same order as the single chain: bit-identical values.
+        double *carries = zm8;  // [2][nblk32 + 1], free until the block maxima are formed
+        const int total = n_bins + 1, nblk32 = (total + 31) >> 5;
+        if (wtid < 2) {
+            const double *comp = wtid ? wa : ya;
+            double *car = carries + wtid * (nblk32 + 1);
+            double acc = 0.0;
+            car[0] = 0.0;
+            const int nfull = total >> 5;  // full 32-bin blocks
+            if (nfull > 0) {
+                double x0[8], x1[8], x2[8], x3[8];
+                const int lastq = nfull * 4 - 1;  // last 8-bin step inside the full blocks
+                auto load8 = [&](double(&x)[8], int q) {
+                    const double *cp = comp + (min(q, lastq) << 3);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = cp[u];
+                };
+                auto add8 = [&](double(&x)[8]) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = x[u] + acc;
+                };
+                load8(x0, 0);
+                load8(x1, 1);
+                load8(x2, 2);
+                load8(x3, 3);
+                for (int blk = 0; blk < nfull; ++blk) {  // loads run one block (32 dependent adds) ahead
+                    const int q = blk << 2;
+                    // sched_barrier: keep each set's reload right behind its adds (left alone, the scheduler sinks all
+                    // sixteen loads to the bottom of the loop and the next iteration waits out the full LDS round trip)
+                    add8(x0);
+                    load8(x0, q + 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add8(x1);
+                    load8(x1, q + 5);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add8(x2);
+                    load8(x2, q + 6);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add8(x3);
+                    load8(x3, q + 7);
+                    car[blk + 1] = acc;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the ragged last block needs no carry-out
+        }
+        __syncthreads();
+        for (int item = tid; item < 2 * nblk32; item += NT) {
+            const int c = item >= nblk32, blk = item - c * nblk32;
+            double *comp = c ? wa : ya;
+            double acc = carries[c * (nblk32 + 1) + blk];
+            const int i0 = blk << 5, i1 = min(i0 + 32, total);
+            int i = i0;
+            for (; i + 8 <= i1; i += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = comp[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc = x[u] + acc;
+                    x[u] = acc;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) comp[i + u] = x[u];
+            }
+            for (; i < i1; ++i) {
+                acc = comp[i] + acc;
+                comp[i] = acc;
+            }
+        }
+    } else if (wwave == 0 && lane < 2 * G && !(ablate & 2)) {
+        // lane 2 g' + c: component c (0: y, 1: ivar) of team g'
+        char *rg = region0 + (size_t)(lane >> 1) * region;
+        double *comp = reinterpret_cast<double *>(rg) + ((lane & 1) ? cap : 0);
+        const int n_bins_c = reinterpret_cast<int *>(rg + (size_t)cap * 16 + 32)[1];
         double acc = 0.0;
-        // Eight bins per step on two register sets: while one set runs its dependent adds the other's loads are in
-        // flight (written out as A / B halves so the compiler's s_waitcnt placement can tell the two apart).
-        const int total = n_bins + 1, nstep = total >> 3;
-        double xa[8], xb[8];
-        auto chain8 = [&](double(&x)[8], double *cp) {
+        // Eight bins per step on a ring of three register sets, software-pipelined by hand: a set's loads are issued two
+        // steps (16 dependent adds, ~150-200 cycles: the LDS round trip seen by a lone wave) before its chain runs, and the
+        // sched_group_barrier pattern asks for one LDS instruction after every add so loads, stores and the 8-cycle
+        // dependent adds share the issue slots.  All loads are unconditional (the last blocks are re-read, unused): a
+        // branch around them would cost the interleave.
+        const int total = n_bins_c + 1, nstep = total >> 3;
+        if (nstep > 0) {
+            double x0[8], x1[8], x2[8];
+            const int last = nstep - 1;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                acc = x[u] + acc;
-                x[u] = acc;
+                x0[u] = comp[u];
+                x1[u] = comp[(min(1, last) << 3) + u];
+                x2[u] = comp[(min(2, last) << 3) + u];
             }
+            auto step8 = [&](double(&x)[8], int blk, int blk_next) {
+                double *cp = comp + (blk << 3);
+                const double *np_ = comp + (min(blk_next, last) << 3);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) cp[u] = x[u];
-        };
-        if (nstep > 0) {
+                for (int u = 0; u < 8; ++u) {
+                    acc = x[u] + acc;
+                    x[u] = acc;
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xa[u] = comp[u];
-        }
-        int it = 0;
-        for (; it + 2 <= nstep; it += 2) {
-            double *cp = comp + (it << 3);
+                for (int u = 0; u < 8; ++u) cp[u] = x[u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xb[u] = cp[8 + u];
-            chain8(xa, cp);
-            if (it + 2 < nstep) {
+                for (int u = 0; u < 8; ++u) x[u] = np_[u];
+            };
+            int it = 0;
+            for (; it + 3 <= nstep; it += 3) {
+                step8(x0, it, it + 3);
+                step8(x1, it + 1, it + 4);
+                step8(x2, it + 2, it + 5);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xa[u] = cp[16 + u];
+                for (int r = 0; r < 24; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // one VALU (the dependent add)
+                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);  // one LDS instruction
+                }
             }
-            chain8(xb, cp + 8);
+            if (it < nstep) step8(x0, it, it);
+            if (it + 1 < nstep) step8(x1, it + 1, it + 1);
         }
-        if (it < nstep) chain8(xa, comp + (it << 3));
         for (int i = nstep << 3; i < total; ++i) {
             acc = comp[i] + acc;
             comp[i] = acc;
@@ -957,6 +1064,7 @@ __device__ __forceinline__ void bls_team_body(
         };
         int n = atomicAdd(s_ctr, 1);
         int k = 0, dur_k = dmin;  // dur_k == dur_bins[k] (the sentinel once k == n_dur)
+        int no64 = 0;
         double lwy = 0.0, lww = 0.0, zn = 0.0, thr_sh = __longlong_as_double(*s_thr);
         if (n + dmin <= n_bins) {
             lwy = ya[n];
@@ -968,6 +1076,7 @@ __device__ __forceinline__ void bls_team_body(
                 n = atomicAdd(s_ctr, 1);
                 k = 0;
                 dur_k = dmin;
+                no64 = 0;
                 if (n + dmin <= n_bins) {
                     lwy = ya[n];
                     lww = wa[n];
@@ -988,9 +1097,14 @@ __device__ __forceinline__ void bls_team_body(
             //      them can win: jump to the first duration that ends beyond the block.
             if (thr > 0.0 && ivar_in >= DBL_EPSILON && !(ablate & 32)) {
                 int jend = ((j >> 6) + 1) << 6;
-                double ub = zm64[j >> 6] - zn + slack;
-                double e_lb = ivar_out - 64.0 * wmax;
-                bool skip = ub < 0.0 || (e_lb > 0.0 && block_below(ub, ivar_in, e_lb, thr));
+                double ub, e_lb;
+                bool skip = false;
+                if (j >= no64) {  // a 64-block that failed once is not asked again while the walk is still inside it
+                    ub = zm64[j >> 6] - zn + slack;
+                    e_lb = ivar_out - 64.0 * wmax;
+                    skip = ub < 0.0 || (e_lb > 0.0 && block_below(ub, ivar_in, e_lb, thr));
+                    if (!skip) no64 = jend;
+                }
                 if (!skip) {
                     jend = ((j >> 3) + 1) << 3;
                     ub = zm8[j >> 3] - zn + slack;
@@ -1055,7 +1169,7 @@ __device__ __forceinline__ void bls_team_body(
     if (lane == 0) s_best[wave] = BlsBest{best, bk, bn};
     __syncthreads();
     BLS_LAP(4);  // scan
-    if (tid == 0) {
+    if (tid == 0 && emit) {
         BlsBest w = s_best[0];
         for (int i = 1; i < NW; ++i) {
             const BlsBest o = s_best[i];
@@ -1101,9 +1215,9 @@ __device__ __forceinline__ void bls_team_body(
     const double *__restrict__ tm, const double2 *__restrict__ yw, const int64_t *__restrict__ n_off,                  \
         const BlsStats *__restrict__ stats, const double *__restrict__ period, const int *__restrict__ pidx,           \
         int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur, double bin_duration, \
-        int oversample, int obj_flag, double *__restrict__ out7, int cap, int ablate, unsigned long long *__restrict__ prof
+        int oversample, int obj_flag, double *__restrict__ out7, int cap, int multi, int ablate, unsigned long long *__restrict__ prof
 #define BLS_TEAM_PASS \
-    tm, yw, n_off, stats, period, pidx, np_group, nP, B, dur_tab, n_dur, max_dur, bin_duration, oversample, obj_flag, out7, cap, ablate, prof
+    tm, yw, n_off, stats, period, pidx, np_group, nP, B, dur_tab, n_dur, max_dur, bin_duration, oversample, obj_flag, out7, cap, multi, ablate, prof
 
 // 80 VGPRs: 6 waves per SIMD, for the groups whose LDS footprint admits >= 3 teams per CU
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 6))) void bls_team_kernel(BLS_TEAM_ARGS) {
@@ -1285,6 +1399,8 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     int force_nw = 0;
     if (const char *e = getenv("LK_BLS_NW")) force_nw = atoi(e);
     const size_t tab_bytes16 = ((dur_tab.size() * 4 + 15) / 16) * 16;
+    int multi_minw = 16;  // multi-period workgroups when they keep at least this many waves per CU
+    if (const char *e = getenv("LK_BLS_MULTI_MINW")) multi_minw = atoi(e);
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_on) {
         LK_HIP_CHECK(hipEventCreate(&pe0));
@@ -1304,23 +1420,46 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         size_t lds;
         if (use_team) {
             const int cap = (head_bins + 2) & ~1;  // doubles per component array (even: both arrays 16-B aligned)
-            const size_t lds0 = tab_bytes16 + (size_t)cap * 16 + 48 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8;
-            // waves per team: fill the 24 wave slots the 80-VGPR build leaves per CU with the teams 160 KB of LDS admit
-            const int teams = std::max(1, (int)((160 * 1024) / (lds0 + 64)));
-            int nw = 1;
-            while (nw < 16 && teams * nw * 2 <= 24) nw *= 2;
-            if (force_nw) nw = force_nw;
-            nt = 64 * nw;
-            lds = lds0 + (size_t)nw * 16;
-            const bool deep = teams * nw <= 16;  // <= 4 waves per SIMD: the 128-VGPR build fits
+            auto region_of = [&](int nw_) {
+                return ((size_t)cap * 16 + 48 + (size_t)nw_ * 16 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8 + 15) & ~(size_t)15;
+            };
+            // shape: short periods -> G one-wave teams per workgroup (shared tables and prefix pass); long periods -> one
+            // team of NW waves.  Either way aim at the 24 wave slots the 80-VGPR build leaves per CU.
+            int multi = 0, nw = 1, gsel = 1, waves_cu = 0;
+            for (int gc : {8, 4, 2}) {
+                const size_t l = tab_bytes16 + (size_t)gc * region_of(1);
+                if (l > 156 * 1024) continue;
+                const int w = std::min(24, (int)((160 * 1024) / (l + 64)) * gc);
+                if (w > waves_cu) {
+                    waves_cu = w;
+                    gsel = gc;
+                }
+            }
+            if (waves_cu >= multi_minw && force_nw <= 0) {
+                multi = 1;
+                if (force_nw < 0) gsel = -force_nw;  // LK_BLS_NW=-G: force G teams per workgroup (tuning)
+                nw = 1;
+                nt = 64 * gsel;
+                lds = tab_bytes16 + (size_t)gsel * region_of(1);
+                waves_cu = std::min(24, (int)((160 * 1024) / (lds + 64)) * gsel);
+            } else {
+                const int teams = std::max(1, (int)((160 * 1024) / (tab_bytes16 + region_of(16) + 64)));
+                while (nw < 16 && teams * nw * 2 <= 24) nw *= 2;
+                if (force_nw > 0) nw = force_nw;
+                nt = 64 * nw;
+                lds = tab_bytes16 + region_of(nw);
+                waves_cu = teams * nw;
+            }
+            const size_t nwg = multi ? (size_t)((B + 7) / 8) * 8 * (((size_t)npg + gsel - 1) / gsel) : nblocks;
+            const bool deep = !multi && waves_cu <= 16;  // <= 4 waves per SIMD: the 128-VGPR build fits
             if (deep)
-                hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
+                hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
                                    period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
-                                   use_likelihood ? 1 : 0, out7, cap, ablate, d_prof);
+                                   use_likelihood ? 1 : 0, out7, cap, multi, ablate, d_prof);
             else
-                hipLaunchKernelGGL(bls_team_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
+                hipLaunchKernelGGL(bls_team_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
                                    period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
-                                   use_likelihood ? 1 : 0, out7, cap, ablate, d_prof);
+                                   use_likelihood ? 1 : 0, out7, cap, multi, ablate, d_prof);
         } else {
             // threads per workgroup by LDS footprint: small-LDS groups fit >= 4 workgroups per CU with 4 waves each;
             // long periods (one or two workgroups per CU) get 8 / 16 waves so the SIMDs still have waves to swap.
