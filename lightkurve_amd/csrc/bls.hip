@@ -617,7 +617,7 @@ __device__ __forceinline__ void bls_team_body(
     const double *__restrict__ tm, const double2 *__restrict__ yw, const int64_t *__restrict__ n_off,
     const BlsStats *__restrict__ stats, const double *__restrict__ period, const int *__restrict__ pidx, int np_group,
     int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur, double bin_duration, int oversample,
-    int obj_flag, double *__restrict__ out7, int cap, int multi, int ablate, unsigned long long *__restrict__ prof) {
+    int obj_flag, double *__restrict__ out7, int cap, int shape, int ablate, unsigned long long *__restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t_last = prof ? wall_clock64() : 0ull;
 #define BLS_LAP(slot_)                                                        \
@@ -632,6 +632,7 @@ __device__ __forceinline__ void bls_team_body(
     // workgroup holds G = blockDim / 64 one-wave teams on G consecutive periods of the sorted grid (short periods); they
     // share the duration tables, the barriers, and — the point — the prefix pass: lane 2g + c of wave 0 runs the chain
     // of team g's component c, so the serial chain instructions are spent on 2 G lanes instead of 2.
+    const int nh_cap = shape >> 8, multi = shape & 1;  // shape: bit 0 multi-period workgroup, bits 8.. histogram waves
     const int wtid = threadIdx.x, lane = wtid & 63;
     const int wwave = __builtin_amdgcn_readfirstlane(wtid >> 6);
     const int G = multi ? ((int)blockDim.x >> 6) : 1;
@@ -682,13 +683,21 @@ __device__ __forceinline__ void bls_team_body(
         s_red[0] = s_red[1] = s_red[2] = 0;
         s_ctr[0] = 0;
         s_ctr[1] = n_bins;
+        s_ctr[2] = 0;  // histogram ticket
     }
     __syncthreads();
     BLS_LAP(0);  // setup
 
     // ---- histogram (wave 0)
     const BlsStats st = stats[target];
-    if (wave == 0 && !(ablate & 1)) {
+    // NH histogram waves (multi-wave teams): wave h takes the cadence groups g = h, h + NH, ... — the arithmetic of NH groups
+    // runs on NH SIMDs at once — and the atomics are issued in group order through a ticket in LDS: wave h waits until the
+    // ticket says g, issues its atomics and then writes g + 1.  A wave's LDS instructions execute in program order, so
+    // the next wave can only see the new ticket after the atomics before it have been applied: the bins still
+    // accumulate in cadence order.
+    const int NH = (multi || (ablate & 256)) ? 1 : min(NW, nh_cap);
+    volatile int *s_ticket = s_ctr + 2;
+    if (wave < NH && !(ablate & 1)) {
         const bool tsorted = st.sorted != 0.0;
         const double inv_bd = 1.0 / bin_duration;
         const double guard = 1e-12 * ((double)n_bins + 2.0);  // >= 1e-12 (q + 1) for every quotient of this period
@@ -697,11 +706,17 @@ __device__ __forceinline__ void bls_team_body(
         double kd0 = 0.0;  // wave-uniform: a cycle number not above that of any cadence still to come (sorted targets)
         // one group: phases, bins, two atomics per cadence.  `full` (a literal at both call sites): every lane holds a
         // cadence, so the fast path carries no masks at all.
-        auto do_group = [&](const double(&tv)[U], const double2(&v)[U], int i_base, bool full) {
+        auto do_group = [&](const double(&tv)[U], const double2(&v)[U], int g, bool full) {
+            const int i_base = g * GC;
             bool act[U];
             int ind[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) act[u] = full || (i_base + (u << 6) + lane < N);
+            if (NH > 1 && tsorted) {  // groups are not consecutive in this wave: the group's first cadence gives the cycle
+                double k, r;
+                fold_exact(tv[0], P, invP, &k, &r);
+                kd0 = readlane_f64(k, 0);
+            }
             bool bad = false, nxt_last = false;
             const double kd1 = kd0 + 1.0;
 #pragma unroll
@@ -731,21 +746,32 @@ __device__ __forceinline__ void bls_team_body(
             } else if (__ballot(nxt_last) >> 63) {
                 kd0 = kd1;
             }
+            if (NH > 1) {
+                while (*s_ticket != g) {
+                    if (!(ablate & 512)) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (act[u]) {
                     atomicAdd(&ya[ind[u]], v[u].x);
                     atomicAdd(&wa[ind[u]], v[u].y);
                 }
+            if (NH > 1) {
+                asm volatile("" ::: "memory");
+                if (lane == 0) *s_ticket = g + 1;
+            }
         };
         const int nfull = N / GC;  // full groups: wave-uniform base pointer + lane offset, unconditional loads (a branch
                                    // around a load would make the compiler wait for every load in flight)
-        if (nfull > 0) {
+        const int nown = nfull > wave ? (nfull - wave + NH - 1) / NH : 0;  // this wave's full groups: wave + j * NH
+        if (nown > 0) {
             double tvb[PFG][U];
             double2 vb[PFG][U];
 #pragma unroll
             for (int s = 0; s < PFG; ++s) {
-                const int gs = min(s, nfull - 1);
+                const int gs = wave + min(s, nown - 1) * NH;
                 const double *tp = tm + (size_t)gs * GC;
                 const double2 *yp = yw + (size_t)gs * GC;
 #pragma unroll
@@ -754,14 +780,14 @@ __device__ __forceinline__ void bls_team_body(
                     vb[s][u] = yp[(u << 6) + lane];
                 }
             }
-            for (int g0 = 0; g0 < nfull; g0 += PFG) {
+            for (int j0 = 0; j0 < nown; j0 += PFG) {
 #pragma unroll
                 for (int s = 0; s < PFG; ++s) {
-                    const int gd = g0 + s;
-                    if (gd < nfull) {  // wave-uniform
+                    const int jd = j0 + s;
+                    if (jd < nown) {  // wave-uniform
                         double tv[U];
                         double2 v[U];
-                        const int gn = min(gd + PFG, nfull - 1);  // the last group is re-loaded at the end: harmless
+                        const int gn = wave + min(jd + PFG, nown - 1) * NH;  // the last group is re-loaded at the end: harmless
                         const double *tp = tm + (size_t)gn * GC;
                         const double2 *yp = yw + (size_t)gn * GC;
 #pragma unroll
@@ -771,12 +797,12 @@ __device__ __forceinline__ void bls_team_body(
                             tvb[s][u] = tp[(u << 6) + lane];
                             vb[s][u] = yp[(u << 6) + lane];
                         }
-                        do_group(tv, v, gd * GC, true);
+                        do_group(tv, v, wave + jd * NH, true);
                     }
                 }
             }
         }
-        if (nfull * GC < N) {  // ragged tail: clamped loads, masked lanes
+        if (nfull * GC < N && wave == nfull % NH) {  // ragged tail (group nfull): clamped loads, masked lanes
             double tv[U];
             double2 v[U];
 #pragma unroll
@@ -785,7 +811,7 @@ __device__ __forceinline__ void bls_team_body(
                 tv[u] = tm[i];
                 v[u] = yw[i];
             }
-            do_group(tv, v, nfull * GC, false);
+            do_group(tv, v, nfull, false);
         }
     }
     __syncthreads();
@@ -1215,9 +1241,9 @@ __device__ __forceinline__ void bls_team_body(
     const double *__restrict__ tm, const double2 *__restrict__ yw, const int64_t *__restrict__ n_off,                  \
         const BlsStats *__restrict__ stats, const double *__restrict__ period, const int *__restrict__ pidx,           \
         int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur, double bin_duration, \
-        int oversample, int obj_flag, double *__restrict__ out7, int cap, int multi, int ablate, unsigned long long *__restrict__ prof
+        int oversample, int obj_flag, double *__restrict__ out7, int cap, int shape, int ablate, unsigned long long *__restrict__ prof
 #define BLS_TEAM_PASS \
-    tm, yw, n_off, stats, period, pidx, np_group, nP, B, dur_tab, n_dur, max_dur, bin_duration, oversample, obj_flag, out7, cap, multi, ablate, prof
+    tm, yw, n_off, stats, period, pidx, np_group, nP, B, dur_tab, n_dur, max_dur, bin_duration, oversample, obj_flag, out7, cap, shape, ablate, prof
 
 // 80 VGPRs: 6 waves per SIMD, for the groups whose LDS footprint admits >= 3 teams per CU
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 6))) void bls_team_kernel(BLS_TEAM_ARGS) {
@@ -1399,6 +1425,10 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     int force_nw = 0;
     if (const char *e = getenv("LK_BLS_NW")) force_nw = atoi(e);
     const size_t tab_bytes16 = ((dur_tab.size() * 4 + 15) / 16) * 16;
+    int cut_den = 8;  // groups: cut when the LDS need drops below (cut_den - 1) / cut_den of the group's head
+    if (const char *e = getenv("LK_BLS_CUT")) cut_den = std::max(2, atoi(e));
+    int nh_cap = 4;  // histogram waves per team (ticket-ordered)
+    if (const char *e = getenv("LK_BLS_NH")) nh_cap = std::max(1, atoi(e));
     int multi_minw = 16;  // multi-period workgroups when they keep at least this many waves per CU
     if (const char *e = getenv("LK_BLS_MULTI_MINW")) multi_minw = atoi(e);
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -1412,7 +1442,7 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         if (prof_on) LK_HIP_CHECK(hipEventRecord(pe0, stream));
         // groups: cut whenever the LDS need drops below 7/8 of the group's head (occupancy stays close to the need)
         size_t g1 = g0 + 1;
-        while (g1 < (size_t)nP && nbins_of(order[g1]) * (use_team ? 8 : 4) >= head_bins * (use_team ? 7 : 3)) ++g1;
+        while (g1 < (size_t)nP && nbins_of(order[g1]) * (use_team ? cut_den : 4) >= head_bins * (use_team ? cut_den - 1 : 3)) ++g1;
         const int npg = (int)(g1 - g0);
         const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)npg;
         LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
@@ -1455,11 +1485,11 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
             if (deep)
                 hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
                                    period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
-                                   use_likelihood ? 1 : 0, out7, cap, multi, ablate, d_prof);
+                                   use_likelihood ? 1 : 0, out7, cap, multi | (nh_cap << 8), ablate, d_prof);
             else
                 hipLaunchKernelGGL(bls_team_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
                                    period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
-                                   use_likelihood ? 1 : 0, out7, cap, multi, ablate, d_prof);
+                                   use_likelihood ? 1 : 0, out7, cap, multi | (nh_cap << 8), ablate, d_prof);
         } else {
             // threads per workgroup by LDS footprint: small-LDS groups fit >= 4 workgroups per CU with 4 waves each;
             // long periods (one or two workgroups per CU) get 8 / 16 waves so the SIMDs still have waves to swap.
