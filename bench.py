@@ -14,6 +14,11 @@ A "step" = one pass of the hot path over one batch of targets, inputs already re
     method ls_method="fast" (extirpolation + FFT) followed by the per-target (max power, argmax);
   * `other_method`: the exact direct-sum kernel (lk_ls_power_batch_dev + lk_argmax_batch_dev), same protocol;
   * `bls`: configs[3] (B targets x 50 000 periods x 200 durations) through lk_bls_batch_dev, 1 warm-up + <= 2 steps;
+  * `pld`: configs[4] (500 cutouts 11x11 x 3500 cadences, pld_order 3, 16 components) through lk_pld_design_batch_dev +
+    lk_regress_batch_dev; accuracy against lightkurve's own PLDCorrector output for the first cutouts
+    (tests/golden/pld_c5.npz, made from the reference) and against the numpy port;
+  * `flatten`: 1000 light curves x 20 000 cadences, window 401, through lk_savgol_trend_batch_dev; accuracy and
+    cpu_baseline from scipy's savgol_filter / interp1d (the reference's own calls) run under conda on this box;
   * `accuracy` (N = 1): astropy ITSELF (conda interpreter, oracle/astropy_baseline.py suite) run on the first targets
     of the very same batches, arrays handed over as files: max-power relative error and argmax equality for 'fast'
     (vs astropy 'fast') and exact (vs astropy 'cython') at full N / M, BLS best-period index equality on the full
@@ -75,6 +80,11 @@ def parse(argv=None):
     ap.add_argument("--no-bls", action="store_true", help="workload ls: skip the BLS block of the metric")
     ap.add_argument("--bls-targets", type=int, default=1000, help="workload ls: targets per GPU of the BLS block")
     ap.add_argument("--no-host", action="store_true", help="workload ls: skip the host-to-host measurement")
+    ap.add_argument("--no-pld", action="store_true", help="workload ls: skip the PLD block (configs[4])")
+    ap.add_argument("--no-flatten", action="store_true", help="workload ls: skip the flatten block")
+    ap.add_argument("--flatten-targets", type=int, default=1000, help="workload ls: light curves per GPU of the flatten block")
+    ap.add_argument("--acc-flatten", type=int, default=64,
+                    help="light curves flattened by scipy itself under conda (accuracy reference and cpu_baseline)")
     ap.add_argument("--acc-fast", type=int, default=256, help="targets checked against astropy 'fast' (also the cpu_baseline sample)")
     ap.add_argument("--acc-exact", type=int, default=16, help="targets checked against astropy 'cython' (74 s of one core each)")
     ap.add_argument("--acc-bls", type=int, default=32, help="targets checked against astropy run_bls on the full period grid")
@@ -149,7 +159,7 @@ def dry_run(args, rank, world):
 
 
 # ------------------------------------------------------------------------------------------------ reference runs
-def reference_suite(args, want_ls, want_bls):
+def reference_suite(args, want_ls, want_bls, want_flatten=False):
     """Run astropy itself (the reference's numerical dependency) on the first targets of the bench batches, before
     torch/HIP is initialised: returns the suite's result dict (rates + per-target maxima), or None when the conda
     interpreter / astropy is not there.  Inputs travel as .npz files so both sides see identical arrays."""
@@ -175,6 +185,11 @@ def reference_suite(args, want_ls, want_bls):
             period, duration = synth.bls_grid(args.periods, args.durations)
             np.savez(os.path.join(work, "bls.npz"), t=t, y=y, e=e, off=off, period=period, duration=duration)
             spec["bls"] = {"n": n}
+        if want_flatten and args.acc_flatten > 0:
+            n = min(args.acc_flatten, args.flatten_targets if args.workload == "ls" else args.targets)
+            t, y, dy, off = synth.ls_batch(6, n, args.cadences, first_index=0)
+            np.savez(os.path.join(work, "flatten.npz"), t=t, y=y, off=off)
+            spec["flatten"] = {"n": n}
         json.dump(spec, open(os.path.join(work, "suite.json"), "w"))
         env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "oracle", "shims") + os.pathsep + ROOT)
         if os.path.exists(SYS_STDCXX):
@@ -187,6 +202,8 @@ def reference_suite(args, want_ls, want_bls):
             return None
         res = json.load(open(rpath))
         res["cores"] = cores
+        if "flatten" in res:
+            res["flatten"]["trends"] = np.load(os.path.join(work, "flatten_trends.npy"))
         return res
     except Exception as e:   # the baseline is reported, never required
         sys.stderr.write("astropy suite failed: %r\n" % (e,))
@@ -328,17 +345,25 @@ def main():
         sys.exit(dry_run(args, rank, world))
 
     # ---- the reference's CPU path (cpu_baseline + accuracy reference): rank 0 at N = 1 only, before torch/HIP exist
-    ref, cpu_base, cpu_base_bls = None, None, None
+    ref, cpu_base, cpu_base_bls, cpu_base_pld, cpu_base_flat = None, None, None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.workload == "ls":
-            ref = reference_suite(args, True, not args.no_bls)
+            ref = reference_suite(args, True, not args.no_bls, not args.no_flatten)
             if ref is None:
                 cpu_base = port_baseline_ls(args)
                 cpu_base_bls = None if args.no_bls else port_baseline_bls(args)
+            if not args.no_pld:
+                cpu_base_pld = cpu_baseline_pld(args)
+            if not args.no_flatten and (ref is None or "flatten" not in ref):
+                cpu_base_flat = cpu_baseline_flatten(args)
         elif args.workload == "bls":
             ref = reference_suite(args, False, True)
             if ref is None:
                 cpu_base = port_baseline_bls(args)
+        elif args.workload == "flatten":
+            ref = reference_suite(args, False, False, True)
+            if ref is None or "flatten" not in ref:
+                cpu_base = cpu_baseline_flatten(args)
         else:
             cpu_base = {"pld": cpu_baseline_pld, "flatten": cpu_baseline_flatten, "lschi2": cpu_baseline_lschi2,
                         "pgsmooth": cpu_baseline_pgsmooth, "fold": cpu_baseline_fold,
@@ -369,6 +394,18 @@ def main():
                     cpu_base = cb
                 else:
                     cpu_base_bls = cb
+            if "flatten" in ref:
+                r = ref["flatten"]
+                cb = {"value": r["units_per_s"], "unit": "cadences/sec", "cores": ref["cores"], "kind": "reference",
+                      "sample": "scipy %s savgol_filter + interp1d inside the restated loop of LightCurve.flatten "
+                                "(lightcurve.py:996-1063; lightkurve itself is not installed on this box), %d light curves x %d "
+                                "cadences, window 401, %d processes, %.1f s"
+                                % (r["scipy"], r["n_targets"], args.cadences, ref["procs"], r["seconds"]),
+                      "_results": [r["trends"][i * args.cadences:(i + 1) * args.cadences] for i in range(r["n_targets"])]}
+                if args.workload == "flatten":
+                    cpu_base = cb
+                else:
+                    cpu_base_flat = cb
 
     import ctypes
     import torch
@@ -476,7 +513,7 @@ def main():
             "units_per_step": Bb * nP, "dt": dt, "steps": steps, "warmup": warmup, "kernel_ms": kms,
             "workload": "configs[3]: %d targets x %d cadences, %d periods x %d durations BLS per GPU" % (Bb, N, nP, len(duration)),
             "roofline": {"bound": "valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("bls"), "kernel": "bls_kernel",
+                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("bls"), "kernel": "bls_team_kernel / bls_team_deep_kernel",
                          "kernel_ms_per_step": kms,
                          "note": "algorithmic 12 flop per (start bin, duration) candidate (SURVEY.md 8(d)); the bit-exact "
                                  "kernel skips most candidates with a rigorous growth bound, so this is an equivalent rate; "
@@ -496,6 +533,153 @@ def main():
                 "best_period_index_equal": "%d/%d" % (int(np.sum(a_ref == a_gpu)), n),
                 "max_power_bit_identical": "%d/%d" % (int(np.sum(p_ref == p_gpu)), n),
                 "max_power_relerr_max": float(np.max(np.abs(p_gpu - p_ref) / np.abs(p_ref)))}
+
+
+    # ================================================================================================ PLD block
+    def run_pld(Bc, first_index, steps, warmup, base):
+        """configs[4]: Bc cutouts 11x11 x pld_cadences, pld_order 3, 16 PCA components, all pixels: design matrix +
+        regression through lk_pld_design_batch_dev + lk_regress_batch_dev.  `base`: the numpy port's baseline dict (its
+        "_results" feed one of the two accuracy checks) or None."""
+        Nc, npix = args.pld_cadences, 11
+        P = npix * npix
+        cubes = [synth.pld_cutout(4, first_index + i, n=Nc, npix=npix) for i in range(Bc)]
+        tt = np.stack([c[0] for c in cubes])
+        pix = np.stack([c[1].reshape(Nc, P) for c in cubes]).astype(np.float32)
+        epx = np.stack([c[2].reshape(Nc, P) for c in cubes]).astype(np.float32)
+        lcf = pix.sum(axis=2, dtype=np.float32)
+        lce = np.sqrt((epx.astype(np.float64) ** 2).sum(axis=2))
+        deg, nkn = 5, Nc // 50
+        n_inner = nkn - deg - 1
+        knots = np.stack([np.concatenate([[t_.min()], np.percentile(t_, np.linspace(0, 100, n_inner + 2)[1:-1]), [t_.max()]])
+                          for t_ in tt])
+        K = _capi.pld_design_width(P, P, 3, 16, nkn)
+        d_pix, d_lcf, d_t, d_kn = (torch.from_numpy(a).to(dev) for a in (pix, lcf, tt, knots))
+        d_y, d_err = torch.from_numpy(lcf.astype(np.float64).ravel()).to(dev), torch.from_numpy(lce.ravel()).to(dev)
+        d_X = torch.empty((Bc, Nc, K), dtype=torch.float64, device=dev)
+        d_ps = torch.empty((Bc, K), dtype=torch.float64, device=dev)
+        d_mu = torch.zeros((Bc, K), dtype=torch.float64, device=dev)
+        d_w = torch.empty((Bc, K), dtype=torch.float64, device=dev)
+        d_model = torch.empty(Bc * Nc, dtype=torch.float64, device=dev)
+        d_out = torch.empty(Bc * Nc, dtype=torch.uint8, device=dev)
+        offp = np.arange(Bc + 1, dtype=np.int64) * Nc
+
+        def step(e0, e1):
+            e0.record()
+            _capi._check(lib.lk_pld_design_batch_dev(handle._h, Bc, Nc, P, P, vp(d_pix.data_ptr()), vp(d_pix.data_ptr()),
+                                                     vp(d_lcf.data_ptr()), vp(d_t.data_ptr()), vp(d_kn.data_ptr()),
+                                                     n_inner, 3, 16, nkn, deg, 1, K, vp(d_X.data_ptr()),
+                                                     vp(d_ps.data_ptr()), vp(stream)))
+            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(i64p), K,
+                                                  vp(d_X.data_ptr()), vp(d_y.data_ptr()), vp(d_err.data_ptr()), None,
+                                                  vp(d_mu.data_ptr()), vp(d_ps.data_ptr()), 5.0, 5, vp(d_w.data_ptr()),
+                                                  vp(d_model.data_ptr()), vp(d_out.data_ptr()), vp(stream)))
+            e1.record()
+
+        dt, kms = timed(step, warmup, steps)
+        del d_X
+        acc = {}
+        from lightkurve_amd.correctors.pldcorrector import PixelCube, pld_correct_batch
+        gpath = os.path.join(ROOT, "tests", "golden", "pld_c5.npz")
+        if rank == 0 and first_index == 0 and Nc == 3500 and os.path.exists(gpath):
+            # the product path (PLDCorrector mirror: design matrix, regression, restored trend) on the cutouts the REFERENCE
+            # itself corrected when the fixture was made (oracle/gen_golden.py gen_pld_c5: lightkurve's PLDCorrector on
+            # these very synth cutouts — regenerated here, SHA-256 checked)
+            import hashlib
+            g = np.load(gpath)
+            ng = min(int(g["n_cutouts"]), Bc)
+            same = all(hashlib.sha256(cubes[i][0].tobytes() + cubes[i][1].tobytes() + cubes[i][2].tobytes()).hexdigest()
+                       == str(g["sha_%d" % i]) for i in range(ng))
+            if same:
+                cg = [PixelCube(g["time_%d" % i], cubes[i][1], cubes[i][2], mission="K2") for i in range(ng)]
+                corr, outl = pld_correct_batch(cg, pld_order=3, pca_components=16)
+                rel = [float(np.max(np.abs(corr[i] - g["corrected_%d" % i])) / np.median(g["corrected_%d" % i])) for i in range(ng)]
+                acc["vs_reference"] = {
+                    "reference": "lightkurve PLDCorrector.correct itself (pldcorrector.py:304-427) on these synthetic cutouts, "
+                                 "outputs committed as tests/golden/pld_c5.npz (lightkurve is not installed on this box); "
+                                 "%d cutouts 11x11 x %d cadences, order 3, 16 components" % (ng, Nc),
+                    "corrected_flux_relerr_max": max(rel), "tolerance": 1e-6,
+                    "outlier_masks_equal": "%d/%d" % (sum(int(np.array_equal(outl[i], g["outlier_mask_%d" % i])) for i in range(ng)), ng)}
+        if base is not None and "_results" in base and first_index == 0:
+            kept = base.pop("_results")
+            cubes2 = [PixelCube(cubes[i][0], cubes[i][1], cubes[i][2], mission="K2") for i in range(len(kept))]
+            corr, outl = pld_correct_batch(cubes2, pld_order=3, pca_components=16)
+            relerr = [float(np.max(np.abs(corr[i] - kept[i][0])) / np.median(kept[i][0])) for i in range(len(kept))]
+            acc["vs_port"] = {"reference": "numpy/LAPACK port of PLDCorrector.correct (exact SVD), %d cutouts 11x11 x %d "
+                                           "cadences, order 3, 16 components" % (len(kept), Nc),
+                              "corrected_flux_relerr_max": max(relerr),
+                              "outlier_masks_equal": "%d/%d" % (sum(int(np.array_equal(outl[i], kept[i][1])) for i in range(len(kept))), len(kept))}
+        gram_cols = [P, 136, 816, P]
+        # MFMA flop actually executed: the Gram kernels build the UPPER TRIANGLE only — N*P*(P+1) per PCA Gram, and
+        # N*(K+1)*(K+2) for ONE regression Gram (the clip loop stops at its fixed point: passes that would repeat the same
+        # fit are not executed, so they are not counted either)
+        flop = float(Bc) * (Nc * sum(c * (c + 1) for c in gram_cols) + Nc * (K + 1) * (K + 2))
+        ach = flop / (kms * 1e-3) / 1e12
+        rl = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("pld"),
+              "kernel": "gram128_kernel + gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kms,
+              "mfma_busy_gram128": traffic_all.get("pld_gram128_mfma_busy"),
+              "note": "useful (upper-triangle) Gram flop — N*P*(P+1) per PCA Gram (P = 121, 136, 816, 121) + N*(K+1)*(K+2) "
+                      "for the regression — over the WHOLE step time (eigen-solver, projections, LU, clipping included) "
+                      "against the fp64 MFMA dense peak.  mfma_busy_gram128: SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles of the "
+                      "816-column Gram kernel alone (profiles/, separate --pmc pass; not re-measured in this run)"}
+        return {"dt": dt, "kernel_ms": kms, "units_per_step": Bc, "steps": steps, "warmup": warmup,
+                "metric": "PLD cutouts/sec (design matrix + regression)", "unit": "cutouts/sec",
+                "workload": "configs[4]: %d K2-like 11x11-pixel cutouts x %d cadences, 3rd-order design matrix (K=%d), "
+                            "MFMA Gram per GPU" % (Bc, Nc, K), "roofline": rl, "accuracy": acc, "Nc": Nc}
+
+    # ================================================================================================ flatten block
+    def run_flatten(Bf, first_index, steps, warmup, base):
+        """LightCurve.flatten (window 401, polyorder 2, niters 3) on Bf light curves of N cadences through
+        lk_savgol_trend_batch_dev.  `base`: a cpu_baseline dict whose "_results" are trends of the first light curves of
+        this batch (scipy under conda, or the numpy port)."""
+        t, y, dy, off = synth.ls_batch(6, Bf, N, first_index=first_index)
+        d_t, d_y = torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev)
+        d_tr = torch.empty_like(d_y)
+
+        def step(e0, e1):
+            e0.record()
+            _capi._check(lib.lk_savgol_trend_batch_dev(handle._h, Bf, off.ctypes.data_as(i64p),
+                                                       vp(d_t.data_ptr()), vp(d_y.data_ptr()), None, 401, 2, 5.0, 3, 3.0,
+                                                       vp(d_tr.data_ptr()), None, vp(stream)))
+            e1.record()
+
+        dt, kms = timed(step, warmup, steps)
+        acc = None
+        if base is not None and "_results" in base and first_index == 0:
+            kept = base.pop("_results")   # the reference trends of the first light curves of this batch, full config shape
+            tr = d_tr.cpu().numpy()
+            rel = []
+            for i, ref_tr in enumerate(kept[:Bf]):
+                mine = tr[off[i]:off[i + 1]]
+                okm = np.isfinite(ref_tr)
+                rel.append(float(np.max(np.abs(mine[okm] - ref_tr[okm]) / np.abs(ref_tr[okm]))) if np.array_equal(okm, np.isfinite(mine)) else float("inf"))
+            acc = {"reference": ("scipy savgol_filter + interp1d (the reference's own calls) inside the restated loop of "
+                                 "LightCurve.flatten, run under conda on this box" if base.get("kind") == "reference" else
+                                 "numpy port of LightCurve.flatten (scipy savgol semantics)") +
+                                ", %d light curves x %d cadences, window 401" % (len(rel), N),
+                   "trend_relerr_max": max(rel), "tolerance": 1e-10}
+        algo = 24.0 * float(off[-1])
+        rl = {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "traffic": traffic_all.get("flatten"), "kernel": "flatten_kernel", "kernel_ms_per_step": kms,
+              "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
+        return {"dt": dt, "kernel_ms": kms, "units_per_step": int(off[-1]), "steps": steps, "warmup": warmup,
+                "metric": "flatten cadences/sec (window 401, niters 3)", "unit": "cadences/sec",
+                "workload": "flatten: %d light curves x %d cadences, window 401, polyorder 2, niters 3 per GPU" % (Bf, N),
+                "roofline": rl, "accuracy": acc}
+
+    def block_of(res, base):
+        """JSON block of a secondary workload inside the default line."""
+        val = res["units_per_step"] * world * res["steps"] / res["dt"]
+        blk = {"metric": res["metric"], "value": val, "unit": res["unit"], "steps": res["steps"], "warmup": res["warmup"],
+               "ms_per_step": 1e3 * res["dt"] / res["steps"], "scaling": "weak", "config": {"workload": res["workload"]},
+               "roofline": res["roofline"]}
+        if res.get("accuracy"):
+            blk["accuracy"] = res["accuracy"]
+        if base is not None:
+            blk["cpu_baseline"] = {k: v for k, v in base.items() if not k.startswith("_")}
+            blk["speedup_vs_cpu_baseline"] = val / base["value"]
+        return blk
 
     if args.workload == "ls":
         # ---- synthetic inputs (SURVEY.md 8(d)); rank r owns targets [first, first + B)
@@ -707,6 +891,15 @@ def main():
             if ref is not None and "bls" in ref and rank == 0:
                 blk["accuracy"] = bls_accuracy(bres, ref["bls"])
             extra["bls"] = blk
+        # ---- configs[4] PLD and LightCurve.flatten: the other two rows of the hot path, same protocol
+        if not args.no_pld:
+            torch.cuda.empty_cache()
+            pres = run_pld(args.cutouts, rank * args.cutouts, max(1, min(args.steps, 5)), 1, cpu_base_pld)
+            extra["pld"] = block_of(pres, cpu_base_pld)
+        if not args.no_flatten:
+            torch.cuda.empty_cache()
+            fres = run_flatten(args.flatten_targets, rank * args.flatten_targets, max(1, min(args.steps, 10)), 1, cpu_base_flat)
+            extra["flatten"] = block_of(fres, cpu_base_flat)
     elif args.workload == "bls":
         bres = run_bls(B, first, args.steps, args.warmup)
         dt, kern_ms = bres["dt"], bres["kernel_ms"]
@@ -715,103 +908,20 @@ def main():
         if ref is not None and "bls" in ref and rank == 0:
             extra["accuracy"] = bls_accuracy(bres, ref["bls"])
     elif args.workload == "pld":
-        Bc, Nc, npix = args.cutouts, args.pld_cadences, 11
-        P = npix * npix
-        cubes = [synth.pld_cutout(4, rank * Bc + i, n=Nc, npix=npix) for i in range(Bc)]
-        tt = np.stack([c[0] for c in cubes])
-        pix = np.stack([c[1].reshape(Nc, P) for c in cubes]).astype(np.float32)
-        epx = np.stack([c[2].reshape(Nc, P) for c in cubes]).astype(np.float32)
-        lcf = pix.sum(axis=2, dtype=np.float32)
-        lce = np.sqrt((epx.astype(np.float64) ** 2).sum(axis=2))
-        deg, nkn = 5, Nc // 50
-        n_inner = nkn - deg - 1
-        knots = np.stack([np.concatenate([[t_.min()], np.percentile(t_, np.linspace(0, 100, n_inner + 2)[1:-1]), [t_.max()]])
-                          for t_ in tt])
-        K = _capi.pld_design_width(P, P, 3, 16, nkn)
-        d_pix, d_lcf, d_t, d_kn = (torch.from_numpy(a).to(dev) for a in (pix, lcf, tt, knots))
-        d_y, d_err = torch.from_numpy(lcf.astype(np.float64).ravel()).to(dev), torch.from_numpy(lce.ravel()).to(dev)
-        d_X = torch.empty((Bc, Nc, K), dtype=torch.float64, device=dev)
-        d_ps = torch.empty((Bc, K), dtype=torch.float64, device=dev)
-        d_mu = torch.zeros((Bc, K), dtype=torch.float64, device=dev)
-        d_w = torch.empty((Bc, K), dtype=torch.float64, device=dev)
-        d_model = torch.empty(Bc * Nc, dtype=torch.float64, device=dev)
-        d_out = torch.empty(Bc * Nc, dtype=torch.uint8, device=dev)
-        offp = np.arange(Bc + 1, dtype=np.int64) * Nc
-
-        def step(e0, e1):
-            e0.record()
-            _capi._check(lib.lk_pld_design_batch_dev(handle._h, Bc, Nc, P, P, vp(d_pix.data_ptr()), vp(d_pix.data_ptr()),
-                                                     vp(d_lcf.data_ptr()), vp(d_t.data_ptr()), vp(d_kn.data_ptr()),
-                                                     n_inner, 3, 16, nkn, deg, 1, K, vp(d_X.data_ptr()),
-                                                     vp(d_ps.data_ptr()), vp(stream)))
-            _capi._check(lib.lk_regress_batch_dev(handle._h, Bc, offp.ctypes.data_as(i64p), K,
-                                                  vp(d_X.data_ptr()), vp(d_y.data_ptr()), vp(d_err.data_ptr()), None,
-                                                  vp(d_mu.data_ptr()), vp(d_ps.data_ptr()), 5.0, 5, vp(d_w.data_ptr()),
-                                                  vp(d_model.data_ptr()), vp(d_out.data_ptr()), vp(stream)))
-            e1.record()
-
-        dt, kern_ms = timed(step, args.warmup, args.steps)
-        units_per_step = Bc * world
-        if cpu_base is not None and "_results" in cpu_base:
-            # accuracy at the FULL config shape: the product path (PLDCorrector mirror: design matrix, regression, restored
-            # trend) on the cutouts the numpy/LAPACK port just corrected
-            from lightkurve_amd.correctors.pldcorrector import PixelCube, pld_correct_batch
-            kept = cpu_base.pop("_results")
-            cubes2 = [PixelCube(cubes[i][0], cubes[i][1], cubes[i][2], mission="K2") for i in range(len(kept))]
-            corr, outl = pld_correct_batch(cubes2, pld_order=3, pca_components=16)
-            relerr = [float(np.max(np.abs(corr[i] - kept[i][0])) / np.median(kept[i][0])) for i in range(len(kept))]
-            extra["accuracy"] = {"reference": "numpy/LAPACK port of PLDCorrector.correct (exact SVD), %d cutouts 11x11 x %d "
-                                              "cadences, order 3, 16 components" % (len(kept), Nc),
-                                 "corrected_flux_relerr_max": max(relerr),
-                                 "outlier_masks_equal": "%d/%d" % (sum(int(np.array_equal(outl[i], kept[i][1])) for i in range(len(kept))), len(kept))}
-        gram_cols = [P, 136, 816, P]
-        # MFMA flop: the four PCA Grams + ONE regression Gram (the clip loop stops at its fixed point: later passes that
-        # would repeat the same fit are not executed, so they are not counted either)
-        flop = float(Bc) * (2.0 * Nc * sum(c * c for c in gram_cols) + 1 * 2.0 * Nc * (K + 1) ** 2)
-        metric, unit = "PLD cutouts/sec (design matrix + regression)", "cutouts/sec"
-        workload = ("configs[4]: %d K2-like 11x11-pixel cutouts x %d cadences, 3rd-order design matrix (K=%d), "
-                    "MFMA Gram per GPU" % (Bc, Nc, K))
-        ach = flop / (kern_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("pld"),
-                    "kernel": "gram128_kernel + gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
-                    "note": "algorithmic 2*N*P^2 flop per PCA Gram (P = 121, 136, 816, 121) + 1 x 2*N*(K+1)^2 "
-                            "for the regression (clip passes after the fixed point are skipped, not counted), over the WHOLE step time (eigen-solver, projections, LU, "
-                            "clipping included), against the fp64 MFMA dense peak; the 816-column Gram alone "
-                            "(gram128_kernel, 25.3 ms) keeps the matrix cores 75 % busy "
-                            "(profiles/r02_pld_pmc_sq.txt: SQ_VALU_MFMA_BUSY_CYCLES)"}
-        B, N = Bc, Nc
+        pres = run_pld(args.cutouts, rank * args.cutouts, args.steps, args.warmup, cpu_base)
+        dt, kern_ms = pres["dt"], pres["kernel_ms"]
+        units_per_step = pres["units_per_step"] * world
+        metric, unit, workload, roofline = pres["metric"], pres["unit"], pres["workload"], pres["roofline"]
+        if pres["accuracy"]:
+            extra["accuracy"] = pres["accuracy"]
+        B, N = args.cutouts, pres["Nc"]
     elif args.workload == "flatten":
-        t, y, dy, off = synth.ls_batch(6, B, N, first_index=first)
-        d_t, d_y = torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev)
-        d_tr = torch.empty_like(d_y)
-
-        def step(e0, e1):
-            e0.record()
-            _capi._check(lib.lk_savgol_trend_batch_dev(handle._h, B, off.ctypes.data_as(i64p),
-                                                       vp(d_t.data_ptr()), vp(d_y.data_ptr()), None, 401, 2, 5.0, 3, 3.0,
-                                                       vp(d_tr.data_ptr()), None, vp(stream)))
-            e1.record()
-
-        dt, kern_ms = timed(step, args.warmup, args.steps)
-        units_per_step = int(off[-1]) * world
-        if cpu_base is not None and "_results" in cpu_base and first == 0:
-            kept = cpu_base.pop("_results")   # the port's trends of the first light curves of this batch, full config shape
-            tr = d_tr.cpu().numpy()
-            rel = []
-            for i, ref_tr in enumerate(kept[:B]):
-                mine = tr[off[i]:off[i + 1]]
-                okm = np.isfinite(ref_tr)
-                rel.append(float(np.max(np.abs(mine[okm] - ref_tr[okm]) / np.abs(ref_tr[okm]))) if np.array_equal(okm, np.isfinite(mine)) else float("inf"))
-            extra["accuracy"] = {"reference": "numpy port of LightCurve.flatten (scipy savgol semantics), %d light curves x %d "
-                                              "cadences, window 401" % (len(rel), N), "trend_relerr_max": max(rel)}
-        metric, unit = "flatten cadences/sec (window 401, niters 3)", "cadences/sec"
-        workload = "flatten: %d light curves x %d cadences, window 401, polyorder 2, niters 3 per GPU" % (B, N)
-        algo = 24.0 * float(off[-1])
-        roofline = {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "traffic": traffic_all.get("flatten"), "kernel": "flatten_kernel", "kernel_ms_per_step": kern_ms,
-                    "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
+        fres = run_flatten(B, first, args.steps, args.warmup, cpu_base)
+        dt, kern_ms = fres["dt"], fres["kernel_ms"]
+        units_per_step = fres["units_per_step"] * world
+        metric, unit, workload, roofline = fres["metric"], fres["unit"], fres["workload"], fres["roofline"]
+        if fres["accuracy"]:
+            extra["accuracy"] = fres["accuracy"]
     elif args.workload == "regress":
         Bc, Nc, K = args.cutouts, args.pld_cadences, args.regressors
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -837,14 +947,14 @@ def main():
 
         dt, kern_ms = timed(step, args.warmup, args.steps)
         units_per_step = Bc * world
-        flop = float(Bc) * 1 * 2.0 * Nc * (K + 1) ** 2   # ONE Gram build: clip passes after the fixed point are skipped
+        flop = float(Bc) * Nc * (K + 1) * (K + 2)   # ONE Gram build (upper triangle: what the kernel executes); later clip passes are skipped
         metric, unit = "RegressionCorrector fits/sec (N=%d, K=%d, 5 sigma-clip iterations)" % (Nc, K), "fits/sec"
         workload = "configs[4] regression stage: %d fits, N=%d cadences, K=%d regressors per GPU" % (Bc, Nc, K)
         ach = flop / (kern_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
                     "kernel": "gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kern_ms,
-                    "note": "algorithmic 2*N*(K+1)^2 flop for ONE Gram build per fit (SURVEY.md 8(d) counts one per clip "
+                    "note": "useful N*(K+1)*(K+2) flop (upper triangle) for ONE Gram build per fit (SURVEY.md 8(d) counts one per clip "
                             "pass; a target whose pass adds no outlier has reached the fixed point of the reference's "
                             "loop and its remaining passes — identical by construction — are skipped, so only the first "
                             "is counted); each executed pass also runs an LU solve, a model product and a sigma-clip"}

@@ -3,26 +3,25 @@
 // Replaces astropy methods.bls_fast -> C run_bls behind BoxLeastSquaresPeriodogram.from_lightcurve
 // (reference: src/lightkurve/periodogram.py:1161-1169; algorithm: SURVEY.md App. B.2).  Compiled with
 // -ffp-contract=off: every product, sum and quotient rounds separately, exactly as the reference C does,
-// and every per-bin sum is accumulated in cadence order, so for time-sorted input all seven outputs are
+// and every per-bin sum is accumulated in cadence order, so all seven outputs are
 // BIT-IDENTICAL to the reference (tests/test_bls_gpu.py compares with ==).
 //
-// One 256-thread workgroup per (target, period); everything lives in LDS:
-//   pass A  round boundaries.  A "round" is a maximal run of cadences whose bin index does not decrease, so every
-//           bin is touched by ONE contiguous run of cadences per round.  Time-sorted targets (flagged by the prep
-//           kernel): rounds are the cycles k = floor(t/P), found by one binary search each; otherwise two sweeps with
-//           the exact (k, r) = (trunc(t/P), fmod(t, P)) by fma remainder with +-1 correction.
-//   pass B  ordered histogram.  Bins are split into NW contiguous ranges, one per wave; a wave walks the rounds in
-//           order over its own bins (no workgroup barrier).  Per 64-cadence chunk the leader lane of each equal-bin run
-//           folds the run's members (parked in LDS) into the bin one cadence at a time: the reference's order.
-//   wrap    pad + sequential inclusive prefix sums (lane 0: y, lane 1: ivar; sequential = same rounding).
-//   scan    a thread owns a start bin and walks the durations in ascending length.  From each evaluation a rigorous
-//           bound on how fast the objective can grow with the window tells how many longer durations can be SKIPPED
-//           (they are strictly below the best seen so far); candidates that are reached pass a division-free
-//           conservative filter and only survivors run the reference's exact arithmetic (IEEE divisions), which alone
-//           decides the result.  Ties are broken by (caller's duration index, start bin) = the reference's
-//           duration-major / phase-minor "first wins" order.  The winner recomputes the reported statistics.
-// blockIdx -> (target, period) is XCD-aware (all periods of a target on one XCD; its t / y*ivar / ivar arrays,
-// 24 B per cadence, stay in that XCD's L2).
+// One team of waves per (target, period); everything lives in LDS (bls_team_body has the details):
+//   histogram  every cadence is added into its phase bin with an LDS floating-point atomic.  Same-address lanes of one
+//              ds_add_f64 are applied in lane order and a wave's LDS instructions execute in program order (measured:
+//              tools/microbench/lds_atomic_order.hip; re-checked on the device by bls_selftest_kernel), so a bin
+//              accumulates in cadence order — the reference's order — with no sorting, rounds or leader election.  Up to
+//              four waves share the arithmetic; a ticket in LDS keeps their atomics in cadence-group order.
+//   wrap       pad, then sequential inclusive prefix sums: a loads-only serial pass keeps every 32nd running sum, then
+//              all threads re-run the 32-bin blocks from those exact carries (same operands, same order: same bits).
+//   scan       a lane owns a start bin and walks the durations in ascending length.  Block maxima of
+//              Z = S*W - E*Y (Nn(n, dur) = Z[n + dur] - Z[n]) bound whole blocks of 64 / 8 end bins at once, a rigorous
+//              growth bound skips further, candidates that are reached pass a division-free conservative filter and only
+//              survivors run the reference's exact arithmetic (IEEE divisions), which alone decides the result.  Ties are
+//              broken by (caller's duration index, start bin) = the reference's "first wins" order.
+// Short periods (two thirds of a grid uniform in frequency) pack up to eight one-wave teams into a workgroup that shares
+// the duration tables and the serial prefix pass.  blockIdx -> (target, period) is XCD-aware (all periods of a target on
+// one XCD; its t / y*ivar / ivar arrays, 24 B per cadence, stay in that XCD's L2).
 #include <cfloat>
 #include <cstdlib>
 #include <cmath>
@@ -110,477 +109,10 @@ __device__ __forceinline__ int bin_of_fast(double r, double bin_duration, double
     return bin_of(r, bin_duration);
 }
 
-constexpr int BLS_RMAX = 256;   // most rounds ever kept (4-wave blocks)
-constexpr int BLS_RSEG = 768;   // ints reserved for the per-round wave boundaries: (NW-1) * (BLS_RSEG/NW)  // round boundaries kept in LDS; more rounds (badly unsorted time) -> serial path
-
 struct BlsBest {
     double obj;
     int k, n;
 };
-
-// amdgpu_waves_per_eu(8, 8): 57 VGPRs without a spill instead of the 66 the allocator takes by itself — the short-period
-// groups then fit 8 workgroups per CU instead of 7 (-1.4 % on configs[3])
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void bls_kernel(
-    const double *__restrict__ tm, const double2 *__restrict__ yw,
-    const int64_t *__restrict__ n_off, const BlsStats *__restrict__ stats, const double *__restrict__ period,
-    const int *__restrict__ pidx, int np_group, int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur,
-    double bin_duration, int oversample, int obj_flag, double *__restrict__ out7, int ablate,
-    unsigned long long *__restrict__ prof) {  // prof: LK_BLS_PROF=1 debug only (per-phase 100 MHz ticks, summed by atomics)
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS is dynamic: keeps the base 16-B aligned
-
-    unsigned long long t_last = prof ? wall_clock64() : 0ull;
-#define BLS_LAP(slot_)                                                        \
-    do {                                                                      \
-        if (prof && threadIdx.x == 0) {                                       \
-            const unsigned long long now_ = wall_clock64();                   \
-            atomicAdd(&prof[slot_], now_ - t_last);                           \
-            t_last = now_;                                                    \
-        }                                                                     \
-    } while (0)
-    const unsigned bid = blockIdx.x;
-    const unsigned xcd = bid & 7u, slot = bid >> 3;
-    const int target = (int)((slot / (unsigned)np_group) * 8u + xcd);
-    if (target >= B) return;
-    const int p = pidx[slot % (unsigned)np_group];
-    const int tid = threadIdx.x;
-    const double P = period[p];
-    const double invP = 1.0 / P;
-    const int n_bins = (int)(ceil(P / bin_duration)) + oversample;
-    const int64_t lo = n_off[target];
-    const int N = (int)(n_off[target + 1] - lo);
-    tm += lo;
-    yw += lo;
-
-    // LDS carve (every offset a multiple of 16): bins | s_best[NT] | rstart | s_cnt | s_thr | segs
-    const int NT = blockDim.x, NW = NT >> 6;  // 4, 8 or 16 waves: big-LDS (long-period) groups get more waves
-    const int rmax = BLS_RSEG / NW;           // rounds kept in LDS; beyond that the serial path runs
-    double2 *bins = reinterpret_cast<double2 *>(smem);  // [n_bins + 1] (y, ivar)
-    char *after = smem + (size_t)(n_bins + 1) * 16;
-    BlsBest *s_best = reinterpret_cast<BlsBest *>(after);                       // [NT]
-    int *rstart = reinterpret_cast<int *>(after + (size_t)NT * sizeof(BlsBest));  // [BLS_RMAX + 4]
-    int *s_cnt = rstart + (BLS_RMAX + 4);                                       // [16]
-    long long *s_thr = reinterpret_cast<long long *>(s_cnt + 16);               // 8-B aligned
-    long long *s_red = reinterpret_cast<long long *>(s_cnt + 18);               // gmax, wmax (bit patterns), yabs (double)
-    int *segs = s_cnt + 32;                                                     // [(NW-1) * rmax] <= BLS_RSEG
-    // duration tables (sorted ascending by length): dur_bins[k] (k = n_dur: a sentinel no window fits), the caller's
-    // index korig[k] (tie-break order) and first_kd[L] = k | dur_bins[k] << 16 for the first k with dur_bins[k] >= L,
-    // L = 0 .. max_dur + 1
-    int *dur_bins = segs + BLS_RSEG;
-    int *korig = dur_bins + n_dur + 1;
-    int *first_kd = korig + n_dur;
-    for (int i = tid; i < 2 * n_dur + 1 + max_dur + 2; i += blockDim.x) dur_bins[i] = dur_tab[i];
-
-    for (int i = tid; i <= n_bins; i += NT) bins[i] = make_double2(0.0, 0.0);
-
-    // ---- pass A: round boundaries.  Wave w sweeps cadences [w*Q, (w+1)*Q) 64 at a time (coalesced loads); the
-    //      predecessor's (k, r) comes from the lane below (lane 0: carried from the previous sweep step).
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int Q = (((N + NW - 1) / NW) + 63) & ~63;
-    const int w0 = min(wave * Q, N), w1 = min(w0 + Q, N);
-    auto sweep = [&](int write_base) -> int {
-        int found = 0;
-        double kc = -1.0, rc = 0.0;  // carry: (k, r) of cadence i0 - 1
-        if (w0 > 0 && w0 < N) fold_exact(tm[w0 - 1], P, invP, &kc, &rc);
-        for (int i0 = w0; i0 < w1; i0 += 64) {
-            const int i = i0 + lane;
-            double k = -1.0, r = 0.0;
-            if (i < w1) fold_exact(tm[i], P, invP, &k, &r);
-            double kp = __shfl_up(k, 1), rp = __shfl_up(r, 1);
-            if (lane == 0) {
-                kp = kc;
-                rp = rc;
-            }
-            const bool flag = (i < w1) && (i > 0) && (k != kp || r < rp);
-            const unsigned long long bal = __ballot(flag);
-            if (write_base >= 0 && flag) {
-                const int pos = write_base + found + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pos <= rmax) rstart[pos] = i;
-            }
-            found += __popcll(bal);
-            kc = __shfl(k, 63);
-            rc = __shfl(r, 63);
-        }
-        return found;
-    };
-    // Time-sorted targets (the common case; flagged by bls_prep_kernel): inside one cycle k the phase r = t - k P
-    // grows with the cadence index, so the rounds are exactly the runs of equal k and round k starts at the first
-    // cadence with floor(t / P) >= k — one binary search per round instead of two sweeps over all cadences.
-    const bool tsorted = stats[target].sorted != 0.0 && !(ablate & 16);
-    int nrounds = 1;
-    bool serial = false;
-    if (tsorted) {
-        double kl, rl;
-        fold_exact(tm[N - 1], P, invP, &kl, &rl);
-        serial = !(kl + 1.0 <= (double)rmax);
-        nrounds = serial ? 1 : (int)kl + 1;
-        if (!serial)
-            for (int q = tid; q <= nrounds; q += NT) {
-                int lo_i = 0, hi_i = N;  // first i with k_i >= q (q = nrounds: N)
-                while (lo_i < hi_i) {
-                    const int mid = (lo_i + hi_i) >> 1;
-                    double k, r;
-                    fold_exact(tm[mid], P, invP, &k, &r);
-                    if (k < (double)q)
-                        lo_i = mid + 1;
-                    else
-                        hi_i = mid;
-                }
-                rstart[q] = lo_i;
-            }
-        if (tid == 0) {
-            *s_thr = __double_as_longlong(-INFINITY);
-            s_red[0] = s_red[1] = s_red[2] = 0;
-        }
-        __syncthreads();
-    } else {
-        {
-            const int cnt = sweep(-1);
-            if (lane == 0) s_cnt[wave] = cnt;
-        }
-        __syncthreads();
-        int wbase = 1;  // round 0 starts at cadence 0
-        for (int w = 0; w < wave; ++w) wbase += s_cnt[w];
-        for (int w = 0; w < NW; ++w) nrounds += s_cnt[w];
-        serial = nrounds > rmax;
-        if (tid == 0) {
-            *s_thr = __double_as_longlong(-INFINITY);
-            s_red[0] = s_red[1] = s_red[2] = 0;
-            rstart[0] = 0;
-            if (!serial) rstart[nrounds] = N;
-        }
-        if (!serial && !(ablate & 8)) (void)sweep(wbase);
-        __syncthreads();
-    }
-
-    BLS_LAP(0);  // setup + round boundaries
-    // ---- pass B: ordered histogram
-    if (ablate & 1) {
-    } else if (serial) {
-        if (tid == 0) {
-            for (int i = 0; i < N; ++i) {
-                double k, r;
-                fold_exact(tm[i], P, invP, &k, &r);
-                const int ind = bin_of(r, bin_duration);
-                double2 v = bins[ind];
-                v.x += yw[i].x;
-                v.y += yw[i].y;
-                bins[ind] = v;
-            }
-        }
-        __syncthreads();
-    } else {
-        // Bins are split into four contiguous ranges, one per wave: inside a round the bin index is non-decreasing
-        // in cadence order, so each wave's cadences form one contiguous segment of the round, found by a
-        // per-thread binary search (all rounds x 3 boundaries at once).  A wave then walks the rounds in order on
-        // its own bins only: no workgroup barrier, and per-bin additions stay in cadence order.
-        const double inv_bd = 1.0 / bin_duration;
-        const int nb1 = NW - 1;
-        for (int q = tid; q < nb1 * nrounds; q += NT) {
-            const int rd = q / nb1, wb = q - nb1 * rd + 1;
-            const int bound = (int)(((long long)wb * (n_bins + 1)) / NW);  // first bin owned by wave wb
-            int lo_i = rstart[rd], hi_i = rstart[rd + 1];
-            while (lo_i < hi_i) {
-                const int mid = (lo_i + hi_i) >> 1;
-                double k, r;
-                if (tsorted)
-                    r = fma(-(double)rd, P, tm[mid]);  // the round index IS the cycle number: exact remainder
-                else
-                    fold_exact(tm[mid], P, invP, &k, &r);
-                if (bin_of_fast(r, bin_duration, inv_bd) < bound)
-                    lo_i = mid + 1;
-                else
-                    hi_i = mid;
-            }
-            segs[q] = lo_i;
-        }
-        __syncthreads();
-        // (round, 64-cadence chunk) pairs of this wave are walked as one flat sequence so the next chunk's three
-        // global loads are in flight while the current one is folded into the bins
-        int rd = -1, i0 = 0, s1 = 0;  // wave-uniform cursor
-        auto advance = [&]() {
-            i0 += 64;
-            while (i0 >= s1) {
-                if (++rd >= nrounds) return false;
-                i0 = __builtin_amdgcn_readfirstlane((wave == 0) ? rstart[rd] : segs[nb1 * rd + wave - 1]);
-                s1 = __builtin_amdgcn_readfirstlane((wave == NW - 1) ? rstart[rd + 1] : segs[nb1 * rd + wave]);
-            }
-            return true;
-        };
-        bool have = advance();
-        double c_t = 0.0;
-        double2 c_yw = make_double2(0.0, 0.0);
-        bool c_act = false;
-        if (have) {
-            c_act = i0 + lane < s1;
-            if (c_act) {
-                c_t = tm[i0 + lane];
-                c_yw = yw[i0 + lane];
-            }
-        }
-        while (have) {
-            const bool act = c_act;
-            const double tv = c_t, vy = c_yw.x, vi = c_yw.y;  // inactive lanes hold stale values nobody reads
-            const double kcur = (double)rd;  // cycle number of the chunk being folded (time-sorted targets)
-            have = advance();
-            if (have) {
-                c_act = i0 + lane < s1;
-                if (c_act) {
-                    c_t = tm[i0 + lane];
-                    c_yw = yw[i0 + lane];
-                }
-            }
-            // every lane adds its cadence with LDS atomics: same-address lanes of one ds_add_f64 are applied in lane order
-            // (= cadence order) and the wave's LDS instructions run in program order, so the bin sums keep the reference's
-            // order without leader election (tools/microbench/lds_atomic_order.hip; checked again by bls_selftest_kernel)
-            if (act) {
-                double k, r;
-                if (tsorted)
-                    r = fma(-kcur, P, tv);
-                else
-                    fold_exact(tv, P, invP, &k, &r);
-                const int ind = bin_of_fast(r, bin_duration, inv_bd);
-                atomicAdd(&bins[ind].x, vy);
-                atomicAdd(&bins[ind].y, vi);
-            }
-        }
-        __syncthreads();
-    }
-
-    BLS_LAP(1);  // histogram (incl. the segment searches)
-    // ---- wrap pad (reference: for n=1..oversample: mean[n_bins-oversample+n-1] = mean[n], in that order),
-    //      then sequential inclusive prefix sums (y on wave 0, ivar on wave 1)
-    if (n_bins - oversample > oversample) {  // source [1, os] and destination [n_bins-os, n_bins-1] are disjoint
-        for (int q = 1 + tid; q <= oversample; q += NT) bins[n_bins - oversample + q - 1] = bins[q];
-    } else if (tid == 0) {
-        for (int q = 1; q <= oversample; ++q) bins[n_bins - oversample + q - 1] = bins[q];
-    }
-    __syncthreads();
-    // constants of the scan's skip bound, from the per-bin sums while they are still per-bin
-    const BlsStats st = stats[target];
-    const double sum_y = st.sum_y, sum_ivar = st.sum_ivar;
-    {
-        double g = 0.0, wm = 0.0, ya = 0.0;
-        for (int i = 1 + tid; i <= n_bins; i += NT) {
-            const double2 v = bins[i];
-            g = fmax(g, fabs(sum_y * v.y - sum_ivar * v.x));
-            wm = fmax(wm, v.y);
-            ya += fabs(v.x);
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            g = fmax(g, __shfl_xor(g, o));
-            wm = fmax(wm, __shfl_xor(wm, o));
-            ya += __shfl_xor(ya, o);
-        }
-        if (lane == 0) {
-            atomicMax(&s_red[0], __double_as_longlong(g));
-            atomicMax(&s_red[1], __double_as_longlong(wm));
-            atomicAdd(reinterpret_cast<double *>(&s_red[2]), ya * (1.0 + 1e-6));
-        }
-    }
-    __syncthreads();
-    BLS_LAP(2);  // wrap pad + gmax / wmax reductions
-    // Sequential chain acc = bins[i] + acc in index order (same rounding as the reference loop).  bins[0] is always
-    // (0, 0), so starting at i = 0 with acc = 0 is the same chain.
-    if (wave == 0 && lane < 2 && !(ablate & 2)) {
-        // lane 0 runs the y chain, lane 1 the ivar chain (same instruction stream, adjacent addresses): per bin one
-        // LDS read, one dependent add and one LDS write, eight bins in flight
-        double acc = 0.0;
-        double *comp = reinterpret_cast<double *>(bins) + lane;  // .x for lane 0, .y for lane 1 (stride 2 doubles)
-        const int total = n_bins + 1, nfull = total >> 3;
-        double x[8], nx[8];
-        if (nfull > 0) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = comp[2 * u];
-        }
-        for (int it = 0; it < nfull; ++it) {  // the next eight bins load while the dependent adds of these eight run
-            double *cp = comp + (it << 4);
-            if (it + 1 < nfull) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) nx[u] = cp[16 + 2 * u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                acc = x[u] + acc;
-                x[u] = acc;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) cp[2 * u] = x[u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = nx[u];
-        }
-        for (int i = nfull << 3; i < total; ++i) {
-            acc = comp[2 * i] + acc;
-            comp[2 * i] = acc;
-        }
-    }
-    __syncthreads();
-    BLS_LAP(3);  // prefix chains
-
-    // ---- scan
-    // A thread owns start bins n = tid, tid + NT, ... and walks the durations in ascending length.  With a = y_out sum,
-    // b = ivar_in, c = y_in sum, e = ivar_out and Nn = a*b - c*e = S*b - E*c (S, E the totals):
-    //     likelihood  0.5*b*(a/e - c/b)^2 = 0.5*Nn^2 / (b*e^2)        snr  (a/e - c/b)/sqrt(1/b+1/e) = Nn / sqrt(b*e*E)
-    // (1) skip-ahead: growing the window by one bin changes Nn by at most gmax, only raises b, lowers e by at most wmax,
-    //     so from one evaluation the largest m with "every window up to m bins longer is STRICTLY below thr" follows
-    //     in closed form (1e-4 safety factors, absolute slack far above the prefix-sum rounding); the walk jumps there.
-    // (2) candidates that are reached go through a division-free conservative filter with an absolute slack eN >= every
-    //     rounding the exact chain can commit, so a rejected candidate is STRICTLY below the threshold and can never be
-    //     the winner (ties always reach the exact path).
-    // (3) survivors (a handful per workgroup) run the reference's exact arithmetic, which alone decides the result.
-    // thr = the best objective seen so far by anyone in the workgroup (s_thr), warm-started from a coarse lattice.
-    double best = -INFINITY;
-    int bk = -1, bn = -1;
-    if (!(ablate & 4)) {
-        const double S = sum_y, E = sum_ivar;
-        const double gmax = __longlong_as_double(s_red[0]) * (1.0 + 1e-9);  // max_i |S w_i - E y_i|
-        const double wmax = __longlong_as_double(s_red[1]);                 // max_i w_i
-        const double yabs = __longlong_as_double(s_red[2]);                 // sum_i |y_i|
-        // |Nn computed from the rounded prefix sums - Nn of the real bin sums| is below ~n_bins eps E (|S| + yabs);
-        // 1e-9 leaves four orders of magnitude
-        const double slack = 1e-9 * E * (fabs(S) + yabs);
-        const int dmin = dur_bins[0];
-        // conservative filter, then the reference's exact arithmetic; keeps the FIRST best in (caller's duration
-        // index, start bin) order
-        auto finish = [&](int n, int kc, double y_in, double ivar_in, double ivar_out, double Nn, double eN, double thr) {
-            if (Nn + eN < 0.0) return;  // certainly y_out < y_in
-            {
-                const double m = fabs(Nn) + eN;
-                double lhs, rhs;
-                if (obj_flag) {
-                    lhs = 0.5 * m * m;
-                    rhs = thr * ivar_in * ivar_out * ivar_out;
-                } else {
-                    lhs = m * m;
-                    rhs = (thr < 0.0 ? -1.0 : thr * thr) * ivar_in * ivar_out * (ivar_in + ivar_out);
-                }
-                if (lhs * (1.0 + 1e-12) < rhs) return;  // certainly objective < thr
-            }
-            double y_out = S - y_in;
-            y_in /= ivar_in;
-            y_out /= ivar_out;
-            double obj;
-            if (obj_flag) {
-                const double arg = y_out - y_in;
-                obj = 0.5 * ivar_in * arg * arg;
-            } else {
-                const double depth = y_out - y_in;
-                const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
-                obj = depth / depth_err;
-            }
-            if (y_out >= y_in &&
-                (obj > best || (obj == best && (korig[kc] < korig[bk] || (kc == bk && n < bn))))) {
-                best = obj;
-                bk = kc;
-                bn = n;
-                atomicMax(s_thr, __double_as_longlong(obj));  // obj >= 0 here: the bit pattern orders like the value
-            }
-        };
-        // ---- warm start: every 8th start bin x every 8th duration (1.6 % of the candidates) gives the walk below a
-        //      threshold close to the final best from its first step
-        if (!(ablate & 128)) {
-            const int cn = (n_bins - dmin) / 8 + 1, ck = (n_dur + 7) / 8;
-            for (int c = tid; c < cn * ck; c += NT) {
-                const int kc = (c / cn) * 8, n = (c - (c / cn) * cn) * 8;
-                const int dur = dur_bins[kc];
-                if (n + dur > n_bins) continue;
-                const double2 lw = bins[n], hi = bins[n + dur];
-                const double y_in = hi.x - lw.x, ivar_in = hi.y - lw.y, ivar_out = E - ivar_in;
-                if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
-                const double ab = S * ivar_in, ce = E * y_in;
-                finish(n, kc, y_in, ivar_in, ivar_out, ab - ce, (fabs(ab) + fabs(ce)) * 1e-15,
-                       fmax(best, __longlong_as_double(*s_thr)));
-            }
-            __syncthreads();
-        }
-        for (int n = tid; n + dmin <= n_bins; n += NT) {
-            const double2 lw = bins[n];
-            double thr_sh = __longlong_as_double(*s_thr);  // workgroup-wide best so far
-            int k = 0, dur_k = dmin;  // dur_k == dur_bins[k] (the sentinel once k == n_dur)
-            while (n + dur_k <= n_bins) {  // durations ascend: once one overruns, every later one does too
-                const int dur = dur_k, kc = k;
-                const double2 hi = bins[n + dur];
-                dur_k = dur_bins[++k];
-                const double thr = fmax(best, thr_sh);  // one iteration stale: still a valid (lower) bound
-                thr_sh = __longlong_as_double(*s_thr);
-                const double y_in = hi.x - lw.x;
-                const double ivar_in = hi.y - lw.y;
-                const double ivar_out = E - ivar_in;
-                if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
-                // Nn = y_out ivar_in - y_in ivar_out = S ivar_in - E y_in in real arithmetic
-                const double ab = S * ivar_in, ce = E * y_in;
-                const double Nn = ab - ce;
-                // ---- how many more bins this window may grow before it could reach thr: growing by one bin moves
-                //      Nn by at most gmax, ivar_in only up, ivar_out down by at most wmax
-                if (thr > 0.0 && !(ablate & 64)) {
-                    double mf;
-                    if (obj_flag) {
-                        const double q = __builtin_amdgcn_sqrt(2.0 * thr * ivar_in) * (1.0 - 1e-4);
-                        mf = (q * ivar_out - Nn - slack) * __builtin_amdgcn_rcp(gmax + q * wmax) * (1.0 - 1e-4) - 1.0;
-                    } else {
-                        const double e_lo = ivar_out - 64.0 * wmax;
-                        const double q = thr * __builtin_amdgcn_sqrt(ivar_in * e_lo * E) * (1.0 - 1e-4);
-                        mf = e_lo > 0.0 ? fmin((q - Nn - slack) * __builtin_amdgcn_rcp(gmax) * (1.0 - 1e-4) - 1.0, 64.0) : 0.0;
-                    }
-                    if (mf >= 1.0) {
-                        const int m = (int)fmin(mf, 1.0e6);
-                        const int kd = first_kd[min(dur + m, max_dur) + 1];  // >= kc + 1 since dur_bins[kc] < dur + m + 1
-                        k = kd & 0xffff;
-                        dur_k = (int)((unsigned)kd >> 16);
-                        continue;  // m >= 1 means this candidate itself is below thr as well
-                    }
-                }
-                finish(n, kc, y_in, ivar_in, ivar_out, Nn, (fabs(ab) + fabs(ce)) * 1e-15, thr);
-            }
-        }
-    }
-    s_best[tid] = BlsBest{best, bk, bn};
-    __syncthreads();
-    BLS_LAP(4);  // scan
-    for (int s = NT >> 1; s > 0; s >>= 1) {
-        if (tid < s) {
-            const BlsBest o = s_best[tid + s], m = s_best[tid];
-            const bool take = o.k >= 0 && (m.k < 0 || o.obj > m.obj ||
-                                            (o.obj == m.obj && (korig[o.k] < korig[m.k] || (o.k == m.k && o.n < m.n))));
-            if (take) s_best[tid] = o;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const BlsBest w = s_best[0];
-        const size_t stride = (size_t)B * (size_t)nP;
-        double *o = out7 + (size_t)target * (size_t)nP + (size_t)p;
-        if (w.k < 0) {
-            o[0] = -INFINITY;
-            for (int f = 1; f < 7; ++f) o[f * stride] = 0.0;
-        } else {
-            const int dur = dur_bins[w.k], n = w.n;
-            const double2 hi = bins[n + dur], lw = bins[n];
-            double y_in = hi.x - lw.x;
-            const double ivar_in = hi.y - lw.y;
-            double y_out = sum_y - y_in;
-            const double ivar_out = sum_ivar - ivar_in;
-            y_in /= ivar_in;
-            y_out /= ivar_out;
-            const double arg = y_out - y_in;
-            const double log_like = 0.5 * ivar_in * arg * arg;
-            const double depth = y_out - y_in;
-            const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
-            const double depth_snr = depth / depth_err;
-            const double duration = dur * bin_duration;
-            const double phase = fmod(n * bin_duration + 0.5 * duration + st.min_t, P);
-            o[0] = w.obj;
-            o[1 * stride] = depth;
-            o[2 * stride] = depth_err;
-            o[3 * stride] = duration;
-            o[4 * stride] = phase;
-            o[5 * stride] = depth_snr;
-            o[6 * stride] = log_like;
-        }
-    }
-    BLS_LAP(5);  // final reduction + outputs
-    if (prof && threadIdx.x == 0) atomicAdd(&prof[7], 1ull);
-#undef BLS_LAP
-}
 
 // ------------------------------------------------------------------------------------------------ team kernel
 // One workgroup ("team", NW = 1 .. 16 waves by LDS footprint) per (target, period); everything lives in LDS.
@@ -747,9 +279,7 @@ __device__ __forceinline__ void bls_team_body(
                 kd0 = kd1;
             }
             if (NH > 1) {
-                while (*s_ticket != g) {
-                    if (!(ablate & 512)) __builtin_amdgcn_s_sleep(1);
-                }
+                while (*s_ticket != g) __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
             }
 #pragma unroll
@@ -1361,14 +891,14 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     auto nbins_of = [&](int p) { return (int)(std::ceil(period_host[p] / bin_duration)) + oversample; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return period_host[a] > period_host[b]; });
     const int max_bins = nbins_of(order[0]);
-    auto lds_fixed_of = [&](int nt) {
-        return (size_t)nt * sizeof(BlsBest) + (size_t)(BLS_RMAX + 4) * 4 + 32 * 4 + (size_t)BLS_RSEG * 4 + tab_bytes;
+    const size_t tab_bytes16 = tab_bytes;
+    // LDS of one team: ya | wa | header | s_best[NW] | block maxima (bls_team_body's carve)
+    auto region_of = [&](int cap, int nw_) {
+        return ((size_t)cap * 16 + 48 + (size_t)nw_ * 16 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8 + 15) & ~(size_t)15;
     };
-    const size_t lds_fixed = lds_fixed_of(1024);
-    const size_t lds_max = (size_t)(max_bins + 1) * 16 + lds_fixed;
-    LK_REQUIRE(lds_max <= 156 * 1024,
-               "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most %d", max_bins,
-               (int)((156 * 1024 - lds_fixed) / 16 - 1));
+    LK_REQUIRE(tab_bytes16 + region_of((max_bins + 2) & ~1, 16) <= 156 * 1024,
+               "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most about %d", max_bins,
+               (int)((156 * 1024 - tab_bytes16 - 512) / 17.2));
 
     const size_t ntot = (size_t)n_off_host[B];
     h->ws.reset();
@@ -1390,8 +920,6 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     hipLaunchKernelGGL(bls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, ivar, d_off, d_tm, d_yw, d_stats);
 
     if (h->bls_attr_set != 1) {
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_team_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_team_deep_kernel),
@@ -1411,26 +939,18 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         }
         h->bls_attr_set = 1;
     }
-    int ablate = 0;
-    if (const char *e = getenv("LK_BLS_ABLATE")) ablate = atoi(e);  // profiling only: skips phases, results wrong
-    // LK_BLS_PROF=1 (debug): per-phase wall time of the teams (thread 0's clock) and the wall time of every launch
+    // debug knobs, read once per process: LK_BLS_ABLATE skips phases (results wrong; phase costs by difference),
+    // LK_BLS_PROF=1 prints the wall time of every launch, =2 adds per-phase clocks (their atomics distort short teams)
+    static const int ablate = getenv("LK_BLS_ABLATE") ? atoi(getenv("LK_BLS_ABLATE")) : 0;
+    static const int prof_level = getenv("LK_BLS_PROF") ? atoi(getenv("LK_BLS_PROF")) : 0;
+    const bool prof_on = prof_level != 0;
     unsigned long long *d_prof = nullptr;
-    const int prof_level = getenv("LK_BLS_PROF") ? atoi(getenv("LK_BLS_PROF")) : 0;  // 1: launch times; 2: + phases (the
-    const bool prof_on = prof_level != 0;                                            // in-kernel atomics distort short teams)
     if (prof_level >= 2) {
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_prof), 64));
         LK_HIP_CHECK(hipMemset(d_prof, 0, 64));
     }
-    const bool use_team = !(getenv("LK_BLS_TEAM") && atoi(getenv("LK_BLS_TEAM")) == 0);
-    int force_nw = 0;
-    if (const char *e = getenv("LK_BLS_NW")) force_nw = atoi(e);
-    const size_t tab_bytes16 = ((dur_tab.size() * 4 + 15) / 16) * 16;
-    int cut_den = 8;  // groups: cut when the LDS need drops below (cut_den - 1) / cut_den of the group's head
-    if (const char *e = getenv("LK_BLS_CUT")) cut_den = std::max(2, atoi(e));
-    int nh_cap = 4;  // histogram waves per team (ticket-ordered)
-    if (const char *e = getenv("LK_BLS_NH")) nh_cap = std::max(1, atoi(e));
-    int multi_minw = 16;  // multi-period workgroups when they keep at least this many waves per CU
-    if (const char *e = getenv("LK_BLS_MULTI_MINW")) multi_minw = atoi(e);
+    constexpr int kHistWaves = 4;   // ticket-ordered histogram waves per team (8 and 16 measure the same)
+    constexpr int kMultiMinWaves = 16;  // multi-period workgroups only where they keep this many waves per CU
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_on) {
         LK_HIP_CHECK(hipEventCreate(&pe0));
@@ -1442,64 +962,47 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         if (prof_on) LK_HIP_CHECK(hipEventRecord(pe0, stream));
         // groups: cut whenever the LDS need drops below 7/8 of the group's head (occupancy stays close to the need)
         size_t g1 = g0 + 1;
-        while (g1 < (size_t)nP && nbins_of(order[g1]) * (use_team ? cut_den : 4) >= head_bins * (use_team ? cut_den - 1 : 3)) ++g1;
+        while (g1 < (size_t)nP && nbins_of(order[g1]) * 8 >= head_bins * 7) ++g1;
         const int npg = (int)(g1 - g0);
-        const size_t nblocks = (size_t)((B + 7) / 8) * 8 * (size_t)npg;
-        LK_REQUIRE(nblocks < ((size_t)1 << 31), "grid too large");
+        const int cap = (head_bins + 2) & ~1;  // doubles per component array (even: both arrays 16-B aligned)
+        // shape: short periods -> G one-wave teams per workgroup (shared tables and prefix pass); long periods -> one
+        // team of NW waves.  Either way aim at the 24 wave slots the 80-VGPR build leaves per CU.
+        int multi = 0, nw = 1, gsel = 1, waves_cu = 0;
+        for (int gc : {8, 4, 2}) {
+            const size_t l = tab_bytes16 + (size_t)gc * region_of(cap, 1);
+            if (l > 156 * 1024) continue;
+            const int w = std::min(24, (int)((160 * 1024) / (l + 64)) * gc);
+            if (w > waves_cu) {
+                waves_cu = w;
+                gsel = gc;
+            }
+        }
         int nt;
         size_t lds;
-        if (use_team) {
-            const int cap = (head_bins + 2) & ~1;  // doubles per component array (even: both arrays 16-B aligned)
-            auto region_of = [&](int nw_) {
-                return ((size_t)cap * 16 + 48 + (size_t)nw_ * 16 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8 + 15) & ~(size_t)15;
-            };
-            // shape: short periods -> G one-wave teams per workgroup (shared tables and prefix pass); long periods -> one
-            // team of NW waves.  Either way aim at the 24 wave slots the 80-VGPR build leaves per CU.
-            int multi = 0, nw = 1, gsel = 1, waves_cu = 0;
-            for (int gc : {8, 4, 2}) {
-                const size_t l = tab_bytes16 + (size_t)gc * region_of(1);
-                if (l > 156 * 1024) continue;
-                const int w = std::min(24, (int)((160 * 1024) / (l + 64)) * gc);
-                if (w > waves_cu) {
-                    waves_cu = w;
-                    gsel = gc;
-                }
-            }
-            if (waves_cu >= multi_minw && force_nw <= 0) {
-                multi = 1;
-                if (force_nw < 0) gsel = -force_nw;  // LK_BLS_NW=-G: force G teams per workgroup (tuning)
-                nw = 1;
-                nt = 64 * gsel;
-                lds = tab_bytes16 + (size_t)gsel * region_of(1);
-                waves_cu = std::min(24, (int)((160 * 1024) / (lds + 64)) * gsel);
-            } else {
-                const int teams = std::max(1, (int)((160 * 1024) / (tab_bytes16 + region_of(16) + 64)));
-                while (nw < 16 && teams * nw * 2 <= 24) nw *= 2;
-                if (force_nw > 0) nw = force_nw;
-                nt = 64 * nw;
-                lds = tab_bytes16 + region_of(nw);
-                waves_cu = teams * nw;
-            }
-            const size_t nwg = multi ? (size_t)((B + 7) / 8) * 8 * (((size_t)npg + gsel - 1) / gsel) : nblocks;
-            const bool deep = !multi && waves_cu <= 16;  // <= 4 waves per SIMD: the 128-VGPR build fits
-            if (deep)
-                hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
-                                   period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
-                                   use_likelihood ? 1 : 0, out7, cap, multi | (nh_cap << 8), ablate, d_prof);
-            else
-                hipLaunchKernelGGL(bls_team_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
-                                   period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
-                                   use_likelihood ? 1 : 0, out7, cap, multi | (nh_cap << 8), ablate, d_prof);
+        if (waves_cu >= kMultiMinWaves) {
+            multi = 1;
+            nt = 64 * gsel;
+            lds = tab_bytes16 + (size_t)gsel * region_of(cap, 1);
         } else {
-            // threads per workgroup by LDS footprint: small-LDS groups fit >= 4 workgroups per CU with 4 waves each;
-            // long periods (one or two workgroups per CU) get 8 / 16 waves so the SIMDs still have waves to swap.
-            const size_t bins_bytes = (size_t)(head_bins + 1) * 16;
-            nt = bins_bytes <= 28 * 1024 ? 256 : (bins_bytes <= 64 * 1024 ? 512 : 1024);
-            lds = bins_bytes + lds_fixed_of(nt);
-            hipLaunchKernelGGL(bls_kernel, dim3((unsigned)nblocks), dim3(nt), lds, stream, d_tm, d_yw, d_off,
-                               d_stats, period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration,
-                               oversample, use_likelihood ? 1 : 0, out7, ablate, d_prof);
+            const int teams = std::max(1, (int)((160 * 1024) / (tab_bytes16 + region_of(cap, 16) + 64)));
+            nw = 2;  // the two-pass prefix and the ticket histogram want at least two waves
+            while (nw < 16 && teams * nw * 2 <= 24) nw *= 2;
+            nt = 64 * nw;
+            lds = tab_bytes16 + region_of(cap, nw);
+            waves_cu = teams * nw;
         }
+        const size_t nwg = (size_t)((B + 7) / 8) * 8 * (((size_t)npg + gsel * multi + (1 - multi) - 1) / (multi ? gsel : 1));
+        LK_REQUIRE(nwg < ((size_t)1 << 31), "grid too large");
+        const bool deep = !multi && waves_cu <= 16;  // <= 4 waves per SIMD: the 128-VGPR build fits
+        const int shape = multi | (kHistWaves << 8);
+        if (deep)
+            hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
+                               period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
+                               use_likelihood ? 1 : 0, out7, cap, shape, ablate, d_prof);
+        else
+            hipLaunchKernelGGL(bls_team_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
+                               period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,
+                               use_likelihood ? 1 : 0, out7, cap, shape, ablate, d_prof);
         if (prof_on) {
             unsigned long long hp[8];
             float ms = 0.f;
@@ -1513,17 +1016,17 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
             }
             const double nb = (double)std::max<unsigned long long>(hp[7], 1);
             fprintf(stderr,
-                    "[bls prof] head_bins %5d periods %6d nt %4d lds %6zu | %7.2f ms = %6.2f CU-us per (target, period) | us per "
+                    "[bls prof] head_bins %5d periods %6d %s nt %4d lds %6zu | %7.2f ms = %6.2f CU-us per (target, period) | us per "
                     "team: setup %.1f  hist %.1f  pad+red %.1f  prefix %.1f  scan %.1f  out %.1f\n",
-                    head_bins, npg, nt, lds, ms, ms * 1e3 * 256.0 / ((double)npg * B), hp[0] / nb * 0.01, hp[1] / nb * 0.01,
-                    hp[2] / nb * 0.01, hp[3] / nb * 0.01, hp[4] / nb * 0.01, hp[5] / nb * 0.01);
+                    head_bins, npg, multi ? "multi " : (deep ? "deep  " : "single"), nt, lds, ms, ms * 1e3 * 256.0 / ((double)npg * B),
+                    hp[0] / nb * 0.01, hp[1] / nb * 0.01, hp[2] / nb * 0.01, hp[3] / nb * 0.01, hp[4] / nb * 0.01, hp[5] / nb * 0.01);
         }
         g0 = g1;
     }
     if (d_prof) LK_HIP_CHECK(hipFree(d_prof));
     if (pe0) {
-        hipEventDestroy(pe0);
-        hipEventDestroy(pe1);
+        (void)hipEventDestroy(pe0);
+        (void)hipEventDestroy(pe1);
     }
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;

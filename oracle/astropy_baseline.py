@@ -12,7 +12,8 @@ Two modes:
     astropy_baseline.py suite <workdir> <procs>
 
 ``suite`` is what bench.py uses: the INPUT ARRAYS of the sampled bench targets are handed over as files
-(<workdir>/ls.npz: t, y, off, f0, df, M;  <workdir>/bls.npz: t, y, e, off, period, duration) so both sides
+(<workdir>/ls.npz: t, y, off, f0, df, M;  <workdir>/bls.npz: t, y, e, off, period, duration;  <workdir>/flatten.npz:
+t, y, off -> flatten_trends.npy, scipy's savgol_filter / interp1d inside the restated lightkurve loop) so both sides
 provably see identical numbers, every job is timed (-> cpu_baseline rates), and the per-target results the
 BASELINE metric's accuracy columns need are written to <workdir>/result.json: max power and argmax for LS
 ('fast' = the reference default; 'cython' = the exact method), and for BLS the argmax of power (best-period
@@ -79,6 +80,40 @@ def _suite_bls(b):
             float(r.transit_time[k]))
 
 
+def _suite_flatten(b):
+    """LightCurve.flatten's trend for light curve b with the reference's own numerical calls — scipy.signal.savgol_filter
+    per gap-free segment and scipy.interpolate.interp1d(fill_value="extrapolate") — inside a restatement of the loop of
+    src/lightkurve/lightcurve.py:996-1063 (lightkurve itself is not installed on the GPU box; this loop is pinned to it
+    by tests/golden/flatten_20k.npz).  Returns the trend."""
+    from scipy.interpolate import interp1d
+    from scipy.signal import savgol_filter
+    d = _G["flatten"]
+    s = slice(int(d["off"][b]), int(d["off"][b + 1]))
+    time, flux = d["t"][s], d["y"][s]
+    window_length, polyorder, break_tolerance, niters, sigma = 401, 2, 5, 3, 3
+    mask = np.ones(len(time), dtype=bool)
+    with np.errstate(invalid="ignore"):
+        extra = np.isfinite(flux)
+        extra &= np.nan_to_num(np.abs(flux - np.nanmedian(flux))) <= np.nanstd(flux) * sigma
+    mask &= extra
+    trend = None
+    for _ in range(niters):
+        tm, fm = time[mask], flux[mask]
+        dt = tm[1:] - tm[:-1]
+        cut = np.where(dt > break_tolerance * np.nanmedian(dt))[0] + 1
+        low, high = np.append([0], cut), np.append(cut, len(tm))
+        tr = np.zeros(len(tm))
+        for l, h in zip(low, high):
+            if window_length > (h - l) or (h - l) < break_tolerance:
+                tr[l:h] = np.nanmedian(fm[l:h])
+            else:
+                tr[l:h] = savgol_filter(x=fm[l:h], window_length=window_length, polyorder=polyorder)
+        mask1 = np.nan_to_num(np.abs(fm - tr)) < (np.nanstd(fm - tr) * sigma + 1e-14)
+        trend = interp1d(tm[mask1], tr[mask1], fill_value="extrapolate")(time)
+        mask[mask] &= mask1
+    return trend
+
+
 def _warm(_):
     """Imports + one tiny call of each astropy kernel in every worker (not timed)."""
     from astropy.timeseries import BoxLeastSquares, LombScargle
@@ -106,6 +141,8 @@ def suite(workdir, procs):
         _G["ls"] = dict(np.load(os.path.join(workdir, "ls.npz")))
     if "bls" in spec:
         _G["bls"] = dict(np.load(os.path.join(workdir, "bls.npz")))
+    if "flatten" in spec:
+        _G["flatten"] = dict(np.load(os.path.join(workdir, "flatten.npz")))
     with mp.get_context("fork").Pool(procs) as pool:
         if "ls" in spec:
             M = int(_G["ls"]["M"])
@@ -122,6 +159,13 @@ def suite(workdir, procs):
                           "argmax": [o[0] for o in out], "max_power": [o[1] for o in out],
                           "period": [o[2] for o in out], "duration": [o[3] for o in out],
                           "depth": [o[4] for o in out], "transit_time": [o[5] for o in out]}
+        if "flatten" in spec and spec["flatten"].get("n", 0) > 0:
+            import scipy
+            n = spec["flatten"]["n"]
+            out, dt = _timed_map(pool, _suite_flatten, list(range(n)), procs)
+            np.save(os.path.join(workdir, "flatten_trends.npy"), np.concatenate(out))
+            res["flatten"] = {"n_targets": n, "seconds": dt, "units_per_s": float(len(_G["flatten"]["t"])) / dt,
+                              "scipy": scipy.__version__}
     json.dump(res, open(os.path.join(workdir, "result.json"), "w"))
     print("BASELINE " + json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items()
                                                                              if not isinstance(vv, list)})

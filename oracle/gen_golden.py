@@ -584,6 +584,59 @@ def gen_pld():
               background_aperture_mask="all", spline_degree=3)
 
 
+def _sha(*arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def gen_pld_c5():
+    """BASELINE configs[4] at its REAL shape: 11x11-pixel cutouts x 3500 cadences, pld_order=3, 16 PCA components, all
+    pixels in the PLD and background blocks (what bench.py --workload pld runs).  The inputs are lightkurve_amd.synth
+    cutouts — bit-identical under numpy 1.26 and 2.2, so only their SHA-256 is stored and tests regenerate them — and
+    the outputs are what PLDCorrector.correct returns for them (src/lightkurve/correctors/pldcorrector.py:304-427)."""
+    from lightkurve.targetpixelfile import TargetPixelFileFactory
+    from lightkurve.correctors import PLDCorrector
+    out = {}
+    n_cut = 3
+    for i in range(n_cut):
+        t, flux, err, truth = synth.pld_cutout(4, i, n=3500, npix=11)
+        fac = TargetPixelFileFactory(len(t), 11, 11)
+        for k in range(len(t)):
+            fac.add_cadence(frameno=k, flux=flux[k], flux_err=err[k],
+                            header={"TSTART": 2000.0 + t[k] - 0.0102, "TSTOP": 2000.0 + t[k] + 0.0102})
+        tpf = fac.get_tpf(hdu0_keywords={"TELESCOP": "Kepler", "INSTRUME": "Kepler Photometer", "MISSION": "K2",
+                                         "OBSMODE": "long cadence"},
+                          ext_info={"1CRV5P": 100, "2CRV5P": 200, "1CRV4P": 100, "2CRV4P": 200})
+        pld = PLDCorrector(tpf, aperture_mask="all")
+        clc = pld.correct(pld_order=3, pca_components=16, pld_aperture_mask="all", background_aperture_mask="all")
+        out["sha_%d" % i] = np.array(_sha(t, flux, err))
+        out["time_%d" % i] = np.asarray(pld.tpf.time.value, float)
+        out["corrected_%d" % i] = np.asarray(clc.flux.value, float)
+        out["outlier_mask_%d" % i] = np.asarray(pld.outlier_mask, bool)
+        out["lc_flux_%d" % i] = np.asarray(pld.lc.flux.value, float)
+        out["widths_%d" % i] = np.array([m.shape[1] for m in pld.design_matrix_collection.matrices])
+    out["n_cutouts"] = n_cut
+    save("pld_c5", **out)
+
+
+def gen_flatten_20k():
+    """LightCurve.flatten at the bench shape: 20 000 cadences, window 401 (bench.py --workload flatten).  Inputs =
+    synth.ls_target(6, i, 20000) (SHA-256 stored); outputs = the reference's trend (lightcurve.py:943-1078)."""
+    out = {}
+    n_lc = 3
+    for i in range(n_lc):
+        t, y, e, _ = synth.ls_target(6, i, 20000)
+        lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+        flat, trend = lc.flatten(window_length=401, polyorder=2, break_tolerance=5, niters=3, sigma=3, return_trend=True)
+        out["sha_%d" % i] = np.array(_sha(t, y))
+        out["trend_%d" % i] = np.asarray(trend.flux.value, float)
+    out["n_lc"] = n_lc
+    save("flatten_20k", **out)
+
+
 def gen_fits():
     """FITS light-curve files -> arrays through the reference's own readers (io/kepler.py, io/tess.py, io/generic.py).
     The files are SYNTHETIC (written here with astropy.io.fits in the layout of the mission products: big-endian records,

@@ -33,6 +33,21 @@ def test_golden_user_mask_and_short_segment(golden):
     assert np.allclose(trend.flux, g["trend"], rtol=RTOL, atol=0)
 
 
+def test_golden_bench_shape(golden):
+    """bench.py's flatten workload (20 000 cadences, window 401) against the REFERENCE's trend (fixture generated from
+    lightkurve itself; inputs regenerated from lightkurve_amd.synth and checked by SHA-256)."""
+    import hashlib
+    g = golden("flatten_20k")
+    n = int(g["n_lc"])
+    lcs = [synth.ls_target(6, i, 20000) for i in range(n)]
+    for i, (t, y, e, _) in enumerate(lcs):
+        assert hashlib.sha256(t.tobytes() + y.tobytes()).hexdigest() == str(g["sha_%d" % i])
+    trends = flatten_trend_batch([LightCurve(time=t, flux=y) for t, y, e, _ in lcs], window_length=401, polyorder=2,
+                                 break_tolerance=5, niters=3, sigma=3)
+    for i in range(n):
+        assert np.allclose(trends[i], g["trend_%d" % i], rtol=RTOL, atol=0), i
+
+
 def test_reference_robustness_cases():
     """reference tests/test_lightcurve.py:1284-1361: NaNs kept, linear data flattens to 1, one outlier survives."""
     lc = LightCurve(time=[1, 2, 3, 4, 5], flux=[np.nan, 1.1, 1.2, np.nan, 1.4])

@@ -249,6 +249,25 @@ def test_flatten_user_mask(golden):
     assert np.allclose(trend, g["trend"], rtol=1e-11, atol=0)
 
 
+def _sha(*arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def test_flatten_bench_shape(golden):
+    """20 000 cadences, window 401 (bench.py's flatten workload): the reference's own trend for lightkurve_amd.synth
+    light curves; the fixture stores the SHA-256 of the inputs, which are regenerated here."""
+    from lightkurve_amd import synth
+    g = golden("flatten_20k")
+    t, y, e, _ = synth.ls_target(6, 0, 20000)
+    assert _sha(t, y) == str(g["sha_0"]), "synth light curve differs from the one the golden was made from"
+    trend, _ = O.flatten_trend(t, y, 401, 2, 5, 3, 3)
+    assert np.allclose(trend, g["trend_0"], rtol=1e-11, atol=0)
+
+
 # ------------------------------------------------------------------ regression
 def test_regression_k8(golden):
     g = golden("regress_k8")
@@ -309,6 +328,20 @@ def test_pld_corrected_flux(golden, name):
     assert r["X"].shape == g["X"].shape and np.allclose(r["prior_sigma"], g["prior_sigma"], rtol=1e-6)
     assert np.array_equal(r["outlier_mask"], g["outlier_mask"])
     assert np.max(np.abs(r["corrected"] - g["corrected"])) / np.median(g["corrected"]) < 1e-6
+
+
+def test_pld_bench_shape(golden):
+    """configs[4] at its real shape (11x11 pixels x 3500 cadences, order 3, 16 components, all pixels): the reference's
+    PLDCorrector output for a lightkurve_amd.synth cutout (inputs regenerated, SHA-256 checked)."""
+    from lightkurve_amd import synth
+    g = golden("pld_c5")
+    t, flux, err, _ = synth.pld_cutout(4, 0, n=3500, npix=11)
+    assert _sha(t, flux, err) == str(g["sha_0"]), "synth cutout differs from the one the golden was made from"
+    allm = np.ones((11, 11), bool)
+    r = O.pld_correct(g["time_0"], flux, err, allm, allm, allm, pld_order=3, pca_components=16, spline_degree=5)
+    assert np.allclose(r["lc_flux"], g["lc_flux_0"], rtol=1e-6)
+    assert np.array_equal(r["outlier_mask"], g["outlier_mask_0"])
+    assert np.max(np.abs(r["corrected"] - g["corrected_0"])) / np.median(g["corrected_0"]) < 1e-6
 
 
 def test_ingest_oracle_vs_reference(golden):

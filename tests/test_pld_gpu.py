@@ -58,6 +58,25 @@ def test_golden_default_path_and_factory_cutout(golden):
     assert np.max(np.abs(clc.flux - g["corrected"])) / np.median(g["corrected"]) < 1e-6
 
 
+def test_golden_bench_shape(golden):
+    """BASELINE configs[4] at its real shape — 11x11 pixels x 3500 cadences, pld_order 3, 16 components, all pixels —
+    against the REFERENCE's PLDCorrector output (tests/golden/pld_c5.npz, made by oracle/gen_golden.py from lightkurve
+    itself; the synthetic cutouts are regenerated here and checked by SHA-256)."""
+    import hashlib
+    from lightkurve_amd import synth
+    g = golden("pld_c5")
+    n = int(g["n_cutouts"])
+    cubes = []
+    for i in range(n):
+        t, flux, err, _ = synth.pld_cutout(4, i, n=3500, npix=11)
+        assert hashlib.sha256(t.tobytes() + flux.tobytes() + err.tobytes()).hexdigest() == str(g["sha_%d" % i])
+        cubes.append(PixelCube(g["time_%d" % i], flux, err, mission="K2"))
+    corrected, outl = pld_correct_batch(cubes, pld_order=3, pca_components=16)
+    for i in range(n):
+        assert np.array_equal(outl[i], g["outlier_mask_%d" % i]), i
+        assert np.max(np.abs(corrected[i] - g["corrected_%d" % i])) / np.median(g["corrected_%d" % i]) < 1e-6, i
+
+
 def test_batch_of_cutouts_vs_oracle():
     """config[4] shape at reduced cadence count: 4 cutouts 11x11, order 3, 16 components, all pixels."""
     from lightkurve_amd import synth
