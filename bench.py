@@ -762,9 +762,8 @@ def main():
             if method == "fast":
                 nfft = 1 << int(np.ceil(np.log2(5 * M)))
                 n2 = 1 << (int(np.log2(nfft)) // 2)
-                # the extirpolation is its own kernel (lsf_spread_owner_kernel) and its output is real traffic, unless the opt-in
-                # fused path is on (LK_LSF_FUSED_SPREAD=1: the spread grid is never materialised)
-                fused_spread = os.environ.get("LK_LSF_FUSED_SPREAD", "0") == "1"
+                # the extirpolation is its own kernel (lsf_spread_owner_kernel) and its output is real traffic
+                fused_spread = False
                 used = 0.0   # grid rows that can hold samples: written by the spreader and read by FFT step 1
                 for b in range(B):
                     span = (t[off[b + 1] - 1] - t[off[b]]) * nfft * df

@@ -239,8 +239,8 @@ class PLDCorrector(RegressionCorrector):
         """DesignMatrixCollection [pixel_series | background | spline] built on the GPU (one cutout = a batch of 1)."""
         if pca_components is None or pca_components < 1:
             raise NotImplementedError("pca_components must be >= 1 on the HIP path")
-        if pld_aperture_mask is None:
-            pld_aperture_mask = "empty"
+        # None -> all pixels, exactly as the reference's create_design_matrix treats it (pldcorrector.py:203-207;
+        # correct() resolves the mission-dependent default before it calls this)
         self.pld_aperture_mask = self.tpf._parse_aperture_mask(pld_aperture_mask)
         self.background_aperture_mask = self.tpf._parse_aperture_mask(background_aperture_mask)
         n = len(self.lc)

@@ -623,11 +623,9 @@ int lk_ls_fast_peaks_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, c
     LK_REQUIRE(h != nullptr, "handle is NULL");
     LK_REQUIRE(power != nullptr, "power must be non-NULL for the device flavour (the spectra stay in HBM anyway)");
     LK_HIP_CHECK(hipSetDevice(h->device));
-    int rc = lk::lsfast_launch(h, B, n_off_host, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
-                               oversampling, power, static_cast<hipStream_t>(stream));
-    if (rc || B == 0 || M == 0 || (!max_power && !argmax)) return rc;
-    LK_REQUIRE(max_power && argmax, "max_power and argmax must both be given (or both NULL)");
-    return lk::argmax_launch(h, B, M, power, max_power, argmax, static_cast<hipStream_t>(stream));
+    // the per-target (max power, argmax) come out of the fused FFT step itself (no second pass over the spectra)
+    return lk::lsfast_launch(h, B, n_off_host, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
+                             oversampling, power, static_cast<hipStream_t>(stream), max_power, argmax);
 }
 
 extern "C++" {

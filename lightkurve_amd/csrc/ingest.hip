@@ -156,11 +156,10 @@ int ingest_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, stream, d_kept, B, d_new);
     constexpr int cap = 4096;
     const size_t lds = 512 * 8 + (size_t)cap * 8 + 64 * 4;
-    static bool attr = false;
-    if (!attr) {
+    if (!(h->attr_set & 1)) {  // per handle = per device (a process may drive several GPUs)
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ingest_pack_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        h->attr_set |= 1;
     }
     hipLaunchKernelGGL(ingest_pack_kernel, dim3(B), dim3(512), lds, stream, t, flux, err, d_off, d_new, normalize, t_out,
                        f_out, e_out, median_out, cap);
@@ -314,14 +313,13 @@ int fits_unpack_launch(lk_handle *h, int B, const uint8_t *raw, const int64_t *r
     LK_HIP_CHECK(hipMemcpyAsync(d_desc, desc_host, (size_t)B * sizeof(FitsDesc), hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // pageable sources may be reused by the caller
     const size_t lds = (size_t)FITS_ROWS * max_row + 16;
-    static bool attr = false;
-    if (!attr) {
+    if (!(h->attr_set & 2)) {
         // (the kernel also has 16 bytes of static LDS: the dynamic part may not claim all 160 KB)
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<false, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<true, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr = true;
+        h->attr_set |= 2;
     }
     hipLaunchKernelGGL((fits_unpack_kernel<false, true>), dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask, d_kept,
                        (const int64_t *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr, 0,
@@ -363,7 +361,11 @@ int fits_cube_launch(lk_handle *h, const uint8_t *raw, int row_bytes, int n_rows
     LK_REQUIRE(row_bytes >= 1 && n_rows >= 0 && ncols >= 1 && ncols <= 4 && npix >= 1, "bad table description");
     LK_REQUIRE(code_time >= 0 && code_time <= 1 && off_time >= 0 && off_time + (code_time ? 4 : 8) <= row_bytes,
                "TIME does not fit the record");
-    LK_REQUIRE(off_qual < 0 || (code_qual >= 2 && code_qual <= 5 && off_qual + 1 <= row_bytes), "QUALITY does not fit the record");
+    {
+        const int widths[6] = {8, 4, 4, 8, 2, 1};  // D, E, J, K, I, B (as in fits_unpack_launch)
+        LK_REQUIRE(off_qual < 0 || (code_qual >= 2 && code_qual <= 5 && off_qual + widths[code_qual] <= row_bytes),
+                   "QUALITY does not fit the record");
+    }
     for (int c = 0; c < ncols; ++c)
         LK_REQUIRE(col_off_host[c] >= 0 && (int64_t)col_off_host[c] + 4ll * npix <= row_bytes,
                    "pixel column %d (offset %d, %d pixels) does not fit the %d-byte record", c, col_off_host[c], npix, row_bytes);

@@ -76,6 +76,8 @@ struct lk_handle {
     hipStream_t s_rows = nullptr;  // stream of the LS 'fast' row transforms when they overlap the next chunk's column transforms
     hipEvent_t ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};  // [0..1] columns done (per intermediate buffer), [2..3] rows done
     int *h_plan = nullptr;         // 64 B of pinned host memory: device -> host plan words (lsfast.hip)
+    std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS attribute has been raised on this device
+    unsigned attr_set = 0;         // per-device hipFuncSetAttribute calls already made through this handle (bit per kernel family)
     int bls_attr_set = 0;          // bls.hip: kernel attributes set and the LDS-atomic order self-test passed on this device
 };
 
@@ -137,7 +139,8 @@ int pg_acf2d_launch(lk_handle *h, int B, int64_t M, const double *power, int n_w
                     double *acf2d, double *metric, hipStream_t stream);
 int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
                   double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
-                  const double *scale, int oversampling, double *power, hipStream_t stream);
+                  const double *scale, int oversampling, double *power, hipStream_t stream, double *max_out = nullptr,
+                  int64_t *arg_out = nullptr);
 int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
                       double f0, double df, int64_t M, int nterms, int fit_mean, int center_data, int normalization,
                       const double *scale, int oversampling, double *power, hipStream_t stream);

@@ -9,11 +9,22 @@
 //   astropy lombscargle/implementations/utils.py:14-78         (extirpolate: 4-point Lagrange spreading)
 // called by lightkurve at src/lightkurve/periodogram.py:961-964 with method='fast' (the default, :650).
 //
-// This is the HBM-bound formulation of the path: per target 3 complex grids of Nfft = 2^19 points (8 MB each) are
-// zeroed, filled by atomics, transformed by a hand-written four-step FFT (Nfft = N1 x N2: column FFTs of length N1
-// with the inter-step twiddles, then row FFTs of length N2, both in LDS, in-place radix-2 on bit-reversed loads)
-// and reduced to M powers.  Algorithmic HBM traffic per target: grids 3 x (zero 8 MB + 2 passes x (read + write)
-// 8 MB) = 120 MB, + 16 B/cadence in and 8 B/frequency out.
+// This is the HBM-bound formulation of the path.  Per target, three complex grids of Nfft = bitceil(5 M) points:
+//   lsf_prep_kernel           weights, centring, per-target sums, the rows of each grid that can hold samples, and the
+//                             per-1024-cell cadence tables of the spreader
+//   lsf_spread_owner_kernel   extirpolation without global atomics (time-sorted targets whose 2f grid does not wrap): a
+//                             workgroup owns 1024 cells, each of its waves 256 of them, accumulated in LDS in a fixed
+//                             order (lane-ordered ds_add_f64: bitwise reproducible) and written once, zeros included.
+//                             Other targets: lsf_zero_kernel + lsf_scatter_kernel (global atomics).
+//   fft_cols_pruned_kernel    step 1 of a hand-written four-step FFT (Nfft = N1 x N2): only P << N1 rows hold samples,
+//                             so the N1-point column transform is N1 / P interleaved P-point transforms in registers;
+//                             output x inter-step twiddle into a column-tiled intermediate [c / 16][k1][c % 16]
+//   fft_rows_power_kernel     step 2 fused with the closed form: the three spectra never reach HBM; the M powers are
+//                             written and (peaks entry) a per-workgroup (max, argmax) partial, reduced by lsf_peaks_kernel
+// Register FFTs cover 2^4 <= N1, N2 <= 2^10; other sizes run the in-LDS radix-2 kernels (fft_cols_kernel,
+// fft_rows_kernel + lsf_power_kernel), which the multi-term fastchi2 path (3 nterms grids per target) shares with
+// fft_cols_reg_kernel / fft_rows_reg_kernel.  Algorithmic HBM traffic per target at configs[1]: the intermediate out and
+// in (2 x 3 x 16 B x Nfft = 50 MB), the sample-bearing rows out and in (~6 MB), 40 B per cadence, 8 B per frequency.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -31,20 +42,22 @@ struct FastStats {
 };
 
 // per target: weights, mean about y[0], YY, t0 = min t; w[i] (normalised) and wy[i] = w (y - ybar)
-__global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict__ t, const double *__restrict__ y,
+constexpr int PREP_NT = 1024;
+__global__ __launch_bounds__(PREP_NT) void lsf_prep_kernel(const double *__restrict__ t, const double *__restrict__ y,
                                                         const double *__restrict__ dy,
                                                         const int64_t *__restrict__ n_off, int center,
                                                         double *__restrict__ w_out, double *__restrict__ wy_out,
                                                         FastStats *__restrict__ stats, double df, int nfft, int m2,
                                                         int *__restrict__ rows_used, int *__restrict__ spread_tab,
-                                                        int ntab, int *__restrict__ tab16 = nullptr, int ntab16 = 0) {
-    __shared__ double sh[256];
+                                                        int ntab) {
+    constexpr int NT = PREP_NT;
+    __shared__ double sh[NT];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
     auto bsum = [&](double x) {
         sh[tid] = x;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
+        for (int s = NT / 2; s > 0; s >>= 1) {
             if (tid < s) sh[tid] += sh[tid + s];
             __syncthreads();
         }
@@ -52,19 +65,23 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
         __syncthreads();
         return r;
     };
+    // (the kernel is bound by its sweeps over the cadences: one for the time statistics, one for the tables, two over y)
     double acc = 0.0, tmin = INFINITY, tmax = -INFINITY;
-    for (int64_t i = tid; i < n; i += 256) {
+    int unsorted = 0;
+    for (int64_t i = tid; i < n; i += NT) {
         if (dy) {
             const double d = dy[lo + i];
             acc += 1.0 / (d * d);
         }
-        tmin = fmin(tmin, t[lo + i]);
-        tmax = fmax(tmax, t[lo + i]);
+        const double ti = t[lo + i];
+        tmin = fmin(tmin, ti);
+        tmax = fmax(tmax, ti);
+        if (i + 1 < n) unsorted |= (t[lo + i + 1] < ti) ? 1 : 0;
     }
     const double wsum = dy ? bsum(acc) : (double)n;
     sh[tid] = tmin;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = NT / 2; s > 0; s >>= 1) {
         if (tid < s) sh[tid] = fmin(sh[tid], sh[tid + s]);
         __syncthreads();
     }
@@ -72,7 +89,7 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
     __syncthreads();
     sh[tid] = tmax;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = NT / 2; s > 0; s >>= 1) {
         if (tid < s) sh[tid] = fmax(sh[tid], sh[tid + s]);
         __syncthreads();
     }
@@ -88,8 +105,6 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
     if (rows_used) {
         // "ordered" targets (time sorted, no wrap of the 2 df grid): grid positions are monotone in the cadence
         // index, so the spreading kernel can own cell ranges and use plain stores instead of global atomics
-        int unsorted = 0;
-        for (int64_t i = tid; i + 1 < n; i += 256) unsorted |= (t[lo + i + 1] < t[lo + i]) ? 1 : 0;
         const int any_unsorted = __syncthreads_or(unsorted);
         const bool nowrap = (t1 - t0) * (double)nfft * df * 2.0 < (double)nfft - 8.0;
         if (tid == 0) rows_used[b * 4 + 3] = (!any_unsorted && nowrap) ? 1 : 0;
@@ -100,70 +115,67 @@ __global__ __launch_bounds__(256) void lsf_prep_kernel(const double *__restrict_
         // cadence with position >= k W + 3 — what the spreader used to find with two block-wide binary searches per
         // workgroup.  Every cadence fills the thresholds that fall between its predecessor's position and its own.
         int *tab = spread_tab + (size_t)b * 6 * ntab;
-        const double W = (double)SPREAD_W_C;
-        for (int g = 0; g < 3; ++g) {
-            const double dff = df * (g == 2 ? 2.0 : 1.0);
-            int *lo_tab = tab + (size_t)(2 * g) * ntab, *hi_tab = lo_tab + ntab;
-            for (int64_t i = tid; i < n; i += 256) {
-                const double p = fmod((t[lo + i] - t0) * (double)nfft * dff, (double)nfft);
-                const double pp = i > 0 ? fmod((t[lo + i - 1] - t0) * (double)nfft * dff, (double)nfft) : -1e300;
+        const double W = (double)SPREAD_W_C, dn = (double)nfft;
+        auto posn = [&](double tt, double dff) {
+            const double x = (tt - t0) * dn * dff;
+            return x < dn ? x : fmod(x, dn);  // the reference's fmod; the identity for every target the spreader takes
+        };
+        // grids 0 and 1 share df (identical tables, both written: the spreader indexes them by grid), grid 2 uses 2 df
+        for (int64_t i = tid; i < n; i += NT) {
+            const double ti = t[lo + i], tp = i > 0 ? t[lo + i - 1] : 0.0;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const double dff = df * (gg ? 2.0 : 1.0);
+                const double p = posn(ti, dff), pp = i > 0 ? posn(tp, dff) : -1e300;
+                int *lo_a = tab + (size_t)(gg ? 4 : 0) * ntab, *hi_a = lo_a + ntab;
+                int *lo_b = gg ? nullptr : tab + (size_t)2 * ntab, *hi_b = gg ? nullptr : lo_b + ntab;
                 // thresholds x_k = k W - 4 with pp < x_k <= p
                 long long k0 = i > 0 ? (long long)floor((pp + 4.0) / W) + 1 : 0, k1 = (long long)floor((p + 4.0) / W);
-                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) lo_tab[k] = (int)i;
+                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) {
+                    lo_a[k] = (int)i;
+                    if (lo_b) lo_b[k] = (int)i;
+                }
                 k0 = i > 0 ? (long long)floor((pp - 3.0) / W) + 1 : 0;
                 k1 = (long long)floor((p - 3.0) / W);
-                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) hi_tab[k] = (int)i;
+                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) {
+                    hi_a[k] = (int)i;
+                    if (hi_b) hi_b[k] = (int)i;
+                }
             }
-            // thresholds beyond the last cadence
-            const double pl = fmod((t[lo + n - 1] - t0) * (double)nfft * dff, (double)nfft);
-            for (int k = tid; k < ntab; k += 256) {
+        }
+        // thresholds beyond the last cadence
+        for (int g = 0; g < 3; ++g) {
+            int *lo_tab = tab + (size_t)(2 * g) * ntab, *hi_tab = lo_tab + ntab;
+            const double pl = posn(t[lo + n - 1], df * (g == 2 ? 2.0 : 1.0));
+            for (int k = tid; k < ntab; k += NT) {
                 if ((double)k * W - 4.0 > pl) lo_tab[k] = (int)n;
                 if ((double)k * W + 3.0 > pl) hi_tab[k] = (int)n;
             }
-        }
-    }
-    if (tab16) {
-        // Fine table for the extirpolation fused into the pruned column kernel: per grid g and 16-cell group G,
-        // tab16[G] = first cadence with position >= 16 G - 4 (ordered targets).  A tile row then knows its cadences without
-        // any search: [tab16[G], tab16[G + 2]) covers every stencil that reaches cells [16 G, 16 G + 16).
-        int *tb = tab16 + (size_t)b * 3 * ntab16;
-        for (int g = 0; g < 3; ++g) {
-            const double dff = df * (g == 2 ? 2.0 : 1.0);
-            int *tg = tb + (size_t)g * ntab16;
-            for (int64_t i = tid; i < n; i += 256) {
-                const double p = fmod((t[lo + i] - t0) * (double)nfft * dff, (double)nfft);
-                const double pp = i > 0 ? fmod((t[lo + i - 1] - t0) * (double)nfft * dff, (double)nfft) : -1e300;
-                const long long k0 = i > 0 ? (long long)floor((pp + 4.0) / 16.0) + 1 : 0, k1 = (long long)floor((p + 4.0) / 16.0);
-                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab16 - 1); ++k) tg[k] = (int)i;
-            }
-            const double pl = fmod((t[lo + n - 1] - t0) * (double)nfft * dff, (double)nfft);
-            for (int k = tid; k < ntab16; k += 256)
-                if ((double)k * 16.0 - 4.0 > pl) tg[k] = (int)n;
         }
     }
     const double y0 = y[lo];
     double ybar = 0.0;
     if (center) {
         acc = 0.0;
-        for (int64_t i = tid; i < n; i += 256) {
+        for (int64_t i = tid; i < n; i += NT) {
             const double d = dy ? dy[lo + i] : 1.0;
             acc = fma((1.0 / (d * d)) / wsum, y[lo + i] - y0, acc);
         }
         ybar = bsum(acc) + y0;
     }
     acc = 0.0;
-    for (int64_t i = tid; i < n; i += 256) {
+    double acc2 = 0.0;
+    for (int64_t i = tid; i < n; i += NT) {
         const double d = dy ? dy[lo + i] : 1.0;
         const double w = (1.0 / (d * d)) / wsum;
         const double yc = y[lo + i] - ybar;
         acc = fma(w * yc, yc, acc);
+        acc2 += w * yc;
         w_out[lo + i] = w;
         wy_out[lo + i] = w * yc;
     }
     const double YY = bsum(acc);
-    acc = 0.0;
-    for (int64_t i = tid; i < n; i += 256) acc += wy_out[lo + i];  // each thread re-reads what it wrote
-    const double yws = bsum(acc);
+    const double yws = bsum(acc2);
     if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0, yws, 0.0};
 }
 
@@ -226,9 +238,12 @@ __global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restri
 }
 
 // Owner-computes spreading for ordered targets (sorted time, no wrap): grid positions grow with the cadence index,
-// so workgroup (x, target, g) owns cells [x W, (x+1) W) of grid g, finds the cadences whose 4-point stencils reach
-// them by two block-wide probes, accumulates in LDS (ds_add_f64) and writes its cells once with plain, coalesced
-// stores — zeros included, so no memset and no global atomics.  g: 0 = w*y at f, 1 = w at f, 2 = w at 2 f.
+// so workgroup (x, target, g) owns cells [x W, (x+1) W) of grid g and knows from the prep kernel's tables which cadences
+// reach them.  Each of its four waves owns 256 of the cells: it walks ALL the workgroup's cadences and adds the stencil
+// points that fall in its own cells with LDS atomics.  Same-address lanes of one ds_add_f64 are applied in lane order and
+// a wave's LDS instructions execute in program order (tools/microbench/lds_atomic_order.hip), and no cell is touched by
+// two waves, so the accumulation order is fixed: two runs give bit-identical grids.  The cells are written once with
+// plain, coalesced stores — zeros included, so no memset and no global atomics.  g: 0 = w*y at f, 1 = w at f, 2 = w at 2f.
 constexpr int SPREAD_W = SPREAD_W_C;
 
 __global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__restrict__ t, const double *__restrict__ w,
@@ -252,51 +267,46 @@ __global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__r
     }
     const int b = b0 + lb;
     const int64_t lo = n_off[b];
-    const int n = (int)(n_off[b + 1] - lo);
     t += lo;
     const double t0 = stats[b].t0;
     const double fac = g == 2 ? 2.0 : 1.0;
     const double dff = df * fac, f0f = f0 * fac;
     const double *amp = (g == 0 ? wy : w) + lo;
-    auto pos = [&](int i) { return fmod((t[i] - t0) * (double)nfft * dff, (double)nfft); };
-    // first cadence with pos >= x (positions are non-decreasing): 256-way probes until the bracket fits one pass
-    auto lower = [&](double x) -> int {
-        int lo_i = 0, hi_i = n;  // answer in [lo_i, hi_i]
-        while (hi_i - lo_i > 256) {
-            const int stride = (hi_i - lo_i + 255) / 256;
-            const int ip = lo_i + tid * stride;
-            const int cnt = __syncthreads_count(ip < hi_i && pos(ip) < x);  // probes below x form a prefix
-            if (cnt == 0) {
-                hi_i = lo_i;  // even the first element is >= x
-                break;
-            }
-            const int nlo = lo_i + (cnt - 1) * stride + 1;  // just after the last probe below x
-            hi_i = min(lo_i + cnt * stride, hi_i);
-            lo_i = nlo;
-        }
-        const int i2 = lo_i + tid;
-        const int cnt2 = __syncthreads_count(i2 < hi_i && pos(i2) < x);
-        return lo_i + cnt2;
-    };
-    int i_lo, i_hi;
-    if (spread_tab) {  // precomputed by lsf_prep_kernel: no searching
-        const int *tab = spread_tab + ((size_t)b * 6 + 2 * g) * ntab;
-        i_lo = tab[blockIdx.x];
-        i_hi = tab[ntab + min((int)blockIdx.x + 1, ntab - 1)];
-    } else {
-        i_lo = lower((double)c_lo - 4.0);
-        i_hi = lower((double)c_hi + 3.0);
-    }
+    // cadences whose 4-point stencils can reach this workgroup's cells (lsf_prep_kernel's tables)
+    const int *tab = spread_tab + ((size_t)b * 6 + 2 * g) * ntab;
+    const int i_lo = tab[blockIdx.x], i_hi = tab[ntab + min((int)blockIdx.x + 1, ntab - 1)];
     for (int c = tid; c < SPREAD_W; c += 256) acc[c] = make_double2(0.0, 0.0);
     __syncthreads();
     const double twopi = 6.283185307179586;
+    const int lane = tid & 63, w_lo = c_lo + (tid >> 6) * (SPREAD_W / 4), w_hi = min(w_lo + SPREAD_W / 4, c_hi);
     auto add = [&](int cell, double vr, double vi) {
-        if (cell >= c_lo && cell < c_hi) {
+        if (cell >= w_lo && cell < w_hi) {  // this wave's cells only
             unsafeAtomicAdd(&acc[cell - c_lo].x, vr);
             unsafeAtomicAdd(&acc[cell - c_lo].y, vi);
         }
     };
-    for (int i = i_lo + tid; i < i_hi; i += 256) {
+    // the wave's own cadences: positions grow with the cadence index, so those whose stencils reach [w_lo, w_hi) are one
+    // run inside [i_lo, i_hi), found by 64-way probes (wave ballots)
+    auto pos = [&](int i) { return fmod((t[i] - t0) * (double)nfft * dff, (double)nfft); };
+    auto lower = [&](double x) -> int {  // first cadence in [i_lo, i_hi) with position >= x
+        int lo_i = i_lo, hi_i = i_hi;
+        while (hi_i - lo_i > 64) {
+            const int stride = (hi_i - lo_i + 63) / 64;
+            const int ip = lo_i + lane * stride;
+            const int cnt = __popcll(__ballot(ip < hi_i && pos(ip) < x));  // probes below x form a prefix
+            if (cnt == 0) {
+                hi_i = lo_i;
+                break;
+            }
+            const int nlo = lo_i + (cnt - 1) * stride + 1;
+            hi_i = min(lo_i + cnt * stride, hi_i);
+            lo_i = nlo;
+        }
+        const int i2 = lo_i + lane;
+        return lo_i + __popcll(__ballot(i2 < hi_i && pos(i2) < x));
+    };
+    const int wi_lo = lower((double)w_lo - 4.0), wi_hi = lower((double)w_hi + 3.0);
+    for (int i = wi_lo + lane; i < wi_hi; i += 64) {
         const double tt = t[i] - t0;
         double c = 1.0, s = 0.0;
         if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
@@ -506,74 +516,9 @@ __device__ __forceinline__ void block_fft(int NF, double2 *tile, Load load, Stor
     }
 }
 
-// Same transform with the LDS exchange done in two halves (real parts, then imaginary parts): the tile is
-// NF * (A * (Bq + 1) + pad) doubles — half the footprint, so twice the workgroups fit a CU — at the price of two more
-// barriers.  A thread holds im(v) (A doubles) and re(u) (Bq doubles) across the exchange, no more than v or u alone.
-// pad = 32 / NF doubles keeps the f-fastest phase-2 reads and phase-1 writes on distinct banks.
-template <int LA, int LB, int MODE, class Load, class Store>
-__device__ __forceinline__ void block_fft_split(int NF, double *tile, Load load, Store store, int tw = 1) {
-    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1;
-    const int FST = A * LDT + (NF >= 32 ? 1 : 32 / NF);
-    const int tid = threadIdx.x;
-    const bool p1 = tid < NF * Bq, p2 = tid < NF * A;
-    int f = 0, j = 0;
-    if (MODE == 1) {
-        f = tid % NF;
-        j = tid / NF;
-    } else if (MODE == 2) {
-        const int jl = tid % tw, rest = tid / tw;
-        f = rest % NF;
-        j = jl + tw * (rest / NF);
-    } else {
-        f = tid / Bq;
-        j = tid % Bq;
-    }
-    double2 v[A];
-    if (p1) {
-#pragma unroll
-        for (int i = 0; i < A; ++i) v[i] = load(f, i * Bq + j);
-        reg_fft<LA>(v);
-        double s1, c1;
-        sincospi(2.0 * (double)j / (double)n, &s1, &c1);
-        const double2 step = make_double2(c1, s1);
-        double2 w = make_double2(1.0, 0.0);
-#pragma unroll
-        for (int ka = 0; ka < A; ++ka) {
-            v[brev_c(ka, LA)] = cmul(v[brev_c(ka, LA)], w);
-            w = cmul(w, step);
-        }
-    }
-    double *row1 = tile + (size_t)f * FST + j;
-    const int ka2 = tid / NF, f2 = tid - ka2 * NF;
-    const double *row2 = tile + (size_t)f2 * FST + (size_t)ka2 * LDT;
-    double2 u[Bq];
-    if (p1) {
-#pragma unroll
-        for (int ka = 0; ka < A; ++ka) row1[ka * LDT] = v[brev_c(ka, LA)].x;
-    }
-    __syncthreads();
-    if (p2) {
-#pragma unroll
-        for (int q = 0; q < Bq; ++q) u[q].x = row2[q];
-    }
-    __syncthreads();
-    if (p1) {
-#pragma unroll
-        for (int ka = 0; ka < A; ++ka) row1[ka * LDT] = v[brev_c(ka, LA)].y;
-    }
-    __syncthreads();
-    if (p2) {
-#pragma unroll
-        for (int q = 0; q < Bq; ++q) u[q].y = row2[q];
-        reg_fft<LB>(u);
-#pragma unroll
-        for (int kb = 0; kb < Bq; ++kb) store(f2, ka2 + A * kb, u[brev_c(kb, LB)], kb);
-    }
-}
-
 // step 1 (register version): CT columns c0..c0+CT-1; rows >= rows_used[g] are known zeros and are not loaded
-template <int LA, int LB, bool SPLIT>
-__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double2 *__restrict__ grids, int m2, int CT,
+template <int LA, int LB>
+__global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__ grids, int m2, int CT,
                                                             const int *__restrict__ rows_used,
                                                             double2 *__restrict__ gout, int tw) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
@@ -590,7 +535,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double
     // k1 = ka + A kb, advances by e^{2 pi i c A / N} each time
     int last_f = -1;
     double2 w = make_double2(1.0, 0.0), step = w;
-    const int twl = tw > 0 ? 31 - __clz(tw) : 0;  // tw is a power of two (negative: row-tiled layout, see below)
+    const int twl = 31 - __clz(max(tw, 1));  // tw is a power of two
     auto store = [&](int f, int k1, double2 v, int) {
         const int c = c0 + f;
         if (f != last_f) {  // first output of this thread: k1 = ka
@@ -603,21 +548,13 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double
         }
         // gout: separate buffer in the tiled layout [c / tw][k1][c % tw] (a workgroup's output is one contiguous
         // run and step 2 reads 16 B x tw x RT runs); otherwise in place in the natural layout
-        if (gout && tw < 0) {
-            // row-tiled layout [k1 / H][c][k1 % H], H = -tw: the H rows one step-2 workgroup transforms are one
-            // contiguous N2 * H * 16-B chunk; this kernel's stores come in runs of CT * H * 16 B
-            const int hl = 31 - __clz(-tw);
-            gout[((size_t)blockIdx.y << (m1 + m2)) + (((((size_t)(k1 >> hl)) << m2) + c) << hl) + (k1 & (-tw - 1))] = cmul(v, w);
-        } else if (gout)
+        if (gout)
             gout[((size_t)blockIdx.y << (m1 + m2)) + ((((size_t)(c >> twl) << m1) + k1) << twl) + (c & (tw - 1))] = cmul(v, w);
         else
             G[(size_t)k1 * N2 + c] = cmul(v, w);
         w = cmul(w, step);
     };
-    if (SPLIT)
-        block_fft_split<LA, LB, 1>(CT, reinterpret_cast<double *>(lds2), load, store);
-    else
-        block_fft<LA, LB, 1>(CT, lds2, load, store);
+    block_fft<LA, LB, 1>(CT, lds2, load, store);
 }
 
 // step 1 for grids whose samples sit in the first rows only (time span x df << 1, the normal case: lightkurve's
@@ -628,33 +565,18 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void fft_cols_reg_kernel(double
 // holds 4.  That is what this kernel is for — 16-column tiles make the intermediate's [c / 16][k1][c % 16] layout
 // deliver 256-B runs per row to this kernel's loads and RT x 256-B runs to the row kernel (4 x the run length of the
 // full-length kernel above), and the workgroups are small enough for 2 waves per SIMD.  The input column is loaded
-// once and kept in registers over the Q passes.  perm != 0 stores pass s as one contiguous block (row index
-// k1' = s P + q; the row kernel undoes the permutation), perm == 0 keeps the natural row order k1 = Q q + s.
+// once and kept in registers over the Q passes; rows keep their natural order k1 = Q q + s.
 constexpr int PRUNED_CT = 16;
-
-// Arguments of the extirpolation when it is fused into the pruned column kernel (t == nullptr: not fused, the kernel
-// reads the grids lsf_spread_owner_kernel wrote).
-struct SpreadArgs {
-    const double *t, *w, *wy;
-    const int64_t *n_off;
-    const FastStats *stats;
-    const int *tab16;  // lsf_prep_kernel's per-16-cell table: first cadence with position >= 16 G - 4
-    int b0, ntab16, nfft, fit_mean;
-    double f0, df;
-};
 
 template <int LP>
 __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols_pruned_kernel(
-    const double2 *__restrict__ grids, int m1, int m2, const int *__restrict__ rows_used, double2 *__restrict__ gout,
-    int perm, int tpad, SpreadArgs sa) {
+    const double2 *__restrict__ grids, int m1, int m2, const int *__restrict__ rows_used, double2 *__restrict__ gout) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, P = 1 << LP, LDT = Bq + 1, FST = A * LDT + 1;
     constexpr int CT = PRUNED_CT;
     const int N1 = 1 << m1, N2 = 1 << m2, Q = N1 >> LP;
     const double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
-    // tpad elements of padding after every column tile of the intermediate: without it the 32 tiles of a row start
-    // exactly N1 * 256 B = 256 KB apart and step 2's reads of one row all fall on the same HBM channel
-    const size_t tstride = ((size_t)CT << m1) + (size_t)tpad, gstride = (size_t)(N2 / CT) * tstride;
+    const size_t tstride = (size_t)CT << m1, gstride = (size_t)(N2 / CT) * tstride;
     double2 *O = gout + (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * tstride;  // this column tile
     const int c0 = blockIdx.x * CT;
     const int ru = rows_used[(blockIdx.y / 3) * 4 + (blockIdx.y % 3)];
@@ -663,80 +585,7 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
     const bool p1 = jk < Bq, p2 = jk < A;
     const double invN1 = 1.0 / (double)N1, invN = 1.0 / (double)((size_t)1 << (m1 + m2));
     double2 xin[A];
-    if (sa.t != nullptr) {
-        // ---- fused extirpolation (ordered targets: grid position grows with the cadence index).  The tile's inputs are
-        // 16 cells of each of the P live rows: thread r builds row r's 16 cells in LDS from the few cadences whose 4-point
-        // stencils reach them — found through the prep kernel's per-1024-cell tables and a short binary search — adding
-        // in cadence order (deterministic, unlike the LDS atomics of lsf_spread_owner_kernel).  The spread grid, 81 %
-        // zeros, is never written to or read from HBM: that was 13 % of the step's bytes and two launches per chunk.
-        const int lb = blockIdx.y / 3, g = blockIdx.y - 3 * lb, b = sa.b0 + lb;
-        const int64_t lo = sa.n_off[b];
-        const double *tt = sa.t + lo, *amp = (g == 0 ? sa.wy : sa.w) + lo;
-        const double t0 = sa.stats[b].t0, fac = g == 2 ? 2.0 : 1.0, dff = sa.df * fac, f0f = sa.f0 * fac;
-        const double dn = (double)sa.nfft;
-        const int *tg = sa.tab16 + ((size_t)b * 3 + g) * sa.ntab16;
-        const bool unused = g == 1 && !sa.fit_mean;
-        for (int r = tid; r < P; r += (int)blockDim.x) {
-            double2 *cells = lds2 + (size_t)r * 17;
-#pragma unroll
-            for (int j = 0; j < CT; ++j) cells[j] = make_double2(0.0, 0.0);
-            if (r < ru && !unused) {
-                const int nA = r * N2 + c0, G16 = nA >> 4;
-                const double xhi = (double)nA + 19.0;
-                // candidates: positions in [nA - 4, nA + 28): no search, a handful of cadences, loads issued four at a time
-                const int i_lo = tg[G16], i_hi = tg[min(G16 + 2, sa.ntab16 - 1)];
-                for (int i0 = i_lo; i0 < i_hi; i0 += 4) {
-                    double tdv[4], av[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = min(i0 + u, i_hi - 1);
-                        tdv[u] = tt[i] - t0;
-                        av[u] = amp[i];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (i0 + u >= i_hi) break;
-                        const double td = tdv[u];
-                        double x = td * dn * dff;
-                        if (!(x < dn)) x = fmod(x, dn);  // ordered targets never wrap: the fmod of the reference is the identity
-                        if (x >= xhi) break;
-                        double c = 1.0, sn = 0.0;
-                        if (f0f > 0.0) sincos(6.283185307179586 * f0f * td, &sn, &c);
-                        const double hr = av[u] * c, hi = av[u] * sn;
-                        auto add = [&](int cell, double vr, double vi) {
-                            const int j = cell - nA;
-                            if (j >= 0 && j < CT) {
-                                double2 v = cells[j];
-                                v.x += vr;
-                                v.y += vi;
-                                cells[j] = v;
-                            }
-                        };
-                        if (x == floor(x)) {  // fmod(x, 1) == 0
-                            add((int)x, hr, hi);
-                        } else {  // astropy extirpolate, M = 4 (same arithmetic as extirpolate4 above)
-                            int ilo = (int)(x - 2.0);
-                            ilo = min(max(ilo, 0), sa.nfft - 4);
-                            const double d0 = x - (double)ilo, d1 = d0 - 1.0, d2 = d0 - 2.0, d3 = d0 - 3.0;
-                            const double prod = ((d0 * d1) * d2) * d3;
-                            const double nr = hr * prod, ni = hi * prod;
-                            const double q3 = 6.0 * d3, q2 = -2.0 * d2, q1 = 2.0 * d1, q0 = -6.0 * d0;
-                            add(ilo + 3, nr / q3, ni / q3);
-                            add(ilo + 2, nr / q2, ni / q2);
-                            add(ilo + 1, nr / q1, ni / q1);
-                            add(ilo, nr / q0, ni / q0);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (p1) {
-#pragma unroll
-            for (int i = 0; i < A; ++i) xin[i] = lds2[(size_t)(i * Bq + jk) * 17 + f];
-        }
-        __syncthreads();  // the exchange tile of the passes below reuses this LDS
-    } else if (p1) {
+    if (p1) {
 #pragma unroll
         for (int i = 0; i < A; ++i) {
             const int r = i * Bq + jk;
@@ -790,8 +639,7 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
 #pragma unroll
             for (int kb = 0; kb < Bq; ++kb) {
                 const int q = jk + A * kb;
-                const int k1p = perm ? s * P + q : Q * q + s;
-                O[(size_t)k1p * CT + f] = cmul(u[brev_c(kb, LB)], w);
+                O[(size_t)(Q * q + s) * CT + f] = cmul(u[brev_c(kb, LB)], w);
                 w = cmul(w, stepc);
             }
         }
@@ -817,323 +665,146 @@ __global__ __launch_bounds__(256) void fft_rows_reg_kernel(const double2 *__rest
     block_fft<LA, LB, 0>(RT, lds2, load, store);
 }
 
-// ------------------------------------------------------------------------------------------------ three-phase FFT
-// Block transform of NF sequences of length n = A*B*C (A = 2^LA, ...) in THREE register phases with two LDS exchanges.
-// A thread never holds more than max(A, B, C) <= 16 points, so the kernels built on it need ~100 VGPRs instead of
-// ~220-290 and 4-5 waves per SIMD stay resident: loads of one wave overlap the butterflies of the others (the
-// two-phase kernels above run 1-2 waves per SIMD and alternate between waiting on HBM and computing).
-//   input index  e = a*B*C + b*C + c,   output index  k = ka + A*kb + A*B*kc
-//   phase 1  thread t = b*C + c        A-point FFT over a, times W_n^{t ka}            -> LDS [ka][t]       (stride S1)
-//   phase 2  thread (ka, c)            B-point FFT over b, times W_{BC}^{c kb}         -> LDS [c][ka + A kb] (stride S3)
-//   phase 3  thread t3 = ka + A*kb     C-point FFT over c                               -> store(f, t3 + A*B*kc, ., kc)
-// load(f, e) / store(f, k, value, kc) as in block_fft.  Threads per sequence T = max(BC, AC, AB); tile: NF * FFT3_TILE
-// double2.  MODE as in block_fft (thread order of the phase-1 loads).
-template <int LA, int LB, int LC>
-struct Fft3 {
-    static constexpr int A = 1 << LA, B = 1 << LB, C = 1 << LC, n = A * B * C;
-    static constexpr int T = (B * C > A * C ? (B * C > A * B ? B * C : A * B) : (A * C > A * B ? A * C : A * B));
-    static constexpr int S1 = B * C + 8, S3 = A * B + 2;  // strides chosen so 16-lane groups of 16-B accesses tile the banks
-    static constexpr int TILE = (A * S1 > C * S3 ? A * S1 : C * S3);
-};
-
-// KOUT: only the outputs kc < KOUT of phase 3 are wanted (C = 8, KOUT <= 2: two direct sums instead of the 8-point FFT).
-// steps != nullptr: the two per-thread twiddle steps (W_n^t, W_{BC}^{c2}), which depend on the thread only — a caller
-// that transforms several arrays with the same thread mapping computes them once (fft3_twiddle_steps) instead of two
-// sincospi per array.
-template <int LA, int LB, int LC, int MODE, int KOUT = (1 << LC), class Load, class Store>
-__device__ __forceinline__ void block_fft3(int NF, double2 *tile, Load load, Store store, int tw = 1,
-                                           const double2 *steps = nullptr) {
-    using F = Fft3<LA, LB, LC>;
-    constexpr int A = F::A, B = F::B, C = F::C, n = F::n, T = F::T, S1 = F::S1, S3 = F::S3;
-    const int tid = threadIdx.x;
-    int f, t;
-    if (MODE == 1) {
-        f = tid % NF;
-        t = tid / NF;
-    } else if (MODE == 2) {
-        const int jl = tid % tw, rest = tid / tw;
-        f = rest % NF;
-        t = jl + tw * (rest / NF);
-    } else {
-        f = tid / T;
-        t = tid % T;
-    }
-    const bool live = tid < NF * T;
-    double2 *my = tile + (size_t)f * F::TILE;
-    // ---- phase 1
-    if (live && t < B * C) {
-        double2 v[A];
-#pragma unroll
-        for (int a = 0; a < A; ++a) v[a] = load(f, a * (B * C) + t);
-        reg_fft<LA>(v);
-        double2 step;
-        if (steps) {
-            step = steps[0];
-        } else {
-            double s1, c1;
-            sincospi(2.0 * (double)t / (double)n, &s1, &c1);
-            step = make_double2(c1, s1);
-        }
-        double2 w = make_double2(1.0, 0.0);
-#pragma unroll
-        for (int ka = 0; ka < A; ++ka) {
-            my[ka * S1 + t] = cmul(v[brev_c(ka, LA)], w);
-            w = cmul(w, step);
-        }
-    }
-    __syncthreads();
-    // ---- phase 2
-    double2 u[B];
-    const int ka2 = t / C, c2 = t % C;
-    if (live && t < A * C) {
-#pragma unroll
-        for (int b = 0; b < B; ++b) u[b] = my[ka2 * S1 + b * C + c2];
-        reg_fft<LB>(u);
-    }
-    __syncthreads();  // every read of the [ka][t] layout is done before the tile is overwritten
-    if (live && t < A * C) {
-        double2 step;
-        if (steps) {
-            step = steps[1];
-        } else {
-            double s1, c1;
-            sincospi(2.0 * (double)c2 / (double)(B * C), &s1, &c1);
-            step = make_double2(c1, s1);
-        }
-        double2 w = make_double2(1.0, 0.0);
-#pragma unroll
-        for (int kb = 0; kb < B; ++kb) {
-            my[c2 * S3 + ka2 + A * kb] = cmul(u[brev_c(kb, LB)], w);
-            w = cmul(w, step);
-        }
-    }
-    __syncthreads();
-    // ---- phase 3
-    if (live && t < A * B) {
-        double2 z[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) z[c] = my[c * S3 + t];
-        if (C == 8 && KOUT <= 2) {
-            // X[0] = sum z_c;  X[1] = sum z_c W^c, W = e^{+2 pi i / 8}: (z0 - z4) + i (z2 - z6) + W (z1 - z5) + W^3 (z3 - z7)
-            const double2 x0 = make_double2(((z[0].x + z[4].x) + (z[2].x + z[6].x)) + ((z[1].x + z[5].x) + (z[3].x + z[7].x)),
-                                            ((z[0].y + z[4].y) + (z[2].y + z[6].y)) + ((z[1].y + z[5].y) + (z[3].y + z[7].y)));
-            store(f, t, x0, 0);
-            if (KOUT > 1) {
-                const double r = 0.70710678118654752440;
-                const double2 d04 = make_double2(z[0].x - z[4].x, z[0].y - z[4].y), d26 = make_double2(z[2].x - z[6].x, z[2].y - z[6].y);
-                const double2 d15 = make_double2(z[1].x - z[5].x, z[1].y - z[5].y), d37 = make_double2(z[3].x - z[7].x, z[3].y - z[7].y);
-                // W d15 = r ((x - y) + i (x + y));  W^3 d37 = r ((-x - y) + i (x - y))
-                const double2 x1 = make_double2((d04.x - d26.y) + r * ((d15.x - d15.y) - (d37.x + d37.y)),
-                                                (d04.y + d26.x) + r * ((d15.x + d15.y) + (d37.x - d37.y)));
-                store(f, t + A * B, x1, 1);
-            }
-        } else {
-            reg_fft<LC>(z);
-#pragma unroll
-            for (int kc = 0; kc < C; ++kc) store(f, t + A * B * kc, z[brev_c(kc, LC)], kc);
-        }
-    }
-}
-
-// the two twiddle steps of block_fft3 for this thread (MODE 1 / 2 thread mapping as in block_fft3)
-template <int LA, int LB, int LC, int MODE>
-__device__ __forceinline__ void fft3_twiddle_steps(int NF, int tw, double2 *steps) {
-    using F = Fft3<LA, LB, LC>;
-    const int tid = threadIdx.x;
-    int t;
-    if (MODE == 1) {
-        t = tid / NF;
-    } else if (MODE == 2) {
-        const int jl = tid % tw, rest = tid / tw;
-        t = jl + tw * (rest / NF);
-    } else {
-        t = tid % F::T;
-    }
-    double s1, c1;
-    sincospi(2.0 * (double)t / (double)F::n, &s1, &c1);
-    steps[0] = make_double2(c1, s1);
-    sincospi(2.0 * (double)(t % F::C) / (double)(F::B * F::C), &s1, &c1);
-    steps[1] = make_double2(c1, s1);
-}
-
-// step 2 fused with the closed form, three-phase version: thread (f, t3) ends with the outputs k2 = t3 + A*B*kc of row
-// r0 + f and keeps those below M / N1 (kc < KC) for the three grids
-template <int LA, int LB, int LC, int KC>
-__global__ __launch_bounds__(512) void fft_rows_power3_kernel(const double2 *__restrict__ grids, int m1, int RT,
-                                                               const int64_t *__restrict__ n_off,
-                                                               const FastStats *__restrict__ stats, int b0, double f0,
-                                                               double df, int64_t M, int fit_mean, int norm,
-                                                               const double *__restrict__ scale,
-                                                               double *__restrict__ power, int tw) {
-    extern __shared__ __attribute__((aligned(16))) double2 lds2[];
-    using F = Fft3<LA, LB, LC>;
-    constexpr int m2 = LA + LB + LC;
-    const int twl = tw > 0 ? 31 - __clz(tw) : 0;
-    const int lb = blockIdx.y, r0 = blockIdx.x * RT;
-    double2 keep[3][KC];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int q = 0; q < KC; ++q) keep[g][q] = make_double2(0.0, 0.0);
-    double2 steps[2];  // the thread's twiddle steps are the same for the three grids
-    if (tw < 0)
-        fft3_twiddle_steps<LA, LB, LC, 1>(RT, tw, steps);
-    else
-        fft3_twiddle_steps<LA, LB, LC, 2>(RT, tw, steps);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        if (g == 1 && !fit_mean) continue;
-        const double2 *G = grids + ((size_t)(lb * 3 + g) << (m1 + m2));
-        auto store = [&](int, int, double2 v, int kc) {
-            if (kc < KC) keep[g][kc < KC ? kc : 0] = v;
-        };
-        if (tw < 0) {  // row-tiled layout (RT == -tw): this workgroup's rows are one contiguous chunk, f fastest
-            const double2 *Gt = G + (((size_t)blockIdx.x << m2) * (size_t)RT);
-            auto load = [&](int f, int c) -> double2 { return Gt[(size_t)c * RT + f]; };
-            block_fft3<LA, LB, LC, 1, KC>(RT, lds2, load, store, 1, steps);
-        } else {
-            auto load = [&](int f, int c) -> double2 {
-                return G[((((size_t)(c >> twl) << m1) + (r0 + f)) << twl) + (c & (tw - 1))];
-            };
-            block_fft3<LA, LB, LC, 2, KC>(RT, lds2, load, store, tw, steps);
-        }
-        __syncthreads();
-    }
-    // the (f, t) mapping of block_fft3 (MODE 1 for the row-tiled layout, MODE 2 otherwise)
-    const int tid = threadIdx.x;
-    if (tid >= RT * F::T) return;
-    int f, t3;
-    if (tw < 0) {
-        f = tid % RT;
-        t3 = tid / RT;
-    } else {
-        const int jl = tid % tw, rest = tid / tw;
-        f = rest % RT;
-        t3 = jl + tw * (rest / RT);
-    }
-    if (t3 >= F::A * F::B) return;
-    const int b = b0 + lb;
-    const FastStats st = stats[b];
-    const double nn = (double)(n_off[b + 1] - n_off[b]);
-    const double sc = scale ? scale[b] : 1.0;
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-        const long long k = (long long)(r0 + f) + ((long long)(t3 + F::A * F::B * kc) << m1);
-        if (k >= M) continue;
-        double2 a = keep[0][kc], bq = keep[1][kc], c2 = keep[2][kc];
-        if (st.t0 != 0.0) {
-            const double twopi = 6.283185307179586;
-            double s, c;
-            sincos(twopi * st.t0 * (f0 + df * (double)k), &s, &c);
-            a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
-            bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
-            sincos(twopi * st.t0 * (2.0 * f0 + 2.0 * df * (double)k), &s, &c);
-            c2 = make_double2(c2.x * c - c2.y * s, c2.x * s + c2.y * c);
-        }
-        power[(size_t)b * (size_t)M + k] = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY,
-                                                          0.5 * st.wsum, nn, sc);
-    }
-}
-
 // step 2 fused with the closed form: one workgroup transforms rows r0..r0+RT-1 of the THREE grids of a target in
 // turn (the LDS tile is reused), each phase-2 thread keeps the <= KB outputs it owns that fall below M, and the
-// power is computed in registers: the three spectra never go to memory.
+// power is computed in registers: the three spectra never go to memory.  With `peaks` the workgroup also leaves its
+// (largest power, lowest index attaining it; NaN skipped) in peaks[target][blockIdx.x] for lsf_peaks_kernel — the
+// periodogram's max_power / argmax without a second pass over the B x M spectra.
+struct PeakPart {
+    double v;
+    long long k;  // -1: no finite power in this workgroup's share
+};
+
+__device__ __forceinline__ bool peak_better(double v2, long long k2, double v, long long k) {
+    return k2 >= 0 && (k < 0 || v2 > v || (v2 == v && k2 < k));  // np.nanargmax: the first maximum wins
+}
+
 template <int LA, int LB, int KB>
 __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__restrict__ grids, int m1, int RT,
                                                               const int64_t *__restrict__ n_off,
                                                               const FastStats *__restrict__ stats, int b0, double f0,
                                                               double df, int64_t M, int fit_mean, int norm,
                                                               const double *__restrict__ scale,
-                                                              double *__restrict__ power, int tw, int lp, int tpad) {
+                                                              double *__restrict__ power, int tw,
+                                                              PeakPart *__restrict__ peaks) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int m2 = LA + LB, A = 1 << LA;
     const int N2 = 1 << m2;
     const int twl = tw ? 31 - __clz(tw) : 0;
-    // padded column-tile stride of the intermediate (see fft_cols_pruned_kernel); tpad = 0: the plain power-of-two layout
-    const size_t tstride = tw ? (((size_t)tw << m1) + (size_t)tpad) : 0, gstride = tw ? (size_t)(N2 >> twl) * tstride : ((size_t)1 << (m1 + m2));
+    // column-tiled intermediate [c / tw][k1][c % tw] (tw = 0: the natural row-major layout)
+    const size_t tstride = tw ? ((size_t)tw << m1) : 0, gstride = (size_t)1 << (m1 + m2);
     const int lb = blockIdx.y, r0 = blockIdx.x * RT;
     double2 keep0[KB], keep1[KB], keep2[KB];
 #pragma unroll
     for (int q = 0; q < KB; ++q) keep0[q] = keep1[q] = keep2[q] = make_double2(0.0, 0.0);
-    {
-        const double2 *G = grids + (size_t)(lb * 3 + 0) * gstride;
+    auto transform = [&](int g, double2(&keep)[KB]) {
+        const double2 *G = grids + (size_t)(lb * 3 + g) * gstride;
         auto load = [&](int f, int c) -> double2 {
             return tw ? G[(size_t)(c >> twl) * tstride + ((size_t)(r0 + f) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
         };
         auto store = [&](int, int, double2 v, int kb) {
-            if (kb < KB) keep0[kb < KB ? kb : 0] = v;
+            if (kb < KB) keep[kb < KB ? kb : 0] = v;
         };
         if (tw)
             block_fft<LA, LB, 2>(RT, lds2, load, store, tw);
         else
             block_fft<LA, LB, 0>(RT, lds2, load, store);
-    }
+    };
+    transform(0, keep0);
     __syncthreads();
-    if (fit_mean) {
-        const double2 *G = grids + (size_t)(lb * 3 + 1) * gstride;
-        auto load = [&](int f, int c) -> double2 {
-            return tw ? G[(size_t)(c >> twl) * tstride + ((size_t)(r0 + f) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
-        };
-        auto store = [&](int, int, double2 v, int kb) {
-            if (kb < KB) keep1[kb < KB ? kb : 0] = v;
-        };
-        if (tw)
-            block_fft<LA, LB, 2>(RT, lds2, load, store, tw);
-        else
-            block_fft<LA, LB, 0>(RT, lds2, load, store);
-    }
+    if (fit_mean) transform(1, keep1);
     __syncthreads();
-    {
-        const double2 *G = grids + (size_t)(lb * 3 + 2) * gstride;
-        auto load = [&](int f, int c) -> double2 {
-            return tw ? G[(size_t)(c >> twl) * tstride + ((size_t)(r0 + f) << twl) + (c & (tw - 1))] : G[(size_t)(r0 + f) * N2 + c];
-        };
-        auto store = [&](int, int, double2 v, int kb) {
-            if (kb < KB) keep2[kb < KB ? kb : 0] = v;
-        };
-        if (tw)
-            block_fft<LA, LB, 2>(RT, lds2, load, store, tw);
-        else
-            block_fft<LA, LB, 0>(RT, lds2, load, store);
-    }
+    transform(2, keep2);
     const int tid = threadIdx.x;
-    if (tid >= RT * A) return;
-    const int ka = tid / RT, f = tid - ka * RT;  // the phase-2 mapping of block_fft
-    const int b = b0 + lb;
-    const FastStats st = stats[b];
-    const double nn = (double)(n_off[b + 1] - n_off[b]);
-    const double sc = scale ? scale[b] : 1.0;
-    // row r0 + f of the intermediate is k1 itself, or (lp > 0: fft_cols_pruned_kernel with perm) row s P + q of k1 = Q q + s
-    const int rp = r0 + f;
-    const int k1 = lp ? (((rp & ((1 << lp) - 1)) << (m1 - lp)) + (rp >> lp)) : rp;
-    // e^{2 pi i t0 f} for this thread's outputs k = k1 + N1 (ka + A kb): one sincos for kb = 0 and one for the step between
-    // consecutive kb (a rotation by 2 pi t0 df N1 A), the 2f phase by the double-angle formulas (its argument is exactly
-    // twice the 1f one) — 2 sincos per thread instead of 2 per output; the products drift by < 1e-15 over KB <= 8 steps.
-    const double twopi = 6.283185307179586;
-    double ph_c = 1.0, ph_s = 0.0, st_c = 1.0, st_s = 0.0;
-    if (st.t0 != 0.0) {
-        const long long kfirst = (long long)k1 + ((long long)ka << m1);
-        sincos(twopi * st.t0 * (f0 + df * (double)kfirst), &ph_s, &ph_c);
-        sincos(twopi * st.t0 * (df * (double)((long long)A << m1)), &st_s, &st_c);
-    }
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const long long k = (long long)k1 + ((long long)(ka + A * kb) << m1);
-        if (k < M) {
-            double2 a = keep0[kb], bq = keep1[kb], c2 = keep2[kb];
-            if (st.t0 != 0.0) {
-                const double c = ph_c, s = ph_s;
-                a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
-                bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
-                const double cc = c * c - s * s, ss = 2.0 * s * c;
-                c2 = make_double2(c2.x * cc - c2.y * ss, c2.x * ss + c2.y * cc);
-            }
-            power[(size_t)b * (size_t)M + k] = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY,
-                                                              0.5 * st.wsum, nn, sc);
+    double best_v = 0.0;
+    long long best_k = -1;
+    if (tid < RT * A) {
+        const int ka = tid / RT, f = tid - ka * RT;  // the phase-2 mapping of block_fft
+        const int b = b0 + lb;
+        const FastStats st = stats[b];
+        const double nn = (double)(n_off[b + 1] - n_off[b]);
+        const double sc = scale ? scale[b] : 1.0;
+        const int k1 = r0 + f;
+        // e^{2 pi i t0 f} for this thread's outputs k = k1 + N1 (ka + A kb): one sincos for kb = 0 and one for the step
+        // between consecutive kb (a rotation by 2 pi t0 df N1 A), the 2f phase by the double-angle formulas (its argument is
+        // exactly twice the 1f one) — 2 sincos per thread instead of 2 per output; the products drift by < 1e-15 over KB <= 8
+        const double twopi = 6.283185307179586;
+        double ph_c = 1.0, ph_s = 0.0, st_c = 1.0, st_s = 0.0;
+        if (st.t0 != 0.0) {
+            const long long kfirst = (long long)k1 + ((long long)ka << m1);
+            sincos(twopi * st.t0 * (f0 + df * (double)kfirst), &ph_s, &ph_c);
+            sincos(twopi * st.t0 * (df * (double)((long long)A << m1)), &st_s, &st_c);
         }
-        const double nc = ph_c * st_c - ph_s * st_s, ns = ph_s * st_c + ph_c * st_s;
-        ph_c = nc;
-        ph_s = ns;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const long long k = (long long)k1 + ((long long)(ka + A * kb) << m1);
+            if (k < M) {
+                double2 a = keep0[kb], bq = keep1[kb], c2 = keep2[kb];
+                if (st.t0 != 0.0) {
+                    const double c = ph_c, s = ph_s;
+                    a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+                    bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
+                    const double cc = c * c - s * s, ss = 2.0 * s * c;
+                    c2 = make_double2(c2.x * cc - c2.y * ss, c2.x * ss + c2.y * cc);
+                }
+                const double pw = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY, 0.5 * st.wsum, nn, sc);
+                power[(size_t)b * (size_t)M + k] = pw;
+                if (pw == pw && peak_better(pw, k, best_v, best_k)) {  // ascending k within the thread: strict > would do
+                    best_v = pw;
+                    best_k = k;
+                }
+            }
+            const double nc = ph_c * st_c - ph_s * st_s, ns = ph_s * st_c + ph_c * st_s;
+            ph_c = nc;
+            ph_s = ns;
+        }
+    }
+    if (peaks == nullptr) return;
+    // workgroup reduction of (best_v, best_k): waves by shuffles, then through the (now idle) exchange tile
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(best_v, o);
+        const long long k2 = __shfl_xor(best_k, o);
+        if (peak_better(v2, k2, best_v, best_k)) {
+            best_v = v2;
+            best_k = k2;
+        }
+    }
+    __syncthreads();  // every phase-2 read of the tile is done
+    PeakPart *wp = reinterpret_cast<PeakPart *>(lds2);
+    if ((tid & 63) == 0) wp[tid >> 6] = PeakPart{best_v, best_k};
+    __syncthreads();
+    if (tid == 0) {
+        PeakPart r = wp[0];
+        for (int wv = 1; wv < ((int)blockDim.x >> 6); ++wv)
+            if (peak_better(wp[wv].v, wp[wv].k, r.v, r.k)) r = wp[wv];
+        peaks[(size_t)lb * gridDim.x + blockIdx.x] = r;
+    }
+}
+
+// per target: the best of its workgroups' partials -> max_power (NaN if no finite power), argmax (-1 then)
+__global__ __launch_bounds__(64) void lsf_peaks_kernel(const PeakPart *__restrict__ peaks, int nparts, int b0,
+                                                        double *__restrict__ max_out, int64_t *__restrict__ arg_out) {
+    const PeakPart *pp = peaks + (size_t)blockIdx.x * nparts;
+    double v = 0.0;
+    long long k = -1;
+    for (int i = threadIdx.x; i < nparts; i += 64)
+        if (peak_better(pp[i].v, pp[i].k, v, k)) {
+            v = pp[i].v;
+            k = pp[i].k;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(v, o);
+        const long long k2 = __shfl_xor(k, o);
+        if (peak_better(v2, k2, v, k)) {
+            v = v2;
+            k = k2;
+        }
+    }
+    if (threadIdx.x == 0) {
+        max_out[b0 + blockIdx.x] = k >= 0 ? v : NAN;
+        arg_out[b0 + blockIdx.x] = (int64_t)k;
     }
 }
 
@@ -1236,54 +907,43 @@ __global__ __launch_bounds__(256) void lsf_zero_kernel(double2 *__restrict__ gri
         for (int c = threadIdx.x; c < N2; c += 256) G[(size_t)r * N2 + c] = make_double2(0.0, 0.0);
 }
 
+// kernels with more than 64 KB of dynamic LDS need the attribute once per device: remembered in the handle
+static void want_lds(lk_handle *h, const void *fn, int bytes) {
+    for (const void *f : h->lds_attr_done)
+        if (f == fn) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    h->lds_attr_done.push_back(fn);
+}
+
+constexpr int COLS_TILE_PTS = 4096;  // points per column tile of the full-length register kernel
+
 template <int LA, int LB>
-static void launch_cols_t(int m2, int ngrids, double2 *grids, const int *rows_used, double2 *gout, int tw,
+static void launch_cols_t(lk_handle *h, int m2, int ngrids, double2 *grids, const int *rows_used, double2 *gout, int tw,
                           hipStream_t stream) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N2 = 1 << m2;
-    static const int ct_pts = getenv("LK_FFT_CT_PTS") ? atoi(getenv("LK_FFT_CT_PTS")) : 4096;  // points per column tile
-    const int CT = std::max(1, std::min(N2, std::min(ct_pts / n, 256 / std::max(A, Bq))));
+    const int CT = std::max(1, std::min(N2, std::min(COLS_TILE_PTS / n, 256 / std::max(A, Bq))));
     const int nt = ((CT * std::max(A, Bq) + 63) / 64) * 64;
-    static const bool split = getenv("LK_FFT_SPLIT") ? atoi(getenv("LK_FFT_SPLIT")) != 0 : false;  // measured 4 % slower (spills at 2 waves/SIMD)
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    if (split) {
-        const int fsts = A * LDT + (CT >= 32 ? 1 : 32 / CT);
-        hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB, true>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * fsts * 8,
-                           stream, grids, m2, CT, rows_used, gout, tw);
-    } else {
-        hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB, false>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * FST * 16,
-                           stream, grids, m2, CT, rows_used, gout, tw);
-    }
+    want_lds(h, reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB>), 160 * 1024);
+    hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * FST * 16, stream, grids,
+                       m2, CT, rows_used, gout, tw);
 }
 
 // width of the tiled intermediate layout: the column kernel's CT, capped by the row kernel's Bq (both powers of 2)
 static int tile_width(int m1, int m2) {
     const int la1 = (m1 + 1) / 2, lb1 = m1 / 2, n1 = 1 << m1;
-    static const int ct_pts = getenv("LK_FFT_CT_PTS") ? atoi(getenv("LK_FFT_CT_PTS")) : 4096;
-    const int ct = std::max(1, std::min(1 << m2, std::min(ct_pts / n1, 256 / std::max(1 << la1, 1 << lb1))));
+    const int ct = std::max(1, std::min(1 << m2, std::min(COLS_TILE_PTS / n1, 256 / std::max(1 << la1, 1 << lb1))));
     const int bq2 = 1 << (m2 / 2);
     return std::min(ct, bq2);
 }
 
 template <int LA, int LB>
-static void launch_rows_t(int m1, int ngrids, const double2 *grids, int nkeep, double2 *spec, hipStream_t stream) {
+static void launch_rows_t(lk_handle *h, int m1, int ngrids, const double2 *grids, int nkeep, double2 *spec, hipStream_t stream) {
     constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
     const int N1 = 1 << m1;
     const int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
     const int nt = ((RT * std::max(A, Bq) + 63) / 64) * 64;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_reg_kernel<LA, LB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        attr = true;
-    }
+    want_lds(h, reinterpret_cast<const void *>(fft_rows_reg_kernel<LA, LB>), 100 * 1024);
     hipLaunchKernelGGL((fft_rows_reg_kernel<LA, LB>), dim3(N1 / RT, ngrids), dim3(nt), (size_t)RT * FST * 16, stream,
                        grids, m1, RT, nkeep, spec);
 }
@@ -1297,32 +957,27 @@ struct FusedArgs {
     int fit_mean, norm;
     const double *scale;
     double *power;
+    PeakPart *peaks;  // nullptr: spectra only
 };
 
+// rows per workgroup of the fused step 2 for an N2 = 2^(LA+LB)-point row transform
+template <int LA, int LB>
+static int rows_power_rt(int m1) {
+    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq;
+    return std::max(1, std::min(1 << m1, std::min(4096 / n, 256 / std::max(A, Bq))));
+}
+
 template <int LA, int LB, int KB>
-static void launch_rows_power_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
-                                hipStream_t stream, int lp = 0, int tpad = 0) {
-    constexpr int A = 1 << LA, Bq = 1 << LB, n = A * Bq, LDT = Bq + 1, FST = A * LDT + 1;
+static void launch_rows_power_t(lk_handle *h, int m1, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
+                                hipStream_t stream) {
+    constexpr int A = 1 << LA, Bq = 1 << LB, LDT = Bq + 1, FST = A * LDT + 1;
     const int N1 = 1 << m1;
-    int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
-    // LK_FFT_RT=16: twice the rows per workgroup (twice the contiguous run per column tile the loads see) at the price
-    // of one workgroup per CU (140 KB of LDS at N2 = 512)
-    if (const char *e = getenv("LK_FFT_RT")) {
-        const int want = atoi(e);
-        if (want >= 1 && want <= N1 && (N1 % want) == 0 && want * std::max(A, Bq) <= 512 &&
-            (size_t)want * FST * 16 <= 160 * 1024)
-            RT = want;
-    }
+    const int RT = rows_power_rt<LA, LB>(m1);
     const int nt = ((RT * std::max(A, Bq) + 63) / 64) * 64;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_power_kernel<LA, LB, KB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    want_lds(h, reinterpret_cast<const void *>(fft_rows_power_kernel<LA, LB, KB>), 160 * 1024);
     hipLaunchKernelGGL((fft_rows_power_kernel<LA, LB, KB>), dim3(N1 / RT, ntargets), dim3(nt), (size_t)RT * FST * 16,
                        stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm, a.scale,
-                       a.power, tw, lp, tpad);
+                       a.power, tw, a.peaks);
 }
 
 // returns false if the (m2, outputs-per-thread) combination has no fused instantiation
@@ -1332,108 +987,62 @@ static bool rows_power_available(int m1, int m2, int64_t M) {
     return m2 >= 4 && m2 <= 10 && (k2need + Aa - 1) / Aa <= 8;
 }
 
-template <int LA, int LB, int LC, int KC>
-static void launch_rows_power3_t(int m1, int ntargets, const double2 *grids, const FusedArgs &a, int tw, hipStream_t stream) {
-    using F = Fft3<LA, LB, LC>;
-    const int N1 = 1 << m1;
-    static const int rt_env = getenv("LK_FFT3_RT") ? atoi(getenv("LK_FFT3_RT")) : 4;  // 4 rows: 37 KB LDS, 4 workgroups per CU
-    int RT = std::max(1, std::min(N1, 512 / F::T));
-    if (rt_env > 0) RT = std::max(1, std::min(RT, rt_env));
-    while (RT > 1 && (N1 % RT)) --RT;
-    if (tw < 0) RT = -tw;  // the row-tiled intermediate fixes the rows per workgroup
-    const int nt = ((RT * F::T + 63) / 64) * 64;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_power3_kernel<LA, LB, LC, KC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        attr = true;
+#define LK_M2_SWITCH(m2, X) \
+    switch (m2) {           \
+        case 4: X(2, 2)     \
+        case 5: X(3, 2)     \
+        case 6: X(3, 3)     \
+        case 7: X(4, 3)     \
+        case 8: X(4, 4)     \
+        case 9: X(5, 4)     \
+        default: X(5, 5)    \
     }
-    hipLaunchKernelGGL((fft_rows_power3_kernel<LA, LB, LC, KC>), dim3(N1 / RT, ntargets), dim3(nt),
-                       (size_t)RT * F::TILE * 16, stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M,
-                       a.fit_mean, a.norm, a.scale, a.power, tw);
+
+// workgroups per target of the fused step 2 (= per-target peak partials)
+static int rows_power_parts(int m1, int m2) {
+#define LK_X(la, lb) return (1 << m1) / rows_power_rt<la, lb>(m1);
+    LK_M2_SWITCH(m2, LK_X)
+#undef LK_X
 }
 
-// three-phase step 2 where an instantiation exists (needs the tiled intermediate layout, tw >= 1, T % tw == 0)
-static bool launch_rows_power3(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
-                               hipStream_t stream) {
-    // measured on configs[1]: +2 % on one box, -1.3 % on another vs the two-phase kernel at 2 waves/SIMD — step 2 is
-    // limited by how fast HBM serves its 64-B x RT runs, not by occupancy — so the three-phase kernel is opt-in
-    if (!(getenv("LK_FFT3") && atoi(getenv("LK_FFT3")) == 1)) return false;
-    const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
-#define LK_RP3(la, lb, lc)                                                              \
-    {                                                                                   \
-        const int ab = 1 << ((la) + (lb));                                              \
-        const int kc = (int)((k2need + ab - 1) / ab);                                   \
-        if (kc <= 2) {                                                                  \
-            launch_rows_power3_t<la, lb, lc, 2>(m1, ntargets, grids, a, tw, stream);    \
-            return true;                                                                \
-        }                                                                               \
-        if (kc <= 4 && (1 << (lc)) >= 4) {                                              \
-            launch_rows_power3_t<la, lb, lc, 4>(m1, ntargets, grids, a, tw, stream);    \
-            return true;                                                                \
-        }                                                                               \
-        return false;                                                                   \
-    }
-    switch (m2) {
-        case 8: LK_RP3(3, 3, 2)
-        case 9: LK_RP3(3, 3, 3)
-        case 10: LK_RP3(4, 3, 3)
-        default: return false;
-    }
-#undef LK_RP3
-}
-
-static bool launch_rows_power(int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
-                              hipStream_t stream, int lp = 0, int tpad = 0) {
-    if (lp == 0 && launch_rows_power3(m1, m2, ntargets, grids, a, tw, stream)) return true;
-    if (tw < 0) return false;  // the two-phase kernel below reads the column-tiled layout only
+static bool launch_rows_power(lk_handle *h, int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
+                              hipStream_t stream) {
     const int LA = (m2 + 1) / 2, Aa = 1 << LA;
     const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
     const int kb = (int)((k2need + Aa - 1) / Aa);
-    if (kb > 8) return false;
-#define LK_RP(la, lb)                                                                  \
-    if (kb <= 4)                                                                       \
-        launch_rows_power_t<la, lb, 4>(m1, ntargets, grids, a, tw, stream, lp, tpad);  \
-    else                                                                               \
-        launch_rows_power_t<la, lb, 8>(m1, ntargets, grids, a, tw, stream, lp, tpad);  \
-    return true;
-    switch (m2) {
-        case 4: LK_RP(2, 2)
-        case 5: LK_RP(3, 2)
-        case 6: LK_RP(3, 3)
-        case 7: LK_RP(4, 3)
-        case 8: LK_RP(4, 4)
-        case 9: LK_RP(5, 4)
-        case 10: LK_RP(5, 5)
-        default: return false;
+    if (kb > 8 || m2 < 4 || m2 > 10) return false;
+#define LK_X(la, lb)                                                            \
+    {                                                                           \
+        if (kb <= 4)                                                            \
+            launch_rows_power_t<la, lb, 4>(h, m1, ntargets, grids, a, tw, stream); \
+        else                                                                    \
+            launch_rows_power_t<la, lb, 8>(h, m1, ntargets, grids, a, tw, stream); \
+        return true;                                                            \
     }
-#undef LK_RP
+    LK_M2_SWITCH(m2, LK_X)
+#undef LK_X
 }
 
-static void launch_cols_reg(int m1, int m2, int ngrids, double2 *grids, const int *rows_used, double2 *gout, int tw,
-                            hipStream_t stream) {
-    switch (m1) {
-        case 4: launch_cols_t<2, 2>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
-        case 5: launch_cols_t<3, 2>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
-        case 6: launch_cols_t<3, 3>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
-        case 7: launch_cols_t<4, 3>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
-        case 8: launch_cols_t<4, 4>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
-        case 9: launch_cols_t<5, 4>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
-        default: launch_cols_t<5, 5>(m2, ngrids, grids, rows_used, gout, tw, stream); break;
+static void launch_cols_reg(lk_handle *h, int m1, int m2, int ngrids, double2 *grids, const int *rows_used, double2 *gout,
+                            int tw, hipStream_t stream) {
+#define LK_X(la, lb)                                                                  \
+    {                                                                                 \
+        launch_cols_t<la, lb>(h, m2, ngrids, grids, rows_used, gout, tw, stream);      \
+        break;                                                                        \
     }
+    LK_M2_SWITCH(m1, LK_X)
+#undef LK_X
 }
 
-static void launch_rows_reg(int m1, int m2, int ngrids, const double2 *grids, int nkeep, double2 *spec,
+static void launch_rows_reg(lk_handle *h, int m1, int m2, int ngrids, const double2 *grids, int nkeep, double2 *spec,
                             hipStream_t stream) {
-    switch (m2) {
-        case 4: launch_rows_t<2, 2>(m1, ngrids, grids, nkeep, spec, stream); break;
-        case 5: launch_rows_t<3, 2>(m1, ngrids, grids, nkeep, spec, stream); break;
-        case 6: launch_rows_t<3, 3>(m1, ngrids, grids, nkeep, spec, stream); break;
-        case 7: launch_rows_t<4, 3>(m1, ngrids, grids, nkeep, spec, stream); break;
-        case 8: launch_rows_t<4, 4>(m1, ngrids, grids, nkeep, spec, stream); break;
-        case 9: launch_rows_t<5, 4>(m1, ngrids, grids, nkeep, spec, stream); break;
-        default: launch_rows_t<5, 5>(m1, ngrids, grids, nkeep, spec, stream); break;
+#define LK_X(la, lb)                                                          \
+    {                                                                         \
+        launch_rows_t<la, lb>(h, m1, ngrids, grids, nkeep, spec, stream);      \
+        break;                                                                \
     }
+    LK_M2_SWITCH(m2, LK_X)
+#undef LK_X
 }
 
 // per call: the largest rows_used over all targets and grids, and the number of targets that are not "ordered"
@@ -1461,27 +1070,21 @@ __global__ __launch_bounds__(256) void lsf_plan_kernel(const int *__restrict__ r
 }
 
 template <int LP>
-static void launch_cols_pruned_t(int m1, int m2, int ngrids, const double2 *grids, const int *rows_used, double2 *gout,
-                                 int perm, int tpad, const SpreadArgs &sa, hipStream_t stream) {
+static void launch_cols_pruned_t(lk_handle *h, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
+                                 double2 *gout, hipStream_t stream) {
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, LDT = Bq + 1, FST = A * LDT + 1;
-    static_assert(PRUNED_CT * FST >= (1 << LP) * 17, "the exchange tile must hold the fused spreader's P x 17 input cells");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_pruned_kernel<LP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    want_lds(h, reinterpret_cast<const void *>(fft_cols_pruned_kernel<LP>), 160 * 1024);
     hipLaunchKernelGGL((fft_cols_pruned_kernel<LP>), dim3((1 << m2) / PRUNED_CT, ngrids), dim3(PRUNED_CT * A),
-                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout, perm, tpad, sa);
+                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout);
 }
 
-static bool launch_cols_pruned(int lp, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
-                               double2 *gout, int perm, int tpad, const SpreadArgs &sa, hipStream_t stream) {
+static bool launch_cols_pruned(lk_handle *h, int lp, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
+                               double2 *gout, hipStream_t stream) {
     switch (lp) {
-        case 5: launch_cols_pruned_t<5>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
-        case 6: launch_cols_pruned_t<6>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
-        case 7: launch_cols_pruned_t<7>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
-        case 8: launch_cols_pruned_t<8>(m1, m2, ngrids, grids, rows_used, gout, perm, tpad, sa, stream); return true;
+        case 5: launch_cols_pruned_t<5>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
+        case 6: launch_cols_pruned_t<6>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
+        case 7: launch_cols_pruned_t<7>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
+        case 8: launch_cols_pruned_t<8>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
         default: return false;
     }
 }
@@ -1492,13 +1095,17 @@ static int ilog2_ceil(long long v) {
     return m;
 }
 
+// max_out / arg_out (both or neither): per-target nanmax / nanargmax of the spectra, from the fused kernel's partials where
+// that kernel runs, by argmax_launch over `power` otherwise.
 int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
                   double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
-                  const double *scale, int oversampling, double *power, hipStream_t stream) {
+                  const double *scale, int oversampling, double *power, hipStream_t stream, double *max_out,
+                  int64_t *arg_out) {
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
     LK_REQUIRE(M >= 0, "M must be >= 0");
     if (B == 0 || M == 0) return LK_OK;
     LK_REQUIRE(t && y && power, "t, y, power must be non-NULL");
+    LK_REQUIRE((max_out == nullptr) == (arg_out == nullptr), "max_power and argmax must both be given (or both NULL)");
     LK_REQUIRE(normalization >= LK_NORM_STANDARD && normalization <= LK_NORM_LK_PSD, "unknown normalization %d",
                normalization);
     LK_REQUIRE(f0 >= 0.0, "Frequencies must be positive");
@@ -1517,90 +1124,54 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int N1 = 1 << m1, N2 = 1 << m2;
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
     const size_t ntot = (size_t)n_off_host[B];
-    // targets per chunk: keep the grids (3 x 16 B x Nfft per target) within ~2 GiB
-    size_t chunk_bytes = (size_t)2 << 30;
-    if (const char *e = getenv("LK_FAST_CHUNK_MB")) chunk_bytes = (size_t)std::max(1, atoi(e)) << 20;  // tuning knob
+    // targets per chunk: the grids (3 x 16 B x Nfft per target) stay within 2 GiB (smaller chunks leave too few workgroups
+    // per launch, larger ones fall out of the Infinity Cache: measured)
+    const size_t chunk_bytes = (size_t)2 << 30;
     const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
+    const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
+    const bool fused = reg_path && rows_power_available(m1, m2, M);
+    const int nparts = fused ? rows_power_parts(m1, m2) : 0;
+    const int ntab = (nfft + SPREAD_W - 1) / SPREAD_W + 2;
     h->ws.reset();
-    // padding after each 16-column tile of the FFT intermediate (pruned path only), in 16-byte elements
-    static const int tpad_env = getenv("LK_LSF_TILE_PAD") ? std::max(0, atoi(getenv("LK_LSF_TILE_PAD"))) : 0;
-    const size_t pad_elems = ((size_t)(nfft >> m1) / PRUNED_CT + 1) * (size_t)tpad_env;
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
-                           (size_t)Bc * 3 * nfft * 16 * 4 + (size_t)Bc * 3 * pad_elems * 16 * 2 + (size_t)Bc * 3 * M * 16 +
-                           (size_t)B * 16 + (size_t)B * 6 * ((nfft + 1023) / 1024 + 2) * 4 + (size_t)B * 3 * (nfft / 16 + 2) * 4 + 16384);
+                           (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
+                           (size_t)B * 6 * ntab * 4 + (size_t)Bc * (nparts + 1) * sizeof(PeakPart) + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
     double *d_w = (double *)h->ws.alloc(ntot * 8), *d_wy = (double *)h->ws.alloc(ntot * 8);
     double2 *d_grids = (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16);
-    double2 *d_spec = (double2 *)h->ws.alloc((size_t)Bc * 3 * M * 16);
+    double2 *d_spec = fused ? nullptr : (double2 *)h->ws.alloc((size_t)Bc * 3 * M * 16);
     rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
     if (rc) return rc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        attr_set = true;
-    }
-    const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10 && !getenv("LK_FFT_RADIX2");
-    const bool fused = reg_path && !getenv("LK_FFT_UNFUSED") && rows_power_available(m1, m2, M);
-    int tw = tile_width(m1, m2);
-    {
-        // row-tiled intermediate (negative tw = -rows per tile): step-2 workgroups would stream contiguous chunks, but
-        // step 1's stores shrink to CT * H * 16-B runs — measured slower (18.5 ms at H = 8, 15.5 at H = 4 vs 15.0), so
-        // it stays an experiment behind LK_FFT_LAYOUT=1 (LK_FFT_RTILE sets H).
-        const long long k2need = (M + ((long long)1 << m1) - 1) >> m1;
-        const int la3 = m2 == 10 ? 4 : 3, lb3 = 3, lc3 = m2 - la3 - lb3;
-        const bool three = fused && m2 >= 8 && m2 <= 10 && getenv("LK_FFT3") && atoi(getenv("LK_FFT3")) == 1 &&
-                           (k2need + (1 << (la3 + lb3)) - 1) / (1 << (la3 + lb3)) <= (lc3 >= 2 ? 4 : 2);
-        const int h8 = getenv("LK_FFT_RTILE") ? atoi(getenv("LK_FFT_RTILE")) : 8;
-        const int T3 = 1 << std::max(std::max(lb3 + lc3, la3 + lc3), la3 + lb3);
-        if (three && getenv("LK_FFT_LAYOUT") && atoi(getenv("LK_FFT_LAYOUT")) == 1 && (h8 == 2 || h8 == 4 || h8 == 8) &&
-            h8 * T3 <= 512 && (1 << m1) % h8 == 0)
-            tw = -h8;
-    }
-    double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * (nfft + pad_elems) * 16) : nullptr;
+    const int tw = tile_width(m1, m2);
+    double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16) : nullptr;
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     int *d_plan = (int *)h->ws.alloc(64);
-    const bool tab_env = getenv("LK_LSF_TABLES") ? atoi(getenv("LK_LSF_TABLES")) != 0 : true;
-    const int ntab = (nfft + SPREAD_W - 1) / SPREAD_W + 2;
-    int *d_tab = (reg_path && tab_env) ? (int *)h->ws.alloc((size_t)B * 6 * ntab * 4) : nullptr;
-    // Fused extirpolation (LK_LSF_FUSED_SPREAD=1, off by default): measured 13.55 ms against 13.49 ms per 1000 targets —
-    // the column kernel grows by 93 us per launch (sincos and four divisions per cadence visit next to the FFT's own fp64
-    // work), the separate spreader's 100 us were mostly hidden behind its neighbours, and the prep kernel pays 0.3 ms for
-    // the fine table.  It would start to pay with the phases precomputed per cadence and the Lagrange weights formed
-    // without divisions; until then the separate spreader stays.
-    static const bool fuse_env = getenv("LK_LSF_FUSED_SPREAD") && atoi(getenv("LK_LSF_FUSED_SPREAD")) == 1;
-    const int ntab16 = nfft / 16 + 2;
-    int *d_tab16 = (d_tab && fuse_env && nfft >= 4096) ? (int *)h->ws.alloc((size_t)B * 3 * ntab16 * 4) : nullptr;
-    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
-                       d_w, d_wy, d_stats, df, nfft, m2, d_rows, d_tab, ntab, d_tab16, ntab16);
+    int *d_tab = reg_path ? (int *)h->ws.alloc((size_t)B * 6 * ntab * 4) : nullptr;
+    PeakPart *d_peaks = (fused && max_out) ? (PeakPart *)h->ws.alloc((size_t)Bc * nparts * sizeof(PeakPart)) : nullptr;
+    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
+                       d_w, d_wy, d_stats, df, nfft, m2, d_rows, d_tab, ntab);
     // ---- plan: the pruned column kernel applies when every grid of every target keeps its samples in the first
-    // P <= 256 rows (P < N1) and the row kernel can read 16-column tiles.  The decision needs one device word, so
+    // P <= 256 rows (P < N1) and the row kernel can read 16-column tiles.  The decision needs two device words, so
     // the call synchronises `stream` once here (20-30 us against a >= 1 ms step).
-    const bool pruned_env = getenv("LK_LSF_PRUNED") ? atoi(getenv("LK_LSF_PRUNED")) != 0 : true;
-    const int perm_env = getenv("LK_LSF_PERM") ? atoi(getenv("LK_LSF_PERM")) : 0;
-    const bool streams_env = getenv("LK_LSF_STREAMS") ? atoi(getenv("LK_LSF_STREAMS")) != 0 : true;
-    int lp = 0;
-    if (fused && pruned_env && tw > 0 && m2 >= 8 && m2 <= 10 && N2 >= PRUNED_CT) {
+    int lp = 0, n_unordered = B;
+    if (fused) {
         if (!h->h_plan) LK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h->h_plan), 64, hipHostMallocDefault));
         hipLaunchKernelGGL(lsf_plan_kernel, dim3(1), dim3(256), 0, stream, d_rows, B, d_plan);
         LK_HIP_CHECK(hipMemcpyAsync(h->h_plan, d_plan, 8, hipMemcpyDeviceToHost, stream));
         LK_HIP_CHECK(hipStreamSynchronize(stream));
-        const int max_rows = h->h_plan[0];
-        const int want = std::max(5, ilog2_ceil(std::max(1, max_rows)));
-        if (want <= 8 && want < m1) lp = want;
+        n_unordered = h->h_plan[1];
+        if (m2 >= 8 && m2 <= 10 && N2 >= PRUNED_CT) {
+            const int want = std::max(5, ilog2_ceil(std::max(1, h->h_plan[0])));
+            if (want <= 8 && want < m1) lp = want;
+        }
     }
-    // ---- fused extirpolation (opt-in, see above): every target ordered (h_plan[1] = number of unordered ones), the pruned
-    // column kernel in use and the fine table built -> no spread grid at all
-    const bool fused_spread = lp != 0 && d_tab16 != nullptr && h->h_plan[1] == 0 && PRUNED_CT == 16 && N2 % PRUNED_CT == 0;
     // ---- two streams: the spreader of chunk k+1 (LDS atomics, latency bound) runs on h->s_aux under the FFT kernels
     // of chunk k (HBM / VALU bound) on the caller's stream; the spread grids are double buffered, events order the
     // hand-overs.  All s_aux work is consumed through events by `stream`, so the caller still sees one stream.
-    const bool two_streams = fused && streams_env && B > Bc && !fused_spread;
+    const bool two_streams = fused && B > Bc;
     double2 *d_gridsB = nullptr;
     if (two_streams) {
         d_gridsB = (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16);
@@ -1613,49 +1184,31 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         LK_HIP_CHECK(hipEventRecord(h->ev_aux[0], stream));
         LK_HIP_CHECK(hipStreamWaitEvent(h->s_aux, h->ev_aux[0], 0));
     }
-    // ---- rows on their own stream: step 2 of chunk k (reads, with compute gaps: 4.4 TB/s) runs on h->s_rows while step 1
-    // of chunk k + 1 (mostly writes, 5.7 TB/s) runs on the caller's stream — a CU holds one workgroup of each (LDS 70 + 70
-    // KB) — the intermediate is double buffered.  Measured 13.29 against 13.39 ms per 1000 targets (-0.8 %): the step moves
-    // 64 GB at an average 4.8 TB/s whichever way the kernels are interleaved, so it is opt-in (LK_LSF_ROWS_STREAM=1).
-    static const bool rows_env = getenv("LK_LSF_ROWS_STREAM") && atoi(getenv("LK_LSF_ROWS_STREAM")) == 1;
-    const bool rows_stream = fused && rows_env && B > Bc;
-    double2 *d_grids2B = nullptr;
-    if (rows_stream) {
-        d_grids2B = (double2 *)h->ws.alloc((size_t)Bc * 3 * (nfft + pad_elems) * 16);
-        LK_REQUIRE(d_grids2B != nullptr, "workspace exhausted");
-        if (!h->s_rows) {
-            LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_rows, hipStreamNonBlocking));
-            for (int i = 0; i < 4; ++i) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_rows[i], hipEventDisableTiming));
-        }
-    }
     hipEvent_t *ev_spread = &h->ev_aux[0], *ev_cols = &h->ev_aux[2];  // [2] each, indexed by the grid buffer
+    if (!reg_path) {
+        want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
+        want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
+    }
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
     int chunk = 0;
-    bool rows_pending[2] = {false, false};
     for (int b0 = 0; b0 < B; b0 += Bc, ++chunk) {
         const int nb = std::min(Bc, B - b0);
         const int buf = two_streams ? (chunk & 1) : 0;
         double2 *gr = buf ? d_gridsB : d_grids;
         hipStream_t ss = two_streams ? h->s_aux : stream;  // the spreader's stream
         if (two_streams && chunk >= 2) LK_HIP_CHECK(hipStreamWaitEvent(ss, ev_cols[buf], 0));  // chunk-2's step 1 has read gr
-        if (fused_spread) {
-            const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power};
-            const SpreadArgs sa{t, d_w, d_wy, d_off, d_stats, d_tab16, b0, ntab16, nfft, fit_mean, f0, df};
-            LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, perm_env, tpad_env, sa, stream),
-                       "no pruned column kernel for 2^%d rows", lp);
-            LK_REQUIRE(launch_rows_power(m1, m2, nb, d_grids2, fa, PRUNED_CT, stream, perm_env ? lp : 0, tpad_env),
-                       "no step-2 kernel for this layout");
-            continue;
-        }
-        if (reg_path) {
+        // targets that are not "ordered" (unsorted time, or a 2f grid that wraps): zero their live rows, scatter with global
+        // atomics.  Skipped when the plan found none (the usual batch).
+        if (!reg_path) {
+            LK_HIP_CHECK(hipMemsetAsync(gr, 0, (size_t)nb * 3 * nfft * 16, ss));
+        } else if (n_unordered > 0) {
             hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, ss, gr, m1, m2,
                                d_rows + (size_t)b0 * 4);
-        } else {
-            LK_HIP_CHECK(hipMemsetAsync(gr, 0, (size_t)nb * 3 * nfft * 16, ss));
         }
-        hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, ss, t, d_w,
-                           d_wy, d_off, d_stats, b0, f0, df, nfft, fit_mean, gr,
-                           reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr);
+        if (!reg_path || n_unordered > 0)
+            hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, ss, t, d_w,
+                               d_wy, d_off, d_stats, b0, f0, df, nfft, fit_mean, gr,
+                               reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr);
         if (reg_path)
             hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)((nfft + SPREAD_W - 1) / SPREAD_W), nb, 3),
                                dim3(256), 0, ss, t, d_w, d_wy, d_off, d_stats, b0, f0, df, nfft, m2, fit_mean,
@@ -1664,35 +1217,25 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             LK_HIP_CHECK(hipEventRecord(ev_spread[buf], ss));
             LK_HIP_CHECK(hipStreamWaitEvent(stream, ev_spread[buf], 0));
         }
-        if (reg_path) {
-            const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power};
-            if (fused) {
-                // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
-                const int ib = rows_stream ? (chunk & 1) : 0;
-                double2 *g2 = ib ? d_grids2B : d_grids2;
-                if (rows_stream && rows_pending[ib]) LK_HIP_CHECK(hipStreamWaitEvent(stream, h->ev_rows[2 + ib], 0));  // chunk - 2's rows have read g2
-                if (lp) {
-                    LK_REQUIRE(launch_cols_pruned(lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, g2, perm_env, tpad_env, SpreadArgs{}, stream),
-                               "no pruned column kernel for 2^%d rows", lp);
-                } else {
-                    launch_cols_reg(m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, g2, tw, stream);
-                }
-                if (two_streams) LK_HIP_CHECK(hipEventRecord(ev_cols[buf], stream));
-                if (rows_stream) {
-                    LK_HIP_CHECK(hipEventRecord(h->ev_rows[ib], stream));            // columns of this chunk are in g2
-                    LK_HIP_CHECK(hipStreamWaitEvent(h->s_rows, h->ev_rows[ib], 0));
-                    LK_REQUIRE(launch_rows_power(m1, m2, nb, g2, fa, lp ? PRUNED_CT : tw, h->s_rows, (lp && perm_env) ? lp : 0, lp ? tpad_env : 0),
-                               "no step-2 kernel for this layout");
-                    LK_HIP_CHECK(hipEventRecord(h->ev_rows[2 + ib], h->s_rows));    // g2 may be overwritten after this
-                    rows_pending[ib] = true;
-                    continue;
-                }
-                LK_REQUIRE(launch_rows_power(m1, m2, nb, g2, fa, lp ? PRUNED_CT : tw, stream, (lp && perm_env) ? lp : 0, lp ? tpad_env : 0),
-                           "no step-2 kernel for this layout");
-                continue;
+        if (fused) {
+            // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
+            const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power, d_peaks};
+            if (lp) {
+                LK_REQUIRE(launch_cols_pruned(h, lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, stream),
+                           "no pruned column kernel for 2^%d rows", lp);
+            } else {
+                launch_cols_reg(h, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
             }
-            launch_cols_reg(m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, nullptr, 1, stream);
-            launch_rows_reg(m1, m2, nb * 3, gr, (int)M, d_spec, stream);
+            if (two_streams) LK_HIP_CHECK(hipEventRecord(ev_cols[buf], stream));
+            LK_REQUIRE(launch_rows_power(h, m1, m2, nb, d_grids2, fa, lp ? PRUNED_CT : tw, stream),
+                       "no step-2 kernel for this layout");
+            if (d_peaks)
+                hipLaunchKernelGGL(lsf_peaks_kernel, dim3(nb), dim3(64), 0, stream, d_peaks, nparts, b0, max_out, arg_out);
+            continue;
+        }
+        if (reg_path) {
+            launch_cols_reg(h, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, nullptr, 1, stream);
+            launch_rows_reg(h, m1, m2, nb * 3, gr, (int)M, d_spec, stream);
         } else {
             hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * 3), dim3(256), ldsA, stream, gr, m1, m2, CT);
             hipLaunchKernelGGL(fft_rows_kernel, dim3(N1 / RT, nb * 3), dim3(256), ldsB, stream, gr, m1, m2, RT,
@@ -1701,9 +1244,8 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         hipLaunchKernelGGL(lsf_power_kernel, dim3((unsigned)((M + 255) / 256), nb), dim3(256), 0, stream, d_spec,
                            d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power);
     }
-    for (int ib = 0; ib < 2; ++ib)  // the caller's stream sees every row transform finished
-        if (rows_pending[ib]) LK_HIP_CHECK(hipStreamWaitEvent(stream, h->ev_rows[2 + ib], 0));
     LK_HIP_CHECK(hipGetLastError());
+    if (max_out && !fused) return argmax_launch(h, B, M, power, max_out, arg_out, stream);
     return LK_OK;
 }
 
@@ -1714,7 +1256,7 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
     LK_REQUIRE(nterms >= 1 && nterms <= LK_MAX_NTERMS, "nterms must be between 1 and %d (got %d)", LK_MAX_NTERMS, nterms);
     if (nterms == 1)
         return lsfast_launch(h, B, n_off_host, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
-                             oversampling, power, stream);
+                             oversampling, power, stream, nullptr, nullptr);
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
     LK_REQUIRE(M >= 0, "M must be >= 0");
     if (B == 0 || M == 0) return LK_OK;
@@ -1751,16 +1293,12 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
     double2 *d_spec = (double2 *)h->ws.alloc((size_t)Bc * NG * M * 16);
     rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
+    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
                        d_w, d_wy, d_stats, df, nfft, m2, (int *)nullptr, (int *)nullptr, 0);
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_cols_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_rows_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-        attr_set = true;
+    if (!reg_path) {
+        want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
+        want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
     }
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
@@ -1770,8 +1308,8 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
         hipLaunchKernelGGL(lsf_scatter_multi_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, d_w,
                            d_wy, d_off, d_stats, b0, f0, df, nfft, nterms, d_grids);
         if (reg_path) {
-            launch_cols_reg(m1, m2, nb * NG, d_grids, nullptr, nullptr, 1, stream);
-            launch_rows_reg(m1, m2, nb * NG, d_grids, (int)M, d_spec, stream);
+            launch_cols_reg(h, m1, m2, nb * NG, d_grids, nullptr, nullptr, 1, stream);
+            launch_rows_reg(h, m1, m2, nb * NG, d_grids, (int)M, d_spec, stream);
         } else {
             hipLaunchKernelGGL(fft_cols_kernel, dim3(N2 / CT, nb * NG), dim3(256), ldsA, stream, d_grids, m1, m2, CT);
             hipLaunchKernelGGL(fft_rows_kernel, dim3(N1 / RT, nb * NG), dim3(256), ldsB, stream, d_grids, m1, m2, RT,

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 256 * q, r = e >> 6, c = (e & 63) * 2;
                 const int nn = n0 + r;
-                const size_t rowo = (size_t)min(nn, n - 1) * K;
+                const size_t rowo = (size_t)max(0, min(nn, n - 1)) * K;  // n == 0: stay inside A (values are masked)
                 const double2_t va = *reinterpret_cast<const double2_t *>(A + rowo + min(i0 + c, K - 2));
                 const double2_t vb = *reinterpret_cast<const double2_t *>(A + rowo + min(j0 + c, K - 2));
                 ra[q] = (nn < n && i0 + c < K) ? va : (double2_t){0.0, 0.0};
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__
                 for (int h = 0; h < 2; ++h) {
                     const int e = tid + 256 * (2 * q + h), r = e >> 7, c = e & 127;
                     const int nn = n0 + r;
-                    const size_t rowo = (size_t)min(nn, n - 1) * K;
+                    const size_t rowo = (size_t)max(0, min(nn, n - 1)) * K;
                     const double va = A[rowo + min(i0 + c, K - 1)], vb = A[rowo + min(j0 + c, K - 1)];
                     ra[q][h] = (nn < n && i0 + c < K) ? va : 0.0;
                     rb[q][h] = (nn < n && j0 + c < K) ? vb : 0.0;

@@ -37,6 +37,7 @@ class LightCurveBatch(object):
         if self.n_off[0] != 0 or self.n_off[-1] != self.time.size or np.any(np.diff(self.n_off) < 0):
             raise ValueError("n_off must be non-decreasing prefix offsets over the arrays")
         self.meta = list(meta) if meta is not None else [{} for _ in range(len(self))]
+        self.quality = None   # per-cadence quality flags (set by from_fits; carried through remove_nans / normalize)
 
     @classmethod
     def from_lightcurves(cls, lcs):
@@ -92,6 +93,13 @@ class LightCurveBatch(object):
                                                normalize=normalize, device=device)
         out = LightCurveBatch(t, f, e, off, [dict(m) for m in self.meta])
         out.median_flux = med
+        if self.quality is not None:
+            # lk_ingest_batch keeps exactly the cadences with finite flux, in order: the flags follow by the same test
+            keep = ~np.isnan(self.flux)
+            if int(keep.sum()) != len(t):
+                raise RuntimeError("quality flags out of step with the ingest kernel (kept %d of %d cadences, expected %d)"
+                                   % (len(t), len(self.flux), int(keep.sum())))
+            out.quality = np.ascontiguousarray(np.asarray(self.quality)[keep])
         return out
 
     def remove_nans(self, device=0):
@@ -117,7 +125,7 @@ class LightCurveBatch(object):
         """Equal-width time bins (reference :1558-1763 with ``time_bin_size`` in days): nanmean flux, rms flux_err."""
         t, f, e, boff = _capi.bin_batch(self.time, self.flux, self.n_off, flux_err=self.flux_err,
                                         time_bin_size=time_bin_size, time_bin_start=time_bin_start, device=device)
-        return LightCurveBatch(t, f, e, boff, [dict(m) for m in self.meta])
+        return LightCurveBatch(t, f, e, boff, [dict(m) for m in self.meta])   # binned cadences have no quality flag
 
     def to_periodogram_power(self, frequency, normalization="amplitude", ls_method="fast", device=0, **kw):
         """Lomb-Scargle power of every light curve on one shared grid (``batch.lombscargle_batch``) -> float64[B, M]."""

@@ -13,7 +13,9 @@
 * S4  ``RegressionCorrector._fit_coefficients`` (regressioncorrector.py:127-189; the sigma-clip loop around it stays the
       reference's) and — faster, ``full_loop=True`` — ``RegressionCorrector.correct`` itself (:191-309, all iterations in one
       lk_regress_cov_batch call); ``PLDCorrector.create_design_matrix`` (pldcorrector.py:125-287) builds its PCA blocks with
-      lk_pld_design_batch.  Sparse collections are densified; ``pca_components=0`` goes to the original method.
+      lk_pld_design_batch.  Sparse collections are densified; ``pca_components=0``, ``sparse=True``, more than 1023
+      regressors or a sparse collection that would not fit densified go to the original methods.
+      Every call handed back to a CPU implementation logs one ``log.debug`` line saying which seam and why.
 
 ``backend`` is the module that provides the compute entry points (default: ``lightkurve_amd._capi``, i.e. the GPU).  The
 tests pass a stand-in to check the wiring against a real lightkurve on a machine without a GPU (tests/test_seams_cpu.py);
@@ -22,12 +24,26 @@ nothing in the package itself ever substitutes a CPU implementation.
 astropy / lightkurve are NOT importable in the product interpreter of this image; on the GPU box the seams are exercised
 under the conda interpreter that ships astropy 4.3.1 (tests/test_seams_gpu.py).
 """
+import logging
+
 import numpy as np
 
 from . import _capi
 
+log = logging.getLogger(__name__)
+
 _BACKEND = _capi
 _ORIG = {}
+
+# limits of lk_regress_cov_batch (include/lkhip.h) and a budget for densified sparse collections
+_MAX_REGRESSORS = 1023
+_DENSE_BUDGET_BYTES = 8 << 30
+
+
+def _fell_back(seam, why):
+    """Every call a seam hands back to the original CPU implementation says so (same channel and level the reference
+    uses for its own notes, e.g. regressioncorrector.py:270-273)."""
+    log.debug("lightkurve_amd: %s fell back to the CPU implementation: %s", seam, why)
 
 
 def _be():
@@ -39,6 +55,7 @@ def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit
                     nterms=1, **unused):
     """Signature of astropy's METHODS entries (lombscargle/implementations/main.py:182-217)."""
     if nterms > _capi.MAX_NTERMS and "chi2" in _ORIG:     # beyond the instantiated kernels: astropy's own chi2
+        _fell_back("lombscargle METHODS['chi2']", "nterms=%d > %d" % (nterms, _capi.MAX_NTERMS))
         return _ORIG["chi2"](t, y, dy, frequency=frequency, normalization=normalization, fit_mean=fit_mean,
                              center_data=center_data, nterms=nterms)
     if not 1 <= nterms <= _capi.MAX_NTERMS:
@@ -64,6 +81,9 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
     if unsupported and ("fastchi2" if nterms > 1 else "fast") in _ORIG:
         name = "fastchi2" if nterms > 1 else "fast"
         extra = dict(nterms=nterms) if nterms > 1 else {}
+        _fell_back("lombscargle METHODS['%s']" % name,
+                   "nterms=%d > %d" % (nterms, _capi.MAX_NTERMS) if nterms > _capi.MAX_NTERMS else
+                   ("use_fft=False" if not use_fft else "Mfft=%s (the kernels extirpolate with Mfft=4)" % kw.get("Mfft")))
         return _ORIG[name](t, y, dy, f0=f0, df=df, Nf=Nf, center_data=center_data, fit_mean=fit_mean,
                            normalization=normalization, use_fft=use_fft, trig_sum_kwds=trig_sum_kwds, **extra)
     if not 1 <= nterms <= _capi.MAX_NTERMS:
@@ -113,6 +133,9 @@ def _make_flatten(lk_lightcurve_mod):
                 mask=None, **kwargs):
         time = _plain(self.time.value)
         if kwargs or (len(time) > 1 and np.any(np.diff(time) < 0)) or window_length % 2 != 1 or niters < 1:
+            _fell_back("LightCurve.flatten", "extra savgol_filter keyword arguments %s" % sorted(kwargs) if kwargs else
+                       ("time is not sorted" if window_length % 2 == 1 and niters >= 1 else
+                        "window_length=%d, niters=%d" % (window_length, niters)))
             return orig(self, window_length=window_length, polyorder=polyorder, return_trend=return_trend,
                         break_tolerance=break_tolerance, niters=niters, sigma=sigma, mask=mask, **kwargs)
         if polyorder >= window_length:
@@ -163,10 +186,25 @@ def _regress(self, cadence_mask, prior_mu, prior_sigma, sigma, niters, want_cov)
                                sigma=sigma, niters=niters, return_cov=want_cov)
 
 
+def _outside_kernel_limits(dmc):
+    """Why this design-matrix collection cannot go through lk_regress_cov_batch, or None."""
+    n, k = dmc.X.shape
+    if k > _MAX_REGRESSORS:
+        return "%d regressors > %d" % (k, _MAX_REGRESSORS)
+    if hasattr(dmc.X, "toarray") and n * k * 8 > _DENSE_BUDGET_BYTES:
+        return "sparse collection of %d x %d would densify to %.1f GB" % (n, k, n * k * 8 / 1e9)
+    return None
+
+
 def _fit_coefficients_hip(self, cadence_mask=None, prior_mu=None, prior_sigma=None, propagate_errors=False):
     """RegressionCorrector._fit_coefficients (regressioncorrector.py:127-189): one weighted ridge fit on the GPU."""
     if (prior_mu is None) != (prior_sigma is None):
         raise ValueError("Please specify both `prior_mu` and `prior_sigma`")
+    why = _outside_kernel_limits(self.dmc)
+    if why is not None and "_fit_coefficients" in _ORIG:
+        _fell_back("RegressionCorrector._fit_coefficients", why)
+        return _ORIG["_fit_coefficients"](self, cadence_mask=cadence_mask, prior_mu=prior_mu, prior_sigma=prior_sigma,
+                                          propagate_errors=propagate_errors)
     if cadence_mask is None:
         cadence_mask = np.ones(len(self.lc.flux), bool)
     res = _regress(self, cadence_mask, prior_mu, prior_sigma, sigma=5.0, niters=1, want_cov=bool(propagate_errors))
@@ -191,6 +229,12 @@ def _make_correct(lk_regcorr_mod):
             elif isinstance(design_matrix_collection, DM):
                 design_matrix_collection = DMC([design_matrix_collection])
         design_matrix_collection.validate()
+        why = _outside_kernel_limits(design_matrix_collection)
+        if why is not None:
+            # the original loop; its _fit_coefficients calls fall back by the same test
+            _fell_back("RegressionCorrector.correct", why)
+            return orig(self, design_matrix_collection, cadence_mask=cadence_mask, sigma=sigma, niters=niters,
+                        propagate_errors=propagate_errors)
         self.design_matrix_collection = design_matrix_collection
         n = len(self.lc.time)
         self.cadence_mask = np.ones(n, bool) if cadence_mask is None else cadence_mask
@@ -235,12 +279,13 @@ def _make_create_design_matrix(lk_pld_mod):
                              background_aperture_mask="background", spline_n_knots=None, spline_degree=3,
                              normalize_background_pixels=None, sparse=False):
         if sparse or not pca_components or pca_components < 1:
+            _fell_back("PLDCorrector.create_design_matrix", "sparse=True" if sparse else "pca_components=%r" % (pca_components,))
             return orig(self, pld_order=pld_order, pca_components=pca_components, pld_aperture_mask=pld_aperture_mask,
                         background_aperture_mask=background_aperture_mask, spline_n_knots=spline_n_knots,
                         spline_degree=spline_degree, normalize_background_pixels=normalize_background_pixels,
                         sparse=sparse)
-        if pld_aperture_mask is None:
-            pld_aperture_mask = "empty"
+        # None -> all pixels, as the reference's create_design_matrix does (pldcorrector.py:203-207; the mission-dependent
+        # default is resolved by correct() before it gets here)
         self.pld_aperture_mask = self.tpf._parse_aperture_mask(pld_aperture_mask)
         self.background_aperture_mask = self.tpf._parse_aperture_mask(background_aperture_mask)
         n = len(self.lc)

@@ -117,8 +117,13 @@ def test_fits_files_to_batch_vs_reference_readers(golden):
         assert np.array_equal(one.flux_err, g[tag + "_flux_err"], equal_nan=True)
         assert np.array_equal(one.quality, g[tag + "_quality"])
     # the batch goes straight on: remove_nans + normalize + periodogram of the Kepler file
-    clean = LightCurveBatch.from_fits(paths[:2]).remove_nans().normalize()
+    raw2 = LightCurveBatch.from_fits(paths[:2])
+    clean = raw2.remove_nans().normalize()
     assert np.isfinite(clean.flux).all() and abs(np.median(clean[0].flux) - 1.0) < 1e-12
+    # the quality flags stay in step with the cadences that survive (reference: lc.remove_nans() keeps lc.quality aligned)
+    assert clean.quality is not None and len(clean.quality) == len(clean.time)
+    assert np.array_equal(clean.quality, raw2.quality[~np.isnan(raw2.flux)])
+    assert clean.bin(time_bin_size=0.5).quality is None
     # many files: more workgroups than one wave of CUs, records staged through LDS in several trips
     big = LightCurveBatch.from_fits(paths[:3] * 40)
     assert len(big) == 120 and np.array_equal(big[117].time, g["kepler_default_time"])
