@@ -74,7 +74,8 @@ def run_all(lk):
     out["regress_coefficients"] = rc.coefficients
     out["regress_outliers"] = rc.outlier_mask
     out["regress_diag"] = rc.diagnostic_lightcurves["X"]
-    ref_data = "/root/reference/tests/data/synthetic/synthetic-k2-sinusoid.targ.fits.gz"
+    ref_data = os.path.join(os.environ.get("LK_REFERENCE_ROOT", "/root/reference"),
+                            "tests/data/synthetic/synthetic-k2-sinusoid.targ.fits.gz")
     if os.path.exists(ref_data):
         tpf = lk.read(ref_data)
         pld = PLDCorrector(tpf)
@@ -87,6 +88,11 @@ def run_all(lk):
 def compare(bname):
     import lightkurve as lk
     from lightkurve_amd import seams
+    if os.environ.get("LK_SEAMS_LOG"):        # show the seams' "fell back to the CPU implementation" notes
+        import logging
+        logging.basicConfig(level=os.environ["LK_SEAMS_LOG"], format="%(name)s %(levelname)s %(message)s")
+        logging.getLogger().setLevel(logging.WARNING)
+        logging.getLogger("lightkurve_amd.seams").setLevel(os.environ["LK_SEAMS_LOG"])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ref = run_all(lk)
@@ -139,6 +145,9 @@ def compare(bname):
     if bname == "oracle":
         import oracle_backend
         res["calls"] = sorted(set(oracle_backend.CALLS))
+    else:
+        from lightkurve_amd import _capi
+        res["library"] = _capi.LIB_PATH
     print("SEAMS_LK_RESULT " + json.dumps(res))
 
 

@@ -38,3 +38,25 @@ def test_astropy_seams_under_conda():
     for k, v in res["flatten_relerr"].items():          # S3 vs live scipy
         assert v < 1e-10, (k, v)
     assert res["fit_relerr"]["w"] < 1e-9 and res["fit_relerr"]["cov"] < 1e-9      # S4 vs numpy.linalg
+
+
+def test_all_seams_through_real_lightkurve_when_staged():
+    """The nine seams through an UNMODIFIED lightkurve with the HIP backend (tests/seams_lk_worker.py compare hip).
+    lightkurve is not installed on the GPU box: the test runs wherever a checkout is reachable — LK_REFERENCE_ROOT (what
+    tools/seams_e2e_gpu.sh sets after unpacking the staged tarball to /tmp) or /root/reference — and skips otherwise; the
+    kept log of such a run is profiles/r03_seams_e2e_gpu.log."""
+    ref = os.environ.get("LK_REFERENCE_ROOT", "/root/reference")
+    if not os.path.exists(CONDA) or not os.path.isdir(os.path.join(ref, "src", "lightkurve")):
+        pytest.skip("no lightkurve checkout reachable on this box (see tools/seams_e2e_gpu.sh)")
+    env = dict(os.environ, LK_REFERENCE_ROOT=ref,
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "oracle", "shims"), os.path.join(ref, "src"), ROOT]))
+    sys_stdcxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_stdcxx):
+        env["LD_PRELOAD"] = sys_stdcxx
+    p = subprocess.run([CONDA, "-W", "ignore", os.path.join(ROOT, "tests", "seams_lk_worker.py"), "compare", "hip"], env=env,
+                       capture_output=True, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_LK_RESULT ")][-1]
+    res = json.loads(line[len("SEAMS_LK_RESULT "):])
+    assert len(res["installed"]) == 9 and res["library"].endswith("liblkhip.so")
+    assert res["errors"]["bls"] == 0.0

@@ -1,0 +1,26 @@
+#!/bin/bash
+# End-to-end proof on the GPU box: an UNMODIFIED lightkurve (staged by tools/stage_reference.sh, unpacked to /tmp — outside
+# the repo) with lightkurve_amd.seams installed returns its own LightCurve / Periodogram objects from liblkhip.so:
+#   1. tests/seams_lk_worker.py compare hip   — all nine seams through lightkurve's public API against the reference path
+#   2. tests/seams_lk_worker.py reftests hip  — the reference's own periodogram / corrector / flatten tests, seams active
+# The log is what profiles/r03_seams_e2e_gpu.log holds.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/seams_e2e; mkdir -p $O
+if [ ! -f .stage/lkref.tar.gz ]; then echo "no .stage/lkref.tar.gz: run tools/stage_reference.sh first"; exit 2; fi
+rm -rf /tmp/lkref && mkdir -p /tmp/lkref && tar -C /tmp/lkref -xzf .stage/lkref.tar.gz
+export LK_REFERENCE_ROOT=/tmp/lkref
+R="$PWD"
+export PYTHONPATH="$R/oracle/shims:/tmp/lkref/src:$R"
+export LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6
+CONDA=/opt/conda/bin/python3.9
+{
+echo "# $(date -u) seams end-to-end on the GPU box ($(/opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 -o 'gfx9[0-9a-z]*'))"
+echo "## compare hip"
+LK_SEAMS_LOG=DEBUG $CONDA -W ignore tests/seams_lk_worker.py compare hip 2>&1 | grep -v "No period specified\|No duration specified\|No transit time specified" | tail -40
+echo "## reference test files with the seams active (hip backend)"
+( cd /tmp/lkref/tests && $CONDA -W ignore "$R/tests/seams_lk_worker.py" reftests hip \
+    test_periodogram.py correctors/test_regressioncorrector.py correctors/test_designmatrix.py \
+    "correctors/test_metrics.py::test_overfit_metric_lombscargle" \
+    "test_lightcurve.py::test_flatten_with_nans" "test_lightcurve.py::test_flatten_robustness" \
+    "test_lightcurve.py::test_flatten_returns_normalized" "test_lightcurve.py::test_iterative_flatten" 2>&1 | tail -15 )
+} | tee $O/seams_e2e_gpu.log
