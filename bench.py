@@ -134,11 +134,38 @@ def dry_run(args, rank, world):
         dist.init_process_group("gloo")
     from lightkurve_amd.distributed import shard_bounds
     total = args.total_targets or args.targets * world
-    bounds = shard_bounds(total, world) if args.total_targets else np.arange(world + 1) * args.targets
+    bounds = strong_bounds(args, world) if args.total_targets else np.arange(world + 1) * args.targets
     mine = int(bounds[rank + 1] - bounds[rank])
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
     dt = time.perf_counter() - t0
+    # the gathers of the real step on CPU tensors: shards padded to the largest one, chunked all-gather of the "spectra"
+    # (row b of rank r holds its global target index), per-target summaries — and a check that every rank can rebuild
+    # the whole batch from what it received
+    gather_checked = None
+    if world > 1 and args.gather != "none":
+        first = int(bounds[rank])
+        Bmax = int(np.max(np.diff(bounds)))
+        Md = 16
+        pad = torch.zeros((Bmax, Md), dtype=torch.float64)
+        pad[:mine] = torch.arange(first, first + mine, dtype=torch.float64)[:, None] + 0.001 * torch.arange(Md, dtype=torch.float64)
+        ok = True
+        if args.gather == "spectra":
+            nch = max(1, min(args.chunks, max(mine, 1)))
+            cb = np.linspace(0, Bmax, nch + 1).astype(int)
+            full = torch.full((world, Bmax, Md), -1.0, dtype=torch.float64)
+            for c in range(nch):
+                out = torch.empty((world, int(cb[c + 1] - cb[c]), Md), dtype=torch.float64)
+                dist.all_gather_into_tensor(out.view(-1, Md), pad[int(cb[c]):int(cb[c + 1])].contiguous())
+                full[:, int(cb[c]):int(cb[c + 1])] = out
+        else:
+            full = torch.empty((world, Bmax, Md), dtype=torch.float64)
+            dist.all_gather_into_tensor(full.view(world * Bmax, Md), pad)
+        for r in range(world):
+            nr = int(bounds[r + 1] - bounds[r])
+            want = torch.arange(int(bounds[r]), int(bounds[r]) + nr, dtype=torch.float64)
+            ok = ok and bool(torch.equal(full[r, :nr, 0], want)) and bool(torch.all(full[r, nr:] == 0))
+        gather_checked = ok
     tt = torch.tensor([dt, float(mine)], dtype=torch.float64)
     if world > 1:
         dist.barrier()
@@ -152,10 +179,20 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "dry run (no GPU work)", "dry": True, "n_gpus": world, "value": 0.0,
                           "targets_total": total_seen, "scaling": "strong" if args.total_targets else "weak",
+                          "gather": args.gather, "gather_checked": gather_checked, "shards": [int(x) for x in np.diff(bounds)],
                           "ms_per_step": 1e3 * dt, "steps": args.steps, "warmup": args.warmup}))
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def strong_bounds(args, world):
+    """--total-targets: contiguous shards balanced by cost (sum of N_b * M per shard, lightkurve_amd.distributed
+    .partition_by_cost), not by count — the synthetic targets all have N cadences, so here the two coincide; a ragged
+    batch would not."""
+    from lightkurve_amd.distributed import shard_bounds
+    costs = np.full(args.total_targets, float(args.cadences) * float(args.freqs))
+    return shard_bounds(args.total_targets, world, costs=costs)
 
 
 # ------------------------------------------------------------------------------------------------ reference runs
@@ -346,7 +383,9 @@ def main():
 
     # ---- the reference's CPU path (cpu_baseline + accuracy reference): rank 0 at N = 1 only, before torch/HIP exist
     ref, cpu_base, cpu_base_bls, cpu_base_pld, cpu_base_flat = None, None, None, None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # (rank 0 does this for any world: the other ranks wait for it at the rendezvous, so N > 1 lines carry the reference's
+    # numbers and the accuracy block too)
+    if rank == 0 and not args.no_cpu_baseline:
         if args.workload == "ls":
             ref = reference_suite(args, True, not args.no_bls, not args.no_flatten)
             if ref is None:
@@ -469,7 +508,7 @@ def main():
     # ---- how many targets this rank owns
     strong = args.total_targets > 0
     if strong:
-        bounds = shard_bounds(args.total_targets, world)
+        bounds = strong_bounds(args, world)
         first, B = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
         total_targets = args.total_targets
     else:
@@ -696,7 +735,7 @@ def main():
         # gathers need equal shard sizes per rank (weak scaling always; strong: pad to the largest shard)
         Bmax = B
         if dist_on and strong:
-            Bmax = int(np.max(np.diff(shard_bounds(args.total_targets, world))))
+            Bmax = int(np.max(np.diff(strong_bounds(args, world))))
         nch = max(1, min(args.chunks, B)) if gather_spec else 1
         cb = np.linspace(0, Bmax, nch + 1).astype(int)
         d_all = [torch.empty((world, cb[c + 1] - cb[c], M), dtype=torch.float64, device=dev)

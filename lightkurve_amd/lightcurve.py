@@ -8,7 +8,7 @@ import copy as _copy
 
 import numpy as np
 
-__all__ = ["LightCurve", "FoldedLightCurve"]
+__all__ = ["LightCurve", "FoldedLightCurve", "estimate_cdpp_batch", "running_mean"]
 
 
 class LightCurve(object):
@@ -146,6 +146,13 @@ class LightCurve(object):
             return flat, tr
         return flat
 
+    def estimate_cdpp(self, transit_duration=13, savgol_window=101, savgol_polyorder=2, sigma=5.0, device=0):
+        """Savitzky-Golay CDPP noise metric in ppm (reference :1764-1833): flatten -> remove_outliers -> normalize("ppm")
+        -> standard deviation of the ``transit_duration``-cadence running mean.  The flatten and the sigma clip run on the
+        GPU; see ``estimate_cdpp_batch`` for many light curves in two launches."""
+        return float(estimate_cdpp_batch([self], transit_duration=transit_duration, savgol_window=savgol_window,
+                                         savgol_polyorder=savgol_polyorder, sigma=sigma, device=device)[0])
+
     def fold(self, period=None, epoch_time=None, epoch_phase=0, wrap_phase=None, normalize_phase=False, device=0):
         """Phase-fold (reference :1089-1214 over astropy TimeSeries.fold, timeseries/sampled.py:230-233):
         phase = ((t - epoch) + epoch_phase + (P - wrap)) % P - (P - wrap), then a stable sort by phase — both on
@@ -178,3 +185,37 @@ class FoldedLightCurve(LightCurve):
     @property
     def phase(self):
         return self.time
+
+
+def running_mean(data, window_size):
+    """Moving average by differences of the cumulative sum (reference utils.py:374-386)."""
+    if window_size > len(data):
+        window_size = len(data)
+    cumsum = np.cumsum(np.insert(data, 0, 0))
+    return (cumsum[window_size:] - cumsum[:-window_size]) / float(window_size)
+
+
+def estimate_cdpp_batch(lcs, transit_duration=13, savgol_window=101, savgol_polyorder=2, sigma=5.0, device=0):
+    """``LightCurve.estimate_cdpp`` (reference lightcurve.py:1764-1833) for a list of light curves: ONE
+    lk_savgol_trend_batch call (the flatten of every light curve) and ONE lk_sigma_clip_batch call (remove_outliers),
+    then per light curve the O(N) tail the reference runs in numpy (normalize to ppm, running mean, np.std).
+    Returns float64[len(lcs)] in ppm."""
+    from . import _capi
+    from .flatten import flatten_trend_batch
+    if not isinstance(transit_duration, int):
+        raise ValueError("transit_duration must be an integer in units number of cadences, got {}.".format(transit_duration))
+    lcs = list(lcs)
+    if not lcs:
+        return np.zeros(0)
+    trends = flatten_trend_batch(lcs, window_length=savgol_window, polyorder=savgol_polyorder, device=device)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        flat = [np.asarray(lc.flux, dtype=np.float64) / tr for lc, tr in zip(lcs, trends)]
+    off = np.zeros(len(lcs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(f) for f in flat])
+    mask = _capi.sigma_clip_batch(np.concatenate(flat), off, sigma=sigma, maxiters=5, device=device)
+    out = np.empty(len(lcs))
+    for b, f in enumerate(flat):
+        kept = f[~mask[off[b]:off[b + 1]]]
+        ppm = kept / np.nanmedian(kept) * 1e6            # normalize("ppm") of the already-normalised flattened curve
+        out[b] = np.std(running_mean(ppm, transit_duration))
+    return out

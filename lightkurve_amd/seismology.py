@@ -12,7 +12,7 @@ import numpy as np
 from . import _capi
 from .periodogram import UHZ_PER_CPD, _freq_unit_factor
 
-__all__ = ["autocorrelate", "estimate_numax_acf2d", "estimate_numax_acf2d_batch"]
+__all__ = ["autocorrelate", "estimate_numax_acf2d", "estimate_numax_acf2d_batch", "estimate_deltanu_acf2d", "get_fwhm"]
 
 
 def _to_uhz(value, unit):
@@ -116,3 +116,88 @@ def estimate_numax_acf2d_batch(periodograms, numaxs=None, window_width=None, spa
     power = np.stack([np.asarray(pg.power, dtype=np.float64) for pg in periodograms])
     acf, met = _capi.pg_acf2d_batch(power, starts, W, device=device)
     return [_finish(numaxs, window_width, acf[b], met[b]) for b in range(len(periodograms))]
+
+
+# ------------------------------------------------------------------------------------------------ deltanu
+def get_fwhm(periodogram, numax):
+    """Width of the mode envelope (seismology/utils.py:62-104): 0.25 numax above 500 microhertz of bandwidth (main
+    sequence), 0.66 numax^0.88 below (red giants); ``numax`` in the periodogram's frequency unit, used as a bare number
+    exactly as the reference does."""
+    freq = np.asarray(periodogram.frequency, dtype=np.float64)
+    if _to_uhz(freq[-1], periodogram.frequency_unit) > 500.0:
+        return 0.25 * numax
+    return 0.66 * numax ** 0.88
+
+
+def _local_maxima_1d(x):
+    """scipy.signal._peak_finding_utils._local_maxima_1d: midpoints of the (plateau) local maxima of x."""
+    mid = []
+    i, i_max = 1, len(x) - 1
+    while i < i_max:
+        if x[i - 1] < x[i]:
+            ahead = i + 1
+            while ahead < i_max and x[ahead] == x[i]:
+                ahead += 1
+            if x[ahead] < x[i]:
+                mid.append((i + ahead - 1) // 2)
+                i = ahead
+        i += 1
+    return np.asarray(mid, dtype=np.intp)
+
+
+def _select_by_peak_distance(peaks, priority, distance):
+    """scipy.signal._peak_finding_utils._select_by_peak_distance: keep the highest-priority peaks, drop neighbours closer
+    than ``distance`` samples."""
+    keep = np.ones(len(peaks), dtype=bool)
+    dist = int(np.ceil(distance))
+    order = np.argsort(priority)
+    for i in range(len(peaks) - 1, -1, -1):
+        j = order[i]
+        if not keep[j]:
+            continue
+        k = j - 1
+        while k >= 0 and peaks[j] - peaks[k] < dist:
+            keep[k] = False
+            k -= 1
+        k = j + 1
+        while k < len(peaks) and peaks[k] - peaks[j] < dist:
+            keep[k] = False
+            k += 1
+    return keep
+
+
+def _find_peaks(x, distance):
+    """scipy.signal.find_peaks(x, distance=distance)[0] (the only form deltanu_estimators.py:127 uses)."""
+    if distance is not None and distance < 1:
+        raise ValueError("`distance` must be greater or equal to 1")
+    peaks = _local_maxima_1d(np.asarray(x, dtype=np.float64))
+    if distance is not None and len(peaks):
+        peaks = peaks[_select_by_peak_distance(peaks, np.asarray(x)[peaks], distance)]
+    return peaks
+
+
+def estimate_deltanu_acf2d(periodogram, numax, device=0):
+    """Large frequency separation by the autocorrelation method (reference seismology/deltanu_estimators.py:18-153): the
+    ACF of the window of one envelope FWHM either side of ``numax`` — the same GPU kernel as the numax estimator
+    (lk_pg_acf2d_batch) — rescaled to the Mosser & Appourchaux noise level, and the ACF peak closest to the empirical
+    0.294 numax^0.772 (in microhertz).  Returns a dict with ``deltanu`` and the reference's diagnostics (``lags``,
+    ``acf``, ``peaks``, ``sel``, ``numax``, ``deltanu_emp``), everything in the periodogram's frequency unit."""
+    if not periodogram._is_evenly_spaced():
+        raise ValueError("the ACF 2D method requires that the periodogram has a grid of uniformly spaced frequencies.")
+    unit = periodogram.frequency_unit
+    freq = np.asarray(periodogram.frequency, dtype=np.float64)
+    numax = float(numax)
+    fs = np.median(np.diff(freq))
+    if numax < fs:
+        raise ValueError("The input numax can not be lower than a single frequency bin.")
+    if numax > np.nanmax(freq):
+        raise ValueError("The input numax can not be higher thanthe highest frequency value in the periodogram.")
+    deltanu_emp = _from_uhz(0.294 * _to_uhz(numax, unit) ** 0.772, unit)
+    window_width = 2 * int(np.floor(get_fwhm(periodogram, numax)))
+    aacf = autocorrelate(periodogram, numax=numax, window_width=window_width, device=device)
+    acf = (np.abs(aacf ** 2) / np.abs(aacf[0] ** 2)) / (3 / (2 * len(aacf)))
+    lags = np.linspace(0.0, len(acf) * fs, len(acf))
+    sel = (lags > deltanu_emp - 0.25 * deltanu_emp) & (lags < deltanu_emp + 0.25 * deltanu_emp)
+    peaks = _find_peaks(acf[sel], distance=np.floor(deltanu_emp / 2.0 / fs))
+    best = lags[sel][peaks][np.argmin(np.abs(lags[sel][peaks] - deltanu_emp))]
+    return dict(deltanu=float(best), lags=lags, acf=acf, peaks=peaks, sel=sel, numax=numax, deltanu_emp=deltanu_emp)

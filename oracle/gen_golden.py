@@ -178,6 +178,35 @@ def gen_acf2d():
     save("acf2d", **out)
 
 
+def gen_deltanu_cdpp():
+    """estimate_deltanu_acf2d (seismology/deltanu_estimators.py:18-153) on the synthetic spectra of gen_acf2d (inputs read
+    back from that fixture), and LightCurve.estimate_cdpp (lightcurve.py:1764-1833) on synthetic light curves."""
+    from lightkurve.periodogram import SNRPeriodogram
+    from lightkurve.seismology.deltanu_estimators import estimate_deltanu_acf2d
+    g = np.load(os.path.join(OUT, "acf2d.npz"))
+    out = {}
+    for tag in ("rg", "ms"):
+        pg = SNRPeriodogram(g[tag + "_frequency"] * u.microhertz, u.Quantity(g[tag + "_power"], None))
+        res = estimate_deltanu_acf2d(pg, numax=float(g[tag + "_numax"]))
+        d = res.diagnostics
+        out.update({tag + "_deltanu": float(res.value), tag + "_lags": np.asarray(d["lags"]), tag + "_acf": np.asarray(d["acf"]),
+                    tag + "_peaks": np.asarray(d["peaks"]), tag + "_sel": np.asarray(d["sel"]),
+                    tag + "_deltanu_emp": float(d["deltanu_emp"])})
+    rng = np.random.default_rng(71)
+    cd = []
+    for i in range(4):
+        t, y, e, _ = synth.ls_target(7, i, 3000 + 500 * i, cadence_days=30.0 / 1440.0)
+        y = y * (1 + 0.004 * np.sin(2 * np.pi * t / 9.0))
+        y[rng.integers(0, len(y), 6)] += 0.01
+        lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+        # estimate_cdpp returns np.std of a ppm Quantity: keep the number in ppm (float() would rescale it to dimensionless)
+        in_ppm = lambda q: float(getattr(q, "value", q)) * (1.0 if str(getattr(q, "unit", "ppm")) == "ppm" else 1e6)
+        cd.append([in_ppm(lc.estimate_cdpp()), in_ppm(lc.estimate_cdpp(transit_duration=7, savgol_window=51, sigma=4.0))])
+        out["cdpp_time_%d" % i], out["cdpp_flux_%d" % i] = t, y
+    out["cdpp"] = np.asarray(cd)
+    save("deltanu_cdpp", **out)
+
+
 def gen_ingest():
     """remove_nans + normalize (lightcurve.py:1300-1327, 1216-1292), create_transit_mask (:2967-3037) and bin (:1558-1763)
     on ragged synthetic light curves with NaNs, gaps and missing errors."""

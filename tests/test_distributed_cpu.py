@@ -91,6 +91,31 @@ def test_bench_gpus_flag_self_launches_ranks():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["dry"] is True
     assert res["targets_total"] == 11 and res["scaling"] == "strong"      # 6 + 5 targets seen by the two ranks
+    assert res["gather"] == "summary" and res["gather_checked"] is True and sorted(res["shards"]) == [5, 6]
+
+
+@pytest.mark.parametrize("extra", [["--gather", "spectra", "--total-targets", "11", "--chunks", "4"],
+                                   ["--gather", "spectra", "--targets", "3"],
+                                   ["--gather", "none", "--total-targets", "7"]])
+def test_bench_dry_gathers_gloo_world2(extra):
+    """The gathers of the real multi-GPU step on gloo / CPU tensors: strong scaling with unequal shards (11 targets over 2
+    ranks: the smaller shard is padded), the chunked all-gather of the spectra, weak scaling, and no gather at all.  Every
+    rank rebuilds the whole batch from what it received (bench.py dry_run)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry"] + extra,
+                       env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    res = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["dry"] is True
+    if "none" in extra:
+        assert res["gather_checked"] is None and res["targets_total"] == 7
+    else:
+        assert res["gather_checked"] is True
+        assert res["targets_total"] == (11 if "--total-targets" in extra else 6)
 
 
 def test_batch_entry_points_work_without_torch():

@@ -59,3 +59,43 @@ def test_autocorrelate_single_window_and_batch(golden):
     assert np.array_equal(np.isnan(got3), np.isnan(ref3))
     ok = ~np.isnan(ref3)
     assert np.max(np.abs(got3[ok] - ref3[ok])) / np.nanmax(np.abs(ref3)) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["rg", "ms"])
+def test_deltanu_acf2d_vs_reference(golden, tag):
+    """estimate_deltanu_acf2d (reference seismology/deltanu_estimators.py:18-153): the second consumer of the ACF kernel.
+    Tolerances (stated): ACF within 1e-12 of its zero lag... after the reference's own rescaling, so relative 1e-10 on the
+    rescaled curve; lags, selection, peak positions and deltanu identical."""
+    g, d = golden("acf2d"), golden("deltanu_cdpp")
+    res = seismology.estimate_deltanu_acf2d(_pg(g, tag), numax=float(g[tag + "_numax"]))
+    assert np.array_equal(res["lags"], d[tag + "_lags"]) and np.array_equal(res["sel"], d[tag + "_sel"])
+    assert np.allclose(res["acf"], d[tag + "_acf"], rtol=1e-10, atol=1e-12 * np.max(d[tag + "_acf"]))
+    assert np.array_equal(res["peaks"], d[tag + "_peaks"])
+    assert res["deltanu"] == float(d[tag + "_deltanu"]) and res["deltanu_emp"] == float(d[tag + "_deltanu_emp"])
+    with pytest.raises(ValueError):
+        seismology.estimate_deltanu_acf2d(_pg(g, tag), numax=1e9)
+
+
+def test_find_peaks_restatement_matches_scipy():
+    """The restated scipy.signal.find_peaks(x, distance=d) on random data with plateaus."""
+    scipy_signal = pytest.importorskip("scipy.signal")
+    rng = np.random.default_rng(2)
+    for n, dist in [(400, 1), (400, 7), (1000, 25.0), (50, 3)]:
+        x = np.round(rng.normal(size=n), 1)          # rounding makes plateaus
+        assert np.array_equal(seismology._find_peaks(x, dist), scipy_signal.find_peaks(x, distance=dist)[0])
+
+
+def test_estimate_cdpp_vs_reference(golden):
+    """LightCurve.estimate_cdpp (reference lightcurve.py:1764-1833) single and batched, in ppm; 1e-9 relative (flatten
+    1e-10, then a standard deviation of a running mean)."""
+    from lightkurve_amd import LightCurve
+    from lightkurve_amd.lightcurve import estimate_cdpp_batch
+    d = golden("deltanu_cdpp")
+    lcs = [LightCurve(time=d["cdpp_time_%d" % i], flux=d["cdpp_flux_%d" % i]) for i in range(4)]
+    got = estimate_cdpp_batch(lcs)
+    assert np.allclose(got, d["cdpp"][:, 0], rtol=1e-9, atol=0)
+    got2 = estimate_cdpp_batch(lcs, transit_duration=7, savgol_window=51, sigma=4.0)
+    assert np.allclose(got2, d["cdpp"][:, 1], rtol=1e-9, atol=0)
+    assert abs(lcs[2].estimate_cdpp() - d["cdpp"][2, 0]) < 1e-9 * d["cdpp"][2, 0]
+    with pytest.raises(ValueError):
+        lcs[0].estimate_cdpp(transit_duration=6.5)
