@@ -920,10 +920,11 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     hipLaunchKernelGGL(bls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, ivar, d_off, d_tm, d_yw, d_stats);
 
     if (h->bls_attr_set != 1) {
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_team_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bls_team_deep_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        {
+            int rc_ = want_lds(h, reinterpret_cast<const void *>(bls_team_kernel), 156 * 1024);
+            if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(bls_team_deep_kernel), 156 * 1024);
+            if (rc_) return rc_;
+        }
         // the histogram rests on one hardware property (same-address lanes of a ds_add_f64 are applied in lane order):
         // check it on this device once per handle and refuse to run without it
         int *d_bad = (int *)h->ws.alloc(256);

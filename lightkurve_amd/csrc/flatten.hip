@@ -735,13 +735,13 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         des = &cache.back();
     }
     double *d_c = des->d_c, *d_e = des->d_e;
-    // moment form of the Savitzky-Golay interior for long windows (see the kernel); LK_FLAT_QUAD_MIN=0 disables it
-    static const int quad_min = getenv("LK_FLAT_QUAD_MIN") ? atoi(getenv("LK_FLAT_QUAD_MIN")) : 201;
+    // moment form of the Savitzky-Golay interior for long windows (see the kernel)
+    constexpr int quad_min = 201;
     const bool use_quad = quad_min > 0 && window >= quad_min && des->quad_b != 0.0;
     const double quad_a = use_quad ? des->quad_a : 0.0, quad_b = use_quad ? des->quad_b : 0.0;
-    static const bool edge_moments = !(getenv("LK_FLAT_EDGE_OPS") && atoi(getenv("LK_FLAT_EDGE_OPS")) != 0);
+    constexpr bool edge_moments = true;
     const double *d_minv = edge_moments ? des->d_minv : nullptr;
-    static const int near_on = getenv("LK_FLAT_NEAR") ? atoi(getenv("LK_FLAT_NEAR")) : 1;  // guided dt median in iterations >= 1
+    constexpr int near_on = 1;  // guided dt median in iterations >= 1
     std::vector<int64_t> soff((size_t)B + 1, 0);
     for (int b = 0; b < B; ++b) {
         const int64_t n = n_off_host[b + 1] - n_off_host[b];
@@ -758,17 +758,15 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
-    static const int flat_nt = getenv("LK_FLAT_NT") ? atoi(getenv("LK_FLAT_NT")) : 512;  // 512 threads x 3 workgroups per CU overlap the barrier-bound phases best
-    static const int fir_lds_env = getenv("LK_FLAT_FIR") ? atoi(getenv("LK_FLAT_FIR")) : 4896;  // 8 x 612: 4096-output tiles at window 401
+    constexpr int flat_nt = 512;       // 512 threads: two workgroups per CU overlap each other's barrier-bound phases best
+    constexpr int fir_lds_env = 4896;  // 8 x 612: 4096-output tiles at window 401
     int fir_lds = std::max(512, fir_lds_env & ~1);
     while (fir_lds < 16384 && window > fir_lds / 2 + 1) fir_lds *= 2;  // keep the tiled FIR path for long windows
     const size_t lds = (size_t)std::max(flat_nt, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)flat_nt * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         // (__syncthreads_or keeps a few bytes of static LDS: the dynamic part may not claim all 160 KB)
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(flatten_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr_set = true;
+        const int rc_ = want_lds(h, reinterpret_cast<const void *>(flatten_kernel), 152 * 1024);
+        if (rc_) return rc_;
     }
     const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see the kernel
     hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,

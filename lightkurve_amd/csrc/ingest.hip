@@ -156,10 +156,9 @@ int ingest_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, stream, d_kept, B, d_new);
     constexpr int cap = 4096;
     const size_t lds = 512 * 8 + (size_t)cap * 8 + 64 * 4;
-    if (!(h->attr_set & 1)) {  // per handle = per device (a process may drive several GPUs)
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ingest_pack_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        h->attr_set |= 1;
+    {  // per handle = per device (a process may drive several GPUs)
+        const int rc_ = want_lds(h, reinterpret_cast<const void *>(ingest_pack_kernel), 160 * 1024);
+        if (rc_) return rc_;
     }
     hipLaunchKernelGGL(ingest_pack_kernel, dim3(B), dim3(512), lds, stream, t, flux, err, d_off, d_new, normalize, t_out,
                        f_out, e_out, median_out, cap);
@@ -313,13 +312,11 @@ int fits_unpack_launch(lk_handle *h, int B, const uint8_t *raw, const int64_t *r
     LK_HIP_CHECK(hipMemcpyAsync(d_desc, desc_host, (size_t)B * sizeof(FitsDesc), hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // pageable sources may be reused by the caller
     const size_t lds = (size_t)FITS_ROWS * max_row + 16;
-    if (!(h->attr_set & 2)) {
+    {
         // (the kernel also has 16 bytes of static LDS: the dynamic part may not claim all 160 KB)
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<false, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fits_unpack_kernel<true, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        h->attr_set |= 2;
+        int rc_ = want_lds(h, reinterpret_cast<const void *>(fits_unpack_kernel<false, true>), 144 * 1024);
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(fits_unpack_kernel<true, true>), 144 * 1024);
+        if (rc_) return rc_;
     }
     hipLaunchKernelGGL((fits_unpack_kernel<false, true>), dim3(B), dim3(256), lds, stream, raw, d_roff, d_desc, d_mask, d_kept,
                        (const int64_t *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr, 0,

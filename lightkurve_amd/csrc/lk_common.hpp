@@ -77,9 +77,20 @@ struct lk_handle {
     hipEvent_t ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};  // [0..1] columns done (per intermediate buffer), [2..3] rows done
     int *h_plan = nullptr;         // 64 B of pinned host memory: device -> host plan words (lsfast.hip)
     std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS attribute has been raised on this device
-    unsigned attr_set = 0;         // per-device hipFuncSetAttribute calls already made through this handle (bit per kernel family)
     int bls_attr_set = 0;          // bls.hip: kernel attributes set and the LDS-atomic order self-test passed on this device
 };
+
+namespace lk {
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize once per DEVICE (a
+// process may drive several GPUs, one handle each): remembered in the handle, not in a function-local static.
+inline int want_lds(lk_handle *h, const void *fn, int bytes) {
+    for (const void *f : h->lds_attr_done)
+        if (f == fn) return LK_OK;
+    LK_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    h->lds_attr_done.push_back(fn);
+    return LK_OK;
+}
+}  // namespace lk
 
 // launchers implemented in the .hip files (device pointers, enqueue on stream, no sync)
 namespace lk {

@@ -517,9 +517,7 @@ int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     } else {
         CadHot *d_hot = (CadHot *)h->ws.alloc(ntot * sizeof(CadHot));
         CadGen *d_gen = (CadGen *)h->ws.alloc(ntot * sizeof(CadGen));
-        int F = LS_F;
-        if (const char *e = getenv("LK_LS_F")) F = atoi(e);  // tuning knob (8 | 16); F=32 would need 384 accumulator VGPRs > the 256 a VALU op can address
-        if (F != 8 && F != 10 && F != 16) F = LS_F;
+        const int F = LS_F;  // 16 frequencies per lane (8, 10, 12 measured slower; 32 would need 384 accumulator VGPRs)
         hipLaunchKernelGGL(ls_prep_kernel, dim3(B), dim3(256), 0, stream, t, y, dy, d_off, center, df, F, d_hot,
                            d_gen, (CadAny *)nullptr, d_stats);
         const int tiles = (int)((M + 64 * F - 1) / (64 * F));

@@ -907,14 +907,6 @@ __global__ __launch_bounds__(256) void lsf_zero_kernel(double2 *__restrict__ gri
         for (int c = threadIdx.x; c < N2; c += 256) G[(size_t)r * N2 + c] = make_double2(0.0, 0.0);
 }
 
-// kernels with more than 64 KB of dynamic LDS need the attribute once per device: remembered in the handle
-static void want_lds(lk_handle *h, const void *fn, int bytes) {
-    for (const void *f : h->lds_attr_done)
-        if (f == fn) return;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    h->lds_attr_done.push_back(fn);
-}
-
 constexpr int COLS_TILE_PTS = 4096;  // points per column tile of the full-length register kernel
 
 template <int LA, int LB>
@@ -924,7 +916,7 @@ static void launch_cols_t(lk_handle *h, int m2, int ngrids, double2 *grids, cons
     const int N2 = 1 << m2;
     const int CT = std::max(1, std::min(N2, std::min(COLS_TILE_PTS / n, 256 / std::max(A, Bq))));
     const int nt = ((CT * std::max(A, Bq) + 63) / 64) * 64;
-    want_lds(h, reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB>), 160 * 1024);
+    (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_reg_kernel<LA, LB>), 160 * 1024);
     hipLaunchKernelGGL((fft_cols_reg_kernel<LA, LB>), dim3(N2 / CT, ngrids), dim3(nt), (size_t)CT * FST * 16, stream, grids,
                        m2, CT, rows_used, gout, tw);
 }
@@ -943,7 +935,7 @@ static void launch_rows_t(lk_handle *h, int m1, int ngrids, const double2 *grids
     const int N1 = 1 << m1;
     const int RT = std::max(1, std::min(N1, std::min(4096 / n, 256 / std::max(A, Bq))));
     const int nt = ((RT * std::max(A, Bq) + 63) / 64) * 64;
-    want_lds(h, reinterpret_cast<const void *>(fft_rows_reg_kernel<LA, LB>), 100 * 1024);
+    (void)want_lds(h, reinterpret_cast<const void *>(fft_rows_reg_kernel<LA, LB>), 100 * 1024);
     hipLaunchKernelGGL((fft_rows_reg_kernel<LA, LB>), dim3(N1 / RT, ngrids), dim3(nt), (size_t)RT * FST * 16, stream,
                        grids, m1, RT, nkeep, spec);
 }
@@ -974,7 +966,7 @@ static void launch_rows_power_t(lk_handle *h, int m1, int ntargets, const double
     const int N1 = 1 << m1;
     const int RT = rows_power_rt<LA, LB>(m1);
     const int nt = ((RT * std::max(A, Bq) + 63) / 64) * 64;
-    want_lds(h, reinterpret_cast<const void *>(fft_rows_power_kernel<LA, LB, KB>), 160 * 1024);
+    (void)want_lds(h, reinterpret_cast<const void *>(fft_rows_power_kernel<LA, LB, KB>), 160 * 1024);
     hipLaunchKernelGGL((fft_rows_power_kernel<LA, LB, KB>), dim3(N1 / RT, ntargets), dim3(nt), (size_t)RT * FST * 16,
                        stream, grids, m1, RT, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm, a.scale,
                        a.power, tw, a.peaks);
@@ -1073,7 +1065,7 @@ template <int LP>
 static void launch_cols_pruned_t(lk_handle *h, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
                                  double2 *gout, hipStream_t stream) {
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, LDT = Bq + 1, FST = A * LDT + 1;
-    want_lds(h, reinterpret_cast<const void *>(fft_cols_pruned_kernel<LP>), 160 * 1024);
+    (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_pruned_kernel<LP>), 160 * 1024);
     hipLaunchKernelGGL((fft_cols_pruned_kernel<LP>), dim3((1 << m2) / PRUNED_CT, ngrids), dim3(PRUNED_CT * A),
                        (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout);
 }
@@ -1186,8 +1178,8 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     }
     hipEvent_t *ev_spread = &h->ev_aux[0], *ev_cols = &h->ev_aux[2];  // [2] each, indexed by the grid buffer
     if (!reg_path) {
-        want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
-        want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
+        (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
+        (void)want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
     }
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
     int chunk = 0;
@@ -1297,8 +1289,8 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
                        d_w, d_wy, d_stats, df, nfft, m2, (int *)nullptr, (int *)nullptr, 0);
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
     if (!reg_path) {
-        want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
-        want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
+        (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
+        (void)want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
     }
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;

@@ -251,11 +251,9 @@ int pg_acf2d_launch(lk_handle *h, int B, int64_t M, const double *power, int n_w
     int *d_start = (int *)h->ws.alloc((size_t)n_win * 4);
     LK_HIP_CHECK(hipMemcpyAsync(d_start, win_start_host, (size_t)n_win * 4, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));
-    static bool attr = false;
-    if (!attr) {
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_acf2d_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+    {
+        const int rc_ = want_lds(h, reinterpret_cast<const void *>(pg_acf2d_kernel), 160 * 1024);
+        if (rc_) return rc_;
     }
     hipLaunchKernelGGL(pg_acf2d_kernel, dim3((unsigned)n_win, (unsigned)B), dim3(256), (size_t)(W + 16) * 8, stream, power,
                        M, d_start, n_win, W, acf2d, metric);

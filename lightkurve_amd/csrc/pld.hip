@@ -967,26 +967,23 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         return LK_ENOMEM;
     }
     gram_plain_launch(A, d_off, B, P, G, stream);
-    static const int direct_max = getenv("LK_PLD_DIRECT_MAX") ? atoi(getenv("LK_PLD_DIRECT_MAX")) : PLD_DIRECT_MAX;
-    static const int npow_std = getenv("LK_PLD_POWER") ? std::max(1, atoi(getenv("LK_PLD_POWER"))) : 3;
+    constexpr int direct_max = PLD_DIRECT_MAX;
+    constexpr int npow_std = 3;  // C^3 (or the degree-3 Chebyshev filter) between two Rayleigh-Ritz steps
     // mid-size product blocks: a product with the 136 x 136 C is cheap next to the l x l Jacobi and the Cholesky-QR of a
     // Rayleigh-Ritz step, and their flat spectrum keeps C^8 R well conditioned — 8 products per step need 5 steps where 3
     // need 12.  (Pixel blocks must NOT do this: their steep spectrum makes C^5 R numerically rank-deficient, the Cholesky
     // breaks down and the iteration stalls.)
-    static const int npow_prod = getenv("LK_PLD_POWER_PROD") ? std::max(1, atoi(getenv("LK_PLD_POWER_PROD"))) : 8;
+    constexpr int npow_prod = 8;
     // Chebyshev-filtered steps: bit 0 = for flat spectra only (round 2's first version), bit 1 = for every spectrum.
     // Default 3: the degree-3 filter on [0, theta_cut] needs 5.0 Rayleigh-Ritz steps where C^3 needs 7.2 on the 816-column
     // blocks (4 instead of 5 on the pixel blocks); the feared Cholesky breakdowns on steep spectra do not occur — the
-    // columns are scaled to unit length first and SVQB stands behind — PLD step 83.7 -> 77.7 ms.  LK_PLD_CHEB=1 or 0 to compare.
-    static const int cheb_on = getenv("LK_PLD_CHEB") ? (atoi(getenv("LK_PLD_CHEB")) & 3) : 3;
+    // columns are scaled to unit length first and SVQB stands behind — PLD step 83.7 -> 77.7 ms.
+    constexpr int cheb_on = 3;
     static const bool dbg_iters = getenv("LK_PLD_ITERS") && atoi(getenv("LK_PLD_ITERS")) != 0;   // print Rayleigh-Ritz step counts
-    static bool attr_set = false;
-    if (!attr_set) {
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel<2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pld_topk_eig_kernel<4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    {
+        int rc_ = want_lds(h, reinterpret_cast<const void *>(pld_topk_eig_kernel<2>), 160 * 1024);
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(pld_topk_eig_kernel<4>), 160 * 1024);
+        if (rc_) return rc_;
     }
     double *V = (double *)ws.alloc((size_t)B * P * k * 8), *lam = (double *)ws.alloc((size_t)B * k * 8);
     if (!V || !lam) {
@@ -998,9 +995,8 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
     // did not converge (2nd-order product blocks decay slowly: ~45 steps of the iteration vs one ~15 ms Jacobi).
     // mid-size product blocks (2nd-order: 136 columns): subspace iteration with 8 products per Rayleigh-Ritz step (5 steps,
     // 4.4 ms per matrix) instead of the direct Jacobi on C (135 rotation rounds x ~10 sweeps, 16 ms per matrix).
-    // LK_PLD_PROD_DIRECT=1 restores the Jacobi; LK_PLD_PROD_L overrides the basis width (default k + 16).
-    static const bool prod_direct = getenv("LK_PLD_PROD_DIRECT") && atoi(getenv("LK_PLD_PROD_DIRECT")) != 0;
-    static const int prod_l = getenv("LK_PLD_PROD_L") ? atoi(getenv("LK_PLD_PROD_L")) : 0;
+    constexpr bool prod_direct = false;
+    constexpr int prod_l = 0;  // basis width of the product blocks: the default k + 16
     const bool wide_sub = products && !prod_direct && P > PLD_LMAX && P <= PLD_DIRECT_MAX;
     const bool two_pass = !wide_sub && P > PLD_LMAX && P <= std::min(direct_max, PLD_DIRECT_MAX);
     const int npow = wide_sub ? npow_prod : npow_std;
@@ -1024,8 +1020,8 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         }
         // 512-thread workgroups, two per CU (LDS 57 KB each): one matrix's serial stretches (l x l Jacobi, Cholesky on one
         // wave, the random start) overlap the other's stream through C — 97.2 -> 86.6 ms per PLD step against one
-        // 1024-thread workgroup per CU (LK_PLD_EIG_NT=1024)
-        static const int nt_env = getenv("LK_PLD_EIG_NT") ? atoi(getenv("LK_PLD_EIG_NT")) : 512;
+        // 1024-thread workgroup per CU
+        constexpr int nt_env = 512;
         int nt_sub = (nt_env == 256 || nt_env == 512 || nt_env == 1024) ? nt_env : 512;
         if (nt_sub == 256 && l > 32) nt_sub = 512;  // 16 partial tiles of eig_xty need the 64-row stage
         const int kc = nt_sub == 256 ? 32 : PLD_KC;  // LDS stage rows: the stage also holds eig_xty's (nt / 64) x 2 KB of partial tiles

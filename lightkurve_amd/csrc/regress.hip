@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__
 // plain Gram matrices G_b = A_b^T A_b of B row-major (N_b x K) blocks (no weights, no masks), for PCA (pld.hip)
 int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, double *G, hipStream_t stream) {
     const int KB = (K + GR_BLK - 1) / GR_BLK;
-    static const int wide_min = getenv("LK_GRAM_WIDE_MIN") ? atoi(getenv("LK_GRAM_WIDE_MIN")) : 192;
+    constexpr int wide_min = 192;  // from this width the 128 x 128-tile kernel wins
     if (K >= wide_min) {
         const int KB2 = (K + G2_BLK - 1) / G2_BLK;
         if (K % 2 == 0)
@@ -725,8 +725,8 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
         if (rcs) return rcs;
     }
     LK_HIP_CHECK(hipMemsetAsync(outl, 0, ntot, stream));
-    // per-target convergence flags of the clip loop (LK_REGRESS_EARLY=0 runs every pass for every target, as round 1 did)
-    static const bool early = !(getenv("LK_REGRESS_EARLY") && atoi(getenv("LK_REGRESS_EARLY")) == 0);
+    // per-target convergence flags of the clip loop: a pass that adds no outlier ends the target's loop
+    constexpr bool early = true;
     int *d_done = early ? (int *)h->ws.alloc((size_t)B * 4) : nullptr;
     if (d_done) LK_HIP_CHECK(hipMemsetAsync(d_done, 0, (size_t)B * 4, stream));
     const int nblk = KB * (KB + 1) / 2;
@@ -734,13 +734,10 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
         hipLaunchKernelGGL(gram_mfma_kernel, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K, KB,
                            d_G, (const int *)d_done);
         const size_t solve_lds = ((size_t)K * (K + 1) + K + 4 + 2) * 8;
-        static const bool lds_solve_ok = !(getenv("LK_SOLVE_LDS") && atoi(getenv("LK_SOLVE_LDS")) == 0);
-        if (lds_solve_ok && solve_lds <= 160 * 1024) {
-            static bool solve_attr = false;
-            if (!solve_attr) {
-                LK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_lds_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                solve_attr = true;
+        if (solve_lds <= 160 * 1024) {
+            {
+                const int rc_ = want_lds(h, reinterpret_cast<const void *>(solve_lds_kernel), 160 * 1024);
+                if (rc_) return rc_;
             }
             hipLaunchKernelGGL(solve_lds_kernel, dim3(B), dim3(256), solve_lds, stream, d_G, K, Kp, prior_mu, prior_sigma, w,
                                (const int *)d_done);
