@@ -667,8 +667,8 @@ __global__ __launch_bounds__(256) void fft_rows_reg_kernel(const double2 *__rest
 
 // step 2 fused with the closed form: one workgroup transforms rows r0..r0+RT-1 of the THREE grids of a target in
 // turn (the LDS tile is reused), each phase-2 thread keeps the <= KB outputs it owns that fall below M, and the
-// power is computed in registers: the three spectra never go to memory.  With `peaks` the workgroup also leaves its
-// (largest power, lowest index attaining it; NaN skipped) in peaks[target][blockIdx.x] for lsf_peaks_kernel — the
+// power is computed in registers: the three spectra never go to memory.  With `peaks` every wave also leaves its
+// (largest power, lowest index attaining it; NaN skipped) in peaks[target][workgroup][wave] for lsf_peaks_kernel — the
 // periodogram's max_power / argmax without a second pass over the B x M spectra.
 struct PeakPart {
     double v;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
         }
     }
     if (peaks == nullptr) return;
-    // workgroup reduction of (best_v, best_k): waves by shuffles, then through the (now idle) exchange tile
+    // one partial per WAVE (shuffles only: no barrier, no LDS): lsf_peaks_kernel reduces them
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const double v2 = __shfl_xor(best_v, o);
@@ -770,16 +770,8 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
             best_k = k2;
         }
     }
-    __syncthreads();  // every phase-2 read of the tile is done
-    PeakPart *wp = reinterpret_cast<PeakPart *>(lds2);
-    if ((tid & 63) == 0) wp[tid >> 6] = PeakPart{best_v, best_k};
-    __syncthreads();
-    if (tid == 0) {
-        PeakPart r = wp[0];
-        for (int wv = 1; wv < ((int)blockDim.x >> 6); ++wv)
-            if (peak_better(wp[wv].v, wp[wv].k, r.v, r.k)) r = wp[wv];
-        peaks[(size_t)lb * gridDim.x + blockIdx.x] = r;
-    }
+    if ((tid & 63) == 0)
+        peaks[((size_t)lb * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (tid >> 6)] = PeakPart{best_v, best_k};
 }
 
 // per target: the best of its workgroups' partials -> max_power (NaN if no finite power), argmax (-1 then)
@@ -990,9 +982,13 @@ static bool rows_power_available(int m1, int m2, int64_t M) {
         default: X(5, 5)    \
     }
 
-// workgroups per target of the fused step 2 (= per-target peak partials)
+// per-target peak partials of the fused step 2: its workgroups per target x waves per workgroup
 static int rows_power_parts(int m1, int m2) {
-#define LK_X(la, lb) return (1 << m1) / rows_power_rt<la, lb>(m1);
+#define LK_X(la, lb)                                                                                   \
+    {                                                                                                  \
+        const int rt = rows_power_rt<la, lb>(m1);                                                      \
+        return ((1 << m1) / rt) * ((rt * std::max(1 << (la), 1 << (lb)) + 63) / 64);                   \
+    }
     LK_M2_SWITCH(m2, LK_X)
 #undef LK_X
 }

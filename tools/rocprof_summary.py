@@ -1,15 +1,24 @@
 #!/usr/bin/env python
 """Turn a rocprofv3 (ROCm 7.2, rocpd sqlite) result DB into a small text summary for profiles/.
 
-    python tools/rocprof_summary.py gpurun_out/prof_ls/ls_results.db [title] > profiles/r01_ls_kernel_stats.txt
+    python tools/rocprof_summary.py gpurun_out/prof_ls/ls_results.db [title] [--skip-frac F] > profiles/r01_ls_kernel_stats.txt
+
+--skip-frac F (e.g. 0.25): a second table over the dispatches that START after the first fraction F of the traced time span
+— the steady state without the cold warm-up launches, which is what the bench line's per-step time corresponds to.
 """
 import sqlite3
 import sys
 
 
 def main():
-    db = sys.argv[1]
-    title = sys.argv[2] if len(sys.argv) > 2 else db
+    argv = list(sys.argv[1:])
+    skip = 0.0
+    if "--skip-frac" in argv:
+        i = argv.index("--skip-frac")
+        skip = float(argv[i + 1])
+        del argv[i:i + 2]
+    db = argv[0]
+    title = argv[1] if len(argv) > 1 else db
     con = sqlite3.connect(db)
     print("# %s" % title)
     print("# source: rocprofv3 result db %s" % db)
@@ -19,6 +28,16 @@ def main():
         print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, tot, avg, pct in rows:
             print("%-60s %8d %14.1f %12.1f %8.3f" % (name.split("(")[0][-60:], calls, tot, avg, pct))
+    if skip > 0.0:
+        t0, t1 = con.execute("select min(start), max(end) from kernels").fetchone()
+        cut = t0 + skip * (t1 - t0)
+        rows = con.execute("select name, count(*), sum(end - start) / 1000.0, avg(end - start) / 1000.0 from kernels "
+                           "where start >= ? group by name order by 3 desc", (cut,)).fetchall()
+        tot_all = sum(r[2] for r in rows) or 1.0
+        print("\n## steady state: dispatches starting after the first %.0f %% of the traced span (durations in microseconds)" % (100 * skip))
+        print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+        for name, calls, tot, avg in rows:
+            print("%-60s %8d %14.1f %12.1f %8.3f" % (name.split("(")[0][-60:], calls, tot, avg, 100.0 * tot / tot_all))
     try:
         rows = con.execute(
             "select kernel_name, counter_name, sum(value), count(*), avg(duration) from counters_collection "
