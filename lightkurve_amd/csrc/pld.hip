@@ -21,6 +21,7 @@
 // answer wherever the spectrum has a gap.  PCA bases are only defined up to rotation inside a block and the
 // regression is invariant to it, so parity is stated on the corrected flux.
 // The order-1 block skips the reference's redundant re-PCA of an already orthonormal basis (same subspace).
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -173,6 +174,232 @@ __global__ __launch_bounds__(256) void pld_products_kernel(const double *__restr
             double prod = us[r][a[0]];
             for (int pos = 1; pos < order; ++pos) prod *= us[r][a[pos]];
             o[(size_t)r * Pc] = prod - m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ moment-form Gram
+// The Gram matrix of an order-o product block never needs the N x Pc matrix of products: its entry for the columns
+// (a1..ao), (b1..bo) is the 2o-th moment sum_n u_a1 .. u_ao u_b1 .. u_bo of the k first-order components, which depends
+// only on the MULTISET of the 2o factors.  Every multiset has one canonical split — its o smallest factors | its o
+// largest — so it suffices to compute the pairs (row tuple x, column tuple y) with max(x) <= min(y): with the rows
+// ordered by their largest factor and the columns in natural (lexicographic = smallest-factor-first) order, that is a
+// staircase of 54 264 entries for k = 16, o = 3 (71 168 in whole 16 x 16 MFMA tiles) against the 458 752 of the upper
+// 128 x 128 blocks of the 816 x 816 matrix — 6.4 x fewer matrix-core instructions, and the 22.8 MB per cutout of
+// materialised products are neither written nor read.  Operands are generated on the fly from a 64-cadence stage of U in
+// LDS (o reads and o - 1 multiplications per element).  A wave owns up to 4 x 4 tiles (a "wave tile" of the host-built
+// list: first row in row order, first column, 16-bit mask of the tiles that hold canonical pairs).
+constexpr int MG_CH = 64;  // cadences per LDS stage
+constexpr int kMomentMinCols = 256;  // product blocks at least this wide take the moment form
+template <int O, bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pld_moment_gram_kernel(
+    const double *__restrict__ X, int ldx, int col0, int k, int N, int Pc, int ldm, const uint8_t *__restrict__ rcomb,
+    const uint8_t *__restrict__ comb, const int4 *__restrict__ wt, int nwt, double *__restrict__ Mcan) {
+    extern __shared__ __attribute__((aligned(16))) double mg_us[];  // 2 x MG_CH x ks
+    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
+    const int ks = k | 1;
+    const int w = blockIdx.x * 4 + wave;
+    const int4 t = wt[min(w, nwt - 1)];
+    const int r0 = t.x, c0 = t.y;
+    const unsigned mask = w < nwt ? (unsigned)t.z : 0u;
+    int ia[4][O], ib[4][O];
+    bool va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i + lr, c = c0 + 16 * i + lr;
+        va[i] = r < Pc;
+        vb[i] = c < Pc;
+#pragma unroll
+        for (int pos = 0; pos < O; ++pos) {
+            ia[i][pos] = rcomb[(size_t)min(r, Pc - 1) * O + pos];
+            ib[i][pos] = comb[(size_t)min(c, Pc - 1) * O + pos];
+        }
+    }
+    pld_d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    const double *u = X + (size_t)b * N * ldx + col0;
+    constexpr int PRE = 12;  // k <= 48: MG_CH * k / 256 elements of the next stage wait in registers
+    double pre[PRE];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e / k, c = e - r * k;
+            pre[q] = (e < MG_CH * k && n0 + r < N) ? u[(size_t)(n0 + r) * ldx + c] : 0.0;
+        }
+    };
+    auto park = [&](double *buf) {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e / k, c = e - r * k;
+            if (e < MG_CH * k) buf[r * ks + c] = pre[q];
+        }
+    };
+    fetch(0);
+    park(mg_us);
+    __syncthreads();
+    int cur = 0;
+    for (int n0 = 0; n0 < N; n0 += MG_CH) {
+        const bool more = n0 + MG_CH < N;
+        if (more) fetch(n0 + MG_CH);
+        const double *stage = mg_us + cur * MG_CH * ks;
+        if (FULL) {
+            for (int sst = 0; sst < MG_CH / 4; ++sst) {
+                const double *row = stage + (4 * sst + lq) * ks;
+                double av[4], bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double pa = row[ia[i][0]], pb = row[ib[i][0]];
+#pragma unroll
+                    for (int pos = 1; pos < O; ++pos) {
+                        pa *= row[ia[i][pos]];
+                        pb *= row[ib[i][pos]];
+                    }
+                    av[i] = va[i] ? pa : 0.0;
+                    bv[i] = vb[i] ? pb : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            for (int sst = 0; sst < MG_CH / 4; ++sst) {
+                const double *row = stage + (4 * sst + lq) * ks;
+                double av[4], bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    av[i] = 0.0;
+                    bv[i] = 0.0;
+                    if (mask & (0xfu << (4 * i))) {
+                        double pa = row[ia[i][0]];
+#pragma unroll
+                        for (int pos = 1; pos < O; ++pos) pa *= row[ia[i][pos]];
+                        av[i] = va[i] ? pa : 0.0;
+                    }
+                    if (mask & (0x1111u << i)) {
+                        double pb = row[ib[i][0]];
+#pragma unroll
+                        for (int pos = 1; pos < O; ++pos) pb *= row[ib[i][pos]];
+                        bv[i] = vb[i] ? pb : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (mask & (1u << (4 * i + j)))
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) park(mg_us + (cur ^ 1) * MG_CH * ks);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double *Mb = Mcan + (size_t)b * ldm * ldm;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (mask & (1u << (4 * i + j))) {
+                const int col = c0 + 16 * j + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowi = r0 + 16 * i + lq + 4 * r;
+                    if (rowi < Pc && col < Pc) Mb[(size_t)rowi * ldm + col] = acc[i][j][r];
+                }
+            }
+}
+
+// G[i][j] = moment of the merged multiset of columns i and j (looked up through the host-built index table) minus
+// N mean_i mean_j: the Gram matrix of the CENTRED products, written in full (both triangles).
+__global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__restrict__ Mcan, size_t mstride,
+                                                                 const uint32_t *__restrict__ src,
+                                                                 const double *__restrict__ mean, int Pc, int ldg, double Nd,
+                                                                 double *__restrict__ G) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Pc * Pc) return;
+    const int i = e / Pc, j = e - i * Pc;
+    const double *mb = mean + (size_t)b * Pc;
+    G[(size_t)b * ldg * ldg + (size_t)i * ldg + j] = Mcan[(size_t)b * mstride + src[e]] - Nd * mb[i] * mb[j];
+}
+
+// U = (products - mean) V diag(lam)^-1/2 into X[:, col0 : col0 + kk] with the products generated on the fly from the
+// first-order components (X[:, col1 : col1 + k1]).  One wave = 16 cadences; the summation index of an MFMA step is the
+// product column p = p0 + (lane >> 4), its factor tuple one packed dword of LDS.
+template <int O, int KT>
+__global__ __launch_bounds__(256) void pld_project_products_kernel(const double *__restrict__ Xin, int ldx, int col1, int k1,
+                                                                    int N, int Pc, const uint32_t *__restrict__ packed,
+                                                                    const double *__restrict__ mean,
+                                                                    const double *__restrict__ V,
+                                                                    const double *__restrict__ lam, int kk, int col0,
+                                                                    double *__restrict__ Xout) {
+    extern __shared__ __attribute__((aligned(16))) double pp_lds[];  // us[64][ks] | mv[64] | red[4][64] | tup[Pc] (dwords)
+    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
+    const int ks = k1 | 1;
+    double *us = pp_lds, *mv = us + 64 * ks, *red = mv + 64;
+    uint32_t *tup = reinterpret_cast<uint32_t *>(red + 256);
+    const int nb = blockIdx.x * 64;
+    for (int e = tid; e < 64 * k1; e += 256) {
+        const int r = e / k1, c = e - r * k1;
+        us[r * ks + c] = nb + r < N ? Xin[((size_t)b * N + nb + r) * ldx + col1 + c] : 0.0;
+    }
+    for (int e = tid; e < Pc; e += 256) tup[e] = packed[e];
+    const double *Vb = V + (size_t)b * Pc * kk, *mb = mean + (size_t)b * Pc;
+    {
+        // mv[a] = sum_p mean[p] V[p][a]: the projection of the column means, subtracted from every cadence below
+        const int a = tid & 63, sl = tid >> 6;
+        double sm = 0.0;
+        if (a < kk)
+            for (int p = sl; p < Pc; p += 4) sm = fma(mb[p], Vb[(size_t)p * kk + a], sm);
+        red[sl * 64 + a] = sm;
+    }
+    __syncthreads();
+    if (tid < 64) mv[tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    __syncthreads();
+    const int n0 = nb + wave * 16;
+    if (n0 >= N) return;
+    const double *row = us + (wave * 16 + lr) * ks;
+    pld_d4 acc[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) acc[c] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < Pc; p0 += 16) {
+        double prod[4], bv[4][KT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + 4 * q + lq, pc = min(p, Pc - 1);
+            const uint32_t tp = tup[pc];
+            double pr = row[tp & 255u];
+#pragma unroll
+            for (int pos = 1; pos < O; ++pos) pr *= row[(tp >> (8 * pos)) & 255u];
+            prod[q] = p < Pc ? pr : 0.0;
+#pragma unroll
+            for (int c = 0; c < KT; ++c) {
+                const int col = c * 16 + lr;
+                const double vraw = Vb[(size_t)pc * kk + min(col, kk - 1)];
+                bv[q][c] = (p < Pc && col < kk) ? vraw : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < KT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(prod[q], bv[q][c], acc[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        const int a = c * 16 + lr;
+        if (a < kk) {
+            const double sc = sqrt(fmax(lam[(size_t)b * kk + a], 1e-300));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + lq + 4 * r;
+                if (n < N) Xout[((size_t)b * N + n) * ldx + col0 + a] = (acc[c][r] - mv[a]) / sc;
+            }
         }
     }
 }
@@ -700,7 +927,8 @@ template <int NA>
 __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__ G, int ldg, int P, int k, int l, int npow,
                                                              double *__restrict__ scratch, double *__restrict__ V,
                                                              double *__restrict__ lam, long long *__restrict__ iters_out,
-                                                             int max_it, int *__restrict__ status, int cheb_on, int kc) {
+                                                             int max_it, int *__restrict__ status, int cheb_on, int kc,
+                                                             int mirror) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     double *Gb = G + (size_t)b * ldg * ldg;
@@ -782,10 +1010,11 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         }
     };
     // the Gram kernel wrote the upper 64x64 blocks only: mirror them so the products below read plain rows
-    for (int e = tid; e < P * P; e += nt) {
-        const int i = e / P, j = e - i * P;
-        if ((j >> 6) < (i >> 6)) Gb[(size_t)i * ldg + j] = Gb[(size_t)j * ldg + i];
-    }
+    if (mirror)
+        for (int e = tid; e < P * P; e += nt) {
+            const int i = e / P, j = e - i * P;
+            if ((j >> 6) < (i >> 6)) Gb[(size_t)i * ldg + j] = Gb[(size_t)j * ldg + i];
+        }
     // deterministic pseudo-random start
     for (int e = tid; e < P * l; e += nt) {
         unsigned int x = (unsigned int)(e + 1) * 2654435761u;
@@ -956,17 +1185,10 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
-// PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
-static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
-                     int col0, hipStream_t stream, Arena &ws, bool centred = false, bool products = false) {
-    if (!centred) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
-    const int KB = (P + 63) / 64, ldg = KB * 64;
-    double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
-    if (!G) {
-        set_error("PLD workspace exhausted (Gram)");
-        return LK_ENOMEM;
-    }
-    gram_plain_launch(A, d_off, B, P, G, stream);
+// top-k eigenpairs of the B Gram matrices G (P x P, leading dimension ldg) -> V (B x P x k), lam (B x k), both allocated
+// from ws.  mirror: G holds the upper 64 x 64 blocks only (gram_plain_launch) and is completed in place first.
+static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool products, bool mirror, double **V_out,
+                    double **lam_out, hipStream_t stream, Arena &ws) {
     constexpr int direct_max = PLD_DIRECT_MAX;
     constexpr int npow_std = 3;  // C^3 (or the degree-3 Chebyshev filter) between two Rayleigh-Ritz steps
     // mid-size product blocks: a product with the 136 x 136 C is cheap next to the l x l Jacobi and the Cholesky-QR of a
@@ -1029,10 +1251,10 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         long long *d_it = dbg_iters ? (long long *)ws.alloc((size_t)B * 64) : nullptr;
         if (l <= 32)
             hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0);
         else
             hipLaunchKernelGGL(pld_topk_eig_kernel<4>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0);
         if (d_it) {
             std::vector<long long> hit((size_t)B * 8);
             LK_HIP_CHECK(hipMemcpyAsync(hit.data(), d_it, (size_t)B * 64, hipMemcpyDeviceToHost, stream));
@@ -1064,8 +1286,27 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         const size_t lds = two_pass ? ((size_t)l * ld + 2 * l + nt_eig + 2 * l + (l + 1) / 2 + 1) * 8 + 64
                                     : ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1) * 8 + 64;
         hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_eig), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                           (long long *)nullptr, 400, status, cheb_on, PLD_KC);
+                           (long long *)nullptr, 400, status, cheb_on, PLD_KC, mirror ? 1 : 0);
     }
+    *V_out = V;
+    *lam_out = lam;
+    return LK_OK;
+}
+
+// PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
+static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
+                     int col0, hipStream_t stream, Arena &ws, bool centred = false, bool products = false) {
+    if (!centred) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
+    const int KB = (P + 63) / 64, ldg = KB * 64;
+    double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
+    if (!G) {
+        set_error("PLD workspace exhausted (Gram)");
+        return LK_ENOMEM;
+    }
+    gram_plain_launch(A, d_off, B, P, G, stream);
+    double *V = nullptr, *lam = nullptr;
+    const int rc = eig_topk(h, G, ldg, B, P, k, products, true, &V, &lam, stream, ws);
+    if (rc) return rc;
     {
         const dim3 grid((N + 63) / 64, B), blk(256);
         const int kt = (k + 15) / 16;
@@ -1081,6 +1322,143 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
             if (v4) LK_PROJ(4, true); else LK_PROJ(4, false);
         }
 #undef LK_PROJ
+    }
+    return LK_OK;
+}
+
+// Host-built tables of the moment-form Gram (see pld_moment_gram_kernel), cached per (device, k, order).
+struct MomentPlan {
+    int device, k, order, Pc, ldm, nwt, nfull;  // nfull: leading wave tiles whose 16 tiles are all needed
+    uint8_t *d_comb, *d_rcomb;  // factor tuples in natural order / in row order (sorted by largest factor)
+    int4 *d_wt;                 // wave tiles: first row (row order), first column, mask of the 16 x 16 tiles to compute
+    uint32_t *d_src;            // [Pc][Pc]: where the moment of columns (i, j) sits in the canonical array
+    uint32_t *d_packed;         // natural-order tuples, one dword each (projection kernel)
+};
+
+static const MomentPlan *moment_plan(lk_handle *h, int k, int o, const std::vector<uint8_t> &comb, int Pc) {
+    static std::vector<MomentPlan *> cache;
+    for (const MomentPlan *pl : cache)
+        if (pl->device == h->device && pl->k == k && pl->order == o) return pl;
+    auto tup = [&](int idx, int pos) { return (int)comb[(size_t)idx * o + pos]; };
+    // row order: stable sort by the largest (= last) factor
+    std::vector<int> rperm(Pc), rowpos(Pc);
+    for (int i = 0; i < Pc; ++i) rperm[i] = i;
+    std::stable_sort(rperm.begin(), rperm.end(), [&](int a, int b2) { return tup(a, o - 1) < tup(b2, o - 1); });
+    for (int r = 0; r < Pc; ++r) rowpos[rperm[r]] = r;
+    std::vector<int> colstart(k + 2, 0);  // number of tuples whose smallest factor is < m
+    for (int m = 0; m <= k + 1; ++m) {
+        int c = 0;
+        while (c < Pc && tup(c, 0) < m) ++c;
+        colstart[m] = c;
+    }
+    // rank of a sorted tuple in natural order
+    size_t kp = 1;
+    for (int pos = 0; pos < o; ++pos) kp *= (size_t)k;
+    std::vector<int> rank(kp, -1);
+    auto key = [&](const int *a) {
+        size_t q = 0;
+        for (int pos = 0; pos < o; ++pos) q = q * k + a[pos];
+        return q;
+    };
+    for (int i = 0; i < Pc; ++i) {
+        int a[4];
+        for (int pos = 0; pos < o; ++pos) a[pos] = tup(i, pos);
+        rank[key(a)] = i;
+    }
+    const int ldm = ((Pc + 63) / 64) * 64;
+    std::vector<uint32_t> src((size_t)Pc * Pc), packed(Pc);
+    for (int i = 0; i < Pc; ++i) {
+        uint32_t pk = 0;
+        for (int pos = 0; pos < o; ++pos) pk |= (uint32_t)tup(i, pos) << (8 * pos);
+        packed[i] = pk;
+        for (int j = 0; j < Pc; ++j) {
+            int z[8], a = 0, b2 = 0;
+            for (int q = 0; q < 2 * o; ++q)  // merge of two sorted tuples
+                z[q] = (b2 >= o || (a < o && tup(i, a) <= tup(j, b2))) ? tup(i, a++) : tup(j, b2++);
+            src[(size_t)i * Pc + j] = (uint32_t)rowpos[rank[key(z)]] * (uint32_t)ldm + (uint32_t)rank[key(z + o)];
+        }
+    }
+    std::vector<int4> wt;
+    for (int r0 = 0; r0 < Pc; r0 += 64) {
+        int rt[4], mn = k;
+        for (int i = 0; i < 4; ++i) {
+            rt[i] = -1;  // smallest "largest factor" among the rows of tile i
+            for (int r = r0 + 16 * i; r < std::min(Pc, r0 + 16 * i + 16); ++r)
+                rt[i] = rt[i] < 0 ? tup(rperm[r], o - 1) : std::min(rt[i], tup(rperm[r], o - 1));
+            if (rt[i] >= 0) mn = std::min(mn, rt[i]);
+        }
+        for (int cg = (colstart[mn] / 16) * 16; cg < Pc; cg += 64) {
+            int mask = 0;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    if (rt[i] >= 0 && cg + 16 * j < Pc && cg + 16 * j + 16 > colstart[rt[i]]) mask |= 1 << (4 * i + j);
+            if (mask) wt.push_back(int4{r0, cg, mask, 0});
+        }
+    }
+    // waves of a workgroup wait for each other at every stage: put tiles of similar size together
+    std::stable_sort(wt.begin(), wt.end(), [](const int4 &a, const int4 &b2) { return __builtin_popcount(a.z) > __builtin_popcount(b2.z); });
+    std::vector<uint8_t> rcomb((size_t)Pc * o);
+    for (int r = 0; r < Pc; ++r)
+        for (int pos = 0; pos < o; ++pos) rcomb[(size_t)r * o + pos] = (uint8_t)tup(rperm[r], pos);
+    int nfull = 0;
+    while (nfull < (int)wt.size() && wt[nfull].z == 0xffff) ++nfull;
+    MomentPlan *pl = new MomentPlan{h->device, k, o, Pc, ldm, (int)wt.size(), nfull, nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto up = [&](void **d, const void *src_, size_t bytes) {
+        if (hipMalloc(d, bytes) != hipSuccess) return false;
+        return hipMemcpy(*d, src_, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    const bool ok = up((void **)&pl->d_comb, comb.data(), comb.size()) && up((void **)&pl->d_rcomb, rcomb.data(), rcomb.size()) &&
+                    up((void **)&pl->d_wt, wt.data(), wt.size() * sizeof(int4)) && up((void **)&pl->d_src, src.data(), src.size() * 4) &&
+                    up((void **)&pl->d_packed, packed.data(), packed.size() * 4);
+    if (!ok) {
+        set_error("PLD: could not allocate the moment-Gram tables");
+        delete pl;
+        return nullptr;
+    }
+    cache.push_back(pl);
+    return pl;
+}
+
+// PCA of an order-o product block without materialising it: moment-form Gram -> eigenpairs -> projection generated on
+// the fly.  Mcan: scratch of B * ldm * ldm doubles.
+static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N, int k1, int ko, double *X, int K, int col1,
+                               int col0, const double *d_mean, double *Mcan, hipStream_t stream, Arena &ws) {
+    const int Pc = pl.Pc, o = pl.order, ldg = ((Pc + 63) / 64) * 64;
+    double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
+    if (!G) {
+        set_error("PLD workspace exhausted (Gram)");
+        return LK_ENOMEM;
+    }
+    {
+        const size_t lds = (size_t)2 * MG_CH * (k1 | 1) * 8;
+#define LK_MG(O)                                                                                                        \
+    do {                                                                                                                \
+        if (pl.nfull > 0)                                                                                               \
+            hipLaunchKernelGGL((pld_moment_gram_kernel<O, true>), dim3((pl.nfull + 3) / 4, B), dim3(256), lds, stream, X, K, \
+                               col1, k1, N, Pc, pl.ldm, pl.d_rcomb, pl.d_comb, pl.d_wt, pl.nfull, Mcan);                \
+        if (pl.nwt > pl.nfull)                                                                                          \
+            hipLaunchKernelGGL((pld_moment_gram_kernel<O, false>), dim3((pl.nwt - pl.nfull + 3) / 4, B), dim3(256), lds,    \
+                               stream, X, K, col1, k1, N, Pc, pl.ldm, pl.d_rcomb, pl.d_comb, pl.d_wt + pl.nfull,        \
+                               pl.nwt - pl.nfull, Mcan);                                                                \
+    } while (0)
+        if (o == 2) LK_MG(2); else if (o == 3) LK_MG(3); else LK_MG(4);
+#undef LK_MG
+    }
+    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * Pc + 255) / 256, B), dim3(256), 0, stream, Mcan,
+                       (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G);
+    double *V = nullptr, *lam = nullptr;
+    const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws);
+    if (rc) return rc;
+    {
+        const size_t lds = (size_t)(64 * (k1 | 1) + 64 + 256) * 8 + (size_t)Pc * 4;
+        const dim3 grid((N + 63) / 64, B);
+        const int kt = (ko + 15) / 16;
+#define LK_PP(O, KT) hipLaunchKernelGGL((pld_project_products_kernel<O, KT>), grid, dim3(256), lds, stream, X, K, col1, k1, N, Pc, \
+                                        pl.d_packed, d_mean, V, lam, ko, col0, X)
+#define LK_PPO(O) do { if (kt <= 1) LK_PP(O, 1); else if (kt == 2) LK_PP(O, 2); else LK_PP(O, 3); } while (0)
+        if (o == 2) LK_PPO(2); else if (o == 3) LK_PPO(3); else LK_PPO(4);
+#undef LK_PPO
+#undef LK_PP
     }
     return LK_OK;
 }
@@ -1151,10 +1529,20 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
             LK_HIP_CHECK(hipStreamSynchronize(stream));  // comb dies at the end of this iteration
             hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(1024), 0, stream, X, K, col1, k1, o,
                                N, Pc, d_comb, d_mean);
-            hipLaunchKernelGGL(pld_products_kernel, dim3((N + PP_ROWS - 1) / PP_ROWS, B), dim3(256), 0, stream, X, K, col1, k1, o, N, Pc,
-                               d_comb, d_mean, A);
-            rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws, true, true);
-            if (rc) return rc;
+            // wide product blocks: moment-form Gram, the products are never materialised (A serves as its scratch)
+            const int ldm = ((Pc + 63) / 64) * 64;
+            const bool moment = Pc >= kMomentMinCols && k1 <= 48 && (size_t)ldm * ldm <= (size_t)N * pmax;
+            if (moment) {
+                const MomentPlan *pl = moment_plan(h, k1, o, comb, Pc);
+                if (!pl) return LK_ENOMEM;
+                rc = pca_products_moment(h, *pl, B, N, k1, ko, X, K, col1, col, d_mean, A, stream, h->ws);
+                if (rc) return rc;
+            } else {
+                hipLaunchKernelGGL(pld_products_kernel, dim3((N + PP_ROWS - 1) / PP_ROWS, B), dim3(256), 0, stream, X, K, col1, k1, o,
+                                   N, Pc, d_comb, d_mean, A);
+                rc = pca_block(h, A, B, N, Pc, ko, d_off, X, K, col, stream, h->ws, true, true);
+                if (rc) return rc;
+            }
             col += ko;
         }
     }

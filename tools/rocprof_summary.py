@@ -3,6 +3,8 @@
 
     python tools/rocprof_summary.py gpurun_out/prof_ls/ls_results.db [title] [--skip-frac F] > profiles/r01_ls_kernel_stats.txt
 
+--timeline N: the last N kernel dispatches in launch order with start offset, duration and the idle gap before each (all in
+microseconds) — shows host-side bubbles between launches that the per-kernel sums hide.
 --skip-frac F (e.g. 0.25): a second table over the dispatches that START after the first fraction F of the traced time span
 — the steady state without the cold warm-up launches, which is what the bench line's per-step time corresponds to.
 """
@@ -16,6 +18,11 @@ def main():
     if "--skip-frac" in argv:
         i = argv.index("--skip-frac")
         skip = float(argv[i + 1])
+        del argv[i:i + 2]
+    timeline = 0
+    if "--timeline" in argv:
+        i = argv.index("--timeline")
+        timeline = int(argv[i + 1])
         del argv[i:i + 2]
     db = argv[0]
     title = argv[1] if len(argv) > 1 else db
@@ -38,6 +45,19 @@ def main():
         print("%-60s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, tot, avg in rows:
             print("%-60s %8d %14.1f %12.1f %8.3f" % (name.split("(")[0][-60:], calls, tot, avg, 100.0 * tot / tot_all))
+    if timeline > 0:
+        rows = con.execute("select name, start, end from kernels order by start").fetchall()[-timeline:]
+        print("\n## timeline of the last %d dispatches (microseconds; gap = idle time since the previous dispatch ended)" % len(rows))
+        print("%-60s %12s %12s %10s" % ("kernel", "start_us", "dur_us", "gap_us"))
+        base, prev_end = rows[0][1], rows[0][1]
+        busy = gap_tot = 0.0
+        for name, st, en in rows:
+            gap = max(0.0, (st - prev_end) / 1000.0)
+            print("%-60s %12.1f %12.1f %10.1f" % (name.split("(")[0][-60:], (st - base) / 1000.0, (en - st) / 1000.0, gap))
+            busy += (en - st) / 1000.0
+            gap_tot += gap
+            prev_end = max(prev_end, en)
+        print("# span %.1f us, kernels %.1f us, idle gaps %.1f us" % ((prev_end - base) / 1000.0, busy, gap_tot))
     try:
         rows = con.execute(
             "select kernel_name, counter_name, sum(value), count(*), avg(duration) from counters_collection "
