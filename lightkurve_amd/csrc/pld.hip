@@ -17,8 +17,8 @@
 // for P <= 64 the Jacobi always runs on C itself.
 // Then U = A V diag(lambda)^-1/2 (pld_project_kernel, MFMA) written straight into X.  The reference uses fbpca
 // (randomised range finder, 10 power iterations, 2 oversampling columns, unseeded RNG => not reproducible); the oracle
-// uses an exact SVD; the iteration here converges the residual ||C r - theta r|| to 1e-13 theta_max, i.e. to the exact
-// answer wherever the spectrum has a gap.  PCA bases are only defined up to rotation inside a block and the
+// uses an exact SVD; the iteration here converges the residual ||C r - theta r|| to 1e-10 theta_max, i.e. to ten digits
+// wherever the spectrum has a gap.  PCA bases are only defined up to rotation inside a block and the
 // regression is invariant to it, so parity is stated on the corrected flux.
 // The order-1 block skips the reference's redundant re-PCA of an already orthonormal basis (same subspace).
 #include <algorithm>
@@ -190,25 +190,23 @@ __global__ __launch_bounds__(256) void pld_products_kernel(const double *__restr
 // LDS (o reads and o - 1 multiplications per element).  A wave owns up to 4 x 4 tiles (a "wave tile" of the host-built
 // list: first row in row order, first column, 16-bit mask of the tiles that hold canonical pairs).
 constexpr int MG_CH = 64;  // cadences per LDS stage
-constexpr int kMomentMinCols = 256;  // product blocks at least this wide take the moment form
-template <int O, bool FULL>
+constexpr int kMomentMinCols = 100;  // product blocks at least this wide take the moment form
+template <int O, bool FULL, int PRE, int KS>  // KS: LDS row stride (k | 1) when known at compile time, else 0; PRE: MG_CH * k / 256 elements of the next stage wait in registers (4: k <= 16, 12: k <= 48)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pld_moment_gram_kernel(
     const double *__restrict__ X, int ldx, int col0, int k, int N, int Pc, int ldm, const uint8_t *__restrict__ rcomb,
     const uint8_t *__restrict__ comb, const int4 *__restrict__ wt, int nwt, double *__restrict__ Mcan) {
     extern __shared__ __attribute__((aligned(16))) double mg_us[];  // 2 x MG_CH x ks
     const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
-    const int ks = k | 1;
+    const int ks = KS > 0 ? KS : (k | 1);
     const int w = blockIdx.x * 4 + wave;
     const int4 t = wt[min(w, nwt - 1)];
     const int r0 = t.x, c0 = t.y;
     const unsigned mask = w < nwt ? (unsigned)t.z : 0u;
+    // rows / columns past the end are clamped, not zeroed: their accumulator entries are simply never stored
     int ia[4][O], ib[4][O];
-    bool va[4], vb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + 16 * i + lr, c = c0 + 16 * i + lr;
-        va[i] = r < Pc;
-        vb[i] = c < Pc;
 #pragma unroll
         for (int pos = 0; pos < O; ++pos) {
             ia[i][pos] = rcomb[(size_t)min(r, Pc - 1) * O + pos];
@@ -221,7 +219,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = pld_d4{0.0, 0.0, 0.0, 0.0};
     const double *u = X + (size_t)b * N * ldx + col0;
-    constexpr int PRE = 12;  // k <= 48: MG_CH * k / 256 elements of the next stage wait in registers
     double pre[PRE];
     auto fetch = [&](int n0) {
 #pragma unroll
@@ -242,59 +239,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fetch(0);
     park(mg_us);
     __syncthreads();
+    // byte offsets of the factors inside a stage row; rows / columns that no needed tile touches are never generated
+    int oa[4][O], ob[4][O];
+    bool ua[4], ub[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ua[i] = FULL || (mask & (0xfu << (4 * i))) != 0;
+        ub[i] = FULL || (mask & (0x1111u << i)) != 0;
+#pragma unroll
+        for (int pos = 0; pos < O; ++pos) {
+            oa[i][pos] = ia[i][pos] * 8;
+            ob[i][pos] = ib[i][pos] * 8;
+        }
+    }
+    // Software pipeline: the 8 x O LDS reads of step s + 1 are issued before the 16 MFMAs of step s and multiplied out
+    // after them (left to itself the compiler chains read -> wait -> multiply 17 times per step: 1700 cycles of exposed
+    // LDS latency next to 1024 cycles of matrix-core work).
+    double ra[4][O], rb[4][O], av[4], bv[4];
+    auto issue = [&](const char *rowp) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (ua[i]) {
+#pragma unroll
+                for (int pos = 0; pos < O; ++pos) ra[i][pos] = *reinterpret_cast<const double *>(rowp + oa[i][pos]);
+            }
+            if (ub[i]) {
+#pragma unroll
+                for (int pos = 0; pos < O; ++pos) rb[i][pos] = *reinterpret_cast<const double *>(rowp + ob[i][pos]);
+            }
+        }
+    };
+    auto multiply = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double pa = ra[i][0], pb = rb[i][0];
+#pragma unroll
+            for (int pos = 1; pos < O; ++pos) {
+                pa *= ra[i][pos];
+                pb *= rb[i][pos];
+            }
+            av[i] = pa;
+            bv[i] = pb;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int pos = 0; pos < O; ++pos) ra[i][pos] = rb[i][pos] = 0.0;
     int cur = 0;
     for (int n0 = 0; n0 < N; n0 += MG_CH) {
         const bool more = n0 + MG_CH < N;
         if (more) fetch(n0 + MG_CH);
-        const double *stage = mg_us + cur * MG_CH * ks;
-        if (FULL) {
-            for (int sst = 0; sst < MG_CH / 4; ++sst) {
-                const double *row = stage + (4 * sst + lq) * ks;
-                double av[4], bv[4];
+        const char *stage = reinterpret_cast<const char *>(mg_us + cur * MG_CH * ks) + lq * ks * 8;
+        issue(stage);
+        multiply();
+#pragma unroll 1
+        for (int sst = 0; sst < MG_CH / 4; ++sst) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (sst + 1 < MG_CH / 4) issue(stage + (sst + 1) * 4 * ks * 8);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    double pa = row[ia[i][0]], pb = row[ib[i][0]];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int pos = 1; pos < O; ++pos) {
-                        pa *= row[ia[i][pos]];
-                        pb *= row[ib[i][pos]];
-                    }
-                    av[i] = va[i] ? pa : 0.0;
-                    bv[i] = vb[i] ? pb : 0.0;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-            for (int sst = 0; sst < MG_CH / 4; ++sst) {
-                const double *row = stage + (4 * sst + lq) * ks;
-                double av[4], bv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    av[i] = 0.0;
-                    bv[i] = 0.0;
-                    if (mask & (0xfu << (4 * i))) {
-                        double pa = row[ia[i][0]];
-#pragma unroll
-                        for (int pos = 1; pos < O; ++pos) pa *= row[ia[i][pos]];
-                        av[i] = va[i] ? pa : 0.0;
-                    }
-                    if (mask & (0x1111u << i)) {
-                        double pb = row[ib[i][0]];
-#pragma unroll
-                        for (int pos = 1; pos < O; ++pos) pb *= row[ib[i][pos]];
-                        bv[i] = vb[i] ? pb : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (mask & (1u << (4 * i + j)))
-                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 4; ++j)
+                    if (FULL || (mask & (1u << (4 * i + j))))
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sst + 1 < MG_CH / 4) multiply();
         }
         if (more) park(mg_us + (cur ^ 1) * MG_CH * ks);
         __syncthreads();
@@ -928,7 +939,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
                                                              double *__restrict__ scratch, double *__restrict__ V,
                                                              double *__restrict__ lam, long long *__restrict__ iters_out,
                                                              int max_it, int *__restrict__ status, int cheb_on, int kc,
-                                                             int mirror) {
+                                                             int mirror, double tol) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     double *Gb = G + (size_t)b * ldg * ldg;
@@ -1057,7 +1068,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         if (tid < k) lamb[tid] = theta[tid];
         __syncthreads();
         lap(4);
-        if (res <= 1e-13 * th0 * sqrt((double)k)) {
+        if (res <= tol * th0 * sqrt((double)k)) {
             converged = true;
             break;
         }
@@ -1190,6 +1201,11 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
 static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool products, bool mirror, double **V_out,
                     double **lam_out, hipStream_t stream, Arena &ws) {
     constexpr int direct_max = PLD_DIRECT_MAX;
+    // Convergence: || C r - theta r || <= eig_tol * theta_max * sqrt(k) over the k wanted pairs.  1e-10 (round 3; 1e-13 before)
+    // costs one Rayleigh-Ritz step less per matrix (816 columns: 4.0 instead of 5.0) and moves the corrected flux of the
+    // reference-generated C5 golden by 1e-11 relative — the reference's own PCA is a randomised range finder run for a fixed
+    // 10 iterations, three orders of magnitude less reproducible than that (the golden itself sits 1.5e-8 away either way).
+    constexpr double eig_tol = 1e-10;
     constexpr int npow_std = 3;  // C^3 (or the degree-3 Chebyshev filter) between two Rayleigh-Ritz steps
     // mid-size product blocks: a product with the 136 x 136 C is cheap next to the l x l Jacobi and the Cholesky-QR of a
     // Rayleigh-Ritz step, and their flat spectrum keeps C^8 R well conditioned — 8 products per step need 5 steps where 3
@@ -1251,10 +1267,10 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
         long long *d_it = dbg_iters ? (long long *)ws.alloc((size_t)B * 64) : nullptr;
         if (l <= 32)
             hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol);
         else
             hipLaunchKernelGGL(pld_topk_eig_kernel<4>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol);
         if (d_it) {
             std::vector<long long> hit((size_t)B * 8);
             LK_HIP_CHECK(hipMemcpyAsync(hit.data(), d_it, (size_t)B * 64, hipMemcpyDeviceToHost, stream));
@@ -1286,7 +1302,7 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
         const size_t lds = two_pass ? ((size_t)l * ld + 2 * l + nt_eig + 2 * l + (l + 1) / 2 + 1) * 8 + 64
                                     : ((size_t)2 * l * ld + 2 * l + 1024 + 2 * l + (l + 1) / 2 + 1) * 8 + 64;
         hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_eig), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                           (long long *)nullptr, 400, status, cheb_on, PLD_KC, mirror ? 1 : 0);
+                           (long long *)nullptr, 400, status, cheb_on, PLD_KC, mirror ? 1 : 0, eig_tol);
     }
     *V_out = V;
     *lam_out = lam;
@@ -1431,17 +1447,21 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
     }
     {
         const size_t lds = (size_t)2 * MG_CH * (k1 | 1) * 8;
-#define LK_MG(O)                                                                                                        \
+#define LK_MG(O, PRE, KS)                                                                                                     \
     do {                                                                                                                \
         if (pl.nfull > 0)                                                                                               \
-            hipLaunchKernelGGL((pld_moment_gram_kernel<O, true>), dim3((pl.nfull + 3) / 4, B), dim3(256), lds, stream, X, K, \
+            hipLaunchKernelGGL((pld_moment_gram_kernel<O, true, PRE, KS>), dim3((pl.nfull + 3) / 4, B), dim3(256), lds, stream, X, K, \
                                col1, k1, N, Pc, pl.ldm, pl.d_rcomb, pl.d_comb, pl.d_wt, pl.nfull, Mcan);                \
         if (pl.nwt > pl.nfull)                                                                                          \
-            hipLaunchKernelGGL((pld_moment_gram_kernel<O, false>), dim3((pl.nwt - pl.nfull + 3) / 4, B), dim3(256), lds,    \
+            hipLaunchKernelGGL((pld_moment_gram_kernel<O, false, PRE, KS>), dim3((pl.nwt - pl.nfull + 3) / 4, B), dim3(256), lds,    \
                                stream, X, K, col1, k1, N, Pc, pl.ldm, pl.d_rcomb, pl.d_comb, pl.d_wt + pl.nfull,        \
                                pl.nwt - pl.nfull, Mcan);                                                                \
     } while (0)
-        if (o == 2) LK_MG(2); else if (o == 3) LK_MG(3); else LK_MG(4);
+        if (k1 <= 16) {
+            if (o == 2) LK_MG(2, 4, 0); else if (o == 3) LK_MG(3, 4, 0); else LK_MG(4, 4, 0);
+        } else {
+            if (o == 2) LK_MG(2, 12, 0); else if (o == 3) LK_MG(3, 12, 0); else LK_MG(4, 12, 0);
+        }
 #undef LK_MG
     }
     hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * Pc + 255) / 256, B), dim3(256), 0, stream, Mcan,
