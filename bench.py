@@ -196,6 +196,27 @@ def strong_bounds(args, world):
 
 
 # ------------------------------------------------------------------------------------------------ reference runs
+def _moment_tiles(k, order):
+    """Number of 16 x 16 MFMA tiles pld_moment_gram_kernel computes per cadence step for the order-`order` products of k
+    components (same construction as lightkurve_amd/csrc/pld.hip: moment_plan): rows ordered by largest factor, columns in
+    lexicographic order, wave tiles of 4 x 4 tiles masked to those that hold a canonical (max(row) <= min(col)) pair."""
+    import itertools
+    cols = list(itertools.combinations_with_replacement(range(k), order))
+    pc = len(cols)
+    rperm = sorted(range(pc), key=lambda i: (cols[i][-1], i))
+    colstart = [sum(1 for c in cols if c[0] < m) for m in range(k + 2)]
+    tiles = 0
+    for r0 in range(0, pc, 64):
+        rt = [min((cols[x][-1] for x in rperm[r0 + 16 * i:r0 + 16 * i + 16]), default=None) for i in range(4)]
+        mn = min(x for x in rt if x is not None)
+        for cg in range((colstart[mn] // 16) * 16, pc, 64):
+            for i in range(4):
+                for j in range(4):
+                    if rt[i] is not None and cg + 16 * j < pc and cg + 16 * j + 16 > colstart[rt[i]]:
+                        tiles += 1
+    return tiles
+
+
 def reference_suite(args, want_ls, want_bls, want_flatten=False):
     """Run astropy itself (the reference's numerical dependency) on the first targets of the bench batches, before
     torch/HIP is initialised: returns the suite's result dict (rates + per-target maxima), or None when the conda
@@ -647,20 +668,26 @@ def main():
                                            "cadences, order 3, 16 components" % (len(kept), Nc),
                               "corrected_flux_relerr_max": max(relerr),
                               "outlier_masks_equal": "%d/%d" % (sum(int(np.array_equal(outl[i], kept[i][1])) for i in range(len(kept))), len(kept))}
-        gram_cols = [P, 136, 816, P]
-        # MFMA flop actually executed: the Gram kernels build the UPPER TRIANGLE only — N*P*(P+1) per PCA Gram, and
-        # N*(K+1)*(K+2) for ONE regression Gram (the clip loop stops at its fixed point: passes that would repeat the same
-        # fit are not executed, so they are not counted either)
-        flop = float(Bc) * (Nc * sum(c * (c + 1) for c in gram_cols) + Nc * (K + 1) * (K + 2))
+        # MFMA flop actually EXECUTED per cutout.  Pixel and background blocks (121 columns): upper-triangle Gram,
+        # N*P*(P+1).  Product blocks (136 and 816 columns): the moment-form Gram computes only the canonical staircase of
+        # the 4th / 6th moments in whole 16 x 16 tiles (pld.hip: pld_moment_gram_kernel) — 512 flop per tile and cadence.
+        # Regression: N*(K+1)*(K+2) for ONE Gram (the clip loop stops at its fixed point; repeated passes are not executed).
+        tiles2, tiles3 = _moment_tiles(16, 2), _moment_tiles(16, 3)
+        flop = float(Bc) * Nc * (2 * P * (P + 1) + 512 * (tiles2 + tiles3) + (K + 1) * (K + 2))
+        flop_plain = float(Bc) * Nc * (sum(c * (c + 1) for c in (P, 136, 816, P)) + (K + 1) * (K + 2))
         ach = flop / (kms * 1e-3) / 1e12
         rl = {"bound": "mfma", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
               "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("pld"),
-              "kernel": "gram128_kernel + gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kms,
-              "mfma_busy_gram128": traffic_all.get("pld_gram128_mfma_busy"),
-              "note": "useful (upper-triangle) Gram flop — N*P*(P+1) per PCA Gram (P = 121, 136, 816, 121) + N*(K+1)*(K+2) "
-                      "for the regression — over the WHOLE step time (eigen-solver, projections, LU, clipping included) "
-                      "against the fp64 MFMA dense peak.  mfma_busy_gram128: SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles of the "
-                      "816-column Gram kernel alone (profiles/, separate --pmc pass; not re-measured in this run)"}
+              "kernel": "pld_moment_gram_kernel + gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kms,
+              "executed_gram_flop_per_step": flop, "plain_gram_flop_per_step": flop_plain,
+              "frac_plain_gram_equivalent": flop_plain / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+              "note": "Gram flop EXECUTED on the matrix cores — N*P*(P+1) for the two 121-column blocks, 512 flop per "
+                      "16x16 tile and cadence of the moment-form staircase for the 136- and 816-column product blocks "
+                      "(%d + %d tiles instead of the 9316 + 333336 upper-triangle entries: the multiset symmetry of the "
+                      "product columns), N*(K+1)*(K+2) for the regression — over the WHOLE step time (eigen-solver, "
+                      "projections, LU, clipping included) against the fp64 MFMA dense peak.  frac_plain_gram_equivalent: "
+                      "the same time priced with the flop of plain upper-triangle Grams (round 2's count), for comparison "
+                      "across rounds only" % (tiles2, tiles3)}
         return {"dt": dt, "kernel_ms": kms, "units_per_step": Bc, "steps": steps, "warmup": warmup,
                 "metric": "PLD cutouts/sec (design matrix + regression)", "unit": "cutouts/sec",
                 "workload": "configs[4]: %d K2-like 11x11-pixel cutouts x %d cadences, 3rd-order design matrix (K=%d), "
