@@ -229,24 +229,28 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     {
         auto val = [&](int i) { return flux[i]; };
         auto notnan = [&](int i) { return !isnan(flux[i]); };
+        // count, sum and sum of squares in ONE sweep, about a shift taken from the first finite sample (the variance of
+        // the shifted data is the variance; with the shift inside the data's range the subtraction below cancels nothing
+        // that matters: relative error ~ eps (1 + (mean - shift)^2 / var))
+        double shift = 0.0;
+        for (int i = 0; i < min(N, 8); ++i)
+            if (isfinite(flux[i])) {
+                shift = flux[i];
+                break;
+            }
         long long c = 0;
-        double part = 0.0;
+        double part = 0.0, part2 = 0.0;
         strided_pass<8>(N, val, [&](int, double f) {
             if (!isnan(f)) {
+                const double d = f - shift;
                 ++c;
-                part += f;
+                part += d;
+                part2 = fma(d, d, part2);
             }
         });
         const long long cnt = block_count_fast(c, shl);
-        const double mean = block_sum_fast(part, shd) / (double)cnt;
-        part = 0.0;
-        strided_pass<8>(N, val, [&](int, double f) {
-            if (!isnan(f)) {
-                const double d = f - mean;
-                part = fma(d, d, part);
-            }
-        });
-        const double sd = sqrt(block_sum_fast(part, shd) / (double)cnt);
+        const double s1 = block_sum_fast(part, shd), s2 = block_sum_fast(part2, shd);
+        const double sd = sqrt(fmax(0.0, (s2 - s1 * s1 / (double)cnt) / (double)cnt));
         __syncthreads();
         lap(0);
         const double med = block_median_sampled(N, cnt, val, notnan, sh, fir, FIR_LDS, (stop_at >= 100 && stop_at < 200) ? stop_at - 100 : -1);
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     double dmed_prev = qnan, dspacing = 0.0;  // previous iteration's median dt and the mean gap between dt values around it
     int nm_prev = 0;
     int removed_any = 1;
+    int t_nan = 1;  // may a kept cadence have a NaN time?  Settled by the first compaction (the mask only shrinks)
     for (int it = 0; it < niters; ++it) {
         const bool last = it == niters - 1;
         lap_iter = it;
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             }
             nm = total;
             lap(3);
+            bool saw_nan = false;
             for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
                 bool m[4];
                 double tv[4], fv[4];
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                     m[u] = in && mask[k] != 0;
                     tv[u] = in ? t[k] : 0.0;
                     fv[u] = in ? flux[k] : 0.0;
+                    saw_nan |= m[u] && isnan(tv[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -311,7 +318,8 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                     base += __popcll(bal);
                 }
             }
-            __syncthreads();
+            if (it == 0) t_nan = __syncthreads_or(saw_nan ? 1 : 0);
+            else __syncthreads();
         }
         lap(4);
         if (nm == 0) {
@@ -324,10 +332,13 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         if (nm >= 2) {
             auto dval = [&](int i) { return tm[i + 1] - tm[i]; };
             auto dkeep = [&](int i) { return !isnan(tm[i + 1] - tm[i]); };
-            long long c = 0;
-            strided_pass<8>(nm - 1, dval, [&](int, double d) { c += isnan(d) ? 0 : 1; });
-            const long long cnt = block_count_fast(c, shl);
-            __syncthreads();
+            long long cnt = (long long)(nm - 1);  // no NaN among the kept times: every gap counts, no sweep needed
+            if (t_nan) {
+                long long c = 0;
+                strided_pass<8>(nm - 1, dval, [&](int, double d) { c += isnan(d) ? 0 : 1; });
+                cnt = block_count_fast(c, shl);
+                __syncthreads();
+            }
             lap(5);
             // Later iterations: the dt's are the previous iteration's minus the few clipped cadences (each removes two
             // gaps and adds their sum), so the median moved by at most ~3 ranks per clipped cadence — look for it within
@@ -349,7 +360,16 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         const int nseg = strip_compact(
             nm, [&](int i) { return i == 0 || (tm[i] - tm[i - 1]) > thr; }, segs, shi);
         lap(7);
-        // ---- per segment: median for short ones, Savitzky-Golay otherwise   (:1030-1046)
+        // ---- per segment: median for short ones, Savitzky-Golay otherwise   (:1030-1046).  Every kept cadence gets its
+        // trend exactly once here; its residual goes into the two running sums of the clip right away (rs1, rs2), which
+        // spares the clip its two sweeps over flux and trend.
+        double rs1 = 0.0, rs2 = 0.0;
+        auto put = [&](int i, double v) {
+            tr[i] = v;
+            const double r = fm[i] - v;
+            rs1 += r;
+            rs2 = fma(r, r, rs2);
+        };
         for (int sg = 0; sg < nseg; ++sg) {
             const int l = segs[sg], h = (sg + 1 < nseg) ? segs[sg + 1] : nm;
             const int len = h - l;
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                 auto keep = [&](int i) { return true; };  // masked flux is finite
                 __syncthreads();
                 const double med = block_median_sampled(len, (long long)len, val, keep, sh, fir, FIR_LDS);
-                for (int i = l + tid; i < h; i += nt) tr[i] = med;
+                for (int i = l + tid; i < h; i += nt) put(i, med);
             } else {
                 // interior: correlate with the taps (window fully inside the segment)
                 const int o_lo = l + half, o_hi = h - half;  // outputs [o_lo, o_hi)
@@ -389,11 +409,26 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                         const int CH = (ni + nt - 1) / nt;
                         const int e0 = min(ni, tid * CH), e1 = min(ni, e0 + CH);
                         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                        for (int e = e0; e < e1; ++e) {
-                            const double yv = x[e], u = (double)e - uc;
-                            s0 += yv;
-                            s1 = fma(u, yv, s1);
-                            s2 = fma(u * u, yv, s2);
+                        double xr[4] = {0.0, 0.0, 0.0, 0.0};  // CH <= 4: the thread's inputs stay in registers for the second sweep
+                        if (CH <= 4) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (e0 + q < e1) xr[q] = x[e0 + q];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (e0 + q < e1) {
+                                    const double yv = xr[q], u = (double)(e0 + q) - uc;
+                                    s0 += yv;
+                                    s1 = fma(u, yv, s1);
+                                    s2 = fma(u * u, yv, s2);
+                                }
+                        } else {
+                            for (int e = e0; e < e1; ++e) {
+                                const double yv = x[e], u = (double)e - uc;
+                                s0 += yv;
+                                s1 = fma(u, yv, s1);
+                                s2 = fma(u * u, yv, s2);
+                            }
                         }
                         double i0 = s0, i1 = s1, i2 = s2;  // inclusive scan over the wave, then over the waves
                         for (int off = 1; off < 64; off <<= 1) {
@@ -425,14 +460,29 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                                 r2 += x2;
                             }
                         }
-                        for (int e = e0; e < e1; ++e) {
-                            const double yv = x[e], u = (double)e - uc;
-                            r0 += yv;
-                            r1 = fma(u, yv, r1);
-                            r2 = fma(u * u, yv, r2);
-                            p0[e] = r0;
-                            p1[e] = r1;
-                            p2[e] = r2;
+                        if (CH <= 4) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (e0 + q < e1) {
+                                    const int e = e0 + q;
+                                    const double yv = xr[q], u = (double)e - uc;
+                                    r0 += yv;
+                                    r1 = fma(u, yv, r1);
+                                    r2 = fma(u * u, yv, r2);
+                                    p0[e] = r0;
+                                    p1[e] = r1;
+                                    p2[e] = r2;
+                                }
+                        } else {
+                            for (int e = e0; e < e1; ++e) {
+                                const double yv = x[e], u = (double)e - uc;
+                                r0 += yv;
+                                r1 = fma(u, yv, r1);
+                                r2 = fma(u * u, yv, r2);
+                                p0[e] = r0;
+                                p1[e] = r1;
+                                p2[e] = r2;
+                            }
                         }
                         __syncthreads();
                         for (int q = tid; q < no; q += nt) {
@@ -445,7 +495,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                             }
                             const double v = (double)(q + half) - uc;
                             const double m2 = fma(v, fma(v, w0, -2.0 * w1), w2);  // sum (u - v)^2 y
-                            tr[o0 + q] = fma(quad_b, m2, quad_a * w0);
+                            put(o0 + q, fma(quad_b, m2, quad_a * w0));
                         }
                     }
                 } else if (TO >= FP) {
@@ -485,7 +535,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                             }
 #pragma unroll
                             for (int r = 0; r < FP; ++r)
-                                if (FP * q + r < no) tr[o0 + FP * q + r] = acc[r];
+                                if (FP * q + r < no) put(o0 + FP * q + r, acc[r]);
                         }
                     }
                 } else {
@@ -493,7 +543,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                         const double *x = fm + (i - half);
                         double acc = 0.0;
                         for (int j = 0; j < window; ++j) acc = fma(coeffs[j], x[j], acc);
-                        tr[i] = acc;
+                        put(i, acc);
                     }
                 }
                 // edges: polynomial refit of the first / last `window` samples (mode='interp').  The two windows are
@@ -538,7 +588,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                             for (int b = 0; b < np1; ++b) beta = fma(edge_minv[a * np1 + b], mom[side * np1 + b], beta);
                             acc = fma(acc, u, beta);
                         }
-                        tr[side ? (h - half + r) : (l + r)] = acc;
+                        put(side ? (h - half + r) : (l + r), acc);
                     }
                 } else {
                 for (int e = tid; e < 2 * half; e += nt) {
@@ -555,7 +605,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                         for (int u = 0; u < 8; ++u) acc = fma(ev[u], x[j + u], acc);
                     }
                     for (; j < window; ++j) acc = fma(E[(size_t)j * half], x[j], acc);
-                    tr[side ? (h - half + r) : (l + r)] = acc;
+                    put(side ? (h - half + r) : (l + r), acc);
                 }
                 }
             }
@@ -565,15 +615,9 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         {
             lap(8);
             auto resid = [&](int i) { return fm[i] - tr[i]; };
-            double part = 0.0;
-            strided_pass<8>(nm, resid, [&](int, double r) { part += r; });
-            const double mean = block_sum_fast(part, shd) / (double)nm;
-            part = 0.0;
-            strided_pass<8>(nm, resid, [&](int, double r) {
-                const double d = r - mean;
-                part = fma(d, d, part);
-            });
-            const double sd = sqrt(block_sum_fast(part, shd) / (double)nm);
+            // nanstd of the residuals from the sums gathered above (mean ~ 0: nothing cancels in s2 - s1^2 / n)
+            const double s1 = block_sum_fast(rs1, shd), s2 = block_sum_fast(rs2, shd);
+            const double sd = sqrt(fmax(0.0, (s2 - s1 * s1 / (double)nm) / (double)nm));
             const double lim = sd * sigma + 1e-14;
             // mask1, and mask[mask] &= mask1 (:1060-1063) in the same sweep
             int removed = 0;
