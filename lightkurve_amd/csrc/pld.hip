@@ -340,38 +340,52 @@ __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__
     G[(size_t)b * ldg * ldg + (size_t)i * ldg + j] = Mcan[(size_t)b * mstride + src[e]] - Nd * mb[i] * mb[j];
 }
 
+// mv[b][a] = sum_p mean[b][p] V[b][p][a]: the projection of the column means, subtracted from every cadence by the
+// projection kernel below (one workgroup per cutout; inside the projection kernel this was a 204-step dependent chain
+// of global loads in front of every workgroup's MFMA loop)
+__global__ __launch_bounds__(256) void pld_mean_proj_kernel(const double *__restrict__ mean, const double *__restrict__ V,
+                                                             int Pc, int kk, double *__restrict__ mv) {
+    __shared__ double red[4][64];
+    const int b = blockIdx.x, a = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const double *Vb = V + (size_t)b * Pc * kk, *mb = mean + (size_t)b * Pc;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the loads of 16 steps are in flight together
+    if (a < kk) {
+        int p = sl;
+        for (; p + 12 < Pc; p += 16) {
+            s0 = fma(mb[p], Vb[(size_t)p * kk + a], s0);
+            s1 = fma(mb[p + 4], Vb[(size_t)(p + 4) * kk + a], s1);
+            s2 = fma(mb[p + 8], Vb[(size_t)(p + 8) * kk + a], s2);
+            s3 = fma(mb[p + 12], Vb[(size_t)(p + 12) * kk + a], s3);
+        }
+        for (; p < Pc; p += 4) s0 = fma(mb[p], Vb[(size_t)p * kk + a], s0);
+    }
+    red[sl][a] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < 64 && a < kk) mv[(size_t)b * kk + a] = ((red[0][a] + red[1][a]) + red[2][a]) + red[3][a];
+}
+
 // U = (products - mean) V diag(lam)^-1/2 into X[:, col0 : col0 + kk] with the products generated on the fly from the
 // first-order components (X[:, col1 : col1 + k1]).  One wave = 16 cadences; the summation index of an MFMA step is the
 // product column p = p0 + (lane >> 4), its factor tuple one packed dword of LDS.
 template <int O, int KT>
 __global__ __launch_bounds__(256) void pld_project_products_kernel(const double *__restrict__ Xin, int ldx, int col1, int k1,
                                                                     int N, int Pc, const uint32_t *__restrict__ packed,
-                                                                    const double *__restrict__ mean,
+                                                                    const double *__restrict__ mvg,
                                                                     const double *__restrict__ V,
                                                                     const double *__restrict__ lam, int kk, int col0,
                                                                     double *__restrict__ Xout) {
-    extern __shared__ __attribute__((aligned(16))) double pp_lds[];  // us[64][ks] | mv[64] | red[4][64] | tup[Pc] (dwords)
+    extern __shared__ __attribute__((aligned(16))) double pp_lds[];  // us[64][ks] | tup[Pc] (dwords)
     const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
     const int ks = k1 | 1;
-    double *us = pp_lds, *mv = us + 64 * ks, *red = mv + 64;
-    uint32_t *tup = reinterpret_cast<uint32_t *>(red + 256);
+    double *us = pp_lds;
+    uint32_t *tup = reinterpret_cast<uint32_t *>(us + 64 * ks);
     const int nb = blockIdx.x * 64;
     for (int e = tid; e < 64 * k1; e += 256) {
         const int r = e / k1, c = e - r * k1;
         us[r * ks + c] = nb + r < N ? Xin[((size_t)b * N + nb + r) * ldx + col1 + c] : 0.0;
     }
     for (int e = tid; e < Pc; e += 256) tup[e] = packed[e];
-    const double *Vb = V + (size_t)b * Pc * kk, *mb = mean + (size_t)b * Pc;
-    {
-        // mv[a] = sum_p mean[p] V[p][a]: the projection of the column means, subtracted from every cadence below
-        const int a = tid & 63, sl = tid >> 6;
-        double sm = 0.0;
-        if (a < kk)
-            for (int p = sl; p < Pc; p += 4) sm = fma(mb[p], Vb[(size_t)p * kk + a], sm);
-        red[sl * 64 + a] = sm;
-    }
-    __syncthreads();
-    if (tid < 64) mv[tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+    const double *Vb = V + (size_t)b * Pc * kk, *mv = mvg + (size_t)b * kk;
     __syncthreads();
     const int n0 = nb + wave * 16;
     if (n0 >= N) return;
@@ -1470,11 +1484,17 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
     const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws);
     if (rc) return rc;
     {
-        const size_t lds = (size_t)(64 * (k1 | 1) + 64 + 256) * 8 + (size_t)Pc * 4;
+        const size_t lds = (size_t)(64 * (k1 | 1)) * 8 + (size_t)Pc * 4;
         const dim3 grid((N + 63) / 64, B);
         const int kt = (ko + 15) / 16;
+        double *d_mv = (double *)ws.alloc((size_t)B * ko * 8);
+        if (!d_mv) {
+            set_error("PLD workspace exhausted (mean projection)");
+            return LK_ENOMEM;
+        }
+        hipLaunchKernelGGL(pld_mean_proj_kernel, dim3(B), dim3(256), 0, stream, d_mean, V, Pc, ko, d_mv);
 #define LK_PP(O, KT) hipLaunchKernelGGL((pld_project_products_kernel<O, KT>), grid, dim3(256), lds, stream, X, K, col1, k1, N, Pc, \
-                                        pl.d_packed, d_mean, V, lam, ko, col0, X)
+                                        pl.d_packed, d_mv, V, lam, ko, col0, X)
 #define LK_PPO(O) do { if (kt <= 1) LK_PP(O, 1); else if (kt == 2) LK_PP(O, 2); else LK_PP(O, 3); } while (0)
         if (o == 2) LK_PPO(2); else if (o == 3) LK_PPO(3); else LK_PPO(4);
 #undef LK_PPO
