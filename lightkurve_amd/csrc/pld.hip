@@ -194,7 +194,8 @@ constexpr int kMomentMinCols = 100;  // product blocks at least this wide take t
 template <int O, bool FULL, int PRE, int KS>  // KS: LDS row stride (k | 1) when known at compile time, else 0; PRE: MG_CH * k / 256 elements of the next stage wait in registers (4: k <= 16, 12: k <= 48)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pld_moment_gram_kernel(
     const double *__restrict__ X, int ldx, int col0, int k, int N, int Pc, int ldm, const uint8_t *__restrict__ rcomb,
-    const uint8_t *__restrict__ comb, const int4 *__restrict__ wt, int nwt, double *__restrict__ Mcan) {
+    const uint8_t *__restrict__ comb, const int4 *__restrict__ wt, int nwt, double *__restrict__ Mcan,
+    const int *__restrict__ rperm, double *__restrict__ mean) {
     extern __shared__ __attribute__((aligned(16))) double mg_us[];  // 2 x MG_CH x ks
     const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
     const int ks = KS > 0 ? KS : (k | 1);
@@ -202,6 +203,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int4 t = wt[min(w, nwt - 1)];
     const int r0 = t.x, c0 = t.y;
     const unsigned mask = w < nwt ? (unsigned)t.z : 0u;
+    // bit i: this wave tile is the one that also sums the products of row tile i over the cadences (their column means:
+    // every (row, cadence) pair passes through exactly one lane of the A operand)
+    const unsigned mflag = (!FULL && w < nwt) ? (unsigned)t.w : 0u;  // (the host keeps such wave tiles out of the FULL launch)
+    double msum[4] = {0.0, 0.0, 0.0, 0.0};
     // rows / columns past the end are clamped, not zeroed: their accumulator entries are simply never stored
     int ia[4][O], ib[4][O];
 #pragma unroll
@@ -304,12 +309,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int j = 0; j < 4; ++j)
                     if (FULL || (mask & (1u << (4 * i + j))))
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+            if (!FULL && mflag) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (mflag & (1u << i)) msum[i] += av[i];
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (sst + 1 < MG_CH / 4) multiply();
         }
         if (more) park(mg_us + (cur ^ 1) * MG_CH * ks);
         __syncthreads();
         cur ^= 1;
+    }
+    if (!FULL && mflag) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (mflag & (1u << i)) {
+                double m = msum[i];
+                m += __shfl_xor(m, 16);
+                m += __shfl_xor(m, 32);
+                const int r = r0 + 16 * i + lr;
+                if (lq == 0 && r < Pc) mean[(size_t)b * Pc + rperm[r]] = m / (double)N;
+            }
     }
     double *Mb = Mcan + (size_t)b * ldm * ldm;
 #pragma unroll
@@ -393,22 +414,25 @@ __global__ __launch_bounds__(256) void pld_project_products_kernel(const double 
     pld_d4 acc[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) acc[c] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    // Out-of-range columns are handled by CLAMPED unconditional loads times a 0 / 1 factor: a guarded load ends up behind a
+    // branch with a full s_waitcnt right after it, one L2 round trip per MFMA (all operands are finite).
+    double cflag[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) cflag[c] = c * 16 + lr < kk ? 1.0 : 0.0;
     for (int p0 = 0; p0 < Pc; p0 += 16) {
         double prod[4], bv[4][KT];
+        uint32_t tp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tp[q] = tup[min(p0 + 4 * q + lq, Pc - 1)];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = p0 + 4 * q + lq, pc = min(p, Pc - 1);
-            const uint32_t tp = tup[pc];
-            double pr = row[tp & 255u];
+            double pr = row[tp[q] & 255u];
 #pragma unroll
-            for (int pos = 1; pos < O; ++pos) pr *= row[(tp >> (8 * pos)) & 255u];
-            prod[q] = p < Pc ? pr : 0.0;
+            for (int pos = 1; pos < O; ++pos) pr *= row[(tp[q] >> (8 * pos)) & 255u];
+            prod[q] = pr * (p < Pc ? 1.0 : 0.0);
 #pragma unroll
-            for (int c = 0; c < KT; ++c) {
-                const int col = c * 16 + lr;
-                const double vraw = Vb[(size_t)pc * kk + min(col, kk - 1)];
-                bv[q][c] = (p < Pc && col < kk) ? vraw : 0.0;
-            }
+            for (int c = 0; c < KT; ++c) bv[q][c] = Vb[(size_t)pc * kk + min(c * 16 + lr, kk - 1)] * cflag[c];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -1363,6 +1387,7 @@ struct MomentPlan {
     int4 *d_wt;                 // wave tiles: first row (row order), first column, mask of the 16 x 16 tiles to compute
     uint32_t *d_src;            // [Pc][Pc]: where the moment of columns (i, j) sits in the canonical array
     uint32_t *d_packed;         // natural-order tuples, one dword each (projection kernel)
+    int *d_rperm;               // row order -> natural index
 };
 
 static const MomentPlan *moment_plan(lk_handle *h, int k, int o, const std::vector<uint8_t> &comb, int Pc) {
@@ -1427,19 +1452,33 @@ static const MomentPlan *moment_plan(lk_handle *h, int k, int o, const std::vect
     }
     // waves of a workgroup wait for each other at every stage: put tiles of similar size together
     std::stable_sort(wt.begin(), wt.end(), [](const int4 &a, const int4 &b2) { return __builtin_popcount(a.z) > __builtin_popcount(b2.z); });
+    {   // column means: one wave tile that generates row tile (r0, i) also sums it — a masked one where there is a choice
+        // (the FULL body has no registers to spare), and a full one that has to do it moves to the masked launch
+        std::vector<char> done((size_t)(Pc + 15) / 16, 0);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int4 &w4 : wt)
+                for (int i = 0; i < 4; ++i) {
+                    const int rt_ = w4.x / 16 + i;
+                    if ((pass == 1 || w4.z != 0xffff) && (w4.z & (0xf << (4 * i))) && rt_ < (int)done.size() && !done[rt_]) {
+                        done[rt_] = 1;
+                        w4.w |= 1 << i;
+                    }
+                }
+        std::stable_partition(wt.begin(), wt.end(), [](const int4 &a) { return a.z == 0xffff && a.w == 0; });
+    }
     std::vector<uint8_t> rcomb((size_t)Pc * o);
     for (int r = 0; r < Pc; ++r)
         for (int pos = 0; pos < o; ++pos) rcomb[(size_t)r * o + pos] = (uint8_t)tup(rperm[r], pos);
     int nfull = 0;
-    while (nfull < (int)wt.size() && wt[nfull].z == 0xffff) ++nfull;
-    MomentPlan *pl = new MomentPlan{h->device, k, o, Pc, ldm, (int)wt.size(), nfull, nullptr, nullptr, nullptr, nullptr, nullptr};
+    while (nfull < (int)wt.size() && wt[nfull].z == 0xffff && wt[nfull].w == 0) ++nfull;
+    MomentPlan *pl = new MomentPlan{h->device, k, o, Pc, ldm, (int)wt.size(), nfull, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     auto up = [&](void **d, const void *src_, size_t bytes) {
         if (hipMalloc(d, bytes) != hipSuccess) return false;
         return hipMemcpy(*d, src_, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
     const bool ok = up((void **)&pl->d_comb, comb.data(), comb.size()) && up((void **)&pl->d_rcomb, rcomb.data(), rcomb.size()) &&
                     up((void **)&pl->d_wt, wt.data(), wt.size() * sizeof(int4)) && up((void **)&pl->d_src, src.data(), src.size() * 4) &&
-                    up((void **)&pl->d_packed, packed.data(), packed.size() * 4);
+                    up((void **)&pl->d_packed, packed.data(), packed.size() * 4) && up((void **)&pl->d_rperm, rperm.data(), rperm.size() * 4);
     if (!ok) {
         set_error("PLD: could not allocate the moment-Gram tables");
         delete pl;
@@ -1452,7 +1491,7 @@ static const MomentPlan *moment_plan(lk_handle *h, int k, int o, const std::vect
 // PCA of an order-o product block without materialising it: moment-form Gram -> eigenpairs -> projection generated on
 // the fly.  Mcan: scratch of B * ldm * ldm doubles.
 static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N, int k1, int ko, double *X, int K, int col1,
-                               int col0, const double *d_mean, double *Mcan, hipStream_t stream, Arena &ws) {
+                               int col0, double *d_mean, double *Mcan, hipStream_t stream, Arena &ws) {
     const int Pc = pl.Pc, o = pl.order, ldg = ((Pc + 63) / 64) * 64;
     double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
     if (!G) {
@@ -1465,11 +1504,11 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
     do {                                                                                                                \
         if (pl.nfull > 0)                                                                                               \
             hipLaunchKernelGGL((pld_moment_gram_kernel<O, true, PRE, KS>), dim3((pl.nfull + 3) / 4, B), dim3(256), lds, stream, X, K, \
-                               col1, k1, N, Pc, pl.ldm, pl.d_rcomb, pl.d_comb, pl.d_wt, pl.nfull, Mcan);                \
+                               col1, k1, N, Pc, pl.ldm, pl.d_rcomb, pl.d_comb, pl.d_wt, pl.nfull, Mcan, pl.d_rperm, d_mean); \
         if (pl.nwt > pl.nfull)                                                                                          \
             hipLaunchKernelGGL((pld_moment_gram_kernel<O, false, PRE, KS>), dim3((pl.nwt - pl.nfull + 3) / 4, B), dim3(256), lds,    \
                                stream, X, K, col1, k1, N, Pc, pl.ldm, pl.d_rcomb, pl.d_comb, pl.d_wt + pl.nfull,        \
-                               pl.nwt - pl.nfull, Mcan);                                                                \
+                               pl.nwt - pl.nfull, Mcan, pl.d_rperm, d_mean);                                           \
     } while (0)
         if (k1 <= 16) {
             if (o == 2) LK_MG(2, 4, 0); else if (o == 3) LK_MG(3, 4, 0); else LK_MG(4, 4, 0);
@@ -1567,11 +1606,13 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
             }
             LK_HIP_CHECK(hipMemcpyAsync(d_comb, comb.data(), comb.size(), hipMemcpyHostToDevice, stream));
             LK_HIP_CHECK(hipStreamSynchronize(stream));  // comb dies at the end of this iteration
-            hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(1024), 0, stream, X, K, col1, k1, o,
-                               N, Pc, d_comb, d_mean);
-            // wide product blocks: moment-form Gram, the products are never materialised (A serves as its scratch)
+            // wide product blocks: moment-form Gram, the products are never materialised (A serves as its scratch) and their
+            // column means come out of the Gram kernel
             const int ldm = ((Pc + 63) / 64) * 64;
             const bool moment = Pc >= kMomentMinCols && k1 <= 48 && (size_t)ldm * ldm <= (size_t)N * pmax;
+            if (!moment)
+                hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(1024), 0, stream, X, K, col1, k1, o,
+                                   N, Pc, d_comb, d_mean);
             if (moment) {
                 const MomentPlan *pl = moment_plan(h, k1, o, comb, Pc);
                 if (!pl) return LK_ENOMEM;
