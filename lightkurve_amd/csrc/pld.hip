@@ -57,7 +57,8 @@ int pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_kno
 // out[b][n][p] = (double)( pix[b][n][p] / div[b][n] ) with the division in float32 like numpy's float32 / float32;
 // div = SAP flux (PLD pixels) or the float32 row sum of the background pixels (normalize) or 1.
 __global__ __launch_bounds__(256) void pld_ratio_kernel(const float *__restrict__ pix, const float *__restrict__ lc,
-                                                         int mode, int N, int P, double *__restrict__ out) {
+                                                         int mode, int N, int P, double *__restrict__ out,
+                                                         const double *__restrict__ colmean) {
     constexpr int ROWS = 32;  // cadences per workgroup: 32 x P contiguous floats in, 32 x P contiguous doubles out
     __shared__ float div[ROWS];
     const int b = blockIdx.y, n0 = blockIdx.x * ROWS, tid = threadIdx.x;
@@ -81,9 +82,80 @@ __global__ __launch_bounds__(256) void pld_ratio_kernel(const float *__restrict_
     }
     __syncthreads();
     const size_t base = ((size_t)b * N + n0) * P;
-    for (int e = tid; e < nr * P; e += 256) {
-        const float v = pix[base + e];
-        out[base + e] = (double)(mode == 0 ? v : v / div[e / P]);
+    const double *cm = colmean ? colmean + (size_t)b * P : nullptr;  // column means (pld_colmean_kernel): write A centred
+    // two row phases x 128 columns: no integer division per element, a thread's column mean loaded once per column chunk
+    const int cx = tid & 127, ry = tid >> 7;
+    for (int c0 = 0; c0 < P; c0 += 128) {
+        const int c = c0 + cx;
+        if (c >= P) continue;
+        const double m = cm ? cm[c] : 0.0;
+        for (int r = ry; r < nr; r += 2) {
+            const float v = pix[base + (size_t)r * P + c];
+            const double q = (double)(mode == 0 ? v : v / div[r]);
+            out[base + (size_t)r * P + c] = cm ? q - m : q;
+        }
+    }
+}
+
+// float32 row sums of the background pixels (the divisor of mode 2 above, same arithmetic), one wave per cadence
+__global__ __launch_bounds__(256) void pld_rowdiv_kernel(const float *__restrict__ pix, int N, int P, float *__restrict__ div) {
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const float *row = pix + ((size_t)b * N + n) * P;
+    double sm = 0.0;
+    for (int p = lane; p < P; p += 64) {
+        const float v = row[p];
+        if (v == v) sm += (double)v;
+    }
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    if (lane == 0) div[(size_t)b * N + n] = (float)sm;
+}
+
+// Column means of the ratio matrix straight from the float32 pixels (one workgroup per cutout), so that pld_ratio_kernel
+// can write A already centred: the centring pass over the float64 matrix (read, read, write: 1.2 ms per block at
+// configs[4]) becomes one read of the float32 input.  Eight row phases per column summed in the order pld_center_kernel
+// uses, the same float32 division: the means, hence A, are bit-identical to the two-pass form.
+__global__ __launch_bounds__(1024) void pld_colmean_kernel(const float *__restrict__ pix, const float *__restrict__ divv,
+                                                            int mode, int N, int P, double *__restrict__ mean) {
+    __shared__ double sh[8][129];
+    const int b = blockIdx.x, cx = threadIdx.x & 127, ry = threadIdx.x >> 7;
+    const float *pb = pix + (size_t)b * N * P;
+    const float *db = divv ? divv + (size_t)b * N : nullptr;
+    for (int c0 = 0; c0 < P; c0 += 128) {
+        const int c = c0 + cx;
+        double s = 0.0;
+        if (c < P) {
+            int n = ry;
+            for (; n + 24 < N; n += 32) {  // four loads in flight
+                const float v0 = pb[(size_t)n * P + c], v1 = pb[(size_t)(n + 8) * P + c], v2 = pb[(size_t)(n + 16) * P + c],
+                            v3 = pb[(size_t)(n + 24) * P + c];
+                if (mode == 0) {
+                    s += (double)v0;
+                    s += (double)v1;
+                    s += (double)v2;
+                    s += (double)v3;
+                } else {
+                    const float d0 = db[n], d1 = db[n + 8], d2 = db[n + 16], d3 = db[n + 24];
+                    s += (double)(v0 / d0);
+                    s += (double)(v1 / d1);
+                    s += (double)(v2 / d2);
+                    s += (double)(v3 / d3);
+                }
+            }
+            for (; n < N; n += 8) {
+                const float v = pb[(size_t)n * P + c];
+                s += (double)(mode == 0 ? v : v / db[n]);
+            }
+        }
+        __syncthreads();
+        sh[ry][cx] = s;
+        __syncthreads();
+        if (ry == 0 && c < P) {
+            double t = 0.0;
+            for (int r = 0; r < 8; ++r) t += sh[r][cx];
+            mean[(size_t)b * P + c] = t / (double)N;
+        }
     }
 }
 
@@ -1576,8 +1648,11 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     const size_t mark = h->ws.used;
     if (k1 > 0) {
         LK_REQUIRE(pld_pix != nullptr, "pld_pix is NULL");
-        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, pld_pix, lc_flux, 1, N, P, A);
-        rc = pca_block(h, A, B, N, P, k1, d_off, X, K, col, stream, h->ws);
+        double *d_cm = (double *)h->ws.alloc((size_t)B * P * 8);
+        LK_REQUIRE(d_cm != nullptr, "PLD workspace exhausted (column means)");
+        hipLaunchKernelGGL(pld_colmean_kernel, dim3(B), dim3(1024), 0, stream, pld_pix, lc_flux, 1, N, P, d_cm);
+        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, pld_pix, lc_flux, 1, N, P, A, d_cm);
+        rc = pca_block(h, A, B, N, P, k1, d_off, X, K, col, stream, h->ws, true);
         if (rc) return rc;
         const int col1 = col;
         col += k1;
@@ -1629,10 +1704,17 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     }
     const int n_pld_cols = col;
     h->ws.used = mark;
-    hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, lc_flux,
-                       normalize_bkg ? 2 : 0, N, Pb, A);
+    {
+        double *d_cm = (double *)h->ws.alloc((size_t)B * Pb * 8);
+        float *d_div = normalize_bkg ? (float *)h->ws.alloc((size_t)B * N * 4) : nullptr;
+        LK_REQUIRE(d_cm != nullptr && (!normalize_bkg || d_div != nullptr), "PLD workspace exhausted (column means)");
+        if (normalize_bkg) hipLaunchKernelGGL(pld_rowdiv_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, bkg_pix, N, Pb, d_div);
+        hipLaunchKernelGGL(pld_colmean_kernel, dim3(B), dim3(1024), 0, stream, bkg_pix, d_div, normalize_bkg ? 2 : 0, N, Pb, d_cm);
+        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, lc_flux,
+                           normalize_bkg ? 2 : 0, N, Pb, A, d_cm);
+    }
     const int kb = std::min(pca_components, Pb);
-    rc = pca_block(h, A, B, N, Pb, kb, d_off, X, K, col, stream, h->ws);
+    rc = pca_block(h, A, B, N, Pb, kb, d_off, X, K, col, stream, h->ws, true);
     if (rc) return rc;
     col += kb;
     hipLaunchKernelGGL(pld_spline_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, time, knots, n_inner,
