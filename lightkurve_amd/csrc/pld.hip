@@ -58,12 +58,15 @@ int pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_kno
 // div = SAP flux (PLD pixels) or the float32 row sum of the background pixels (normalize) or 1.
 __global__ __launch_bounds__(256) void pld_ratio_kernel(const float *__restrict__ pix, const float *__restrict__ lc,
                                                          int mode, int N, int P, double *__restrict__ out,
-                                                         const double *__restrict__ colmean) {
+                                                         const double *__restrict__ colmean,
+                                                         const float *__restrict__ rowdiv) {
     constexpr int ROWS = 32;  // cadences per workgroup: 32 x P contiguous floats in, 32 x P contiguous doubles out
     __shared__ float div[ROWS];
     const int b = blockIdx.y, n0 = blockIdx.x * ROWS, tid = threadIdx.x;
     const int nr = min(ROWS, N - n0);
-    if (mode == 2) {
+    if (mode == 2 && rowdiv) {
+        if (tid < nr) div[tid] = rowdiv[(size_t)b * N + n0 + tid];  // pld_rowdiv_kernel's sums
+    } else if (mode == 2) {
         // np.nansum over the float32 pixels of a cadence (accumulated in double, rounded once: <= 1 ulp(f32) from numpy's
         // pairwise float32 sum).  A wave per cadence, lanes over pixels; the per-lane partials are added in lane order.
         const int wave = tid >> 6, lane = tid & 63;
@@ -100,16 +103,18 @@ __global__ __launch_bounds__(256) void pld_ratio_kernel(const float *__restrict_
 // float32 row sums of the background pixels (the divisor of mode 2 above, same arithmetic), one wave per cadence
 __global__ __launch_bounds__(256) void pld_rowdiv_kernel(const float *__restrict__ pix, int N, int P, float *__restrict__ div) {
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
-    const float *row = pix + ((size_t)b * N + n) * P;
-    double sm = 0.0;
-    for (int p = lane; p < P; p += 64) {
-        const float v = row[p];
-        if (v == v) sm += (double)v;
+    for (int q = 0; q < 8; ++q) {  // 32 cadences per workgroup
+        const int n = blockIdx.x * 32 + q * 4 + wave;
+        if (n >= N) return;
+        const float *row = pix + ((size_t)b * N + n) * P;
+        double sm = 0.0;
+        for (int p = lane; p < P; p += 64) {
+            const float v = row[p];
+            if (v == v) sm += (double)v;
+        }
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        if (lane == 0) div[(size_t)b * N + n] = (float)sm;
     }
-    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-    if (lane == 0) div[(size_t)b * N + n] = (float)sm;
 }
 
 // Column means of the ratio matrix straight from the float32 pixels (one workgroup per cutout), so that pld_ratio_kernel
@@ -1651,7 +1656,7 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
         double *d_cm = (double *)h->ws.alloc((size_t)B * P * 8);
         LK_REQUIRE(d_cm != nullptr, "PLD workspace exhausted (column means)");
         hipLaunchKernelGGL(pld_colmean_kernel, dim3(B), dim3(1024), 0, stream, pld_pix, lc_flux, 1, N, P, d_cm);
-        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, pld_pix, lc_flux, 1, N, P, A, d_cm);
+        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, pld_pix, lc_flux, 1, N, P, A, d_cm, (const float *)nullptr);
         rc = pca_block(h, A, B, N, P, k1, d_off, X, K, col, stream, h->ws, true);
         if (rc) return rc;
         const int col1 = col;
@@ -1708,10 +1713,10 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
         double *d_cm = (double *)h->ws.alloc((size_t)B * Pb * 8);
         float *d_div = normalize_bkg ? (float *)h->ws.alloc((size_t)B * N * 4) : nullptr;
         LK_REQUIRE(d_cm != nullptr && (!normalize_bkg || d_div != nullptr), "PLD workspace exhausted (column means)");
-        if (normalize_bkg) hipLaunchKernelGGL(pld_rowdiv_kernel, dim3((N + 3) / 4, B), dim3(256), 0, stream, bkg_pix, N, Pb, d_div);
+        if (normalize_bkg) hipLaunchKernelGGL(pld_rowdiv_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, N, Pb, d_div);
         hipLaunchKernelGGL(pld_colmean_kernel, dim3(B), dim3(1024), 0, stream, bkg_pix, d_div, normalize_bkg ? 2 : 0, N, Pb, d_cm);
         hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, lc_flux,
-                           normalize_bkg ? 2 : 0, N, Pb, A, d_cm);
+                           normalize_bkg ? 2 : 0, N, Pb, A, d_cm, d_div);
     }
     const int kb = std::min(pca_components, Pb);
     rc = pca_block(h, A, B, N, Pb, kb, d_off, X, K, col, stream, h->ws, true);
