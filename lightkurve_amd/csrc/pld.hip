@@ -430,12 +430,28 @@ __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__
                                                                  const uint32_t *__restrict__ src,
                                                                  const double *__restrict__ mean, int Pc, int ldg, double Nd,
                                                                  double *__restrict__ G) {
+    // a thread writes four neighbouring columns of one row (one 16-byte read of the index table, one 32-byte store)
     const int b = blockIdx.y;
+    const int q4 = (Pc + 3) >> 2;
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Pc * Pc) return;
-    const int i = e / Pc, j = e - i * Pc;
-    const double *mb = mean + (size_t)b * Pc;
-    G[(size_t)b * ldg * ldg + (size_t)i * ldg + j] = Mcan[(size_t)b * mstride + src[e]] - Nd * mb[i] * mb[j];
+    if (e >= Pc * q4) return;
+    const int i = e / q4, j0 = (e - i * q4) * 4;
+    const double *mb = mean + (size_t)b * Pc, *Mb = Mcan + (size_t)b * mstride;
+    const double mi = Nd * mb[i];
+    double *g = G + (size_t)b * ldg * ldg + (size_t)i * ldg + j0;
+    const uint32_t *sp = src + (size_t)i * Pc + j0;
+    if (j0 + 3 < Pc && (Pc & 3) == 0) {
+        const uint4 sv = *reinterpret_cast<const uint4 *>(sp);
+        const double v0 = Mb[sv.x], v1 = Mb[sv.y], v2 = Mb[sv.z], v3 = Mb[sv.w];
+        pld_d4 o;
+        o[0] = v0 - mi * mb[j0];
+        o[1] = v1 - mi * mb[j0 + 1];
+        o[2] = v2 - mi * mb[j0 + 2];
+        o[3] = v3 - mi * mb[j0 + 3];
+        *reinterpret_cast<pld_d4 *>(g) = o;
+    } else {
+        for (int t = 0; t < 4 && j0 + t < Pc; ++t) g[t] = Mb[sp[t]] - mi * mb[j0 + t];
+    }
 }
 
 // mv[b][a] = sum_p mean[b][p] V[b][p][a]: the projection of the column means, subtracted from every cadence by the
@@ -1600,7 +1616,7 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
         }
 #undef LK_MG
     }
-    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * Pc + 255) / 256, B), dim3(256), 0, stream, Mcan,
+    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 255) / 256, B), dim3(256), 0, stream, Mcan,
                        (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G);
     double *V = nullptr, *lam = nullptr;
     const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws);
