@@ -961,9 +961,19 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     while (g0 < (size_t)nP) {
         const int head_bins = nbins_of(order[g0]);
         if (prof_on) LK_HIP_CHECK(hipEventRecord(pe0, stream));
-        // groups: cut whenever the LDS need drops below 7/8 of the group's head (occupancy stays close to the need)
+        // groups: cut whenever the LDS need drops below 7/8 of the group's head (occupancy stays close to the need) — and
+        // where one more single-period team would fit a CU (a group that straddles such a step runs all its periods at the
+        // head's occupancy: the 4983-bin group ran one team per CU although two thirds of its periods leave room for two)
+        // (LDS is handed out in granules: a team that needs 54.4 KB does not fit three times into 160 KB — measured: the
+        // group ran at two teams per CU — so the estimate rounds the need up to 2 KB)
+        auto teams_of = [&](int nb) {
+            return (int)((160 * 1024) / ((tab_bytes16 + region_of((nb + 2) & ~1, 16) + 2047) & ~(size_t)2047));
+        };
+        const int head_teams = teams_of(head_bins);
         size_t g1 = g0 + 1;
-        while (g1 < (size_t)nP && nbins_of(order[g1]) * 8 >= head_bins * 7) ++g1;
+        while (g1 < (size_t)nP && nbins_of(order[g1]) * 8 >= head_bins * 7 &&
+               (head_teams >= 4 || teams_of(nbins_of(order[g1])) == head_teams))
+            ++g1;
         const int npg = (int)(g1 - g0);
         const int cap = (head_bins + 2) & ~1;  // doubles per component array (even: both arrays 16-B aligned)
         // shape: short periods -> G one-wave teams per workgroup (shared tables and prefix pass); long periods -> one
@@ -985,7 +995,7 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
             nt = 64 * gsel;
             lds = tab_bytes16 + (size_t)gsel * region_of(cap, 1);
         } else {
-            const int teams = std::max(1, (int)((160 * 1024) / (tab_bytes16 + region_of(cap, 16) + 64)));
+            const int teams = std::max(1, teams_of(head_bins));
             nw = 2;  // the two-pass prefix and the ticket histogram want at least two waves
             while (nw < 16 && teams * nw * 2 <= 24) nw *= 2;
             nt = 64 * nw;
