@@ -630,11 +630,17 @@ static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld
         for (int e = tid; e < n * n; e += nt) W[(e / n) * ld + (e % n)] = (e / n == e % n) ? 1.0 : 0.0;
     __syncthreads();
     const int half = n >> 1;
+    // e / n by one multiplication (the loops below split ~1000 indices per round; the compiler's
+    // 32-bit division by a run-time n is ~40 instructions, and this function is nothing but short, latency-bound phases)
+    const unsigned magic = (unsigned)((((unsigned long long)1 << 32) + (unsigned)n - 1u) / (unsigned)n);  // exact while e (n - 1) < 2^32
+    auto divn = [&](int e) { return (int)__umulhi((unsigned)e, magic); };
+    int *roti = reinterpret_cast<int *>(rot);  // (p, q) of the round's pairs as ints, (c, s) as doubles behind them
+    double *rotcs = rot + half;
     for (int sweep = 0; sweep < 40; ++sweep) {
         // convergence: off-diagonal mass vs diagonal mass
         double off = 0.0, dia = 0.0;
         for (int e = tid; e < n * n; e += nt) {
-            const int i = e / n, j = e % n;
+            const int i = divn(e), j = e - i * n;
             const double v = M[i * ld + j];
             if (i == j)
                 dia = fma(v, v, dia);
@@ -653,9 +659,11 @@ static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld
                 if (tid == 0) {
                     p = n - 1;
                     q = r;
-                } else {
-                    p = (r + tid) % (n - 1);
-                    q = (r - tid + n - 1) % (n - 1);
+                } else {  // r, tid < n - 1: one conditional subtraction each instead of two divisions
+                    p = r + tid;
+                    if (p >= n - 1) p -= n - 1;
+                    q = r - tid + n - 1;
+                    if (q >= n - 1) q -= n - 1;
                 }
                 if (p > q) {
                     const int t0 = p;
@@ -670,17 +678,17 @@ static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld
                     c = 1.0 / sqrt(1.0 + t * t);
                     s = t * c;
                 }
-                rot[tid * 4 + 0] = (double)p;
-                rot[tid * 4 + 1] = (double)q;
-                rot[tid * 4 + 2] = c;
-                rot[tid * 4 + 3] = s;
+                roti[2 * tid] = p;
+                roti[2 * tid + 1] = q;
+                rotcs[2 * tid] = c;
+                rotcs[2 * tid + 1] = s;
             }
             __syncthreads();
             // rows: M <- J^T M
             for (int e = tid; e < half * n; e += nt) {
-                const int pr = e / n, j = e % n;
-                const int p = (int)rot[pr * 4], q = (int)rot[pr * 4 + 1];
-                const double c = rot[pr * 4 + 2], s = rot[pr * 4 + 3];
+                const int pr = divn(e), j = e - pr * n;
+                const int p = roti[2 * pr], q = roti[2 * pr + 1];
+                const double c = rotcs[2 * pr], s = rotcs[2 * pr + 1];
                 const double mp = M[p * ld + j], mq = M[q * ld + j];
                 M[p * ld + j] = c * mp - s * mq;
                 M[q * ld + j] = s * mp + c * mq;
@@ -688,9 +696,9 @@ static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld
             __syncthreads();
             // columns: M <- M J, W <- W J
             for (int e = tid; e < half * n; e += nt) {
-                const int pr = e / n, i = e % n;
-                const int p = (int)rot[pr * 4], q = (int)rot[pr * 4 + 1];
-                const double c = rot[pr * 4 + 2], s = rot[pr * 4 + 3];
+                const int pr = divn(e), i = e - pr * n;
+                const int p = roti[2 * pr], q = roti[2 * pr + 1];
+                const double c = rotcs[2 * pr], s = rotcs[2 * pr + 1];
                 const double mp = M[i * ld + p], mq = M[i * ld + q];
                 M[i * ld + p] = c * mp - s * mq;
                 M[i * ld + q] = s * mp + c * mq;
