@@ -673,9 +673,13 @@ static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld
                 const double app = M[p * ld + p], aqq = M[q * ld + q], apq = M[p * ld + q];
                 double c = 1.0, s = 0.0;
                 if (fabs(apq) > 1e-300) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
+                    // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = d / b, written as sgn(d) b / (|d| + hypot(d, b)): one
+                    // square root, one division and one reciprocal square root on the round's critical path instead of
+                    // three divisions and two square roots (the same rotation up to rounding)
+                    const double d = aqq - app, b2 = 2.0 * apq;
+                    const double hh = sqrt(fma(d, d, b2 * b2));
+                    const double t = (d >= 0.0 ? b2 : -b2) / (fabs(d) + hh);
+                    c = rsqrt(fma(t, t, 1.0));
                     s = t * c;
                 }
                 roti[2 * tid] = p;
