@@ -688,24 +688,27 @@ static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld
                 rotcs[2 * tid + 1] = s;
             }
             __syncthreads();
-            // rows: M <- J^T M
-            for (int e = tid; e < half * n; e += nt) {
-                const int pr = divn(e), j = e - pr * n;
-                const int p = roti[2 * pr], q = roti[2 * pr + 1];
-                const double c = rotcs[2 * pr], s = rotcs[2 * pr + 1];
-                const double mp = M[p * ld + j], mq = M[q * ld + j];
-                M[p * ld + j] = c * mp - s * mq;
-                M[q * ld + j] = s * mp + c * mq;
+            // M <- J^T M J in ONE phase: a thread owns the 2 x 2 block (pair a, pair b), applies the row rotation of pair
+            // a and then the column rotation of pair b to it in registers (the arithmetic of the separate row and column
+            // sweeps this replaces) and writes its own four entries back — no other thread touches them, so no barrier
+            // between "rows" and "columns".  W <- W J by (row, pair) threads in the same phase.
+            const unsigned magic_h = (unsigned)((((unsigned long long)1 << 32) + (unsigned)half - 1u) / (unsigned)half);
+            for (int blk = tid; blk < half * half; blk += nt) {
+                const int a = (int)__umulhi((unsigned)blk, magic_h), b2 = blk - a * half;
+                const int p = roti[2 * a], q = roti[2 * a + 1], p2 = roti[2 * b2], q2 = roti[2 * b2 + 1];
+                const double c = rotcs[2 * a], s = rotcs[2 * a + 1], c2 = rotcs[2 * b2], s2 = rotcs[2 * b2 + 1];
+                const double mpp = M[p * ld + p2], mpq = M[p * ld + q2], mqp = M[q * ld + p2], mqq = M[q * ld + q2];
+                const double rpp = c * mpp - s * mqp, rpq = c * mpq - s * mqq;  // rows
+                const double rqp = s * mpp + c * mqp, rqq = s * mpq + c * mqq;
+                M[p * ld + p2] = c2 * rpp - s2 * rpq;                            // columns
+                M[p * ld + q2] = s2 * rpp + c2 * rpq;
+                M[q * ld + p2] = c2 * rqp - s2 * rqq;
+                M[q * ld + q2] = s2 * rqp + c2 * rqq;
             }
-            __syncthreads();
-            // columns: M <- M J, W <- W J
             for (int e = tid; e < half * n; e += nt) {
                 const int pr = divn(e), i = e - pr * n;
                 const int p = roti[2 * pr], q = roti[2 * pr + 1];
                 const double c = rotcs[2 * pr], s = rotcs[2 * pr + 1];
-                const double mp = M[i * ld + p], mq = M[i * ld + q];
-                M[i * ld + p] = c * mp - s * mq;
-                M[i * ld + q] = s * mp + c * mq;
                 if (WT) {
                     const double wp = Wt[(size_t)p * n + i], wq = Wt[(size_t)q * n + i];
                     Wt[(size_t)p * n + i] = c * wp - s * wq;
