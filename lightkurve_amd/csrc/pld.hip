@@ -6,13 +6,17 @@
 // where every PLD/background block is the PCA (top-k left singular vectors of the column-centred matrix) of
 //   order 1: pixel flux / SAP flux;  order n: all n-fold products of the order-1 components;  background pixels.
 //
-// PCA = Gram + eigen: C = A^T A on the fp64 matrix cores (gram_mfma_kernel for narrow blocks; gram128_kernel — 128 x 128
-// output blocks, 4 x 4 MFMA tiles per wave, 76 % of the fp64 MFMA peak — for the wide product blocks: the "MFMA A^T A"
-// of config[4]), the top-k eigenpairs of C by blocked subspace iteration with Rayleigh-Ritz.  Every dense step of the
+// PCA = Gram + eigen.  Pixel and background blocks: C = A^T A on the fp64 matrix cores (gram_mfma_kernel; gram128_kernel
+// — 128 x 128 output blocks, 4 x 4 MFMA tiles per wave — for blocks wider than 256 columns), A written already centred
+// (pld_colmean_kernel + pld_ratio_kernel).  Product blocks (order >= 2, at least 100 columns): the products are never
+// materialised; their Gram matrix is expanded from the canonical staircase of the 2o-th moments of the first-order
+// components (pld_moment_gram_kernel + pld_moment_expand_kernel, see there: 6.4 x fewer MFMAs at k = 16, o = 3) and the
+// projection generates them on the fly (pld_project_products_kernel).  Top-k eigenpairs of C by blocked subspace
+// iteration with Rayleigh-Ritz.  Every dense step of the
 // iteration is MFMA work in one workgroup per matrix: C Q (32-byte row loads two steps ahead of the matrix cores), the
 // skinny products Q^T Z and X M, Ritz vectors + residual in one pass; three products with C per Ritz step (eight for the
-// mid-size product blocks, whose flat spectrum tolerates it), column-scaled Cholesky-QR between steps (SVQB as the
-// fallback and for the random start; small l x l eigenproblems by parallel cyclic Jacobi in LDS).  Pixel blocks of at
+// mid-size product blocks, whose flat spectrum tolerates it), column-scaled Cholesky-QR between steps and for the random
+// start (SVQB as the fallback; small l x l eigenproblems by parallel cyclic Jacobi in LDS).  Pixel blocks of at
 // most 138 columns whose iteration does not converge in eight steps fall through to a direct Jacobi on C held in LDS;
 // for P <= 64 the Jacobi always runs on C itself.
 // Then U = A V diag(lambda)^-1/2 (pld_project_kernel, MFMA) written straight into X.  The reference uses fbpca
@@ -1675,8 +1679,8 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     const int lmax = PLD_LMAX;
     const int ldgmax = ((pmax + 63) / 64) * 64;
     h->ws.reset();
-    const size_t per = (size_t)N * pmax * 8 + (size_t)ldgmax * ldgmax * 8 + (size_t)4 * pmax * lmax * 8 +
-                       (size_t)pmax * pca_components * 8 + 4096;
+    const size_t per = (size_t)N * pmax * 8 + (size_t)2 * ldgmax * ldgmax * 8 + (size_t)4 * pmax * lmax * 8 +
+                       (size_t)pmax * pca_components * 8 + 4096;  // 2 x ldgmax^2: Gram + the moment form's canonical array
     int rc = h->ws.reserve((size_t)B * per * 2 + (size_t)(B + 1) * 8 + 65536);
     if (rc) return rc;
     std::vector<int64_t> off((size_t)B + 1);
@@ -1726,14 +1730,20 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
             // wide product blocks: moment-form Gram, the products are never materialised (A serves as its scratch) and their
             // column means come out of the Gram kernel
             const int ldm = ((Pc + 63) / 64) * 64;
-            const bool moment = Pc >= kMomentMinCols && k1 <= 48 && (size_t)ldm * ldm <= (size_t)N * pmax;
+            const bool moment = Pc >= kMomentMinCols && k1 <= 48;
             if (!moment)
                 hipLaunchKernelGGL(pld_products_mean_kernel, dim3((Pc + 255) / 256, B), dim3(1024), 0, stream, X, K, col1, k1, o,
                                    N, Pc, d_comb, d_mean);
             if (moment) {
                 const MomentPlan *pl = moment_plan(h, k1, o, comb, Pc);
                 if (!pl) return LK_ENOMEM;
-                rc = pca_products_moment(h, *pl, B, N, k1, ko, X, K, col1, col, d_mean, A, stream, h->ws);
+                // scratch for the canonical moments: A is free during a product block — when it is large enough
+                double *Mcan = (size_t)ldm * ldm <= (size_t)N * pmax ? A : (double *)h->ws.alloc((size_t)B * ldm * ldm * 8);
+                if (!Mcan) {
+                    set_error("PLD workspace exhausted (moments)");
+                    return LK_ENOMEM;
+                }
+                rc = pca_products_moment(h, *pl, B, N, k1, ko, X, K, col1, col, d_mean, Mcan, stream, h->ws);
                 if (rc) return rc;
             } else {
                 hipLaunchKernelGGL(pld_products_kernel, dim3((N + PP_ROWS - 1) / PP_ROWS, B), dim3(256), 0, stream, X, K, col1, k1, o,
