@@ -7,7 +7,7 @@
 //   order 1: pixel flux / SAP flux;  order n: all n-fold products of the order-1 components;  background pixels.
 //
 // PCA = Gram + eigen.  Pixel and background blocks: C = A^T A on the fp64 matrix cores (gram_mfma_kernel; gram128_kernel
-// — 128 x 128 output blocks, 4 x 4 MFMA tiles per wave — for blocks wider than 256 columns), A written already centred
+// — 128 x 128 output blocks, 4 x 4 MFMA tiles per wave — from 192 columns), A written already centred
 // (pld_colmean_kernel + pld_ratio_kernel).  Product blocks (order >= 2, at least 100 columns): the products are never
 // materialised; their Gram matrix is expanded from the canonical staircase of the 2o-th moments of the first-order
 // components (pld_moment_gram_kernel + pld_moment_expand_kernel, see there: 6.4 x fewer MFMAs at k = 16, o = 3) and the
