@@ -95,7 +95,8 @@ def test_batch_of_cutouts_vs_oracle():
 @pytest.mark.parametrize("order,comps,npix", [(2, 24, 11), (3, 20, 9), (2, 40, 11)])
 def test_wide_bases_vs_oracle(order, comps, npix):
     """More than 16 PCA components: the 40- to 56-wide subspace (4 column tiles per wave in the eigen-solver, 2 to 3 in
-    the projection), product blocks of 300 / 1540 / 820 columns through the 128 x 128 Gram kernel."""
+    the projection), product blocks of 300 / 1540 / 820 columns through the moment-form Gram (the 12-register stage
+    variant of pld_moment_gram_kernel: k1 > 16)."""
     from lightkurve_amd import synth
     cubes = []
     for i in range(2):
@@ -106,6 +107,24 @@ def test_wide_bases_vs_oracle(order, comps, npix):
     for i, c in enumerate(cubes):
         r = O.pld_correct(c.time, c.flux, c.flux_err, allm, allm, allm, pld_order=order, pca_components=comps,
                           spline_degree=5)
+        assert np.array_equal(outl[i], r["outlier_mask"]), i
+        assert np.max(np.abs(corrected[i] - r["corrected"])) / np.median(r["corrected"]) < 1e-6, i
+
+
+@pytest.mark.parametrize("npix", [14, 15])
+def test_large_cutouts_vs_oracle(npix):
+    """196 / 225 PLD pixels: the pixel and background blocks go through the 128 x 128-tile Gram kernel (gram128_kernel,
+    even and odd column counts) and the subspace iteration on a 196- / 225-column Gram matrix; the product block of the
+    second order through the moment form."""
+    from lightkurve_amd import synth
+    cubes = []
+    for i in range(2):
+        t, flux, err, truth = synth.pld_cutout(4, 20 + i, n=600, npix=npix)
+        cubes.append(PixelCube(t, flux, err, mission="K2"))
+    corrected, outl = pld_correct_batch(cubes, pld_order=2, pca_components=16)
+    allm = np.ones((npix, npix), bool)
+    for i, c in enumerate(cubes):
+        r = O.pld_correct(c.time, c.flux, c.flux_err, allm, allm, allm, pld_order=2, pca_components=16, spline_degree=5)
         assert np.array_equal(outl[i], r["outlier_mask"]), i
         assert np.max(np.abs(corrected[i] - r["corrected"])) / np.median(r["corrected"]) < 1e-6, i
 
