@@ -111,6 +111,19 @@ def test_wide_bases_vs_oracle(order, comps, npix):
         assert np.max(np.abs(corrected[i] - r["corrected"])) / np.median(r["corrected"]) < 1e-6, i
 
 
+def test_fourth_order_vs_oracle():
+    """pld_order = 4 with 16 components: 3876 product columns (the widest block the path admits) through the order-4
+    instantiations of the moment-form Gram (8th moments), its 15-million-entry index table and the product projection."""
+    from lightkurve_amd import synth
+    t, flux, err, truth = synth.pld_cutout(4, 30, n=400, npix=5)
+    cube = PixelCube(t, flux, err, mission="K2")
+    corrected, outl = pld_correct_batch([cube], pld_order=4, pca_components=16)
+    allm = np.ones((5, 5), bool)
+    r = O.pld_correct(cube.time, cube.flux, cube.flux_err, allm, allm, allm, pld_order=4, pca_components=16, spline_degree=5)
+    assert np.array_equal(outl[0], r["outlier_mask"])
+    assert np.max(np.abs(corrected[0] - r["corrected"])) / np.median(r["corrected"]) < 1e-6
+
+
 @pytest.mark.parametrize("npix", [14, 15])
 def test_large_cutouts_vs_oracle(npix):
     """196 / 225 PLD pixels: the pixel and background blocks go through the 128 x 128-tile Gram kernel (gram128_kernel,
