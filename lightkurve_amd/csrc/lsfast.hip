@@ -38,7 +38,8 @@ constexpr int SPREAD_W_C = 1024;  // cells owned by one workgroup of lsf_spread_
 
 struct FastStats {
     double wsum, ybar, YY, t0;
-    double yws, pad;  // sum w (y - ybar) (the bias entry of X^T y in the multi-term solve)
+    double yws;   // sum w (y - ybar) (the bias entry of X^T y in the multi-term solve)
+    double vmax;  // max over the cadences of max(w, |w (y - ybar)|): the scale of the scatter kernels' quantum
 };
 
 // per target: weights, mean about y[0], YY, t0 = min t; w[i] (normalised) and wy[i] = w (y - ybar)
@@ -164,27 +165,52 @@ __global__ __launch_bounds__(PREP_NT) void lsf_prep_kernel(const double *__restr
         ybar = bsum(acc) + y0;
     }
     acc = 0.0;
-    double acc2 = 0.0;
+    double acc2 = 0.0, vmx = 0.0;
     for (int64_t i = tid; i < n; i += NT) {
         const double d = dy ? dy[lo + i] : 1.0;
         const double w = (1.0 / (d * d)) / wsum;
         const double yc = y[lo + i] - ybar;
         acc = fma(w * yc, yc, acc);
         acc2 += w * yc;
+        vmx = fmax(vmx, fmax(w, fabs(w * yc)));
         w_out[lo + i] = w;
         wy_out[lo + i] = w * yc;
     }
     const double YY = bsum(acc);
     const double yws = bsum(acc2);
-    if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0, yws, 0.0};
+    sh[tid] = vmx;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] = fmax(sh[tid], sh[tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0, yws, sh[0]};
 }
 
 // astropy extirpolate (M = 4) of one complex sample h at position x into grid[0..nfft)
-__device__ __forceinline__ void extirpolate4(double2 *__restrict__ grid, int nfft, double x, double hr, double hi) {
+// The scatter kernels add with GLOBAL atomics, whose order is not fixed.  To be reproducible bit for bit all the same,
+// every addend is first rounded to a multiple of a quantum q = 2^e chosen per target (2^-50 of the largest possible
+// addend, i.e. about the addend's own last bit): sums of such multiples are exact in double as long as they stay below
+// 2^53 q = 4 x the largest possible addend, and exact additions commute.  That holds wherever the grid is sparsely
+// filled — the 5-fold oversampled grids of real periodograms receive ~0.15 cadences per cell; a cell that piles up more
+// (tiny grids, many coinciding times) is rounded like any double sum: as accurate as before, merely no longer
+// order-independent.  (A coarser quantum with more headroom was tried first: 2^-46 cost 1e-9 of the power where the
+// five-point fit is ill-conditioned.)
+struct Quantum {
+    double q, iq;
+    __device__ __forceinline__ double operator()(double v) const { return q > 0.0 ? rint(v * iq) * q : v; }
+};
+__device__ __forceinline__ Quantum make_quantum(double vmax) {
+    const double q = (vmax > 0.0 && isfinite(vmax)) ? ldexp(1.0, ilogb(1.25 * vmax) - 49) : 0.0;
+    return Quantum{q, q > 0.0 ? 1.0 / q : 0.0};
+}
+
+__device__ __forceinline__ void extirpolate4(double2 *__restrict__ grid, int nfft, double x, double hr, double hi,
+                                             const Quantum &Q) {
     if (fmod(x, 1.0) == 0.0) {
         const int i = (int)x;
-        unsafeAtomicAdd(&grid[i].x, hr);
-        unsafeAtomicAdd(&grid[i].y, hi);
+        unsafeAtomicAdd(&grid[i].x, Q(hr));
+        unsafeAtomicAdd(&grid[i].y, Q(hi));
         return;
     }
     int ilo = (int)(x - 2.0);  // astype(int): truncation toward zero
@@ -195,14 +221,14 @@ __device__ __forceinline__ void extirpolate4(double2 *__restrict__ grid, int nff
     const double nr = hr * prod, ni = hi * prod;
     // j = 0..3: ind = ilo + 3 - j, denominators 6, -2, 2, -6
     const double q3 = 6.0 * d3, q2 = -2.0 * d2, q1 = 2.0 * d1, q0 = -6.0 * d0;
-    unsafeAtomicAdd(&grid[ilo + 3].x, nr / q3);
-    unsafeAtomicAdd(&grid[ilo + 3].y, ni / q3);
-    unsafeAtomicAdd(&grid[ilo + 2].x, nr / q2);
-    unsafeAtomicAdd(&grid[ilo + 2].y, ni / q2);
-    unsafeAtomicAdd(&grid[ilo + 1].x, nr / q1);
-    unsafeAtomicAdd(&grid[ilo + 1].y, ni / q1);
-    unsafeAtomicAdd(&grid[ilo].x, nr / q0);
-    unsafeAtomicAdd(&grid[ilo].y, ni / q0);
+    unsafeAtomicAdd(&grid[ilo + 3].x, Q(nr / q3));
+    unsafeAtomicAdd(&grid[ilo + 3].y, Q(ni / q3));
+    unsafeAtomicAdd(&grid[ilo + 2].x, Q(nr / q2));
+    unsafeAtomicAdd(&grid[ilo + 2].y, Q(ni / q2));
+    unsafeAtomicAdd(&grid[ilo + 1].x, Q(nr / q1));
+    unsafeAtomicAdd(&grid[ilo + 1].y, Q(ni / q1));
+    unsafeAtomicAdd(&grid[ilo].x, Q(nr / q0));
+    unsafeAtomicAdd(&grid[ilo].y, Q(ni / q0));
 }
 
 // spread every cadence of targets [b0, b0 + nb) into its three grids: 0: w*y at f, 1: w at f, 2: w at 2f
@@ -223,16 +249,17 @@ __global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restri
     double2 *g0 = grids + (size_t)blockIdx.y * 3 * nfft, *g1 = g0 + nfft, *g2 = g1 + nfft;
     const double wi = w[lo + i], wyi = wy[lo + i];
     const double twopi = 6.283185307179586;
+    const Quantum Q = make_quantum(stats[b].vmax);
     for (int fac = 1; fac <= 2; ++fac) {
         const double dff = df * (double)fac, f0f = f0 * (double)fac;
         double c = 1.0, s = 0.0;
         if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
         const double tn = fmod(tt * (double)nfft * dff, (double)nfft);
         if (fac == 1) {
-            extirpolate4(g0, nfft, tn, wyi * c, wyi * s);
-            if (fit_mean) extirpolate4(g1, nfft, tn, wi * c, wi * s);
+            extirpolate4(g0, nfft, tn, wyi * c, wyi * s, Q);
+            if (fit_mean) extirpolate4(g1, nfft, tn, wi * c, wi * s, Q);
         } else {
-            extirpolate4(g2, nfft, tn, wi * c, wi * s);
+            extirpolate4(g2, nfft, tn, wi * c, wi * s, Q);
         }
     }
 }
@@ -819,13 +846,14 @@ __global__ __launch_bounds__(256) void lsf_scatter_multi_kernel(const double *__
     double2 *g0 = grids + (size_t)blockIdx.y * 3 * nterms * nfft;
     const double wi = w[lo + i], wyi = wy[lo + i];
     const double twopi = 6.283185307179586;
+    const Quantum Q = make_quantum(stats[b].vmax);
     for (int fac = 1; fac <= 2 * nterms; ++fac) {
         const double dff = df * (double)fac, f0f = f0 * (double)fac;
         double c = 1.0, s = 0.0;
         if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
         const double tn = fmod(tt * (double)nfft * dff, (double)nfft);
-        extirpolate4(g0 + (size_t)(nterms + fac - 1) * nfft, nfft, tn, wi * c, wi * s);
-        if (fac <= nterms) extirpolate4(g0 + (size_t)(fac - 1) * nfft, nfft, tn, wyi * c, wyi * s);
+        extirpolate4(g0 + (size_t)(nterms + fac - 1) * nfft, nfft, tn, wi * c, wi * s, Q);
+        if (fac <= nterms) extirpolate4(g0 + (size_t)(fac - 1) * nfft, nfft, tn, wyi * c, wyi * s, Q);
     }
 }
 

@@ -1,8 +1,8 @@
-"""GPU: run-twice bitwise determinism of the compute entry points (a run-twice bitwise test).  With one
-stated exception (global-atomic scatter: 'fastchi2' and unordered Lomb-Scargle targets, see below) none of the kernels
-accumulates in an order that depends on scheduling: the BLS histogram and the LS spreader use LDS atomics
-whose order is fixed (same-address lanes of one ds_add_f64 in lane order, one wave per cell range), everything else is
-plain reductions in a fixed tree.  Each call is made twice in one process and once more after other work has touched the
+"""GPU: run-twice bitwise determinism of the compute entry points (a run-twice bitwise test).  No kernel
+accumulates in an order that depends on scheduling: the BLS histogram and the LS spreader use LDS atomics whose order is
+fixed (same-address lanes of one ds_add_f64 in lane order, one wave per cell range), the global-atomic scatter of the
+fallback paths ('fastchi2', unordered Lomb-Scargle targets) adds multiples of one quantum (exact, hence commutative),
+everything else is plain reductions in a fixed tree.  Each call is made twice in one process and once more after other work has touched the
 device (different scratch contents), and compared with ==."""
 import numpy as np
 import pytest
@@ -47,15 +47,18 @@ def test_ls_entry_points_bitwise():
     thrice(lambda: _capi.ls_fast_peaks_batch(t, y, off, f0=df, df=df, M=40000, normalization="lk_amplitude"), _disturb, "ls_fast_peaks")
     thrice(lambda: _capi.ls_power_batch(t, y, off, f0=df, df=df, M=5000, normalization="psd"), _disturb, "exact LS")
     thrice(lambda: _capi.ls_power_batch(t, y, off, f0=df, df=df, M=3000, normalization="standard", nterms=2), _disturb, "chi2")
-    # The one exception: the multi-term 'fastchi2' grids (and targets the owner spreader cannot take: unsorted time, a
-    # wrapping 2f grid) are filled by lsf_scatter*_kernel with GLOBAL atomics, whose order is not fixed: two runs agree to
-    # rounding, not bit for bit.  Stated here so the exception is a tested fact, not an omission.
-    a = _capi.ls_fast_batch(t, y, off, f0=df, df=df, M=20000, normalization="psd", nterms=2)
-    b = _capi.ls_fast_batch(t, y, off, f0=df, df=df, M=20000, normalization="psd", nterms=2)
-    ok = np.isfinite(a)
-    # (the grids differ by ~1e-16 relative; the 5 x 5 normal equations of the two-term fit amplify that where they are
-    # ill-conditioned — 2e-10 of the peak has been seen — so the bound is loose on purpose: it documents, it must not flake)
-    assert np.array_equal(ok, np.isfinite(b)) and np.max(np.abs(a[ok] - b[ok])) <= 1e-6 * np.max(np.abs(a[ok]))
+    # The grids of the multi-term 'fastchi2' method and of targets the owner spreader cannot take (unsorted time, a
+    # wrapping 2f grid) are filled by lsf_scatter*_kernel with GLOBAL atomics, whose order is not fixed — but every addend is
+    # a multiple of one per-target quantum (lsfast.hip: Quantum), so the additions are exact and commute: bitwise all the same.
+    thrice(lambda: _capi.ls_fast_batch(t, y, off, f0=df, df=df, M=20000, normalization="psd", nterms=2), _disturb, "fastchi2")
+    tu, yu = t.copy(), y.copy()
+    rng = np.random.default_rng(5)
+    for b in range(0, 6, 2):  # every other target: shuffled cadences (unsorted time)
+        p = rng.permutation(off[b + 1] - off[b])
+        tu[off[b]:off[b + 1]] = t[off[b]:off[b + 1]][p]
+        yu[off[b]:off[b + 1]] = y[off[b]:off[b + 1]][p]
+    thrice(lambda: _capi.ls_fast_batch(tu, yu, off, f0=df, df=df, M=40000, normalization="lk_amplitude"), _disturb, "ls_fast unsorted")
+    thrice(lambda: _capi.ls_fast_batch(t, y, off, f0=0.05, df=0.05, M=40000, normalization="psd"), _disturb, "ls_fast wrapping grid")
 
 
 def test_bls_flatten_fold_bitwise():
