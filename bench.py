@@ -262,6 +262,8 @@ def reference_suite(args, want_ls, want_bls, want_flatten=False):
         res["cores"] = cores
         if "flatten" in res:
             res["flatten"]["trends"] = np.load(os.path.join(work, "flatten_trends.npy"))
+        if "bls" in res and os.path.exists(os.path.join(work, "bls_folded.npy")):
+            res["bls"]["folded_flux"] = np.load(os.path.join(work, "bls_folded.npy"))
         return res
     except Exception as e:   # the baseline is reported, never required
         sys.stderr.write("astropy suite failed: %r\n" % (e,))
@@ -544,6 +546,9 @@ def main():
     def run_bls(Bb, first_index, steps, warmup):
         t, y, dy, off = synth.bls_batch(3, Bb, N, first_index=first_index)
         ivar = 1.0 / dy ** 2
+        nchk = min(Bb, max(args.acc_bls, 1))
+        raw_t, raw_y = t[:off[nchk]].copy(), y[:off[nchk]].copy()   # as the reference sees them (the folded-flux check)
+        tmin = np.array([t[off[b]:off[b + 1]].min() for b in range(nchk)])
         for b in range(Bb):
             s = slice(off[b], off[b + 1])
             t[s] -= t[s].min()
@@ -581,6 +586,10 @@ def main():
             "argmax": d_arg.cpu().numpy(), "max_power": d_max.cpu().numpy(),
             "period_at_max": period[np.clip(d_arg.cpu().numpy(), 0, nP - 1)],
         }
+        # transit time at the best period of the first targets (row 4 of the seven outputs) + their inputs: the folded-flux check
+        am = np.clip(res["argmax"][:nchk], 0, nP - 1)
+        res["transit_time_at_max"] = d_out[4, torch.arange(nchk, device=dev), torch.from_numpy(am).to(dev)].cpu().numpy() + tmin
+        res["_fold_inputs"] = (raw_t, raw_y, off[:nchk + 1].copy())
         del d_out
         return res
 
@@ -592,7 +601,24 @@ def main():
                 % (ref["astropy"], args.periods),
                 "best_period_index_equal": "%d/%d" % (int(np.sum(a_ref == a_gpu)), n),
                 "max_power_bit_identical": "%d/%d" % (int(np.sum(p_ref == p_gpu)), n),
-                "max_power_relerr_max": float(np.max(np.abs(p_gpu - p_ref) / np.abs(p_ref)))}
+                "max_power_relerr_max": float(np.max(np.abs(p_gpu - p_ref) / np.abs(p_ref))),
+                **folded_flux_check(res, refb, n)}
+
+    def folded_flux_check(res, refb, n):
+        """BASELINE's third accuracy item: the light curve folded at the best period (lk_fold_batch at OUR best period and
+        transit time) against astropy's TimeSeries.fold + sort at ITS best period, as lightkurve.fold does."""
+        if "folded_flux" not in refb or "_fold_inputs" not in res:
+            return {}
+        tt, yy, oo = res["_fold_inputs"]
+        n = min(n, len(oo) - 1)
+        _, order, cols = _capi.fold_batch(tt[:oo[n]], oo[:n + 1], res["period_at_max"][:n], res["transit_time_at_max"][:n],
+                                          columns=(yy[:oo[n]],))
+        ref_f = np.asarray(refb["folded_flux"])[:oo[n]]
+        same = cols[0] == ref_f
+        return {"folded_flux_max_abs_diff": float(np.max(np.abs(cols[0] - ref_f))),
+                "folded_flux_cadences_in_same_position": "%d/%d" % (int(np.sum(same)), same.size),
+                "folded_flux_reference": "astropy TimeSeries.fold(period, epoch_time=transit_time) + sort('time') at astropy's "
+                                         "best period (what LightCurve.fold runs, lightcurve.py:1173-1212), %d targets" % n}
 
 
     # ================================================================================================ PLD block

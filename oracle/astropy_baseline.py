@@ -76,8 +76,16 @@ def _suite_bls(b):
     s = slice(int(d["off"][b]), int(d["off"][b + 1]))
     r = BoxLeastSquares(d["t"][s], d["y"][s], d["e"][s]).power(d["period"], d["duration"])
     k = int(np.argmax(r.power))
+    # the light curve folded at the best period, as lightkurve does it (lightcurve.py:1173-1212): astropy's
+    # TimeSeries.fold with the transit time as epoch, then a table sort by the folded time
+    import astropy.units as u
+    from astropy.time import Time
+    from astropy.timeseries import TimeSeries
+    ts = TimeSeries(time=Time(d["t"][s], format="mjd"), data={"flux": d["y"][s]})
+    folded = ts.fold(period=float(r.period[k]) * u.day, epoch_time=Time(float(r.transit_time[k]), format="mjd"))
+    folded.sort("time")
     return (k, float(r.power[k]), float(r.period[k]), float(r.duration[k]), float(r.depth[k]),
-            float(r.transit_time[k]))
+            float(r.transit_time[k]), np.asarray(folded["flux"], dtype=np.float64))
 
 
 def _suite_flatten(b):
@@ -159,6 +167,7 @@ def suite(workdir, procs):
                           "argmax": [o[0] for o in out], "max_power": [o[1] for o in out],
                           "period": [o[2] for o in out], "duration": [o[3] for o in out],
                           "depth": [o[4] for o in out], "transit_time": [o[5] for o in out]}
+            np.save(os.path.join(workdir, "bls_folded.npy"), np.concatenate([o[6] for o in out]))
         if "flatten" in spec and spec["flatten"].get("n", 0) > 0:
             import scipy
             n = spec["flatten"]["n"]
