@@ -27,6 +27,7 @@
 // in (2 x 3 x 16 B x Nfft = 50 MB), the sample-bearing rows out and in (~6 MB), 40 B per cadence, 8 B per frequency.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "lk_common.hpp"
@@ -34,168 +35,222 @@
 
 namespace lk {
 
-constexpr int SPREAD_W_C = 1024;  // cells owned by one workgroup of lsf_spread_owner_kernel
+typedef double lk_d2v __attribute__((ext_vector_type(2)));  // for the non-temporal load / store builtins
+
+constexpr int SPREAD_W = 1024;   // cells owned by one workgroup of lsf_spread_owner_kernel
+constexpr int SPREAD_WW = 256;   // ... and by each of its four waves: the granularity of the prep kernel's cadence tables
 
 struct FastStats {
     double wsum, ybar, YY, t0;
     double yws;   // sum w (y - ybar) (the bias entry of X^T y in the multi-term solve)
-    double vmax;  // max over the cadences of max(w, |w (y - ybar)|): the scale of the scatter kernels' quantum
+    double wmax;  // max over the cadences of w and of |w (y - ybar)|: the scales of the scatter kernels' two quanta (the w
+    double vmax;  // grids and the w y grids each get their own — |w y| is 1e-4 .. 1e-6 of w for a normalised light curve)
 };
 
-// per target: weights, mean about y[0], YY, t0 = min t; w[i] (normalised) and wy[i] = w (y - ybar)
-constexpr int PREP_NT = 1024;
+// the normalised weight of cadence i and the weighted, centred flux: the ONE place these are formed (prep sums, spreaders)
+__device__ __forceinline__ void cadence_weights(const double *__restrict__ y, const double *__restrict__ dy, int64_t i,
+                                                double wsum, double ybar, double &w, double &wy) {
+    const double d = dy ? dy[i] : 1.0;
+    w = (1.0 / (d * d)) / wsum;
+    wy = w * (y[i] - ybar);
+}
+
+// per target: weights, the mean about y[0], YY, t0 = min t, and the rows of each grid that can hold samples — ONE sweep over
+// the cadences (the kernel is a streaming reduction; round 3 swept four times): with u = 1 / dy^2, z = y - y[0],
+//     A = sum u,  Bz = sum u z,  Cz = sum u z^2   ->   ybar = y[0] + Bz / A,   YY = (Cz - Bz^2 / A) / A
+// (the shifted-data form: y[0] sits within a few sigma of the mean, so the subtraction costs a digit at most, and a constant
+// light curve still centres to exactly 0).  Targets the owner-computes spreader cannot take (unsorted, wrapping) and the
+// multi-term path need the scales of the scatter kernels' quanta and the bias sum: a second sweep, for those only.
+// Also prefills the target's spreader tables with "past the last cadence" (lsf_tables_kernel overwrites what is not).
+constexpr int PREP_NT = 512;
 __global__ __launch_bounds__(PREP_NT) void lsf_prep_kernel(const double *__restrict__ t, const double *__restrict__ y,
                                                         const double *__restrict__ dy,
                                                         const int64_t *__restrict__ n_off, int center,
-                                                        double *__restrict__ w_out, double *__restrict__ wy_out,
                                                         FastStats *__restrict__ stats, double df, int nfft, int m2,
                                                         int *__restrict__ rows_used, int *__restrict__ spread_tab,
                                                         int ntab) {
     constexpr int NT = PREP_NT;
-    __shared__ double sh[NT];
+    __shared__ double sh[NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
-    auto bsum = [&](double x) {
-        sh[tid] = x;
+    // block reductions: a butterfly inside each wave (every lane ends with the same bits), then the wave results in order
+    auto breduce = [&](double x, auto op) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x = op(x, __shfl_xor(x, o));
+        if ((tid & 63) == 0) sh[tid >> 6] = x;
         __syncthreads();
-        for (int s = NT / 2; s > 0; s >>= 1) {
-            if (tid < s) sh[tid] += sh[tid + s];
-            __syncthreads();
-        }
-        const double r = sh[0];
+        double r = sh[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) r = op(r, sh[w]);
         __syncthreads();
         return r;
     };
-    // (the kernel is bound by its sweeps over the cadences: one for the time statistics, one for the tables, two over y)
-    double acc = 0.0, tmin = INFINITY, tmax = -INFINITY;
+    auto bsum = [&](double x) { return breduce(x, [](double a, double b2) { return a + b2; }); };
+    auto bmax = [&](double x) { return breduce(x, [](double a, double b2) { return fmax(a, b2); }); };
+    if (spread_tab) {
+        int *tab = spread_tab + (size_t)b * 4 * ntab;
+        for (int k = tid; k < 4 * ntab; k += NT) tab[k] = (int)n;
+    }
+    const double y0 = y[lo];
+    double A = 0.0, Bz = 0.0, Cz = 0.0, tmin = INFINITY, tmax = -INFINITY;
     int unsorted = 0;
+#pragma unroll 4
     for (int64_t i = tid; i < n; i += NT) {
+        const double ti = t[lo + i], z = y[lo + i] - y0;
+        double u = 1.0;
         if (dy) {
             const double d = dy[lo + i];
-            acc += 1.0 / (d * d);
+            u = 1.0 / (d * d);
         }
-        const double ti = t[lo + i];
+        A += u;
+        Bz = fma(u, z, Bz);
+        Cz = fma(u * z, z, Cz);
         tmin = fmin(tmin, ti);
         tmax = fmax(tmax, ti);
         if (i + 1 < n) unsorted |= (t[lo + i + 1] < ti) ? 1 : 0;
     }
-    const double wsum = dy ? bsum(acc) : (double)n;
-    sh[tid] = tmin;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] = fmin(sh[tid], sh[tid + s]);
-        __syncthreads();
-    }
-    const double t0 = sh[0];
-    __syncthreads();
-    sh[tid] = tmax;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] = fmax(sh[tid], sh[tid + s]);
-        __syncthreads();
-    }
-    const double t1 = sh[0];
-    __syncthreads();
-    if (tid < 3 && rows_used) {
-        // grid rows (of N2 cells) that can receive a sample: cells <= tnorm_max + 1; everything wraps if the span
-        // reaches Nfft.  Grids 0, 1 use df, grid 2 uses 2 df.
-        const double span = (t1 - t0) * (double)nfft * df * (tid == 2 ? 2.0 : 1.0);
-        const int nrows = nfft >> m2;
-        rows_used[b * 4 + tid] = (span >= (double)nfft - 8.0) ? nrows : min(nrows, (int)((span + 4.0) / (double)(1 << m2)) + 1);
-    }
+    const double wsum = dy ? bsum(A) : (double)n;
+    Bz = bsum(Bz);
+    Cz = bsum(Cz);
+    const double t0 = -bmax(-tmin);
+    const double t1 = bmax(tmax);
+    const int any_unsorted = __syncthreads_or(unsorted);
+    const bool nowrap = (t1 - t0) * (double)nfft * df * 2.0 < (double)nfft - 8.0;
+    const bool ordered = !any_unsorted && nowrap;
     if (rows_used) {
+        if (tid < 3) {
+            // grid rows (of N2 cells) that can receive a sample: cells <= tnorm_max + 1; everything wraps if the span
+            // reaches Nfft.  Grids 0, 1 use df, grid 2 uses 2 df.
+            const double span = (t1 - t0) * (double)nfft * df * (tid == 2 ? 2.0 : 1.0);
+            const int nrows = nfft >> m2;
+            rows_used[b * 4 + tid] = (span >= (double)nfft - 8.0) ? nrows : min(nrows, (int)((span + 4.0) / (double)(1 << m2)) + 1);
+        }
         // "ordered" targets (time sorted, no wrap of the 2 df grid): grid positions are monotone in the cadence
         // index, so the spreading kernel can own cell ranges and use plain stores instead of global atomics
-        const int any_unsorted = __syncthreads_or(unsorted);
-        const bool nowrap = (t1 - t0) * (double)nfft * df * 2.0 < (double)nfft - 8.0;
-        if (tid == 0) rows_used[b * 4 + 3] = (!any_unsorted && nowrap) ? 1 : 0;
+        if (tid == 0) rows_used[b * 4 + 3] = ordered ? 1 : 0;
     }
-    if (spread_tab) {
-        // Search tables for the owner-computes spreader (ordered targets: grid positions grow with the cadence index).
-        // Per grid g and 1024-cell block k:  lo_tab[k] = first cadence with position >= k W - 4,  hi_tab[k] = first
-        // cadence with position >= k W + 3 — what the spreader used to find with two block-wide binary searches per
-        // workgroup.  Every cadence fills the thresholds that fall between its predecessor's position and its own.
-        int *tab = spread_tab + (size_t)b * 6 * ntab;
-        const double W = (double)SPREAD_W_C, dn = (double)nfft;
-        auto posn = [&](double tt, double dff) {
-            const double x = (tt - t0) * dn * dff;
-            return x < dn ? x : fmod(x, dn);  // the reference's fmod; the identity for every target the spreader takes
-        };
-        // grids 0 and 1 share df (identical tables, both written: the spreader indexes them by grid), grid 2 uses 2 df
+    const double delta = center ? Bz / wsum : 0.0;
+    const double ybar = center ? y0 + delta : 0.0;
+    // sum w (y - ybar)^2 with w = u / wsum: about y0 when centred (then ybar - y0 = delta), about 0 otherwise
+    double YY;
+    if (center)
+        YY = fmax(0.0, (Cz - Bz * delta) / wsum);
+    else
+        YY = (Cz + y0 * (2.0 * Bz + y0 * wsum)) / wsum;  // sum u (z + y0)^2
+    double yws = 0.0, wmx = 0.0, vmx = 0.0;
+    if (!(rows_used && ordered)) {
+        double acc2 = 0.0;
         for (int64_t i = tid; i < n; i += NT) {
-            const double ti = t[lo + i], tp = i > 0 ? t[lo + i - 1] : 0.0;
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const double dff = df * (gg ? 2.0 : 1.0);
-                const double p = posn(ti, dff), pp = i > 0 ? posn(tp, dff) : -1e300;
-                int *lo_a = tab + (size_t)(gg ? 4 : 0) * ntab, *hi_a = lo_a + ntab;
-                int *lo_b = gg ? nullptr : tab + (size_t)2 * ntab, *hi_b = gg ? nullptr : lo_b + ntab;
-                // thresholds x_k = k W - 4 with pp < x_k <= p
-                long long k0 = i > 0 ? (long long)floor((pp + 4.0) / W) + 1 : 0, k1 = (long long)floor((p + 4.0) / W);
-                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) {
-                    lo_a[k] = (int)i;
-                    if (lo_b) lo_b[k] = (int)i;
-                }
-                k0 = i > 0 ? (long long)floor((pp - 3.0) / W) + 1 : 0;
-                k1 = (long long)floor((p - 3.0) / W);
-                for (long long k = max(k0, 0ll); k <= min(k1, (long long)ntab - 1); ++k) {
-                    hi_a[k] = (int)i;
-                    if (hi_b) hi_b[k] = (int)i;
-                }
-            }
+            double w, wy;
+            cadence_weights(y, dy, lo + i, wsum, ybar, w, wy);
+            acc2 += wy;
+            wmx = fmax(wmx, w);
+            vmx = fmax(vmx, fabs(wy));
         }
-        // thresholds beyond the last cadence
-        for (int g = 0; g < 3; ++g) {
-            int *lo_tab = tab + (size_t)(2 * g) * ntab, *hi_tab = lo_tab + ntab;
-            const double pl = posn(t[lo + n - 1], df * (g == 2 ? 2.0 : 1.0));
-            for (int k = tid; k < ntab; k += NT) {
-                if ((double)k * W - 4.0 > pl) lo_tab[k] = (int)n;
-                if ((double)k * W + 3.0 > pl) hi_tab[k] = (int)n;
-            }
-        }
+        yws = bsum(acc2);
+        wmx = bmax(wmx);
+        vmx = bmax(vmx);
     }
-    const double y0 = y[lo];
-    double ybar = 0.0;
-    if (center) {
-        acc = 0.0;
-        for (int64_t i = tid; i < n; i += NT) {
-            const double d = dy ? dy[lo + i] : 1.0;
-            acc = fma((1.0 / (d * d)) / wsum, y[lo + i] - y0, acc);
-        }
-        ybar = bsum(acc) + y0;
-    }
-    acc = 0.0;
-    double acc2 = 0.0, vmx = 0.0;
-    for (int64_t i = tid; i < n; i += NT) {
-        const double d = dy ? dy[lo + i] : 1.0;
-        const double w = (1.0 / (d * d)) / wsum;
-        const double yc = y[lo + i] - ybar;
-        acc = fma(w * yc, yc, acc);
-        acc2 += w * yc;
-        vmx = fmax(vmx, fmax(w, fabs(w * yc)));
-        w_out[lo + i] = w;
-        wy_out[lo + i] = w * yc;
-    }
-    const double YY = bsum(acc);
-    const double yws = bsum(acc2);
-    sh[tid] = vmx;
-    __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] = fmax(sh[tid], sh[tid + s]);
-        __syncthreads();
-    }
-    if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0, yws, sh[0]};
+    if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0, yws, wmx, vmx};
 }
 
-// astropy extirpolate (M = 4) of one complex sample h at position x into grid[0..nfft)
+// Cadence tables of the owner-computes spreader (ordered targets: grid positions grow with the cadence index), one thread
+// per cadence.  Per frequency step (df: the w y and w grids; 2 df: the third grid) and block k of SPREAD_WW cells:
+//   lo_tab[k] = first cadence with position >= k WW - 4,   hi_tab[k] = first cadence with position >= k WW + 3,
+// so the wave that owns cells [k WW, (k + 1) WW) walks cadences [lo_tab[k], hi_tab[k + 1]) and needs no search.
+// Every cadence fills the thresholds that fall between its predecessor's position and its own; thresholds beyond the last
+// cadence keep the prep kernel's prefill (n).
+__global__ __launch_bounds__(256) void lsf_tables_kernel(const double *__restrict__ t, const int64_t *__restrict__ n_off,
+                                                          const FastStats *__restrict__ stats,
+                                                          const int *__restrict__ rows_used, double df, int nfft,
+                                                          int *__restrict__ spread_tab, int ntab) {
+    const int b = blockIdx.y;
+    if (!rows_used[b * 4 + 3]) return;  // not an owner-spreader target
+    const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double t0 = stats[b].t0;
+    int *tab = spread_tab + (size_t)b * 4 * ntab;
+    const double iW = 1.0 / (double)SPREAD_WW, dn = (double)nfft;
+    auto posn = [&](double tt, double dff) {
+        const double x = (tt - t0) * dn * dff;
+        return x < dn ? x : fmod(x, dn);  // the reference's fmod; the identity for every target the spreader takes
+    };
+    const double ti = t[lo + i], tp = i > 0 ? t[lo + i - 1] : 0.0;
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+        const double dff = df * (gg ? 2.0 : 1.0);
+        const double p = posn(ti, dff), pp = i > 0 ? posn(tp, dff) : -1e300;
+        int *lo_a = tab + (size_t)(2 * gg) * ntab, *hi_a = lo_a + ntab;
+        // thresholds x_k = k W - 4 with pp < x_k <= p
+        int k0 = i > 0 ? (int)floor((pp + 4.0) * iW) + 1 : 0, k1 = (int)floor((p + 4.0) * iW);
+        for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) lo_a[k] = (int)i;
+        // thresholds x_k = k W + 3
+        k0 = i > 0 ? (int)floor((pp - 3.0) * iW) + 1 : 0;
+        k1 = (int)floor((p - 3.0) * iW);
+        for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) hi_a[k] = (int)i;
+    }
+}
+
+static void launch_prep(int B, int64_t nmax, hipStream_t stream, const double *t, const double *y, const double *dy,
+                        const int64_t *d_off, int center, FastStats *d_stats, double df, int nfft, int m2, int *d_rows,
+                        int *d_tab, int ntab) {
+    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, center, d_stats, df, nfft, m2,
+                       d_rows, d_tab, ntab);
+    if (d_tab)
+        hipLaunchKernelGGL(lsf_tables_kernel, dim3((unsigned)((nmax + 255) / 256), B), dim3(256), 0, stream, t, d_off, d_stats,
+                           d_rows, df, nfft, d_tab, ntab);
+}
+
+// e^{2 pi i f t}: the phase in cycles is reduced exactly first (the rounding error of the product comes back through fma),
+// then one sincospi on [-1, 1] — cheaper than sincos with its argument reduction, and at least as close to the reference's
+// np.exp(2j pi f0 (t - t0)) as that expression is to the true value
+__device__ __forceinline__ void phase_factor(double f, double tt, double &c, double &s) {
+    const double p = f * tt, e = fma(f, tt, -p);
+    const double r = (p - rint(p)) + e;
+    sincospi(2.0 * r, &s, &c);
+}
+
+// astropy extirpolate (M = 4), utils.py:14-78: a sample at position x goes to cells i0 .. i0 + n - 1 with weights wt[.]
+// (n = 1, weight 1 when x is an integer; else the four Lagrange weights prod_k (x - ilo - k) / (denominator_j (x - ind_j)))
+struct Stencil4 {
+    int i0, n;
+    double wt[4];
+};
+__device__ __forceinline__ Stencil4 stencil4(double x, int nfft) {
+    Stencil4 st;
+    if (fmod(x, 1.0) == 0.0) {
+        st.i0 = (int)x;
+        st.n = 1;
+        st.wt[0] = 1.0;
+        st.wt[1] = st.wt[2] = st.wt[3] = 0.0;
+        return st;
+    }
+    int ilo = (int)(x - 2.0);  // astype(int): truncation toward zero
+    ilo = min(max(ilo, 0), nfft - 4);
+    // d1..d3 as the reference forms them: x - ilo - k (same value: ilo + k is exact in double)
+    const double d0 = x - (double)ilo, d1 = d0 - 1.0, d2 = d0 - 2.0, d3 = d0 - 3.0;
+    const double prod = ((d0 * d1) * d2) * d3;
+    // j = 0..3: ind = ilo + 3 - j, denominators 6, -2, 2, -6
+    st.i0 = ilo;
+    st.n = 4;
+    st.wt[3] = prod / (6.0 * d3);
+    st.wt[2] = prod / (-2.0 * d2);
+    st.wt[1] = prod / (2.0 * d1);
+    st.wt[0] = prod / (-6.0 * d0);
+    return st;
+}
+
 // The scatter kernels add with GLOBAL atomics, whose order is not fixed.  To be reproducible bit for bit all the same,
-// every addend is first rounded to a multiple of a quantum q = 2^e chosen per target (2^-50 of the largest possible
-// addend, i.e. about the addend's own last bit): sums of such multiples are exact in double as long as they stay below
-// 2^53 q = 4 x the largest possible addend, and exact additions commute.  That holds wherever the grid is sparsely
+// every addend is first rounded to a multiple of a quantum q = 2^e chosen per target AND per kind of grid (2^-50 of the
+// largest possible addend, i.e. about the addend's own last bit): sums of such multiples are exact in double as long as they
+// stay below 2^53 q = 4 x the largest possible addend, and exact additions commute.  That holds wherever the grid is sparsely
 // filled — the 5-fold oversampled grids of real periodograms receive ~0.15 cadences per cell; a cell that piles up more
 // (tiny grids, many coinciding times) is rounded like any double sum: as accurate as before, merely no longer
-// order-independent.  (A coarser quantum with more headroom was tried first: 2^-46 cost 1e-9 of the power where the
-// five-point fit is ill-conditioned.)
+// order-independent.  The w grids and the w (y - ybar) grids have their own quanta (FastStats::wmax, ::vmax): one shared
+// quantum, scaled by w, would leave the w y addends of a normalised low-amplitude light curve only 2^-30 of relative
+// precision.  (A coarser quantum with more headroom was tried first: 2^-46 cost 1e-9 of the power where the five-point fit
+// is ill-conditioned.)
 struct Quantum {
     double q, iq;
     __device__ __forceinline__ double operator()(double v) const { return q > 0.0 ? rint(v * iq) * q : v; }
@@ -205,35 +260,19 @@ __device__ __forceinline__ Quantum make_quantum(double vmax) {
     return Quantum{q, q > 0.0 ? 1.0 / q : 0.0};
 }
 
-__device__ __forceinline__ void extirpolate4(double2 *__restrict__ grid, int nfft, double x, double hr, double hi,
+__device__ __forceinline__ void extirpolate4(double2 *__restrict__ grid, const Stencil4 &sp, double hr, double hi,
                                              const Quantum &Q) {
-    if (fmod(x, 1.0) == 0.0) {
-        const int i = (int)x;
-        unsafeAtomicAdd(&grid[i].x, Q(hr));
-        unsafeAtomicAdd(&grid[i].y, Q(hi));
-        return;
-    }
-    int ilo = (int)(x - 2.0);  // astype(int): truncation toward zero
-    ilo = min(max(ilo, 0), nfft - 4);
-    const double d0 = x - (double)ilo, d1 = d0 - 1.0, d2 = d0 - 2.0, d3 = d0 - 3.0;
-    // d1..d3 as the reference forms them: x - ilo - k (same value: ilo + k is exact in double)
-    const double prod = ((d0 * d1) * d2) * d3;
-    const double nr = hr * prod, ni = hi * prod;
-    // j = 0..3: ind = ilo + 3 - j, denominators 6, -2, 2, -6
-    const double q3 = 6.0 * d3, q2 = -2.0 * d2, q1 = 2.0 * d1, q0 = -6.0 * d0;
-    unsafeAtomicAdd(&grid[ilo + 3].x, Q(nr / q3));
-    unsafeAtomicAdd(&grid[ilo + 3].y, Q(ni / q3));
-    unsafeAtomicAdd(&grid[ilo + 2].x, Q(nr / q2));
-    unsafeAtomicAdd(&grid[ilo + 2].y, Q(ni / q2));
-    unsafeAtomicAdd(&grid[ilo + 1].x, Q(nr / q1));
-    unsafeAtomicAdd(&grid[ilo + 1].y, Q(ni / q1));
-    unsafeAtomicAdd(&grid[ilo].x, Q(nr / q0));
-    unsafeAtomicAdd(&grid[ilo].y, Q(ni / q0));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < sp.n) {
+            unsafeAtomicAdd(&grid[sp.i0 + k].x, Q(hr * sp.wt[k]));
+            unsafeAtomicAdd(&grid[sp.i0 + k].y, Q(hi * sp.wt[k]));
+        }
 }
 
 // spread every cadence of targets [b0, b0 + nb) into its three grids: 0: w*y at f, 1: w at f, 2: w at 2f
-__global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restrict__ t, const double *__restrict__ w,
-                                                           const double *__restrict__ wy,
+__global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restrict__ t, const double *__restrict__ y,
+                                                           const double *__restrict__ dy,
                                                            const int64_t *__restrict__ n_off,
                                                            const FastStats *__restrict__ stats, int b0, double f0,
                                                            double df, int nfft, int fit_mean,
@@ -245,117 +284,95 @@ __global__ __launch_bounds__(256) void lsf_scatter_kernel(const double *__restri
     const int n = (int)(n_off[b + 1] - lo);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double tt = t[lo + i] - stats[b].t0;
+    const FastStats st = stats[b];
+    const double tt = t[lo + i] - st.t0;
     double2 *g0 = grids + (size_t)blockIdx.y * 3 * nfft, *g1 = g0 + nfft, *g2 = g1 + nfft;
-    const double wi = w[lo + i], wyi = wy[lo + i];
-    const double twopi = 6.283185307179586;
-    const Quantum Q = make_quantum(stats[b].vmax);
+    double wi, wyi;
+    cadence_weights(y, dy, lo + i, st.wsum, st.ybar, wi, wyi);
+    const Quantum Qy = make_quantum(st.vmax), Qw = make_quantum(st.wmax);
     for (int fac = 1; fac <= 2; ++fac) {
         const double dff = df * (double)fac, f0f = f0 * (double)fac;
         double c = 1.0, s = 0.0;
-        if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
-        const double tn = fmod(tt * (double)nfft * dff, (double)nfft);
+        if (f0f > 0.0) phase_factor(f0f, tt, c, s);
+        const Stencil4 sp = stencil4(fmod(tt * (double)nfft * dff, (double)nfft), nfft);
         if (fac == 1) {
-            extirpolate4(g0, nfft, tn, wyi * c, wyi * s, Q);
-            if (fit_mean) extirpolate4(g1, nfft, tn, wi * c, wi * s, Q);
+            extirpolate4(g0, sp, wyi * c, wyi * s, Qy);
+            if (fit_mean) extirpolate4(g1, sp, wi * c, wi * s, Qw);
         } else {
-            extirpolate4(g2, nfft, tn, wi * c, wi * s, Q);
+            extirpolate4(g2, sp, wi * c, wi * s, Qw);
         }
     }
 }
 
-// Owner-computes spreading for ordered targets (sorted time, no wrap): grid positions grow with the cadence index,
-// so workgroup (x, target, g) owns cells [x W, (x+1) W) of grid g and knows from the prep kernel's tables which cadences
-// reach them.  Each of its four waves owns 256 of the cells: it walks ALL the workgroup's cadences and adds the stencil
-// points that fall in its own cells with LDS atomics.  Same-address lanes of one ds_add_f64 are applied in lane order and
-// a wave's LDS instructions execute in program order (tools/microbench/lds_atomic_order.hip), and no cell is touched by
-// two waves, so the accumulation order is fixed: two runs give bit-identical grids.  The cells are written once with
-// plain, coalesced stores — zeros included, so no memset and no global atomics.  g: 0 = w*y at f, 1 = w at f, 2 = w at 2f.
-constexpr int SPREAD_W = SPREAD_W_C;
-
-__global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__restrict__ t, const double *__restrict__ w,
-                                                                const double *__restrict__ wy,
+// Owner-computes spreading for ordered targets (sorted time, no wrap): grid positions grow with the cadence index, so
+// workgroup (x, target) owns cells [x W, (x + 1) W) and each of its four waves 256 of them; the prep kernel's tables give
+// every wave the cadences whose stencils reach its cells — no search.  A lane takes a cadence, forms its weight, phase
+// factor and stencil ONCE and adds the stencil points that fall into the wave's cells with LDS atomics.  blockIdx.z = 0
+// serves the w y AND the w grid at df (same positions, same stencil, same phase: one pass, two accumulators), z = 1 the w
+// grid at 2 df.  Same-address lanes of one ds_add_f64 are applied in lane order and a wave's LDS instructions execute in
+// program order (tools/microbench/lds_atomic_order.hip), and no cell is touched by two waves, so the accumulation order is
+// fixed: two runs give bit-identical grids.  The cells are written once with plain, coalesced stores — zeros included, so no
+// memset and no global atomics.  Weights come straight from y, dy and the prep statistics (nothing per cadence is staged).
+__global__ __launch_bounds__(256) void lsf_spread_owner_kernel(const double *__restrict__ t, const double *__restrict__ y,
+                                                                const double *__restrict__ dy,
                                                                 const int64_t *__restrict__ n_off,
                                                                 const FastStats *__restrict__ stats, int b0, double f0,
                                                                 double df, int nfft, int m2, int fit_mean,
                                                                 double2 *__restrict__ grids,
                                                                 const int *__restrict__ rows_used,
                                                                 const int *__restrict__ spread_tab, int ntab) {
-    __shared__ double2 acc[SPREAD_W];
-    const int lb = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
+    __shared__ double2 acc0[SPREAD_W], acc1[SPREAD_W];
+    const int lb = blockIdx.y, tid = threadIdx.x;
+    const bool pair = blockIdx.z == 0;
     if (!rows_used[lb * 4 + 3]) return;
-    const int ncell = rows_used[lb * 4 + g] << m2;  // cells the column transform will read
+    const int g = pair ? 0 : 2;
+    const int ncell = rows_used[lb * 4 + g] << m2;  // cells the column transform will read (grids 0 and 1: the same count)
     const int c_lo = blockIdx.x * SPREAD_W, c_hi = min(c_lo + SPREAD_W, ncell);
     if (c_lo >= ncell) return;
-    double2 *G = grids + ((size_t)lb * 3 + g) * (size_t)nfft;
-    if (g == 1 && !fit_mean) {  // unused grid: keep it defined
-        for (int c = c_lo + tid; c < c_hi; c += 256) G[c] = make_double2(0.0, 0.0);
-        return;
-    }
+    double2 *G0 = grids + ((size_t)lb * 3 + g) * (size_t)nfft, *G1 = G0 + nfft;
     const int b = b0 + lb;
     const int64_t lo = n_off[b];
-    t += lo;
-    const double t0 = stats[b].t0;
-    const double fac = g == 2 ? 2.0 : 1.0;
+    const FastStats st = stats[b];
+    const double fac = pair ? 1.0 : 2.0;
     const double dff = df * fac, f0f = f0 * fac;
-    const double *amp = (g == 0 ? wy : w) + lo;
-    // cadences whose 4-point stencils can reach this workgroup's cells (lsf_prep_kernel's tables)
-    const int *tab = spread_tab + ((size_t)b * 6 + 2 * g) * ntab;
-    const int i_lo = tab[blockIdx.x], i_hi = tab[ntab + min((int)blockIdx.x + 1, ntab - 1)];
-    for (int c = tid; c < SPREAD_W; c += 256) acc[c] = make_double2(0.0, 0.0);
+    for (int c = tid; c < SPREAD_W; c += 256) {
+        acc0[c] = make_double2(0.0, 0.0);
+        acc1[c] = make_double2(0.0, 0.0);
+    }
     __syncthreads();
-    const double twopi = 6.283185307179586;
-    const int lane = tid & 63, w_lo = c_lo + (tid >> 6) * (SPREAD_W / 4), w_hi = min(w_lo + SPREAD_W / 4, c_hi);
-    auto add = [&](int cell, double vr, double vi) {
-        if (cell >= w_lo && cell < w_hi) {  // this wave's cells only
-            unsafeAtomicAdd(&acc[cell - c_lo].x, vr);
-            unsafeAtomicAdd(&acc[cell - c_lo].y, vi);
-        }
-    };
-    // the wave's own cadences: positions grow with the cadence index, so those whose stencils reach [w_lo, w_hi) are one
-    // run inside [i_lo, i_hi), found by 64-way probes (wave ballots)
-    auto pos = [&](int i) { return fmod((t[i] - t0) * (double)nfft * dff, (double)nfft); };
-    auto lower = [&](double x) -> int {  // first cadence in [i_lo, i_hi) with position >= x
-        int lo_i = i_lo, hi_i = i_hi;
-        while (hi_i - lo_i > 64) {
-            const int stride = (hi_i - lo_i + 63) / 64;
-            const int ip = lo_i + lane * stride;
-            const int cnt = __popcll(__ballot(ip < hi_i && pos(ip) < x));  // probes below x form a prefix
-            if (cnt == 0) {
-                hi_i = lo_i;
-                break;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int w_lo = c_lo + wv * SPREAD_WW, w_hi = min(w_lo + SPREAD_WW, c_hi);
+    if (w_lo < w_hi) {
+        const int *tab = spread_tab + ((size_t)b * 4 + (pair ? 0 : 2)) * ntab;
+        const int kblk = blockIdx.x * (SPREAD_W / SPREAD_WW) + wv;
+        const int i_lo = tab[kblk], i_hi = tab[ntab + min(kblk + 1, ntab - 1)];
+        for (int i = i_lo + lane; i < i_hi; i += 64) {
+            const double tt = t[lo + i] - st.t0;
+            double wi, wyi;
+            cadence_weights(y, dy, lo + i, st.wsum, st.ybar, wi, wyi);
+            double c = 1.0, s = 0.0;
+            if (f0f > 0.0) phase_factor(f0f, tt, c, s);
+            const Stencil4 sp = stencil4(fmod(tt * (double)nfft * dff, (double)nfft), nfft);
+            const double ar = (pair ? wyi : wi) * c, ai = (pair ? wyi : wi) * s, br = wi * c, bi = wi * s;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = sp.i0 + k;
+                if (k < sp.n && cell >= w_lo && cell < w_hi) {  // this wave's cells only
+                    unsafeAtomicAdd(&acc0[cell - c_lo].x, ar * sp.wt[k]);
+                    unsafeAtomicAdd(&acc0[cell - c_lo].y, ai * sp.wt[k]);
+                    if (pair && fit_mean) {
+                        unsafeAtomicAdd(&acc1[cell - c_lo].x, br * sp.wt[k]);
+                        unsafeAtomicAdd(&acc1[cell - c_lo].y, bi * sp.wt[k]);
+                    }
+                }
             }
-            const int nlo = lo_i + (cnt - 1) * stride + 1;
-            hi_i = min(lo_i + cnt * stride, hi_i);
-            lo_i = nlo;
-        }
-        const int i2 = lo_i + lane;
-        return lo_i + __popcll(__ballot(i2 < hi_i && pos(i2) < x));
-    };
-    const int wi_lo = lower((double)w_lo - 4.0), wi_hi = lower((double)w_hi + 3.0);
-    for (int i = wi_lo + lane; i < wi_hi; i += 64) {
-        const double tt = t[i] - t0;
-        double c = 1.0, s = 0.0;
-        if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
-        const double x = fmod(tt * (double)nfft * dff, (double)nfft);
-        const double hr = amp[i] * c, hi = amp[i] * s;
-        if (fmod(x, 1.0) == 0.0) {
-            add((int)x, hr, hi);
-        } else {
-            int ilo = (int)(x - 2.0);
-            ilo = min(max(ilo, 0), nfft - 4);
-            const double d0 = x - (double)ilo, d1 = d0 - 1.0, d2 = d0 - 2.0, d3 = d0 - 3.0;
-            const double prod = ((d0 * d1) * d2) * d3;
-            const double nr = hr * prod, ni = hi * prod;
-            const double q3 = 6.0 * d3, q2 = -2.0 * d2, q1 = 2.0 * d1, q0 = -6.0 * d0;
-            add(ilo + 3, nr / q3, ni / q3);
-            add(ilo + 2, nr / q2, ni / q2);
-            add(ilo + 1, nr / q1, ni / q1);
-            add(ilo, nr / q0, ni / q0);
         }
     }
     __syncthreads();
-    for (int c = c_lo + tid; c < c_hi; c += 256) G[c] = acc[c - c_lo];
+    for (int c = c_lo + tid; c < c_hi; c += 256) {
+        G0[c] = acc0[c - c_lo];
+        if (pair) G1[c] = acc1[c - c_lo];  // (fit_mean = 0: zeros — the unused grid stays defined)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ four-step FFT
@@ -619,6 +636,19 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
             xin[i] = r < ru ? G[(size_t)r * N2 + c0 + f] : make_double2(0.0, 0.0);
         }
     }
+    // Every twiddle of the Q passes is a running product of a handful of roots taken once (the passes used to spend five
+    // sincospi each):   pre-twiddle W_N1^{(i Bq + j) s} = (W_N1^j)^s (W_N1^{Bq s})^i,   intra-transform W_P^{j ka},
+    // inter-step W_N^{c (Q (ka + A kb) + s)} = W_N^{c Q ka} (W_N^c)^s (W_N^{c Q A})^kb
+    auto root = [](double x) {
+        double sn, cs;
+        sincospi(2.0 * x, &sn, &cs);
+        return make_double2(cs, sn);
+    };
+    const double2 wj = root((double)jk * invN1), wq = root((double)Bq * invN1);  // W_N1^j, W_N1^Bq
+    const double2 tw_j = root((double)jk / (double)P);
+    const double2 wc = root((double)(c0 + f) * invN), stepc = root((double)((long long)(c0 + f) * Q * A) * invN);
+    double2 wjs = make_double2(1.0, 0.0), wqs = wjs;                                  // (W_N1^j)^s, (W_N1^Bq)^s
+    double2 wout = root((double)((long long)(c0 + f) * Q * jk) * invN);               // W_N^{c (Q ka + s)}
     for (int s = 0; s < Q; ++s) {
         if (p1) {
             double2 v[A];
@@ -626,22 +656,14 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
 #pragma unroll
                 for (int i = 0; i < A; ++i) v[i] = xin[i];
             } else {
-                // W_N1^{(i Bq + j) s} = e^{2 pi i j s / N1} (e^{2 pi i Bq s / N1})^i
-                double sn, cs;
-                sincospi(2.0 * (double)(jk * s) * invN1, &sn, &cs);
-                double2 w = make_double2(cs, sn);
-                sincospi(2.0 * (double)(Bq * s) * invN1, &sn, &cs);
-                const double2 st = make_double2(cs, sn);
+                double2 w = wjs;
 #pragma unroll
                 for (int i = 0; i < A; ++i) {
                     v[i] = cmul(xin[i], w);
-                    w = cmul(w, st);
+                    w = cmul(w, wqs);
                 }
             }
             reg_fft<LA>(v);
-            double sn, cs;
-            sincospi(2.0 * (double)jk / (double)P, &sn, &cs);  // intra-transform twiddle e^{2 pi i j ka / P}, by running product
-            const double2 tw_j = make_double2(cs, sn);
             double2 w = make_double2(1.0, 0.0);
             double2 *row = lds2 + (size_t)f * FST + jk;
 #pragma unroll
@@ -657,12 +679,7 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
 #pragma unroll
             for (int j = 0; j < Bq; ++j) u[j] = row[j];
             reg_fft<LB>(u);
-            // inter-step twiddle e^{2 pi i c k1 / N}, k1 = Q (ka + A kb) + s: advances by e^{2 pi i c Q A / N} per kb
-            double sn, cs;
-            sincospi(2.0 * (double)((long long)(c0 + f) * Q * A) * invN, &sn, &cs);
-            const double2 stepc = make_double2(cs, sn);
-            sincospi(2.0 * (double)((long long)(c0 + f) * (Q * jk + s)) * invN, &sn, &cs);
-            double2 w = make_double2(cs, sn);
+            double2 w = wout;
 #pragma unroll
             for (int kb = 0; kb < Bq; ++kb) {
                 const int q = jk + A * kb;
@@ -670,6 +687,9 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
                 w = cmul(w, stepc);
             }
         }
+        wjs = cmul(wjs, wj);
+        wqs = cmul(wqs, wq);
+        wout = cmul(wout, wc);
         __syncthreads();
     }
 }
@@ -801,6 +821,248 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
         peaks[((size_t)lb * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (tid >> 6)] = PeakPart{best_v, best_k};
 }
 
+// ---- step 2 for 512-point rows (N2 = 2^9, the configs[1] shape), built for bytes in flight rather than for few LDS passes.
+// The generic kernel above runs the 512-point transform as 32 x 16 with a 32-point register FFT: 222 VGPRs and a 70-KB
+// exchange tile, i.e. two 4-wave workgroups per CU, each with one grid's 64 KB in flight at a time and only half of its
+// threads loading — the kernel waits on HBM with ~40-60 KB outstanding per CU (3.6 TB/s).  Here the transform is 16 x 32:
+//   phase 1  thread (row f, j < 32) loads x[32 i + j], i < 16 — EVERY thread loads, 1 KB contiguous per wave instruction
+//            from the [c / 16][k1][c % 16] intermediate — runs a 16-point register FFT and multiplies by W_512^{j ka};
+//   exchange through LDS as two 8-byte planes (real, then imaginary): half the tile, so twice the workgroups per CU;
+//   phase 2  X[ka + 16 kb] = sum_{j < 32} T[ka][j] W_32^{j kb} is needed for kb < 8 only (k2 < 128 covers M <= 128 N1):
+//            a PAIR of threads (ka, e) splits the sum by the parity of j — thread e runs two 8-point FFTs over
+//            j = j1 + 4 j2, j1 = e, e + 2, combines them with constant 32nd roots, and the two partial sums meet through
+//            one DPP row rotation (lane ^ 8); thread e keeps kb = 4 e .. 4 e + 3 of each grid for the closed form.
+// No thread ever holds more than 16 points.  With PF the loads of grid g + 1 are issued as soon as grid g's points sit in
+// LDS, under phase 2.
+
+__device__ __forceinline__ double dpp_ror8(double x) {  // the value of lane ^ 8 (rotation by 8 inside rows of 16 lanes)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int RT>
+struct Rows512 {
+    static constexpr int LRT = RT == 8 ? 3 : 4;
+    static constexpr int SK = 34;                          // doubles per (row, ka) line: 32 + 2 -> pairs of ka tile the banks
+    static constexpr int SF = 16 * SK + (RT == 8 ? 4 : 2); // doubles per row: the 32 lanes of a ds_read_b64 group hit 32 bank pairs
+    static constexpr int NT = RT * 32;
+    static constexpr size_t LDS_BYTES = (size_t)RT * SF * 8;
+};
+
+template <int RT, int PF, int NTL, int WPE>
+__global__ __launch_bounds__(RT * 32, WPE) void fft_rows512_power_kernel(
+    const double2 *__restrict__ grids, int m1, const int64_t *__restrict__ n_off, const FastStats *__restrict__ stats,
+    int b0, double f0, double df, int64_t M, int fit_mean, int norm, const double *__restrict__ scale,
+    double *__restrict__ power, PeakPart *__restrict__ peaks) {
+    using R = Rows512<RT>;
+    constexpr int LRT = R::LRT, SK = R::SK, SF = R::SF;
+    extern __shared__ __attribute__((aligned(16))) double tile512[];
+    // targets last-written first: the tail of what step 1 has just written is still in the Infinity Cache
+    const int tid = threadIdx.x, lb = gridDim.y - 1 - blockIdx.y, r0 = blockIdx.x * RT;
+    const size_t gstride = (size_t)1 << (m1 + 9);
+    // phase-1 identity: lanes (j % 16, row) make 1-KB runs, j / 16 selects the neighbouring column tile
+    const int jl = tid & 15, f1 = (tid >> 4) & (RT - 1), jh = tid >> (4 + LRT), j = jl + 16 * jh;
+    // phase-2 identity: row fastest (neighbouring lanes write neighbouring frequencies), the pair bit at lane bit 3
+    const int f2 = (tid & 7) | (RT == 16 ? ((tid >> 1) & 8) : 0), e = (tid >> 3) & 1, ka = tid >> (LRT + 1);
+    const double2 *Gt = grids + (size_t)lb * 3 * gstride + ((size_t)jh << (m1 + 4)) + ((size_t)(r0 + f1) << 4) + jl;
+    auto load = [&](double2(&v)[16], int g) {
+        const double2 *G = Gt + (size_t)g * gstride;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (NTL) {
+                const lk_d2v q = __builtin_nontemporal_load(reinterpret_cast<const lk_d2v *>(G + ((size_t)i << (m1 + 5))));
+                v[i] = make_double2(q.x, q.y);
+            } else {
+                v[i] = G[(size_t)i << (m1 + 5)];
+            }
+        }
+    };
+    double2 step1, step4;  // W_512^j, W_512^{4 j}
+    {
+        double s, c;
+        sincospi((double)j * (1.0 / 256.0), &s, &c);
+        step1 = make_double2(c, s);
+        sincospi((double)j * (1.0 / 64.0), &s, &c);
+        step4 = make_double2(c, s);
+    }
+    double2 keep[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[g][q] = make_double2(0.0, 0.0);
+    double *row1 = tile512 + f1 * SF + j;
+    const double *row2 = tile512 + f2 * SF + ka * SK + e;
+    // one grid: the 16 loaded points of v -> keep[G]; `refill` runs once v's last LDS write has been issued (v is dead)
+    auto process = [&](auto Gc, double2(&v)[16], auto refill) {
+        constexpr int G = decltype(Gc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        reg_fft<4>(v);
+        __builtin_amdgcn_sched_barrier(0);
+        // W_512^{j ka}, ka = 4 a + b, as (W^{4 j})^a (W^j)^b: a few twiddles live instead of a chain of fifteen
+        {
+            double2 w = step1;
+#pragma unroll
+            for (int bb = 1; bb < 4; ++bb) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) v[brev_c(4 * a + bb, 4)] = cmul(v[brev_c(4 * a + bb, 4)], w);
+                if (bb < 3) w = cmul(w, step1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            double2 w = step4;
+#pragma unroll
+            for (int a = 1; a < 4; ++a) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) v[brev_c(4 * a + bb, 4)] = cmul(v[brev_c(4 * a + bb, 4)], w);
+                if (a < 3) w = cmul(w, step4);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double ure[16], uim[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) row1[k * SK] = v[brev_c(k, 4)].x;
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) ure[jj] = row2[2 * jj];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) row1[k * SK] = v[brev_c(k, 4)].y;
+        __builtin_amdgcn_sched_barrier(0);
+        refill();
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) uim[jj] = row2[2 * jj];
+        __builtin_amdgcn_sched_barrier(0);
+        double2 s0[8], s1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            s0[q] = make_double2(ure[2 * q], uim[2 * q]);
+            s1[q] = make_double2(ure[2 * q + 1], uim[2 * q + 1]);
+        }
+        reg_fft<3>(s0);
+        __builtin_amdgcn_sched_barrier(0);
+        reg_fft<3>(s1);
+        __builtin_amdgcn_sched_barrier(0);
+        // P[kb] = (e ? W_32^kb : 1) (G0[kb] + W_32^{2 kb} G1[kb]);  X[ka + 16 kb] = P of this thread + P of its partner
+        auto pval = [&](int kb) -> double2 {
+            const double2 a = s0[brev_c(kb, 3)], bq = s1[brev_c(kb, 3)];
+            double2 hsum;
+            if (kb == 0)
+                hsum = make_double2(a.x + bq.x, a.y + bq.y);
+            else if (kb == 4)
+                hsum = make_double2(a.x - bq.y, a.y + bq.x);
+            else
+                hsum = make_double2(a.x + (bq.x * R32C[2 * kb] - bq.y * R32S[2 * kb]),
+                                    a.y + (bq.x * R32S[2 * kb] + bq.y * R32C[2 * kb]));
+            if (kb == 0) return hsum;
+            const double wc = e ? R32C[kb] : 1.0, ws = e ? R32S[kb] : 0.0;
+            return make_double2(hsum.x * wc - hsum.y * ws, hsum.x * ws + hsum.y * wc);
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 plo = pval(q), phi = pval(q + 4);
+            const double2 mine = e ? phi : plo, send = e ? plo : phi;
+            keep[G][q] = make_double2(mine.x + dpp_ror8(send.x), mine.y + dpp_ror8(send.y));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    auto nothing = [] {};
+    // (fit_mean == 0: grid 1 holds zeros — the spreader defines it, step 1 transforms it — and is transformed like the
+    // others; its sums come out as exact zeros)
+    if (PF == 2) {
+        // two register sets: grids 0 and 1 are requested together at the start, grid 2 as soon as grid 0's points sit in LDS —
+        // every load has a whole grid's arithmetic (or more) to arrive
+        double2 va[16], vb[16];
+        load(va, 0);
+        load(vb, 1);
+        process(I0{}, va, [&] { load(va, 2); });
+        __syncthreads();
+        process(I1{}, vb, nothing);
+        __syncthreads();
+        process(I2{}, va, nothing);
+    } else if (PF == 1) {
+        double2 v[16];
+        load(v, 0);
+        process(I0{}, v, [&] { load(v, 1); });
+        __syncthreads();
+        process(I1{}, v, [&] { load(v, 2); });
+        __syncthreads();
+        process(I2{}, v, nothing);
+    } else {
+        double2 v[16];
+        load(v, 0);
+        process(I0{}, v, nothing);
+        __syncthreads();
+        load(v, 1);
+        process(I1{}, v, nothing);
+        __syncthreads();
+        load(v, 2);
+        process(I2{}, v, nothing);
+    }
+    double best_v = 0.0;
+    long long best_k = -1;
+    {
+        const int b = b0 + lb;
+        const FastStats st = stats[b];
+        const double nn = (double)(n_off[b + 1] - n_off[b]);
+        const double sc = scale ? scale[b] : 1.0;
+        const int k1 = r0 + f2;
+        const double twopi = 6.283185307179586;
+        double ph_c = 1.0, ph_s = 0.0, st_c = 1.0, st_s = 0.0;
+        if (st.t0 != 0.0) {
+            const long long kfirst = (long long)k1 + ((long long)(ka + 64 * e) << m1);
+            sincos(twopi * st.t0 * (f0 + df * (double)kfirst), &ph_s, &ph_c);
+            sincos(twopi * st.t0 * (df * (double)((long long)16 << m1)), &st_s, &st_c);
+        }
+        // a rolled loop (the closed form is ~350 instructions per output): the kept outputs rotate through slot 0
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const long long k = (long long)k1 + ((long long)(ka + 16 * (4 * e + q)) << m1);
+            if (k < M) {
+                double2 a = keep[0][0], bq = keep[1][0], c2 = keep[2][0];
+                if (st.t0 != 0.0) {
+                    const double c = ph_c, s = ph_s;
+                    a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+                    bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
+                    const double cc = c * c - s * s, ss = 2.0 * s * c;
+                    c2 = make_double2(c2.x * cc - c2.y * ss, c2.x * ss + c2.y * cc);
+                }
+                const double pw = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY, 0.5 * st.wsum, nn, sc);
+                power[(size_t)b * (size_t)M + k] = pw;
+                if (pw == pw && peak_better(pw, k, best_v, best_k)) {
+                    best_v = pw;
+                    best_k = k;
+                }
+            }
+            const double nc = ph_c * st_c - ph_s * st_s, ns = ph_s * st_c + ph_c * st_s;
+            ph_c = nc;
+            ph_s = ns;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) keep[g][r] = keep[g][r + 1];
+        }
+    }
+    if (peaks == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(best_v, o);
+        const long long k2 = __shfl_xor(best_k, o);
+        if (peak_better(v2, k2, best_v, best_k)) {
+            best_v = v2;
+            best_k = k2;
+        }
+    }
+    if ((tid & 63) == 0)
+        peaks[((size_t)lb * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (tid >> 6)] = PeakPart{best_v, best_k};
+}
+
 // per target: the best of its workgroups' partials -> max_power (NaN if no finite power), argmax (-1 then)
 __global__ __launch_bounds__(64) void lsf_peaks_kernel(const PeakPart *__restrict__ peaks, int nparts, int b0,
                                                         double *__restrict__ max_out, int64_t *__restrict__ arg_out) {
@@ -831,8 +1093,8 @@ __global__ __launch_bounds__(64) void lsf_peaks_kernel(const PeakPart *__restric
 // astropy lombscargle_fastchi2 (fastchi2_impl.py:60-137): the multi-term fit of chi2_impl with every trig sum taken
 // from the extirpolated FFT grids (trig_sum with freq_factor = m).  3 nterms grids per target:
 //   g <  nterms : w (y - ybar) at harmonic g + 1              g >= nterms : w at harmonic g - nterms + 1 (up to 2 nterms)
-__global__ __launch_bounds__(256) void lsf_scatter_multi_kernel(const double *__restrict__ t, const double *__restrict__ w,
-                                                                 const double *__restrict__ wy,
+__global__ __launch_bounds__(256) void lsf_scatter_multi_kernel(const double *__restrict__ t, const double *__restrict__ y,
+                                                                 const double *__restrict__ dy,
                                                                  const int64_t *__restrict__ n_off,
                                                                  const FastStats *__restrict__ stats, int b0, double f0,
                                                                  double df, int nfft, int nterms,
@@ -842,18 +1104,19 @@ __global__ __launch_bounds__(256) void lsf_scatter_multi_kernel(const double *__
     const int n = (int)(n_off[b + 1] - lo);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double tt = t[lo + i] - stats[b].t0;
+    const FastStats st = stats[b];
+    const double tt = t[lo + i] - st.t0;
     double2 *g0 = grids + (size_t)blockIdx.y * 3 * nterms * nfft;
-    const double wi = w[lo + i], wyi = wy[lo + i];
-    const double twopi = 6.283185307179586;
-    const Quantum Q = make_quantum(stats[b].vmax);
+    double wi, wyi;
+    cadence_weights(y, dy, lo + i, st.wsum, st.ybar, wi, wyi);
+    const Quantum Qy = make_quantum(st.vmax), Qw = make_quantum(st.wmax);
     for (int fac = 1; fac <= 2 * nterms; ++fac) {
         const double dff = df * (double)fac, f0f = f0 * (double)fac;
         double c = 1.0, s = 0.0;
-        if (f0f > 0.0) sincos(twopi * f0f * tt, &s, &c);
-        const double tn = fmod(tt * (double)nfft * dff, (double)nfft);
-        extirpolate4(g0 + (size_t)(nterms + fac - 1) * nfft, nfft, tn, wi * c, wi * s, Q);
-        if (fac <= nterms) extirpolate4(g0 + (size_t)(fac - 1) * nfft, nfft, tn, wyi * c, wyi * s, Q);
+        if (f0f > 0.0) phase_factor(f0f, tt, c, s);
+        const Stencil4 sp = stencil4(fmod(tt * (double)nfft * dff, (double)nfft), nfft);
+        extirpolate4(g0 + (size_t)(nterms + fac - 1) * nfft, sp, wi * c, wi * s, Qw);
+        if (fac <= nterms) extirpolate4(g0 + (size_t)(fac - 1) * nfft, sp, wyi * c, wyi * s, Qy);
     }
 }
 
@@ -1021,10 +1284,35 @@ static int rows_power_parts(int m1, int m2) {
 #undef LK_X
 }
 
+template <int RT, int PF, int NTL, int WPE>
+static void launch_rows512_t(lk_handle *h, int m1, int ntargets, const double2 *grids, const FusedArgs &a, hipStream_t stream) {
+    (void)want_lds(h, reinterpret_cast<const void *>(fft_rows512_power_kernel<RT, PF, NTL, WPE>), 160 * 1024);
+    hipLaunchKernelGGL((fft_rows512_power_kernel<RT, PF, NTL, WPE>), dim3((1 << m1) / RT, ntargets), dim3(RT * 32),
+                       Rows512<RT>::LDS_BYTES, stream, grids, m1, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm,
+                       a.scale, a.power, a.peaks);
+}
+
+// the 16 x 32 kernel applies to 512-point rows of the 16-column tiled intermediate with at most 128 kept outputs per row
+static bool rows512_applies(int m1, int m2, int64_t M, int tw) {
+    const long long k2need = (M + ((long long)1 << m1) - 1) >> m1;
+    return m2 == 9 && tw == PRUNED_CT && m1 >= 3 && k2need <= 128;
+}
+
 static bool launch_rows_power(lk_handle *h, int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
                               hipStream_t stream) {
     const int LA = (m2 + 1) / 2, Aa = 1 << LA;
     const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
+    if (rows512_applies(m1, m2, a.M, tw)) {
+        static const int variant = getenv("LK_ROWS_VARIANT") ? atoi(getenv("LK_ROWS_VARIANT")) : 1;  // TEMPORARY (experiments)
+        switch (variant) {
+            case 0: break;
+            case 1: launch_rows512_t<8, 1, 0, 2>(h, m1, ntargets, grids, a, stream); return true;
+            case 2: launch_rows512_t<8, 2, 0, 2>(h, m1, ntargets, grids, a, stream); return true;
+            case 3: launch_rows512_t<8, 2, 1, 2>(h, m1, ntargets, grids, a, stream); return true;
+            case 4: launch_rows512_t<8, 1, 1, 2>(h, m1, ntargets, grids, a, stream); return true;
+            default: launch_rows512_t<8, 0, 0, 3>(h, m1, ntargets, grids, a, stream); return true;
+        }
+    }
     const int kb = (int)((k2need + Aa - 1) / Aa);
     if (kb > 8 || m2 < 4 || m2 > 10) return false;
 #define LK_X(la, lb)                                                            \
@@ -1139,23 +1427,26 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int nfft = 1 << m, m1 = (m + 1) / 2, m2 = m / 2;
     const int N1 = 1 << m1, N2 = 1 << m2;
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
-    const size_t ntot = (size_t)n_off_host[B];
     // targets per chunk: the grids (3 x 16 B x Nfft per target) stay within 2 GiB (smaller chunks leave too few workgroups
     // per launch, larger ones fall out of the Infinity Cache: measured)
     const size_t chunk_bytes = (size_t)2 << 30;
-    const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
+    int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
+    if (getenv("LK_CHUNK_TARGETS")) Bc = std::max(1, std::min(B, atoi(getenv("LK_CHUNK_TARGETS"))));  // TEMPORARY (experiments)
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
     const bool fused = reg_path && rows_power_available(m1, m2, M);
-    const int nparts = fused ? rows_power_parts(m1, m2) : 0;
-    const int ntab = (nfft + SPREAD_W - 1) / SPREAD_W + 2;
+    // peak partials per target: the 16 x 32 kernel leaves one per wave of N1 / 8 four-wave workgroups (the tile width it needs is
+    // only known after the plan, so the larger of the two counts is reserved)
+    const int nparts512 = (m2 == 9) ? (N1 / 8) * 4 : 0;
+    const int nparts_gen = fused ? rows_power_parts(m1, m2) : 0;
+    const int nparts_max = std::max(nparts512, nparts_gen);
+    const int ntab = (nfft + SPREAD_WW - 1) / SPREAD_WW + 2;
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 512 +
                            (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
-                           (size_t)B * 6 * ntab * 4 + (size_t)Bc * (nparts + 1) * sizeof(PeakPart) + 16384);
+                           (size_t)B * 4 * ntab * 4 + (size_t)(B + 1) * nparts_max * sizeof(PeakPart) + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
-    double *d_w = (double *)h->ws.alloc(ntot * 8), *d_wy = (double *)h->ws.alloc(ntot * 8);
     double2 *d_grids = (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16);
     double2 *d_spec = fused ? nullptr : (double2 *)h->ws.alloc((size_t)Bc * 3 * M * 16);
     rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
@@ -1165,20 +1456,21 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     int *d_plan = (int *)h->ws.alloc(64);
-    int *d_tab = reg_path ? (int *)h->ws.alloc((size_t)B * 6 * ntab * 4) : nullptr;
-    PeakPart *d_peaks = (fused && max_out) ? (PeakPart *)h->ws.alloc((size_t)Bc * nparts * sizeof(PeakPart)) : nullptr;
-    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
-                       d_w, d_wy, d_stats, df, nfft, m2, d_rows, d_tab, ntab);
+    int *d_tab = reg_path ? (int *)h->ws.alloc((size_t)B * 4 * ntab * 4) : nullptr;
+    PeakPart *d_peaks = (fused && max_out) ? (PeakPart *)h->ws.alloc((size_t)B * nparts_max * sizeof(PeakPart)) : nullptr;
+    launch_prep(B, nmax, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0, d_stats, df, nfft, m2, d_rows, d_tab, ntab);
     // ---- plan: the pruned column kernel applies when every grid of every target keeps its samples in the first
     // P <= 256 rows (P < N1) and the row kernel can read 16-column tiles.  The decision needs two device words, so
     // the call synchronises `stream` once here (20-30 us against a >= 1 ms step).
-    int lp = 0, n_unordered = B;
+    int lp = 0, n_unordered = B, spread_blocks = (nfft + SPREAD_W - 1) / SPREAD_W;
     if (fused) {
         if (!h->h_plan) LK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h->h_plan), 64, hipHostMallocDefault));
         hipLaunchKernelGGL(lsf_plan_kernel, dim3(1), dim3(256), 0, stream, d_rows, B, d_plan);
         LK_HIP_CHECK(hipMemcpyAsync(h->h_plan, d_plan, 8, hipMemcpyDeviceToHost, stream));
         LK_HIP_CHECK(hipStreamSynchronize(stream));
         n_unordered = h->h_plan[1];
+        // the spreader's workgroups only need to cover the rows that can hold samples
+        spread_blocks = std::min(spread_blocks, (int)((((size_t)std::max(1, h->h_plan[0]) << m2) + SPREAD_W - 1) / SPREAD_W));
         if (m2 >= 8 && m2 <= 10 && N2 >= PRUNED_CT) {
             const int want = std::max(5, ilog2_ceil(std::max(1, h->h_plan[0])));
             if (want <= 8 && want < m1) lp = want;
@@ -1193,7 +1485,12 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         d_gridsB = (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16);
         LK_REQUIRE(d_gridsB != nullptr, "workspace exhausted");
         if (!h->s_aux) {
-            LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+            {
+                int plo = 0, phi = 0;  // TEMPORARY experiment: LK_AUX_PRIO = -1 (high) / 1 (low) / 0 (default)
+                LK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+                const int want = getenv("LK_AUX_PRIO") ? atoi(getenv("LK_AUX_PRIO")) : 0;
+                LK_HIP_CHECK(hipStreamCreateWithPriority(&h->s_aux, hipStreamNonBlocking, want < 0 ? phi : (want > 0 ? plo : (plo + phi) / 2)));
+            }
             for (int i = 0; i < 4; ++i) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
         }
         // s_aux may start once the prep kernel's outputs exist
@@ -1222,20 +1519,22 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
                                d_rows + (size_t)b0 * 4);
         }
         if (!reg_path || n_unordered > 0)
-            hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, ss, t, d_w,
-                               d_wy, d_off, d_stats, b0, f0, df, nfft, fit_mean, gr,
+            hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, ss, t, y,
+                               dy, d_off, d_stats, b0, f0, df, nfft, fit_mean, gr,
                                reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr);
         if (reg_path)
-            hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)((nfft + SPREAD_W - 1) / SPREAD_W), nb, 3),
-                               dim3(256), 0, ss, t, d_w, d_wy, d_off, d_stats, b0, f0, df, nfft, m2, fit_mean,
-                               gr, d_rows + (size_t)b0 * 4, d_tab, ntab);
+            hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)spread_blocks, nb, 2), dim3(256), 0, ss, t, y, dy,
+                               d_off, d_stats, b0, f0, df, nfft, m2, fit_mean, gr, d_rows + (size_t)b0 * 4, d_tab, ntab);
         if (two_streams) {
             LK_HIP_CHECK(hipEventRecord(ev_spread[buf], ss));
             LK_HIP_CHECK(hipStreamWaitEvent(stream, ev_spread[buf], 0));
         }
         if (fused) {
             // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
-            const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power, d_peaks};
+            // peak partials of every chunk side by side: one reduction launch after the last chunk
+            const int nparts = rows512_applies(m1, m2, M, lp ? PRUNED_CT : tw) ? nparts512 : nparts_gen;
+            const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power,
+                               d_peaks ? d_peaks + (size_t)b0 * nparts : nullptr};
             if (lp) {
                 LK_REQUIRE(launch_cols_pruned(h, lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, stream),
                            "no pruned column kernel for 2^%d rows", lp);
@@ -1245,8 +1544,8 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             if (two_streams) LK_HIP_CHECK(hipEventRecord(ev_cols[buf], stream));
             LK_REQUIRE(launch_rows_power(h, m1, m2, nb, d_grids2, fa, lp ? PRUNED_CT : tw, stream),
                        "no step-2 kernel for this layout");
-            if (d_peaks)
-                hipLaunchKernelGGL(lsf_peaks_kernel, dim3(nb), dim3(64), 0, stream, d_peaks, nparts, b0, max_out, arg_out);
+            if (d_peaks && b0 + nb == B)
+                hipLaunchKernelGGL(lsf_peaks_kernel, dim3(B), dim3(64), 0, stream, d_peaks, nparts, 0, max_out, arg_out);
             continue;
         }
         if (reg_path) {
@@ -1295,22 +1594,19 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
     const int nfft = 1 << m, m1 = (m + 1) / 2, m2 = m / 2;
     const int N1 = 1 << m1, N2 = 1 << m2;
     const int NG = 3 * nterms;
-    const size_t ntot = (size_t)n_off_host[B];
     const size_t per_target = (size_t)NG * nfft * 16;
     const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)2 << 30) / per_target));
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 2 * (ntot * 8 + 256) +
+    int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 512 +
                            (size_t)Bc * per_target + (size_t)Bc * NG * M * 16 + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
-    double *d_w = (double *)h->ws.alloc(ntot * 8), *d_wy = (double *)h->ws.alloc(ntot * 8);
     double2 *d_grids = (double2 *)h->ws.alloc((size_t)Bc * per_target);
     double2 *d_spec = (double2 *)h->ws.alloc((size_t)Bc * NG * M * 16);
     rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
-                       d_w, d_wy, d_stats, df, nfft, m2, (int *)nullptr, (int *)nullptr, 0);
+    launch_prep(B, nmax, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0, d_stats, df, nfft, m2, nullptr, nullptr, 0);
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
     if (!reg_path) {
         (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
@@ -1321,8 +1617,8 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
         LK_HIP_CHECK(hipMemsetAsync(d_grids, 0, (size_t)nb * per_target, stream));
-        hipLaunchKernelGGL(lsf_scatter_multi_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, d_w,
-                           d_wy, d_off, d_stats, b0, f0, df, nfft, nterms, d_grids);
+        hipLaunchKernelGGL(lsf_scatter_multi_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, y,
+                           dy, d_off, d_stats, b0, f0, df, nfft, nterms, d_grids);
         if (reg_path) {
             launch_cols_reg(h, m1, m2, nb * NG, d_grids, nullptr, nullptr, 1, stream);
             launch_rows_reg(h, m1, m2, nb * NG, d_grids, (int)M, d_spec, stream);

@@ -172,3 +172,28 @@ def test_peaks_dev_entry_point_matches_host_path():
         assert relmax(d_p[b], ref[b]) < 1e-12
     assert np.array_equal(d_a, np.nanargmax(ref, axis=1))
     assert np.array_equal(d_m, np.nanmax(ref, axis=1))
+
+
+def test_low_amplitude_scatter_paths_keep_their_precision():
+    """the scatter fallback rounds its addends to a per-target quantum so that global atomics commute.  With one
+    quantum scaled by max(w, |w y|) the w (y - ybar) addends of a low-amplitude light curve kept only ~2^-30 of relative
+    precision; the w grids and the w y grids now have their own quanta.  A light curve scaled by 1e-6 (so that |w y| is 1e-6
+    of w) must match the reference port as closely as the unscaled one, relative to its own maximum power — through the
+    unsorted 'fast' path and through fastchi2."""
+    rng = np.random.default_rng(11)
+    tt, yy, ee, _ = synth.ls_target(21, 0, 2500, cadence_days=10.0 / 1440.0)
+    tt = tt - tt[0]
+    p = rng.permutation(len(tt))
+    tt, yy = tt[p], yy[p]                              # unsorted: lsf_scatter_kernel
+    off = np.array([0, len(tt)], dtype=np.int64)
+    M, df = 20000, 0.004
+    for scale in (1.0, 1e-6):
+        ys = yy * scale
+        ref = O.ls_power_fast(tt, ys, None, df, df, M, normalization="psd")
+        got = _capi.ls_fast_batch(tt, ys, off, f0=df, df=df, M=M, normalization="psd")[0]
+        ok = np.isfinite(ref) & (df * (1 + np.arange(M)) * (tt.max() - tt.min()) >= 1.0)
+        assert np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok])) < TOL, scale
+        ref2 = O.ls_power_fastchi2(tt, ys, None, df, df, M, nterms=2, normalization="psd")
+        got2 = _capi.ls_fast_batch(tt, ys, off, f0=df, df=df, M=M, nterms=2, normalization="psd")[0]
+        ok2 = np.isfinite(ref2) & ok
+        assert np.max(np.abs(got2[ok2] - ref2[ok2])) / np.max(np.abs(ref2[ok2])) < TOL, scale
