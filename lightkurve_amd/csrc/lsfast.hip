@@ -61,14 +61,12 @@ __device__ __forceinline__ void cadence_weights(const double *__restrict__ y, co
 // (the shifted-data form: y[0] sits within a few sigma of the mean, so the subtraction costs a digit at most, and a constant
 // light curve still centres to exactly 0).  Targets the owner-computes spreader cannot take (unsorted, wrapping) and the
 // multi-term path need the scales of the scatter kernels' quanta and the bias sum: a second sweep, for those only.
-// Also prefills the target's spreader tables with "past the last cadence" (lsf_tables_kernel overwrites what is not).
 constexpr int PREP_NT = 512;
 __global__ __launch_bounds__(PREP_NT) void lsf_prep_kernel(const double *__restrict__ t, const double *__restrict__ y,
                                                         const double *__restrict__ dy,
                                                         const int64_t *__restrict__ n_off, int center,
                                                         FastStats *__restrict__ stats, double df, int nfft, int m2,
-                                                        int *__restrict__ rows_used, int *__restrict__ spread_tab,
-                                                        int ntab) {
+                                                        int *__restrict__ rows_used) {
     constexpr int NT = PREP_NT;
     __shared__ double sh[NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -87,10 +85,6 @@ __global__ __launch_bounds__(PREP_NT) void lsf_prep_kernel(const double *__restr
     };
     auto bsum = [&](double x) { return breduce(x, [](double a, double b2) { return a + b2; }); };
     auto bmax = [&](double x) { return breduce(x, [](double a, double b2) { return fmax(a, b2); }); };
-    if (spread_tab) {
-        int *tab = spread_tab + (size_t)b * 4 * ntab;
-        for (int k = tid; k < 4 * ntab; k += NT) tab[k] = (int)n;
-    }
     const double y0 = y[lo];
     double A = 0.0, Bz = 0.0, Cz = 0.0, tmin = INFINITY, tmax = -INFINITY;
     int unsorted = 0;
@@ -154,16 +148,17 @@ __global__ __launch_bounds__(PREP_NT) void lsf_prep_kernel(const double *__restr
     if (tid == 0) stats[b] = FastStats{wsum, ybar, YY, t0, yws, wmx, vmx};
 }
 
-// Cadence tables of the owner-computes spreader (ordered targets: grid positions grow with the cadence index), one thread
-// per cadence.  Per frequency step (df: the w y and w grids; 2 df: the third grid) and block k of SPREAD_WW cells:
-//   lo_tab[k] = first cadence with position >= k WW - 4,   hi_tab[k] = first cadence with position >= k WW + 3,
-// so the wave that owns cells [k WW, (k + 1) WW) walks cadences [lo_tab[k], hi_tab[k + 1]) and needs no search.
-// Every cadence fills the thresholds that fall between its predecessor's position and its own; thresholds beyond the last
-// cadence keep the prep kernel's prefill (n).
+// Cadence tables of the owner-computes spreaders (ordered targets: grid positions grow with the cadence index), one thread
+// per cadence.  Per frequency step (df: the w y and w grids; 2 df: the third grid) and block k of W = 2^logW cells:
+//   lo_tab[k] = first cadence with position >= k W - 4,   hi_tab[k] = first cadence with position >= k W + 3,
+// so whoever owns cells [k W, (k + 1) W) walks cadences [lo_tab[k], hi_tab[k + 1]) and needs no search.  W = 256: the waves of
+// lsf_spread_owner_kernel; W = 16: the tile rows of the column kernel with the extirpolation fused in.  Every cadence fills
+// the thresholds that fall between its predecessor's position and its own; the last one also fills those up to the end of
+// the rows that can hold samples (no block beyond them is ever looked up).
 __global__ __launch_bounds__(256) void lsf_tables_kernel(const double *__restrict__ t, const int64_t *__restrict__ n_off,
                                                           const FastStats *__restrict__ stats,
-                                                          const int *__restrict__ rows_used, double df, int nfft,
-                                                          int *__restrict__ spread_tab, int ntab) {
+                                                          const int *__restrict__ rows_used, double df, int nfft, int m2,
+                                                          int logW, int *__restrict__ spread_tab, int ntab) {
     const int b = blockIdx.y;
     if (!rows_used[b * 4 + 3]) return;  // not an owner-spreader target
     const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
@@ -171,7 +166,7 @@ __global__ __launch_bounds__(256) void lsf_tables_kernel(const double *__restric
     if (i >= n) return;
     const double t0 = stats[b].t0;
     int *tab = spread_tab + (size_t)b * 4 * ntab;
-    const double iW = 1.0 / (double)SPREAD_WW, dn = (double)nfft;
+    const double iW = 1.0 / (double)(1 << logW), dn = (double)nfft;
     auto posn = [&](double tt, double dff) {
         const double x = (tt - t0) * dn * dff;
         return x < dn ? x : fmod(x, dn);  // the reference's fmod; the identity for every target the spreader takes
@@ -182,24 +177,19 @@ __global__ __launch_bounds__(256) void lsf_tables_kernel(const double *__restric
         const double dff = df * (gg ? 2.0 : 1.0);
         const double p = posn(ti, dff), pp = i > 0 ? posn(tp, dff) : -1e300;
         int *lo_a = tab + (size_t)(2 * gg) * ntab, *hi_a = lo_a + ntab;
+        const int nfill = min(ntab, (int)((((long long)rows_used[b * 4 + 2 * gg] << m2) >> logW) + 3));
         // thresholds x_k = k W - 4 with pp < x_k <= p
         int k0 = i > 0 ? (int)floor((pp + 4.0) * iW) + 1 : 0, k1 = (int)floor((p + 4.0) * iW);
         for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) lo_a[k] = (int)i;
+        if (i == n - 1)
+            for (int k = max(k1 + 1, 0); k < nfill; ++k) lo_a[k] = (int)n;
         // thresholds x_k = k W + 3
         k0 = i > 0 ? (int)floor((pp - 3.0) * iW) + 1 : 0;
         k1 = (int)floor((p - 3.0) * iW);
         for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) hi_a[k] = (int)i;
+        if (i == n - 1)
+            for (int k = max(k1 + 1, 0); k < nfill; ++k) hi_a[k] = (int)n;
     }
-}
-
-static void launch_prep(int B, int64_t nmax, hipStream_t stream, const double *t, const double *y, const double *dy,
-                        const int64_t *d_off, int center, FastStats *d_stats, double df, int nfft, int m2, int *d_rows,
-                        int *d_tab, int ntab) {
-    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, center, d_stats, df, nfft, m2,
-                       d_rows, d_tab, ntab);
-    if (d_tab)
-        hipLaunchKernelGGL(lsf_tables_kernel, dim3((unsigned)((nmax + 255) / 256), B), dim3(256), 0, stream, t, d_off, d_stats,
-                           d_rows, df, nfft, d_tab, ntab);
 }
 
 // e^{2 pi i f t}: the phase in cycles is reduced exactly first (the rounding error of the product comes back through fma),
@@ -612,24 +602,93 @@ __global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__
 // once and kept in registers over the Q passes; rows keep their natural order k1 = Q q + s.
 constexpr int PRUNED_CT = 16;
 
+// Extirpolation fused in (ordered targets, `tab16` given): the workgroup's input — the cells of its 16 columns in the rows
+// that can hold samples — is not read from a spread grid but built here: the 16-cell-granular tables of lsf_tables_kernel
+// name, for every tile row, the cadences whose 4-point stencils reach it; a wave owns a contiguous range of rows, a group of
+// S lanes serves one row (lane k takes the row's k-th cadence: weight, phase factor, stencil), and the stencil points that
+// fall into the tile are added to an LDS image [row][16] with ds_add_f64 — same-address lanes in lane order, a wave's LDS
+// instructions in program order, no row touched by two waves: a fixed order, bitwise reproducible.  The sample-bearing
+// rows (3.4 MB per target) are then never written to or read from HBM, and no spreader kernel runs beside the FFT kernels
+// (round 3's ran on a second stream and cost the row kernel as much as it took alone).  Other targets (unsorted times,
+// wrapping grids) still come through `grids`, filled by lsf_zero_kernel + lsf_scatter_kernel.
 template <int LP>
 __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols_pruned_kernel(
-    const double2 *__restrict__ grids, int m1, int m2, const int *__restrict__ rows_used, double2 *__restrict__ gout) {
+    const double2 *__restrict__ grids, int m1, int m2, const int *__restrict__ rows_used, double2 *__restrict__ gout,
+    const double *__restrict__ t, const double *__restrict__ y, const double *__restrict__ dy,
+    const int64_t *__restrict__ n_off, const FastStats *__restrict__ stats, int b0, double f0, double df, int fit_mean,
+    const int *__restrict__ tab16, int ntab16) {
     extern __shared__ __attribute__((aligned(16))) double2 lds2[];
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, P = 1 << LP, LDT = Bq + 1, FST = A * LDT + 1;
-    constexpr int CT = PRUNED_CT;
+    constexpr int CT = PRUNED_CT, NT = CT * A;
     const int N1 = 1 << m1, N2 = 1 << m2, Q = N1 >> LP;
     const double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
     const size_t tstride = (size_t)CT << m1, gstride = (size_t)(N2 / CT) * tstride;
     double2 *O = gout + (size_t)blockIdx.y * gstride + (size_t)blockIdx.x * tstride;  // this column tile
     const int c0 = blockIdx.x * CT;
-    const int ru = rows_used[(blockIdx.y / 3) * 4 + (blockIdx.y % 3)];
+    const int lbt = blockIdx.y / 3, g = blockIdx.y % 3;
+    const int ru = rows_used[lbt * 4 + g];
     const int tid = threadIdx.x;
     const int f = tid % CT, jk = tid / CT;  // column of the tile; j (phase 1) or ka (phase 2)
     const bool p1 = jk < Bq, p2 = jk < A;
     const double invN1 = 1.0 / (double)N1, invN = 1.0 / (double)((size_t)1 << (m1 + m2));
     double2 xin[A];
-    if (p1) {
+    if (tab16 != nullptr && rows_used[lbt * 4 + 3]) {
+        double2 *acc = lds2;  // [ru][CT]: ru <= P rows of 256 B fit the exchange tile
+        for (int e = tid; e < ru * CT; e += NT) acc[e] = make_double2(0.0, 0.0);
+        __syncthreads();
+        if (!(g == 1 && !fit_mean)) {  // (the unused grid stays zero)
+            const int b = b0 + lbt;
+            const int64_t lo = n_off[b];
+            const FastStats st = stats[b];
+            const double fac = g == 2 ? 2.0 : 1.0, dff = df * fac, f0f = f0 * fac, dn = (double)((size_t)1 << (m1 + m2));
+            const int nfft = 1 << (m1 + m2);
+            const int *tlo = tab16 + ((size_t)b * 4 + (g == 2 ? 2 : 0)) * ntab16, *thi = tlo + ntab16;
+            // S lanes per row: 19 cells hold ~4 cadences at the usual 5 cells per cadence of the df grids, ~2 at 2 df
+            const int S = g == 2 ? 4 : 8, rpi = 64 / S;
+            const int lane = tid & 63, wv = tid >> 6, rr = lane / S, k = lane - rr * S;
+            const int rpw = (ru + NT / 64 - 1) / (NT / 64);
+            const int r_end = min(ru, (wv + 1) * rpw);
+            for (int rb = wv * rpw; rb < r_end; rb += rpi) {
+                const int r = rb + rr;
+                int i = 0, i_hi = 0;
+                if (r < r_end) {
+                    const int blk = (r << (m2 - 4)) + blockIdx.x;
+                    i = tlo[blk] + k;
+                    i_hi = thi[blk + 1];
+                }
+                const int cbase = (r << m2) + c0;  // first cell of this tile row
+                while (__any(i < i_hi)) {
+                    if (i < i_hi) {
+                        const double tt = t[lo + i] - st.t0;
+                        double wi, wyi;
+                        cadence_weights(y, dy, lo + i, st.wsum, st.ybar, wi, wyi);
+                        double c = 1.0, sn = 0.0;
+                        if (f0f > 0.0) phase_factor(f0f, tt, c, sn);
+                        const Stencil4 sp = stencil4(fmod(tt * dn * dff, dn), nfft);
+                        const double amp = g == 0 ? wyi : wi, ar = amp * c, ai = amp * sn;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned col = (unsigned)(sp.i0 + q - cbase);
+                            if (q < sp.n && col < (unsigned)CT) {
+                                unsafeAtomicAdd(&acc[r * CT + col].x, ar * sp.wt[q]);
+                                unsafeAtomicAdd(&acc[r * CT + col].y, ai * sp.wt[q]);
+                            }
+                        }
+                    }
+                    i += S;
+                }
+            }
+        }
+        __syncthreads();
+        if (p1) {
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const int r = i * Bq + jk;
+                xin[i] = r < ru ? acc[r * CT + f] : make_double2(0.0, 0.0);
+            }
+        }
+        __syncthreads();  // the image is read before the first pass overwrites the tile
+    } else if (p1) {
 #pragma unroll
         for (int i = 0; i < A; ++i) {
             const int r = i * Bq + jk;
@@ -1373,22 +1432,35 @@ __global__ __launch_bounds__(256) void lsf_plan_kernel(const int *__restrict__ r
     }
 }
 
+// the cadence side of the fused extirpolation (tab16 == nullptr: every target's rows come from `grids`)
+struct SpreadArgs {
+    const double *t, *y, *dy;
+    const int64_t *n_off;
+    const FastStats *stats;
+    int b0;
+    double f0, df;
+    int fit_mean;
+    const int *tab16;
+    int ntab16;
+};
+
 template <int LP>
 static void launch_cols_pruned_t(lk_handle *h, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
-                                 double2 *gout, hipStream_t stream) {
+                                 double2 *gout, const SpreadArgs &sa, hipStream_t stream) {
     constexpr int LA = (LP + 1) / 2, LB = LP / 2, A = 1 << LA, Bq = 1 << LB, LDT = Bq + 1, FST = A * LDT + 1;
     (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_pruned_kernel<LP>), 160 * 1024);
     hipLaunchKernelGGL((fft_cols_pruned_kernel<LP>), dim3((1 << m2) / PRUNED_CT, ngrids), dim3(PRUNED_CT * A),
-                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout);
+                       (size_t)PRUNED_CT * FST * 16, stream, grids, m1, m2, rows_used, gout, sa.t, sa.y, sa.dy, sa.n_off,
+                       sa.stats, sa.b0, sa.f0, sa.df, sa.fit_mean, sa.tab16, sa.ntab16);
 }
 
 static bool launch_cols_pruned(lk_handle *h, int lp, int m1, int m2, int ngrids, const double2 *grids, const int *rows_used,
-                               double2 *gout, hipStream_t stream) {
+                               double2 *gout, const SpreadArgs &sa, hipStream_t stream) {
     switch (lp) {
-        case 5: launch_cols_pruned_t<5>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
-        case 6: launch_cols_pruned_t<6>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
-        case 7: launch_cols_pruned_t<7>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
-        case 8: launch_cols_pruned_t<8>(h, m1, m2, ngrids, grids, rows_used, gout, stream); return true;
+        case 5: launch_cols_pruned_t<5>(h, m1, m2, ngrids, grids, rows_used, gout, sa, stream); return true;
+        case 6: launch_cols_pruned_t<6>(h, m1, m2, ngrids, grids, rows_used, gout, sa, stream); return true;
+        case 7: launch_cols_pruned_t<7>(h, m1, m2, ngrids, grids, rows_used, gout, sa, stream); return true;
+        case 8: launch_cols_pruned_t<8>(h, m1, m2, ngrids, grids, rows_used, gout, sa, stream); return true;
         default: return false;
     }
 }
@@ -1428,10 +1500,9 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int N1 = 1 << m1, N2 = 1 << m2;
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
     // targets per chunk: the grids (3 x 16 B x Nfft per target) stay within 2 GiB (smaller chunks leave too few workgroups
-    // per launch, larger ones fall out of the Infinity Cache: measured)
+    // per launch; larger ones measured the same)
     const size_t chunk_bytes = (size_t)2 << 30;
-    int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
-    if (getenv("LK_CHUNK_TARGETS")) Bc = std::max(1, std::min(B, atoi(getenv("LK_CHUNK_TARGETS"))));  // TEMPORARY (experiments)
+    const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
     const bool fused = reg_path && rows_power_available(m1, m2, M);
     // peak partials per target: the 16 x 32 kernel leaves one per wave of N1 / 8 four-wave workgroups (the tile width it needs is
@@ -1439,11 +1510,15 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int nparts512 = (m2 == 9) ? (N1 / 8) * 4 : 0;
     const int nparts_gen = fused ? rows_power_parts(m1, m2) : 0;
     const int nparts_max = std::max(nparts512, nparts_gen);
-    const int ntab = (nfft + SPREAD_WW - 1) / SPREAD_WW + 2;
+    // cadence tables: 256-cell blocks over the whole grid for lsf_spread_owner_kernel, or 16-cell blocks over the (at most
+    // 256) sample-bearing rows for the column kernel with the extirpolation fused in — which one is known after the plan
+    const int ntab256 = (nfft + SPREAD_WW - 1) / SPREAD_WW + 3;
+    const int ntab16 = (m2 >= 8 && m2 <= 10) ? (int)((((size_t)256 << m2) >> 4) + 3) : 0;
+    const int ntab_max = std::max(ntab256, ntab16);
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 512 +
-                           (size_t)Bc * 3 * nfft * 16 * 3 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
-                           (size_t)B * 4 * ntab * 4 + (size_t)(B + 1) * nparts_max * sizeof(PeakPart) + 16384);
+                           (size_t)Bc * 3 * nfft * 16 * 2 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
+                           (size_t)B * 4 * ntab_max * 4 + (size_t)(B + 1) * nparts_max * sizeof(PeakPart) + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     FastStats *d_stats = (FastStats *)h->ws.alloc((size_t)B * sizeof(FastStats));
@@ -1456,9 +1531,10 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     int *d_plan = (int *)h->ws.alloc(64);
-    int *d_tab = reg_path ? (int *)h->ws.alloc((size_t)B * 4 * ntab * 4) : nullptr;
+    int *d_tab = reg_path ? (int *)h->ws.alloc((size_t)B * 4 * ntab_max * 4) : nullptr;
     PeakPart *d_peaks = (fused && max_out) ? (PeakPart *)h->ws.alloc((size_t)B * nparts_max * sizeof(PeakPart)) : nullptr;
-    launch_prep(B, nmax, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0, d_stats, df, nfft, m2, d_rows, d_tab, ntab);
+    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
+                       d_stats, df, nfft, m2, d_rows);
     // ---- plan: the pruned column kernel applies when every grid of every target keeps its samples in the first
     // P <= 256 rows (P < N1) and the row kernel can read 16-column tiles.  The decision needs two device words, so
     // the call synchronises `stream` once here (20-30 us against a >= 1 ms step).
@@ -1476,72 +1552,48 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             if (want <= 8 && want < m1) lp = want;
         }
     }
-    // ---- two streams: the spreader of chunk k+1 (LDS atomics, latency bound) runs on h->s_aux under the FFT kernels
-    // of chunk k (HBM / VALU bound) on the caller's stream; the spread grids are double buffered, events order the
-    // hand-overs.  All s_aux work is consumed through events by `stream`, so the caller still sees one stream.
-    const bool two_streams = fused && B > Bc;
-    double2 *d_gridsB = nullptr;
-    if (two_streams) {
-        d_gridsB = (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16);
-        LK_REQUIRE(d_gridsB != nullptr, "workspace exhausted");
-        if (!h->s_aux) {
-            {
-                int plo = 0, phi = 0;  // TEMPORARY experiment: LK_AUX_PRIO = -1 (high) / 1 (low) / 0 (default)
-                LK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&plo, &phi));
-                const int want = getenv("LK_AUX_PRIO") ? atoi(getenv("LK_AUX_PRIO")) : 0;
-                LK_HIP_CHECK(hipStreamCreateWithPriority(&h->s_aux, hipStreamNonBlocking, want < 0 ? phi : (want > 0 ? plo : (plo + phi) / 2)));
-            }
-            for (int i = 0; i < 4; ++i) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_aux[i], hipEventDisableTiming));
-        }
-        // s_aux may start once the prep kernel's outputs exist
-        LK_HIP_CHECK(hipEventRecord(h->ev_aux[0], stream));
-        LK_HIP_CHECK(hipStreamWaitEvent(h->s_aux, h->ev_aux[0], 0));
-    }
-    hipEvent_t *ev_spread = &h->ev_aux[0], *ev_cols = &h->ev_aux[2];  // [2] each, indexed by the grid buffer
+    // cadence tables for the ordered targets (any there are): 16-cell blocks when the pruned column kernel spreads itself
+    const int ntab = lp ? ntab16 : ntab256;
+    if (reg_path && n_unordered < B)
+        hipLaunchKernelGGL(lsf_tables_kernel, dim3((unsigned)((nmax + 255) / 256), B), dim3(256), 0, stream, t, d_off, d_stats,
+                           d_rows, df, nfft, m2, lp ? 4 : 8, d_tab, ntab);
     if (!reg_path) {
         (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);
         (void)want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
     }
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
-    int chunk = 0;
-    for (int b0 = 0; b0 < B; b0 += Bc, ++chunk) {
+    for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
-        const int buf = two_streams ? (chunk & 1) : 0;
-        double2 *gr = buf ? d_gridsB : d_grids;
-        hipStream_t ss = two_streams ? h->s_aux : stream;  // the spreader's stream
-        if (two_streams && chunk >= 2) LK_HIP_CHECK(hipStreamWaitEvent(ss, ev_cols[buf], 0));  // chunk-2's step 1 has read gr
+        double2 *gr = d_grids;
         // targets that are not "ordered" (unsorted time, or a 2f grid that wraps): zero their live rows, scatter with global
         // atomics.  Skipped when the plan found none (the usual batch).
         if (!reg_path) {
-            LK_HIP_CHECK(hipMemsetAsync(gr, 0, (size_t)nb * 3 * nfft * 16, ss));
+            LK_HIP_CHECK(hipMemsetAsync(gr, 0, (size_t)nb * 3 * nfft * 16, stream));
         } else if (n_unordered > 0) {
-            hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, ss, gr, m1, m2,
+            hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, stream, gr, m1, m2,
                                d_rows + (size_t)b0 * 4);
         }
         if (!reg_path || n_unordered > 0)
-            hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, ss, t, y,
+            hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, y,
                                dy, d_off, d_stats, b0, f0, df, nfft, fit_mean, gr,
                                reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr);
-        if (reg_path)
-            hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)spread_blocks, nb, 2), dim3(256), 0, ss, t, y, dy,
+        // ordered targets: spread by the pruned column kernel itself, or (other shapes) by the owner-computes spreader
+        if (reg_path && !lp && n_unordered < B)
+            hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)spread_blocks, nb, 2), dim3(256), 0, stream, t, y, dy,
                                d_off, d_stats, b0, f0, df, nfft, m2, fit_mean, gr, d_rows + (size_t)b0 * 4, d_tab, ntab);
-        if (two_streams) {
-            LK_HIP_CHECK(hipEventRecord(ev_spread[buf], ss));
-            LK_HIP_CHECK(hipStreamWaitEvent(stream, ev_spread[buf], 0));
-        }
         if (fused) {
-            // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`
+            // step 1 into the second buffer in the tiled layout, step 2 + closed form straight to `power`;
             // peak partials of every chunk side by side: one reduction launch after the last chunk
             const int nparts = rows512_applies(m1, m2, M, lp ? PRUNED_CT : tw) ? nparts512 : nparts_gen;
             const FusedArgs fa{d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power,
                                d_peaks ? d_peaks + (size_t)b0 * nparts : nullptr};
             if (lp) {
-                LK_REQUIRE(launch_cols_pruned(h, lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, stream),
+                const SpreadArgs sa{t, y, dy, d_off, d_stats, b0, f0, df, fit_mean, n_unordered < B ? d_tab : nullptr, ntab};
+                LK_REQUIRE(launch_cols_pruned(h, lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, sa, stream),
                            "no pruned column kernel for 2^%d rows", lp);
             } else {
                 launch_cols_reg(h, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
             }
-            if (two_streams) LK_HIP_CHECK(hipEventRecord(ev_cols[buf], stream));
             LK_REQUIRE(launch_rows_power(h, m1, m2, nb, d_grids2, fa, lp ? PRUNED_CT : tw, stream),
                        "no step-2 kernel for this layout");
             if (d_peaks && b0 + nb == B)
@@ -1606,7 +1658,8 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
     double2 *d_spec = (double2 *)h->ws.alloc((size_t)Bc * NG * M * 16);
     rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
     if (rc) return rc;
-    launch_prep(B, nmax, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0, d_stats, df, nfft, m2, nullptr, nullptr, 0);
+    hipLaunchKernelGGL(lsf_prep_kernel, dim3(B), dim3(PREP_NT), 0, stream, t, y, dy, d_off, (fit_mean || center_data) ? 1 : 0,
+                       d_stats, df, nfft, m2, (int *)nullptr);
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
     if (!reg_path) {
         (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);

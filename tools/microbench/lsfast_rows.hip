@@ -147,7 +147,7 @@ int main(int argc, char **argv) {
         float total = 0.f;
         for (int r = 0; r < 7; ++r) {
             CK(hipEventRecord(e0, 0));
-            launch_cols_pruned_t<8>(&h, m1, m2, B * 3, d_in, d_rows, d_mid, 0);
+            launch_cols_pruned_t<8>(&h, m1, m2, B * 3, d_in, d_rows, d_mid, SpreadArgs{nullptr, nullptr, nullptr, d_off, d_stats, 0, f0, df, 1, nullptr, 0}, 0);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms;
