@@ -155,6 +155,7 @@ __global__ __launch_bounds__(PREP_NT) void lsf_prep_kernel(const double *__restr
 // lsf_spread_owner_kernel; W = 16: the tile rows of the column kernel with the extirpolation fused in.  Every cadence fills
 // the thresholds that fall between its predecessor's position and its own; the last one also fills those up to the end of
 // the rows that can hold samples (no block beyond them is ever looked up).
+constexpr int TAB_PER_LANE = 8;  // cadences per lane of lsf_tables_kernel: a wave takes 512 consecutive ones
 __global__ __launch_bounds__(256) void lsf_tables_kernel(const double *__restrict__ t, const int64_t *__restrict__ n_off,
                                                           const FastStats *__restrict__ stats,
                                                           const int *__restrict__ rows_used, double df, int nfft, int m2,
@@ -162,33 +163,51 @@ __global__ __launch_bounds__(256) void lsf_tables_kernel(const double *__restric
     const int b = blockIdx.y;
     if (!rows_used[b * 4 + 3]) return;  // not an owner-spreader target
     const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * TAB_PER_LANE);  // this wave's first cadence
+    if (base >= n) return;
     const double t0 = stats[b].t0;
     int *tab = spread_tab + (size_t)b * 4 * ntab;
     const double iW = 1.0 / (double)(1 << logW), dn = (double)nfft;
-    auto posn = [&](double tt, double dff) {
-        const double x = (tt - t0) * dn * dff;
+    auto posn = [&](double tt) {
+        const double x = (tt - t0) * dn * df;
         return x < dn ? x : fmod(x, dn);  // the reference's fmod; the identity for every target the spreader takes
     };
-    const double ti = t[lo + i], tp = i > 0 ? t[lo + i - 1] : 0.0;
+    // positions at df of the wave's cadences (short-lived one-cadence waves were bound by their two dependent loads); at
+    // 2 df a position is exactly twice as large (a scaling by 2 commutes with every rounding; ordered targets do not wrap)
+    double p1[TAB_PER_LANE];
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-        const double dff = df * (gg ? 2.0 : 1.0);
-        const double p = posn(ti, dff), pp = i > 0 ? posn(tp, dff) : -1e300;
-        int *lo_a = tab + (size_t)(2 * gg) * ntab, *hi_a = lo_a + ntab;
-        const int nfill = min(ntab, (int)((((long long)rows_used[b * 4 + 2 * gg] << m2) >> logW) + 3));
-        // thresholds x_k = k W - 4 with pp < x_k <= p
-        int k0 = i > 0 ? (int)floor((pp + 4.0) * iW) + 1 : 0, k1 = (int)floor((p + 4.0) * iW);
-        for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) lo_a[k] = (int)i;
-        if (i == n - 1)
-            for (int k = max(k1 + 1, 0); k < nfill; ++k) lo_a[k] = (int)n;
-        // thresholds x_k = k W + 3
-        k0 = i > 0 ? (int)floor((pp - 3.0) * iW) + 1 : 0;
-        k1 = (int)floor((p - 3.0) * iW);
-        for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) hi_a[k] = (int)i;
-        if (i == n - 1)
-            for (int k = max(k1 + 1, 0); k < nfill; ++k) hi_a[k] = (int)n;
+    for (int u = 0; u < TAB_PER_LANE; ++u) {
+        const int64_t i = base + 64 * u + lane;
+        p1[u] = posn(t[lo + (i < n ? i : n - 1)]);
+    }
+    const int nf0 = min(ntab, (int)((((long long)rows_used[b * 4 + 0] << m2) >> logW) + 3));
+    const int nf2 = min(ntab, (int)((((long long)rows_used[b * 4 + 2] << m2) >> logW) + 3));
+    double prev_last = base > 0 ? posn(t[lo + base - 1]) : -1e300;  // the position before this wave's first cadence
+#pragma unroll
+    for (int u = 0; u < TAB_PER_LANE; ++u) {
+        const int64_t i = base + 64 * u + lane;
+        double pp1 = __shfl_up(p1[u], 1);
+        if (lane == 0) pp1 = prev_last;
+        prev_last = __shfl(p1[u], 63);
+        if (i >= n) continue;
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const double p = gg ? 2.0 * p1[u] : p1[u], pp = i > 0 ? (gg ? 2.0 * pp1 : pp1) : -1e300;
+            int *lo_a = tab + (size_t)(2 * gg) * ntab, *hi_a = lo_a + ntab;
+            const int nfill = gg ? nf2 : nf0;
+            // thresholds x_k = k W - 4 with pp < x_k <= p
+            int k0 = i > 0 ? (int)floor((pp + 4.0) * iW) + 1 : 0, k1 = (int)floor((p + 4.0) * iW);
+            for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) lo_a[k] = (int)i;
+            if (i == n - 1)
+                for (int k = max(k1 + 1, 0); k < nfill; ++k) lo_a[k] = (int)n;
+            // thresholds x_k = k W + 3
+            k0 = i > 0 ? (int)floor((pp - 3.0) * iW) + 1 : 0;
+            k1 = (int)floor((p - 3.0) * iW);
+            for (int k = max(k0, 0); k <= min(k1, ntab - 1); ++k) hi_a[k] = (int)i;
+            if (i == n - 1)
+                for (int k = max(k1 + 1, 0); k < nfill; ++k) hi_a[k] = (int)n;
+        }
     }
 }
 
@@ -648,34 +667,58 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
             const int lane = tid & 63, wv = tid >> 6, rr = lane / S, k = lane - rr * S;
             const int rpw = (ru + NT / 64 - 1) / (NT / 64);
             const int r_end = min(ru, (wv + 1) * rpw);
-            for (int rb = wv * rpw; rb < r_end; rb += rpi) {
-                const int r = rb + rr;
-                int i = 0, i_hi = 0;
-                if (r < r_end) {
-                    const int blk = (r << (m2 - 4)) + blockIdx.x;
-                    i = tlo[blk] + k;
-                    i_hi = thi[blk + 1];
-                }
+            // one visit: cadence i's stencil points that fall into tile row r
+            auto visit = [&](int r, double ti, double yi, double di) {
+                const double tt = ti - st.t0;
+                const double wi = (1.0 / (di * di)) / st.wsum, wyi = wi * (yi - st.ybar);  // (= cadence_weights)
+                double c = 1.0, sn = 0.0;
+                if (f0f > 0.0) phase_factor(f0f, tt, c, sn);
+                const double xp = tt * dn * dff;
+                const Stencil4 sp = stencil4(xp < dn ? xp : fmod(xp, dn), nfft);
+                const double amp = g == 0 ? wyi : wi, ar = amp * c, ai = amp * sn;
                 const int cbase = (r << m2) + c0;  // first cell of this tile row
-                while (__any(i < i_hi)) {
-                    if (i < i_hi) {
-                        const double tt = t[lo + i] - st.t0;
-                        double wi, wyi;
-                        cadence_weights(y, dy, lo + i, st.wsum, st.ybar, wi, wyi);
-                        double c = 1.0, sn = 0.0;
-                        if (f0f > 0.0) phase_factor(f0f, tt, c, sn);
-                        const Stencil4 sp = stencil4(fmod(tt * dn * dff, dn), nfft);
-                        const double amp = g == 0 ? wyi : wi, ar = amp * c, ai = amp * sn;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const unsigned col = (unsigned)(sp.i0 + q - cbase);
-                            if (q < sp.n && col < (unsigned)CT) {
-                                unsafeAtomicAdd(&acc[r * CT + col].x, ar * sp.wt[q]);
-                                unsafeAtomicAdd(&acc[r * CT + col].y, ai * sp.wt[q]);
-                            }
-                        }
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned col = (unsigned)(sp.i0 + q - cbase);
+                    if (q < sp.n && col < (unsigned)CT) {
+                        unsafeAtomicAdd(&acc[r * CT + col].x, ar * sp.wt[q]);
+                        unsafeAtomicAdd(&acc[r * CT + col].y, ai * sp.wt[q]);
                     }
-                    i += S;
+                }
+            };
+            // four row groups at a time: their table entries, then their cadences, are all requested before the first is used
+            constexpr int UN = 4;
+            for (int rb = wv * rpw; rb < r_end; rb += UN * rpi) {
+                int ii[UN], ih[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int r = rb + u * rpi + rr;
+                    ii[u] = ih[u] = 0;
+                    if (r < r_end) {
+                        const int blk = (r << (m2 - 4)) + blockIdx.x;
+                        ii[u] = tlo[blk] + k;
+                        ih[u] = thi[blk + 1];
+                    }
+                }
+                double tv[UN], yv[UN], dv[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const bool ok = ii[u] < ih[u];
+                    const int64_t ix = lo + (ok ? ii[u] : 0);
+                    tv[u] = t[ix];
+                    yv[u] = y[ix];
+                    dv[u] = dy ? dy[ix] : 1.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int r = rb + u * rpi + rr;
+                    if (ii[u] < ih[u]) visit(r, tv[u], yv[u], dv[u]);
+                    // rows with more than S cadences (dense sampling): further rounds, still in cadence order
+                    int i = ii[u] + S;
+                    while (__any(i < ih[u])) {
+                        if (i < ih[u]) visit(r, t[lo + i], y[lo + i], dy ? dy[lo + i] : 1.0);
+                        i += S;
+                    }
                 }
             }
         }
@@ -883,17 +926,20 @@ __global__ __launch_bounds__(512) void fft_rows_power_kernel(const double2 *__re
 // ---- step 2 for 512-point rows (N2 = 2^9, the configs[1] shape), built for bytes in flight rather than for few LDS passes.
 // The generic kernel above runs the 512-point transform as 32 x 16 with a 32-point register FFT: 222 VGPRs and a 70-KB
 // exchange tile, i.e. two 4-wave workgroups per CU, each with one grid's 64 KB in flight at a time and only half of its
-// threads loading — the kernel waits on HBM with ~40-60 KB outstanding per CU (3.6 TB/s).  Here the transform is 16 x 32:
+// threads loading — it waits on HBM with ~40-60 KB outstanding per CU (3.6 TB/s in the round-3 trace).  Here the transform
+// is 16 x 32:
 //   phase 1  thread (row f, j < 32) loads x[32 i + j], i < 16 — EVERY thread loads, 1 KB contiguous per wave instruction
 //            from the [c / 16][k1][c % 16] intermediate — runs a 16-point register FFT and multiplies by W_512^{j ka};
-//   exchange through LDS as two 8-byte planes (real, then imaginary): half the tile, so twice the workgroups per CU;
+//   exchange through LDS as two 8-byte planes (real, then imaginary): 35 KB instead of 70;
 //   phase 2  X[ka + 16 kb] = sum_{j < 32} T[ka][j] W_32^{j kb} is needed for kb < 8 only (k2 < 128 covers M <= 128 N1):
 //            a PAIR of threads (ka, e) splits the sum by the parity of j — thread e runs two 8-point FFTs over
 //            j = j1 + 4 j2, j1 = e, e + 2, combines them with constant 32nd roots, and the two partial sums meet through
 //            one DPP row rotation (lane ^ 8); thread e keeps kb = 4 e .. 4 e + 3 of each grid for the closed form.
-// No thread ever holds more than 16 points.  With PF the loads of grid g + 1 are issued as soon as grid g's points sit in
-// LDS, under phase 2.
-
+// No thread ever holds more than 16 points, so the next grid's 64 KB are requested the moment a grid's points sit in LDS,
+// under phase 2.  Loads are non-temporal (each byte is read once), targets go last-written first (the tail of what step 1
+// has just written is still in the Infinity Cache).  Measured alone on an 85-target chunk: 430 us = 5.1 TB/s against 560-610 us for the generic kernel
+// (tools/microbench/lsfast_rows.hip has the variants that were tried: no prefetch at 3 or 4 waves per SIMD — spills —, two
+// register sets, 16-row tiles).
 __device__ __forceinline__ double dpp_ror8(double x) {  // the value of lane ^ 8 (rotation by 8 inside rows of 16 lanes)
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true);
@@ -901,41 +947,39 @@ __device__ __forceinline__ double dpp_ror8(double x) {  // the value of lane ^ 8
     return __hiloint2double(hi, lo);
 }
 
-template <int RT>
 struct Rows512 {
-    static constexpr int LRT = RT == 8 ? 3 : 4;
-    static constexpr int SK = 34;                          // doubles per (row, ka) line: 32 + 2 -> pairs of ka tile the banks
-    static constexpr int SF = 16 * SK + (RT == 8 ? 4 : 2); // doubles per row: the 32 lanes of a ds_read_b64 group hit 32 bank pairs
+    static constexpr int RT = 8;             // rows per tile
+    static constexpr int SK = 34;            // doubles per (row, ka) line: 32 + 2 -> pairs of ka tile the banks
+    static constexpr int SF = 16 * SK + 4;   // doubles per row: the 32 lanes of a ds_read_b64 group hit 32 bank pairs
     static constexpr int NT = RT * 32;
     static constexpr size_t LDS_BYTES = (size_t)RT * SF * 8;
 };
 
-template <int RT, int PF, int NTL, int WPE>
-__global__ __launch_bounds__(RT * 32, WPE) void fft_rows512_power_kernel(
-    const double2 *__restrict__ grids, int m1, const int64_t *__restrict__ n_off, const FastStats *__restrict__ stats,
-    int b0, double f0, double df, int64_t M, int fit_mean, int norm, const double *__restrict__ scale,
-    double *__restrict__ power, PeakPart *__restrict__ peaks) {
-    using R = Rows512<RT>;
-    constexpr int LRT = R::LRT, SK = R::SK, SF = R::SF;
+__global__ __launch_bounds__(Rows512::NT, 2) void fft_rows512_power_kernel(
+    const double2 *__restrict__ grids, int m1, int ntargets, const int64_t *__restrict__ n_off,
+    const FastStats *__restrict__ stats, int b0, double f0, double df, int64_t M, int fit_mean, int norm,
+    const double *__restrict__ scale, double *__restrict__ power, PeakPart *__restrict__ peaks) {
+    using R = Rows512;
+    constexpr int RT = R::RT, SK = R::SK, SF = R::SF;
     extern __shared__ __attribute__((aligned(16))) double tile512[];
-    // targets last-written first: the tail of what step 1 has just written is still in the Infinity Cache
-    const int tid = threadIdx.x, lb = gridDim.y - 1 - blockIdx.y, r0 = blockIdx.x * RT;
+    const int tid = threadIdx.x;
     const size_t gstride = (size_t)1 << (m1 + 9);
+    const int tiles_per_target = (1 << m1) / RT;
     // phase-1 identity: lanes (j % 16, row) make 1-KB runs, j / 16 selects the neighbouring column tile
-    const int jl = tid & 15, f1 = (tid >> 4) & (RT - 1), jh = tid >> (4 + LRT), j = jl + 16 * jh;
+    const int jl = tid & 15, f1 = (tid >> 4) & (RT - 1), jh = tid >> 7, j = jl + 16 * jh;
     // phase-2 identity: row fastest (neighbouring lanes write neighbouring frequencies), the pair bit at lane bit 3
-    const int f2 = (tid & 7) | (RT == 16 ? ((tid >> 1) & 8) : 0), e = (tid >> 3) & 1, ka = tid >> (LRT + 1);
-    const double2 *Gt = grids + (size_t)lb * 3 * gstride + ((size_t)jh << (m1 + 4)) + ((size_t)(r0 + f1) << 4) + jl;
-    auto load = [&](double2(&v)[16], int g) {
-        const double2 *G = Gt + (size_t)g * gstride;
+    const int f2 = tid & 7, e = (tid >> 3) & 1, ka = tid >> 4;
+    // tile T: targets last-written first
+    auto tile_base = [&](int T) {
+        const int lbT = ntargets - 1 - T / tiles_per_target, r0T = (T % tiles_per_target) * RT;
+        return grids + (size_t)lbT * 3 * gstride + ((size_t)jh << (m1 + 4)) + ((size_t)(r0T + f1) << 4) + jl;
+    };
+    double2 v[16];
+    auto load = [&](const double2 *G) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (NTL) {
-                const lk_d2v q = __builtin_nontemporal_load(reinterpret_cast<const lk_d2v *>(G + ((size_t)i << (m1 + 5))));
-                v[i] = make_double2(q.x, q.y);
-            } else {
-                v[i] = G[(size_t)i << (m1 + 5)];
-            }
+            const lk_d2v q = __builtin_nontemporal_load(reinterpret_cast<const lk_d2v *>(G + ((size_t)i << (m1 + 5))));
+            v[i] = make_double2(q.x, q.y);
         }
     };
     double2 step1, step4;  // W_512^j, W_512^{4 j}
@@ -947,14 +991,10 @@ __global__ __launch_bounds__(RT * 32, WPE) void fft_rows512_power_kernel(
         step4 = make_double2(c, s);
     }
     double2 keep[3][4];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) keep[g][q] = make_double2(0.0, 0.0);
     double *row1 = tile512 + f1 * SF + j;
     const double *row2 = tile512 + f2 * SF + ka * SK + e;
     // one grid: the 16 loaded points of v -> keep[G]; `refill` runs once v's last LDS write has been issued (v is dead)
-    auto process = [&](auto Gc, double2(&v)[16], auto refill) {
+    auto process = [&](auto Gc, auto refill) {
         constexpr int G = decltype(Gc)::value;
         __builtin_amdgcn_sched_barrier(0);
         reg_fft<4>(v);
@@ -1031,95 +1071,81 @@ __global__ __launch_bounds__(RT * 32, WPE) void fft_rows512_power_kernel(
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    auto nothing = [] {};
-    // (fit_mean == 0: grid 1 holds zeros — the spreader defines it, step 1 transforms it — and is transformed like the
-    // others; its sums come out as exact zeros)
-    if (PF == 2) {
-        // two register sets: grids 0 and 1 are requested together at the start, grid 2 as soon as grid 0's points sit in LDS —
-        // every load has a whole grid's arithmetic (or more) to arrive
-        double2 va[16], vb[16];
-        load(va, 0);
-        load(vb, 1);
-        process(I0{}, va, [&] { load(va, 2); });
-        __syncthreads();
-        process(I1{}, vb, nothing);
-        __syncthreads();
-        process(I2{}, va, nothing);
-    } else if (PF == 1) {
-        double2 v[16];
-        load(v, 0);
-        process(I0{}, v, [&] { load(v, 1); });
-        __syncthreads();
-        process(I1{}, v, [&] { load(v, 2); });
-        __syncthreads();
-        process(I2{}, v, nothing);
-    } else {
-        double2 v[16];
-        load(v, 0);
-        process(I0{}, v, nothing);
-        __syncthreads();
-        load(v, 1);
-        process(I1{}, v, nothing);
-        __syncthreads();
-        load(v, 2);
-        process(I2{}, v, nothing);
-    }
-    double best_v = 0.0;
-    long long best_k = -1;
+    // one tile per workgroup.  (Persistent workgroups that request the next tile's first grid under the closed form were
+    // measured: the 64 prefetch registers live across the closed form push the kernel into scratch, 620 against 430 us.)
+    const int T = blockIdx.x;
+    const double2 *Gt = tile_base(T);
+    load(Gt);
     {
-        const int b = b0 + lb;
-        const FastStats st = stats[b];
-        const double nn = (double)(n_off[b + 1] - n_off[b]);
-        const double sc = scale ? scale[b] : 1.0;
-        const int k1 = r0 + f2;
-        const double twopi = 6.283185307179586;
-        double ph_c = 1.0, ph_s = 0.0, st_c = 1.0, st_s = 0.0;
-        if (st.t0 != 0.0) {
-            const long long kfirst = (long long)k1 + ((long long)(ka + 64 * e) << m1);
-            sincos(twopi * st.t0 * (f0 + df * (double)kfirst), &ph_s, &ph_c);
-            sincos(twopi * st.t0 * (df * (double)((long long)16 << m1)), &st_s, &st_c);
-        }
-        // a rolled loop (the closed form is ~350 instructions per output): the kept outputs rotate through slot 0
+        const int lb = ntargets - 1 - T / tiles_per_target, r0 = (T % tiles_per_target) * RT;
+        // (fit_mean == 0: grid 1 holds zeros — step 1 transforms the zero rows — and is transformed like the others; its
+        // sums come out as exact zeros)
+        process(I0{}, [&] { load(Gt + gstride); });
+        __syncthreads();
+        process(I1{}, [&] { load(Gt + 2 * gstride); });
+        __syncthreads();
+        process(I2{}, [] {});
+        double best_v = 0.0;
+        long long best_k = -1;
+        {
+            const int b = b0 + lb;
+            const FastStats st = stats[b];
+            const double nn = (double)(n_off[b + 1] - n_off[b]);
+            const double sc = scale ? scale[b] : 1.0;
+            const int k1 = r0 + f2;
+            const double twopi = 6.283185307179586;
+            double ph_c = 1.0, ph_s = 0.0, st_c = 1.0, st_s = 0.0;
+            if (st.t0 != 0.0) {
+                // e^{2 pi i t0 f} for this thread's outputs: one sincos for the first and one for the step between consecutive
+                // ones (a rotation by 2 pi t0 df 16 N1), the 2f phase by the double-angle formulas
+                const long long kfirst = (long long)k1 + ((long long)(ka + 64 * e) << m1);
+                sincos(twopi * st.t0 * (f0 + df * (double)kfirst), &ph_s, &ph_c);
+                sincos(twopi * st.t0 * (df * (double)((long long)16 << m1)), &st_s, &st_c);
+            }
+            // a rolled loop (the closed form is ~350 instructions per output): the kept outputs rotate through slot 0
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-            const long long k = (long long)k1 + ((long long)(ka + 16 * (4 * e + q)) << m1);
-            if (k < M) {
-                double2 a = keep[0][0], bq = keep[1][0], c2 = keep[2][0];
-                if (st.t0 != 0.0) {
-                    const double c = ph_c, s = ph_s;
-                    a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
-                    bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
-                    const double cc = c * c - s * s, ss = 2.0 * s * c;
-                    c2 = make_double2(c2.x * cc - c2.y * ss, c2.x * ss + c2.y * cc);
+            for (int q = 0; q < 4; ++q) {
+                const long long k = (long long)k1 + ((long long)(ka + 16 * (4 * e + q)) << m1);
+                if (k < M) {
+                    double2 a = keep[0][0], bq = keep[1][0], c2 = keep[2][0];
+                    if (st.t0 != 0.0) {
+                        const double c = ph_c, s = ph_s;
+                        a = make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+                        bq = make_double2(bq.x * c - bq.y * s, bq.x * s + bq.y * c);
+                        const double cc = c * c - s * s, ss = 2.0 * s * c;
+                        c2 = make_double2(c2.x * cc - c2.y * ss, c2.x * ss + c2.y * cc);
+                    }
+                    const double pw = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY, 0.5 * st.wsum, nn, sc);
+                    power[(size_t)b * (size_t)M + k] = pw;
+                    if (pw == pw && peak_better(pw, k, best_v, best_k)) {  // ascending k within the thread
+                        best_v = pw;
+                        best_k = k;
+                    }
                 }
-                const double pw = gls_power_sums(a.y, a.x, bq.y, bq.x, c2.y, c2.x, fit_mean, norm, st.YY, 0.5 * st.wsum, nn, sc);
-                power[(size_t)b * (size_t)M + k] = pw;
-                if (pw == pw && peak_better(pw, k, best_v, best_k)) {
-                    best_v = pw;
-                    best_k = k;
+                const double nc = ph_c * st_c - ph_s * st_s, ns = ph_s * st_c + ph_c * st_s;
+                ph_c = nc;
+                ph_s = ns;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) keep[g][r] = keep[g][r + 1];
+            }
+        }
+        if (peaks != nullptr) {
+            // one partial per wave and tile (shuffles only): lsf_peaks_kernel reduces a target's tiles x waves
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double v2 = __shfl_xor(best_v, o);
+                const long long k2 = __shfl_xor(best_k, o);
+                if (peak_better(v2, k2, best_v, best_k)) {
+                    best_v = v2;
+                    best_k = k2;
                 }
             }
-            const double nc = ph_c * st_c - ph_s * st_s, ns = ph_s * st_c + ph_c * st_s;
-            ph_c = nc;
-            ph_s = ns;
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) keep[g][r] = keep[g][r + 1];
+            if ((tid & 63) == 0)
+                peaks[((size_t)lb * tiles_per_target + (T % tiles_per_target)) * (R::NT / 64) + (tid >> 6)] = PeakPart{best_v, best_k};
         }
     }
-    if (peaks == nullptr) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(best_v, o);
-        const long long k2 = __shfl_xor(best_k, o);
-        if (peak_better(v2, k2, best_v, best_k)) {
-            best_v = v2;
-            best_k = k2;
-        }
-    }
-    if ((tid & 63) == 0)
-        peaks[((size_t)lb * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (tid >> 6)] = PeakPart{best_v, best_k};
 }
 
 // per target: the best of its workgroups' partials -> max_power (NaN if no finite power), argmax (-1 then)
@@ -1343,18 +1369,16 @@ static int rows_power_parts(int m1, int m2) {
 #undef LK_X
 }
 
-template <int RT, int PF, int NTL, int WPE>
-static void launch_rows512_t(lk_handle *h, int m1, int ntargets, const double2 *grids, const FusedArgs &a, hipStream_t stream) {
-    (void)want_lds(h, reinterpret_cast<const void *>(fft_rows512_power_kernel<RT, PF, NTL, WPE>), 160 * 1024);
-    hipLaunchKernelGGL((fft_rows512_power_kernel<RT, PF, NTL, WPE>), dim3((1 << m1) / RT, ntargets), dim3(RT * 32),
-                       Rows512<RT>::LDS_BYTES, stream, grids, m1, a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm,
-                       a.scale, a.power, a.peaks);
-}
-
 // the 16 x 32 kernel applies to 512-point rows of the 16-column tiled intermediate with at most 128 kept outputs per row
 static bool rows512_applies(int m1, int m2, int64_t M, int tw) {
     const long long k2need = (M + ((long long)1 << m1) - 1) >> m1;
     return m2 == 9 && tw == PRUNED_CT && m1 >= 3 && k2need <= 128;
+}
+
+static void launch_rows512(lk_handle *h, int m1, int ntargets, const double2 *grids, const FusedArgs &a, hipStream_t stream) {
+    const int ntiles = ((1 << m1) / Rows512::RT) * ntargets;  // two 4-wave workgroups per CU (256 VGPRs, 35 KB of LDS each)
+    hipLaunchKernelGGL(fft_rows512_power_kernel, dim3(ntiles), dim3(Rows512::NT), Rows512::LDS_BYTES, stream, grids, m1, ntargets,
+                       a.n_off, a.stats, a.b0, a.f0, a.df, a.M, a.fit_mean, a.norm, a.scale, a.power, a.peaks);
 }
 
 static bool launch_rows_power(lk_handle *h, int m1, int m2, int ntargets, const double2 *grids, const FusedArgs &a, int tw,
@@ -1362,15 +1386,8 @@ static bool launch_rows_power(lk_handle *h, int m1, int m2, int ntargets, const 
     const int LA = (m2 + 1) / 2, Aa = 1 << LA;
     const long long k2need = (a.M + ((long long)1 << m1) - 1) >> m1;
     if (rows512_applies(m1, m2, a.M, tw)) {
-        static const int variant = getenv("LK_ROWS_VARIANT") ? atoi(getenv("LK_ROWS_VARIANT")) : 1;  // TEMPORARY (experiments)
-        switch (variant) {
-            case 0: break;
-            case 1: launch_rows512_t<8, 1, 0, 2>(h, m1, ntargets, grids, a, stream); return true;
-            case 2: launch_rows512_t<8, 2, 0, 2>(h, m1, ntargets, grids, a, stream); return true;
-            case 3: launch_rows512_t<8, 2, 1, 2>(h, m1, ntargets, grids, a, stream); return true;
-            case 4: launch_rows512_t<8, 1, 1, 2>(h, m1, ntargets, grids, a, stream); return true;
-            default: launch_rows512_t<8, 0, 0, 3>(h, m1, ntargets, grids, a, stream); return true;
-        }
+        launch_rows512(h, m1, ntargets, grids, a, stream);
+        return true;
     }
     const int kb = (int)((k2need + Aa - 1) / Aa);
     if (kb > 8 || m2 < 4 || m2 > 10) return false;
@@ -1502,7 +1519,8 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     // targets per chunk: the grids (3 x 16 B x Nfft per target) stay within 2 GiB (smaller chunks leave too few workgroups
     // per launch; larger ones measured the same)
     const size_t chunk_bytes = (size_t)2 << 30;
-    const int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
+    int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
+    if (Bc >= 8) Bc &= ~3;  // N1 / 8 row tiles per target x a multiple of 4 targets: a whole number of rounds of 2 x 256 workgroups
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
     const bool fused = reg_path && rows_power_available(m1, m2, M);
     // peak partials per target: the 16 x 32 kernel leaves one per wave of N1 / 8 four-wave workgroups (the tile width it needs is
@@ -1555,7 +1573,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     // cadence tables for the ordered targets (any there are): 16-cell blocks when the pruned column kernel spreads itself
     const int ntab = lp ? ntab16 : ntab256;
     if (reg_path && n_unordered < B)
-        hipLaunchKernelGGL(lsf_tables_kernel, dim3((unsigned)((nmax + 255) / 256), B), dim3(256), 0, stream, t, d_off, d_stats,
+        hipLaunchKernelGGL(lsf_tables_kernel, dim3((unsigned)((nmax + 256 * TAB_PER_LANE - 1) / (256 * TAB_PER_LANE)), B), dim3(256), 0, stream, t, d_off, d_stats,
                            d_rows, df, nfft, m2, lp ? 4 : 8, d_tab, ntab);
     if (!reg_path) {
         (void)want_lds(h, reinterpret_cast<const void *>(fft_cols_kernel), 100 * 1024);

@@ -1,5 +1,5 @@
 // Microbenchmark of LS-fast step 2 (row transforms + closed form) on gfx950: the generic 32 x 16 kernel against the
-// 16 x 32 kernel family fft_rows512_power_kernel<RT, PF, NTL, WPE>, on a synthetic 85-target chunk (2.1 GB of intermediate),
+// 16 x 32 kernel fft_rows512_power_kernel, on a synthetic 85-target chunk (2.1 GB of intermediate),
 // each timed on "cold" data (written long ago) and right after a kernel that rewrites the intermediate (what the pipeline
 // does: the column kernel has just written it).  Also times the column kernel.  Every variant's spectra are compared with
 // the generic kernel's.
@@ -123,24 +123,14 @@ int main(int argc, char **argv) {
         a.power = p;
         launch_rows_power_t<5, 4, 4>(&h, m1, B, d_mid, a, PRUNED_CT, 0);
     }, d_pref, mid_bytes);
-#define VARIANT(RT, PF, NTL, WPE)                                                                                          \
-    {                                                                                                                      \
-        char nm[96];                                                                                                       \
-        snprintf(nm, sizeof nm, "rows512 RT=%d PF=%d NT=%d WPE=%d", RT, PF, NTL, WPE);                                      \
-        (void)want_lds(&h, reinterpret_cast<const void *>(fft_rows512_power_kernel<RT, PF, NTL, WPE>), 160 * 1024);        \
-        timeit(nm, [&](double *p) {                                                                                         \
-            hipLaunchKernelGGL((fft_rows512_power_kernel<RT, PF, NTL, WPE>), dim3(N1 / RT, B), dim3(RT * 32),               \
-                               Rows512<RT>::LDS_BYTES, 0, d_mid, m1, d_off, d_stats, 0, f0, df, M, 1, LK_NORM_LK_AMPLITUDE, \
-                               (const double *)nullptr, p, d_peaks);                                                       \
-        }, d_p, mid_bytes);                                                                                                \
-        compare(nm);                                                                                                       \
-    }
-    VARIANT(8, 1, 0, 2)
-    VARIANT(8, 2, 0, 2)
-    VARIANT(8, 2, 1, 2)
-    VARIANT(8, 0, 0, 3)
-    VARIANT(16, 2, 0, 2)
-    VARIANT(16, 2, 0, 1)
+    // ---- the 16 x 32 kernel (prefetch of the next grid, non-temporal loads)
+    (void)want_lds(&h, reinterpret_cast<const void *>(fft_rows512_power_kernel), 160 * 1024);
+    timeit("rows512 16x32 (2 WG/CU)", [&](double *p) {
+        FusedArgs a = fa;
+        a.power = p;
+        launch_rows512(&h, m1, B, d_mid, a, 0);
+    }, d_p, mid_bytes);
+    compare("rows512");
     // ---- column kernel (reads the spread rows, writes the intermediate)
     {
         const double cbytes = (double)ng * 16 + (double)B * (103 + 103 + 205) * N2 * 16;
