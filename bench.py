@@ -132,6 +132,7 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("gloo")
+    from lightkurve_amd import distributed as LD
     from lightkurve_amd.distributed import shard_bounds
     total = args.total_targets or args.targets * world
     bounds = strong_bounds(args, world) if args.total_targets else np.arange(world + 1) * args.targets
@@ -156,11 +157,11 @@ def dry_run(args, rank, world):
             full = torch.full((world, Bmax, Md), -1.0, dtype=torch.float64)
             for c in range(nch):
                 out = torch.empty((world, int(cb[c + 1] - cb[c]), Md), dtype=torch.float64)
-                dist.all_gather_into_tensor(out.view(-1, Md), pad[int(cb[c]):int(cb[c + 1])].contiguous())
+                LD.all_gather_equal(out, pad[int(cb[c]):int(cb[c + 1])])
                 full[:, int(cb[c]):int(cb[c + 1])] = out
         else:
             full = torch.empty((world, Bmax, Md), dtype=torch.float64)
-            dist.all_gather_into_tensor(full.view(world * Bmax, Md), pad)
+            LD.all_gather_equal(full, pad)
         for r in range(world):
             nr = int(bounds[r + 1] - bounds[r])
             want = torch.arange(int(bounds[r]), int(bounds[r]) + nr, dtype=torch.float64)
@@ -473,6 +474,7 @@ def main():
     import torch
     import torch.distributed as dist
     from lightkurve_amd import _capi, synth
+    from lightkurve_amd import distributed as LD
     from lightkurve_amd.distributed import shard_bounds
 
     if not torch.cuda.is_available():
@@ -825,11 +827,12 @@ def main():
                         if d_powpad is not None:
                             d_powpad[:B] = d_pow
                             src = d_powpad
-                        works.append(dist.all_gather_into_tensor(d_all[c], src[int(cb[c]):int(cb[c + 1])], async_op=True))
+                        # the product's collective (lightkurve_amd.distributed): device tensors in, device tensors out
+                        works.append(LD.all_gather_equal(d_all[c], src[int(cb[c]):int(cb[c + 1])], async_op=True))
                 if gather_sum:   # every rank ends with every target's (max power, argmax): 16 B per target over xGMI
                     d_sum[:B, 0] = d_max
                     d_sum[:B, 1] = d_arg.to(torch.float64)
-                    dist.all_gather_into_tensor(d_sum_all.view(world * Bmax, 2), d_sum)
+                    LD.all_gather_equal(d_sum_all, d_sum)
                 for w in works:
                     w.wait()
             return step

@@ -347,6 +347,26 @@ int lk_pld_design_batch_dev(lk_handle *h, int B, int N, int P, int Pb, const flo
                             int pld_order, int pca_components, int n_knots, int spline_degree, int normalize_bkg,
                             int K, double *X, double *prior_sigma, void *stream);
 
+/* ---- Standalone design-matrix operations (correctors/designmatrix.py) for B same-shaped matrices ----------------
+ * lk_pca_batch          <- DesignMatrix.pca(nterms), designmatrix.py:252-282 (fbpca.pca(values, nterms) -> U): the first
+ *                          k = nterms left singular vectors of the column-centred matrix; A: B x N x P row-major,
+ *                          U: B x N x k.  A basis of the same subspace as the reference's (fbpca is a randomised range
+ *                          finder: columns are defined up to sign, and up to rotation inside a degenerate cluster).
+ *                          1 <= k <= min(48, P), P <= 4096.
+ * lk_spline_basis_batch <- create_spline_matrix, designmatrix.py:952-997 (patsy bs(x, ..., include_intercept=True) - 1):
+ *                          x: B x N; knots: B x (n_inner + 2) = [lower bound, interior knots, upper bound];
+ *                          out: B x N x (n_inner + degree + 1).  (include_intercept=False drops column 0.)
+ * lk_standardize_batch  <- DesignMatrix.standardize, designmatrix.py:215-250: per column, zeros are missing values;
+ *                          (x - nanmedian) / nanstd of the rest, missing -> 0, constant columns unchanged. */
+int lk_pca_batch(lk_handle *h, int B, int N, int P, int k, const double *A, double *U);
+int lk_pca_batch_dev(lk_handle *h, int B, int N, int P, int k, const double *A, double *U, void *stream);
+int lk_spline_basis_batch(lk_handle *h, int B, int N, const double *x, const double *knots, int n_inner, int degree,
+                          double *out);
+int lk_spline_basis_batch_dev(lk_handle *h, int B, int N, const double *x, const double *knots, int n_inner, int degree,
+                              double *out, void *stream);
+int lk_standardize_batch(lk_handle *h, int B, int N, int P, const double *A, double *out);
+int lk_standardize_batch_dev(lk_handle *h, int B, int N, int P, const double *A, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

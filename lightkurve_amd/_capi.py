@@ -140,6 +140,14 @@ SIGNATURES = [
     ("lk_pld_design_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_pca_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
+    ("lk_pca_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_spline_basis_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp, ctypes.c_int, ctypes.c_int, _c_dp]),
+    ("lk_spline_basis_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    ("lk_standardize_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
+    ("lk_standardize_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
 ]
 
 _lib = None
@@ -610,6 +618,54 @@ def pld_design_batch(pld_pix, bkg_pix, lc_flux, time, knots, pld_order, pca_comp
                                     _ptr(time), _ptr(knots), n_inner, int(pld_order), int(pca_components), n_knots,
                                     int(spline_degree), int(bool(normalize_bkg)), K, _ptr(X), _ptr(ps)))
     return X, ps
+
+
+# --------------------------------------------------------------------------------------------- design-matrix operations
+def pca_batch(A, nterms, device=0):
+    """``DesignMatrix.pca`` (reference correctors/designmatrix.py:252-282) for B same-shaped matrices: A (B, N, P) or (N, P)
+    -> the first ``nterms`` left singular vectors of each column-centred matrix, (B, N, nterms) / (N, nterms)."""
+    h = Handle.get(device)
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    single = A.ndim == 2
+    if single:
+        A = A[None]
+    if A.ndim != 3:
+        raise ValueError("A must be (B, N, P) or (N, P)")
+    B, N, P = A.shape
+    k = int(nterms)
+    U = np.empty((B, N, k), dtype=np.float64)
+    _check(_lib.lk_pca_batch(h._h, B, N, P, k, _ptr(A), _ptr(U)))
+    return U[0] if single else U
+
+
+def spline_basis_batch(x, knots, degree=3, device=0):
+    """Clamped B-spline basis (patsy ``bs(x, knots=..., degree, include_intercept=True)``) of x (B, N) or (N,) on
+    knots (B, n_inner + 2) / (n_inner + 2,) = [lower bound, interior knots, upper bound] -> (B, N, n_inner + degree + 1)."""
+    h = Handle.get(device)
+    x, knots = _f64(x), _f64(knots)
+    single = x.ndim == 1
+    if single:
+        x, knots = x[None], knots[None]
+    B, N = x.shape
+    if knots.ndim != 2 or knots.shape[0] != B or knots.shape[1] < 2:
+        raise ValueError("knots must be (B, n_inner + 2)")
+    n_inner = knots.shape[1] - 2
+    out = np.empty((B, N, n_inner + int(degree) + 1), dtype=np.float64)
+    _check(_lib.lk_spline_basis_batch(h._h, B, N, _ptr(x), _ptr(knots), n_inner, int(degree), _ptr(out)))
+    return out[0] if single else out
+
+
+def standardize_batch(A, device=0):
+    """``DesignMatrix.standardize`` (reference correctors/designmatrix.py:215-250): A (B, N, P) or (N, P) -> same shape."""
+    h = Handle.get(device)
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    single = A.ndim == 2
+    if single:
+        A = A[None]
+    B, N, P = A.shape
+    out = np.empty_like(A)
+    _check(_lib.lk_standardize_batch(h._h, B, N, P, _ptr(A), _ptr(out)))
+    return out[0] if single else out
 
 
 # --------------------------------------------------------------------------------------------- batch ingest (N4)

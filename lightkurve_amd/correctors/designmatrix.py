@@ -1,13 +1,20 @@
-"""Dense design-matrix containers (reference: src/lightkurve/correctors/designmatrix.py:28-130, 284-304, 387-444).
+"""Dense design-matrix containers (reference: src/lightkurve/correctors/designmatrix.py:28-130, 167-349, 387-444) and the
+spline builders (:896-997).
 
 pandas-free: the values are a float64 (cadences x regressors) ndarray; column names, name, prior_mu and
-prior_sigma carry the same meaning as in the reference (prior_sigma defaults to +inf = no prior)."""
+prior_sigma carry the same meaning as in the reference (prior_sigma defaults to +inf = no prior).  ``pca``, ``standardize``
+and ``create_spline_matrix`` run on the GPU (lk_pca_batch, lk_standardize_batch, lk_spline_basis_batch)."""
 import copy as _copy
+import warnings
 
 import numpy as np
 
 __all__ = ["DesignMatrix", "DesignMatrixCollection", "SparseDesignMatrix", "SparseDesignMatrixCollection",
-           "create_sparse_spline_matrix"]
+           "create_sparse_spline_matrix", "create_spline_matrix", "LightkurveWarning"]
+
+
+class LightkurveWarning(Warning):
+    """Mirror of lightkurve.utils.LightkurveWarning (the class the reference's validate() warns with)."""
 
 
 class DesignMatrix(object):
@@ -55,9 +62,70 @@ class DesignMatrix(object):
         dm.prior_sigma = np.append(self.prior_sigma, prior_sigma)
         return dm
 
-    def validate(self, rank=False):
-        if self.values.shape[1] != len(self.prior_mu) or self.values.shape[1] != len(self.prior_sigma):
-            raise ValueError("prior_mu and prior_sigma must have one entry per column")
+    def split(self, row_indices, inplace=False):
+        """Every regressor split over len(row_indices) + 1 columns that are non-zero on consecutive row ranges only
+        (reference :167-213): shape (n_rows, (len(row_indices) + 1) * n_columns), priors repeated per range, column
+        "name" of range i renamed "name i+1"."""
+        if isinstance(row_indices, (int, np.integer)):
+            row_indices = [int(row_indices)]
+        if row_indices is None or len(row_indices) == 0 or list(row_indices) == [0]:
+            return self
+        lower = np.append(0, row_indices).astype(int)
+        upper = np.append(row_indices, self.shape[0]).astype(int)
+        n, k = self.shape
+        vals = np.zeros((n, k * len(lower)))
+        cols = []
+        for idx, (a, b) in enumerate(zip(lower, upper)):
+            vals[a:b, idx * k:(idx + 1) * k] = self.values[a:b]
+            cols += ["{} {}".format(c, idx + 1) for c in self.columns]
+        dm = self if inplace else self.copy()
+        dm.values = vals
+        dm.columns = cols
+        dm.prior_mu = np.hstack([self.prior_mu for _ in lower])
+        dm.prior_sigma = np.hstack([self.prior_sigma for _ in lower])
+        return dm
+
+    def standardize(self, inplace=False, device=0):
+        """Columns median-subtracted and sigma-divided, zeros treated as missing, constant columns unchanged (reference
+        :215-250) — on the GPU (lk_standardize_batch: one radix-select median per column)."""
+        from .. import _capi
+        dm = self if inplace else self.copy()
+        dm.values = _capi.standardize_batch(self.values, device=device)
+        return dm
+
+    def pca(self, nterms=6, n_iter=10, device=0):
+        """A new DesignMatrix whose ``nterms`` columns are the leading left singular vectors of the column-centred matrix
+        (reference :252-282, which calls the randomised ``fbpca.pca(values, nterms, n_iter)``; ``n_iter`` is accepted and
+        ignored: the GPU path iterates its subspace to a 1e-10 residual, i.e. to the exact singular subspace)."""
+        from .. import _capi
+        if nterms > self.shape[1]:
+            nterms = self.shape[1]
+        return DesignMatrix(_capi.pca_batch(self.values, nterms, device=device), name=self.name)
+
+    @property
+    def rank(self):
+        return np.linalg.matrix_rank(self.values)
+
+    def _validate(self, rank=True):
+        """Reference :306-337: LightkurveWarning for a matrix whose rank is below half its column count, ValueError for
+        priors of the wrong length and for prior widths <= 0 (which would otherwise reach the kernel's 1 / sigma^2)."""
+        if rank and self.shape[1] > 0:
+            r = self.rank
+            if r < 0.5 * self.shape[1]:
+                warnings.warn("The design matrix has low rank ({}) compared to the number of columns ({}), which suggests "
+                              "that the matrix contains duplicate or correlated columns. This may prevent the regression "
+                              "from succeeding. Consider reducing the dimensionality by calling the `pca()` method."
+                              "".format(r, self.shape[1]), LightkurveWarning)
+        if self.prior_mu is not None and len(self.prior_mu) != self.shape[1]:
+            raise ValueError("`prior_mu` must have shape {}".format(self.shape[1]))
+        if self.prior_sigma is not None:
+            if len(self.prior_sigma) != self.shape[1]:
+                raise ValueError("`prior_sigma` must have shape {}".format(self.shape[1]))
+            if np.any(np.asarray(self.prior_sigma) <= 0):
+                raise ValueError("`prior_sigma` values cannot be smaller than or equal to zero")
+
+    def validate(self, rank=True):
+        self._validate(rank=rank)
 
     def __repr__(self):
         return "{} DesignMatrix {}".format(self.name, self.shape)
@@ -117,6 +185,10 @@ class SparseDesignMatrix(DesignMatrix):
     row), so a sparse matrix is accepted and densified at construction; names, priors and collection semantics are the
     reference's."""
 
+    def validate(self, rank=False):
+        """Rank checks are off by default for sparse matrices (reference designmatrix.py:339-349)."""
+        self._validate(rank=rank)
+
     def __repr__(self):
         return "{} SparseDesignMatrix {}".format(self.name, self.shape)
 
@@ -160,3 +232,26 @@ def create_sparse_spline_matrix(x, n_knots=20, knots=None, degree=3, name="splin
     cols = [_spline_basis_vector(x, degree, idx, knots_wbounds) for idx in np.arange(-1, len(knots_wbounds) - degree - 1)]
     cols = [c for c in cols if c.sum() != 0]
     return SparseDesignMatrix(np.column_stack(cols), name=name)
+
+
+def create_spline_matrix(x, n_knots=20, knots=None, degree=3, name="spline", include_intercept=True, device=0):
+    """DesignMatrix of B-splines as ``patsy.dmatrix("bs(x, df|knots, degree, include_intercept) - 1")`` builds it (reference
+    designmatrix.py:952-997): with ``knots`` the given interior knots, otherwise ``n_knots`` = df columns whose interior
+    knots are equally spaced quantiles of x (numpy's linear-interpolation percentiles, as patsy takes them); the boundary
+    knots are min(x) and max(x).  The basis itself is evaluated on the GPU (lk_spline_basis_batch, de Boor)."""
+    from .. import _capi
+    x = np.asarray(x, dtype=np.float64)
+    order = int(degree) + 1
+    if knots is not None:
+        inner = np.sort(np.asarray(knots, dtype=np.float64))
+    else:
+        n_inner = int(n_knots) - order + (0 if include_intercept else 1)
+        if n_inner < 0:
+            raise ValueError("df={} is too small for degree={}; must be >= {}".format(
+                n_knots, degree, order - (0 if include_intercept else 1)))
+        inner = np.percentile(x, np.linspace(0, 100, n_inner + 2)[1:-1]) if n_inner > 0 else np.zeros(0)
+    full = np.concatenate([[np.min(x)], inner, [np.max(x)]])
+    basis = _capi.spline_basis_batch(x, full, degree=degree, device=device)
+    if not include_intercept:
+        basis = basis[:, 1:]
+    return DesignMatrix(basis, columns=["knot{}".format(i + 1) for i in range(basis.shape[1])], name=name)

@@ -602,6 +602,76 @@ int lk_pld_design_batch(lk_handle *h, int B, int N, int P, int Pb, const float *
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ design-matrix operations
+int lk_pca_batch_dev(lk_handle *h, int B, int N, int P, int k, const double *A, double *U, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::dm_pca_launch(h, B, N, P, k, A, U, static_cast<hipStream_t>(stream));
+}
+
+int lk_pca_batch(lk_handle *h, int B, int N, int P, int k, const double *A, double *U) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 1 && N >= 1 && P >= 1 && k >= 1 && A && U, "bad arguments");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ab = (size_t)B * N * P * 8, ub = (size_t)B * N * k * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(ab + ub + 1024);
+    if (rc) return rc;
+    double *dA = (double *)h->staging.alloc(ab), *dU = (double *)h->staging.alloc(ub);
+    LK_HIP_CHECK(hipMemcpy(dA, A, ab, hipMemcpyHostToDevice));
+    rc = lk::dm_pca_launch(h, B, N, P, k, dA, dU, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(U, dU, ub, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
+int lk_spline_basis_batch_dev(lk_handle *h, int B, int N, const double *x, const double *knots, int n_inner, int degree,
+                              double *out, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::dm_spline_launch(h, B, N, x, knots, n_inner, degree, out, static_cast<hipStream_t>(stream));
+}
+
+int lk_spline_basis_batch(lk_handle *h, int B, int N, const double *x, const double *knots, int n_inner, int degree,
+                          double *out) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 1 && N >= 1 && n_inner >= 0 && degree >= 0 && x && knots && out, "bad arguments");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t xb = (size_t)B * N * 8, kb = (size_t)B * (n_inner + 2) * 8, ob = (size_t)B * N * (n_inner + degree + 1) * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(xb + kb + ob + 1024);
+    if (rc) return rc;
+    double *dx = (double *)h->staging.alloc(xb), *dk = (double *)h->staging.alloc(kb), *dout = (double *)h->staging.alloc(ob);
+    LK_HIP_CHECK(hipMemcpy(dx, x, xb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dk, knots, kb, hipMemcpyHostToDevice));
+    rc = lk::dm_spline_launch(h, B, N, dx, dk, n_inner, degree, dout, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
+int lk_standardize_batch_dev(lk_handle *h, int B, int N, int P, const double *A, double *out, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    return lk::dm_standardize_launch(h, B, N, P, A, out, static_cast<hipStream_t>(stream));
+}
+
+int lk_standardize_batch(lk_handle *h, int B, int N, int P, const double *A, double *out) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 1 && N >= 1 && P >= 1 && A && out, "bad arguments");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t ab = (size_t)B * N * P * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(2 * ab + 1024);
+    if (rc) return rc;
+    double *dA = (double *)h->staging.alloc(ab), *dO = (double *)h->staging.alloc(ab);
+    LK_HIP_CHECK(hipMemcpy(dA, A, ab, hipMemcpyHostToDevice));
+    rc = lk::dm_standardize_launch(h, B, N, P, dA, dO, nullptr);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipMemcpy(out, dO, ab, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ pinned host memory
 int lk_host_alloc(void **ptr, size_t bytes) {
     LK_REQUIRE(ptr != nullptr, "ptr is NULL");

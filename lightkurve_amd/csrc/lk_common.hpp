@@ -119,6 +119,10 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
                       int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,
                       double *prior_sigma, hipStream_t stream);
 int pld_design_width(int P, int Pb, int pld_order, int pca_components, int n_knots);
+int dm_pca_launch(lk_handle *h, int B, int N, int P, int k, const double *A, double *U, hipStream_t stream);
+int dm_spline_launch(lk_handle *h, int B, int N, const double *x, const double *knots, int n_inner, int degree, double *out,
+                     hipStream_t stream);
+int dm_standardize_launch(lk_handle *h, int B, int N, int P, const double *A, double *out, hipStream_t stream);
 int fold_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *period_host,
                 const double *epoch_time_host, double epoch_phase, const double *wrap_phase_host, int normalize_phase,
                 int ncols, const double *const *cols_in, double *const *cols_out, double *phase, int64_t *order,

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void pld_prior_kernel(const float *__restrict_
 
 // clamped B-spline basis (patsy bs(x, df, degree, include_intercept=True)) + constant column
 __global__ void pld_spline_kernel(const double *__restrict__ time, const double *__restrict__ knots, int n_inner,
-                                  int degree, int N, int ldx, int col0, double *__restrict__ X) {
+                                  int degree, int N, int ldx, int col0, double *__restrict__ X, int with_const) {
     const int b = blockIdx.y;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -591,7 +591,7 @@ __global__ void pld_spline_kernel(const double *__restrict__ time, const double 
         return kn[1 + i - order];
     };
     double *row = X + ((size_t)b * N + n) * ldx + col0;
-    for (int j = 0; j <= nb; ++j) row[j] = j == nb ? 1.0 : 0.0;
+    for (int j = 0; j < nb + with_const; ++j) row[j] = j == nb ? 1.0 : 0.0;
     // knot span: largest mu with T(mu) <= x < T(mu+1), the right end belongs to the last non-empty span
     int mu = order - 1;
     const int last = order + n_inner - 1;
@@ -1770,9 +1770,51 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     if (rc) return rc;
     col += kb;
     hipLaunchKernelGGL(pld_spline_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, time, knots, n_inner,
-                       spline_degree, N, K, col, X);
+                       spline_degree, N, K, col, X, 1);
     hipLaunchKernelGGL(pld_prior_kernel, dim3(B), dim3(256), 0, stream, lc_flux, N, K, n_pld_cols, pca_components,
                        prior_sigma);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// ---------------------------------------------------------------------------------------- standalone design-matrix operations
+// DesignMatrix.pca (correctors/designmatrix.py:252-282: fbpca.pca(values, nterms) -> U): the first k left singular vectors of
+// the column-centred matrix, for B same-shaped matrices.  Same machinery as the PLD blocks: Gram on the fp64 matrix cores,
+// top-k eigenpairs by subspace iteration, U = A V diag(lambda)^(-1/2).  A is not modified.
+int dm_pca_launch(lk_handle *h, int B, int N, int P, int k, const double *A_in, double *U, hipStream_t stream) {
+    LK_REQUIRE(B >= 1 && N >= 2 && P >= 1, "need B >= 1 matrices of N >= 2 rows and P >= 1 columns");
+    LK_REQUIRE(k >= 1 && k <= 48 && k <= P, "nterms must be between 1 and min(48, columns) on the HIP path (got %d for %d columns)", k, P);
+    LK_REQUIRE(P <= 4096, "the HIP path supports up to 4096 columns (got %d)", P);
+    LK_REQUIRE(A_in && U, "NULL buffer");
+    const int lmax = PLD_LMAX, ldg = ((P + 63) / 64) * 64;
+    h->ws.reset();
+    const size_t per = (size_t)N * P * 8 + (size_t)2 * ldg * ldg * 8 + (size_t)4 * P * lmax * 8 + (size_t)P * k * 8 + 4096;
+    int rc = h->ws.reserve((size_t)B * per * 2 + (size_t)(B + 1) * 8 + 65536);
+    if (rc) return rc;
+    std::vector<int64_t> off((size_t)B + 1);
+    for (int b = 0; b <= B; ++b) off[b] = (int64_t)b * N;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    LK_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
+    LK_HIP_CHECK(hipStreamSynchronize(stream));  // `off` leaves scope
+    double *A = (double *)h->ws.alloc((size_t)B * N * P * 8);
+    LK_REQUIRE(A != nullptr, "workspace exhausted");
+    LK_HIP_CHECK(hipMemcpyAsync(A, A_in, (size_t)B * N * P * 8, hipMemcpyDeviceToDevice, stream));
+    rc = pca_block(h, A, B, N, P, k, d_off, U, k, 0, stream, h->ws, false);
+    if (rc) return rc;
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// create_spline_matrix (correctors/designmatrix.py:952-997: patsy bs(x, ..., include_intercept=True) - 1): the clamped
+// B-spline basis of x on knots [lo, interior..., hi] -> out[B][N][n_inner + degree + 1]
+int dm_spline_launch(lk_handle *h, int B, int N, const double *x, const double *knots, int n_inner, int degree, double *out,
+                     hipStream_t stream) {
+    LK_REQUIRE(B >= 1 && N >= 1 && n_inner >= 0, "bad shapes");
+    LK_REQUIRE(degree >= 0 && degree <= 7, "spline degree outside 0..7");
+    LK_REQUIRE(x && knots && out, "NULL buffer");
+    (void)h;
+    const int nb = n_inner + degree + 1;
+    hipLaunchKernelGGL(pld_spline_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, knots, n_inner, degree, N, nb, 0, out, 0);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

@@ -756,4 +756,58 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ DesignMatrix.standardize
+// correctors/designmatrix.py:215-250: per column, zeros count as missing; subtract the nanmedian and divide by the nanstd of
+// the remaining values, missing values come back as 0; a column whose values are all equal (nanstd == 0) is left unchanged.
+// One workgroup per (column, matrix); the column is read through a strided view (no staging copy).
+__global__ __launch_bounds__(256) void dm_standardize_kernel(const double *__restrict__ A, int N, int P, double *__restrict__ out) {
+    __shared__ unsigned long long sh[264];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const double *col = A + (size_t)b * N * P + c;
+    double *oc = out + (size_t)b * N * P + c;
+    auto val = [&](int i) { return col[(size_t)i * P]; };
+    auto keep = [&](int i) {
+        const double v = col[(size_t)i * P];
+        return v == v && v != 0.0;
+    };
+    long long cnt = 0;
+    double sum = 0.0;
+    for (int i = tid; i < N; i += 256)
+        if (keep(i)) {
+            ++cnt;
+            sum += val(i);
+        }
+    const long long count = block_count_dyn(cnt, reinterpret_cast<long long *>(sh));
+    if (count == 0) {  // nothing but zeros / NaN: every entry is "missing" -> 0
+        for (int i = tid; i < N; i += 256) oc[(size_t)i * P] = 0.0;
+        return;
+    }
+    const double mean = block_sum_dyn(sum, reinterpret_cast<double *>(sh)) / (double)count;
+    double ss = 0.0;
+    for (int i = tid; i < N; i += 256)
+        if (keep(i)) {
+            const double d = val(i) - mean;
+            ss = fma(d, d, ss);
+        }
+    const double sd = sqrt(block_sum_dyn(ss, reinterpret_cast<double *>(sh)) / (double)count);  // numpy nanstd (ddof = 0)
+    if (sd == 0.0) {  // constant column: unchanged (its zeros were "missing" and come back as zeros)
+        for (int i = tid; i < N; i += 256) {
+            const double v = val(i);
+            oc[(size_t)i * P] = v == v ? v : 0.0;
+        }
+        return;
+    }
+    const double med = block_median(N, count, val, keep, sh);
+    for (int i = tid; i < N; i += 256) oc[(size_t)i * P] = keep(i) ? (val(i) - med) / sd : 0.0;
+}
+
+int dm_standardize_launch(lk_handle *h, int B, int N, int P, const double *A, double *out, hipStream_t stream) {
+    LK_REQUIRE(B >= 1 && N >= 1 && P >= 1 && P <= 65535, "bad shapes");
+    LK_REQUIRE(A && out, "NULL buffer");
+    (void)h;
+    hipLaunchKernelGGL(dm_standardize_kernel, dim3(P, B), dim3(256), 0, stream, A, N, P, out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 }  // namespace lk

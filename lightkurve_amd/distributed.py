@@ -9,7 +9,8 @@ The only exchange is the optional all-gather of the per-shard results (power spe
 """
 import numpy as np
 
-__all__ = ["partition_by_cost", "shard_bounds", "all_gather_rows", "sharded_map"]
+__all__ = ["partition_by_cost", "shard_bounds", "all_gather_equal", "all_gather_rows", "device_gather_available",
+           "sharded_map", "sharded_map_ragged"]
 
 
 def partition_by_cost(costs, world):
@@ -55,10 +56,23 @@ def _dist():
     return dist if dist.is_available() else None
 
 
+def all_gather_equal(out, local, group=None, async_op=False):
+    """The collective itself, on tensors that already live where the backend wants them (HBM for "nccl" = RCCL over xGMI,
+    host memory for "gloo"): ``out[(world, n, ...)]`` <- every rank's ``local[(n, ...)]``.  No staging, no allocation —
+    ``bench.py``'s multi-GPU step and ``all_gather_rows`` below both end here.  Returns the work handle when ``async_op``."""
+    dist = _dist()
+    world = dist.get_world_size(group)
+    if out.shape[0] != world or tuple(out.shape[1:]) != tuple(local.shape):
+        raise ValueError("out must be (world_size,) + local.shape, got %s for local %s" % (tuple(out.shape), tuple(local.shape)))
+    return dist.all_gather_into_tensor(out.view((world * local.shape[0],) + tuple(local.shape[1:])), local.contiguous(),
+                                       group=group, async_op=async_op)
+
+
 def all_gather_rows(local, bounds, group=None):
     """All-gather row blocks of unequal height: rank r contributes ``local`` of shape (bounds[r+1]-bounds[r], ...);
-    every rank gets the (bounds[-1], ...) concatenation.  torch.Tensor in -> torch.Tensor out (same device);
-    numpy in -> numpy out (staged through the backend's device).  One padded all_gather_into_tensor call."""
+    every rank gets the (bounds[-1], ...) concatenation.  torch.Tensor in -> torch.Tensor out on the same device: with
+    RCCL a device tensor (what the ``*_batch_dev`` entry points fill) never touches the host.  numpy in -> numpy out, staged
+    through the backend's device (one copy each way: use the tensor form to avoid them).  One padded all-gather."""
     dist = _dist()
     if dist is None or not dist.is_initialized():
         return local
@@ -80,12 +94,25 @@ def all_gather_rows(local, bounds, group=None):
         raise ValueError("rank %d holds %d rows, bounds say %d" % (rank, x.shape[0], counts[rank]))
     cmax = int(counts.max()) if world else 0
     tail = tuple(x.shape[1:])
-    pad = torch.zeros((cmax,) + tail, dtype=x.dtype, device=x.device)
-    pad[: x.shape[0]] = x
+    if int(counts.min()) == cmax:
+        pad = x                                      # equal shards: gather straight out of the caller's tensor
+    else:
+        pad = torch.zeros((cmax,) + tail, dtype=x.dtype, device=x.device)
+        pad[: x.shape[0]] = x
     out = torch.empty((world, cmax) + tail, dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out.view((world * cmax,) + tail), pad, group=group)
-    full = torch.cat([out[r, : int(counts[r])] for r in range(world)], dim=0)
+    all_gather_equal(out, pad, group=group)
+    full = out.view((world * cmax,) + tail) if int(counts.min()) == cmax else \
+        torch.cat([out[r, : int(counts[r])] for r in range(world)], dim=0)
     return full.cpu().numpy() if is_np else full
+
+
+def device_gather_available(group=None):
+    """True when results can be gathered without leaving HBM: a RCCL ("nccl") process group and a GPU torch can see."""
+    dist = _dist()
+    if dist is None or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return False
+    import torch
+    return torch.cuda.is_available()
 
 
 def sharded_map(items, fn, costs=None, gather=True, group=None):
@@ -101,3 +128,31 @@ def sharded_map(items, fn, costs=None, gather=True, group=None):
     if not gather:
         return local
     return all_gather_rows(local, bounds, group=group)
+
+
+def sharded_map_ragged(items, fn, lengths, costs=None, gather=True, group=None, dtype=np.float64):
+    """``sharded_map`` for results of unequal length: ``fn(local_items)`` returns one 1-D array per item (``lengths[i]``
+    long — every rank can compute the lengths of all items, e.g. ``len(lc)``).  The local rows are packed into a
+    NaN-padded block for the all-gather and unpacked again: every rank returns the list of all ``len(items)`` arrays."""
+    items = list(items)
+    lengths = [int(n) for n in lengths]
+    if len(lengths) != len(items):
+        raise ValueError("lengths must hold one entry per item")
+    dist = _dist()
+    if dist is None or not dist.is_initialized() or not gather:
+        if dist is None or not dist.is_initialized():
+            return list(fn(items))
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        bounds = shard_bounds(len(items), world, costs if costs is not None else lengths)
+        return list(fn(items[int(bounds[rank]):int(bounds[rank + 1])]))
+    lmax = max(lengths) if lengths else 0
+
+    def padded(local):
+        rows = fn(local)
+        out = np.full((len(local), lmax), np.nan, dtype=dtype)
+        for i, r in enumerate(rows):
+            out[i, : len(r)] = r
+        return out
+
+    full = sharded_map(items, padded, costs=costs if costs is not None else lengths, gather=True, group=group)
+    return [full[i, : lengths[i]] for i in range(len(items))]

@@ -13,8 +13,10 @@
 * S4  ``RegressionCorrector._fit_coefficients`` (regressioncorrector.py:127-189; the sigma-clip loop around it stays the
       reference's) and — faster, ``full_loop=True`` — ``RegressionCorrector.correct`` itself (:191-309, all iterations in one
       lk_regress_cov_batch call); ``PLDCorrector.create_design_matrix`` (pldcorrector.py:125-287) builds its PCA blocks with
-      lk_pld_design_batch.  Sparse collections are densified; ``pca_components=0``, ``sparse=True``, more than 1023
-      regressors or a sparse collection that would not fit densified go to the original methods.
+      lk_pld_design_batch (``sparse=True`` included: same PCA blocks, the reference's sparse spline basis beside them);
+      ``DesignMatrix.pca`` / ``.standardize`` (designmatrix.py:215-282) go to lk_pca_batch / lk_standardize_batch for every
+      caller.  Sparse collections are densified; ``pca_components=0``, more than 1023 regressors, ``pca`` beyond 48 terms
+      or a sparse collection that would not fit densified go to the original methods.
       Every call handed back to a CPU implementation logs one ``log.debug`` line saying which seam and why.
 
 ``backend`` is the module that provides the compute entry points (default: ``lightkurve_amd._capi``, i.e. the GPU).  The
@@ -278,8 +280,8 @@ def _make_create_design_matrix(lk_pld_mod):
     def create_design_matrix(self, pld_order=3, pca_components=16, pld_aperture_mask=None,
                              background_aperture_mask="background", spline_n_knots=None, spline_degree=3,
                              normalize_background_pixels=None, sparse=False):
-        if sparse or not pca_components or pca_components < 1:
-            _fell_back("PLDCorrector.create_design_matrix", "sparse=True" if sparse else "pca_components=%r" % (pca_components,))
+        if not pca_components or pca_components < 1:
+            _fell_back("PLDCorrector.create_design_matrix", "pca_components=%r" % (pca_components,))
             return orig(self, pld_order=pld_order, pca_components=pca_components, pld_aperture_mask=pld_aperture_mask,
                         background_aperture_mask=background_aperture_mask, spline_n_knots=spline_n_knots,
                         spline_degree=spline_degree, normalize_background_pixels=normalize_background_pixels,
@@ -309,15 +311,59 @@ def _make_create_design_matrix(lk_pld_mod):
         if npld > 0:
             mats.append(DM(pd.DataFrame(X[:, :npld]), name="pixel_series", prior_sigma=ps[:npld]))
         mats.append(DM(pd.DataFrame(X[:, npld:npld + kb]), name="background", prior_sigma=ps[npld:npld + kb]))
+        import warnings
+        if sparse:
+            # reference :194-199, 226-230: the sparse collection carries the reference's OTHER spline basis
+            # (create_sparse_spline_matrix, host-side like the knot selection); the pixel and background blocks are the same
+            # PCA'd matrices, built on the GPU above
+            sp = lk_pld_mod.create_sparse_spline_matrix(time, n_knots=spline_n_knots, degree=spline_degree).append_constant()
+            sp.prior_sigma = np.ones(sp.shape[1]) * ps[-1]
+            mats.append(sp)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return lk_pld_mod.SparseDesignMatrixCollection(mats)
         cols = ["knot{}".format(i + 1) for i in range(spline_n_knots)] + ["offset"]
         mats.append(DM(pd.DataFrame(X[:, npld + kb:], columns=cols), name="spline", prior_sigma=ps[npld + kb:]))
-        import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             return DMC(mats)
 
     create_design_matrix.__doc__ = orig.__doc__
     return create_design_matrix
+
+
+def _make_dm_pca(lk_dm_mod):
+    """``DesignMatrix.pca`` (correctors/designmatrix.py:252-282) -> lk_pca_batch.  Whoever calls it — PLD through the
+    reference's own create_design_matrix, CBV ``ext_dm``, SFF, user code — gets the GPU's Gram + eigen-solver instead of
+    fbpca on the CPU."""
+    orig = lk_dm_mod.DesignMatrix.pca
+
+    def pca(self, nterms=6, n_iter=10):
+        if nterms > self.shape[1]:
+            nterms = self.shape[1]
+        if nterms < 1 or nterms > 48 or self.shape[1] > 4096 or self.shape[0] < 2:
+            _fell_back("DesignMatrix.pca", "nterms=%d of %d columns is outside the kernel's range (1..48 of <= 4096)"
+                       % (nterms, self.shape[1]))
+            return orig(self, nterms=nterms, n_iter=n_iter)
+        vals = np.ascontiguousarray(np.asarray(self.values, dtype=np.float64))
+        return lk_dm_mod.DesignMatrix(_be().pca_batch(vals, nterms), name=self.name)
+
+    pca.__doc__ = orig.__doc__
+    return pca
+
+
+def _make_dm_standardize(lk_dm_mod):
+    import pandas as pd
+    orig = lk_dm_mod.DesignMatrix.standardize
+
+    def standardize(self, inplace=False):
+        vals = _be().standardize_batch(np.ascontiguousarray(np.asarray(self.df, dtype=np.float64)))
+        dm = self if inplace else self.copy()
+        dm.df = pd.DataFrame(vals, columns=self.columns)
+        return dm
+
+    standardize.__doc__ = orig.__doc__
+    return standardize
 
 
 # ------------------------------------------------------------------------------------------------ install / uninstall
@@ -364,6 +410,12 @@ def install(backend=None, lightkurve=True, full_loop=True):
         done.append("lightkurve:RegressionCorrector.correct")
     lk_pld.PLDCorrector.create_design_matrix = _make_create_design_matrix(lk_pld)
     done.append("lightkurve:PLDCorrector.create_design_matrix")
+    import lightkurve.correctors.designmatrix as lk_dm
+    _ORIG.setdefault("dm_pca", lk_dm.DesignMatrix.pca)
+    _ORIG.setdefault("dm_standardize", lk_dm.DesignMatrix.standardize)
+    lk_dm.DesignMatrix.pca = _make_dm_pca(lk_dm)
+    lk_dm.DesignMatrix.standardize = _make_dm_standardize(lk_dm)
+    done += ["lightkurve:DesignMatrix.pca", "lightkurve:DesignMatrix.standardize"]
     return done
 
 
@@ -393,3 +445,8 @@ def uninstall():
         lk_rc.RegressionCorrector.correct = _ORIG["correct"]
     if "create_design_matrix" in _ORIG:
         lk_pld.PLDCorrector.create_design_matrix = _ORIG["create_design_matrix"]
+    import lightkurve.correctors.designmatrix as lk_dm
+    if "dm_pca" in _ORIG:
+        lk_dm.DesignMatrix.pca = _ORIG["dm_pca"]
+    if "dm_standardize" in _ORIG:
+        lk_dm.DesignMatrix.standardize = _ORIG["dm_standardize"]

@@ -825,6 +825,35 @@ def gen_fits():
     save("fits_ingest", **out)
 
 
+def gen_designmatrix():
+    """DesignMatrix.pca / .standardize / .split (correctors/designmatrix.py:167-282) and create_spline_matrix (:952-997,
+    patsy) on a synthetic matrix — the standalone design-matrix operations of VERDICT r3 #3."""
+    from lightkurve.correctors import DesignMatrix
+    from lightkurve.correctors.designmatrix import create_spline_matrix
+    rng = np.random.default_rng(77)
+    N, P = 700, 24
+    basis = rng.normal(size=(N, 10))
+    mix = rng.normal(size=(10, P)) * (0.55 ** np.arange(10))[:, None]       # a decaying spectrum with clear gaps
+    A = basis @ mix + 1e-4 * rng.normal(size=(N, P)) + rng.normal(size=P)    # non-zero column means
+    out = dict(A=A, pca6=DesignMatrix(A, name="a").pca(6).values, pca3=DesignMatrix(A, name="a").pca(3).values)
+    S = A[:, :12].copy()
+    S[rng.random(S.shape) < 0.05] = 0.0        # zeros are "missing" to standardize()
+    S[:, 3] = 2.5                              # constant column: left unchanged
+    S[:, 5] = 0.0                              # all-zero column
+    out["S"] = S
+    out["standardized"] = DesignMatrix(S, name="s").standardize().values
+    dm3 = DesignMatrix(A[:, :3], name="three", prior_mu=[1.0, 2.0, 3.0], prior_sigma=[0.1, 0.2, 0.3])
+    sp = dm3.split([200, 450])
+    out["split"], out["split_mu"], out["split_sigma"] = sp.values, sp.prior_mu, sp.prior_sigma
+    x = np.sort(rng.uniform(0.0, 27.4, N))
+    out["x"] = x
+    out["spline_n20_d3"] = create_spline_matrix(x, n_knots=20, degree=3).values
+    out["spline_n12_d5_noint"] = create_spline_matrix(x, n_knots=12, degree=5, include_intercept=False).values
+    out["spline_knots_d3"] = create_spline_matrix(x, knots=[5.0, 11.0, 20.0], degree=3).values
+    out["knots_given"] = np.array([5.0, 11.0, 20.0])
+    save("designmatrix_ops", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ls", "ls_multiterm", "pg_smooth", "pg_misc", "acf2d", "ingest", "fits", "pixel_pg", "metrics", "fold", "cbv", "cbv_goodness", "bls", "bls_model", "flatten", "regression", "pld"]
     for w in which:

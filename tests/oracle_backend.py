@@ -104,3 +104,50 @@ def pld_design_batch(pld_pix, bkg_pix, lc_flux, time, knots, pld_order, pca_comp
         Xs.append(X)
         pss.append(ps)
     return np.array(Xs), np.array(pss)
+
+
+def pca_batch(A, nterms, device=0):
+    """Stand-in for lk_pca_batch: exact SVD of the column-centred matrix (what the GPU path converges to)."""
+    CALLS.append("pca_batch")
+    A = np.asarray(A, dtype=float)
+    single = A.ndim == 2
+    As = A[None] if single else A
+    out = np.stack([O.pca_exact(a, int(nterms)) for a in As])
+    return out[0] if single else out
+
+
+def standardize_batch(A, device=0):
+    """Stand-in for lk_standardize_batch: designmatrix.py:215-250 in numpy."""
+    CALLS.append("standardize_batch")
+    A = np.asarray(A, dtype=float)
+    single = A.ndim == 2
+    outs = []
+    for a in (A[None] if single else A):
+        ar = np.copy(a)
+        ar[ar == 0] = np.nan
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sd = np.nanstd(ar, axis=0)
+                md = np.nanmedian(ar, axis=0)
+        const = sd == 0
+        ar[:, ~const] = (ar[:, ~const] - md[~const]) / sd[~const]
+        outs.append(np.nan_to_num(ar, nan=0.0))
+    out = np.stack(outs)
+    return out[0] if single else out
+
+
+def spline_basis_batch(x, knots, degree=3, device=0):
+    CALLS.append("spline_basis_batch")
+    from scipy.interpolate import BSpline
+    x, knots = np.asarray(x, float), np.asarray(knots, float)
+    single = x.ndim == 1
+    xs, ks = (x[None], knots[None]) if single else (x, knots)
+    outs = []
+    for xx, kk in zip(xs, ks):
+        full = np.concatenate([[kk[0]] * (degree + 1), kk[1:-1], [kk[-1]] * (degree + 1)])
+        nb = len(full) - degree - 1
+        outs.append(np.column_stack([BSpline(full, np.eye(nb)[i], degree, extrapolate=False)(xx) for i in range(nb)]))
+    out = np.nan_to_num(np.stack(outs))
+    return out[0] if single else out

@@ -33,13 +33,27 @@ def main():
         f = synth.ls_frequency_grid(400, fmax=50.0)
         full = batch.lombscargle_batch(lcs, f)                       # gathered over RCCL
         local = batch.lombscargle_batch(lcs, f, gather=False)        # this rank's block only
-        # (the spreader accumulates with LDS atomics: two runs agree to rounding, not bit for bit)
-        assert full.shape == (3, 400) and np.allclose(full, local, rtol=1e-11, atol=0)
+        # the whole 'fast' path is bitwise reproducible (ordered LDS accumulation): gathered (device-resident route) and
+        # local (host route) results are the same bits
+        assert full.shape == (3, 400) and np.array_equal(full, local, equal_nan=True)
         for b, lc in enumerate(lcs):
             single = lc.to_periodogram(frequency=f)
             assert np.max(np.abs(full[b] - np.asarray(single.power))) <= 1e-11 * np.max(full[b])
         exact = batch.lombscargle_batch(lcs, f, ls_method="chi2", nterms=2)
         assert exact.shape == (3, 400) and np.all(np.isfinite(exact))
+        # round 4: the other sharded paths under the RCCL group (flatten, CDPP, regression) against the per-target calls
+        trends = batch.flatten_batch(lcs, window_length=51)
+        for lc, tr in zip(lcs, trends):
+            assert np.array_equal(tr, np.asarray(lc.flatten(window_length=51, return_trend=True)[1].flux), equal_nan=True)
+        cd = batch.estimate_cdpp_batch(lcs, savgol_window=51)
+        assert np.allclose(cd, [lc.estimate_cdpp(savgol_window=51) for lc in lcs], rtol=1e-12, atol=0)
+        from lightkurve_amd.correctors import DesignMatrix, RegressionCorrector
+        dms = [DesignMatrix(np.column_stack([np.ones(len(lc.time)), lc.time - lc.time.mean()]), name="lin") for lc in lcs]
+        flux, coef, outl = batch.regression_correct_batch(lcs, dms)
+        for lc, dm, fl, co in zip(lcs, dms, flux, coef):
+            rc = RegressionCorrector(lc)
+            one = rc.correct(dm)
+            assert np.allclose(fl, one.flux, rtol=0, atol=1e-12 * np.max(np.abs(one.flux))) and np.allclose(co, rc.coefficients, rtol=1e-9)
     finally:
         dist.destroy_process_group()
     print("RCCL_WORKER_OK")

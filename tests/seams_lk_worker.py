@@ -74,6 +74,16 @@ def run_all(lk):
     out["regress_coefficients"] = rc.coefficients
     out["regress_outliers"] = rc.outlier_mask
     out["regress_diag"] = rc.diagnostic_lightcurves["X"]
+    # standalone design-matrix operations (round 4): DesignMatrix.pca / .standardize reach the GPU for ANY caller
+    Ad = np.column_stack([np.sin(2 * np.pi * t / p) for p in (0.7, 1.3, 2.9, 7.7, 11.0)]) @ rng.normal(size=(5, 14)) \
+        + 1e-3 * rng.standard_normal((n, 14)) + rng.normal(size=14)
+    dmA = DesignMatrix(pd.DataFrame(Ad), name="A")
+    U = dmA.pca(4).values
+    out["dm_pca_projector"] = U @ U.T @ Ad[:, :3]              # invariant under sign flips / rotations of the basis
+    Sd = Ad.copy()
+    Sd[rng.random(Sd.shape) < 0.03] = 0.0
+    Sd[:, 2] = 1.5
+    out["dm_standardize"] = DesignMatrix(pd.DataFrame(Sd), name="S").standardize().values
     ref_data = os.path.join(os.environ.get("LK_REFERENCE_ROOT", "/root/reference"),
                             "tests/data/synthetic/synthetic-k2-sinusoid.targ.fits.gz")
     if os.path.exists(ref_data):
@@ -82,6 +92,9 @@ def run_all(lk):
         out["pld"] = pld.correct(pld_order=2, pca_components=8, pld_aperture_mask="all")   # S4: design matrix + regression
         out["pld_outliers"] = pld.outlier_mask
         out["pld_blocks"] = [mm.name for mm in pld.design_matrix_collection.matrices]
+        plds = PLDCorrector(tpf)
+        out["pld_sparse"] = plds.correct(pld_order=2, pca_components=8, pld_aperture_mask="all", sparse=True)
+        out["pld_sparse_blocks"] = [type(mm).__name__ for mm in plds.design_matrix_collection.matrices]
     return out
 
 
@@ -104,7 +117,7 @@ def compare(bname):
             seams.uninstall()
         again = run_all(lk)                                  # uninstall really restores the reference path
     res = {"installed": installed, "errors": {}, "types": {}}
-    tol = {"pld": 1e-6}
+    tol = {"pld": 1e-6, "pld_sparse": 1e-6, "dm_pca_projector": 1e-6}
     for k, r in ref.items():
         g = got[k]
         assert type(g) is type(r), (k, type(g), type(r))
@@ -132,7 +145,7 @@ def compare(bname):
             assert dict(g.meta).get("NORMALIZED") == dict(r.meta).get("NORMALIZED"), k
         elif k.endswith("outliers"):
             assert np.array_equal(np.asarray(g), np.asarray(r)), k
-        elif k == "pld_blocks":
+        elif k in ("pld_blocks", "pld_sparse_blocks"):
             assert g == r
         else:
             res["errors"][k] = float(np.max(np.abs(np.asarray(g) - np.asarray(r))) / np.max(np.abs(np.asarray(r))))

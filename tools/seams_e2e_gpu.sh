@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-to-end proof on the GPU box: an UNMODIFIED lightkurve (staged by tools/stage_reference.sh, unpacked to /tmp — outside
 # the repo) with lightkurve_amd.seams installed returns its own LightCurve / Periodogram objects from liblkhip.so:
-#   1. tests/seams_lk_worker.py compare hip   — all nine seams through lightkurve's public API against the reference path
+#   1. tests/seams_lk_worker.py compare hip   — all eleven seams through lightkurve's public API against the reference path
 #   2. tests/seams_lk_worker.py reftests hip  — the reference's own periodogram / corrector / flatten tests, seams active
 # The log is what profiles/r03_seams_e2e_gpu.log holds.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
