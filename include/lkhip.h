@@ -70,6 +70,9 @@ int lk_version(void);
 const char *lk_last_error(void);
 int lk_device_count(int *count);
 int lk_init(int device_id, lk_handle **out);
+/* Chunk size (MiB of spectra) of the pinned, double-buffered host pipeline behind lk_ls_fast_*_batch; default 64, or the
+ * environment variable LK_HOST_CHUNK_MB read once by lk_init — the library's only environment knob. */
+int lk_set_host_chunk_mb(lk_handle *h, int mb);
 void lk_destroy(lk_handle *h);
 /* Block until every kernel / copy issued through this handle's GPU has finished (hipDeviceSynchronize): for callers
  * of the *_dev entry points that do not hold a HIP runtime of their own. */

@@ -31,6 +31,7 @@ SIGNATURES = [
     ("lk_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ("lk_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     ("lk_destroy", None, [_vp]),
+    ("lk_set_host_chunk_mb", ctypes.c_int, [_vp, ctypes.c_int]),
     ("lk_workspace_bytes", ctypes.c_int64, [_vp]),
     ("lk_synchronize", ctypes.c_int, [_vp]),
     ("lk_ls_power_batch", ctypes.c_int,
@@ -240,6 +241,11 @@ class Handle:
 
     def workspace_bytes(self):
         return int(_lib.lk_workspace_bytes(self._h))
+
+    def set_host_chunk_mb(self, mb):
+        """MiB of spectra per chunk of the pinned host pipeline behind ls_fast_batch / ls_fast_peaks_batch (default 64, or
+        LK_HOST_CHUNK_MB when the handle was created)."""
+        _check(_lib.lk_set_host_chunk_mb(self._h, int(mb)))
 
 
 def device_count():

@@ -149,7 +149,16 @@ __device__ __forceinline__ void bls_team_body(
     const double *__restrict__ tm, const double2 *__restrict__ yw, const int64_t *__restrict__ n_off,
     const BlsStats *__restrict__ stats, const double *__restrict__ period, const int *__restrict__ pidx, int np_group,
     int64_t nP, int B, const int *__restrict__ dur_tab, int n_dur, int max_dur, double bin_duration, int oversample,
-    int obj_flag, double *__restrict__ out7, int cap, int shape, int ablate, unsigned long long *__restrict__ prof) {
+    int obj_flag, double *__restrict__ out7, int cap, int shape, int ablate_arg, unsigned long long *__restrict__ prof_arg) {
+#ifdef LK_BLS_DEBUG
+    const int ablate = ablate_arg;
+    unsigned long long *const prof = prof_arg;
+#else   // release build: the switches are constants and every branch on them folds away
+    constexpr int ablate = 0;
+    constexpr unsigned long long *prof = nullptr;
+    (void)ablate_arg;
+    (void)prof_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t_last = prof ? wall_clock64() : 0ull;
 #define BLS_LAP(slot_)                                                        \
@@ -227,7 +236,7 @@ __device__ __forceinline__ void bls_team_body(
     // ticket says g, issues its atomics and then writes g + 1.  A wave's LDS instructions execute in program order, so
     // the next wave can only see the new ticket after the atomics before it have been applied: the bins still
     // accumulate in cadence order.
-    const int NH = (multi || (ablate & 256)) ? 1 : min(NW, nh_cap);
+    const int NH = (multi || (ablate & 256) != 0) ? 1 : min(NW, nh_cap);
     volatile int *s_ticket = s_ctr + 2;
     if (wave < NH && !(ablate & 1)) {
         const bool tsorted = st.sorted != 0.0;
@@ -942,8 +951,12 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     }
     // debug knobs, read once per process: LK_BLS_ABLATE skips phases (results wrong; phase costs by difference),
     // LK_BLS_PROF=1 prints the wall time of every launch, =2 adds per-phase clocks (their atomics distort short teams)
+#ifdef LK_BLS_DEBUG   // `make DEBUG=1`: the phase-ablation and profiling switches of the development builds
     static const int ablate = getenv("LK_BLS_ABLATE") ? atoi(getenv("LK_BLS_ABLATE")) : 0;
     static const int prof_level = getenv("LK_BLS_PROF") ? atoi(getenv("LK_BLS_PROF")) : 0;
+#else
+    constexpr int ablate = 0, prof_level = 0;
+#endif
     const bool prof_on = prof_level != 0;
     unsigned long long *d_prof = nullptr;
     if (prof_level >= 2) {

@@ -109,7 +109,17 @@ int lk_init(int device_id, lk_handle **out) {
     if (!h) return LK_ENOMEM;
     h->device = device_id;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // the library's ONE environment knob, read once per handle: the chunk size of the pinned host pipeline
+    // (lk_set_host_chunk_mb changes it afterwards)
+    if (const char *e = getenv("LK_HOST_CHUNK_MB")) h->host_chunk_mb = std::max(1, atoi(e));
     *out = h;
+    return LK_OK;
+}
+
+int lk_set_host_chunk_mb(lk_handle *h, int mb) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(mb >= 1, "chunk size must be >= 1 MiB");
+    h->host_chunk_mb = mb;
     return LK_OK;
 }
 
@@ -736,8 +746,7 @@ int lk_ls_fast_peaks_batch(lk_handle *h, int B, const int64_t *n_off, const doub
     int rc = pipeline_init(h);
     if (rc) return rc;
     // chunk = as many targets as give ~64 MiB of spectra (large enough to amortise launches, small enough to pipeline)
-    size_t chunk_mb = 64;
-    if (const char *e = getenv("LK_HOST_CHUNK_MB")) chunk_mb = (size_t)std::max(1, atoi(e));
+    const size_t chunk_mb = (size_t)std::max(1, h->host_chunk_mb);
     const int C = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, (chunk_mb << 20) / ((size_t)M * 8)));
     const int nchunks = (B + C - 1) / C;
     size_t in_max = 0;

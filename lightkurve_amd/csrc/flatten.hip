@@ -187,14 +187,20 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask,
     int FIR_LDS, int stop_at, double quad_a, double quad_b, const double *__restrict__ edge_minv, int near_on) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
-    // Phase profiling aid: LK_FLAT_STOP=<16 * iteration + phase> makes every workgroup return when it reaches that
+    // Phase profiling aid (development builds, -DLK_FLAT_PROFILE): LK_FLAT_STOP=<16 * iteration + phase> makes every workgroup return when it reaches that
     // point (phase numbers as in the lap() calls below), so kernel time differences between successive stop points
     // give the cost of each phase.  Workgroup-uniform, no timers, no atomics; -1 (default) never stops.
+#ifdef LK_FLAT_PROFILE   // `make DEBUG=1` (tools/flat_phase_profile.py)
     int lap_iter = 0;
 #define lap(phase)                                                \
     do {                                                          \
         if (stop_at == 16 * lap_iter + (phase)) return;           \
     } while (0)
+#else   // release build: no stop points, the argument is ignored
+#define lap(phase) do { } while (0)
+    stop_at = -1;
+    [[maybe_unused]] int lap_iter = 0;
+#endif
     unsigned long long *sh = dyn_lds;
     const int sh_words = max((int)blockDim.x, 264);
     double *fir = reinterpret_cast<double *>(sh + sh_words);           // 16-B aligned: sh_words is even
@@ -812,7 +818,11 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         const int rc_ = want_lds(h, reinterpret_cast<const void *>(flatten_kernel), 152 * 1024);
         if (rc_) return rc_;
     }
+#ifdef LK_FLAT_PROFILE
     const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see the kernel
+#else
+    constexpr int stop_at = -1;
+#endif
     hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
                        break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
     LK_HIP_CHECK(hipGetLastError());

@@ -64,6 +64,7 @@ struct HostStage {
 struct lk_handle {
     int device = 0;
     int num_cu = 256;
+    int host_chunk_mb = 64;  // MiB of spectra per chunk of the pinned host pipeline (LK_HOST_CHUNK_MB at lk_init, lk_set_host_chunk_mb)
     lk::HostStage stage;
     lk::Arena ws;        // kernel scratch (prepped per-cadence records, per-target stats)
     lk::Arena staging;   // device mirrors of host buffers for the *_batch (host pointer) entry points

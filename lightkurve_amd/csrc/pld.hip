@@ -575,44 +575,61 @@ __global__ __launch_bounds__(256) void pld_prior_kernel(const float *__restrict_
     for (int j = tid; j < K; j += 256) prior_sigma[(size_t)b * K + j] = j < n_pld_cols ? sd / (double)pca : sd;
 }
 
-// clamped B-spline basis (patsy bs(x, df, degree, include_intercept=True)) + constant column
-__global__ void pld_spline_kernel(const double *__restrict__ time, const double *__restrict__ knots, int n_inner,
-                                  int degree, int N, int ldx, int col0, double *__restrict__ X, int with_const) {
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// clamped B-spline basis (patsy bs(x, df, degree, include_intercept=True)) (+ constant column).  A thread evaluates ONE row
+// (de Boor: the degree + 1 non-zero values and the span they start at) and parks it in LDS; then the workgroup writes the
+// rows out with the lanes across the COLUMNS, so a row's nb (+ 1) doubles go out as one contiguous run instead of one
+// 8-byte store per lane at a 1-KB stride (the block is mostly zeros: 0.5 ms -> the write bandwidth of its 1 GB).
+__global__ __launch_bounds__(256) void pld_spline_kernel(const double *__restrict__ time, const double *__restrict__ knots,
+                                                          int n_inner, int degree, int N, int ldx, int col0,
+                                                          double *__restrict__ X, int with_const) {
+    __shared__ double s_nv[256][9];
+    __shared__ int s_mu[256];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int n = blockIdx.x * 256 + tid;
     const double *t = time + (size_t)b * N;
     const double *kn = knots + (size_t)b * (n_inner + 2);  // [lo, inner..., hi]
-    const double x = t[n], lo = kn[0], hi = kn[n_inner + 1];
     const int order = degree + 1, nb = n_inner + order;
-    auto T = [&](int i) -> double {  // full knot vector: order copies of lo, inner, order copies of hi
-        if (i < order) return lo;
-        if (i >= order + n_inner) return hi;
-        return kn[1 + i - order];
-    };
-    double *row = X + ((size_t)b * N + n) * ldx + col0;
-    for (int j = 0; j < nb + with_const; ++j) row[j] = j == nb ? 1.0 : 0.0;
-    // knot span: largest mu with T(mu) <= x < T(mu+1), the right end belongs to the last non-empty span
-    int mu = order - 1;
-    const int last = order + n_inner - 1;
-    while (mu < last && !(x < T(mu + 1))) ++mu;
-    while (mu > order - 1 && T(mu) == T(mu + 1)) --mu;  // skip empty spans at repeated interior knots
-    double Nv[8] = {1.0, 0, 0, 0, 0, 0, 0, 0}, left[8], right[8];
-    for (int j = 1; j <= degree; ++j) {
-        left[j] = x - T(mu + 1 - j);
-        right[j] = T(mu + j) - x;
-        double saved = 0.0;
-        for (int r = 0; r < j; ++r) {
-            const double den = right[r + 1] + left[j - r];
-            const double tmp = den != 0.0 ? Nv[r] / den : 0.0;
-            Nv[r] = saved + right[r + 1] * tmp;
-            saved = left[j - r] * tmp;
+    if (n < N) {
+        const double x = t[n], lo = kn[0], hi = kn[n_inner + 1];
+        auto T = [&](int i) -> double {  // full knot vector: order copies of lo, inner, order copies of hi
+            if (i < order) return lo;
+            if (i >= order + n_inner) return hi;
+            return kn[1 + i - order];
+        };
+        // knot span: largest mu with T(mu) <= x < T(mu+1), the right end belongs to the last non-empty span
+        int mu = order - 1;
+        const int last = order + n_inner - 1;
+        while (mu < last && !(x < T(mu + 1))) ++mu;
+        while (mu > order - 1 && T(mu) == T(mu + 1)) --mu;  // skip empty spans at repeated interior knots
+        double Nv[8] = {1.0, 0, 0, 0, 0, 0, 0, 0}, left[8], right[8];
+        for (int j = 1; j <= degree; ++j) {
+            left[j] = x - T(mu + 1 - j);
+            right[j] = T(mu + j) - x;
+            double saved = 0.0;
+            for (int r = 0; r < j; ++r) {
+                const double den = right[r + 1] + left[j - r];
+                const double tmp = den != 0.0 ? Nv[r] / den : 0.0;
+                Nv[r] = saved + right[r + 1] * tmp;
+                saved = left[j - r] * tmp;
+            }
+            Nv[j] = saved;
         }
-        Nv[j] = saved;
+        s_mu[tid] = mu - degree;  // column of Nv[0]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_nv[tid][j] = Nv[j];
     }
-    for (int j = 0; j <= degree; ++j) {
-        const int c = mu - degree + j;
-        if (c >= 0 && c < nb) row[c] = Nv[j];
+    __syncthreads();
+    const int ncol = nb + with_const, nrow = min(256, N - blockIdx.x * 256);
+    double *base = X + ((size_t)b * N + (size_t)blockIdx.x * 256) * ldx + col0;
+    for (int e = tid; e < nrow * ncol; e += 256) {
+        const int r = e / ncol, c = e - r * ncol;
+        const int j = c - s_mu[r];
+        double v = 0.0;
+        if (c == nb)
+            v = 1.0;
+        else if (j >= 0 && j <= degree)
+            v = s_nv[r][j];
+        base[(size_t)r * ldx + c] = v;
     }
 }
 
@@ -1373,7 +1390,11 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
     // blocks (4 instead of 5 on the pixel blocks); the feared Cholesky breakdowns on steep spectra do not occur — the
     // columns are scaled to unit length first and SVQB stands behind — PLD step 83.7 -> 77.7 ms.
     constexpr int cheb_on = 3;
-    static const bool dbg_iters = getenv("LK_PLD_ITERS") && atoi(getenv("LK_PLD_ITERS")) != 0;   // print Rayleigh-Ritz step counts
+#ifdef LK_PLD_DEBUG   // `make DEBUG=1`: LK_PLD_ITERS=1 prints Rayleigh-Ritz step counts and per-phase clocks
+    static const bool dbg_iters = getenv("LK_PLD_ITERS") && atoi(getenv("LK_PLD_ITERS")) != 0;
+#else
+    constexpr bool dbg_iters = false;
+#endif
     {
         int rc_ = want_lds(h, reinterpret_cast<const void *>(pld_topk_eig_kernel<2>), 160 * 1024);
         if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(pld_topk_eig_kernel<4>), 160 * 1024);

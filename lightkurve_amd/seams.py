@@ -53,6 +53,19 @@ def _be():
 
 
 # ------------------------------------------------------------------------------------------------ S1
+def _split_normalization(normalization):
+    """astropy's four Lomb-Scargle normalisations (fast_impl.py:124-135, chi2_impl.py:74-84, slow_impl.py:98-109) on top of the
+    two the kernels produce: with p the 'standard' power, 'log' is -log(1 - p) and 'model' is p / (1 - p) — element-wise
+    maps of the B x M result, applied here (lightkurve itself only ever asks for 'psd', periodogram.py:964-967)."""
+    if normalization in ("standard", "psd"):
+        return normalization, (lambda p: p)
+    if normalization == "log":
+        return "standard", (lambda p: -np.log(1.0 - p))
+    if normalization == "model":
+        return "standard", (lambda p: p / (1.0 - p))
+    raise ValueError("normalization='{}' not recognized".format(normalization))
+
+
 def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit_mean=True, center_data=True,
                     nterms=1, **unused):
     """Signature of astropy's METHODS entries (lombscargle/implementations/main.py:182-217)."""
@@ -62,16 +75,15 @@ def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit
                              center_data=center_data, nterms=nterms)
     if not 1 <= nterms <= _capi.MAX_NTERMS:
         raise ValueError("the HIP kernels are instantiated for 1 <= nterms <= %d" % _capi.MAX_NTERMS)
-    if normalization not in ("standard", "psd"):
-        raise ValueError("normalization='{}' not recognized".format(normalization))
+    norm, finish = _split_normalization(normalization)
     t = np.asarray(t, dtype=np.float64)
     frequency = np.asarray(frequency, dtype=np.float64)
     from .periodogram import exact_grid
     grid = exact_grid(frequency)
-    kw = dict(dy=dy, fit_mean=fit_mean, center_data=center_data, normalization=normalization, nterms=nterms)
+    kw = dict(dy=dy, fit_mean=fit_mean, center_data=center_data, normalization=norm, nterms=nterms)
     if grid is not None:
-        return _be().ls_power_batch(t, y, [0, len(t)], f0=grid[0], df=grid[1], M=len(frequency), **kw)[0]
-    return _be().ls_power_batch(t, y, [0, len(t)], frequency=frequency, **kw)[0]
+        return finish(_be().ls_power_batch(t, y, [0, len(t)], f0=grid[0], df=grid[1], M=len(frequency), **kw)[0])
+    return finish(_be().ls_power_batch(t, y, [0, len(t)], frequency=frequency, **kw)[0])
 
 
 def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True, fit_mean=True,
@@ -90,8 +102,7 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
                            normalization=normalization, use_fft=use_fft, trig_sum_kwds=trig_sum_kwds, **extra)
     if not 1 <= nterms <= _capi.MAX_NTERMS:
         raise ValueError("the HIP kernels are instantiated for 1 <= nterms <= %d" % _capi.MAX_NTERMS)
-    if normalization not in ("standard", "psd"):
-        raise ValueError("normalization='{}' not recognized".format(normalization))
+    norm, finish = _split_normalization(normalization)
     if f0 < 0:
         raise ValueError("Frequencies must be positive")
     if df <= 0:
@@ -99,9 +110,9 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
     if Nf <= 0:
         raise ValueError("Number of frequencies must be positive")
     t = np.asarray(t, dtype=np.float64)
-    return _be().ls_fast_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
-                               center_data=center_data, normalization=normalization,
-                               oversampling=int(kw.get("oversampling", 5)), nterms=nterms)[0]
+    return finish(_be().ls_fast_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
+                                      center_data=center_data, normalization=norm,
+                                      oversampling=int(kw.get("oversampling", 5)), nterms=nterms)[0])
 
 
 # ------------------------------------------------------------------------------------------------ S2

@@ -22,7 +22,7 @@ def main():
     errs = {}
     for dy in (None, e * np.linspace(0.5, 2, len(e))):
         ls = LombScargle(t - t[0], y, dy)
-        for norm in ("standard", "psd"):
+        for norm in ("standard", "psd", "model", "log"):        # astropy's four normalisations through the 'hip' seam
             ref = ls.power(f, method="cython", normalization=norm)
             got = ls.power(f, method="hip", normalization=norm)
             errs["%s_%s" % (norm, "dy" if dy is not None else "nody")] = float(np.max(np.abs(got - ref)) / np.max(ref))

@@ -3,8 +3,6 @@ column FFT, fused row FFT + closed form + peak partials, two-stream chunk pipeli
 pipelined host-pointer entry point with pinned / pageable buffers and the peaks-only flavour — against the numpy port of
 astropy's fast_impl (pinned to the reference at 1e-9).  Tolerance (stated): 1e-9 of the target's maximum power, identical
 NaN pattern; the same call twice: bit for bit."""
-import os
-
 import numpy as np
 import pytest
 
@@ -21,20 +19,17 @@ def relmax(a, b):
     return np.max(np.abs(a[ok] - b[ok])) / np.max(np.abs(b[ok]))
 
 
-class env:
-    def __init__(self, **kw):
-        self.kw = {k: str(v) for k, v in kw.items()}
+class host_chunk:
+    """Chunk size (MiB of spectra) of the pinned host pipeline for the calls inside the block (lk_set_host_chunk_mb)."""
+
+    def __init__(self, mb):
+        self.mb = mb
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        os.environ.update(self.kw)
+        _capi.Handle.get(0).set_host_chunk_mb(self.mb)
 
     def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        _capi.Handle.get(0).set_host_chunk_mb(64)
 
 
 def _batch(B, N, config=1):
@@ -52,12 +47,12 @@ def test_full_size_chunks_two_streams_and_determinism():
     t, y, dy, off = _batch(B, N)
     df = 360.0 / M
     kw = dict(f0=df, df=df, M=M, normalization="lk_amplitude")
-    with env(LK_HOST_CHUNK_MB=4096):               # one host chunk: the device path sees all 90 targets at once
+    with host_chunk(4096):               # one host chunk: the device path sees all 90 targets at once
         got = _capi.ls_fast_batch(t, y, off, **kw)
     for b in (0, 84, 85, 89):
         ref = O.ls_power_fast(t[off[b]:off[b + 1]], y[off[b]:off[b + 1]], None, df, df, M, normalization="lk_amplitude")
         assert relmax(got[b], ref) < TOL, b
-    with env(LK_HOST_CHUNK_MB=4096):
+    with host_chunk(4096):
         again = _capi.ls_fast_batch(t, y, off, **kw)
     assert np.array_equal(got, again, equal_nan=True)
     # chunked by the host pipeline instead (80 targets per 64-MB chunk): the same bits again
@@ -125,11 +120,11 @@ def test_host_pipeline_chunks_pinned_pageable_and_peaks():
     y, _ = synth.pack_ragged(ys)
     df = 0.01
     kw = dict(f0=df, df=df, M=M, normalization="lk_amplitude")
-    with env(LK_HOST_CHUNK_MB=4096):
+    with host_chunk(4096):
         one = _capi.ls_fast_batch(t, y, off, **kw)                        # a single chunk
     ref = O.ls_power_fast(ts[5], ys[5], None, df, df, M, normalization="lk_amplitude")
     assert relmax(one[5], ref) < TOL
-    with env(LK_HOST_CHUNK_MB=1):                                         # 1 MiB / (M * 8 B) = 6 targets per chunk -> 4 chunks
+    with host_chunk(1):                                         # 1 MiB / (M * 8 B) = 6 targets per chunk -> 4 chunks
         pw, mx, am = _capi.ls_fast_peaks_batch(t, y, off, **kw)
         for b in range(B):
             assert relmax(pw[b], one[b]) < 1e-12, b
