@@ -1368,6 +1368,336 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ direct solver, P <= 138
+// Top-k eigenpairs of a Gram matrix that fits LDS (the 121-column pixel and background blocks, the 136-column 2nd-order
+// product block), computed DIRECTLY instead of by subspace iteration (whose Rayleigh-Ritz steps — a 32 x 32 Jacobi and a
+// Cholesky-QR each — cost 2-3 ms per launch in barrier-separated latency-bound phases): the LAPACK route for a few
+// eigenpairs of a dense symmetric matrix,
+//   1. Householder tridiagonalisation of the packed lower triangle in LDS (two barriers per column: the symmetric
+//      matrix-vector product and the rank-2 update; norms and inner products are recomputed by every wave — cheaper than a
+//      barrier); the reflectors stay in the eliminated columns (unscaled, with their scale factors beside them);
+//   2. the k largest eigenvalues of the tridiagonal matrix by multisection on Sturm counts, one wave per eigenvalue
+//      (64 trial points per round: 10 rounds reach the last bit);
+//   3. their eigenvectors from the twisted factorisation of T - lambda I (one lane per vector, one pass), modified
+//      Gram-Schmidt inside clusters of close eigenvalues;
+//   4. back-transformation by the reflectors, one wave per vector (the vector in registers), no barrier.
+// Residuals ||C v - lambda v|| <= 1e-15 lambda_max in the numpy restatement this was written from (steep pixel-block
+// spectra, flat product-block spectra, repeated eigenvalues).  One 1024-thread workgroup per matrix (LDS: 76 KB triangle +
+// 18 KB vectors + 36 KB scratch of the twisted factorisations).
+constexpr int TD_NT = 1024, TD_LANES = 16;  // eigenvectors factorised at a time (LDS scratch 2 P doubles each)
+
+// Wave-wide sum in every lane without the LDS crossbar: four DPP levels inside each row of 16 lanes (quad swaps, half-row and
+// row mirrors), then the four row sums through v_readlane.  ~10x shorter than six dependent ds_bpermute round trips — the
+// direct solver's phases are chains of such reductions.
+template <int CTRL>
+__device__ __forceinline__ double td_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double td_readlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double td_quad_sum(double x) {  // sum over each aligned group of 4 lanes, in all 4
+    x += td_dpp<0xB1>(x);   // quad_perm [1, 0, 3, 2]
+    x += td_dpp<0x4E>(x);   // quad_perm [2, 3, 0, 1]
+    return x;
+}
+__device__ __forceinline__ double td_wave_sum(double x) {
+    x = td_quad_sum(x);
+    x += td_dpp<0x141>(x);  // row_half_mirror: the other quad of each group of 8
+    x += td_dpp<0x140>(x);  // row_mirror: the other half of the row of 16
+    return (td_readlane(x, 0) + td_readlane(x, 16)) + (td_readlane(x, 32) + td_readlane(x, 48));
+}
+
+__device__ __forceinline__ int td_tri(int i, int j) { return ((i * (i + 1)) >> 1) + j; }  // j <= i
+
+__global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__restrict__ G, int ldg, int P, int k,
+                                                                 double *__restrict__ V, double *__restrict__ lam,
+                                                                 unsigned long long *__restrict__ clk) {
+#ifdef LK_PLD_DEBUG   // per-phase clocks of matrix 0 (100 MHz wall clock), `make DEBUG=1`
+#define TD_CLK(slot)                                                                 \
+    do {                                                                             \
+        if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[slot] = wall_clock64();  \
+    } while (0)
+#else
+#define TD_CLK(slot) do { } while (0)
+    (void)clk;
+#endif
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    constexpr int NW = TD_NT / 64;
+    const double *Gb = G + (size_t)b * ldg * ldg;
+    const int ntri = (P * (P + 1)) >> 1;
+    double *At = lds;                       // packed lower triangle
+    double *dd = At + ((ntri + 1) & ~1);    // diagonal of T
+    double *ee = dd + P;                    // ee[i] = T[i + 1][i]
+    double *tau = ee + P;                   // reflector factors
+    double *scl = tau + P;                  // v = [1, x[1:] * scl]
+    double *pb = scl + P;                   // p = tau S v
+    double *vb = pb + P;                    // the current reflector
+    double *e2 = pb;                        // squared off-diagonal of T (phase 2 on)
+    double *lamv = vb + P;                  // k eigenvalues (descending)
+    double *Z = lamv + ((k + 1) & ~1);      // P x k eigenvectors (row-major, like V)
+    double *ws = Z + (size_t)P * k;         // TD_LANES x 2 x P scratch of the twisted factorisations, [which][i][lane]
+    // ---- load the lower triangle (G's upper triangle is always valid: element (i, j <= i) = G[j][i])
+    for (int j = wave; j < P; j += NW)  // row j of G from its diagonal on: coalesced
+        for (int i = j + lane; i < P; i += 64) At[td_tri(i, j)] = Gb[(size_t)j * ldg + i];
+    __syncthreads();
+    TD_CLK(0);
+    // ---- 1. tridiagonalisation
+    for (int kk = 0; kk < P - 2; ++kk) {
+        const int m = P - kk - 1, r0 = kk + 1;  // trailing block: rows / columns r0 .. P - 1; x_i = A[r0 + i][kk]
+        // every wave: alpha, sigma = sum_{i >= 1} x_i^2 (same order in every wave: identical bits, and no barrier)
+        double part = 0.0;
+        for (int i = 1 + lane; i < m; i += 64) {
+            const double x = At[td_tri(r0 + i, kk)];
+            part = fma(x, x, part);
+        }
+        const double sigma = td_wave_sum(part), alpha = At[td_tri(r0, kk)];
+        double tk = 0.0, sc = 0.0, beta = alpha;
+        if (sigma != 0.0) {
+            const double nrm = sqrt(fma(alpha, alpha, sigma));
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tk = (beta - alpha) / beta;
+            sc = 1.0 / (alpha - beta);
+        }
+        if (tid == 0) {
+            dd[kk] = At[td_tri(kk, kk)];
+            ee[kk] = beta;
+            tau[kk] = tk;
+            scl[kk] = sc;
+        }
+        if (tk != 0.0) {  // (workgroup-uniform)
+            // v into LDS once (vb), then p = tau S v with FOUR threads per row (a quarter of the columns each, two shuffles)
+            if (tid < m) vb[tid] = tid == 0 ? 1.0 : At[td_tri(r0 + tid, kk)] * sc;
+            __syncthreads();
+            {
+                const int i = tid >> 2, q = tid & 3;
+                double acc = 0.0;
+                if (i < m) {
+                    const int jq = (m + 3) >> 2, j_lo = q * jq, j_hi = min(m, j_lo + jq);
+                    const int rowbase = td_tri(r0 + i, r0);
+                    int j = j_lo;
+                    for (; j < min(j_hi, i + 1); ++j) acc = fma(At[rowbase + j], vb[j], acc);       // S_ij, j <= i: row i
+                    for (; j < j_hi; ++j) acc = fma(At[td_tri(r0 + j, r0 + i)], vb[j], acc);         // j > i: column i
+                }
+                acc = td_quad_sum(acc);
+                if (i < m && q == 0) pb[i] = tk * acc;
+            }
+            __syncthreads();
+            // every wave: K = tau / 2 p^T v;  w = p - K v
+            double dot = 0.0;
+            for (int i = lane; i < m; i += 64) dot = fma(pb[i], vb[i], dot);
+            const double Kc = 0.5 * tk * td_wave_sum(dot);
+            // rank-2 update of the lower triangle, S_ij -= v_i w_j + w_i v_j: seven threads per row, four columns at a time —
+            // the operands of a batch are all loaded before its read-modify-writes (left to the compiler, every store to the
+            // triangle fences the loads behind it: they may alias)
+            {
+                const int i = tid / 7, q = tid - i * 7;
+                if (i < m) {
+                    const double vi = vb[i], wi = pb[i] - Kc * vi;
+                    const int rowbase = td_tri(r0 + i, r0);
+                    for (int c0 = q; c0 <= i; c0 += 28) {
+                        double vj[4], pj[4], av[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = min(c0 + 7 * u, i);
+                            vj[u] = vb[c];
+                            pj[u] = pb[c];
+                            av[u] = At[rowbase + c];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = c0 + 7 * u;
+                            if (c <= i) At[rowbase + c] = av[u] - fma(vi, pj[u] - Kc * vj[u], wi * vj[u]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (P >= 2) {
+            dd[P - 2] = At[td_tri(P - 2, P - 2)];
+            ee[P - 2] = At[td_tri(P - 1, P - 2)];
+        }
+        dd[P - 1] = At[td_tri(P - 1, P - 1)];
+        ee[P - 1] = 0.0;
+    }
+    __syncthreads();
+    TD_CLK(1);
+    // ---- 2. eigenvalues: Gershgorin bounds, then multisection on Sturm counts (a wave per eigenvalue)
+    double gl = INFINITY, gu = -INFINITY, e2max = 0.0;
+    for (int i = 0; i < P; ++i) {  // (every thread: P <= 138 LDS broadcasts)
+        const double r = (i > 0 ? fabs(ee[i - 1]) : 0.0) + (i < P - 1 ? fabs(ee[i]) : 0.0);
+        gl = fmin(gl, dd[i] - r);
+        gu = fmax(gu, dd[i] + r);
+        if (i < P - 1) e2max = fmax(e2max, ee[i] * ee[i]);
+    }
+    for (int i = tid; i < P - 1; i += TD_NT) e2[i] = ee[i] * ee[i];  // (pb is free after the tridiagonalisation)
+    __syncthreads();
+    const double tnorm = fmax(fabs(gl), fabs(gu)), eps = 2.220446049250313e-16;
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max);
+    auto count_below = [&](double x) {  // eigenvalues of T below x
+        int cnt = 0;
+        double q = dd[0] - x;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += q < 0.0;
+        double dn = dd[1], en = e2[0];  // (P >= 3) the next step's coefficients are requested one step ahead
+        for (int i = 1; i < P; ++i) {
+            const double di = dn, ei = en;
+            if (i + 1 < P) {
+                dn = dd[i + 1];
+                en = e2[i];
+            }
+            // 1 / q by v_rcp_f64 and one Newton step (~1e-14: the count is a sign test, and the recurrence is the long
+            // dependent chain of this phase — an IEEE division is four times as deep)
+            double r = __builtin_amdgcn_rcp(q);
+            r = fma(fma(-q, r, 1.0), r, r);
+            q = fma(-ei, r, di - x);
+            if (fabs(q) < pivmin) q = -pivmin;
+            cnt += q < 0.0;
+        }
+        return cnt;
+    };
+    for (int j = wave; j < k; j += NW) {
+        const int want = P - 1 - j;  // ascending index of the j-th largest
+        const double pad = 2.0 * tnorm * eps * P + 2.0 * pivmin;
+        double lo = gl - pad, hi = gu + pad;  // invariant: count_below(lo) <= want < count_below(hi)
+        for (int round = 0; round < 14; ++round) {
+            const double step = (hi - lo) / 65.0;
+            const double x = lo + step * (double)(lane + 1);
+            const bool below = !(x < hi) ? false : (count_below(x) <= want);  // trial points that are still "lo" candidates
+            const unsigned long long bal = __ballot(below);
+            const int nlo = __popcll(bal);  // monotone in x: the first nlo points are <= the eigenvalue's side
+            const double nlo_x = lo + step * (double)nlo, nhi_x = nlo < 64 ? lo + step * (double)(nlo + 1) : hi;
+            const double new_lo = nlo > 0 ? nlo_x : lo;
+            if (!(new_lo > lo) && !(nhi_x < hi)) break;
+            lo = new_lo;
+            hi = fmin(hi, nhi_x);
+            if (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
+        }
+        if (lane == 0) lamv[j] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    TD_CLK(2);
+    // ---- 3. eigenvectors of T from the twisted factorisation of T - lambda I (Parlett & Dhillon), one lane per vector:
+    // D+ / L from the top, D- / U from the bottom, the twist index r where |gamma_i| = |D+_i + D-_i - (d_i - lambda)| is smallest,
+    // z_r = 1, z_{i+1} = -U_i z_i below it and z_{i-1} = -L_{i-1} z_i above it.  One pass, 2 P doubles of scratch per vector
+    // (the LU-based inverse iteration this replaced kept 4 P and swept the matrix four times).
+    const double cl_tol = 1e-3 * tnorm;  // "close" eigenvalues: orthogonalised against each other afterwards
+    for (int j0 = 0; j0 < k; j0 += TD_LANES) {
+        if (wave == 0 && lane < TD_LANES && j0 + lane < k) {
+            const int j = j0 + lane;
+            double x0 = lamv[j];
+            // equal eigenvalues are perturbed apart so that their factorisations (hence their vectors) differ
+            int rank_in_cluster = 0;
+            for (int jj = 0; jj < j; ++jj) rank_in_cluster += fabs(lamv[jj] - lamv[j]) < 10.0 * eps * tnorm ? 1 : 0;
+            x0 -= 10.0 * eps * tnorm * (double)rank_in_cluster;
+            double *Ls = ws + lane, *Ds = Ls + (size_t)P * TD_LANES;  // [i][lane]
+            const double floor_ = eps * eps * tnorm;                    // breakdown guard for a vanishing pivot
+            double dp = dd[0] - x0;
+            for (int i = 0; i < P - 1; ++i) {
+                if (fabs(dp) < floor_) dp = dp < 0.0 ? -floor_ : floor_;
+                const double ei = ee[i], li = ei / dp;
+                Ds[(size_t)i * TD_LANES] = dp;
+                Ls[(size_t)i * TD_LANES] = li;
+                dp = (dd[i + 1] - x0) - li * ei;
+            }
+            Ds[(size_t)(P - 1) * TD_LANES] = dp;
+            // from the bottom: D-_i, gamma_i, the twist; U_i overwrites D+_{i+1} (no longer needed once gamma_{i+1} is known)
+            double dm = dd[P - 1] - x0;
+            double gbest = fabs(dp + dm - (dd[P - 1] - x0));
+            int r = P - 1;
+            for (int i = P - 2; i >= 0; --i) {
+                if (fabs(dm) < floor_) dm = dm < 0.0 ? -floor_ : floor_;
+                const double ei = ee[i], ui = ei / dm;
+                Ds[(size_t)(i + 1) * TD_LANES] = ui;  // U_i lives at slot i + 1
+                dm = (dd[i] - x0) - ui * ei;
+                const double g = fabs(Ds[(size_t)i * TD_LANES] + dm - (dd[i] - x0));
+                if (g < gbest) {
+                    gbest = g;
+                    r = i;
+                }
+            }
+            double nrm2 = 1.0, zi = 1.0;
+            Z[(size_t)r * k + j] = 1.0;
+            for (int i = r; i < P - 1; ++i) {
+                zi = -Ds[(size_t)(i + 1) * TD_LANES] * zi;
+                Z[(size_t)(i + 1) * k + j] = zi;
+                nrm2 = fma(zi, zi, nrm2);
+            }
+            zi = 1.0;
+            for (int i = r; i > 0; --i) {
+                zi = -Ls[(size_t)(i - 1) * TD_LANES] * zi;
+                Z[(size_t)(i - 1) * k + j] = zi;
+                nrm2 = fma(zi, zi, nrm2);
+            }
+            const double inv = 1.0 / sqrt(nrm2);
+            for (int i = 0; i < P; ++i) Z[(size_t)i * k + j] *= inv;
+        }
+        __syncthreads();
+    }
+    TD_CLK(3);
+    // modified Gram-Schmidt inside clusters, in eigenvalue order (a wave per step; rare: spectra of real blocks are separated)
+    if (wave == 0) {
+        for (int j = 1; j < k; ++j) {
+            bool any = false;
+            for (int jj = 0; jj < j; ++jj)
+                if (fabs(lamv[jj] - lamv[j]) < cl_tol) {
+                    any = true;
+                    double dot = 0.0;
+                    for (int i = lane; i < P; i += 64) dot = fma(Z[(size_t)i * k + j], Z[(size_t)i * k + jj], dot);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+                    for (int i = lane; i < P; i += 64) Z[(size_t)i * k + j] -= dot * Z[(size_t)i * k + jj];
+                }
+            if (any) {
+                double n2 = 0.0;
+                for (int i = lane; i < P; i += 64) n2 = fma(Z[(size_t)i * k + j], Z[(size_t)i * k + j], n2);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
+                const double inv = 1.0 / sqrt(n2);
+                for (int i = lane; i < P; i += 64) Z[(size_t)i * k + j] *= inv;
+            }
+        }
+    }
+    __syncthreads();
+    TD_CLK(4);
+    // ---- 4. back-transformation: V = H_0 H_1 ... H_{P-3} Z, a wave per vector with the vector in REGISTERS (P <= 192: three
+    // entries per lane) — no barrier, no LDS traffic but the reflector itself
+    for (int j = wave; j < k; j += NW) {
+        double z0 = lane < P ? Z[(size_t)lane * k + j] : 0.0;
+        double z1 = lane + 64 < P ? Z[(size_t)(lane + 64) * k + j] : 0.0;
+        double z2 = lane + 128 < P ? Z[(size_t)(lane + 128) * k + j] : 0.0;
+        for (int kk = P - 3; kk >= 0; --kk) {
+            const double tk = tau[kk];
+            if (tk == 0.0) continue;
+            const int r0 = kk + 1;
+            const double sc = scl[kk];
+            // v_i for row i: 0 above r0, 1 at r0, the stored column entry times the scale below
+            auto vrow = [&](int i) { return i < r0 ? 0.0 : (i == r0 ? 1.0 : (i < P ? At[td_tri(i, kk)] * sc : 0.0)); };
+            const double v0 = vrow(lane), v1 = vrow(lane + 64), v2 = vrow(lane + 128);
+            const double f = tk * td_wave_sum(fma(v0, z0, fma(v1, z1, v2 * z2)));
+            z0 = fma(-f, v0, z0);
+            z1 = fma(-f, v1, z1);
+            z2 = fma(-f, v2, z2);
+        }
+        if (lane < P) Z[(size_t)lane * k + j] = z0;
+        if (lane + 64 < P) Z[(size_t)(lane + 64) * k + j] = z1;
+        if (lane + 128 < P) Z[(size_t)(lane + 128) * k + j] = z2;
+    }
+    __syncthreads();
+    TD_CLK(5);
+    double *Vb = V + (size_t)b * P * k;
+    for (int e = tid; e < P * k; e += TD_NT) Vb[e] = Z[e];
+    if (tid < k) lam[(size_t)b * k + tid] = lamv[tid];
+#undef TD_CLK
+}
+
 // ------------------------------------------------------------------------------------------------ launcher
 // top-k eigenpairs of the B Gram matrices G (P x P, leading dimension ldg) -> V (B x P x k), lam (B x k), both allocated
 // from ws.  mirror: G holds the upper 64 x 64 blocks only (gram_plain_launch) and is completed in place first.
@@ -1404,6 +1734,34 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
     if (!V || !lam) {
         set_error("PLD workspace exhausted (V)");
         return LK_ENOMEM;
+    }
+    // Gram matrices that fit LDS (pixel / background blocks of <= 138 pixels, the 136-column 2nd-order product block): the
+    // direct tridiagonal solver — ~0.5 ms per launch and matrix instead of the 2-3 ms of a subspace iteration's
+    // Rayleigh-Ritz steps at this size
+    if (P >= 3 && P <= PLD_DIRECT_MAX) {
+        const int ntri = (P * (P + 1)) / 2;
+        const size_t lds = ((size_t)((ntri + 1) & ~1) + 6 * (size_t)P + ((k + 1) & ~1) + (size_t)P * k + (size_t)TD_LANES * 2 * P) * 8 + 16;
+        int rc_ = want_lds(h, reinterpret_cast<const void *>(pld_tridiag_eig_kernel), 160 * 1024);
+        if (rc_) return rc_;
+        LK_REQUIRE(lds <= 160 * 1024, "internal: %zu bytes of LDS for a %d-column direct solve", lds, P);
+        unsigned long long *d_clk = nullptr;
+#ifdef LK_PLD_DEBUG
+        if (dbg_iters) d_clk = (unsigned long long *)ws.alloc(64);
+#endif
+        hipLaunchKernelGGL(pld_tridiag_eig_kernel, dim3(B), dim3(TD_NT), lds, stream, G, ldg, P, k, V, lam, d_clk);
+#ifdef LK_PLD_DEBUG
+        if (d_clk) {
+            unsigned long long hc[8];
+            LK_HIP_CHECK(hipMemcpyAsync(hc, d_clk, 48, hipMemcpyDeviceToHost, stream));
+            LK_HIP_CHECK(hipStreamSynchronize(stream));
+            fprintf(stderr, "[pld tridiag] P=%d k=%d per matrix us: tridiagonalise %.0f | eigenvalues %.0f | twisted factorisation %.0f | "
+                            "Gram-Schmidt %.0f | back-transform %.0f\n", P, k, (hc[1] - hc[0]) * 0.01, (hc[2] - hc[1]) * 0.01,
+                    (hc[3] - hc[2]) * 0.01, (hc[4] - hc[3]) * 0.01, (hc[5] - hc[4]) * 0.01);
+        }
+#endif
+        *V_out = V;
+        *lam_out = lam;
+        return LK_OK;
     }
     // Mid-size blocks (PLD_LMAX < P <= PLD_DIRECT_MAX) get two passes: a SHORT subspace iteration (a pixel block with a
     // few dominant stars converges in ~5 Rayleigh-Ritz steps), then the direct Jacobi on C itself for the matrices that
