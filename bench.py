@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--no-pld", action="store_true", help="workload ls: skip the PLD block (configs[4])")
     ap.add_argument("--no-flatten", action="store_true", help="workload ls: skip the flatten block")
     ap.add_argument("--flatten-targets", type=int, default=1000, help="workload ls: light curves per GPU of the flatten block")
+    ap.add_argument("--flatten-window", type=int, default=401,
+                    help="flatten: Savitzky-Golay window (401 with the 20 000-cadence bench shape; `--workload flatten "
+                         "--cadences 4500 --flatten-window 101` is the long-cadence shape of the LDS-resident kernel)")
     ap.add_argument("--acc-flatten", type=int, default=64,
                     help="light curves flattened by scipy itself under conda (accuracy reference and cpu_baseline)")
     ap.add_argument("--acc-fast", type=int, default=256, help="targets checked against astropy 'fast' (also the cpu_baseline sample)")
@@ -247,7 +250,7 @@ def reference_suite(args, want_ls, want_bls, want_flatten=False):
         if want_flatten and args.acc_flatten > 0:
             n = min(args.acc_flatten, args.flatten_targets if args.workload == "ls" else args.targets)
             t, y, dy, off = synth.ls_batch(6, n, args.cadences, first_index=0)
-            np.savez(os.path.join(work, "flatten.npz"), t=t, y=y, off=off)
+            np.savez(os.path.join(work, "flatten.npz"), t=t, y=y, off=off, window=args.flatten_window)
             spec["flatten"] = {"n": n}
         json.dump(spec, open(os.path.join(work, "suite.json"), "w"))
         env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "oracle", "shims") + os.pathsep + ROOT)
@@ -344,10 +347,10 @@ def cpu_baseline_flatten(args):
     n = 8
     lcs = [synth.ls_target(6, i, args.cadences) for i in range(n)]
     t0 = time.perf_counter()
-    kept = [O.flatten_trend(t, y, 401, 2, 5, 3, 3)[0] for t, y, e, _ in lcs]
+    kept = [O.flatten_trend(t, y, args.flatten_window, 2, 5, 3, 3)[0] for t, y, e, _ in lcs]
     dt = time.perf_counter() - t0
     return {"value": n * args.cadences / dt, "unit": "cadences/sec", "cores": 1, "kind": "port",
-            "sample": "%d light curves x %d cadences, window 401, numpy port of LightCurve.flatten" % (n, args.cadences),
+            "sample": "%d light curves x %d cadences, window %d, numpy port of LightCurve.flatten" % (n, args.cadences, args.flatten_window),
             "_results": kept}   # popped before the JSON line: the accuracy block compares the GPU trends with these
 
 
@@ -514,8 +517,8 @@ def main():
                 cb = {"value": r["units_per_s"], "unit": "cadences/sec", "cores": ref["cores"], "kind": "reference",
                       "sample": "scipy %s savgol_filter + interp1d inside the restated loop of LightCurve.flatten "
                                 "(lightcurve.py:996-1063; lightkurve itself is not installed on this box), %d light curves x %d "
-                                "cadences, window 401, %d processes, %.1f s"
-                                % (r["scipy"], r["n_targets"], args.cadences, ref["procs"], r["seconds"]),
+                                "cadences, window %d, %d processes, %.1f s"
+                                % (r["scipy"], r["n_targets"], args.cadences, args.flatten_window, ref["procs"], r["seconds"]),
                       "_results": [r["trends"][i * args.cadences:(i + 1) * args.cadences] for i in range(r["n_targets"])]}
                 if args.workload == "flatten":
                     cpu_base = cb
@@ -780,7 +783,7 @@ def main():
         def step(e0, e1):
             e0.record()
             _capi._check(lib.lk_savgol_trend_batch_dev(handle._h, Bf, off.ctypes.data_as(i64p),
-                                                       vp(d_t.data_ptr()), vp(d_y.data_ptr()), None, 401, 2, 5.0, 3, 3.0,
+                                                       vp(d_t.data_ptr()), vp(d_y.data_ptr()), None, args.flatten_window, 2, 5.0, 3, 3.0,
                                                        vp(d_tr.data_ptr()), None, vp(stream)))
             e1.record()
 
@@ -797,7 +800,7 @@ def main():
             acc = {"reference": ("scipy savgol_filter + interp1d (the reference's own calls) inside the restated loop of "
                                  "LightCurve.flatten, run under conda on this box" if base.get("kind") == "reference" else
                                  "numpy port of LightCurve.flatten (scipy savgol semantics)") +
-                                ", %d light curves x %d cadences, window 401" % (len(rel), N),
+                                ", %d light curves x %d cadences, window %d" % (len(rel), N, args.flatten_window),
                    "trend_relerr_max": max(rel), "tolerance": 1e-10}
         algo = 24.0 * float(off[-1])
         rl = {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -805,8 +808,8 @@ def main():
               "traffic": traffic_all.get("flatten"), "kernel": "flatten_kernel", "kernel_ms_per_step": kms,
               "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
         return {"dt": dt, "kernel_ms": kms, "units_per_step": int(off[-1]), "steps": steps, "warmup": warmup,
-                "metric": "flatten cadences/sec (window 401, niters 3)", "unit": "cadences/sec",
-                "workload": "flatten: %d light curves x %d cadences, window 401, polyorder 2, niters 3 per GPU" % (Bf, N),
+                "metric": "flatten cadences/sec (window %d, niters 3)" % args.flatten_window, "unit": "cadences/sec",
+                "workload": "flatten: %d light curves x %d cadences, window %d, polyorder 2, niters 3 per GPU" % (Bf, N, args.flatten_window),
                 "roofline": rl, "accuracy": acc}
 
     def block_of(res, base):

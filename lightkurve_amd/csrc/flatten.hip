@@ -180,6 +180,11 @@ __device__ int strip_compact(int n, Pred pred, int *out, int *sh) {
 // for a FIR tile's inputs (8 interleaved sub-arrays, see the FIR below); outside the FIR the same doubles hold the
 // candidates of the sampled order statistics (block_select.hpp).
 
+// RES: the RESIDENT variant for light curves of at most FLAT_RES_MAX cadences (Kepler / K2 long cadence, TESS FFI and
+// 10-minute light curves): the compacted times, fluxes, the trend and the index map — every array the phases of an
+// iteration sweep again and again — live in LDS for the whole kernel (28 B per cadence behind the work areas; one
+// 1024-thread workgroup per CU), instead of in a scratch slab that streams through L2 / HBM once per phase.
+template <bool RES>
 __global__ __launch_bounds__(1024) void flatten_kernel(
     const double *__restrict__ t, const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
     const int64_t *__restrict__ n_off, int window, int polyorder, double break_tol, int niters, double sigma,
@@ -225,6 +230,13 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
     double *yk = xk + Npad;
     int *idx = reinterpret_cast<int *>(yk + Npad);
     int *idx2 = idx + Npad;
+    if (RES) {  // (compile-time: the four arrays are LDS pointers, their accesses LDS instructions)
+        double *res = reinterpret_cast<double *>(shi + ((nt + 3) & ~3));
+        tm = res;
+        fm = tm + Npad;
+        tr = fm + Npad;
+        idx = reinterpret_cast<int *>(tr + Npad);
+    }
     int *segs = idx2 + Npad;
     uint8_t *mask = reinterpret_cast<uint8_t *>(segs + Npad + 8);
     uint8_t *mask1 = mask + Npad;
@@ -808,14 +820,28 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
-    constexpr int flat_nt = 512;       // 512 threads: two workgroups per CU overlap each other's barrier-bound phases best
+    // resident variant: every light curve of the batch short enough for its four hot arrays to sit in LDS behind the work
+    // areas (a smaller FIR / candidate area than the streaming variant's: the windows that go with short light curves are
+    // short) — one 1024-thread workgroup per CU
+    int64_t nmax = 0;
+    for (int b = 0; b < B; ++b) nmax = std::max(nmax, n_off_host[b + 1] - n_off_host[b]);
+    constexpr int res_nt = 512, res_fir = 2048;
+    const size_t res_work = (size_t)std::max(res_nt, 264) * 8 + (size_t)(res_fir + 2) * 8 + (size_t)((res_nt + 3) & ~3) * 4;
+    const size_t res_arrays = (size_t)((nmax + 7) & ~(int64_t)7) * 28;
+    // TWO workgroups per CU must still fit (76 KB each): one 1024-thread resident workgroup per CU was measured at the
+    // 4500-cadence shape and lost to the streaming variant (0.965 against 0.907 ms per 1000 light curves) — what it gains in
+    // latency per sweep it loses in the overlap of two workgroups' barrier-bound phases
+    const bool resident = window <= res_fir / 2 + 1 && res_work + res_arrays + 64 <= (size_t)76 * 1024;
+    const int flat_nt = 512;  // two 512-thread workgroups per CU overlap each other's barrier-bound phases best
     constexpr int fir_lds_env = 4896;  // 8 x 612: 4096-output tiles at window 401
-    int fir_lds = std::max(512, fir_lds_env & ~1);
-    while (fir_lds < 16384 && window > fir_lds / 2 + 1) fir_lds *= 2;  // keep the tiled FIR path for long windows
-    const size_t lds = (size_t)std::max(flat_nt, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)flat_nt * 4;
+    int fir_lds = resident ? res_fir : std::max(512, fir_lds_env & ~1);
+    while (!resident && fir_lds < 16384 && window > fir_lds / 2 + 1) fir_lds *= 2;  // keep the tiled FIR path for long windows
+    const size_t lds = resident ? res_work + res_arrays + 64
+                                : (size_t)std::max(flat_nt, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)flat_nt * 4;
     {
         // (__syncthreads_or keeps a few bytes of static LDS: the dynamic part may not claim all 160 KB)
-        const int rc_ = want_lds(h, reinterpret_cast<const void *>(flatten_kernel), 152 * 1024);
+        int rc_ = want_lds(h, reinterpret_cast<const void *>(flatten_kernel<false>), 152 * 1024);
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flatten_kernel<true>), 152 * 1024);
         if (rc_) return rc_;
     }
 #ifdef LK_FLAT_PROFILE
@@ -823,8 +849,12 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
 #else
     constexpr int stop_at = -1;
 #endif
-    hipLaunchKernelGGL(flatten_kernel, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
-                       break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
+    if (resident)
+        hipLaunchKernelGGL(flatten_kernel<true>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
+                           break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
+    else
+        hipLaunchKernelGGL(flatten_kernel<false>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
+                           break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

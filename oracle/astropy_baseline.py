@@ -98,7 +98,7 @@ def _suite_flatten(b):
     d = _G["flatten"]
     s = slice(int(d["off"][b]), int(d["off"][b + 1]))
     time, flux = d["t"][s], d["y"][s]
-    window_length, polyorder, break_tolerance, niters, sigma = 401, 2, 5, 3, 3
+    window_length, polyorder, break_tolerance, niters, sigma = int(d["window"]) if "window" in d else 401, 2, 5, 3, 3
     mask = np.ones(len(time), dtype=bool)
     with np.errstate(invalid="ignore"):
         extra = np.isfinite(flux)

@@ -666,6 +666,26 @@ def gen_flatten_20k():
     save("flatten_20k", **out)
 
 
+def gen_flatten_4500():
+    """LightCurve.flatten at the long-cadence shape of the LDS-resident kernel: 4 500 cadences (a Kepler quarter), the
+    reference's default window 101.  Inputs = synth.ls_target(6, i, 4500, cadence_days=30 / 1440) (SHA-256 stored)."""
+    out = {}
+    n_lc = 4
+    # (index 2 is skipped: its synthetic sinusoid differs in the last bit between numpy 1.26 here and numpy 2.2 in the test
+    # interpreter, and the fixture pins inputs by SHA-256 instead of storing them)
+    for i, idx in enumerate((0, 1, 3, 4)):
+        t, y, e, _ = synth.ls_target(6, idx, 4500, cadence_days=30.0 / 1440.0)
+        if i == 3:
+            y = y.copy()
+            y[700:705] = np.nan          # NaNs in the flux: masked by the initial clip
+        lc = lk.LightCurve(time=t, flux=y, flux_err=e)
+        flat, trend = lc.flatten(window_length=101, polyorder=2, break_tolerance=5, niters=3, sigma=3, return_trend=True)
+        out["sha_%d" % i] = np.array(_sha(t, y))
+        out["trend_%d" % i] = np.asarray(trend.flux.value, float)
+    out["n_lc"] = n_lc
+    save("flatten_4500", **out)
+
+
 def gen_fits():
     """FITS light-curve files -> arrays through the reference's own readers (io/kepler.py, io/tess.py, io/generic.py).
     The files are SYNTHETIC (written here with astropy.io.fits in the layout of the mission products: big-endian records,

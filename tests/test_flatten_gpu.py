@@ -48,6 +48,34 @@ def test_golden_bench_shape(golden):
         assert np.allclose(trends[i], g["trend_%d" % i], rtol=RTOL, atol=0), i
 
 
+def test_golden_long_cadence_shape_resident_kernel(golden):
+    """4 500 cadences at 30 min (a Kepler quarter), the reference's default window 101: the batch is short enough for the
+    LDS-RESIDENT variant of the kernel (compacted time / flux / trend / index map in LDS).  Against lightkurve's own trend
+    (fixture from the reference; inputs regenerated and checked by SHA-256), NaN fluxes included; and the same light curves
+    in a batch with one 20 000-cadence light curve — which takes the streaming variant — give the same bits."""
+    import hashlib
+    g = golden("flatten_4500")
+    n = int(g["n_lc"])
+    lcs = []
+    for i, idx in enumerate((0, 1, 3, 4)[:n]):
+        t, y, e, _ = synth.ls_target(6, idx, 4500, cadence_days=30.0 / 1440.0)
+        if i == 3:
+            y = y.copy()
+            y[700:705] = np.nan
+        assert hashlib.sha256(t.tobytes() + y.tobytes()).hexdigest() == str(g["sha_%d" % i])
+        lcs.append(LightCurve(time=t, flux=y))
+    trends = flatten_trend_batch(lcs, window_length=101, polyorder=2, break_tolerance=5, niters=3, sigma=3)
+    for i in range(n):
+        ok = np.isfinite(g["trend_%d" % i])
+        assert np.array_equal(ok, np.isfinite(trends[i])), i
+        assert np.allclose(trends[i][ok], g["trend_%d" % i][ok], rtol=RTOL, atol=0), i
+    t, y, e, _ = synth.ls_target(6, 9, 20000)
+    mixed = flatten_trend_batch(lcs + [LightCurve(time=t, flux=y)], window_length=101, polyorder=2, break_tolerance=5,
+                                niters=3, sigma=3)
+    for i in range(n):
+        assert np.array_equal(mixed[i], trends[i], equal_nan=True), i
+
+
 def test_reference_robustness_cases():
     """reference tests/test_lightcurve.py:1284-1361: NaNs kept, linear data flattens to 1, one outlier survives."""
     lc = LightCurve(time=[1, 2, 3, 4, 5], flux=[np.nan, 1.1, 1.2, np.nan, 1.4])

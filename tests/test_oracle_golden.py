@@ -268,6 +268,21 @@ def test_flatten_bench_shape(golden):
     assert np.allclose(trend, g["trend_0"], rtol=1e-11, atol=0)
 
 
+def test_flatten_long_cadence_shape(golden):
+    """4 500 cadences at 30 min, the reference's default window 101 (the shape of the LDS-resident flatten kernel), NaN
+    fluxes included: lightkurve's own trends for lightkurve_amd.synth light curves (inputs pinned by SHA-256)."""
+    from lightkurve_amd import synth
+    g = golden("flatten_4500")
+    for i, idx in enumerate((0, 1, 3, 4)):
+        t, y, e, _ = synth.ls_target(6, idx, 4500, cadence_days=30.0 / 1440.0)
+        if i == 3:
+            y = y.copy()
+            y[700:705] = np.nan
+        assert _sha(t, y) == str(g["sha_%d" % i]), "synth light curve differs from the one the golden was made from"
+        trend, _ = O.flatten_trend(t, y, 101, 2, 5, 3, 3)
+        assert np.allclose(trend, g["trend_%d" % i], rtol=1e-11, atol=0)
+
+
 # ------------------------------------------------------------------ regression
 def test_regression_k8(golden):
     g = golden("regress_k8")
