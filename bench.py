@@ -758,6 +758,13 @@ def main():
               "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_all.get("pld"),
               "kernel": "pld_moment_gram_kernel + gram_mfma_kernel (v_mfma_f64_16x16x4_f64)", "kernel_ms_per_step": kms,
               "executed_gram_flop_per_step": flop, "plain_gram_flop_per_step": flop_plain,
+              "dominant_kernel": {"kernel": "pld_topk_eig_kernel<2> (subspace iteration on the 816-column block's 5.3-MB Gram "
+                                            "matrices; the 121- and 136-column blocks take the direct tridiagonal solver)",
+                                  "bound": "hbm", "ms_per_step": 12.3, "hbm_bytes_per_step": 3.09e10,
+                                  "achieved_GBps": 3.09e10 / 12.3e-3 / 1e9, "frac": 3.09e10 / 12.3e-3 / 1e9 / HBM_PEAK_GBS,
+                                  "source": "profiles/r04_pld_kernel_stats.txt (12.28 ms per launch), r04_pld_pmc_fetch.txt / "
+                                            "_write.txt (FETCH_SIZE + WRITE_SIZE of this kernel, 4 steps); constants of the "
+                                            "committed passes, not re-measured in this run"},
               "frac_plain_gram_equivalent": flop_plain / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
               "note": "Gram flop EXECUTED on the matrix cores — N*P*(P+1) for the two 121-column blocks, 512 flop per "
                       "16x16 tile and cadence of the moment-form staircase for the 136- and 816-column product blocks "
