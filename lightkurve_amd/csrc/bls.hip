@@ -299,6 +299,9 @@ __device__ __forceinline__ void bls_team_body(
                 }
             if (NH > 1) {
                 asm volatile("" ::: "memory");
+                // lgkmcnt(0): the wave's LDS atomics above have been executed before the ticket store is issued (LDS
+                // instructions of one wave complete in order; the wait makes that independent of the queue's behaviour)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
                 if (lane == 0) *s_ticket = g + 1;
             }
         };

@@ -250,25 +250,40 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
         // count, sum and sum of squares in ONE sweep, about a shift taken from the first finite sample (the variance of
         // the shifted data is the variance; with the shift inside the data's range the subtraction below cancels nothing
         // that matters: relative error ~ eps (1 + (mean - shift)^2 / var))
-        double shift = 0.0;
-        for (int i = 0; i < min(N, 8); ++i)
+        // the shift = the first FINITE sample of the light curve, wherever it sits (block-wide minimum index)
+        int first = N;
+        for (int i = tid; i < N; i += nt)
             if (isfinite(flux[i])) {
-                shift = flux[i];
+                first = i;
                 break;
             }
-        long long c = 0;
+        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+        if ((tid & 63) == 0) shi[tid >> 6] = first;
+        __syncthreads();
+        for (int w = 0; w < (nt >> 6); ++w) first = min(first, shi[w]);
+        __syncthreads();
+        const double shift = first < N ? flux[first] : 0.0;
+        long long c = 0, cinf = 0;
         double part = 0.0, part2 = 0.0;
         strided_pass<8>(N, val, [&](int, double f) {
             if (!isnan(f)) {
-                const double d = f - shift;
                 ++c;
-                part += d;
-                part2 = fma(d, d, part2);
+                if (isinf(f)) {
+                    ++cinf;
+                } else {
+                    const double d = f - shift;
+                    part += d;
+                    part2 = fma(d, d, part2);
+                }
             }
         });
         const long long cnt = block_count_fast(c, shl);
+        const long long ninf = block_count_fast(cinf, shl);
         const double s1 = block_sum_fast(part, shd), s2 = block_sum_fast(part2, shd);
-        const double sd = sqrt(fmax(0.0, (s2 - s1 * s1 / (double)cnt) / (double)cnt));
+        // an infinite sample makes numpy's nanstd NaN (inf - inf): every comparison of the initial clip is then false and
+        // the trend comes out all-NaN, as in the reference — the NaN must not be clamped to 0 by fmax
+        const double sd = ninf > 0 ? __longlong_as_double(0x7ff8000000000000ll)
+                                   : sqrt(fmax(0.0, (s2 - s1 * s1 / (double)cnt) / (double)cnt));
         __syncthreads();
         lap(0);
         const double med = block_median_sampled(N, cnt, val, notnan, sh, fir, FIR_LDS, (stop_at >= 100 && stop_at < 200) ? stop_at - 100 : -1);

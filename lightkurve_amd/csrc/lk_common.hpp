@@ -78,18 +78,31 @@ struct lk_handle {
     hipEvent_t ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};  // [0..1] columns done (per intermediate buffer), [2..3] rows done
     int *h_plan = nullptr;         // 64 B of pinned host memory: device -> host plan words (lsfast.hip)
     std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS attribute has been raised on this device
+    int lds_attr_rc = 0;                      // first failure of want_lds inside a void launch helper (take_lds_error)
     int bls_attr_set = 0;          // bls.hip: kernel attributes set and the LDS-atomic order self-test passed on this device
 };
 
 namespace lk {
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize once per DEVICE (a
 // process may drive several GPUs, one handle each): remembered in the handle, not in a function-local static.
-inline int want_lds(lk_handle *h, const void *fn, int bytes) {
-    for (const void *f : h->lds_attr_done)
-        if (f == fn) return LK_OK;
+inline int want_lds_checked(lk_handle *h, const void *fn, int bytes) {
     LK_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     h->lds_attr_done.push_back(fn);
     return LK_OK;
+}
+// A failure is returned AND remembered in the handle (lds_attr_rc): launch helpers that return void cannot pass it up, the
+// launcher that called them checks take_lds_error() before it reports success.
+inline int want_lds(lk_handle *h, const void *fn, int bytes) {
+    for (const void *f : h->lds_attr_done)
+        if (f == fn) return LK_OK;
+    const int rc = want_lds_checked(h, fn, bytes);
+    if (rc) h->lds_attr_rc = rc;
+    return rc;
+}
+inline int take_lds_error(lk_handle *h) {
+    const int rc = h->lds_attr_rc;
+    h->lds_attr_rc = 0;
+    return rc;
 }
 }  // namespace lk
 

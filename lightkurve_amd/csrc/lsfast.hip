@@ -1629,6 +1629,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         hipLaunchKernelGGL(lsf_power_kernel, dim3((unsigned)((M + 255) / 256), nb), dim3(256), 0, stream, d_spec,
                            d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power);
     }
+    if (const int lrc = take_lds_error(h)) return lrc;  // a launch helper could not raise a kernel's dynamic-LDS limit
     LK_HIP_CHECK(hipGetLastError());
     if (max_out && !fused) return argmax_launch(h, B, M, power, max_out, arg_out, stream);
     return LK_OK;
@@ -1709,6 +1710,7 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
         }
 #undef LK_FC2
     }
+    if (const int lrc = take_lds_error(h)) return lrc;
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

@@ -27,6 +27,7 @@
 // The order-1 block skips the reference's redundant re-PCA of an already orthonormal basis (same subspace).
 #include <algorithm>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 #include "block_select.hpp"
@@ -1888,7 +1889,11 @@ struct MomentPlan {
 };
 
 static const MomentPlan *moment_plan(lk_handle *h, int k, int o, const std::vector<uint8_t> &comb, int Pc) {
+    // one plan per (device, k, order) for the life of the process (a few MB of index tables each); the cache is shared by
+    // the handles of a process, so two handles driven from two threads must not build / look up concurrently
     static std::vector<MomentPlan *> cache;
+    static std::mutex cache_mutex;
+    std::lock_guard<std::mutex> guard(cache_mutex);
     for (const MomentPlan *pl : cache)
         if (pl->device == h->device && pl->k == k && pl->order == o) return pl;
     auto tup = [&](int idx, int pos) { return (int)comb[(size_t)idx * o + pos]; };

@@ -127,3 +127,22 @@ def test_flatten_errors():
         lc.flatten(window_length=3)
     with pytest.raises(ValueError, match="odd"):
         LightCurve(time=np.arange(10.0), flux=np.ones(10)).flatten(window_length=4)
+
+
+def test_infinite_flux_sample_and_leading_nans():
+    """with a +inf flux sample numpy's nanstd is NaN (inf - inf) and every comparison of the initial clip is False:
+    no cadence is kept (the reference then fails inside interp1d; the kernel returns an all-NaN trend, as its two-pass
+    predecessor did) — the one-pass variance used to clamp that NaN to 0 through fmax and fit a bogus trend.  Also: the
+    shift of the one-pass moments is the first FINITE sample anywhere (here the first 40 are NaN)."""
+    t, y, e, _ = synth.ls_target(6, 1, 3000)
+    y1 = y.copy()
+    y1[1500] = np.inf
+    tr = flatten_trend_batch([LightCurve(time=t, flux=y1)], window_length=101)[0]
+    assert np.all(np.isnan(tr))
+    y2 = y.copy() * 1e6 + 3e9                  # a large offset: a zero shift would cost ~ eps * mean^2 / var
+    y2[:40] = np.nan
+    got = flatten_trend_batch([LightCurve(time=t, flux=y2)], window_length=101)[0]
+    from oracle import np_oracle as O
+    ref = O.flatten_trend(t, y2, 101, 2, 5, 3, 3)[0]
+    ok = np.isfinite(ref)
+    assert np.array_equal(ok, np.isfinite(got)) and np.allclose(got[ok], ref[ok], rtol=RTOL, atol=0)
