@@ -127,15 +127,11 @@ void lk_destroy(lk_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     h->stage.release();
-    for (hipStream_t st : {h->s_in, h->s_comp, h->s_out, h->s_aux, h->s_rows})
+    for (hipStream_t st : {h->s_in, h->s_comp, h->s_out})
         if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t *arr : {h->ev_in, h->ev_comp, h->ev_out})
         for (int i = 0; i < 2; ++i)
             if (arr[i]) (void)hipEventDestroy(arr[i]);
-    for (int i = 0; i < 4; ++i) {
-        if (h->ev_aux[i]) (void)hipEventDestroy(h->ev_aux[i]);
-        if (h->ev_rows[i]) (void)hipEventDestroy(h->ev_rows[i]);
-    }
     if (h->h_plan) (void)hipHostFree(h->h_plan);
     h->ws.release();
     h->staging.release();

@@ -72,10 +72,6 @@ struct lk_handle {
     // the two halves of the double buffers; created on first use
     hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    hipStream_t s_aux = nullptr;   // second compute stream of the LS 'fast' chunk pipeline (lsfast.hip)
-    hipEvent_t ev_aux[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t s_rows = nullptr;  // stream of the LS 'fast' row transforms when they overlap the next chunk's column transforms
-    hipEvent_t ev_rows[4] = {nullptr, nullptr, nullptr, nullptr};  // [0..1] columns done (per intermediate buffer), [2..3] rows done
     int *h_plan = nullptr;         // 64 B of pinned host memory: device -> host plan words (lsfast.hip)
     std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS attribute has been raised on this device
     int lds_attr_rc = 0;                      // first failure of want_lds inside a void launch helper (take_lds_error)
