@@ -966,8 +966,15 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_prof), 64));
         LK_HIP_CHECK(hipMemset(d_prof, 0, 64));
     }
-    constexpr int kHistWaves = 4;   // ticket-ordered histogram waves per team (8 and 16 measure the same)
+#ifdef LK_BLS_DEBUG   // shape experiments of the development builds
+    static const int kMultiMinWaves = getenv("LK_BLS_MULTIMIN") ? atoi(getenv("LK_BLS_MULTIMIN")) : 16;
+    static const int nh_of_nw2 = getenv("LK_BLS_NH2") ? atoi(getenv("LK_BLS_NH2")) : 2;
+    static const int nh_of_nw4 = getenv("LK_BLS_NH4") ? atoi(getenv("LK_BLS_NH4")) : 4;
+#else
     constexpr int kMultiMinWaves = 16;  // multi-period workgroups only where they keep this many waves per CU
+    constexpr int nh_of_nw2 = 2, nh_of_nw4 = 4;
+#endif
+    constexpr int kHistWaves = 4;   // ticket-ordered histogram waves per team (8 and 16 measure the same)
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_on) {
         LK_HIP_CHECK(hipEventCreate(&pe0));
@@ -1021,7 +1028,7 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         const size_t nwg = (size_t)((B + 7) / 8) * 8 * (((size_t)npg + gsel * multi + (1 - multi) - 1) / (multi ? gsel : 1));
         LK_REQUIRE(nwg < ((size_t)1 << 31), "grid too large");
         const bool deep = !multi && waves_cu <= 16;  // <= 4 waves per SIMD: the 128-VGPR build fits
-        const int shape = multi | (kHistWaves << 8);
+        const int shape = multi | ((nw <= 2 ? nh_of_nw2 : nw <= 4 ? nh_of_nw4 : kHistWaves) << 8);
         if (deep)
             hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
                                period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,

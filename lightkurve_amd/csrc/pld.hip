@@ -1317,20 +1317,24 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
     const int lq = lane >> 4, lr = lane & 15, row = n0 + lr;
     const double *Ar = A + ((size_t)b * N + min(row, N - 1)) * P;
     const double *Vb = V + (size_t)b * P * k;
-    // loads are UNCONDITIONAL on clamped addresses and masked afterwards: guarded loads end up behind branches and are
-    // no longer issued back to back
+    // loads are UNCONDITIONAL on clamped addresses and masked afterwards BY A 0/1 FACTOR: guarded loads end up behind
+    // branches and are no longer issued back to back — and so does `cond ? loaded : 0.0`, which the compiler turns back
+    // into a branch around the load with a full wait behind it (round 4: every load of A and V of this kernel was
+    // serialised that way, 32 round trips per 64 columns).  A product cannot be if-converted.  Clamped addresses hold
+    // finite values of the same matrix, so 0 x value is 0.
     auto load_a = [&](int p0) -> pld_d4 {
         const int p = p0 + 4 * lq;
         pld_d4 v;
         if (VEC4) {
             v = *reinterpret_cast<const pld_d4 *>(Ar + min(p, P - 4));
-            if (!(row < N && p < P)) v = pld_d4{0.0, 0.0, 0.0, 0.0};
+            const double f = (row < N && p < P) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= f;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double x = Ar[min(p + j, P - 1)];
-                v[j] = (row < N && p + j < P) ? x : 0.0;
-            }
+            for (int j = 0; j < 4; ++j) v[j] = Ar[min(p + j, P - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= (row < N && p + j < P) ? 1.0 : 0.0;
         }
         return v;
     };
@@ -1350,7 +1354,7 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
                 for (int c = 0; c < KT; ++c) {
                     const int col = c * 16 + lr;
                     const double vraw = Vb[(size_t)min(p, P - 1) * k + min(col, k - 1)];
-                    const double bv = (p < P && col < k) ? vraw : 0.0;
+                    const double bv = vraw * ((p < P && col < k) ? 1.0 : 0.0);
                     acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[u][j], bv, acc[c], 0, 0, 0);
                 }
             }
@@ -1855,7 +1859,7 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         set_error("PLD workspace exhausted (Gram)");
         return LK_ENOMEM;
     }
-    gram_plain_launch(A, d_off, B, P, G, stream);
+    gram_plain_launch(A, d_off, B, P, G, stream, h);
     double *V = nullptr, *lam = nullptr;
     const int rc = eig_topk(h, G, ldg, B, P, k, products, true, &V, &lam, stream, ws);
     if (rc) return rc;

@@ -32,12 +32,20 @@ __device__ __forceinline__ double aug(const double *__restrict__ X, const double
     return (c == K && y) ? y[n] : 0.0;
 }
 
+// DELTA (passes 2.. of the clip loop): the fit mask only ever loses cadences (outl |= clipped), so the normal matrix of
+// the next pass is the previous one minus the contributions of the cadences the last clip ADDED to the outlier set:
+// clip_kernel leaves them as an ascending list (new_idx, new_cnt) and this kernel runs its stages over the list instead of
+// over all N cadences and subtracts the result from G in place — tens of rows instead of thousands.  A target whose list
+// overflowed (new_cnt > new_cap) is recomputed in full.  The list order and the stage order are fixed: same bits every run.
+template <bool DELTA>
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict__ X, const double *__restrict__ y,
                                                          const double *__restrict__ err,
                                                          const uint8_t *__restrict__ cmask,
                                                          const uint8_t *__restrict__ outl,
                                                          const int64_t *__restrict__ n_off, int K, int KB,
-                                                         double *__restrict__ G, const int *__restrict__ done = nullptr) {
+                                                         double *__restrict__ G, const int *__restrict__ done = nullptr,
+                                                         const int *__restrict__ new_cnt = nullptr,
+                                                         const int *__restrict__ new_idx = nullptr, int new_cap = 0) {
     if (done && done[blockIdx.y]) return;  // this target's clip loop has converged (see regress_launch): G is final
     __shared__ double sa[GR_RC][GR_LD];  // weighted left tile  (rows: cadence, cols: 64 output rows)
     __shared__ double sb[GR_RC][GR_LD];  // right tile          (cols: 64 output cols)
@@ -50,7 +58,15 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
     bj += bi;
     const int target = blockIdx.y;
     const int64_t lo = n_off[target];
-    const int n = (int)(n_off[target + 1] - lo);
+    int n = (int)(n_off[target + 1] - lo);
+    const int *rows = nullptr;  // DELTA: the cadences to take away (ascending); nullptr = all cadences
+    if (DELTA) {
+        const int cnt = new_cnt[target];
+        if (cnt <= new_cap) {
+            rows = new_idx + (size_t)target * new_cap;
+            n = cnt;
+        }
+    }
     X += lo * K;
     if (y) y += lo;
     const int Kp = KB * GR_BLK, Ka = K + (y ? 1 : 0);
@@ -73,16 +89,20 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + 256 * q, r = e >> 6, c = e & 63;
-            const int nn = n0 + r;
-            ra[q] = nn < n ? aug(X, y, K, nn, i0 + c) : 0.0;
-            rb[q] = nn < n ? aug(X, y, K, nn, j0 + c) : 0.0;
+            int nn = n0 + r;
+            const bool in = nn < n;
+            if (DELTA && rows && in) nn = rows[nn];
+            ra[q] = in ? aug(X, y, K, nn, i0 + c) : 0.0;
+            rb[q] = in ? aug(X, y, K, nn, j0 + c) : 0.0;
         }
         if (tid < GR_RC) {
-            const int nn = n0 + tid;
+            int nn = n0 + tid;
             wv = 0.0;
             if (nn < n) {
+                if (DELTA && rows) nn = rows[nn];
                 const int64_t g = lo + nn;
-                if ((!cmask || cmask[g]) && !(outl && outl[g])) {
+                // a listed cadence was in the previous fit unless cadence_mask excludes it (the clip runs over all cadences)
+                if ((!cmask || cmask[g]) && ((DELTA && rows) || !(outl && outl[g]))) {
                     const double s = err ? err[g] : 1.0;
                     wv = 1.0 / (s * s);
                 }
@@ -123,8 +143,207 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wi * 32 + a * 16 + (lane >> 4) + 4 * r;
                 const int col = j0 + wj * 32 + b * 16 + (lane & 15);
-                Gt[(size_t)row * Kp + col] = acc[a][b][r];
+                if (DELTA && rows)
+                    Gt[(size_t)row * Kp + col] -= acc[a][b][r];
+                else
+                    Gt[(size_t)row * Kp + col] = acc[a][b][r];
             }
+}
+
+// ------------------------------------------------------------------------------------------------ narrow Grams (<= 144 columns)
+// gram_mfma_kernel spends 48 (121 columns) or 57 (136 + 1) MFMA tiles per cadence step on a matrix whose upper triangle has
+// 36 or 45, stages every 64-column strip through LDS once per block pair and meets two barriers per 32 cadences with
+// four waves: 40 % of the fp64 MFMA rate.  Here ONE 8-wave workgroup owns a matrix: the upper-triangular 16 x 16 tiles
+// (row-major) are dealt to the waves in contiguous runs of <= GT_NS; a stage of 32 cadences x all columns sits in LDS
+// column-major ([column][cadence], leading dimension 40: a lane's 16-byte read is conflict-free across the wave), so one
+// ds_read_b128 feeds TWO MFMA steps — the summation index of v_mfma_f64_16x16x4_f64 is permuted (step 2m + h takes
+// cadences 8m + 2q + h from lane group q) — double-buffered with one barrier per stage.  The left operand of a tile row is
+// the same LDS value as the right operand of that tile column, times the cadence weight (X / err^2 as the reference forms
+// it): no second tile.  Off-diagonal tiles are written to both triangles.
+constexpr int GT_RC = 32, GT_LDC = 34, GT_NT = 512, GT_MAXT = 9;
+
+// NS = tiles per wave = ceil(T (T + 1) / 2 / 8).  The hot loop is branch-free: a wave with fewer tiles than NS repeats its
+// last one (the copy is not written), every slot reads both its operands, every global load is unconditional (clamped
+// address, value selected afterwards) — a branch around a load or an MFMA makes the compiler wait for everything in flight.
+template <bool WEIGHTED, int NS>
+__global__ __launch_bounds__(GT_NT) void gram_tri_kernel(const double *__restrict__ X, const double *__restrict__ y,
+                                                         const double *__restrict__ err,
+                                                         const uint8_t *__restrict__ cmask,
+                                                         const uint8_t *__restrict__ outl,
+                                                         const int64_t *__restrict__ n_off, int K, int ldg,
+                                                         double *__restrict__ G, const int *__restrict__ done = nullptr) {
+    if (done && done[blockIdx.x]) return;
+    extern __shared__ __attribute__((aligned(16))) double gt_sm[];
+    const int target = blockIdx.x;
+    const int64_t lo = n_off[target];
+    const int n = (int)(n_off[target + 1] - lo);
+    X += lo * K;
+    if (y) y += lo;
+    const int Ka = K + (y ? 1 : 0), T = (Ka + 15) >> 4, Tc = T << 4;
+    double *tile = gt_sm;                               // [2][Tc][GT_LDC]
+    double *sw = gt_sm + 2 * (size_t)Tc * GT_LDC;       // [2][GT_RC] cadence weights of the stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, cc = lane & 15;
+    // this wave's run of upper-triangular tiles (row-major): waves 0 .. rem-1 take per + 1, the others per
+    const int nti = T * (T + 1) / 2, per = nti >> 3, rem = nti & 7;
+    const int first = wave * per + min(wave, rem), cnt = per + (wave < rem ? 1 : 0);
+    int aoff[NS], boff[NS], ti[NS], tj[NS];  // LDS offsets (doubles) of a slot's operands for lane group 0, cadence 0
+    {
+        int i = 0, j = first;
+        while (i < T - 1 && j >= T - i) {
+            j -= T - i;
+            ++i;
+        }
+        j = min(j + i, T - 1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ti[s] = i;
+            tj[s] = j;
+            aoff[s] = ((i << 4) + cc) * GT_LDC + 2 * q;
+            boff[s] = ((j << 4) + cc) * GT_LDC + 2 * q;
+            if (s + 1 < cnt) {  // slots beyond the run repeat its last tile
+                if (++j == T) {
+                    ++i;
+                    j = i;
+                }
+            }
+        }
+    }
+    double4_t acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    // global -> registers -> LDS: thread (c16, row pair rp, column-tile parity) takes cadences 2 rp, 2 rp + 1 of column
+    // 16 tc + c16 for tc = parity, parity + 2, ...: one 16-byte LDS write each.  Per column: base pointer and row stride
+    // (X: K, y: 1, nothing: a valid address with stride 0 whose value is dropped).
+    const int c16 = tid & 15, rp = (tid >> 4) & 15, tcs = tid >> 8;
+    constexpr int NP = (GT_MAXT + 1) / 2;
+    const double *cbase[NP];
+    int cstride[NP];
+    bool clive[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int col = ((tcs + 2 * u) << 4) + c16;
+        const bool isx = col < K, isy = (col == K) && y != nullptr;
+        clive[u] = isx || isy;
+        cbase[u] = isx ? X + col : (isy ? y : X);
+        cstride[u] = isx ? K : (isy ? 1 : 0);
+    }
+    double f0[NP], f1[NP], wv = 1.0;
+    uint8_t wc = 1, wo = 0;
+    auto fetch = [&](int n0) {
+        const int r0 = n0 + 2 * rp, ra = min(r0, n - 1), rb = min(r0 + 1, n - 1);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            f0[u] = cbase[u][(size_t)ra * cstride[u]];
+            f1[u] = cbase[u][(size_t)rb * cstride[u]];
+        }
+        if (WEIGHTED && tid < GT_RC) {  // raw values only: nothing here may wait for a load (the MFMAs of the stage follow)
+            const int64_t g = lo + min(n0 + tid, n - 1);
+            wv = err ? err[g] : 1.0;
+            wc = cmask ? cmask[g] : (uint8_t)1;
+            wo = outl ? outl[g] : (uint8_t)0;
+        }
+    };
+    auto stash = [&](int buf, int n0) {  // values beyond the matrix or the batch become zeros on their way into LDS
+        double *tb = tile + (size_t)buf * Tc * GT_LDC;
+        const int r0 = n0 + 2 * rp;
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+            if (tcs + 2 * u < T) {
+                const int col = ((tcs + 2 * u) << 4) + c16;
+                *reinterpret_cast<double2 *>(tb + (size_t)col * GT_LDC + 2 * rp) =
+                    make_double2((clive[u] && r0 < n) ? f0[u] : 0.0, (clive[u] && r0 + 1 < n) ? f1[u] : 0.0);
+            }
+        if (WEIGHTED && tid < GT_RC) sw[buf * GT_RC + tid] = (wc != 0 && wo == 0 && n0 + tid < n) ? 1.0 / (wv * wv) : 0.0;
+    };
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int n0 = 0; n0 < n; n0 += GT_RC) {
+        if (n0 + GT_RC < n) fetch(n0 + GT_RC);  // wave-uniform; the last stage stashes stale registers into the idle buffer
+        const double *tb = tile + (size_t)buf * Tc * GT_LDC;
+#pragma unroll
+        for (int m = 0; m < GT_RC / 8; ++m) {
+            // lane group q: cadences 8m + 2q, 8m + 2q + 1 of the step pair (2m, 2m + 1)
+            double2 w2 = make_double2(1.0, 1.0);
+            if (WEIGHTED) w2 = *reinterpret_cast<const double2 *>(sw + buf * GT_RC + 8 * m + 2 * q);
+            double2 a2[NS], b2[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                a2[s] = *reinterpret_cast<const double2 *>(tb + aoff[s] + 8 * m);
+                b2[s] = *reinterpret_cast<const double2 *>(tb + boff[s] + 8 * m);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (WEIGHTED) {
+                    a2[s].x *= w2.x;
+                    a2[s].y *= w2.y;
+                }
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[s].x, b2[s].x, acc[s], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[s].y, b2[s].y, acc[s], 0, 0, 0);
+        }
+        stash(buf ^ 1, n0 + GT_RC);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double *Gt = G + (size_t)target * ldg * ldg;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < cnt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (ti[s] << 4) + q + 4 * r, col = (tj[s] << 4) + cc;
+                Gt[(size_t)row * ldg + col] = acc[s][r];
+                if (ti[s] != tj[s]) Gt[(size_t)col * ldg + row] = acc[s][r];
+            }
+        }
+}
+
+template <bool WEIGHTED, int NS>
+static void gram_tri_go(lk_handle *h, int *rc, size_t lds, const double *X, const double *y, const double *err,
+                        const uint8_t *cmask, const uint8_t *outl, const int64_t *d_off, int B, int K, int ldg, double *G,
+                        const int *done, hipStream_t stream) {
+    *rc = want_lds(h, reinterpret_cast<const void *>(gram_tri_kernel<WEIGHTED, NS>), 160 * 1024);
+    if (*rc) return;
+    hipLaunchKernelGGL((gram_tri_kernel<WEIGHTED, NS>), dim3(B), dim3(GT_NT), lds, stream, X, y, err, cmask, outl, d_off, K, ldg,
+                       G, done);
+}
+
+// launch helper: true if the narrow kernel took the job
+static bool gram_tri_try(lk_handle *h, const double *X, const double *y, const double *err, const uint8_t *cmask,
+                         const uint8_t *outl, const int64_t *d_off, int B, int K, int ldg, double *G, const int *done,
+                         hipStream_t stream) {
+    const int Ka = K + (y ? 1 : 0), T = (Ka + 15) / 16;
+    if (!h || T > GT_MAXT || ldg < 16 * T) return false;
+    const size_t lds = ((size_t)2 * 16 * T * GT_LDC + 2 * GT_RC) * 8;
+    const bool weighted = err || cmask || outl;
+    const int ns = (T * (T + 1) / 2 + 7) / 8;
+    int rc = 0;
+#define GT_CASE(NS_)                                                                                              \
+    case NS_:                                                                                                     \
+        if (weighted)                                                                                             \
+            gram_tri_go<true, NS_>(h, &rc, lds, X, y, err, cmask, outl, d_off, B, K, ldg, G, done, stream);       \
+        else                                                                                                      \
+            gram_tri_go<false, NS_>(h, &rc, lds, X, y, err, cmask, outl, d_off, B, K, ldg, G, done, stream);      \
+        break;
+    switch (ns) {
+        GT_CASE(1)
+        GT_CASE(2)
+        GT_CASE(3)
+        GT_CASE(4)
+        GT_CASE(5)
+        GT_CASE(6)
+        default:
+            return false;
+    }
+#undef GT_CASE
+    return rc == 0;
 }
 
 // A w = b by LU with partial pivoting, one 256-thread workgroup per target.  A lives in global scratch
@@ -358,7 +577,8 @@ __global__ __launch_bounds__(256) void model_kernel(const double *__restrict__ X
 __global__ __launch_bounds__(1024) void clip_kernel(const double *__restrict__ y, const double *__restrict__ model,
                                                      const int64_t *__restrict__ n_off, double sigma, int maxiters,
                                                      uint8_t *__restrict__ flag, uint8_t *__restrict__ outl,
-                                                     int *__restrict__ done = nullptr) {
+                                                     int *__restrict__ done = nullptr, int *__restrict__ new_cnt = nullptr,
+                                                     int *__restrict__ new_idx = nullptr, int new_cap = 0) {
     // done[target] != 0: an earlier pass of the clip loop added no outlier, so the fit mask, the fit, the residuals and
     // this clip would all repeat exactly — the remaining passes of the reference's `for count in range(niters)` are
     // no-ops for this target and are skipped (regressioncorrector.py:245-272 has no early exit; the fixed point is exact)
@@ -413,19 +633,47 @@ __global__ __launch_bounds__(1024) void clip_kernel(const double *__restrict__ y
         count = newcount;
         if (!changed) break;
     }
+    // outl |= clipped; the cadences that are NEW in the outlier set go to new_idx in ascending order (block-wide
+    // compaction per sweep of 1024 cadences: the list order must not depend on scheduling, the DELTA Gram sums over it)
     int added = 0;
-    for (int i = tid; i < n; i += 1024) {
-        const double r = val(i);
-        const bool clipped = !isfinite(r) || r < lo_b || r > hi_b;
-        if (clipped) {
-            added += outl[i] ? 0 : 1;
-            outl[i] = 1;
+    int *wtot = reinterpret_cast<int *>(sh);  // [16] wave totals of the sweep
+    if (new_idx) new_idx += (size_t)target * new_cap;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool isnew = false;
+        if (i < n) {
+            const double r = val(i);
+            const bool clipped = !isfinite(r) || r < lo_b || r > hi_b;
+            if (clipped) {
+                isnew = outl[i] == 0;
+                outl[i] = 1;
+            }
+        }
+        if (new_idx) {
+            const unsigned long long bal = __ballot(isnew);
+            const int lane = tid & 63, wv = tid >> 6;
+            __syncthreads();
+            if (lane == 0) wtot[wv] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) {
+                const int c = wtot[w];
+                before += w < wv ? c : 0;
+                total += c;
+            }
+            const int pos = added + before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (isnew && pos < new_cap) new_idx[pos] = i;
+            added += total;
+        } else {
+            added += isnew ? 1 : 0;
         }
     }
-    if (done) {
+    if (new_idx) {
+        if (tid == 0) new_cnt[target] = added;  // > new_cap: the list overflowed, the next Gram is computed in full
+    } else if (done) {
         added = __syncthreads_or(added);
-        if (tid == 0 && !added) done[target] = 1;
     }
+    if (done && tid == 0 && !added) done[target] = 1;
 }
 
 // model -= median(model)
@@ -650,8 +898,10 @@ __global__ __launch_bounds__(256) void gram128_kernel(const double *__restrict__
 }
 
 // plain Gram matrices G_b = A_b^T A_b of B row-major (N_b x K) blocks (no weights, no masks), for PCA (pld.hip)
-int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, double *G, hipStream_t stream) {
+int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, double *G, hipStream_t stream, lk_handle *h) {
     const int KB = (K + GR_BLK - 1) / GR_BLK;
+    if (gram_tri_try(h, A, nullptr, nullptr, nullptr, nullptr, d_off, B, K, KB * GR_BLK, G, nullptr, stream))
+        return KB * GR_BLK;
     constexpr int wide_min = 192;  // from this width the 128 x 128-tile kernel wins
     if (K >= wide_min) {
         const int KB2 = (K + G2_BLK - 1) / G2_BLK;
@@ -663,7 +913,7 @@ int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, doubl
                                KB * GR_BLK, G);
         return KB * GR_BLK;
     }
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3(KB * (KB + 1) / 2, B), dim3(256), 0, stream, A, (const double *)nullptr,
+    hipLaunchKernelGGL(gram_mfma_kernel<false>, dim3(KB * (KB + 1) / 2, B), dim3(256), 0, stream, A, (const double *)nullptr,
                        (const double *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, d_off, K, KB, G);
     return KB * GR_BLK;  // leading dimension of each G_b
 }
@@ -714,7 +964,7 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     const int KB = (K + 1 + GR_BLK - 1) / GR_BLK, Kp = KB * GR_BLK;
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * Kp * Kp * 8 + (size_t)B * K * (K + 1) * 8 * (w_cov ? 2 : 1) +
-                           ntot + (size_t)B * 4 + 4096);
+                           ntot + (size_t)B * 4 + (size_t)B * 4 * (256 + 1) + 4096);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     double *d_G = (double *)h->ws.alloc((size_t)B * Kp * Kp * 8);
@@ -729,10 +979,21 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     constexpr bool early = true;
     int *d_done = early ? (int *)h->ws.alloc((size_t)B * 4) : nullptr;
     if (d_done) LK_HIP_CHECK(hipMemsetAsync(d_done, 0, (size_t)B * 4, stream));
+    // the cadences each clip adds to the outlier set, for the DELTA Gram of the next pass
+    constexpr int kNewCap = 256;
+    int *d_newcnt = (int *)h->ws.alloc((size_t)B * 4);
+    int *d_newidx = (int *)h->ws.alloc((size_t)B * kNewCap * 4);
+    LK_REQUIRE(d_newcnt && d_newidx, "workspace exhausted");
     const int nblk = KB * (KB + 1) / 2;
     for (int it = 0; it < niters; ++it) {
-        hipLaunchKernelGGL(gram_mfma_kernel, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K, KB,
-                           d_G, (const int *)d_done);
+        if (it == 0) {
+            if (!gram_tri_try(h, X, y, err, cmask, outl, d_off, B, K, Kp, d_G, (const int *)d_done, stream))
+                hipLaunchKernelGGL(gram_mfma_kernel<false>, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off,
+                                   K, KB, d_G, (const int *)d_done);
+        }
+        else
+            hipLaunchKernelGGL(gram_mfma_kernel<true>, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K,
+                               KB, d_G, (const int *)d_done, (const int *)d_newcnt, (const int *)d_newidx, kNewCap);
         const size_t solve_lds = ((size_t)K * (K + 1) + K + 4 + 2) * 8;
         if (solve_lds <= 160 * 1024) {
             {
@@ -747,7 +1008,8 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
         }
         hipLaunchKernelGGL(model_kernel, dim3(64, B), dim3(256), (size_t)K * 8, stream, X, w, d_off, K, model,
                            (const int *)d_done);
-        hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, model, d_off, clip_sigma, 5, d_flag, outl, d_done);
+        hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, stream, y, model, d_off, clip_sigma, 5, d_flag, outl, d_done,
+                           d_newcnt, d_newidx, kNewCap);
     }
     hipLaunchKernelGGL(demedian_kernel, dim3(B), dim3(1024), 0, stream, d_off, model);
     // d_G still holds the normal matrix of the LAST iteration's fit: its inverse is the coefficient covariance
