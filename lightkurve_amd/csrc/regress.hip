@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
             n = cnt;
         }
     }
+    if (n <= 0) return;  // (DELTA: nothing to take away; the clamped loads below need one valid row)
     X += lo * K;
     if (y) y += lo;
     const int Kp = KB * GR_BLK, Ka = K + (y ? 1 : 0);
@@ -83,41 +84,54 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
 
     __shared__ double sw[GR_RC];  // the stage's 32 cadence weights (0 = masked), computed once per cadence
     // Software pipeline: the global loads of stage s + 1 (8 + 8 values per thread, and the stage's weights on the first
-    // 32 threads) are issued before the MFMAs of stage s and land in registers while the matrix cores work.
-    double ra[8], rb[8], wv = 0.0;
+    // 32 threads) are issued before the MFMAs of stage s and land in registers while the matrix cores work.  The loads
+    // are unconditional on clamped addresses (a thread's two columns are fixed: base pointer + row stride each; a
+    // column beyond [X | y] reads a valid address with stride 0) and the zeros are selected on the way into LDS:
+    // `in ? load : 0` ends up as a branch around the load with a full wait behind it, eight round trips per stage.
+    const int ccol = tid & 63, crow = tid >> 6;
+    const double *pa, *pb;
+    int sa_str, sb_str;
+    bool la, lb;
+    {
+        auto col = [&](int c, const double *&base, int &stride, bool &live) {
+            const bool isx = c < K, isy = c == K && y != nullptr;
+            live = isx || isy;
+            base = isx ? X + c : (isy ? y : X);
+            stride = isx ? K : (isy ? 1 : 0);
+        };
+        col(i0 + ccol, pa, sa_str, la);
+        col(j0 + ccol, pb, sb_str, lb);
+    }
+    double ra[8], rb[8], wv = 1.0;
+    uint8_t wc = 1, wo = 0;
     auto fetch = [&](int n0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
-            int nn = n0 + r;
-            const bool in = nn < n;
-            if (DELTA && rows && in) nn = rows[nn];
-            ra[q] = in ? aug(X, y, K, nn, i0 + c) : 0.0;
-            rb[q] = in ? aug(X, y, K, nn, j0 + c) : 0.0;
+            int nn = min(n0 + crow + 4 * q, n - 1);
+            if (DELTA && rows) nn = rows[nn];
+            ra[q] = pa[(size_t)nn * sa_str];
+            rb[q] = pb[(size_t)nn * sb_str];
         }
         if (tid < GR_RC) {
-            int nn = n0 + tid;
-            wv = 0.0;
-            if (nn < n) {
-                if (DELTA && rows) nn = rows[nn];
-                const int64_t g = lo + nn;
-                // a listed cadence was in the previous fit unless cadence_mask excludes it (the clip runs over all cadences)
-                if ((!cmask || cmask[g]) && ((DELTA && rows) || !(outl && outl[g]))) {
-                    const double s = err ? err[g] : 1.0;
-                    wv = 1.0 / (s * s);
-                }
-            }
+            int nn = min(n0 + tid, n - 1);
+            if (DELTA && rows) nn = rows[nn];
+            const int64_t g = lo + nn;
+            wv = err ? err[g] : 1.0;
+            wc = cmask ? cmask[g] : (uint8_t)1;
+            // a listed cadence was in the previous fit unless cadence_mask excludes it (the clip runs over all cadences)
+            wo = (outl && !(DELTA && rows)) ? outl[g] : (uint8_t)0;
         }
     };
     fetch(0);
     for (int n0 = 0; n0 < n; n0 += GR_RC) {
-        if (tid < GR_RC) sw[tid] = wv;
+        if (tid < GR_RC) sw[tid] = (n0 + tid < n && wc != 0 && wo == 0) ? 1.0 / (wv * wv) : 0.0;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q, r = e >> 6, c = e & 63;
-            sa[r][c] = ra[q] * sw[r];   // X / err^2 exactly as the reference forms it (:166)
-            sb[r][c] = rb[q];
+            const int r = crow + 4 * q;
+            const bool in = n0 + r < n;
+            sa[r][ccol] = ((in && la) ? ra[q] : 0.0) * sw[r];   // X / err^2 exactly as the reference forms it (:166)
+            sb[r][ccol] = (in && lb) ? rb[q] : 0.0;
         }
         __syncthreads();
         if (n0 + GR_RC < n) fetch(n0 + GR_RC);

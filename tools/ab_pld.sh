@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of liblkhip.so builds for the PLD bench on ONE box: tools/ab_pld.sh <outdir> <reps> lib1.so lib2.so ...
+out=$1; reps=$2; shift 2
+mkdir -p $out
+for r in $(seq $reps); do
+  for lib in "$@"; do
+    tag=$(basename $lib .so)
+    LK_LIB_PATH=$PWD/$lib python bench.py --workload pld --no-cpu-baseline --steps 5 --warmup 2 > $out/$tag.$r.json 2> $out/$tag.$r.err
+    echo "$tag rep $r $(grep -o 'ms_per_step[^,]*' $out/$tag.$r.json | head -1)"
+  done
+done
