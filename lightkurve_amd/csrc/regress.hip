@@ -473,24 +473,45 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
     double *A = s_A, *x = s_A + (size_t)K * Ka;
     double *s_pv = x + K;
     int *s_pi = reinterpret_cast<int *>(s_pv + 4);
-    for (int i = wave; i < K; i += 4)  // one wave per row: coalesced for the upper part, strided for the mirrored part
-        for (int j = lane; j < Ka; j += 64) {
-            double v;
-            if (j < K) {
-                v = (j >= i || (j / GR_BLK) == (i / GR_BLK)) ? Gt[(size_t)i * Kp + j] : Gt[(size_t)j * Kp + i];
-                if (i == j && prior_sigma) {
-                    const double sg = prior_sigma[(size_t)target * K + i];
-                    v += 1.0 / (sg * sg);
-                }
-            } else {
-                v = Gt[(size_t)i * Kp + K];
-                if (prior_sigma) {
-                    const double sg = prior_sigma[(size_t)target * K + i];
-                    v += prior_mu[(size_t)target * K + i] / (sg * sg);
-                }
-            }
-            A[i * Ka + j] = v;
+    // prior terms once per row (x, s_pv.. are free until the elimination starts): 1 / sigma^2 and mu / sigma^2
+    double *p_d = x, *p_b = s_A + (size_t)K * Ka + K + 8;  // p_b: behind x and the pivot exchange words
+    for (int i = tid; i < K; i += 256) {
+        double d = 0.0, b = 0.0;
+        if (prior_sigma) {
+            const double sg = prior_sigma[(size_t)target * K + i];
+            d = 1.0 / (sg * sg);
+            b = prior_mu[(size_t)target * K + i] / (sg * sg);
         }
+        p_d[i] = d;
+        p_b[i] = b;
+    }
+    __syncthreads();
+    // the augmented system: element e = (i, j), four loads in flight per thread, the source ADDRESS selected (upper 64 x 64
+    // blocks hold the matrix; the mirrored part is read transposed), never the loaded value — a select between two loads
+    // becomes two guarded loads with a wait each
+    const int tot = K * Ka;
+    for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
+        double v[4];
+        int ii[4], jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + 256 * u, tot - 1);
+            const int i = e / Ka, j = e - i * Ka;
+            ii[u] = i;
+            jj[u] = j;
+            const bool direct = j >= i || (j / GR_BLK) == (i / GR_BLK);  // (j == K: the right-hand side column, direct)
+            const double *src = direct ? Gt + (size_t)i * Kp + j : Gt + (size_t)j * Kp + i;
+            v[u] = *src;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + 256 * u < tot) {
+                double a = v[u];
+                if (jj[u] == ii[u]) a += p_d[ii[u]];
+                if (jj[u] == K) a += p_b[ii[u]];
+                A[ii[u] * Ka + jj[u]] = a;
+            }
+    }
     __syncthreads();
     for (int j = 0; j < K; ++j) {
         // pivot: largest |A[i][j]|, i >= j, first one wins (LAPACK idamax)
@@ -1008,7 +1029,7 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
         else
             hipLaunchKernelGGL(gram_mfma_kernel<true>, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K,
                                KB, d_G, (const int *)d_done, (const int *)d_newcnt, (const int *)d_newidx, kNewCap);
-        const size_t solve_lds = ((size_t)K * (K + 1) + K + 4 + 2) * 8;
+        const size_t solve_lds = ((size_t)K * (K + 1) + 2 * K + 8 + 2) * 8;  // system | x | pivot exchange | prior terms
         if (solve_lds <= 160 * 1024) {
             {
                 const int rc_ = want_lds(h, reinterpret_cast<const void *>(solve_lds_kernel), 160 * 1024);
