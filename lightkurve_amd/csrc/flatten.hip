@@ -139,6 +139,24 @@ __device__ int block_compact(int n, Pred pred, int *out, int *sh) {
     return total;
 }
 
+// Number of k in [k_lo + lane, k_hi) step 64 with pred(k) — eight loads in flight per lane (clamped indices, pinned): one
+// load per trip made these counting loops chains of ~40 memory round trips per wave.
+template <class Pred>
+__device__ __forceinline__ int strided_count64(int k_lo, int k_hi, int lane, Pred pred) {
+    int c = 0;
+    for (int k0 = k_lo + lane; k0 < k_hi; k0 += 8 * 64) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pred(min(k0 + 64 * u, k_hi - 1)) ? 1u : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            asm volatile("" : "+v"(v[u]));
+            c += (k0 + 64 * u < k_hi) ? (int)v[u] : 0;
+        }
+    }
+    return c;
+}
+
 // The same compaction with coalesced accesses: every wave owns one contiguous strip of the index range and walks it 64
 // entries at a time (four groups in flight), positions from ballot prefixes; two barriers.
 template <class Pred>
@@ -147,8 +165,7 @@ __device__ int strip_compact(int n, Pred pred, int *out, int *sh) {
     const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
     const int strip = ((n + nw - 1) / nw + 63) & ~63;
     const int k_lo = min(wv * strip, n), k_hi = min(k_lo + strip, n);
-    int c = 0;
-    for (int k = k_lo + lane; k < k_hi; k += 64) c += pred(k) ? 1 : 0;
+    int c = strided_count64(k_lo, k_hi, lane, pred);
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     __syncthreads();
     if (lane == 0) sh[wv] = c;
@@ -160,10 +177,13 @@ __device__ int strip_compact(int n, Pred pred, int *out, int *sh) {
     }
     for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
         bool m[4];
+        unsigned pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pv[u] = pred(min(k0 + 64 * u + lane, k_hi - 1)) ? 1u : 0u;  // clamped: four loads in flight
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + 64 * u + lane;
-            m[u] = k < k_hi && pred(k);
+            asm volatile("" : "+v"(pv[u]));
+            m[u] = k0 + 64 * u + lane < k_hi && pv[u] != 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -313,8 +333,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
             const int strip = ((N + nw - 1) / nw + 63) & ~63;
             const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
-            int c = 0;
-            for (int k = k_lo + lane; k < k_hi; k += 64) c += mask[k] ? 1 : 0;
+            int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
             __syncthreads();
             if (lane == 0) shi[wv] = c;
@@ -329,14 +348,21 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             bool saw_nan = false;
             for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
                 bool m[4];
+                unsigned mk[4];
                 double tv[4], fv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {  // four 64-cadence groups in flight
-                    const int k = k0 + 64 * u + lane;
-                    const bool in = k < k_hi;
-                    m[u] = in && mask[k] != 0;
-                    tv[u] = in ? t[k] : 0.0;
-                    fv[u] = in ? flux[k] : 0.0;
+                    // clamped, unconditional loads, pinned: a value selected by `in` goes back behind a branch with a full
+                    // wait — twelve serialised round trips per trip of this loop instead of one
+                    const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);
+                    mk[u] = mask[kc];
+                    tv[u] = t[kc];
+                    fv[u] = flux[kc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" : "+v"(mk[u]), "+v"(tv[u]), "+v"(fv[u]));
+                    m[u] = k0 + 64 * u + lane < k_hi && mk[u] != 0;
                     saw_nan |= m[u] && isnan(tv[u]);
                 }
 #pragma unroll
@@ -685,8 +711,7 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
             const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
             const int strip = ((N + nw - 1) / nw + 63) & ~63;
             const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
-            int c = 0;
-            for (int k = k_lo + lane; k < k_hi; k += 64) c += mask[k] ? 1 : 0;
+            int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
             __syncthreads();
             if (lane == 0) shi[wv] = c;
@@ -698,13 +723,19 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                 // knot abscissae -> knot ordinates) is issued for all four before the next stage starts
                 bool in[4], kf[4];
                 double xn[4];
+                unsigned mk[4];
                 int j[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + 64 * u + lane;
+                    const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);  // clamped, unconditional, pinned (see the gather)
                     in[u] = k < k_hi;
-                    kf[u] = in[u] && mask[k] != 0;
-                    xn[u] = in[u] ? t[k] : 0.0;
+                    mk[u] = mask[kc];
+                    xn[u] = t[kc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" : "+v"(mk[u]), "+v"(xn[u]));
+                    kf[u] = in[u] && mk[u] != 0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -714,7 +745,12 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
                 }
                 double xb[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xb[u] = (in[u] && j[u] > 0) ? xk[j[u] - 1] : -INFINITY;
+                for (int u = 0; u < 4; ++u) xb[u] = xk[max(j[u] - 1, 0)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" : "+v"(xb[u]));
+                    xb[u] = (in[u] && j[u] > 0) ? xb[u] : -INFINITY;
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (in[u] && xb[u] >= xn[u]) {  // equal times: those knots are not "< xn" (rare)
