@@ -435,27 +435,52 @@ __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__
                                                                  const uint32_t *__restrict__ src,
                                                                  const double *__restrict__ mean, int Pc, int ldg, double Nd,
                                                                  double *__restrict__ G) {
-    // a thread writes four neighbouring columns of one row (one 16-byte read of the index table, one 32-byte store)
+    // a thread writes two groups of four neighbouring columns (16-byte reads of the index table, 32-byte stores); both
+    // groups' index reads are issued before the gathers of either (the kernel is a chain index -> gather -> store, and one
+    // group per thread left it at 2 TB/s of stores)
     const int b = blockIdx.y;
-    const int q4 = (Pc + 3) >> 2;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Pc * q4) return;
-    const int i = e / q4, j0 = (e - i * q4) * 4;
+    const int q4 = (Pc + 3) >> 2, tot = Pc * q4;
+    const int e0 = blockIdx.x * 512 + threadIdx.x;  // the thread's groups: e0 and e0 + 256 (full-density wave stores)
+    if (e0 >= tot) return;
     const double *mb = mean + (size_t)b * Pc, *Mb = Mcan + (size_t)b * mstride;
-    const double mi = Nd * mb[i];
-    double *g = G + (size_t)b * ldg * ldg + (size_t)i * ldg + j0;
-    const uint32_t *sp = src + (size_t)i * Pc + j0;
-    if (j0 + 3 < Pc && (Pc & 3) == 0) {
-        const uint4 sv = *reinterpret_cast<const uint4 *>(sp);
-        const double v0 = Mb[sv.x], v1 = Mb[sv.y], v2 = Mb[sv.z], v3 = Mb[sv.w];
-        pld_d4 o;
-        o[0] = v0 - mi * mb[j0];
-        o[1] = v1 - mi * mb[j0 + 1];
-        o[2] = v2 - mi * mb[j0 + 2];
-        o[3] = v3 - mi * mb[j0 + 3];
-        *reinterpret_cast<pld_d4 *>(g) = o;
+    double *Gb = G + (size_t)b * ldg * ldg;
+    if ((Pc & 3) == 0) {
+        int ii[2], jj[2];
+        uint4 sv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = min(e0 + 256 * u, tot - 1);
+            ii[u] = e / q4;
+            jj[u] = (e - ii[u] * q4) * 4;
+            sv[u] = *reinterpret_cast<const uint4 *>(src + (size_t)ii[u] * Pc + jj[u]);
+        }
+        double v[2][4], mj[2][4], mi[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v[u][0] = Mb[sv[u].x];
+            v[u][1] = Mb[sv[u].y];
+            v[u][2] = Mb[sv[u].z];
+            v[u][3] = Mb[sv[u].w];
+            mi[u] = Nd * mb[ii[u]];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mj[u][t] = mb[jj[u] + t];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (e0 + 256 * u < tot) {
+                pld_d4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = v[u][t] - mi[u] * mj[u][t];
+                *reinterpret_cast<pld_d4 *>(Gb + (size_t)ii[u] * ldg + jj[u]) = o;
+            }
     } else {
-        for (int t = 0; t < 4 && j0 + t < Pc; ++t) g[t] = Mb[sp[t]] - mi * mb[j0 + t];
+        for (int u = 0; u < 2 && e0 + 256 * u < tot; ++u) {
+            const int e = e0 + 256 * u, i = e / q4, j0 = (e - i * q4) * 4;
+            const double mi = Nd * mb[i];
+            const uint32_t *sp = src + (size_t)i * Pc + j0;
+            double *g = Gb + (size_t)i * ldg + j0;
+            for (int t = 0; t < 4 && j0 + t < Pc; ++t) g[t] = Mb[sp[t]] - mi * mb[j0 + t];
+        }
     }
 }
 
@@ -2023,7 +2048,7 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
         }
 #undef LK_MG
     }
-    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 255) / 256, B), dim3(256), 0, stream, Mcan,
+    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 511) / 512, B), dim3(256), 0, stream, Mcan,
                        (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G);
     double *V = nullptr, *lam = nullptr;
     const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws);
