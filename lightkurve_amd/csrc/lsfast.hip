@@ -692,13 +692,16 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
                 int ii[UN], ih[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
+                    // clamped row, unconditional loads (under `if (r < r_end)` each pair waits for its own round trip)
                     const int r = rb + u * rpi + rr;
-                    ii[u] = ih[u] = 0;
-                    if (r < r_end) {
-                        const int blk = (r << (m2 - 4)) + blockIdx.x;
-                        ii[u] = tlo[blk] + k;
-                        ih[u] = thi[blk + 1];
-                    }
+                    const int blk = (min(r, r_end - 1) << (m2 - 4)) + blockIdx.x;
+                    ii[u] = tlo[blk] + k;
+                    ih[u] = thi[blk + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    asm volatile("" : "+v"(ii[u]), "+v"(ih[u]));
+                    if (rb + u * rpi + rr >= r_end) ii[u] = ih[u] = 0;
                 }
                 double tv[UN], yv[UN], dv[UN];
 #pragma unroll
