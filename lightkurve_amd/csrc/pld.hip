@@ -953,13 +953,18 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
         const int grp = gbase + wave;
         const bool active = grp < ngrp;
         const int n0 = grp * (16 * NT) + NT * lr;
-        cgdouble *cp = (cgdouble *)c.Gb + n0;
+        // The loads of C are UNCONDITIONAL: rows clamped to P - 1 (the matching rows of the staged basis are zeros), an idle
+        // wave of the last pass re-reads row 0 of its clamped group (L2).  Written as `(active && krow < P) ? load : 0` the
+        // loads went under a branch and the compiler issued them AFTER the step's MFMAs with a full wait at the top of the
+        // next trip — the "two steps ahead" of the source was no prefetch at all (round 4, from the ISA).
+        cgdouble *cp = (cgdouble *)c.Gb + (active ? n0 : NT * lr);
+        const size_t rstride = active ? (size_t)ldg : 0;
         bool colok[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) colok[j] = active && n0 + j < P;
         auto load_b = [&](int st) -> bvec {
-            const int krow = st * 4 + lq;
-            return (active && krow < P) ? *(cgbvec *)(cp + (size_t)krow * ldg) : bvec(0.0);
+            const int krow = min(st * 4 + lq, P - 1);
+            return *(cgbvec *)(cp + (size_t)krow * rstride);
         };
         pld_d4 acc[NT][NA];
 #pragma unroll
