@@ -832,22 +832,23 @@ static __device__ __noinline__ void eig_xty(EigCtx c, const double *X_, const do
         const int s0 = part * per, s1 = min(steps, s0 + per);
         pld_d4 acc = pld_d4{0.0, 0.0, 0.0, 0.0};
         const bool aok = acol < l, cok = ccol < l;
+        const int acl = min(acol, l - 1), ccl = min(ccol, l - 1);
         int st = s0;
         for (; st + 4 <= s1; st += 4) {  // four steps of loads in flight
             double av[4], bv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = (st + u) * 4 + lq;
-                av[u] = (i < P && aok) ? X[(size_t)i * l + acol] : 0.0;
-                bv[u] = (i < P && cok) ? Yv[(size_t)i * l + ccol] : 0.0;
+            for (int u = 0; u < 4; ++u) {  // clamped addresses, 0/1 factors (a select would put each load back under a branch)
+                const int i = (st + u) * 4 + lq, ic = min(i, P - 1);
+                av[u] = X[(size_t)ic * l + acl] * ((i < P && aok) ? 1.0 : 0.0);
+                bv[u] = Yv[(size_t)ic * l + ccl] * ((i < P && cok) ? 1.0 : 0.0);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
         for (; st < s1; ++st) {
-            const int i = st * 4 + lq;
-            const double av = (i < P && aok) ? X[(size_t)i * l + acol] : 0.0;
-            const double bv = (i < P && cok) ? Yv[(size_t)i * l + ccol] : 0.0;
+            const int i = st * 4 + lq, ic = min(i, P - 1);
+            const double av = X[(size_t)ic * l + acl] * ((i < P && aok) ? 1.0 : 0.0);
+            const double bv = Yv[(size_t)ic * l + ccl] * ((i < P && cok) ? 1.0 : 0.0);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
 #pragma unroll
@@ -887,17 +888,20 @@ static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double 
 #pragma unroll
             for (int t = 0; t < NA; ++t) acc2[t] = pld_d4{0.0, 0.0, 0.0, 0.0};
         }
-        double av[4 * NA];
+        double av[4 * NA], av2s[TWO ? 4 * NA : 1];
+        const int irc = min(irow, P - 1);
 #pragma unroll
-        for (int ks = 0; ks < 4 * NA; ++ks) {
-            const int a = ks * 4 + lq;
-            av[ks] = (irow < P && a < l) ? X[(size_t)irow * l + a] : 0.0;
+        for (int ks = 0; ks < 4 * NA; ++ks) {  // clamped addresses, 0/1 factors: all loads of the strip in flight at once
+            const int a = ks * 4 + lq, ac = min(a, l - 1);
+            const double f = (irow < P && a < l) ? 1.0 : 0.0;
+            av[ks] = X[(size_t)irc * l + ac] * f;
+            if (TWO) av2s[ks] = X2[(size_t)irc * l + ac] * f;
         }
 #pragma unroll
         for (int ks = 0; ks < 4 * NA; ++ks) {
             const int a = ks * 4 + lq;
             double av2 = 0.0;
-            if (TWO) av2 = (irow < P && a < l) ? X2[(size_t)irow * l + a] : 0.0;
+            if (TWO) av2 = av2s[ks];
 #pragma unroll
             for (int t = 0; t < NA; ++t) {
                 const int col = t * 16 + lr;
