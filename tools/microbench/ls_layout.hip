@@ -27,14 +27,14 @@ constexpr int N1 = 1024, N2 = 512, CT = 16;
 __device__ __forceinline__ int pos_of(int k1, int order) { return order ? ((k1 & 3) << 8) + (k1 >> 2) : k1; }
 
 // step 1's stores: workgroup (column tile, grid); thread (f = column of the tile, jk < 16); pass s: rows 4 (jk + 16 kb) + s
-__global__ __launch_bounds__(256) void store_kernel(double2 *__restrict__ out, int order, int spin) {
-    extern __shared__ double pad[];  // 70 KB: two workgroups per CU, as in the product
+__global__ __launch_bounds__(256) void store_kernel(double2 *__restrict__ out, int order, int spin, int pad = 0) {
+    extern __shared__ double lds_pad[];  // 70 KB: two workgroups per CU, as in the product
     const int tid = threadIdx.x, f = tid & 15, jk = tid >> 4;
-    double2 *O = out + ((size_t)blockIdx.y * (N2 / CT) + blockIdx.x) * ((size_t)N1 * CT);
+    double2 *O = out + ((size_t)blockIdx.y * (N2 / CT) + blockIdx.x) * ((size_t)N1 * CT + pad);
     double2 v = make_double2((double)tid, (double)blockIdx.x);
     for (int s = 0; s < 4; ++s) {
         for (int i = 0; i < spin; ++i) v.x = fma(v.x, 1.0000001, 1e-9);  // stands in for the pass's arithmetic
-        if (spin < 0) pad[tid] = v.x;
+        if (spin < 0) lds_pad[tid] = v.x;
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
             const int k1 = 4 * (jk + 16 * kb) + s;
@@ -45,22 +45,22 @@ __global__ __launch_bounds__(256) void store_kernel(double2 *__restrict__ out, i
 }
 
 // step 2's loads: workgroup = 8 rows of one target's three grids; thread (jl, f1 = row, jh): 16 loads per grid
-__global__ __launch_bounds__(256) void load_kernel(const double2 *__restrict__ in, double *__restrict__ sink, int order) {
-    extern __shared__ double pad[];
+__global__ __launch_bounds__(256) void load_kernel(const double2 *__restrict__ in, double *__restrict__ sink, int order, int pad = 0) {
+    extern __shared__ double lds_pad[];
     const int tid = threadIdx.x, jl = tid & 15, f1 = (tid >> 4) & 7, jh = tid >> 7;
     const int tiles = N1 / 8, T = blockIdx.x, tgt = T / tiles, r0 = (T % tiles) * 8;
     double acc = 0.0;
     for (int g = 0; g < 3; ++g) {
-        const double2 *G = in + ((size_t)tgt * 3 + g) * ((size_t)N1 * N2) + ((size_t)jh * N1 * CT) +
-                           (size_t)pos_of(r0 + f1, order) * CT + jl;
+        const size_t ts = (size_t)N1 * CT + pad;  // column-tile stride
+        const double2 *G = in + ((size_t)tgt * 3 + g) * ((N2 / CT) * ts) + (size_t)jh * ts + (size_t)pos_of(r0 + f1, order) * CT + jl;
         d2v v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            v[i] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(G + (size_t)i * 2 * N1 * CT));
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(G + (size_t)i * 2 * ts));
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc += v[i].x + v[i].y;
     }
-    if (acc == 12345.678) sink[0] = acc + pad[0];
+    if (acc == 12345.678) sink[0] = acc + lds_pad[0];
 }
 
 int main() {
@@ -68,9 +68,9 @@ int main() {
     const size_t n = (size_t)ntgt * 3 * N1 * N2;
     double2 *buf;
     double *sink;
-    CK(hipMalloc(&buf, n * 16));
+    CK(hipMalloc(&buf, n * 16 + (size_t)ntgt * 3 * (N2 / CT) * 4096 * 16));
     CK(hipMalloc(&sink, 64));
-    CK(hipMemset(buf, 0, n * 16));
+    CK(hipMemset(buf, 0, n * 16 + (size_t)ntgt * 3 * (N2 / CT) * 4096 * 16));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(store_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(load_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024));
     hipEvent_t e0, e1;
@@ -103,6 +103,27 @@ int main() {
             if (rep > 0 && ms < best) best = ms;
         }
         printf("load   order %d: %7.1f us  %6.0f GB/s\n", order, best * 1e3, gb / (best * 1e-3));
+    }
+    // padded column-tile stride (the 32 tiles a row workgroup reads sit 256 KB apart: a power of two)
+    for (int pad : {0, 16, 64, 256, 1024, 4096}) {
+        float bl = 1e30f, bs = 1e30f;
+        for (int rep = 0; rep < 6; ++rep) {
+            CK(hipEventRecord(e0));
+            store_kernel<<<dim3(N2 / CT, ntgt * 3), 256, 70 * 1024>>>(buf, 0, 200, pad);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < bs) bs = ms;
+            CK(hipEventRecord(e0));
+            load_kernel<<<dim3(ntgt * (N1 / 8)), 256, 36 * 1024>>>(buf, sink, 0, pad);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < bl) bl = ms;
+        }
+        printf("tile stride 256 KB + %6d B: store %7.1f us %6.0f GB/s   load %7.1f us %6.0f GB/s\n", pad * 16, bs * 1e3, gb / (bs * 1e-3),
+               bl * 1e3, gb / (bl * 1e-3));
     }
     // store then load back to back (what the chunk loop does): does the order change what the Infinity Cache keeps?
     for (int order = 0; order < 2; ++order) {
