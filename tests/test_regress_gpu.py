@@ -75,6 +75,33 @@ def test_ragged_batch_k135_vs_oracle():
         assert np.allclose(r["coefficients"][b], ref["coefficients"], rtol=1e-6, atol=1e-9), b
 
 
+def test_clip_loop_delta_gram_and_its_overflow_vs_oracle():
+    """Passes 2.. of the clip loop take the previous normal matrix minus the newly clipped cadences (an ascending list of
+    at most 256 per target); a target whose clip removes more than that at once is recomputed in full.  Both routes, and
+    a target that converges at once, against the oracle: identical masks, models within 1e-9 std(flux)."""
+    K = 40
+    ns = [9000, 3000, 2500]
+    rng = np.random.default_rng(5)
+    X0, y0, e0, c0 = make_problem(rng, ns[0], K, 0)
+    y0[rng.choice(ns[0], 300, replace=False)] += 1.0      # 3.3 % at one amplitude: 5.4 sigma, all clipped by the first clip
+    rng = np.random.default_rng(6)
+    X1, y1, e1, c1 = make_problem(rng, ns[1], K, 0)
+    for amp, cnt in ((0.5, 40), (0.02, 40), (0.004, 40)):  # the small ones only stand out once the large ones are gone
+        y1[rng.choice(ns[1], cnt, replace=False)] += amp * rng.choice([-1, 1], cnt)
+    X2, y2, e2, c2 = make_problem(rng, ns[2], K, 0)
+    Xs, ys, es, cms = (X0, X1, X2), (y0, y1, y2), (e0, e1, e2), (c0, c1, c2)
+    off = np.r_[0, np.cumsum(ns)]
+    r = _capi.regress_batch(np.vstack(Xs), np.concatenate(ys), off, err=np.concatenate(es), cadence_mask=np.concatenate(cms))
+    n_out = []
+    for b, n in enumerate(ns):
+        ref = O.regression_correct(Xs[b], ys[b], es[b], cms[b])
+        s = slice(off[b], off[b + 1])
+        assert np.array_equal(r["outlier_mask"][s], ref["outlier_mask"]), b
+        assert np.max(np.abs(r["model"][s] - ref["model"])) < 1e-9 * np.std(ys[b]), b
+        n_out.append(int(ref["outlier_mask"].sum()))
+    assert n_out[0] >= 300 and n_out[1] >= 100  # the cases are what the docstring says they are
+
+
 def test_full_width_k465_properties():
     """K = 465 (the N = 20000 design-matrix width): residual orthogonality X^T W r ~ 0 on the unclipped cadences
     (a size-independent property of the normal equations), and agreement with the oracle's model."""
