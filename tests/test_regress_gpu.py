@@ -102,6 +102,26 @@ def test_clip_loop_delta_gram_and_its_overflow_vs_oracle():
     assert n_out[0] >= 300 and n_out[1] >= 100  # the cases are what the docstring says they are
 
 
+@pytest.mark.parametrize("K", [3, 16, 17, 33, 50, 70, 90, 110, 128, 141, 143, 145])
+def test_narrow_gram_kernel_every_tile_count(K):
+    """[X | y] of K + 1 <= 144 columns takes the one-workgroup-per-matrix Gram kernel (T = 1 .. 9 tile columns, its waves'
+    tile runs differ with T); 145 is the first width on the 64 x 64-block kernel again.  Ragged N (partial last stage),
+    weights, a cadence mask: coefficients and model against the oracle."""
+    rng = np.random.default_rng(100 + K)
+    ns = [517, 1000, 33]
+    if K >= 33:
+        ns[2] = K + 40
+    Xs, ys, es, cms = zip(*[make_problem(rng, n, K, 3, smooth=False) for n in ns])
+    off = np.r_[0, np.cumsum(ns)]
+    r = _capi.regress_batch(np.vstack(Xs), np.concatenate(ys), off, err=np.concatenate(es), cadence_mask=np.concatenate(cms))
+    for b, n in enumerate(ns):
+        ref = O.regression_correct(Xs[b], ys[b], es[b], cms[b])
+        s = slice(off[b], off[b + 1])
+        assert np.array_equal(r["outlier_mask"][s], ref["outlier_mask"]), (K, b)
+        assert np.max(np.abs(r["model"][s] - ref["model"])) < 1e-9 * np.std(ys[b]), (K, b)
+        assert np.allclose(r["coefficients"][b], ref["coefficients"], rtol=1e-6, atol=1e-9), (K, b)
+
+
 def test_full_width_k465_properties():
     """K = 465 (the N = 20000 design-matrix width): residual orthogonality X^T W r ~ 0 on the unclipped cadences
     (a size-independent property of the normal equations), and agreement with the oracle's model."""
