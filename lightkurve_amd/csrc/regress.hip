@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void solve_kernel(const double *__restrict__ G
 // The same solve for K <= ~138 with the whole augmented system in LDS: no global round trips between the phases of a
 // column, the pivot found by a wave reduction + one 4-entry LDS exchange (2 barriers instead of 9), and a column-oriented
 // back substitution (1 barrier per unknown instead of 9).  Same pivot rule; the update order per element is unchanged.
-__global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict__ G, int K, int Kp,
+constexpr int SOLVE_NT = 1024, SOLVE_NW = SOLVE_NT / 64;  // sixteen waves: the trailing update of a column is rows / waves deep
+__global__ __launch_bounds__(SOLVE_NT) void solve_lds_kernel(const double *__restrict__ G, int K, int Kp,
                                                          const double *__restrict__ prior_mu,
                                                          const double *__restrict__ prior_sigma,
                                                          double *__restrict__ w, const int *__restrict__ done = nullptr) {
@@ -472,10 +473,10 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
     const int Ka = K + 1;
     double *A = s_A, *x = s_A + (size_t)K * Ka;
     double *s_pv = x + K;
-    int *s_pi = reinterpret_cast<int *>(s_pv + 4);
+    int *s_pi = reinterpret_cast<int *>(s_pv + SOLVE_NW);
     // prior terms once per row (x, s_pv.. are free until the elimination starts): 1 / sigma^2 and mu / sigma^2
-    double *p_d = x, *p_b = s_A + (size_t)K * Ka + K + 8;  // p_b: behind x and the pivot exchange words
-    for (int i = tid; i < K; i += 256) {
+    double *p_d = x, *p_b = s_A + (size_t)K * Ka + K + 2 * SOLVE_NW;  // p_b: behind x and the pivot exchange words
+    for (int i = tid; i < K; i += SOLVE_NT) {
         double d = 0.0, b = 0.0;
         if (prior_sigma) {
             const double sg = prior_sigma[(size_t)target * K + i];
@@ -490,12 +491,12 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
     // blocks hold the matrix; the mirrored part is read transposed), never the loaded value — a select between two loads
     // becomes two guarded loads with a wait each
     const int tot = K * Ka;
-    for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
+    for (int e0 = tid; e0 < tot; e0 += 4 * SOLVE_NT) {
         double v[4];
         int ii[4], jj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = min(e0 + 256 * u, tot - 1);
+            const int e = min(e0 + SOLVE_NT * u, tot - 1);
             const int i = e / Ka, j = e - i * Ka;
             ii[u] = i;
             jj[u] = j;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (e0 + 256 * u < tot) {
+            if (e0 + SOLVE_NT * u < tot) {
                 double a = v[u];
                 if (jj[u] == ii[u]) a += p_d[ii[u]];
                 if (jj[u] == K) a += p_b[ii[u]];
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
         // pivot: largest |A[i][j]|, i >= j, first one wins (LAPACK idamax)
         double best = -1.0;
         int bi = j;
-        for (int i = j + tid; i < K; i += 256) {
+        for (int i = j + tid; i < K; i += SOLVE_NT) {
             const double v = fabs(A[i * Ka + j]);
             if (v > best) {
                 best = v;
@@ -540,17 +541,17 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
         int p = s_pi[0];
         double pb = s_pv[0];
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
+        for (int q = 1; q < SOLVE_NW; ++q)
             if (s_pv[q] > pb || (s_pv[q] == pb && s_pi[q] < p)) {
                 pb = s_pv[q];
                 p = s_pi[q];
             }
         // multipliers straight from the un-swapped rows (row p plays the role of row j and vice versa), then the swap
         const double piv = A[p * Ka + j];
-        for (int i = j + 1 + tid; i < K; i += 256) x[i] = A[(i == p ? j : i) * Ka + j] / piv;
+        for (int i = j + 1 + tid; i < K; i += SOLVE_NT) x[i] = A[(i == p ? j : i) * Ka + j] / piv;
         __syncthreads();
         if (p != j) {
-            for (int c = tid; c < Ka; c += 256) {
+            for (int c = tid; c < Ka; c += SOLVE_NT) {
                 const double t0 = A[j * Ka + c];
                 A[j * Ka + c] = A[p * Ka + c];
                 A[p * Ka + c] = t0;
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
             const int c = j + 1 + lane + 64 * u;
             pr[u] = c < Ka ? A[j * Ka + c] : 0.0;
         }
-        for (int i = j + 1 + wave; i < K; i += 4) {
+        for (int i = j + 1 + wave; i < K; i += SOLVE_NW) {
             const double m = x[i];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -581,10 +582,10 @@ __global__ __launch_bounds__(256) void solve_lds_kernel(const double *__restrict
         const double xi = A[i * Ka + K] / A[i * Ka + i];
         __syncthreads();
         if (tid == 0) x[i] = xi;
-        for (int r = tid; r < i; r += 256) A[r * Ka + K] = fma(-A[r * Ka + i], xi, A[r * Ka + K]);
+        for (int r = tid; r < i; r += SOLVE_NT) A[r * Ka + K] = fma(-A[r * Ka + i], xi, A[r * Ka + K]);
         __syncthreads();
     }
-    for (int i = tid; i < K; i += 256) w[(size_t)target * K + i] = x[i];
+    for (int i = tid; i < K; i += SOLVE_NT) w[(size_t)target * K + i] = x[i];
 }
 
 // model[n] = sum_k X[n][k] w[k]; one wavefront per cadence row, lanes over k (coalesced), wave reduction.
@@ -1029,13 +1030,13 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
         else
             hipLaunchKernelGGL(gram_mfma_kernel<true>, dim3(nblk, B), dim3(256), 0, stream, X, y, err, cmask, outl, d_off, K,
                                KB, d_G, (const int *)d_done, (const int *)d_newcnt, (const int *)d_newidx, kNewCap);
-        const size_t solve_lds = ((size_t)K * (K + 1) + 2 * K + 8 + 2) * 8;  // system | x | pivot exchange | prior terms
+        const size_t solve_lds = ((size_t)K * (K + 1) + 2 * K + 2 * SOLVE_NW + 2) * 8;  // system | x | pivot exchange | prior terms
         if (solve_lds <= 160 * 1024) {
             {
                 const int rc_ = want_lds(h, reinterpret_cast<const void *>(solve_lds_kernel), 160 * 1024);
                 if (rc_) return rc_;
             }
-            hipLaunchKernelGGL(solve_lds_kernel, dim3(B), dim3(256), solve_lds, stream, d_G, K, Kp, prior_mu, prior_sigma, w,
+            hipLaunchKernelGGL(solve_lds_kernel, dim3(B), dim3(SOLVE_NT), solve_lds, stream, d_G, K, Kp, prior_mu, prior_sigma, w,
                                (const int *)d_done);
         } else {
             hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(256), 0, stream, d_G, K, Kp, prior_mu, prior_sigma, d_A, w,
