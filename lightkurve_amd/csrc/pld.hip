@@ -37,6 +37,9 @@ namespace lk {
 
 constexpr int PLD_LMAX = 64;  // largest small eigenproblem kept in LDS
 constexpr int PLD_DIRECT_MAX = 138;  // largest P whose Gram matrix fits LDS for the direct Jacobi (512 threads)
+#ifndef PLD_F32_RES
+#define PLD_F32_RES 1e-3  // relative residual above which the Chebyshev filter reads the float32 copy of C
+#endif
 constexpr int PLD_KC = 64;    // rows of the basis staged in LDS per step of the MFMA product C Q (64 x 66 doubles also hold
                               // eig_xty's 16 partial tiles; 128 rows left no room for a second workgroup on the CU)
 constexpr int PLD_QS = PLD_LMAX + 2;  // LDS row stride of that stage (doubles)
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__restrict__ Mcan, size_t mstride,
                                                                  const uint32_t *__restrict__ src,
                                                                  const double *__restrict__ mean, int Pc, int ldg, double Nd,
-                                                                 double *__restrict__ G) {
+                                                                 double *__restrict__ G, float *__restrict__ G32 = nullptr) {
     // a thread writes two groups of four neighbouring columns (16-byte reads of the index table, 32-byte stores); both
     // groups' index reads are issued before the gathers of either (the kernel is a chain index -> gather -> store, and one
     // group per thread left it at 2 TB/s of stores)
@@ -472,6 +475,9 @@ __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = v[u][t] - mi[u] * mj[u][t];
                 *reinterpret_cast<pld_d4 *>(Gb + (size_t)ii[u] * ldg + jj[u]) = o;
+                if (G32)  // the float32 copy the early filter products of the eigen-solver stream instead
+                    *reinterpret_cast<float4 *>(G32 + (size_t)b * ldg * ldg + (size_t)ii[u] * ldg + jj[u]) =
+                        make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
             }
     } else {
         for (int u = 0; u < 2 && e0 + 256 * u < tot; ++u) {
@@ -801,6 +807,7 @@ struct EigCtx {
     int T, W, rot, shred, vec, qstage;  // LDS: two l x ld matrices, rotation table, reduction scratch, 2 l scalars, stage
     int order;                          // LDS: l ints (offset in doubles)
     double *Gb;                         // this matrix (global, leading dimension ldg)
+    const float *G32b;                  // its float32 copy for the filter products of the early steps (or nullptr)
     int ldg, P, k, l, ld;
     int kc;                             // rows of the basis per LDS stage of eig_cq (a multiple of 8)
 };
@@ -939,7 +946,7 @@ static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double 
 // feeds MFMA tile j, whose column (lane & 15) is therefore column 64 w + 4 (lane & 15) + j of C (two and 32 w + 2 (lane &
 // 15) + j for the wide basis).  Loads run two steps
 // ahead of the matrix cores.  Every element of C is streamed exactly once per product.
-template <int NA>
+template <int NA, bool C32 = false>
 static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double *dst_) {
     cgdouble *src = (cgdouble *)src_;
     gdouble *dst = (gdouble *)dst_;
@@ -962,12 +969,23 @@ static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double 
         // loads went under a branch and the compiler issued them AFTER the step's MFMAs with a full wait at the top of the
         // next trip — the "two steps ahead" of the source was no prefetch at all (round 4, from the ISA).
         cgdouble *cp = (cgdouble *)c.Gb + (active ? n0 : NT * lr);
+        typedef float fvec __attribute__((ext_vector_type(NT)));
+        typedef __attribute__((address_space(1))) const fvec cgfvec;
+        typedef __attribute__((address_space(1))) const float cgfloat;
+        cgfloat *cp32 = (cgfloat *)c.G32b + (active ? n0 : NT * lr);  // C32: half the bytes of the stream
         const size_t rstride = active ? (size_t)ldg : 0;
         bool colok[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) colok[j] = active && n0 + j < P;
         auto load_b = [&](int st) -> bvec {
             const int krow = min(st * 4 + lq, P - 1);
+            if (C32) {
+                const fvec f = *(cgfvec *)(cp32 + (size_t)krow * rstride);
+                bvec r;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) r[j] = (double)f[j];
+                return r;
+            }
             return *(cgbvec *)(cp + (size_t)krow * rstride);
         };
         pld_d4 acc[NT][NA];
@@ -1145,7 +1163,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
                                                              double *__restrict__ scratch, double *__restrict__ V,
                                                              double *__restrict__ lam, long long *__restrict__ iters_out,
                                                              int max_it, int *__restrict__ status, int cheb_on, int kc,
-                                                             int mirror, double tol) {
+                                                             int mirror, double tol, const float *__restrict__ G32 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     double *Gb = G + (size_t)b * ldg * ldg;
@@ -1217,7 +1235,7 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
 
     // ---- subspace iteration with Rayleigh-Ritz steps
     double *Q = scratch + (size_t)b * 4 * P * l, *Z = Q + (size_t)P * l, *R = Z + (size_t)P * l, *Y = R + (size_t)P * l;
-    const EigCtx ctx{oT, oW, orot, oshred, ovec, oqstage, oorder, Gb, ldg, P, k, l, ld, kc};
+    const EigCtx ctx{oT, oW, orot, oshred, ovec, oqstage, oorder, Gb, G32 ? G32 + (size_t)b * ldg * ldg : nullptr, ldg, P, k, l, ld, kc};
     long long tprof[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = iters_out ? (long long)wall_clock64() : 0;
     auto lap = [&](int slot) {  // debug (LK_PLD_ITERS=1): per-phase 100 MHz ticks
         if (iters_out) {
@@ -1297,9 +1315,17 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
             for (int e = tid; e < P * l; e += nt) Y[e] = (Y[e] - cc * R[e]) * ie;
             __syncthreads();
             double *prev = R, *cur = Y, *free1 = Z, *free2 = Q;
+            // While the residual is far from the tolerance the filter's products read the FLOAT32 copy of C (half the bytes
+            // of a stream that is all of the product's time): the filter only has to amplify the wanted directions — the
+            // Ritz values, the residual and the convergence test come from the float64 product of the Rayleigh-Ritz step,
+            // and a float32 C limits the reachable residual to ~1e-7 theta_max, so the last steps filter in float64.
+            const bool f32 = ctx.G32b != nullptr && res > PLD_F32_RES * th0;
             for (int pw = 1; pw < npow; ++pw) {
                 double *nxt = free1;
-                eig_cq<NA>(ctx, cur, nxt);
+                if (f32)
+                    eig_cq<NA, true>(ctx, cur, nxt);
+                else
+                    eig_cq<NA>(ctx, cur, nxt);
                 for (int e = tid; e < P * l; e += nt) nxt[e] = 2.0 * ie * (nxt[e] - cc * cur[e]) - prev[e];
                 __syncthreads();
                 free1 = free2;
@@ -1741,7 +1767,7 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
 // top-k eigenpairs of the B Gram matrices G (P x P, leading dimension ldg) -> V (B x P x k), lam (B x k), both allocated
 // from ws.  mirror: G holds the upper 64 x 64 blocks only (gram_plain_launch) and is completed in place first.
 static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool products, bool mirror, double **V_out,
-                    double **lam_out, hipStream_t stream, Arena &ws) {
+                    double **lam_out, hipStream_t stream, Arena &ws, const float *G32 = nullptr) {
     constexpr int direct_max = PLD_DIRECT_MAX;
     // Convergence: || C r - theta r || <= eig_tol * theta_max * sqrt(k) over the k wanted pairs.  1e-10 (round 3; 1e-13 before)
     // costs one Rayleigh-Ritz step less per matrix (816 columns: 4.0 instead of 5.0) and moves the corrected flux of the
@@ -1841,10 +1867,10 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
         long long *d_it = dbg_iters ? (long long *)ws.alloc((size_t)B * 64) : nullptr;
         if (l <= 32)
             hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol, G32);
         else
             hipLaunchKernelGGL(pld_topk_eig_kernel<4>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol, G32);
         if (d_it) {
             std::vector<long long> hit((size_t)B * 8);
             LK_HIP_CHECK(hipMemcpyAsync(hit.data(), d_it, (size_t)B * 64, hipMemcpyDeviceToHost, stream));
@@ -2057,10 +2083,13 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
         }
 #undef LK_MG
     }
+    // blocks that go to the subspace iteration (too wide for the direct solver) also get a float32 copy of C: the
+    // early steps' filter products stream it instead (half the bytes); optional — without workspace nothing changes
+    float *G32 = (Pc > PLD_DIRECT_MAX && (Pc & 3) == 0) ? (float *)ws.alloc((size_t)B * ldg * ldg * 4) : nullptr;
     hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 511) / 512, B), dim3(256), 0, stream, Mcan,
-                       (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G);
+                       (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G, G32);
     double *V = nullptr, *lam = nullptr;
-    const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws);
+    const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws, G32);
     if (rc) return rc;
     {
         const size_t lds = (size_t)(64 * (k1 | 1)) * 8 + (size_t)Pc * 4;
@@ -2102,7 +2131,7 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     const int ldgmax = ((pmax + 63) / 64) * 64;
     h->ws.reset();
     const size_t per = (size_t)N * pmax * 8 + (size_t)2 * ldgmax * ldgmax * 8 + (size_t)4 * pmax * lmax * 8 +
-                       (size_t)pmax * pca_components * 8 + 4096;  // 2 x ldgmax^2: Gram + the moment form's canonical array
+                       (size_t)pmax * pca_components * 8 + (size_t)ldgmax * ldgmax * 4 + 4096;  // 2 x ldgmax^2: Gram + the moment form's canonical array
     int rc = h->ws.reserve((size_t)B * per * 2 + (size_t)(B + 1) * 8 + 65536);
     if (rc) return rc;
     std::vector<int64_t> off((size_t)B + 1);
