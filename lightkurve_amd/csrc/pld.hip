@@ -946,99 +946,139 @@ static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double 
 // feeds MFMA tile j, whose column (lane & 15) is therefore column 64 w + 4 (lane & 15) + j of C (two and 32 w + 2 (lane &
 // 15) + j for the wide basis).  Loads run two steps
 // ahead of the matrix cores.  Every element of C is streamed exactly once per product.
-template <int NA, bool C32 = false>
-static __device__ __noinline__ void eig_cq(EigCtx c, const double *src_, double *dst_) {
+// One pass of dst = C src over the column tiles [tile0, tile0 + nwv * NT): wave w owns NT consecutive tiles (16 NT columns),
+// a lane NT neighbouring columns of each row.  All waves of the workgroup call it together (it stages src through LDS).
+template <int NA, int NT, bool C32>
+static __device__ __noinline__ void eig_cq_pass(EigCtx c, const double *src_, double *dst_, int tile0) {
     cgdouble *src = (cgdouble *)src_;
     gdouble *dst = (gdouble *)dst_;
-    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
     const int lq = lane >> 4, lr = lane & 15, l = c.l, P = c.P, ldg = c.ldg, na = (l + 15) >> 4;
     LK_EIG_LDS;
     double *qstage = lds_dyn + c.qstage;
-    // NT tiles (= NT consecutive columns per lane) per wave: 4 while the 4 x NA accumulator tiles fit the register budget
+    typedef double bvec __attribute__((ext_vector_type(4)));  // (NT of its components are used)
+    typedef __attribute__((address_space(1))) const float cgfloat;
+    const int nsteps = (P + 3) >> 2, KC = c.kc;
+    const int col_w = (tile0 + wave * NT) << 4;  // first column of this wave
+    const bool active = col_w < P;
+    const int n0 = col_w + NT * lr;
+    // The loads of C are UNCONDITIONAL: rows clamped to P - 1 (the matching rows of the staged basis are zeros), an idle
+    // wave of the last pass re-reads row 0 of the first columns (L2).  Written as `(active && krow < P) ? load : 0` the
+    // loads went under a branch and the compiler issued them AFTER the step's MFMAs with a full wait at the top of the
+    // next trip — the "two steps ahead" of the source was no prefetch at all (round 4, from the ISA).
+    cgdouble *cp = (cgdouble *)c.Gb + (active ? n0 : NT * lr);
+    cgfloat *cp32 = (cgfloat *)c.G32b + (active ? n0 : NT * lr);  // C32: half the bytes of the stream
+    const size_t rstride = active ? (size_t)ldg : 0;
+    bool colok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) colok[j] = active && n0 + j < P;
+    auto load_b = [&](int st) -> bvec {
+        const int krow = min(st * 4 + lq, P - 1);
+        bvec r = bvec(0.0);
+        if (C32) {
+            cgfloat *q = cp32 + (size_t)krow * rstride;
+            if (NT == 4) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 f = *(__attribute__((address_space(1))) const f4 *)q;
+                r = bvec{(double)f[0], (double)f[1], (double)f[2], (double)f[3]};
+            } else if (NT >= 2) {  // (dword-aligned multi-dword loads are fine on global memory)
+                typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+                const f2 f = *(__attribute__((address_space(1))) const f2 *)q;
+                r[0] = (double)f[0];
+                r[1] = (double)f[1];
+                if (NT == 3) r[2] = (double)q[2];
+            } else {
+                r[0] = (double)q[0];
+            }
+        } else {
+            cgdouble *q = cp + (size_t)krow * rstride;
+            if (NT == 4) {
+                r = *(cgd4 *)q;
+            } else if (NT >= 2) {
+                typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+                const d2 f = *(__attribute__((address_space(1))) const d2 *)q;
+                r[0] = f[0];
+                r[1] = f[1];
+                if (NT == 3) r[2] = q[2];
+            } else {
+                r[0] = q[0];
+            }
+        }
+        return r;
+    };
+    pld_d4 acc[NT][NA];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    bvec b0 = load_b(0), b1 = load_b(1);
+    for (int k0 = 0; k0 < P; k0 += KC) {
+        __syncthreads();
+        for (int e = tid; e < KC * 16 * na; e += nt) {
+            const int kk = e / (16 * na), a = e - kk * (16 * na);
+            qstage[kk * PLD_QS + a] = (k0 + kk < P && a < l) ? src[(size_t)(k0 + kk) * l + a] : 0.0;
+        }
+        __syncthreads();
+        const int s_lo = k0 >> 2, s_hi = min(nsteps, (k0 + KC) >> 2);
+        for (int st = s_lo; st < s_hi; st += 2) {  // PLD_KC is a multiple of 8: step st + 1 stays inside the stage
+            const bvec c0 = b0, c1 = b1;
+            b0 = load_b(st + 2);
+            b1 = load_b(st + 3);
+            const int kk = st * 4 - k0;
+            double av[NA];
+#pragma unroll
+            for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + lq) * PLD_QS + ai * 16 + lr];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double bv = colok[t] ? c0[t] : 0.0;
+#pragma unroll
+                for (int ai = 0; ai < NA; ++ai)
+                    acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv, acc[t][ai], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + 4 + lq) * PLD_QS + ai * 16 + lr];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double bv = colok[t] ? c1[t] : 0.0;
+#pragma unroll
+                for (int ai = 0; ai < NA; ++ai)
+                    acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv, acc[t][ai], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t;
+#pragma unroll
+        for (int ai = 0; ai < NA; ++ai)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = ai * 16 + lq + 4 * r;
+                if (colok[t] && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
+            }
+    }
+}
+
+// dst = C src: full passes of NTMAX tiles per wave, then ONE last pass with as few tiles per wave as cover the rest —
+// 816 columns = 51 tiles on 8 waves ran as 4 + 4 tiles per wave (the second pass with 5 of 8 waves busy); 4 + 3 is an eighth
+// less (a pass costs what its busiest wave costs).
+template <int NA, bool C32 = false>
+static __device__ __forceinline__ void eig_cq(EigCtx c, const double *src, double *dst) {
+    const int nwv = (int)blockDim.x >> 6, tiles = (c.P + 15) >> 4;
+    // NTMAX tiles (= consecutive columns per lane) per wave: 4 while the 4 x NA accumulator tiles fit the register budget
     // of a 1024-thread workgroup, 2 for the wide basis (NA = 4: 4 x 4 tiles would be all 128 VGPRs)
-    constexpr int NT = NA <= 2 ? 4 : 2;
-    typedef double bvec __attribute__((ext_vector_type(NT)));
-    typedef __attribute__((address_space(1))) const bvec cgbvec;
-    const int ngrp = (P + 16 * NT - 1) / (16 * NT), nsteps = (P + 3) >> 2, KC = c.kc;
-    for (int gbase = 0; gbase < ngrp; gbase += nwv) {
-        const int grp = gbase + wave;
-        const bool active = grp < ngrp;
-        const int n0 = grp * (16 * NT) + NT * lr;
-        // The loads of C are UNCONDITIONAL: rows clamped to P - 1 (the matching rows of the staged basis are zeros), an idle
-        // wave of the last pass re-reads row 0 of its clamped group (L2).  Written as `(active && krow < P) ? load : 0` the
-        // loads went under a branch and the compiler issued them AFTER the step's MFMAs with a full wait at the top of the
-        // next trip — the "two steps ahead" of the source was no prefetch at all (round 4, from the ISA).
-        cgdouble *cp = (cgdouble *)c.Gb + (active ? n0 : NT * lr);
-        typedef float fvec __attribute__((ext_vector_type(NT)));
-        typedef __attribute__((address_space(1))) const fvec cgfvec;
-        typedef __attribute__((address_space(1))) const float cgfloat;
-        cgfloat *cp32 = (cgfloat *)c.G32b + (active ? n0 : NT * lr);  // C32: half the bytes of the stream
-        const size_t rstride = active ? (size_t)ldg : 0;
-        bool colok[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) colok[j] = active && n0 + j < P;
-        auto load_b = [&](int st) -> bvec {
-            const int krow = min(st * 4 + lq, P - 1);
-            if (C32) {
-                const fvec f = *(cgfvec *)(cp32 + (size_t)krow * rstride);
-                bvec r;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) r[j] = (double)f[j];
-                return r;
-            }
-            return *(cgbvec *)(cp + (size_t)krow * rstride);
-        };
-        pld_d4 acc[NT][NA];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_d4{0.0, 0.0, 0.0, 0.0};
-        bvec b0 = load_b(0), b1 = load_b(1);
-        for (int k0 = 0; k0 < P; k0 += KC) {
-            __syncthreads();
-            for (int e = tid; e < KC * 16 * na; e += nt) {
-                const int kk = e / (16 * na), a = e - kk * (16 * na);
-                qstage[kk * PLD_QS + a] = (k0 + kk < P && a < l) ? src[(size_t)(k0 + kk) * l + a] : 0.0;
-            }
-            __syncthreads();
-            const int s_lo = k0 >> 2, s_hi = min(nsteps, (k0 + KC) >> 2);
-            for (int st = s_lo; st < s_hi; st += 2) {  // PLD_KC is a multiple of 8: step st + 1 stays inside the stage
-                const bvec c0 = b0, c1 = b1;
-                b0 = load_b(st + 2);
-                b1 = load_b(st + 3);
-                const int kk = st * 4 - k0;
-                double av[NA];
-#pragma unroll
-                for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + lq) * PLD_QS + ai * 16 + lr];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const double bv = colok[t] ? c0[t] : 0.0;
-#pragma unroll
-                    for (int ai = 0; ai < NA; ++ai)
-                        acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv, acc[t][ai], 0, 0, 0);
-                }
-#pragma unroll
-                for (int ai = 0; ai < NA; ++ai) av[ai] = qstage[(kk + 4 + lq) * PLD_QS + ai * 16 + lr];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const double bv = colok[t] ? c1[t] : 0.0;
-#pragma unroll
-                    for (int ai = 0; ai < NA; ++ai)
-                        acc[t][ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ai], bv, acc[t][ai], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = n0 + t;
-#pragma unroll
-            for (int ai = 0; ai < NA; ++ai)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int a = ai * 16 + lq + 4 * r;
-                    if (colok[t] && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
-                }
-        }
+    constexpr int NTMAX = NA <= 2 ? 4 : 2;
+    int t0 = 0;
+    for (; tiles - t0 > nwv * (NTMAX - 1); t0 += nwv * NTMAX) eig_cq_pass<NA, NTMAX, C32>(c, src, dst, t0);
+    const int rest = tiles - t0;
+    if (rest > 0) {
+        const int ntl = (rest + nwv - 1) / nwv;  // 1 .. NTMAX - 1
+        if (ntl == 1)
+            eig_cq_pass<NA, 1, C32>(c, src, dst, t0);
+        else if (NTMAX > 2 && ntl == 2)
+            eig_cq_pass<NA, 2, C32>(c, src, dst, t0);
+        else if (NTMAX > 3)
+            eig_cq_pass<NA, 3, C32>(c, src, dst, t0);
     }
     __syncthreads();
 }
