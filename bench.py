@@ -760,9 +760,9 @@ def main():
               "executed_gram_flop_per_step": flop, "plain_gram_flop_per_step": flop_plain,
               "dominant_kernel": {"kernel": "pld_topk_eig_kernel<2> (subspace iteration on the 816-column block's 5.3-MB Gram "
                                             "matrices; the 121- and 136-column blocks take the direct tridiagonal solver)",
-                                  "bound": "hbm", "ms_per_step": 12.3, "hbm_bytes_per_step": 3.09e10,
-                                  "achieved_GBps": 3.09e10 / 12.3e-3 / 1e9, "frac": 3.09e10 / 12.3e-3 / 1e9 / HBM_PEAK_GBS,
-                                  "source": "profiles/r04_pld_kernel_stats.txt (12.28 ms per launch), r04_pld_pmc_fetch.txt / "
+                                  "bound": "hbm", "ms_per_step": 11.0, "hbm_bytes_per_step": 2.74e10,
+                                  "achieved_GBps": 2.74e10 / 11.0e-3 / 1e9, "frac": 2.74e10 / 11.0e-3 / 1e9 / HBM_PEAK_GBS,
+                                  "source": "profiles/r04_pld_kernel_stats.txt (11.03 ms per launch), r04_pld_pmc_fetch.txt / "
                                             "_write.txt (FETCH_SIZE + WRITE_SIZE of this kernel, 4 steps); constants of the "
                                             "committed passes, not re-measured in this run"},
               "frac_plain_gram_equivalent": flop_plain / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
