@@ -514,12 +514,15 @@ __global__ __launch_bounds__(SOLVE_NT) void solve_lds_kernel(const double *__res
             }
     }
     __syncthreads();
-    for (int j = 0; j < K; ++j) {
-        // pivot: largest |A[i][j]|, i >= j, first one wins (LAPACK idamax)
+    // The pivot of column j + 1 is found INSIDE the trailing update of column j: lane 0 of the wave that updates row i holds
+    // the new A[i][j + 1], so every wave leaves the best of its rows (first one wins: ascending rows, strict >) and the
+    // search costs no extra pass, no shuffles and no barrier of its own.  Same values compared, same winner as the
+    // separate search (LAPACK idamax: largest magnitude, smallest index).  Column 0 is searched the plain way.
+    {
         double best = -1.0;
-        int bi = j;
-        for (int i = j + tid; i < K; i += SOLVE_NT) {
-            const double v = fabs(A[i * Ka + j]);
+        int bi = 0;
+        for (int i = tid; i < K; i += SOLVE_NT) {
+            const double v = fabs(A[i * Ka]);
             if (v > best) {
                 best = v;
                 bi = i;
@@ -538,6 +541,8 @@ __global__ __launch_bounds__(SOLVE_NT) void solve_lds_kernel(const double *__res
             s_pi[wave] = bi;
         }
         __syncthreads();
+    }
+    for (int j = 0; j < K; ++j) {
         int p = s_pi[0];
         double pb = s_pv[0];
 #pragma unroll
@@ -565,13 +570,27 @@ __global__ __launch_bounds__(SOLVE_NT) void solve_lds_kernel(const double *__res
             const int c = j + 1 + lane + 64 * u;
             pr[u] = c < Ka ? A[j * Ka + c] : 0.0;
         }
+        // (the barrier behind the multipliers separates this column's reads of the candidate words from the next column's writes)
+        double nbest = -1.0;
+        int nbi = 0x7fffffff;
         for (int i = j + 1 + wave; i < K; i += SOLVE_NW) {
             const double m = x[i];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int c = j + 1 + lane + 64 * u;
-                if (c < Ka) A[i * Ka + c] = fma(-m, pr[u], A[i * Ka + c]);
+                if (c < Ka) {
+                    const double v = fma(-m, pr[u], A[i * Ka + c]);
+                    A[i * Ka + c] = v;
+                    if (u == 0 && lane == 0 && fabs(v) > nbest) {  // (lane 0, u = 0: column j + 1)
+                        nbest = fabs(v);
+                        nbi = i;
+                    }
+                }
             }
+        }
+        if (lane == 0) {
+            s_pv[wave] = nbest;  // -1 from a wave without rows: never the winner while a row is left
+            s_pi[wave] = nbi;
         }
         __syncthreads();
     }
