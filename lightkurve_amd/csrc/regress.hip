@@ -598,8 +598,7 @@ __global__ __launch_bounds__(SOLVE_NT) void solve_lds_kernel(const double *__res
     // column K); one barrier per unknown.  (Sum order differs from the dot-product form of the global kernel: results
     // agree to rounding.)
     for (int i = K - 1; i >= 0; --i) {
-        const double xi = A[i * Ka + K] / A[i * Ka + i];
-        __syncthreads();
+        const double xi = A[i * Ka + K] / A[i * Ka + i];  // (row i is not written below: one barrier per unknown is enough)
         if (tid == 0) x[i] = xi;
         for (int r = tid; r < i; r += SOLVE_NT) A[r * Ka + K] = fma(-A[r * Ka + i], xi, A[r * Ka + K]);
         __syncthreads();
