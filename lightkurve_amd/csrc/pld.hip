@@ -1642,29 +1642,49 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
         gu = fmax(gu, dd[i] + r);
         if (i < P - 1) e2max = fmax(e2max, ee[i] * ee[i]);
     }
-    for (int i = tid; i < P - 1; i += TD_NT) e2[i] = ee[i] * ee[i];  // (pb is free after the tridiagonalisation)
-    __syncthreads();
+    // Sturm counts in the PRODUCT form on the matrix scaled to norm ~1 (ddn = d / |T|, e2 = (e / |T|)^2; pb and vb are free
+    // after the tridiagonalisation): p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}, eigenvalues below x = sign changes of p.
+    // Three fp64 operations per step where the quotient form (q_i = d_i - x - e^2 / q_{i-1}, a v_rcp_f64 + Newton step)
+    // needs seven: with 1024 trial points on the CU this phase is bound by fp64 issue, not by the chain's latency
+    // (measured: four steps of operands in flight changed nothing).  p is rescaled every 8 steps (it grows by at most ~3
+    // per step on the scaled matrix); a zero takes the sign opposite to its predecessor's, which is what the quotient
+    // form's q = -pivmin meant.
     const double tnorm = fmax(fabs(gl), fabs(gu)), eps = 2.220446049250313e-16;
+    const double tinv = tnorm > 0.0 ? 1.0 / tnorm : 1.0;
+    double *ddn = vb;
+    for (int i = tid; i < P; i += TD_NT) {
+        ddn[i] = dd[i] * tinv;
+        if (i < P - 1) e2[i] = (ee[i] * tinv) * (ee[i] * tinv);
+    }
+    __syncthreads();
     const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max);
     auto count_below = [&](double x) {  // eigenvalues of T below x
+        const double xs = x * tinv;
         int cnt = 0;
-        double q = dd[0] - x;
-        if (fabs(q) < pivmin) q = -pivmin;
-        cnt += q < 0.0;
-        double dn = dd[1], en = e2[0];  // (P >= 3) the next step's coefficients are requested one step ahead
+        double p0 = 1.0, p1 = ddn[0] - xs;
+        if (p1 == 0.0) p1 = -1e-300;
+        bool neg = p1 < 0.0;
+        cnt += neg;
+        double dn = ddn[1], en = e2[0];  // (P >= 3) the next step's coefficients are requested one step ahead
         for (int i = 1; i < P; ++i) {
             const double di = dn, ei = en;
             if (i + 1 < P) {
-                dn = dd[i + 1];
+                dn = ddn[i + 1];
                 en = e2[i];
             }
-            // 1 / q by v_rcp_f64 and one Newton step (~1e-14: the count is a sign test, and the recurrence is the long
-            // dependent chain of this phase — an IEEE division is four times as deep)
-            double r = __builtin_amdgcn_rcp(q);
-            r = fma(fma(-q, r, 1.0), r, r);
-            q = fma(-ei, r, di - x);
-            if (fabs(q) < pivmin) q = -pivmin;
-            cnt += q < 0.0;
+            double pn = fma(di - xs, p1, -(ei * p0));
+            if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
+            const bool nneg = pn < 0.0;
+            cnt += nneg != neg;
+            neg = nneg;
+            p0 = p1;
+            p1 = pn;
+            if ((i & 7) == 0) {
+                const double ap = fabs(p1);
+                const double sc = ap > 1e150 ? 1e-150 : (ap < 1e-150 ? 1e150 : 1.0);
+                p1 *= sc;
+                p0 *= sc;
+            }
         }
         return cnt;
     };
