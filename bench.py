@@ -65,7 +65,8 @@ def parse(argv=None):
     ap.add_argument("--freqs", type=int, default=100000, help="trial frequencies (M)")
     ap.add_argument("--chunks", type=int, default=4, help="target chunks per step (comm/compute overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the astropy runs (cpu_baseline AND accuracy)")
-    ap.add_argument("--workload", default="ls", choices=["ls", "bls", "pld", "flatten", "lschi2", "pgsmooth", "fold", "regress"])
+    ap.add_argument("--workload", default="ls", choices=["ls", "api", "bls", "pld", "flatten", "lschi2", "pgsmooth", "fold", "regress"])
+    ap.add_argument("--no-api", action="store_true", help="workload ls: skip the api_end_to_end block (Python batch API, host included)")
     ap.add_argument("--regressors", type=int, default=135, help="regress: design-matrix columns K")
     ap.add_argument("--nterms", type=int, default=2, help="lschi2: Fourier terms")
     ap.add_argument("--cutouts", type=int, default=500, help="PLD: cutouts per GPU")
@@ -92,7 +93,15 @@ def parse(argv=None):
     ap.add_argument("--acc-exact", type=int, default=16, help="targets checked against astropy 'cython' (74 s of one core each)")
     ap.add_argument("--acc-bls", type=int, default=32, help="targets checked against astropy run_bls on the full period grid")
     ap.add_argument("--dry", action="store_true", help="CPU only: form the process group (gloo), barrier, max over ranks; no GPU work")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.api_headline = args.workload == "api"
+    if args.api_headline:
+        # the Python batch API as the headline: the LS 'fast' device step (for the kernel time and the results to compare
+        # with) + the api_end_to_end block, nothing else
+        args.workload, args.ls_method = "ls", "fast"
+        args.no_bls = args.no_pld = args.no_flatten = args.no_host = args.no_cpu_baseline = True
+        args.no_api = False
+    return args
 
 
 def effective_cores(cap=64):
@@ -832,9 +841,77 @@ def main():
             blk["speedup_vs_cpu_baseline"] = val / base["value"]
         return blk
 
+    def run_api(t_abs, y, dy, off, df, M, kern_ms, dev_peaks, d_pow):
+        """Wall time of the Python batch API on this rank's B light curves (reference idiom being replaced: the loop over a
+        LightCurveCollection, collections.py:145, calling lc.to_periodogram(), lightcurve.py:2490-2535).  Every figure is
+        host-inclusive wall clock per call: object access + packing + planning + PCIe + kernels."""
+        from lightkurve_amd import batch as LB
+        from lightkurve_amd.ingest import LightCurveBatch
+        from lightkurve_amd.lightcurve import LightCurve
+        from lightkurve_amd.periodogram import LombScarglePeriodogram
+        Bq = len(off) - 1
+        freq = df * (1.0 + np.arange(M))
+        lcs = [LightCurve(time=t_abs[off[b]:off[b + 1]], flux=y[off[b]:off[b + 1]], flux_err=dy[off[b]:off[b + 1]])
+               for b in range(Bq)]
+        kern_per_target = kern_ms / Bq
+
+        def wall(fn, reps=3):
+            fn()                                   # warm-up: pinned pools, workspace, first-touch
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = fn()
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)), r
+
+        def entry(sec, extra_fields=None):
+            ms_t = 1e3 * sec / Bq
+            d = {"wall_ms": 1e3 * sec, "ms_per_target": ms_t, "host_overhead_ms_per_target": ms_t - kern_per_target,
+                 "value": Bq * M / sec}
+            d.update(extra_fields or {})
+            return d
+
+        res = {"unit": "frequencies*targets/sec", "targets": Bq, "kernel_ms_per_target": kern_per_target,
+               "note": "wall clock of one Python call, median of 3 after one warm-up; host_overhead = wall - the HIP-event "
+                       "kernel time of the device-pointer step above (so it includes PCIe).  list_*: a list of B LightCurve "
+                       "objects (packed into the pinned staging pool inside the call); batch_*: a LightCurveBatch whose "
+                       "arrays are page-locked (LightCurveBatch.from_lightcurves(lcs, pinned=True), built once: "
+                       "`pack_once`).  *_spectra_pinned_out: out= a reused page-locked (B, M) array; *_spectra: a fresh "
+                       "pageable numpy result"}
+        sec, pk = wall(lambda: LB.lombscargle_peaks_batch(lcs, freq))
+        res["list_to_peaks"] = entry(sec, {"peaks_match_device_path": bool(np.array_equal(pk[:, 0], dev_peaks[0]) and
+                                                                           np.array_equal(pk[:, 1].astype(np.int64), dev_peaks[1]))})
+        h_pow = _capi.pinned_empty((Bq, M))
+        sec, pw = wall(lambda: LB.lombscargle_batch(lcs, freq, out=h_pow))
+        res["list_to_spectra_pinned_out"] = entry(sec, {"spectra_match_device_path": bool(np.array_equal(pw, d_pow.cpu().numpy(), equal_nan=True))})
+        sec, pw = wall(lambda: LB.lombscargle_batch(lcs, freq), reps=2)
+        res["list_to_spectra"] = entry(sec)
+        del pw
+        t0 = time.perf_counter()
+        lb = LightCurveBatch.from_lightcurves(lcs, pinned=True)
+        res["pack_once"] = {"wall_ms": 1e3 * (time.perf_counter() - t0), "ms_per_target": 1e3 * (time.perf_counter() - t0) / Bq}
+        sec, pk = wall(lambda: lb.to_periodogram_peaks(freq))
+        res["batch_to_peaks"] = entry(sec, {"peaks_match_device_path": bool(np.array_equal(pk[:, 0], dev_peaks[0]) and
+                                                                            np.array_equal(pk[:, 1].astype(np.int64), dev_peaks[1]))})
+        sec, pw = wall(lambda: lb.to_periodogram_power(freq, out=h_pow))
+        res["batch_to_spectra_pinned_out"] = entry(sec)
+        # the reference idiom kept as it is (B = 1 per call): one constructor call per light curve
+        nb1 = min(Bq, 32)
+        LombScarglePeriodogram.from_lightcurve(lcs[0], frequency=freq)
+        t0 = time.perf_counter()
+        for lc in lcs[:nb1]:
+            LombScarglePeriodogram.from_lightcurve(lc, frequency=freq)
+        sec1 = (time.perf_counter() - t0) / nb1
+        res["per_object_loop"] = {"ms_per_target": 1e3 * sec1, "value": M / sec1, "targets": nb1,
+                                  "note": "for lc in lcs: LombScarglePeriodogram.from_lightcurve(lc, frequency=...) — one "
+                                          "GPU call per light curve"}
+        return res
+
     if args.workload == "ls":
         # ---- synthetic inputs (SURVEY.md 8(d)); rank r owns targets [first, first + B)
         t, y, dy, off = synth.ls_batch(1, B, N, first_index=first)
+        t_abs = t.copy()       # the light curves' own times: what the Python batch API is handed (api_end_to_end below)
         for b in range(B):
             t[off[b]:off[b + 1]] -= t[off[b]]
         df = 360.0 / M
@@ -1031,6 +1108,14 @@ def main():
             except Exception as e:   # reported, never fatal for the headline
                 extra["host_to_host"] = {"error": repr(e)}
 
+        # ---- the product's Python batch API, host included: from light-curve objects / a LightCurveBatch to
+        # peaks and to spectra through lightkurve_amd.batch — what replaces the loop over a LightCurveCollection
+        if (not args.no_api) and not dist_on and headline == "fast":
+            try:
+                extra["api_end_to_end"] = run_api(t_abs, y, dy, off, df, M, kern_ms, peaks["fast"], d_pow)
+            except Exception as e:   # reported, never fatal for the headline
+                extra["api_end_to_end"] = {"error": repr(e)}
+
         # ---- BLS block of the metric
         if not args.no_bls:
             del d_pow
@@ -1216,6 +1301,14 @@ def main():
         if "config_ls_method" in extra:
             out["config"]["ls_method"] = extra.pop("config_ls_method")
         out.update(extra)
+        api = out.get("api_end_to_end") or {}
+        if args.api_headline and "batch_to_peaks" in api:
+            # --workload api: the line's value is what the Python API delivers, host included
+            out["device_pointer_step"] = {"value": value, "ms_per_step": out["ms_per_step"], "unit": unit}
+            out["metric"] = ("frequencies*targets/sec through the Python batch API, host included "
+                             "(LightCurveBatch.to_periodogram_peaks, ls_method='fast')")
+            out["value"] = api["batch_to_peaks"]["value"]
+            out["ms_per_step"] = api["batch_to_peaks"]["wall_ms"]
         if cpu_base is not None:
             out["cpu_baseline"] = {k: v for k, v in cpu_base.items() if not k.startswith("_")}
             out["speedup_vs_cpu_baseline"] = value / cpu_base["value"]

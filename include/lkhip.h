@@ -196,6 +196,15 @@ int lk_ls_fast_peaks_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, c
                                int normalization, const double *scale, int oversampling, double *power,
                                double *max_power, int64_t *argmax, void *stream);
 
+/* The batch form of the loop `for lc in collection: lc.to_periodogram(frequency=...)` (reference collections.py:145 over
+ * lightcurve.py:2490-2535 -> periodogram.py:869-967): `time` holds the ABSOLUTE times of the packed light curves; each
+ * chunk is rebased on the device to t - t[first cadence of its light curve] (astropy lombscargle/core.py:119-126 does the
+ * same subtraction per object) before the kernels of lk_ls_fast_peaks_batch run on it.  Everything else as above. */
+int lk_ls_fast_peaks_lc_batch(lk_handle *h, int B, const int64_t *n_off, const double *time, const double *flux,
+                              const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                              int normalization, const double *scale, int oversampling, double *power,
+                              double *max_power, int64_t *argmax);
+
 /* Pinned (page-locked) host memory for the host-pointer entry points: numpy arrays built over it are copied by DMA
  * without a staging pass.  Any host pointer is accepted everywhere; pinned ones are simply faster. */
 int lk_host_alloc(void **ptr, size_t bytes);

@@ -64,6 +64,9 @@ SIGNATURES = [
     ("lk_ls_fast_peaks_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    ("lk_ls_fast_peaks_lc_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int, _c_dp, _c_dp, _c_ip]),
     ("lk_host_alloc", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
     ("lk_host_free", ctypes.c_int, [_vp]),
     ("lk_fold_batch", ctypes.c_int,
@@ -368,13 +371,35 @@ def pinned_empty(shape, dtype=np.float64):
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
 
+_POOL = {}
+
+
+def pinned_pool(key, count, dtype=np.float64):
+    """float64[count] view of a page-locked staging buffer that is kept (and only ever grown) per ``key``: the packing
+    step of the batch front end writes the concatenated light curves here so that the host-pointer entry points DMA
+    them without the runtime's pageable staging.  The contents are valid until the next request for the same key."""
+    dtype = np.dtype(dtype)
+    count = int(count)
+    buf = _POOL.get(key)
+    if buf is None or buf.nbytes < count * dtype.itemsize:
+        _POOL.pop(key, None)
+        cap = max(count * dtype.itemsize + (count * dtype.itemsize >> 3), 1 << 16)
+        buf = _POOL[key] = pinned_empty(cap, np.uint8)
+    return buf[: count * dtype.itemsize].view(dtype)
+
+
+def release_pinned_pool():
+    _POOL.clear()
+
+
 def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True,
                         normalization="psd", scale=None, oversampling=5, device=0, out=None, want_power=True,
-                        want_peaks=True):
+                        want_peaks=True, absolute_time=False):
     """ls_method='fast' for B ragged targets through the pipelined host-pointer entry point.
     Returns (power[B, M] or None, max_power[B] or None, argmax[B] or None).  ``out``: preallocated float64[B, M]
     (e.g. from ``pinned_empty``) to receive the spectra; ``want_power=False`` keeps the spectra on the device and
-    returns only the per-target peaks (Periodogram.max_power / nanargmax)."""
+    returns only the per-target peaks (Periodogram.max_power / nanargmax).  ``absolute_time``: ``t`` holds the light
+    curves' own (absolute) times and each is rebased to ``t - t[first]`` on the device (lk_ls_fast_peaks_lc_batch)."""
     h = Handle.get(device)
     t, y = _f64(t), _f64(y)
     n_off = _offsets(n_off, t.size)
@@ -392,9 +417,10 @@ def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True
         raise ValueError("nothing requested")
     mx = np.empty(B, dtype=np.float64) if want_peaks else None
     am = np.empty(B, dtype=np.int64) if want_peaks else None
-    _check(_lib.lk_ls_fast_peaks_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), float(f0), float(df), M,
-                                       int(bool(fit_mean)), int(bool(center_data)), NORM[normalization], _ptr(scale),
-                                       int(oversampling), _ptr(power), _ptr(mx), _ptr(am, _c_ip)))
+    entry = _lib.lk_ls_fast_peaks_lc_batch if absolute_time else _lib.lk_ls_fast_peaks_batch
+    _check(entry(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), float(f0), float(df), M,
+                 int(bool(fit_mean)), int(bool(center_data)), NORM[normalization], _ptr(scale),
+                 int(oversampling), _ptr(power), _ptr(mx), _ptr(am, _c_ip)))
     return power, mx, am
 
 

@@ -6,142 +6,204 @@ import numpy as np
 
 from . import _capi
 from .distributed import all_gather_rows, device_gather_available, shard_bounds, sharded_map, sharded_map_ragged
-from .periodogram import _bls_plan, _ls_plan, exact_grid
+from . import packed
 
 __all__ = ["lombscargle_batch", "lombscargle_peaks_batch", "bls_batch", "periodogram_peaks", "flatten_batch",
            "estimate_cdpp_batch", "pld_correct_batch", "regression_correct_batch"]
 
 
-def _pack(arrs):
-    off = np.zeros(len(arrs) + 1, dtype=np.int64)
-    off[1:] = np.cumsum([len(a) for a in arrs])
-    return (np.concatenate(arrs) if arrs else np.zeros(0)), off
+def _resolve_device(device):
+    """The GPU this process drives: ``device`` if given; otherwise torch's current device under a RCCL process group
+    (one process per GPU: the launcher's LOCAL_RANK -> torch.cuda.set_device), else 0."""
+    if device is not None:
+        return int(device)
+    if device_gather_available():
+        import torch
+        return int(torch.cuda.current_device())
+    return 0
+
+
+def _slice_packed(cols, n_off, b0, b1):
+    a, b = int(n_off[b0]), int(n_off[b1])
+    return [c[a:b] for c in cols], n_off[b0:b1 + 1] - n_off[b0]
+
+
+def _local_packed(lcs, columns, prefix="pack", pinned="auto"):
+    """This rank's block of the batch as packed arrays -> (columns, n_off, bounds).  ``lcs``: a ``LightCurveBatch`` (its
+    arrays are used as they are; a block is a slice) or an iterable of light curves (one concatenation per column into
+    the pinned staging pool).  Without a process group the block is the whole batch and ``bounds`` is None; with one the
+    batch is cut into contiguous blocks balanced by cadence count (distributed.shard_bounds) BEFORE packing, so a rank
+    only touches its own light curves."""
+    from .distributed import _dist
+    from .ingest import LightCurveBatch
+    dist = _dist()
+    multi = dist is not None and dist.is_initialized()
+    if isinstance(lcs, LightCurveBatch):
+        cols, n_off = [getattr(lcs, c) for c in columns], lcs.n_off
+        if not multi:
+            return cols, n_off, None
+        bounds = shard_bounds(len(n_off) - 1, dist.get_world_size(), np.diff(n_off))
+        r = dist.get_rank()
+        c, o = _slice_packed(cols, n_off, int(bounds[r]), int(bounds[r + 1]))
+        return c, o, bounds
+    lcs = list(lcs)
+    bounds = None
+    if multi:
+        bounds = shard_bounds(len(lcs), dist.get_world_size(), [len(lc.time) for lc in lcs])
+        r = dist.get_rank()
+        lcs = lcs[int(bounds[r]):int(bounds[r + 1])]
+    cols, n_off = packed.pack_columns(lcs, columns, pinned=pinned, pool_prefix=prefix)
+    return cols, n_off, bounds
+
+
+def _finish(local, bounds, gather):
+    return all_gather_rows(local, bounds) if (bounds is not None and gather) else local
+
+
+def _ls_power_packed(time, flux, n_off, plan, device, want_power=True, want_peaks=False, out=None):
+    """Lomb-Scargle of a packed batch on the plan's shared grid -> (power[B, M] or None, max[B] or None, argmax[B] or None).
+    One vectorised NaN pass and one endpoint gather on the host; ``ls_method="fast"`` hands the absolute times to
+    ``lk_ls_fast_peaks_lc_batch`` (rebased on the device), the exact methods rebase in one numpy pass."""
+    time, flux, n_off = packed.drop_nan_flux(time, flux, n_off)
+    counts = np.diff(n_off)
+    B, M = len(counts), len(plan.f_day)
+    if B == 0:
+        return (np.zeros((0, M)) if want_power else None, np.zeros(0) if want_peaks else None,
+                np.zeros(0, np.int64) if want_peaks else None)
+    if counts.min() < 2:
+        raise ValueError("The light curve needs at least two cadences to build a periodogram.")
+    scale = packed.ls_scales(time, n_off, plan)
+    f_day = plan.f_day
+    kw = dict(normalization=plan.norm, scale=scale, device=device)
+    if plan.nterms == 1 and plan.ls_method in ("fast", "fastchi2"):
+        return _capi.ls_fast_peaks_batch(time, flux, n_off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=M,
+                                         want_power=want_power, want_peaks=want_peaks, out=out, absolute_time=True, **kw)
+    trel = packed.rebase_times(time, n_off)
+    if plan.nterms > 1 and plan.ls_method == "fastchi2":
+        power = _capi.ls_fast_batch(trel, flux, n_off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=M,
+                                    nterms=plan.nterms, **kw)
+    elif plan.exact is not None:
+        power = _capi.ls_power_batch(trel, flux, n_off, f0=plan.exact[0], df=plan.exact[1], M=M, nterms=plan.nterms, **kw)
+    else:
+        power = _capi.ls_power_batch(trel, flux, n_off, frequency=f_day, nterms=plan.nterms, **kw)
+    mx = am = None
+    if want_peaks:
+        mx, am = _capi.argmax_batch(power, device=device)
+    if out is not None and want_power:
+        out[...] = power
+        power = out
+    return (power if want_power else None), mx, am
 
 
 def lombscargle_batch(lcs, frequency, normalization="amplitude", freq_unit=None, oversample_factor=None,
-                      ls_method="fast", device=0, gather=True, nterms=1):
+                      ls_method="fast", device=None, gather=True, nterms=1, out=None):
     """Lomb-Scargle power of every light curve on one shared frequency grid -> float64[len(lcs), M].
-    Same semantics per target as ``LombScarglePeriodogram.from_lightcurve(lc, frequency=frequency, ...)``
+    Same result per target as ``LombScarglePeriodogram.from_lightcurve(lc, frequency=frequency, ...)``
     (``ls_method="fast"``: the reference's default FFT method; any other name: the exact kernels; ``nterms`` > 1
-    with ``ls_method`` "chi2"/"fastchi2": the multi-term kernels).
+    with ``ls_method`` "chi2"/"fastchi2": the multi-term kernels), but planned per BATCH: the grid is examined once,
+    the light curves are packed by one concatenation per column (``lcs``: a list of light curves — this package's or
+    lightkurve's — or a ``LightCurveBatch``, whose arrays are used as they are).  ``out``: preallocated float64[B, M]
+    (e.g. ``_capi.pinned_empty``) for the single-process result.
     With torch.distributed initialised, rank r computes a contiguous block of targets (balanced by cadence
     count) and, if ``gather``, the spectra are all-gathered so every rank returns all rows."""
-    frequency = np.asarray(frequency, dtype=np.float64)
-
-    def compute(local):
-        if not local:
-            return np.zeros((0, len(frequency)))
-        plans = [_ls_plan(lc, frequency=frequency, normalization=normalization, freq_unit=freq_unit,
-                          oversample_factor=oversample_factor, ls_method=ls_method, nterms=nterms) for lc in local]
-        t, off = _pack([p["trel"] for p in plans])
-        y, _ = _pack([p["flux"] for p in plans])
-        f_day = plans[0]["f_day"]
-        grid = exact_grid(f_day)
-        kw = dict(normalization=plans[0]["norm"], scale=[p["scale"] for p in plans], device=device)
-        nt = plans[0]["nterms"]
-        if nt > 1 and plans[0]["ls_method"] == "fastchi2":
-            return _capi.ls_fast_batch(t, y, off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=len(f_day),
-                                       nterms=nt, **kw)
-        if nt > 1:
-            if grid is not None:
-                return _capi.ls_power_batch(t, y, off, f0=grid[0], df=grid[1], M=len(f_day), nterms=nt, **kw)
-            return _capi.ls_power_batch(t, y, off, frequency=f_day, nterms=nt, **kw)
-        if plans[0]["ls_method"] in ("fast", "fastchi2"):
-            return _capi.ls_fast_batch(t, y, off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=len(f_day), **kw)
-        if grid is not None:
-            return _capi.ls_power_batch(t, y, off, f0=grid[0], df=grid[1], M=len(f_day), **kw)
-        return _capi.ls_power_batch(t, y, off, frequency=f_day, **kw)
-
-    lcs = list(lcs)
-    if gather and nterms == 1 and ls_method == "fast" and device_gather_available() and exact_grid_ok(frequency):
-        return _lombscargle_fast_gather_on_device(lcs, frequency, normalization, freq_unit, oversample_factor, device)
-    return sharded_map(lcs, compute, costs=[len(lc) for lc in lcs], gather=gather)
+    device = _resolve_device(device)
+    plan = packed.ls_grid_plan(frequency, normalization, freq_unit, oversample_factor, ls_method, nterms)
+    if gather and plan.nterms == 1 and plan.ls_method == "fast" and device_gather_available():
+        return _lombscargle_fast_gather_on_device(lcs, plan, device)
+    (time, flux), n_off, bounds = _local_packed(lcs, ("time", "flux"))
+    power = _ls_power_packed(time, flux, n_off, plan, device, out=out if bounds is None else None)[0]
+    return _finish(power, bounds, gather)
 
 
-def exact_grid_ok(frequency):
-    return len(frequency) >= 2 and np.allclose(np.diff(frequency), frequency[1] - frequency[0], rtol=1e-9, atol=0)
-
-
-def _lombscargle_fast_gather_on_device(lcs, frequency, normalization, freq_unit, oversample_factor, device):
+def _lombscargle_fast_gather_on_device(lcs, plan, device):
     """The multi-GPU form of ``lombscargle_batch`` for the default method with a RCCL group: this rank's block goes
     host -> HBM once, ``lk_ls_fast_peaks_batch_dev`` writes the spectra into a device tensor, the all-gather runs
-    HBM -> xGMI -> HBM, and the full (B, M) result crosses PCIe once on the way out.  (The numpy route stages every
-    shard through the host twice more: VERDICT r3.)"""
+    HBM -> xGMI -> HBM, and the full (B, M) result crosses PCIe once on the way out.  Tensors, stream and the lk_handle
+    all belong to ONE device (``device``: the rank's own GPU), made current for the duration."""
     import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
-    bounds = shard_bounds(len(lcs), world, [len(lc) for lc in lcs])
-    local = lcs[int(bounds[rank]):int(bounds[rank + 1])]
-    M = len(frequency)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    d_pow = torch.empty((len(local), M), dtype=torch.float64, device=dev)
-    if local:
-        plans = [_ls_plan(lc, frequency=frequency, normalization=normalization, freq_unit=freq_unit,
-                          oversample_factor=oversample_factor, ls_method="fast") for lc in local]
-        if plans[0]["ls_method"] != "fast":
-            raise ValueError("the device-resident gather needs a regular frequency grid")
-        t, off = _pack([p["trel"] for p in plans])
-        y, _ = _pack([p["flux"] for p in plans])
-        f_day = plans[0]["f_day"]
-        d_t, d_y = torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev)
-        d_scale = torch.from_numpy(np.asarray([p["scale"] for p in plans], dtype=np.float64)).to(dev)
-        d_max = torch.empty(len(local), dtype=torch.float64, device=dev)
-        d_arg = torch.empty(len(local), dtype=torch.int64, device=dev)
-        h = _capi.Handle.get(device)
-        stream = torch.cuda.current_stream().cuda_stream
-        _capi.ls_fast_peaks_batch_dev(h, len(local), off, d_t.data_ptr(), d_y.data_ptr(), 0, float(f_day[0]),
-                                      float(f_day[1] - f_day[0]), M, True, True, plans[0]["norm"], d_scale.data_ptr(), 5,
-                                      d_pow.data_ptr(), d_max.data_ptr(), d_arg.data_ptr(), stream)
-    return all_gather_rows(d_pow, bounds).cpu().numpy()
+    (t_l, y_l), off, bounds = _local_packed(lcs, ("time", "flux"), pinned=False)
+    t_l, y_l, off = packed.drop_nan_flux(t_l, y_l, off)
+    if len(off) > 1 and np.diff(off).min() < 2:
+        raise ValueError("The light curve needs at least two cadences to build a periodogram.")
+    nb, M = len(off) - 1, len(plan.f_day)
+    dev = torch.device("cuda", device)
+    with torch.cuda.device(dev):
+        d_pow = torch.empty((nb, M), dtype=torch.float64, device=dev)
+        if nb:
+            f_day = plan.f_day
+            d_t = torch.from_numpy(packed.rebase_times(t_l, off)).to(dev)
+            d_y = torch.from_numpy(np.ascontiguousarray(y_l)).to(dev)
+            d_scale = torch.from_numpy(packed.ls_scales(t_l, off, plan)).to(dev)
+            d_max = torch.empty(nb, dtype=torch.float64, device=dev)
+            d_arg = torch.empty(nb, dtype=torch.int64, device=dev)
+            h = _capi.Handle.get(device)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _capi.ls_fast_peaks_batch_dev(h, nb, off, d_t.data_ptr(), d_y.data_ptr(), 0, float(f_day[0]),
+                                          float(f_day[1] - f_day[0]), M, True, True, plan.norm, d_scale.data_ptr(), 5,
+                                          d_pow.data_ptr(), d_max.data_ptr(), d_arg.data_ptr(), stream)
+        return all_gather_rows(d_pow, bounds).cpu().numpy()
 
 
-def lombscargle_peaks_batch(lcs, frequency, normalization="amplitude", freq_unit=None, oversample_factor=None, device=0,
+def lombscargle_peaks_batch(lcs, frequency, normalization="amplitude", freq_unit=None, oversample_factor=None, device=None,
                             gather=True):
     """(max power, argmax) of the default-method (``ls_method="fast"``) periodogram of every light curve on one shared
     regular grid -> float64[len(lcs), 2] (column 1 holds the index).  The spectra never leave the GPU
-    (lk_ls_fast_peaks_batch with power = NULL) and with a process group only 16 B per target cross xGMI: this is the
+    (lk_ls_fast_peaks_lc_batch with power = NULL) and with a process group only 16 B per target cross xGMI: this is the
     collective to use when ``Periodogram.max_power`` / ``frequency_at_max_power`` is what the pipeline keeps
     (reference periodogram.py:127-140) — ``lombscargle_batch(gather=True)`` makes every rank hold all B x M powers."""
-    frequency = np.asarray(frequency, dtype=np.float64)
-
-    def compute(local):
-        if not local:
-            return np.zeros((0, 2))
-        plans = [_ls_plan(lc, frequency=frequency, normalization=normalization, freq_unit=freq_unit,
-                          oversample_factor=oversample_factor, ls_method="fast") for lc in local]
-        if plans[0]["ls_method"] != "fast":
-            raise ValueError("lombscargle_peaks_batch needs a regular frequency grid (the reference switches to 'slow')")
-        t, off = _pack([p["trel"] for p in plans])
-        y, _ = _pack([p["flux"] for p in plans])
-        f_day = plans[0]["f_day"]
-        _pw, mx, am = _capi.ls_fast_peaks_batch(t, y, off, f0=float(f_day[0]), df=float(f_day[1] - f_day[0]), M=len(f_day),
-                                                normalization=plans[0]["norm"], scale=[p["scale"] for p in plans],
-                                                device=device, want_power=False)
-        return np.column_stack([mx, am.astype(np.float64)])
-
-    return sharded_map(list(lcs), compute, costs=[len(lc) for lc in lcs], gather=gather)
+    device = _resolve_device(device)
+    plan = packed.ls_grid_plan(frequency, normalization, freq_unit, oversample_factor, "fast", 1)
+    if plan.ls_method != "fast":
+        raise ValueError("lombscargle_peaks_batch needs a regular frequency grid (the reference switches to 'slow')")
+    (time, flux), n_off, bounds = _local_packed(lcs, ("time", "flux"))
+    _pw, mx, am = _ls_power_packed(time, flux, n_off, plan, device, want_power=False, want_peaks=True)
+    return _finish(np.column_stack([mx, am.astype(np.float64)]), bounds, gather)
 
 
-def bls_batch(lcs, period, duration, objective="likelihood", oversample=10, device=0, gather=True):
+def _bls_options(period, duration, objective, oversample):
+    """The grid-level checks of ``BoxLeastSquaresPeriodogram.from_lightcurve`` / astropy ``BoxLeastSquares.power``
+    (reference periodogram.py:1101-1112, astropy bls/core.py:277-327, 668-700), once per batch."""
+    period = np.atleast_1d(np.asarray(period, dtype=np.float64))
+    if duration is None:
+        duration = [0.05, 0.10, 0.15, 0.20, 0.25, 0.33]
+    duration = np.atleast_1d(np.asarray(duration, dtype=np.float64))
+    if not np.all(np.isfinite(duration)):
+        raise ValueError("`duration` parameter contains illegal nan or inf value(s)")
+    if not np.all(np.isfinite(period)):
+        raise ValueError("`period` parameter contains illegal nan or inf value(s)")
+    if period.ndim != 1 or period.size == 0:
+        raise ValueError("period must be 1-dimensional")
+    if duration.ndim != 1 or duration.size == 0:
+        raise ValueError("duration must be 1-dimensional")
+    if np.min(period) <= np.max(duration):
+        raise ValueError("The maximum transit duration must be shorter than the minimum period")
+    try:
+        oversample = int(oversample)
+    except TypeError:
+        raise ValueError("oversample must be an int, got {0}".format(oversample))
+    if oversample < 1:
+        raise ValueError("oversample must be greater than or equal to 1")
+    objective = objective or "likelihood"
+    if objective not in ["snr", "likelihood"]:
+        raise ValueError("Unrecognized method '{0}'\nallowed methods are: {1}".format(objective, ["snr", "likelihood"]))
+    return period, duration, objective, oversample
+
+
+def bls_batch(lcs, period, duration=None, objective="likelihood", oversample=10, device=None, gather=True):
     """BLS power (and the other six statistics) of every light curve on one shared period grid.
-    Returns float64[len(lcs), 7, nP] ordered as ``_capi.BLS_FIELDS`` (transit_time absolute, like the reference)."""
-    period = np.asarray(period, dtype=np.float64)
-
-    def compute(local):
-        if not local:
-            return np.zeros((0, 7, len(period)))
-        plans = [_bls_plan(lc, period=period, duration=duration, objective=objective, oversample=oversample)
-                 for lc in local]
-        t, off = _pack([p["t"] for p in plans])
-        y, _ = _pack([p["y"] for p in plans])
-        w, _ = _pack([p["ivar"] for p in plans])
-        res = _capi.bls_batch(t, y, w, off, period, plans[0]["duration"], oversample, objective == "likelihood",
-                              device=device)
-        out = np.stack([res[k] for k in _capi.BLS_FIELDS], axis=1)
-        out[:, 4, :] += np.array([p["t_ref"] for p in plans])[:, None]
-        return out
-
-    return sharded_map(list(lcs), compute, costs=[len(lc) for lc in lcs], gather=gather)
+    Returns float64[len(lcs), 7, nP] ordered as ``_capi.BLS_FIELDS`` (transit_time absolute, like the reference).
+    ``lcs``: a list of light curves or a ``LightCurveBatch``; the per-target inputs (t - min t, y - median y, ivar) are
+    built by vectorised passes over the packed arrays (``packed.bls_inputs``)."""
+    device = _resolve_device(device)
+    period, duration, objective, oversample = _bls_options(period, duration, objective, oversample)
+    (time, flux, err), n_off, bounds = _local_packed(lcs, ("time", "flux", "flux_err"), prefix="bls")
+    if len(n_off) == 1:
+        return _finish(np.zeros((0, 7, len(period))), bounds, gather)
+    t, y, w, off2, t_ref = packed.bls_inputs(time, flux, err, n_off)
+    res = _capi.bls_batch(t, y, w, off2, period, duration, oversample, objective == "likelihood", device=device)
+    out = np.stack([res[k] for k in _capi.BLS_FIELDS], axis=1)
+    out[:, 4, :] += t_ref[:, None]
+    return _finish(out, bounds, gather)
 
 
 def periodogram_peaks(power, device=0):

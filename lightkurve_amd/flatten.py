@@ -18,23 +18,24 @@ def flatten_trend_batch(lcs, window_length=101, polyorder=2, break_tolerance=5, 
         log.warning("polyorder must be smaller than window_length, using polyorder={}.".format(polyorder))
     if window_length % 2 != 1:
         raise ValueError("window_length must be odd (scipy.signal.savgol_filter with mode='interp')")
-    ts = [np.asarray(lc.time, dtype=np.float64) for lc in lcs]
-    for t in ts:
-        if len(t) > 1 and np.any(np.diff(t) < 0):
-            raise ValueError("flatten needs the light curve sorted by time")
-    off = np.zeros(len(lcs) + 1, dtype=np.int64)
-    off[1:] = np.cumsum([len(t) for t in ts])
-    t = np.concatenate(ts) if ts else np.zeros(0)
-    f = np.concatenate([np.asarray(lc.flux, dtype=np.float64) for lc in lcs]) if ts else np.zeros(0)
+    from . import packed
+    lcs = list(lcs)
+    (t, f), off = packed.pack_columns(lcs, ("time", "flux"), pinned="auto", pool_prefix="flat")
+    if not packed.check_sorted(t, off):
+        raise ValueError("flatten needs the light curve sorted by time")
     m = None
     if masks is not None:
         if len(masks) != len(lcs):
             raise ValueError("masks must hold one entry (array or None) per light curve")
-        for i, mk in enumerate(masks):
-            if mk is not None and np.shape(mk) != (len(ts[i]),):
-                raise ValueError("mask %d has shape %s, its light curve has %d cadences" % (i, np.shape(mk), len(ts[i])))
-        m = np.concatenate([np.zeros(len(ts[i]), bool) if mk is None else np.asarray(mk, dtype=bool)
-                            for i, mk in enumerate(masks)])
+        if any(mk is not None for mk in masks):
+            m = np.zeros(t.size, dtype=bool)
+            for i, mk in enumerate(masks):
+                if mk is None:
+                    continue
+                n = int(off[i + 1] - off[i])
+                if np.shape(mk) != (n,):
+                    raise ValueError("mask %d has shape %s, its light curve has %d cadences" % (i, np.shape(mk), n))
+                m[off[i]:off[i + 1]] = mk
     trend = _capi.savgol_trend_batch(t, f, off, mask=m, window_length=window_length, polyorder=polyorder,
                                      break_tolerance=break_tolerance, niters=niters, sigma=sigma, device=device)
     return [trend[off[i]:off[i + 1]] for i in range(len(lcs))]

@@ -19,15 +19,12 @@ from .lightcurve import LightCurve
 __all__ = ["LightCurveBatch"]
 
 
-def _values(x):
-    """float64 ndarray of an ndarray / astropy Quantity / Time / masked column."""
-    x = getattr(x, "unmasked", x)
-    x = getattr(x, "value", x)
-    return np.asarray(x, dtype=np.float64)
+from .packed import values as _values  # noqa: E402,F401  (kept under its old name for callers)
 
 
 class LightCurveBatch(object):
     def __init__(self, time, flux, flux_err, n_off, meta=None):
+        # contiguous float64 inputs are kept as they are (page-locked arrays from ``_capi.pinned_empty`` stay page-locked)
         self.time = np.ascontiguousarray(time, dtype=np.float64)
         self.flux = np.ascontiguousarray(flux, dtype=np.float64)
         self.flux_err = np.ascontiguousarray(flux_err, dtype=np.float64)
@@ -40,20 +37,15 @@ class LightCurveBatch(object):
         self.quality = None   # per-cadence quality flags (set by from_fits; carried through remove_nans / normalize)
 
     @classmethod
-    def from_lightcurves(cls, lcs):
+    def from_lightcurves(cls, lcs, pinned=False):
         """From an iterable of light curves (this package's or lightkurve's own: Time / Quantity columns are read through
-        ``.value``)."""
-        ts, fs, es, meta = [], [], [], []
-        for lc in lcs:
-            t = _values(lc.time)
-            f = _values(lc.flux)
-            e = getattr(lc, "flux_err", None)
-            e = np.full(len(t), np.nan) if e is None else np.broadcast_to(_values(e), t.shape)
-            ts.append(t), fs.append(f), es.append(e), meta.append(dict(getattr(lc, "meta", {}) or {}))
-        off = np.zeros(len(ts) + 1, dtype=np.int64)
-        off[1:] = np.cumsum([len(t) for t in ts])
-        cat = lambda a: np.concatenate(a) if a else np.zeros(0)
-        return cls(cat(ts), cat(fs), cat(es), off, meta)
+        ``.value``): one concatenation per column.  ``pinned``: keep the three arrays in page-locked memory (lk_host_alloc)
+        so that every later ``to_periodogram_*`` / ``bls`` / ``flatten_trend`` call DMAs them without staging."""
+        from . import packed
+        lcs = list(lcs)
+        meta = [dict(getattr(lc, "meta", {}) or {}) for lc in lcs]
+        (t, f, e), off = packed.pack_columns(lcs, ("time", "flux", "flux_err"), pinned="own" if pinned else False)
+        return cls(t, f, e, off, meta)
 
     @classmethod
     def from_fits(cls, paths, flux_column=None, quality_bitmask="default", ext=1, device=0):
@@ -127,11 +119,24 @@ class LightCurveBatch(object):
                                         time_bin_size=time_bin_size, time_bin_start=time_bin_start, device=device)
         return LightCurveBatch(t, f, e, boff, [dict(m) for m in self.meta])   # binned cadences have no quality flag
 
-    def to_periodogram_power(self, frequency, normalization="amplitude", ls_method="fast", device=0, **kw):
-        """Lomb-Scargle power of every light curve on one shared grid (``batch.lombscargle_batch``) -> float64[B, M]."""
+    def to_periodogram_power(self, frequency, normalization="amplitude", ls_method="fast", device=None, **kw):
+        """Lomb-Scargle power of every light curve on one shared grid -> float64[B, M]: the packed arrays go straight to
+        the C ABI (``batch.lombscargle_batch`` plans per batch and never rebuilds per-target objects).  ``out=``: a
+        preallocated (e.g. ``_capi.pinned_empty``) float64[B, M]."""
         from .batch import lombscargle_batch
-        return lombscargle_batch(self.to_lightcurves(), frequency, normalization=normalization, ls_method=ls_method,
-                                 device=device, **kw)
+        return lombscargle_batch(self, frequency, normalization=normalization, ls_method=ls_method, device=device, **kw)
+
+    def to_periodogram_peaks(self, frequency, normalization="amplitude", device=None, **kw):
+        """(max power, argmax) per light curve of the default-method periodogram -> float64[B, 2]; the spectra stay in HBM
+        (``batch.lombscargle_peaks_batch``; reference periodogram.py:127-140)."""
+        from .batch import lombscargle_peaks_batch
+        return lombscargle_peaks_batch(self, frequency, normalization=normalization, device=device, **kw)
+
+    def bls(self, period, duration=None, objective="likelihood", oversample=10, device=None, **kw):
+        """The seven BLS statistics of every light curve on one shared period grid -> float64[B, 7, nP]
+        (``batch.bls_batch``)."""
+        from .batch import bls_batch
+        return bls_batch(self, period, duration, objective=objective, oversample=oversample, device=device, **kw)
 
     def flatten_trend(self, device=0, **kw):
         """The trend ``LightCurve.flatten`` divides by, for every light curve -> concatenated array in batch layout."""

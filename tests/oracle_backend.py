@@ -45,6 +45,30 @@ def ls_fast_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, cent
     return np.array(out)
 
 
+def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True, normalization="psd",
+                        scale=None, oversampling=5, device=0, out=None, want_power=True, want_peaks=True,
+                        absolute_time=False):
+    """Stand-in for lk_ls_fast_peaks_batch / lk_ls_fast_peaks_lc_batch (``absolute_time``: rebased per light curve here,
+    on the device in the product)."""
+    CALLS.append("ls_fast_peaks_lc_batch" if absolute_time else "ls_fast_peaks_batch")
+    t = np.asarray(t, float)
+    if absolute_time:
+        t = np.concatenate([tt - tt[0] for tt in _split(t, n_off)]) if len(n_off) > 1 else t
+    power = ls_fast_batch(t, y, n_off, dy=dy, f0=f0, df=df, M=M, fit_mean=fit_mean, center_data=center_data,
+                          normalization=normalization, scale=scale, oversampling=oversampling)
+    CALLS.pop()
+    if scale is not None and normalization == "lk_psd":
+        power = power * np.asarray(scale, float)[:, None]
+    mx = am = None
+    if want_peaks:
+        am = np.array([np.nanargmax(p) for p in power], dtype=np.int64)
+        mx = power[np.arange(len(power)), am]
+    if out is not None and want_power:
+        out[...] = power
+        power = out
+    return (power if want_power else None), mx, am
+
+
 def bls_batch(t, y, ivar, n_off, period, duration, oversample=10, use_likelihood=True, device=0):
     CALLS.append("bls_batch")
     res = [O.bls(tt, yy, ww, period, duration, oversample, use_likelihood)
