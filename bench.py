@@ -418,14 +418,18 @@ def cpu_baseline_fold(args):
             "sample": "32 light curves x %d cadences, numpy mod + stable argsort + two gathers" % args.cadences}
 
 
-# BLS instruction mix per (target, period) of configs[3], from the committed SQ counter passes of the kernels that run here
-# (profiles/r03_bls_pmc_sq.txt, _sq2.txt: 32 targets x 50 000 periods; bls.hip's kernels are unchanged since): busy
-# quad-cycles of the VALU and LDS instruction pipes summed over all SIMDs.
-BLS_PMC = {"valu_busy_quad_cycles": (10612892711 + 29818777104) / (32 * 50000.0),
-           "lds_busy_quad_cycles": (2467334992 + 6423630514) / (32 * 50000.0),
-           "lds_bank_conflict_cycles": (5150640294 + 8912977848) / (32 * 50000.0),
-           "valu_insts": (10379480852 + 29084692642) / (32 * 50000.0),
-           "lds_insts": (1293592587 + 2740276515) / (32 * 50000.0)}
+# BLS instruction mix per (target, period) of configs[3], from the committed SQ counter passes of THIS round's kernels at the
+# bench shape (profiles/r05_bls_pmc_sq.txt, _sq2.txt: `bench.py --workload bls --steps 1 --warmup 1` under rocprofv3 --pmc,
+# i.e. 2 steps x 1000 targets x 50 000 periods; bls_team_deep_kernel + bls_team_kernel): busy quad-cycles of the VALU and
+# LDS instruction pipes summed over all SIMDs.
+_BLS_PMC_UNITS = 2 * 1000 * 50000.0
+BLS_PMC = {"valu_busy_quad_cycles": (903958224704 + 1718560537839) / _BLS_PMC_UNITS,
+           "lds_busy_quad_cycles": (196665709376 + 357009061971) / _BLS_PMC_UNITS,
+           "lds_bank_conflict_cycles": (407316454294 + 476562731349) / _BLS_PMC_UNITS,
+           "lds_wait_cycles": (222445482287 + 407333220130) / _BLS_PMC_UNITS,
+           "valu_insts": (884767612883 + 1677464182329) / _BLS_PMC_UNITS,
+           "salu_insts": (554299774229 + 1072152555377) / _BLS_PMC_UNITS,
+           "lds_insts": (101366606862 + 151239607525) / _BLS_PMC_UNITS}
 
 
 def bls_roofline(Bb, nP, kms, equiv_tflops, traffic):
@@ -439,9 +443,11 @@ def bls_roofline(Bb, nP, kms, equiv_tflops, traffic):
             "unit": "SIMD issue quad-cycles per step", "frac": BLS_PMC["valu_busy_quad_cycles"] * units / slots,
             "lds_issue_frac": BLS_PMC["lds_busy_quad_cycles"] * units / slots,
             "per_target_period": {"valu_instructions": BLS_PMC["valu_insts"], "lds_instructions": BLS_PMC["lds_insts"],
-                                  "lds_bank_conflict_cycles": BLS_PMC["lds_bank_conflict_cycles"]},
-            "counters_from": "profiles/r03_bls_pmc_sq.txt, r03_bls_pmc_sq2.txt (rocprofv3 --pmc, 32 targets; same kernels); the "
-                             "clock under load is below 2.4 GHz, so the true fraction is higher by that ratio",
+                                  "lds_bank_conflict_cycles": BLS_PMC["lds_bank_conflict_cycles"],
+                                  "lds_wait_cycles": BLS_PMC["lds_wait_cycles"], "salu_instructions": BLS_PMC["salu_insts"]},
+            "counters_from": "profiles/r05_bls_pmc_sq.txt, r05_bls_pmc_sq2.txt (rocprofv3 --pmc passes of `bench.py --workload "
+                             "bls` at the bench shape, 1000 targets x 50 000 periods, this round's kernels); the clock under "
+                             "load is below 2.4 GHz, so the true fraction is higher by that ratio",
             "traffic": traffic, "kernel": "bls_team_kernel / bls_team_deep_kernel", "kernel_ms_per_step": kms,
             "equivalent_rate": {"value": equiv_tflops, "unit": "TFLOP/s", "frac_of_fp64_vector_peak": equiv_tflops / FP64_VECTOR_PEAK_TFLOPS,
                                 "note": "12 flop per (start bin, duration) candidate (SURVEY.md 8(d)) x ALL candidates / time — "

@@ -292,11 +292,14 @@ def regression_correct_batch(lcs, design_matrices, cadence_masks=None, sigma=5, 
     lcs, dms = list(lcs), list(design_matrices)
     if len(dms) != len(lcs):
         raise ValueError("one design matrix (collection) per light curve")
-    dms = [d if isinstance(d, DesignMatrixCollection) else DesignMatrixCollection([d]) for d in dms]
     for d in dms:
         if not isinstance(d, (DesignMatrix, DesignMatrixCollection)):
             raise ValueError("design_matrix_collection must be a DesignMatrix or DesignMatrixCollection")
-        d.validate()
+    # shapes and priors are checked for every target; the reference's low-rank WARNING (an SVD per matrix on the host,
+    # designmatrix.py:306-337 — ~50 ms per target, i.e. minutes per 1000 targets) is left to the per-object path
+    dms = [d if isinstance(d, DesignMatrixCollection) else DesignMatrixCollection([d], validate_rank=False) for d in dms]
+    for d in dms:
+        d.validate(rank=False)
     K = dms[0].X.shape[1] if dms else 0
     if any(d.X.shape[1] != K for d in dms):
         raise ValueError("regression_correct_batch needs design matrices with the same number of columns")

@@ -96,7 +96,9 @@ class DesignMatrix(object):
     def pca(self, nterms=6, n_iter=10, device=0):
         """A new DesignMatrix whose ``nterms`` columns are the leading left singular vectors of the column-centred matrix
         (reference :252-282, which calls the randomised ``fbpca.pca(values, nterms, n_iter)``; ``n_iter`` is accepted and
-        ignored: the GPU path iterates its subspace to a 1e-10 residual, i.e. to the exact singular subspace)."""
+        ignored: the GPU path iterates its subspace to a 1e-10 residual, i.e. to the exact singular subspace).
+        The kernel range is lk_pca_batch's (include/lkhip.h): ``nterms`` <= 48, <= 4096 columns, >= 2 rows — a ValueError
+        beyond it (there is no CPU fallback in this class; the lightkurve seam keeps the original method for such calls)."""
         from .. import _capi
         if nterms > self.shape[1]:
             nterms = self.shape[1]
@@ -132,10 +134,12 @@ class DesignMatrix(object):
 
 
 class DesignMatrixCollection(object):
-    def __init__(self, matrices):
+    def __init__(self, matrices, validate_rank=True):
+        """``validate_rank=False`` skips the reference constructor's per-matrix rank check (an SVD on the host, ~25 ms for
+        4500 x 137): the batch entry points build thousands of collections and check shapes / priors only."""
         self.matrices = list(matrices)
         self.X = np.hstack(tuple(m.X for m in self.matrices))
-        self.validate()
+        self.validate(rank=validate_rank)
 
     @property
     def values(self):
@@ -168,12 +172,12 @@ class DesignMatrixCollection(object):
         name = self.matrices[0].name if name is None else name
         return DesignMatrix(self.X, name=name, prior_mu=self.prior_mu, prior_sigma=self.prior_sigma)
 
-    def validate(self):
+    def validate(self, rank=True):
         n = {m.shape[0] for m in self.matrices}
         if len(n) != 1:
             raise ValueError("all design matrices must have the same number of cadences")
         for m in self.matrices:
-            m.validate()
+            m.validate() if rank else m.validate(rank=False)
 
     def __repr__(self):
         return "DesignMatrixCollection:\n" + "".join("\t{}\n".format(m.__repr__()) for m in self.matrices)

@@ -1863,12 +1863,13 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
     // Gram matrices that fit LDS (pixel / background blocks of <= 138 pixels, the 136-column 2nd-order product block): the
     // direct tridiagonal solver — ~0.5 ms per launch and matrix instead of the 2-3 ms of a subspace iteration's
     // Rayleigh-Ritz steps at this size
-    if (P >= 3 && P <= PLD_DIRECT_MAX) {
-        const int ntri = (P * (P + 1)) / 2;
-        const size_t lds = ((size_t)((ntri + 1) & ~1) + 6 * (size_t)P + ((k + 1) & ~1) + (size_t)P * k + (size_t)TD_LANES * 2 * P) * 8 + 16;
+    // (P = 134 .. 138 with k in the 40s needs more than 160 KB: those shapes fall through to the subspace iteration)
+    const size_t td_lds = ((size_t)((((P * (P + 1)) / 2) + 1) & ~1) + 6 * (size_t)P + ((k + 1) & ~1) + (size_t)P * k +
+                           (size_t)TD_LANES * 2 * P) * 8 + 16;
+    if (P >= 3 && P <= PLD_DIRECT_MAX && td_lds <= 160 * 1024) {
+        const size_t lds = td_lds;
         int rc_ = want_lds(h, reinterpret_cast<const void *>(pld_tridiag_eig_kernel), 160 * 1024);
         if (rc_) return rc_;
-        LK_REQUIRE(lds <= 160 * 1024, "internal: %zu bytes of LDS for a %d-column direct solve", lds, P);
         unsigned long long *d_clk = nullptr;
 #ifdef LK_PLD_DEBUG
         if (dbg_iters) d_clk = (unsigned long long *)ws.alloc(64);
@@ -2321,6 +2322,7 @@ int dm_pca_launch(lk_handle *h, int B, int N, int P, int k, const double *A_in, 
 int dm_spline_launch(lk_handle *h, int B, int N, const double *x, const double *knots, int n_inner, int degree, double *out,
                      hipStream_t stream) {
     LK_REQUIRE(B >= 1 && N >= 1 && n_inner >= 0, "bad shapes");
+    LK_REQUIRE(B <= 65535, "at most 65535 sample vectors per call (grid.y; got %d): split the batch", B);
     LK_REQUIRE(degree >= 0 && degree <= 7, "spline degree outside 0..7");
     LK_REQUIRE(x && knots && out, "NULL buffer");
     (void)h;

@@ -551,6 +551,9 @@ __global__ __launch_bounds__(SOLVE_NT) void solve_lds_kernel(const double *__res
                 pb = s_pv[q];
                 p = s_pi[q];
             }
+        // an all-NaN column leaves no candidate (every comparison with NaN is false, p = INT_MAX): keep row j — the result is
+        // NaN either way (numpy.linalg.solve gives NaN coefficients there too), but every LDS access stays in range
+        if (p < j || p >= K) p = j;
         // multipliers straight from the un-swapped rows (row p plays the role of row j and vice versa), then the swap
         const double piv = A[p * Ka + j];
         for (int i = j + 1 + tid; i < K; i += SOLVE_NT) x[i] = A[(i == p ? j : i) * Ka + j] / piv;
@@ -1118,7 +1121,8 @@ __global__ __launch_bounds__(256) void dm_standardize_kernel(const double *__res
 }
 
 int dm_standardize_launch(lk_handle *h, int B, int N, int P, const double *A, double *out, hipStream_t stream) {
-    LK_REQUIRE(B >= 1 && N >= 1 && P >= 1 && P <= 65535, "bad shapes");
+    LK_REQUIRE(B >= 1 && N >= 1 && P >= 1, "bad shapes");
+    LK_REQUIRE(B <= 65535, "at most 65535 matrices per call (grid.y; got %d): split the batch", B);
     LK_REQUIRE(A && out, "NULL buffer");
     (void)h;
     hipLaunchKernelGGL(dm_standardize_kernel, dim3(P, B), dim3(256), 0, stream, A, N, P, out);

@@ -61,3 +61,16 @@ def test_standardize_and_split_match_the_reference():
     assert np.array_equal(sp.values, G["split"])
     assert np.array_equal(sp.prior_mu, G["split_mu"]) and np.array_equal(sp.prior_sigma, G["split_sigma"])
     assert dm3.split([]) is dm3 and dm3.split([0]) is dm3
+
+
+def test_pca_wide_block_with_many_components_falls_to_the_subspace_iteration():
+    """P = 134..138 with k in the 40s needs more than 160 KB of LDS in the direct tridiagonal solver; such
+    shapes must take the subspace iteration instead of failing (reference designmatrix.py:252-282 has no such limit)."""
+    rng = np.random.default_rng(8)
+    N, P, k = 600, 138, 48
+    A = rng.normal(size=(N, 60)) @ rng.normal(size=(60, P)) * np.geomspace(1.0, 1e-3, P) + 1e-6 * rng.normal(size=(N, P))
+    U = _capi.pca_batch(A, k)
+    Ac = A - A.mean(axis=0)
+    ref = np.linalg.svd(Ac, full_matrices=False)[0][:, :k]
+    assert U.shape == (N, k) and np.max(np.abs(U.T @ U - np.eye(k))) < 1e-9
+    assert _subspace_gap(U, ref) < 1e-6

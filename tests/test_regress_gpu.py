@@ -231,3 +231,20 @@ def test_covariance_batch_k135_vs_oracle():
         ref = o["coefficients_cov"]
         scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
         assert np.max(np.abs(r["coefficients_cov"][b] - ref) / scale) < 1e-8
+
+
+def test_nan_regressor_column_gives_nan_coefficients_not_a_fault():
+    """an all-NaN column of the Gram matrix left the fused pivot search of solve_lds_kernel without a candidate
+    (row index INT_MAX).  numpy.linalg.solve returns NaN coefficients for such a system (reference
+    regressioncorrector.py:166-168); so must the kernel — and the other target of the batch must be untouched."""
+    rng = np.random.default_rng(3)
+    K, ns = 12, [500, 400]
+    Xs, ys, es, cms = zip(*[make_problem(rng, n, K, 4) for n in ns])
+    Xs = [x.copy() for x in Xs]
+    Xs[0][:, 5] = np.nan
+    off = np.r_[0, np.cumsum(ns)]
+    r = _capi.regress_batch(np.vstack(Xs), np.concatenate(ys), off, err=np.concatenate(es), cadence_mask=np.concatenate(cms))
+    assert np.all(np.isnan(r["coefficients"][0]))
+    ref = O.regression_correct(Xs[1], ys[1], es[1], cms[1], None, None)
+    assert np.allclose(r["coefficients"][1], ref["coefficients"], rtol=1e-6, atol=1e-9)
+    assert np.array_equal(r["outlier_mask"][off[1]:], ref["outlier_mask"])
