@@ -317,6 +317,91 @@ __device__ __forceinline__ void lds_bitonic_sort(unsigned long long *keys, int S
         }
 }
 
+// ------------------------------------------------------------------------------------------------ histogram select in LDS
+// Ranks qa and qb (either may be -1 = not wanted) among the nc values cand[0..nc) that all lie strictly inside (lo, hi):
+// a SEL_NB-bin histogram over the linear map of (lo, hi) (LDS atomics), a workgroup scan of the bins, the members of the one
+// or two bins that hold the wanted ranks gathered into a short list and ranked by counting.  The map v -> bin is monotone, so
+// every value of a lower bin is smaller than every value of a higher one and the result is the exact order statistic.
+// Two sweeps over the candidates and a 1024-bin scan (~5 us) instead of a 2048- or 4096-key bitonic sort (30 - 100 us with
+// every workgroup of a launch sorting at once: round 5's stop-point profile of the phase-split flatten pipeline).
+// Returns false (workgroup-uniform, nothing modified) when it does not apply: non-finite or empty bracket, no room behind
+// the candidates for the histogram, or more than SEL_LIST values in the wanted bins (heavy ties) — the caller sorts then.
+constexpr int SEL_NB = 1024;
+constexpr int SEL_LIST = 64;
+
+__device__ __forceinline__ bool lds_hist_select(const double *cand, int nc, int cap, int qa, int qb, double lo, double hi,
+                                                unsigned long long *sh, double *va, double *vb) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nc_pad = (nc + 1) & ~1;
+    if (!(hi > lo) || !isfinite(lo) || !isfinite(hi) || nc_pad + SEL_NB / 2 + SEL_LIST + 2 > cap || nc <= 0) return false;
+    int *hist = reinterpret_cast<int *>(const_cast<double *>(cand) + nc_pad);
+    double *list = const_cast<double *>(cand) + nc_pad + SEL_NB / 2;
+    int *ctl = reinterpret_cast<int *>(sh + 210);       // [0] bin of qa, [1] its exclusive prefix, [2], [3] same for qb, [4] list length
+    double *outv = reinterpret_cast<double *>(sh + 220);
+    __syncthreads();
+    for (int i = tid; i < SEL_NB; i += nt) hist[i] = 0;
+    if (tid == 0) {
+        ctl[0] = ctl[2] = -1;
+        ctl[1] = ctl[3] = ctl[4] = 0;
+    }
+    __syncthreads();
+    const double scale = (double)SEL_NB / (hi - lo);
+    auto bin = [&](double v) { return min(max((int)((v - lo) * scale), 0), SEL_NB - 1); };
+    for (int i = tid; i < nc; i += nt) atomicAdd(&hist[bin(cand[i])], 1);
+    __syncthreads();
+    const int BPT = (SEL_NB + nt - 1) / nt, b0 = tid * BPT;
+    int local = 0;
+    for (int u = 0; u < BPT; ++u)
+        if (b0 + u < SEL_NB) local += hist[b0 + u];
+    int tot;
+    int run = block_exscan_int(local, reinterpret_cast<int *>(sh), &tot);
+    for (int u = 0; u < BPT; ++u)
+        if (b0 + u < SEL_NB) {
+            const int c = hist[b0 + u];
+            if (qa >= run && qa < run + c) {
+                ctl[0] = b0 + u;
+                ctl[1] = run;
+            }
+            if (qb >= run && qb < run + c) {
+                ctl[2] = b0 + u;
+                ctl[3] = run;
+            }
+            run += c;
+        }
+    __syncthreads();
+    const int ba = ctl[0], bb = ctl[2];
+    for (int i = tid; i < nc; i += nt) {
+        const double v = cand[i];
+        const int b = bin(v);
+        if (b == ba || b == bb) {
+            const int slot = atomicAdd(&ctl[4], 1);
+            if (slot < SEL_LIST) list[slot] = v;
+        }
+    }
+    __syncthreads();
+    const int m = ctl[4];
+    if (m > SEL_LIST || (qa >= 0 && ba < 0) || (qb >= 0 && bb < 0)) {
+        __syncthreads();
+        return false;
+    }
+    if (tid < m) {
+        const double v = list[tid];
+        const int b = bin(v);
+        int r = (b == ba) ? ctl[1] : ctl[3];
+        for (int u = 0; u < m; ++u) {
+            const double w = list[u];
+            if (bin(w) == b && (w < v || (w == v && u < tid))) ++r;
+        }
+        if (r == qa) outv[0] = v;
+        if (r == qb) outv[1] = v;
+    }
+    __syncthreads();
+    if (qa >= 0) *va = outv[0];
+    if (qb >= 0) *vb = outv[1];
+    __syncthreads();
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ sampled selection
 // k-th smallest of the kept values in about ONE pass over the data instead of the eight of block_select_kth
 // (Floyd-Rivest style): a strided sample of <= SEL_SAMPLE kept values is sorted in LDS, two pivots lo <= hi bracket
@@ -327,11 +412,20 @@ __device__ __forceinline__ void lds_bitonic_sort(unsigned long long *keys, int S
 // an even count) from the same pass: *next receives it when want_next.
 constexpr int SEL_SAMPLE = 1024;
 
-template <class Val, class Keep>
+// A side computation that rides on the ONE pass over all values (the bracket's collect pass): side(i, v, lo) sees every kept
+// value v = val(i) together with `lo`, a lower bound of the order statistic being selected (the bracket's lower pivot).
+// *side_ran tells the caller whether that pass happened (the all-in-LDS and fallback routes do not run it).
+struct NoSide {
+    __device__ __forceinline__ void operator()(int, double, double) const {}
+};
+
+template <class Val, class Keep, class Side = NoSide>
 __device__ double block_select_sampled(int n, long long count, long long k, Val val, Keep keep, unsigned long long *sh,
                                        double *cand, int cap, bool want_next, double *next, int dbg = -1,
-                                       double *spacing = nullptr) {  // *spacing: mean gap between values around rank k (0 = unknown)
+                                       double *spacing = nullptr,  // *spacing: mean gap between values around rank k (0 = unknown)
+                                       Side side = Side(), bool *side_ran = nullptr) {
     if (spacing) *spacing = 0.0;
+    if (side_ran) *side_ran = false;
     const int tid = threadIdx.x, nt = blockDim.x;
     int *ictl = reinterpret_cast<int *>(sh + 200);  // [0] ncand, [1] sample size   (sh[0..199] are used by the callees)
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(cand);
@@ -389,10 +483,13 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         const long long s_all = block_count_fast(c, reinterpret_cast<long long *>(sh));
         if (s_all < 64) return fallback();  // (uniform: every thread sees the same s_all)
         const double pos = ((double)k + 0.5) * (double)s_all / (double)count;
-        // half-width of the bracket in sample ranks: 3.4 sigma of the rank scatter of a random sample, narrowed (never
-        // below 2.6 sigma) when that keeps the expected number of candidates under ~1800, i.e. inside a 2048-key sort
+        // half-width of the bracket in sample ranks: the rank of the wanted value among a random sample scatters by
+        // sigma = sqrt(s_all) / 2 around pos.  4 sigma (a miss — the full radix select, ~300 us — once in ~16 000 selects: with
+        // one light curve per workgroup and all of them in one wave of workgroups, ONE miss is what the whole launch waits
+        // for; at the 2.9 sigma this used before every launch of 1000 selects had a few), never below 2.65 sigma, and not
+        // more than ~2600 expected candidates: they are ranked by a histogram, not sorted (lds_hist_select).
         const double sq = sqrt((double)s_all);
-        const int delta = (int)fmin(1.5 * sq + 6.0, fmax(1.2 * sq + 4.0, 1800.0 * (double)s_all / (2.0 * (double)count)));
+        const int delta = (int)fmin(2.0 * sq + 6.0, fmax(1.2 * sq + 4.0, 2600.0 * (double)s_all / (2.0 * (double)count)));
         const int r_lo = (int)pos - delta, r_hi = (int)pos + delta;
         // pivots (registers, same in every thread): -inf / +inf when the bracket runs off the sample
         const double lo = r_lo < 0 ? -INFINITY : f64_from_sortable(keys[r_lo]);
@@ -403,6 +500,7 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         long long c_less = 0, c_eqlo = 0, c_eqhi = 0;
         strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
             if (keep(i)) {
+                side(i, v, lo);
                 if (v < lo)
                     ++c_less;
                 else if (v == lo)
@@ -414,6 +512,7 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
                     ++c_eqhi;
             }
         });
+        if (side_ran) *side_ran = true;
         if (dbg == 2) return 0.0;
         const long long n_less = block_count_fast(c_less, reinterpret_cast<long long *>(sh));
         const long long n_eqlo = block_count_fast(c_eqlo, reinterpret_cast<long long *>(sh));
@@ -423,10 +522,17 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         if (nc > cap) return fallback();
         if (spacing && nc > 0 && isfinite(lo) && isfinite(hi)) *spacing = (hi - lo) / (double)nc;
         if (dbg == 3) return 0.0;
-        // the candidates, sorted once (keys[] aliases cand[]): rank lookups are then plain LDS reads
+        // ranks k and k + 1 relative to the candidates; if they fall among them: histogram select, else (and when that does
+        // not apply) the candidates are sorted once (keys[] aliases cand[]) and rank lookups are plain LDS reads
+        const long long qa = k - n_less - n_eqlo, qb = qa + 1;
+        const bool need_a = qa >= 0 && qa < (long long)nc;
+        const bool need_b = want_next && k + 1 < count && qb >= 0 && qb < (long long)nc;
+        double hva = 0.0, hvb = 0.0;
+        const bool hist_ok = (need_a || need_b) &&
+                             lds_hist_select(cand, nc, cap, need_a ? (int)qa : -1, need_b ? (int)qb : -1, lo, hi, sh, &hva, &hvb);
         int S2 = 2;
         while (S2 < nc) S2 <<= 1;
-        const bool sorted = S2 <= cap;
+        const bool sorted = !hist_ok && (need_a || need_b) && S2 <= cap;
         if (sorted) {
             for (int i = tid; i < S2; i += nt) keys[i] = i < nc ? f64_sortable(cand[i]) : ~0ull;
             __syncthreads();
@@ -443,7 +549,10 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
             }
             if (q < n_eqlo) return lo;
             q -= n_eqlo;
-            if (q < nc) return sorted ? f64_from_sortable(keys[q]) : block_select_kth(nc, q, lds_val, lds_all, sh);
+            if (q < nc) {
+                if (hist_ok) return q == qa ? hva : hvb;  // (q is relative to the candidates here: qa or qa + 1)
+                return sorted ? f64_from_sortable(keys[q]) : block_select_kth(nc, q, lds_val, lds_all, sh);
+            }
             q -= nc;
             if (q < n_eqhi) return hi;
             miss = true;
@@ -469,14 +578,17 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
 }
 
 // numpy.median of the kept values through block_select_sampled; NaN if none kept.
-template <class Val, class Keep>
+template <class Val, class Keep, class Side = NoSide>
 __device__ double block_median_sampled(int n, long long count, Val val, Keep keep, unsigned long long *sh, double *cand,
-                                       int cap, int dbg = -1, double *spacing = nullptr) {
+                                       int cap, int dbg = -1, double *spacing = nullptr, Side side = Side(),
+                                       bool *side_ran = nullptr) {
     if (spacing) *spacing = 0.0;
+    if (side_ran) *side_ran = false;
     if (count <= 0) return __longlong_as_double(0x7ff8000000000000ll);
     const long long k = (count - 1) / 2;
     double nxt = 0.0;
-    const double a = block_select_sampled(n, count, k, val, keep, sh, cand, cap, (count & 1) == 0, &nxt, dbg, spacing);
+    const double a = block_select_sampled(n, count, k, val, keep, sh, cand, cap, (count & 1) == 0, &nxt, dbg, spacing, side,
+                                          side_ran);
     return (count & 1) ? a : (a + nxt) * 0.5;
 }
 
@@ -484,9 +596,9 @@ __device__ double block_median_sampled(int n, long long count, Val val, Keep kee
 // clipping iteration's): ONE pass counts the values below guess - width and collects those inside [guess - width, guess +
 // width]; if the two middle ranks fall among the collected values they are sorted (a few hundred keys) and the answer is
 // exact.  Otherwise *ok = false (every thread) and the caller runs block_median_sampled.  No sample, no 2048-key sort.
-template <class Val, class Keep>
+template <class Val, class Keep, class Side = NoSide>
 __device__ double block_median_near(int n, long long count, Val val, Keep keep, double guess, double width,
-                                    unsigned long long *sh, double *cand, int cap, bool *ok) {
+                                    unsigned long long *sh, double *cand, int cap, bool *ok, Side side = Side()) {
     const int tid = threadIdx.x, nt = blockDim.x;
     *ok = false;
     if (count <= 0 || !(width > 0.0) || !isfinite(guess)) return 0.0;
@@ -501,6 +613,7 @@ __device__ double block_median_near(int n, long long count, Val val, Keep keep, 
     long long c_less = 0;
     strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
         if (keep(i)) {
+            side(i, v, lo);   // (valid only if *ok comes back true: then the median is >= lo)
             if (v < lo)
                 ++c_less;
             else if (v <= hi) {

@@ -785,6 +785,769 @@ __global__ __launch_bounds__(1024) void flatten_kernel(
 #undef lap
 }
 
+
+// ================================================================================================ phase-split pipeline
+// Round 5.  The monolithic kernel above runs ~75 barrier-separated sweeps of one light curve in one 512-thread workgroup
+// at ONE register budget (128 VGPRs with 79 spilled, two workgroups per CU): it is bound by memory latency at 16 waves per
+// CU.  The same phases as separate kernels — state in the per-target slab plus a 64-byte FlatState — give every phase its own
+// register budget and occupancy (the streaming phases run 4 workgroups per CU, i.e. all 1000 light curves of the bench in
+// ONE wave of workgroups instead of two), and the embarrassingly parallel phases (trend tiles, final interpolation) can
+// use more than one workgroup per light curve.  A kernel boundary costs ~2 us; 1 + 4 niters + 1 = 14 of them per call.
+// The arithmetic of every phase is the monolithic kernel's, statement for statement.
+struct FlatState {
+    double dmed_prev, dspacing, rs1, rs2;
+    int nm, nm_prev, nseg, removed_any, t_nan, done, want_interp, pad;
+};
+
+struct FlatSlab {
+    double *tm, *fm, *tr, *xk, *yk;
+    int *idx, *idx2, *segs;
+    uint8_t *mask, *mask1;
+};
+
+__device__ __forceinline__ FlatSlab flat_slab(char *scratch, const int64_t *scratch_off, int target, int N) {
+    const int Npad = (N + 7) & ~7;
+    char *s = scratch + scratch_off[target];
+    FlatSlab sl;
+    sl.tm = reinterpret_cast<double *>(s);
+    sl.fm = sl.tm + Npad;
+    sl.tr = sl.fm + Npad;
+    sl.xk = sl.tr + Npad;
+    sl.yk = sl.xk + Npad;
+    sl.idx = reinterpret_cast<int *>(sl.yk + Npad);
+    sl.idx2 = sl.idx + Npad;
+    sl.segs = sl.idx2 + Npad;
+    sl.mask = reinterpret_cast<uint8_t *>(sl.segs + Npad + 8);
+    sl.mask1 = sl.mask + Npad;
+    return sl;
+}
+
+constexpr int FLAT_NT = 512;
+
+// ---- phase 0: initial mask (finite & |flux - nanmedian| <= sigma nanstd & ~user_mask), lightcurve.py:1002-1010
+__global__ __launch_bounds__(FLAT_NT, 8) void flat_init_kernel(const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
+                                                            const int64_t *__restrict__ n_off, double sigma,
+                                                            char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
+                                                            FlatState *__restrict__ state, int FIR_LDS, int dbg) {
+    // dbg (development builds, LK_FLAT_STOP=100+k): return at stop point k of the sampled select — kernel-time differences
+    // between successive stop points are the costs of its phases; -1 = run to the end
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
+    unsigned long long *sh = dyn_lds;
+    const int sh_words = max((int)blockDim.x, 264);
+    double *fir = reinterpret_cast<double *>(sh + sh_words);
+    int *shi = reinterpret_cast<int *>(fir + FIR_LDS + 2);
+    double *shd = reinterpret_cast<double *>(sh);
+    long long *shl = reinterpret_cast<long long *>(sh);
+    const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t lo = n_off[target];
+    const int N = (int)(n_off[target + 1] - lo);
+    flux += lo;
+    if (user_mask) user_mask += lo;
+    const FlatSlab sl = flat_slab(scratch, scratch_off, target, N);
+    uint8_t *mask = sl.mask;
+    if (tid == 0) {
+        FlatState st;
+        st.dmed_prev = __longlong_as_double(0x7ff8000000000000ll);
+        st.dspacing = 0.0;
+        st.rs1 = st.rs2 = 0.0;
+        st.nm = st.nm_prev = st.nseg = 0;
+        st.removed_any = 1;
+        st.t_nan = 1;
+        st.done = st.want_interp = st.pad = 0;
+        state[target] = st;
+    }
+    auto val = [&](int i) { return flux[i]; };
+    auto notnan = [&](int i) { return !isnan(flux[i]); };
+    int first = N;
+    for (int i = tid; i < N; i += nt)
+        if (isfinite(flux[i])) {
+            first = i;
+            break;
+        }
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+    if ((tid & 63) == 0) shi[tid >> 6] = first;
+    __syncthreads();
+    for (int w = 0; w < (nt >> 6); ++w) first = min(first, shi[w]);
+    __syncthreads();
+    const double shift = first < N ? flux[first] : 0.0;
+    long long c = 0, cinf = 0;
+    double part = 0.0, part2 = 0.0;
+    strided_pass<8>(N, val, [&](int, double f) {
+        if (!isnan(f)) {
+            ++c;
+            if (isinf(f)) {
+                ++cinf;
+            } else {
+                const double d = f - shift;
+                part += d;
+                part2 = fma(d, d, part2);
+            }
+        }
+    });
+    const long long cnt = block_count_fast(c, shl);
+    const long long ninf = block_count_fast(cinf, shl);
+    const double s1 = block_sum_fast(part, shd), s2 = block_sum_fast(part2, shd);
+    const double sd = ninf > 0 ? __longlong_as_double(0x7ff8000000000000ll)
+                               : sqrt(fmax(0.0, (s2 - s1 * s1 / (double)cnt) / (double)cnt));
+    __syncthreads();
+    if (dbg == 99) return;  // (stop point: statistics done, select not started)
+    const double med = block_median_sampled(N, cnt, val, notnan, sh, fir, FIR_LDS, dbg);
+    if (dbg >= 0) return;
+    strided_pass<8>(N, val, [&](int i, double f) {
+        bool m = isfinite(f) && (fabs(f - med) <= sd * sigma);
+        if (user_mask && user_mask[i]) m = false;
+        mask[i] = m ? 1 : 0;
+    });
+}
+
+// ---- phase 1 of an iteration: order-preserving compaction of the kept cadences fused with the gather of their times / fluxes
+__global__ __launch_bounds__(FLAT_NT) void flat_compact_kernel(const double *__restrict__ t, const double *__restrict__ flux,
+                                                               const int64_t *__restrict__ n_off, char *__restrict__ scratch,
+                                                               const int64_t *__restrict__ scratch_off,
+                                                               FlatState *__restrict__ state, double *__restrict__ trend, int it) {
+    __shared__ int shi[FLAT_NT / 64];
+    const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (state[target].done) return;
+    const int64_t lo = n_off[target];
+    const int N = (int)(n_off[target + 1] - lo);
+    t += lo;
+    flux += lo;
+    trend += lo;
+    const FlatSlab sl = flat_slab(scratch, scratch_off, target, N);
+    const uint8_t *mask = sl.mask;
+    int *idx = sl.idx;
+    double *tm = sl.tm, *fm = sl.fm;
+    const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+    const int strip = ((N + nw - 1) / nw + 63) & ~63;
+    const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
+    int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) shi[wv] = c;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < nw; ++w) {
+        if (w < wv) base += shi[w];
+        total += shi[w];
+    }
+    const int nm = total;
+    bool saw_nan = false;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
+        bool m[4];
+        unsigned mk[4];
+        double tv[4], fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);
+            mk[u] = mask[kc];
+            tv[u] = t[kc];
+            fv[u] = flux[kc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("" : "+v"(mk[u]), "+v"(tv[u]), "+v"(fv[u]));
+            m[u] = k0 + 64 * u + lane < k_hi && mk[u] != 0;
+            saw_nan |= m[u] && isnan(tv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long bal = __ballot(m[u]);
+            if (m[u]) {
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                idx[pos] = k0 + 64 * u + lane;
+                tm[pos] = tv[u];
+                fm[pos] = fv[u];
+            }
+            base += __popcll(bal);
+        }
+    }
+    const int any_nan = __syncthreads_or(saw_nan ? 1 : 0);
+    if (nm == 0) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int i = tid; i < N; i += nt) trend[i] = qnan;
+    }
+    if (tid == 0) {
+        state[target].nm = nm;
+        if (it == 0) state[target].t_nan = any_nan;
+        if (nm == 0) state[target].done = 1;  // (want_interp stays 0: the trend is all NaN)
+    }
+}
+
+// ---- phase 2: gap segmentation — cut where dt > break_tol * nanmedian(dt), lightcurve.py:1022-1027.
+// The cuts ride on the median's own pass over the time steps: every step larger than break_tol x (the bracket's lower pivot, a
+// lower bound of the median) is noted as a CANDIDATE cut in a small LDS list; once the median is known the few candidates
+// are re-tested against the exact threshold and ranked by position.  Two more sweeps over the times (count + compaction of
+// the cut predicate) only when that list overflows or no bound was available.
+constexpr int FLAT_CUT_CAP = 384;
+
+__global__ __launch_bounds__(FLAT_NT, 8) void flat_dtseg_kernel(const int64_t *__restrict__ n_off, double break_tol,
+                                                             char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
+                                                             FlatState *__restrict__ state, int FIR_LDS, int it, int near_on,
+                                                             int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
+    __shared__ int cut_n;
+    __shared__ int cut_i[FLAT_CUT_CAP];
+    unsigned long long *sh = dyn_lds;
+    const int sh_words = max((int)blockDim.x, 264);
+    double *fir = reinterpret_cast<double *>(sh + sh_words);
+    int *shi = reinterpret_cast<int *>(fir + FIR_LDS + 2);
+    long long *shl = reinterpret_cast<long long *>(sh);
+    const int target = blockIdx.x, tid = threadIdx.x;
+    const FlatState st = state[target];
+    if (st.done) return;
+    const int N = (int)(n_off[target + 1] - n_off[target]);
+    const FlatSlab sl = flat_slab(scratch, scratch_off, target, N);
+    const double *tm = sl.tm;
+    int *segs = sl.segs;
+    const int nm = st.nm;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    double dmed = qnan, dspacing = st.dspacing;
+    bool have_cuts = false;  // cut_i[0..cut_n) holds every step that can exceed the threshold (workgroup-uniform)
+    if (nm >= 2) {
+        auto dval = [&](int i) { return tm[i + 1] - tm[i]; };
+        auto dkeep = [&](int i) { return !isnan(tm[i + 1] - tm[i]); };
+        // step i (between kept cadences i and i + 1) cuts in front of cadence i + 1 if it exceeds break_tol * median; with
+        // break_tol >= 0 and a bound lo <= median, break_tol * lo <= break_tol * median (rounding is monotone)
+        const bool bound_ok = break_tol >= 0.0;
+        auto note = [&](int i, double d, double lo) {
+            if (d > break_tol * lo || !(lo >= 0.0)) {
+                const int slot = atomicAdd(&cut_n, 1);
+                if (slot < FLAT_CUT_CAP) cut_i[slot] = i + 1;
+            }
+        };
+        long long cnt = (long long)(nm - 1);
+        if (st.t_nan) {
+            long long c = 0;
+            strided_pass<8>(nm - 1, dval, [&](int, double d) { c += isnan(d) ? 0 : 1; });
+            cnt = block_count_fast(c, shl);
+            __syncthreads();
+        }
+        if (tid == 0) cut_n = 0;
+        __syncthreads();
+        bool near_ok = false;
+        if (it > 0 && near_on && st.dspacing > 0.0 && st.nm_prev >= nm) {
+            const double width = st.dspacing * (3.0 * (double)(st.nm_prev - nm) + 96.0);
+            dmed = block_median_near(nm - 1, cnt, dval, dkeep, st.dmed_prev, width, sh, fir, FIR_LDS, &near_ok, note);
+            have_cuts = near_ok && bound_ok;
+        }
+        if (!near_ok) {
+            __syncthreads();
+            if (tid == 0) cut_n = 0;  // (candidates noted against the failed guess are void)
+            __syncthreads();
+            bool ran = false;
+            dmed = block_median_sampled(nm - 1, cnt, dval, dkeep, sh, fir, FIR_LDS, dbg < 8 ? dbg : -1, &dspacing, note, &ran);
+            if (dbg >= 0 && dbg <= 8) return;  // (8: the whole select, fall-back routes included)
+            have_cuts = ran && bound_ok;
+        }
+        __syncthreads();
+        if (have_cuts && cut_n > FLAT_CUT_CAP) have_cuts = false;
+    }
+    const double thr = break_tol * dmed;  // NaN break_tol => every comparison false => no cuts
+    int nseg;
+    if (have_cuts) {
+        // (a NaN step is never a cut: dkeep excluded it from the pass, and `NaN > thr` is false in the reference too)
+        const int nc = cut_n;
+        int mine = -1;
+        if (tid < nc) {
+            const int i = cut_i[tid];
+            if ((tm[i] - tm[i - 1]) > thr) mine = i;
+        }
+        __syncthreads();
+        if (tid < nc) cut_i[tid] = mine;
+        __syncthreads();
+        int rank = 0, total = 0;
+        for (int j = 0; j < nc; ++j) {
+            const int v = cut_i[j];
+            if (v >= 0) {
+                ++total;
+                if (v < mine) ++rank;
+            }
+        }
+        if (tid == 0) segs[0] = 0;
+        if (mine >= 0) segs[1 + rank] = mine;
+        nseg = 1 + total;
+    } else {
+        nseg = strip_compact(
+            nm, [&](int i) { return i == 0 || (tm[i] - tm[i - 1]) > thr; }, segs, shi);
+    }
+    if (tid == 0) {
+        state[target].nseg = nseg;
+        if (nm >= 2) {
+            state[target].dmed_prev = dmed;
+            state[target].dspacing = dspacing;
+            state[target].nm_prev = nm;
+        }
+    }
+}
+
+// median of a short segment (fewer cadences than the window): the rare path of the trend kernel, kept out of line so that its
+// select machinery does not set the register budget of the streaming paths
+__device__ __noinline__ double flat_segment_median(const double *x, int len, unsigned long long *sh, double *cand, int cap) {
+    auto val = [&](int i) { return x[i]; };
+    auto keep = [&](int) { return true; };  // masked flux is finite
+    return block_median_sampled(len, (long long)len, val, keep, sh, cand, cap);
+}
+
+// ---- phase 3: per segment the median (short ones) or the Savitzky-Golay trend, lightcurve.py:1030-1046.  Every kept cadence
+// gets its trend exactly once; its residual goes into the two running sums the clip needs.  T = gridDim.y workgroups share a
+// light curve: the work items — one per short segment (its median), one per tile of a long segment's interior, one per long
+// segment's pair of edges — are dealt round-robin; a workgroup's residual sums go to rs_part[target * T + y] and the clip adds
+// the T partials in order (deterministic).  QUAD: the moment form of the interior (taps quadratic in the offset) instead of
+// the tap-by-tap FIR — two kernels so that each carries only its own registers.
+template <bool QUAD>
+__global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const int64_t *__restrict__ n_off, int window, int polyorder,
+                                                             double break_tol, const double *__restrict__ coeffs,
+                                                             const double *__restrict__ edge, char *__restrict__ scratch,
+                                                             const int64_t *__restrict__ scratch_off,
+                                                             const FlatState *__restrict__ state, int FIR_LDS, double quad_a,
+                                                             double quad_b, const double *__restrict__ edge_minv,
+                                                             double2 *__restrict__ rs_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
+    unsigned long long *sh = dyn_lds;
+    const int sh_words = max((int)blockDim.x, 264);
+    double *fir = reinterpret_cast<double *>(sh + sh_words);
+    double *shd = reinterpret_cast<double *>(sh);
+    const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const FlatState st = state[target];
+    if (st.done) return;
+    const int N = (int)(n_off[target + 1] - n_off[target]);
+    const FlatSlab sl = flat_slab(scratch, scratch_off, target, N);
+    const double *fm = sl.fm;
+    double *tr = sl.tr;
+    const int *segs = sl.segs;
+    const int nm = st.nm, nseg = st.nseg;
+    const int half = window / 2;
+    const int T = gridDim.y, y = blockIdx.y;
+    int item = 0;  // running work-item number (workgroup-uniform): this workgroup takes those with item % T == y
+    double rs1 = 0.0, rs2 = 0.0;
+    auto put = [&](int i, double v) {
+        tr[i] = v;
+        const double r = fm[i] - v;
+        rs1 += r;
+        rs2 = fma(r, r, rs2);
+    };
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int l = segs[sg], h = (sg + 1 < nseg) ? segs[sg + 1] : nm;
+        const int len = h - l;
+        if (window > len || (double)len < break_tol) {
+            if ((item++ % T) != y) continue;
+            __syncthreads();
+            const double med = flat_segment_median(fm + l, len, sh, fir, FIR_LDS);
+            for (int i = l + tid; i < h; i += nt) put(i, med);
+        } else {
+            // interior: correlate with the taps (window fully inside the segment)
+            const int o_lo = l + half, o_hi = h - half;  // outputs [o_lo, o_hi)
+            // Tiles of TO outputs; the tile's TO + window - 1 inputs are staged in LDS once (coalesced) as FP = 8
+            // interleaved sub-arrays (element e at [e % 8][e / 8], sub-array stride S = 4 mod 32: the staging stores
+            // and the reads below are both bank-conflict free).  A thread produces 8 NEIGHBOURING outputs from a
+            // sliding 8-value register window: per tap one 8-B LDS read (the value entering the window — lanes read
+            // consecutive addresses of one sub-array) and 8 FMAs, so the fp64 pipe is the limit, not the LDS (the
+            // 2-outputs-per-16-B-read version this replaces kept the LDS port 100 % busy at 21 % of the FMA peak).
+            // Every output accumulates its taps in the order of scipy's correlate1d, as before.
+            constexpr int FP = 8;
+            const int S = (((FIR_LDS / FP) - 4) / 32) * 32 + 4;
+            const int TO = S >= 36 ? ((FP * S - FP - (window - 1)) / FP) * FP : 0;
+            // polyorder <= 3: the taps are a quadratic in the offset, c_k = a + b k^2, so an output is
+            // a S0 + b S2 with the window moments S0 = sum y, S2 = sum k^2 y — O(1) per output from three prefix sums
+            // (y, u y, u^2 y; u = position relative to the tile centre) instead of `window` FMAs.  A tile spans at
+            // most 4 windows, which keeps the cancellation in S2 = W2 - 2 v W1 + v^2 W0 to a few bits: the result is
+            // within ~1e-14 of the tap-by-tap sum (tests state 1e-10).  Used for long windows only (quad_b != 0).
+            const int QCAP = QUAD ? FIR_LDS / 4 : FIR_LDS / 3;
+            const int QNI = min(QCAP, 4 * window), QTO = QNI - (window - 1);
+            if (QUAD && quad_b != 0.0 && QTO >= 64) {
+                // p0..p2: the tile's three prefix sums; xs: its inputs (the residual of an output needs its own flux: from LDS,
+                // not a second global round trip).  The inputs of this workgroup's NEXT tile are fetched (clamped, unconditional)
+                // before the scans of the current one: a tile costs one memory latency, hidden behind the previous tile.
+                double *p0 = fir, *p1 = fir + QCAP, *p2 = fir + 2 * QCAP, *xs = fir + 3 * QCAP;
+                const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+                const int ntile = (o_hi - o_lo + QTO - 1) / QTO;
+                int j = ((y - item) % T + T) % T;  // the first tile of this segment that is this workgroup's
+                item += ntile;
+                const int CHF = (QNI + nt - 1) / nt;  // inputs per thread: every tile uses chunks of CHF (<= 4 at 512 threads)
+                double xn[4] = {0.0, 0.0, 0.0, 0.0};
+                auto fetch = [&](int jj) {
+                    const int o0n = o_lo + jj * QTO, nin = min(QTO, o_hi - o0n) + window - 1;
+                    const double *xq = fm + (o0n - half);
+                    const int e0n = min(nin, tid * CHF);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xn[q] = xq[min(e0n + q, nin - 1)];
+                };
+                if (CHF <= 4 && j < ntile) fetch(j);
+                for (; j < ntile; j += T) {
+                    const int o0 = o_lo + j * QTO;
+                    const int no = min(QTO, o_hi - o0), ni = no + window - 1;
+                    const double uc = 0.5 * (double)(ni - 1);
+                    const double *x = fm + (o0 - half);
+                    const int CH = CHF;
+                    const int e0 = min(ni, tid * CH), e1 = min(ni, e0 + CH);
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                    double xr[4] = {0.0, 0.0, 0.0, 0.0};  // CH <= 4: the thread's inputs stay in registers for the second sweep
+                    if (CH <= 4) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            asm volatile("" : "+v"(xn[q]));
+                            xr[q] = xn[q];
+                        }
+                        if (j + T < ntile) fetch(j + T);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < CH && e0 + q < e1) {
+                                const double yv = xr[q], u = (double)(e0 + q) - uc;
+                                s0 += yv;
+                                s1 = fma(u, yv, s1);
+                                s2 = fma(u * u, yv, s2);
+                            }
+                    } else {
+                        for (int e = e0; e < e1; ++e) {
+                            const double yv = x[e], u = (double)e - uc;
+                            s0 += yv;
+                            s1 = fma(u, yv, s1);
+                            s2 = fma(u * u, yv, s2);
+                        }
+                    }
+                    double i0 = s0, i1 = s1, i2 = s2;  // inclusive scan over the wave, then over the waves
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const double a0 = __shfl_up(i0, off), a1 = __shfl_up(i1, off), a2 = __shfl_up(i2, off);
+                        if (lane >= off) {
+                            i0 += a0;
+                            i1 += a1;
+                            i2 += a2;
+                        }
+                    }
+                    __syncthreads();  // shd and the prefix arrays of the previous tile are free
+                    if (lane == 63) {
+                        shd[wv * 3 + 0] = i0;
+                        shd[wv * 3 + 1] = i1;
+                        shd[wv * 3 + 2] = i2;
+                    }
+                    __syncthreads();
+                    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+                    for (int w2 = 0; w2 < wv && w2 < nwv; ++w2) {
+                        r0 += shd[w2 * 3 + 0];
+                        r1 += shd[w2 * 3 + 1];
+                        r2 += shd[w2 * 3 + 2];
+                    }
+                    {
+                        const double x0 = __shfl_up(i0, 1), x1 = __shfl_up(i1, 1), x2 = __shfl_up(i2, 1);
+                        if (lane > 0) {
+                            r0 += x0;
+                            r1 += x1;
+                            r2 += x2;
+                        }
+                    }
+                    if (CH <= 4) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < CH && e0 + q < e1) {
+                                const int e = e0 + q;
+                                const double yv = xr[q], u = (double)e - uc;
+                                r0 += yv;
+                                r1 = fma(u, yv, r1);
+                                r2 = fma(u * u, yv, r2);
+                                p0[e] = r0;
+                                p1[e] = r1;
+                                p2[e] = r2;
+                                xs[e] = yv;
+                            }
+                    } else {
+                        for (int e = e0; e < e1; ++e) {
+                            const double yv = x[e], u = (double)e - uc;
+                            r0 += yv;
+                            r1 = fma(u, yv, r1);
+                            r2 = fma(u * u, yv, r2);
+                            p0[e] = r0;
+                            p1[e] = r1;
+                            p2[e] = r2;
+                            xs[e] = yv;
+                        }
+                    }
+                    __syncthreads();
+                    for (int q = tid; q < no; q += nt) {
+                        const int hi = q + window - 1;
+                        double w0 = p0[hi], w1 = p1[hi], w2 = p2[hi];
+                        if (q > 0) {
+                            w0 -= p0[q - 1];
+                            w1 -= p1[q - 1];
+                            w2 -= p2[q - 1];
+                        }
+                        const double v = (double)(q + half) - uc;
+                        const double m2 = fma(v, fma(v, w0, -2.0 * w1), w2);  // sum (u - v)^2 y
+                        const double tv = fma(quad_b, m2, quad_a * w0);
+                        tr[o0 + q] = tv;
+                        const double r = xs[q + half] - tv;
+                        rs1 += r;
+                        rs2 = fma(r, r, rs2);
+                    }
+                }
+            } else if (!QUAD && TO >= FP) {
+                for (int o0 = o_lo; o0 < o_hi; o0 += TO) {
+                    if ((item++ % T) != y) continue;
+                    const int no = min(TO, o_hi - o0), ni = no + window - 1;
+                    __syncthreads();
+                    for (int e = tid; e < ni + FP; e += nt)   // FP look-ahead slots past the end, zero filled
+                        fir[(e % FP) * S + e / FP] = e < ni ? fm[o0 - half + e] : 0.0;
+                    __syncthreads();
+                    for (int q = tid; FP * q < no; q += nt) {
+                        double win[FP], acc[FP];
+#pragma unroll
+                        for (int r = 0; r < FP; ++r) {
+                            win[r] = fir[r * S + q];  // x[8 q + r]
+                            acc[r] = 0.0;
+                        }
+                        int jb = 0;
+                        for (; jb + FP <= window; jb += FP) {
+                            const int nxt = q + 1 + jb / FP;
+#pragma unroll
+                            for (int jj = 0; jj < FP; ++jj) {
+                                const double cj = coeffs[jb + jj];
+#pragma unroll
+                                for (int r = 0; r < FP; ++r) acc[r] = fma(cj, win[(jj + r) & (FP - 1)], acc[r]);
+                                win[jj] = fir[jj * S + nxt];  // x[8 q + jb + jj + 8] replaces x[8 q + jb + jj]
+                            }
+                        }
+                        const int nxt = q + 1 + jb / FP;
+#pragma unroll
+                        for (int jj = 0; jj < FP - 1; ++jj) {  // the window % 8 last taps
+                            if (jb + jj < window) {
+                                const double cj = coeffs[jb + jj];
+#pragma unroll
+                                for (int r = 0; r < FP; ++r) acc[r] = fma(cj, win[(jj + r) & (FP - 1)], acc[r]);
+                                win[jj] = fir[jj * S + nxt];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < FP; ++r)
+                            if (FP * q + r < no) put(o0 + FP * q + r, acc[r]);
+                    }
+                }
+            } else if ((item++ % T) == y) {
+                for (int i = o_lo + tid; i < o_hi; i += nt) {
+                    const double *x = fm + (i - half);
+                    double acc = 0.0;
+                    for (int j = 0; j < window; ++j) acc = fma(coeffs[j], x[j], acc);
+                    put(i, acc);
+                }
+            }
+            // edges: polynomial refit of the first / last `window` samples (mode='interp').  The two windows are
+            // staged in LDS; thread (side, r) streams row r of the operator (stored transposed, [side][tap][row]:
+            // lanes read neighbouring rows) with 8 loads in flight — the plain tap loop was a chain of ~400
+            // dependent L2 round trips and had become the longest part of the segment.
+            if ((item++ % T) != y) continue;  // the pair of edges of this segment: one work item
+            __syncthreads();
+            for (int e = tid; e < 2 * window; e += nt)
+                fir[e] = e < window ? fm[l + e] : fm[h - window + (e - window)];
+            __syncthreads();
+            const int np1 = polyorder + 1;
+            if (edge_minv && 2 * window + 2 * np1 <= FIR_LDS) {
+                // The edge outputs are the least-squares polynomial of the side's `window` samples evaluated at the
+                // output's position: p + 1 moments sum_j u_j^b x_j per side (one wave per moment), beta = M^-1 m,
+                // then a Horner evaluation per output — O(window p) per segment instead of the half x window
+                // operator rows (401 dependent FMAs per output on L2-resident rows: after the moment-form interior
+                // this was most of the segment).  Abscissae scaled to [-1, 1] as on the host; polyorder <= 5.
+                const double c0 = 0.5 * (double)(window - 1), sc = c0 > 0.0 ? c0 : 1.0;
+                double *mom = fir + 2 * window;
+                const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+                for (int pair = wv; pair < 2 * np1; pair += nwv) {
+                    const int side = pair / np1, b = pair - side * np1;
+                    const double *x = fir + side * window;
+                    double sm = 0.0;
+                    for (int j = lane; j < window; j += 64) {
+                        const double u = ((double)j - c0) / sc;
+                        double ub = 1.0;
+                        for (int q = 0; q < b; ++q) ub *= u;
+                        sm = fma(ub, x[j], sm);
+                    }
+                    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                    if (lane == 0) mom[pair] = sm;
+                }
+                __syncthreads();
+                for (int e = tid; e < 2 * half; e += nt) {
+                    const int side = e >= half, r = e - side * half;
+                    const int pos = side ? (window - half + r) : r;
+                    const double u = ((double)pos - c0) / sc;
+                    double acc = 0.0;
+                    for (int a = np1 - 1; a >= 0; --a) {
+                        double beta = 0.0;
+                        for (int b = 0; b < np1; ++b) beta = fma(edge_minv[a * np1 + b], mom[side * np1 + b], beta);
+                        acc = fma(acc, u, beta);
+                    }
+                    put(side ? (h - half + r) : (l + r), acc);
+                }
+            } else {
+            for (int e = tid; e < 2 * half; e += nt) {
+                const int side = e >= half, r = e - side * half;
+                const double *x = fir + side * window;
+                const double *E = edge + (size_t)side * half * window + r;
+                double acc = 0.0;
+                int j = 0;
+                for (; j + 8 <= window; j += 8) {
+                    double ev[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ev[u] = E[(size_t)(j + u) * half];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = fma(ev[u], x[j + u], acc);
+                }
+                for (; j < window; ++j) acc = fma(E[(size_t)j * half], x[j], acc);
+                put(side ? (h - half + r) : (l + r), acc);
+            }
+            }
+        }
+        __syncthreads();
+    }
+    const double s1 = block_sum_fast(rs1, shd), s2 = block_sum_fast(rs2, shd);
+    if (tid == 0) rs_part[(size_t)target * T + y] = make_double2(s1, s2);
+}
+
+
+// ---- phase 4: clip |flux - trend| < sigma nanstd(flux - trend) + 1e-14 and mask[mask] &= mask1, lightcurve.py:1049-1063.
+// A light curve whose clip removed nothing (or whose last iteration this is) is frozen: done = 1, want_interp = 1.
+__global__ __launch_bounds__(FLAT_NT) void flat_clip_kernel(const int64_t *__restrict__ n_off, double sigma,
+                                                            char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
+                                                            FlatState *__restrict__ state, int last,
+                                                            const double2 *__restrict__ rs_part, int T) {
+    const int target = blockIdx.x, tid = threadIdx.x;
+    const FlatState st = state[target];
+    if (st.done) return;
+    const int N = (int)(n_off[target + 1] - n_off[target]);
+    const FlatSlab sl = flat_slab(scratch, scratch_off, target, N);
+    const double *fm = sl.fm, *tr = sl.tr;
+    const int *idx = sl.idx;
+    uint8_t *mask = sl.mask, *mask1 = sl.mask1;
+    const int nm = st.nm;
+    auto resid = [&](int i) { return fm[i] - tr[i]; };
+    double s1 = 0.0, s2 = 0.0;  // the trend workgroups' residual sums, in workgroup order
+    for (int y = 0; y < T; ++y) {
+        const double2 pr = rs_part[(size_t)target * T + y];
+        s1 += pr.x;
+        s2 += pr.y;
+    }
+    const double sd = sqrt(fmax(0.0, (s2 - s1 * s1 / (double)nm) / (double)nm));
+    const double lim = sd * sigma + 1e-14;
+    int removed = 0;
+    strided_pass<8>(nm, resid, [&](int i, double r) {
+        const bool keepit = fabs(r) < lim;
+        mask1[i] = keepit ? 1 : 0;
+        if (!keepit) {
+            mask[idx[i]] = 0;
+            removed = 1;
+        }
+    });
+    const int removed_any = __syncthreads_or(removed);
+    if (tid == 0) {
+        state[target].removed_any = removed_any;
+        if (last || !removed_any) {
+            state[target].done = 1;
+            state[target].want_interp = 1;
+        }
+    }
+}
+
+// ---- phase 5 (once, after the loop): linear interpolation / extrapolation of the kept trend onto every cadence,
+// lightcurve.py:1053-1058, from the frozen state of the light curve's last iteration; and the final mask.
+__global__ __launch_bounds__(FLAT_NT, 8) void flat_interp_kernel(const double *__restrict__ t, const int64_t *__restrict__ n_off,
+                                                              char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
+                                                              const FlatState *__restrict__ state, double *__restrict__ trend,
+                                                              uint8_t *__restrict__ final_mask) {
+    __shared__ int shi[FLAT_NT];
+    const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const FlatState st = state[target];
+    const int64_t lo = n_off[target];
+    const int N = (int)(n_off[target + 1] - lo);
+    t += lo;
+    trend += lo;
+    const FlatSlab sl = flat_slab(scratch, scratch_off, target, N);
+    const uint8_t *mask = sl.mask, *mask1 = sl.mask1;
+    if (final_mask) {
+        final_mask += lo;
+        for (int i = tid; i < N; i += nt) final_mask[i] = mask[i];
+    }
+    if (!st.want_interp) return;
+    const double *tm = sl.tm, *tr = sl.tr;
+    double *xk = sl.xk, *yk = sl.yk;
+    int *idx2 = sl.idx2;
+    const int nm = st.nm;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const int n2 = strip_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
+    if (n2 < 2) {
+        for (int i = tid; i < N; i += nt) trend[i] = qnan;
+    } else {
+        strided_pass<8>(n2, [&](int j) { return idx2[j]; }, [&](int j, int c) {
+            xk[j] = tm[c];
+            yk[j] = tr[c];
+        });
+        // After the update above mask[c] == 1 exactly for the knot cadences, in knot order.  np.searchsorted(x, xn,
+        // 'left') = number of knots with x < xn = number of knot cadences before cadence k (times are sorted), less
+        // any that share k's time.  Each wave owns a contiguous strip of cadences and carries a running knot count:
+        // no search, no barrier inside the sweep.
+        const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+        const int strip = ((N + nw - 1) / nw + 63) & ~63;
+        const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
+        int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        __syncthreads();
+        if (lane == 0) shi[wv] = c;
+        __syncthreads();  // also orders the xk / yk stores above before the loads below
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += shi[w];
+        for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
+            // four 64-cadence groups in flight: every stage of the dependent chain (mask/time -> knot index ->
+            // knot abscissae -> knot ordinates) is issued for all four before the next stage starts
+            bool in[4], kf[4];
+            double xn[4];
+            unsigned mk[4];
+            int j[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);  // clamped, unconditional, pinned (see the gather)
+                in[u] = k < k_hi;
+                mk[u] = mask[kc];
+                xn[u] = t[kc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("" : "+v"(mk[u]), "+v"(xn[u]));
+                kf[u] = in[u] && mk[u] != 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long bal = __ballot(kf[u]);
+                j[u] = base + __popcll(bal & ((1ull << lane) - 1ull));
+                base += __popcll(bal);
+            }
+            double xb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xb[u] = xk[max(j[u] - 1, 0)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("" : "+v"(xb[u]));
+                xb[u] = (in[u] && j[u] > 0) ? xb[u] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (in[u] && xb[u] >= xn[u]) {  // equal times: those knots are not "< xn" (rare)
+                    --j[u];
+                    while (j[u] > 0 && xk[j[u] - 1] >= xn[u]) --j[u];
+                }
+            }
+            double x0[4], x1[4], y0[4], y1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int hi_i = min(max(j[u], 1), n2 - 1), lo_i = hi_i - 1;
+                x0[u] = xk[lo_i];
+                x1[u] = xk[hi_i];
+                y0[u] = yk[lo_i];
+                y1[u] = yk[hi_i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (in[u]) {
+                    const double slope = (y1[u] - y0[u]) / (x1[u] - x0[u]);
+                    trend[k0 + 64 * u + lane] = isnan(xn[u]) ? qnan : slope * (xn[u] - x0[u]) + y0[u];
+                }
+            }
+        }
+    }
+}
+
 int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
                    const uint8_t *user_mask, int window, int polyorder, double break_tol, int niters, double sigma,
                    double *trend, uint8_t *final_mask, hipStream_t stream) {
@@ -863,7 +1626,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         soff[b + 1] = soff[b] + ((5 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + 8192);
+    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + (size_t)B * (64 + 8 * 16) + 8192);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     int64_t *d_soff = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
@@ -900,12 +1663,59 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
 #else
     constexpr int stop_at = -1;
 #endif
+#ifdef LK_FLAT_MONO
     if (resident)
         hipLaunchKernelGGL(flatten_kernel<true>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
                            break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
     else
         hipLaunchKernelGGL(flatten_kernel<false>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
                            break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
+#else
+    if (resident) {
+        hipLaunchKernelGGL(flatten_kernel<true>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
+                           break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
+    } else {
+        // the phase-split pipeline: 1 + 4 niters + 1 launches, state in the slab + FlatState
+        FlatState *d_state = (FlatState *)h->ws.alloc((size_t)B * sizeof(FlatState));
+        const size_t lds_sel = lds;  // sh | candidates / FIR area | shi: the select phases and the tap-by-tap trend kernel
+        // trend workgroups per light curve: enough tiles for each (a 20 000-cadence light curve has ~17 tiles of 1204 outputs at
+        // window 401; a 4500-cadence one 4), and B x T >= ~4 workgroups per CU
+        const int trend_T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nmax / 4096));
+        double2 *d_rs = (double2 *)h->ws.alloc((size_t)B * trend_T * sizeof(double2));
+        LK_REQUIRE(d_state != nullptr && d_rs != nullptr, "workspace exhausted (flatten state)");
+        // the moment-form trend kernel keeps four tile arrays (three prefix sums + the inputs): a third more LDS than the select
+        // phases' candidate area gives it the same 4-window tiles
+        // (1470 doubles per array: three 512-thread workgroups of this kernel fit a CU's 160 KB of LDS)
+        const int fir_trend = std::max(4 * 1470, ((window > 1470 / 2 ? fir_lds : 0) / 3) * 4);
+        const bool quad_kernel = quad_b != 0.0 && std::min(fir_trend / 4, 4 * window) - (window - 1) >= 64;
+        const size_t lds_trend = quad_kernel ? (size_t)std::max(FLAT_NT, 264) * 8 + (size_t)(fir_trend + 2) * 8 + (size_t)FLAT_NT * 4 : lds_sel;
+        int rc_ = want_lds(h, reinterpret_cast<const void *>(flat_init_kernel), 152 * 1024);
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_dtseg_kernel), 152 * 1024);
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_trend_kernel<true>), 152 * 1024);
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_trend_kernel<false>), 152 * 1024);
+        if (rc_) return rc_;
+        // the select phases: a 4096-double candidate area (the sampled selects collect <= ~1800 candidates) keeps FOUR of their
+        // workgroups on a CU — 1024 slots: the 1000 light curves of the bench shape run as one wave of workgroups
+        constexpr int fir_pick = 4096;
+        const size_t lds_pick = (size_t)std::max(FLAT_NT, 264) * 8 + (size_t)(fir_pick + 2) * 8 + (size_t)FLAT_NT * 4;
+        hipLaunchKernelGGL(flat_init_kernel, dim3(B), dim3(FLAT_NT), lds_pick, stream, flux, user_mask, d_off, sigma, d_s, d_soff,
+                           d_state, fir_pick, (stop_at >= 99 && stop_at < 200) ? stop_at - 100 : -1);
+        for (int it = 0; it < niters; ++it) {
+            hipLaunchKernelGGL(flat_compact_kernel, dim3(B), dim3(FLAT_NT), 0, stream, t, flux, d_off, d_s, d_soff, d_state, trend, it);
+            hipLaunchKernelGGL(flat_dtseg_kernel, dim3(B), dim3(FLAT_NT), lds_pick, stream, d_off, break_tol, d_s, d_soff, d_state,
+                               fir_pick, it, near_on, stop_at >= 200 ? stop_at - 200 : -1);
+            if (quad_kernel)
+                hipLaunchKernelGGL(flat_trend_kernel<true>, dim3(B, trend_T), dim3(FLAT_NT), lds_trend, stream, d_off, window, polyorder,
+                                   break_tol, d_c, d_e, d_s, d_soff, d_state, fir_trend, quad_a, quad_b, d_minv, d_rs);
+            else
+                hipLaunchKernelGGL(flat_trend_kernel<false>, dim3(B, trend_T), dim3(FLAT_NT), lds_sel, stream, d_off, window, polyorder,
+                                   break_tol, d_c, d_e, d_s, d_soff, d_state, fir_lds, quad_a, quad_b, d_minv, d_rs);
+            hipLaunchKernelGGL(flat_clip_kernel, dim3(B), dim3(FLAT_NT), 0, stream, d_off, sigma, d_s, d_soff, d_state,
+                               it == niters - 1 ? 1 : 0, d_rs, trend_T);
+        }
+        hipLaunchKernelGGL(flat_interp_kernel, dim3(B), dim3(FLAT_NT), 0, stream, t, d_off, d_s, d_soff, d_state, trend, final_mask);
+    }
+#endif
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }
