@@ -827,7 +827,8 @@ def main():
         algo = 24.0 * float(off[-1])
         rl = {"bound": "hbm", "achieved": algo / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-              "traffic": traffic_all.get("flatten"), "kernel": "flatten_kernel", "kernel_ms_per_step": kms,
+              "traffic": traffic_all.get("flatten"), "kernel": "the phase-split pipeline of flatten.hip: flat_init + niters x (flat_compact, flat_dtseg, flat_trend, "
+                                                              "flat_clip) + flat_interp, whole step", "kernel_ms_per_step": kms,
               "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
         return {"dt": dt, "kernel_ms": kms, "units_per_step": int(off[-1]), "steps": steps, "warmup": warmup,
                 "metric": "flatten cadences/sec (window %d, niters 3)" % args.flatten_window, "unit": "cadences/sec",

@@ -301,7 +301,9 @@ __device__ __forceinline__ void lds_bitonic_sort(unsigned long long *keys, int S
     if ((nt & 63) == 0 && S == nt) return lds_bitonic_sort_regs<1>(keys, S);
     if ((nt & 63) == 0 && S == 2 * nt) return lds_bitonic_sort_regs<2>(keys, S);
     if ((nt & 63) == 0 && S == 4 * nt) return lds_bitonic_sort_regs<4>(keys, S);
-    if ((nt & 63) == 0 && S == 8 * nt) return lds_bitonic_sort_regs<8>(keys, S);
+    // (S == 8 nt would keep 8 keys = 32 VGPRs of sort state per thread: the plain network below serves it — since the
+    // histogram select took over the large candidate sets this is a rare fall-back, and the register budget of every
+    // caller is set by its hot paths)
     for (int size = 2; size <= S; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int p = tid; p < S / 2; p += nt) {
@@ -455,8 +457,9 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         return a;
     };
     if (cap < 2 * SEL_SAMPLE) return fallback();
-    if (count <= (long long)cap) {
-        // everything fits: collect once, select in LDS
+    if (count <= (long long)min(cap, 2 * SEL_SAMPLE)) {
+        // everything fits a 2048-key sort: collect once, select in LDS (between that and `cap` values the sampled route
+        // below — 1024-key sample sort, ~15 % of the values collected, histogram — beats collecting and sorting them all)
         if (tid == 0) ictl[0] = 0;
         __syncthreads();
         strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
@@ -464,6 +467,36 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         });
         __syncthreads();
         const int nc = ictl[0];
+        // ranks k (and k + 1) by the histogram over [min, max] of the values when there is room for it behind them
+        {
+            double mn = INFINITY, mx = -INFINITY;
+            for (int i = tid; i < nc; i += nt) {
+                mn = fmin(mn, cand[i]);
+                mx = fmax(mx, cand[i]);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = fmin(mn, __shfl_xor(mn, o));
+                mx = fmax(mx, __shfl_xor(mx, o));
+            }
+            double *red = reinterpret_cast<double *>(sh);
+            __syncthreads();
+            if ((tid & 63) == 0) {
+                red[2 * (tid >> 6)] = mn;
+                red[2 * (tid >> 6) + 1] = mx;
+            }
+            __syncthreads();
+            for (int w = 0; w < ((nt + 63) >> 6); ++w) {
+                mn = fmin(mn, red[2 * w]);
+                mx = fmax(mx, red[2 * w + 1]);
+            }
+            __syncthreads();
+            const bool nb = want_next && k + 1 < (long long)nc;
+            double hva = 0.0, hvb = 0.0;
+            if (k < (long long)nc && lds_hist_select(cand, nc, cap, (int)k, nb ? (int)k + 1 : -1, mn, mx, sh, &hva, &hvb)) {
+                if (want_next) *next = nb ? hvb : hva;
+                return hva;
+            }
+        }
         return sorted_ranks(nc, k);
     }
     // ---- strided sample -> keys[0..S), padded with +inf keys to a power of two, bitonic sort

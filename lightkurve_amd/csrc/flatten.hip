@@ -3,13 +3,12 @@
 // scipy.signal.savgol_filter, scipy/signal/_savitzky_golay.py:230-357 mode='interp', and
 // scipy.interpolate.interp1d(kind='linear', fill_value='extrapolate')).
 //
-// One 1024-thread workgroup per light curve runs every iteration of the loop; the curve (N ~ 2e4 doubles) lives
-// in a per-target scratch slab that stays in L2.  HBM traffic is the algorithmic 8 B x (time, flux in; trend
-// out) per cadence; the FIR itself is 2*window flop per cadence per iteration (the one HBM-leaning kernel of the
-// path).  Order statistics (nanmedian of flux, of the time steps, of short segments) use the
-// radix select of block_select.hpp; the FIR taps and the edge-fit operators are built once on the host in long
-// double (savgol_design) — the edge polynomial refit of scipy's mode='interp' is the linear map
-// y_edge = E x_window with E = V_eval (V^T V)^-1 V^T.
+// The curve (N ~ 2e4 doubles) lives in a per-target scratch slab; the loop's phases are separate kernels (see "phase-split
+// pipeline" below).  The FIR itself is 2*window flop per cadence per iteration (the one HBM-leaning kernel of the path,
+// SURVEY.md §8(d)); for long windows its interior is evaluated in moment form (three prefix sums per tile).  Order
+// statistics (nanmedian of flux, of the time steps, of short segments) use the sampled select of block_select.hpp; the
+// FIR taps and the edge-fit operators are built once on the host in long double (savgol_design) — the edge polynomial
+// refit of scipy's mode='interp' is the linear map y_edge = E x_window with E = V_eval (V^T V)^-1 V^T.
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -196,604 +195,23 @@ __device__ int strip_compact(int n, Pred pred, int *out, int *sh) {
     return total;
 }
 
-// LDS plan (dynamic): sh[max(nt, 264)] 64-bit words | fir[FIR_LDS + 2] doubles | shi[nt] ints.  FIR_LDS = doubles of LDS
-// for a FIR tile's inputs (8 interleaved sub-arrays, see the FIR below); outside the FIR the same doubles hold the
-// candidates of the sampled order statistics (block_select.hpp).
-
-// RES: the RESIDENT variant for light curves of at most FLAT_RES_MAX cadences (Kepler / K2 long cadence, TESS FFI and
-// 10-minute light curves): the compacted times, fluxes, the trend and the index map — every array the phases of an
-// iteration sweep again and again — live in LDS for the whole kernel (28 B per cadence behind the work areas; one
-// 1024-thread workgroup per CU), instead of in a scratch slab that streams through L2 / HBM once per phase.
-template <bool RES>
-__global__ __launch_bounds__(1024) void flatten_kernel(
-    const double *__restrict__ t, const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
-    const int64_t *__restrict__ n_off, int window, int polyorder, double break_tol, int niters, double sigma,
-    const double *__restrict__ coeffs, const double *__restrict__ edge, char *__restrict__ scratch,
-    const int64_t *__restrict__ scratch_off, double *__restrict__ trend, uint8_t *__restrict__ final_mask,
-    int FIR_LDS, int stop_at, double quad_a, double quad_b, const double *__restrict__ edge_minv, int near_on) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
-    // Phase profiling aid (development builds, -DLK_FLAT_PROFILE): LK_FLAT_STOP=<16 * iteration + phase> makes every workgroup return when it reaches that
-    // point (phase numbers as in the lap() calls below), so kernel time differences between successive stop points
-    // give the cost of each phase.  Workgroup-uniform, no timers, no atomics; -1 (default) never stops.
-#ifdef LK_FLAT_PROFILE   // `make DEBUG=1` (tools/flat_phase_profile.py)
-    int lap_iter = 0;
-#define lap(phase)                                                \
-    do {                                                          \
-        if (stop_at == 16 * lap_iter + (phase)) return;           \
-    } while (0)
-#else   // release build: no stop points, the argument is ignored
-#define lap(phase) do { } while (0)
-    stop_at = -1;
-    [[maybe_unused]] int lap_iter = 0;
-#endif
-    unsigned long long *sh = dyn_lds;
-    const int sh_words = max((int)blockDim.x, 264);
-    double *fir = reinterpret_cast<double *>(sh + sh_words);           // 16-B aligned: sh_words is even
-    int *shi = reinterpret_cast<int *>(fir + FIR_LDS + 2);
-    double *shd = reinterpret_cast<double *>(sh);
-    long long *shl = reinterpret_cast<long long *>(sh);
-    const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int64_t lo = n_off[target];
-    const int N = (int)(n_off[target + 1] - lo);
-    t += lo;
-    flux += lo;
-    trend += lo;
-    if (user_mask) user_mask += lo;
-    if (final_mask) final_mask += lo;
-    // carve the slab (all 8-B aligned: Npad is a multiple of 8)
-    const int Npad = (N + 7) & ~7;
-    char *s = scratch + scratch_off[target];
-    double *tm = reinterpret_cast<double *>(s);
-    double *fm = tm + Npad;
-    double *tr = fm + Npad;
-    double *xk = tr + Npad;  // dense knots of the interpolation: times and trend of the cadences that survive the clip
-    double *yk = xk + Npad;
-    int *idx = reinterpret_cast<int *>(yk + Npad);
-    int *idx2 = idx + Npad;
-    if (RES) {  // (compile-time: the four arrays are LDS pointers, their accesses LDS instructions)
-        double *res = reinterpret_cast<double *>(shi + ((nt + 3) & ~3));
-        tm = res;
-        fm = tm + Npad;
-        tr = fm + Npad;
-        idx = reinterpret_cast<int *>(tr + Npad);
-    }
-    int *segs = idx2 + Npad;
-    uint8_t *mask = reinterpret_cast<uint8_t *>(segs + Npad + 8);
-    uint8_t *mask1 = mask + Npad;
-    const int half = window / 2;
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-
-    // ---- initial mask: finite & |flux - nanmedian| <= sigma * nanstd, & ~user_mask   (:1002-1010)
-    {
-        auto val = [&](int i) { return flux[i]; };
-        auto notnan = [&](int i) { return !isnan(flux[i]); };
-        // count, sum and sum of squares in ONE sweep, about a shift taken from the first finite sample (the variance of
-        // the shifted data is the variance; with the shift inside the data's range the subtraction below cancels nothing
-        // that matters: relative error ~ eps (1 + (mean - shift)^2 / var))
-        // the shift = the first FINITE sample of the light curve, wherever it sits (block-wide minimum index)
-        int first = N;
-        for (int i = tid; i < N; i += nt)
-            if (isfinite(flux[i])) {
-                first = i;
-                break;
-            }
-        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
-        if ((tid & 63) == 0) shi[tid >> 6] = first;
-        __syncthreads();
-        for (int w = 0; w < (nt >> 6); ++w) first = min(first, shi[w]);
-        __syncthreads();
-        const double shift = first < N ? flux[first] : 0.0;
-        long long c = 0, cinf = 0;
-        double part = 0.0, part2 = 0.0;
-        strided_pass<8>(N, val, [&](int, double f) {
-            if (!isnan(f)) {
-                ++c;
-                if (isinf(f)) {
-                    ++cinf;
-                } else {
-                    const double d = f - shift;
-                    part += d;
-                    part2 = fma(d, d, part2);
-                }
-            }
-        });
-        const long long cnt = block_count_fast(c, shl);
-        const long long ninf = block_count_fast(cinf, shl);
-        const double s1 = block_sum_fast(part, shd), s2 = block_sum_fast(part2, shd);
-        // an infinite sample makes numpy's nanstd NaN (inf - inf): every comparison of the initial clip is then false and
-        // the trend comes out all-NaN, as in the reference — the NaN must not be clamped to 0 by fmax
-        const double sd = ninf > 0 ? __longlong_as_double(0x7ff8000000000000ll)
-                                   : sqrt(fmax(0.0, (s2 - s1 * s1 / (double)cnt) / (double)cnt));
-        __syncthreads();
-        lap(0);
-        const double med = block_median_sampled(N, cnt, val, notnan, sh, fir, FIR_LDS, (stop_at >= 100 && stop_at < 200) ? stop_at - 100 : -1);
-        if (stop_at >= 100 && stop_at < 200) return;
-        lap(1);
-        strided_pass<8>(N, val, [&](int i, double f) {
-            bool m = isfinite(f) && (fabs(f - med) <= sd * sigma);
-            if (user_mask && user_mask[i]) m = false;
-            mask[i] = m ? 1 : 0;
-        });
-        __syncthreads();
-        lap(2);
-    }
-
-    double dmed_prev = qnan, dspacing = 0.0;  // previous iteration's median dt and the mean gap between dt values around it
-    int nm_prev = 0;
-    int removed_any = 1;
-    int t_nan = 1;  // may a kept cadence have a NaN time?  Settled by the first compaction (the mask only shrinks)
-    for (int it = 0; it < niters; ++it) {
-        const bool last = it == niters - 1;
-        lap_iter = it;
-        // ---- compaction of the kept cadences, fused with the gather of their times and fluxes: every wave owns one
-        // contiguous strip of cadences (coalesced byte / double loads), counts its survivors, and after one exchange of
-        // the wave totals writes idx / tm / fm at ballot-prefix positions — order preserving, two barriers.
-        int nm;
-        {
-            const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
-            const int strip = ((N + nw - 1) / nw + 63) & ~63;
-            const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
-            int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-            __syncthreads();
-            if (lane == 0) shi[wv] = c;
-            __syncthreads();
-            int base = 0, total = 0;
-            for (int w = 0; w < nw; ++w) {
-                if (w < wv) base += shi[w];
-                total += shi[w];
-            }
-            nm = total;
-            lap(3);
-            bool saw_nan = false;
-            for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
-                bool m[4];
-                unsigned mk[4];
-                double tv[4], fv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {  // four 64-cadence groups in flight
-                    // clamped, unconditional loads, pinned: a value selected by `in` goes back behind a branch with a full
-                    // wait — twelve serialised round trips per trip of this loop instead of one
-                    const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);
-                    mk[u] = mask[kc];
-                    tv[u] = t[kc];
-                    fv[u] = flux[kc];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    asm volatile("" : "+v"(mk[u]), "+v"(tv[u]), "+v"(fv[u]));
-                    m[u] = k0 + 64 * u + lane < k_hi && mk[u] != 0;
-                    saw_nan |= m[u] && isnan(tv[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned long long bal = __ballot(m[u]);
-                    if (m[u]) {
-                        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                        idx[pos] = k0 + 64 * u + lane;
-                        tm[pos] = tv[u];
-                        fm[pos] = fv[u];
-                    }
-                    base += __popcll(bal);
-                }
-            }
-            if (it == 0) t_nan = __syncthreads_or(saw_nan ? 1 : 0);
-            else __syncthreads();
-        }
-        lap(4);
-        if (nm == 0) {
-            for (int i = tid; i < N; i += nt) trend[i] = qnan;
-            __syncthreads();
-            break;
-        }
-        // ---- gap segmentation: cut where dt > break_tol * nanmedian(dt)   (:1022-1027)
-        double dmed = qnan;
-        if (nm >= 2) {
-            auto dval = [&](int i) { return tm[i + 1] - tm[i]; };
-            auto dkeep = [&](int i) { return !isnan(tm[i + 1] - tm[i]); };
-            long long cnt = (long long)(nm - 1);  // no NaN among the kept times: every gap counts, no sweep needed
-            if (t_nan) {
-                long long c = 0;
-                strided_pass<8>(nm - 1, dval, [&](int, double d) { c += isnan(d) ? 0 : 1; });
-                cnt = block_count_fast(c, shl);
-                __syncthreads();
-            }
-            lap(5);
-            // Later iterations: the dt's are the previous iteration's minus the few clipped cadences (each removes two
-            // gaps and adds their sum), so the median moved by at most ~3 ranks per clipped cadence — look for it within
-            // that many mean gaps of the previous median first (one pass, a few hundred candidates), exact when it hits.
-            bool near_ok = false;
-            if (it > 0 && near_on && dspacing > 0.0 && nm_prev >= nm) {
-                const double width = dspacing * (3.0 * (double)(nm_prev - nm) + 96.0);
-                dmed = block_median_near(nm - 1, cnt, dval, dkeep, dmed_prev, width, sh, fir, FIR_LDS, &near_ok);
-            }
-            if (!near_ok)
-                dmed = block_median_sampled(nm - 1, cnt, dval, dkeep, sh, fir, FIR_LDS, stop_at >= 200 ? stop_at - 200 : -1,
-                                            &dspacing);
-            if (stop_at >= 200) return;
-            dmed_prev = dmed;
-            nm_prev = nm;
-            lap(6);
-        }
-        const double thr = break_tol * dmed;  // NaN break_tol => every comparison false => no cuts
-        const int nseg = strip_compact(
-            nm, [&](int i) { return i == 0 || (tm[i] - tm[i - 1]) > thr; }, segs, shi);
-        lap(7);
-        // ---- per segment: median for short ones, Savitzky-Golay otherwise   (:1030-1046).  Every kept cadence gets its
-        // trend exactly once here; its residual goes into the two running sums of the clip right away (rs1, rs2), which
-        // spares the clip its two sweeps over flux and trend.
-        double rs1 = 0.0, rs2 = 0.0;
-        auto put = [&](int i, double v) {
-            tr[i] = v;
-            const double r = fm[i] - v;
-            rs1 += r;
-            rs2 = fma(r, r, rs2);
-        };
-        for (int sg = 0; sg < nseg; ++sg) {
-            const int l = segs[sg], h = (sg + 1 < nseg) ? segs[sg + 1] : nm;
-            const int len = h - l;
-            if (window > len || (double)len < break_tol) {
-                auto val = [&](int i) { return fm[l + i]; };
-                auto keep = [&](int i) { return true; };  // masked flux is finite
-                __syncthreads();
-                const double med = block_median_sampled(len, (long long)len, val, keep, sh, fir, FIR_LDS);
-                for (int i = l + tid; i < h; i += nt) put(i, med);
-            } else {
-                // interior: correlate with the taps (window fully inside the segment)
-                const int o_lo = l + half, o_hi = h - half;  // outputs [o_lo, o_hi)
-                // Tiles of TO outputs; the tile's TO + window - 1 inputs are staged in LDS once (coalesced) as FP = 8
-                // interleaved sub-arrays (element e at [e % 8][e / 8], sub-array stride S = 4 mod 32: the staging stores
-                // and the reads below are both bank-conflict free).  A thread produces 8 NEIGHBOURING outputs from a
-                // sliding 8-value register window: per tap one 8-B LDS read (the value entering the window — lanes read
-                // consecutive addresses of one sub-array) and 8 FMAs, so the fp64 pipe is the limit, not the LDS (the
-                // 2-outputs-per-16-B-read version this replaces kept the LDS port 100 % busy at 21 % of the FMA peak).
-                // Every output accumulates its taps in the order of scipy's correlate1d, as before.
-                constexpr int FP = 8;
-                const int S = (((FIR_LDS / FP) - 4) / 32) * 32 + 4;
-                const int TO = S >= 36 ? ((FP * S - FP - (window - 1)) / FP) * FP : 0;
-                // polyorder <= 3: the taps are a quadratic in the offset, c_k = a + b k^2, so an output is
-                // a S0 + b S2 with the window moments S0 = sum y, S2 = sum k^2 y — O(1) per output from three prefix sums
-                // (y, u y, u^2 y; u = position relative to the tile centre) instead of `window` FMAs.  A tile spans at
-                // most 4 windows, which keeps the cancellation in S2 = W2 - 2 v W1 + v^2 W0 to a few bits: the result is
-                // within ~1e-14 of the tap-by-tap sum (tests state 1e-10).  Used for long windows only (quad_b != 0).
-                const int QCAP = FIR_LDS / 3;
-                const int QNI = min(QCAP, 4 * window), QTO = QNI - (window - 1);
-                if (quad_b != 0.0 && QTO >= 64) {
-                    double *p0 = fir, *p1 = fir + QCAP, *p2 = fir + 2 * QCAP;
-                    const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
-                    for (int o0 = o_lo; o0 < o_hi; o0 += QTO) {
-                        const int no = min(QTO, o_hi - o0), ni = no + window - 1;
-                        const double uc = 0.5 * (double)(ni - 1);
-                        const double *x = fm + (o0 - half);
-                        const int CH = (ni + nt - 1) / nt;
-                        const int e0 = min(ni, tid * CH), e1 = min(ni, e0 + CH);
-                        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                        double xr[4] = {0.0, 0.0, 0.0, 0.0};  // CH <= 4: the thread's inputs stay in registers for the second sweep
-                        if (CH <= 4) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (e0 + q < e1) xr[q] = x[e0 + q];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (e0 + q < e1) {
-                                    const double yv = xr[q], u = (double)(e0 + q) - uc;
-                                    s0 += yv;
-                                    s1 = fma(u, yv, s1);
-                                    s2 = fma(u * u, yv, s2);
-                                }
-                        } else {
-                            for (int e = e0; e < e1; ++e) {
-                                const double yv = x[e], u = (double)e - uc;
-                                s0 += yv;
-                                s1 = fma(u, yv, s1);
-                                s2 = fma(u * u, yv, s2);
-                            }
-                        }
-                        double i0 = s0, i1 = s1, i2 = s2;  // inclusive scan over the wave, then over the waves
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const double a0 = __shfl_up(i0, off), a1 = __shfl_up(i1, off), a2 = __shfl_up(i2, off);
-                            if (lane >= off) {
-                                i0 += a0;
-                                i1 += a1;
-                                i2 += a2;
-                            }
-                        }
-                        __syncthreads();  // shd and the prefix arrays of the previous tile are free
-                        if (lane == 63) {
-                            shd[wv * 3 + 0] = i0;
-                            shd[wv * 3 + 1] = i1;
-                            shd[wv * 3 + 2] = i2;
-                        }
-                        __syncthreads();
-                        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-                        for (int w2 = 0; w2 < wv && w2 < nwv; ++w2) {
-                            r0 += shd[w2 * 3 + 0];
-                            r1 += shd[w2 * 3 + 1];
-                            r2 += shd[w2 * 3 + 2];
-                        }
-                        {
-                            const double x0 = __shfl_up(i0, 1), x1 = __shfl_up(i1, 1), x2 = __shfl_up(i2, 1);
-                            if (lane > 0) {
-                                r0 += x0;
-                                r1 += x1;
-                                r2 += x2;
-                            }
-                        }
-                        if (CH <= 4) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (e0 + q < e1) {
-                                    const int e = e0 + q;
-                                    const double yv = xr[q], u = (double)e - uc;
-                                    r0 += yv;
-                                    r1 = fma(u, yv, r1);
-                                    r2 = fma(u * u, yv, r2);
-                                    p0[e] = r0;
-                                    p1[e] = r1;
-                                    p2[e] = r2;
-                                }
-                        } else {
-                            for (int e = e0; e < e1; ++e) {
-                                const double yv = x[e], u = (double)e - uc;
-                                r0 += yv;
-                                r1 = fma(u, yv, r1);
-                                r2 = fma(u * u, yv, r2);
-                                p0[e] = r0;
-                                p1[e] = r1;
-                                p2[e] = r2;
-                            }
-                        }
-                        __syncthreads();
-                        for (int q = tid; q < no; q += nt) {
-                            const int hi = q + window - 1;
-                            double w0 = p0[hi], w1 = p1[hi], w2 = p2[hi];
-                            if (q > 0) {
-                                w0 -= p0[q - 1];
-                                w1 -= p1[q - 1];
-                                w2 -= p2[q - 1];
-                            }
-                            const double v = (double)(q + half) - uc;
-                            const double m2 = fma(v, fma(v, w0, -2.0 * w1), w2);  // sum (u - v)^2 y
-                            put(o0 + q, fma(quad_b, m2, quad_a * w0));
-                        }
-                    }
-                } else if (TO >= FP) {
-                    for (int o0 = o_lo; o0 < o_hi; o0 += TO) {
-                        const int no = min(TO, o_hi - o0), ni = no + window - 1;
-                        __syncthreads();
-                        for (int e = tid; e < ni + FP; e += nt)   // FP look-ahead slots past the end, zero filled
-                            fir[(e % FP) * S + e / FP] = e < ni ? fm[o0 - half + e] : 0.0;
-                        __syncthreads();
-                        for (int q = tid; FP * q < no; q += nt) {
-                            double win[FP], acc[FP];
-#pragma unroll
-                            for (int r = 0; r < FP; ++r) {
-                                win[r] = fir[r * S + q];  // x[8 q + r]
-                                acc[r] = 0.0;
-                            }
-                            int jb = 0;
-                            for (; jb + FP <= window; jb += FP) {
-                                const int nxt = q + 1 + jb / FP;
-#pragma unroll
-                                for (int jj = 0; jj < FP; ++jj) {
-                                    const double cj = coeffs[jb + jj];
-#pragma unroll
-                                    for (int r = 0; r < FP; ++r) acc[r] = fma(cj, win[(jj + r) & (FP - 1)], acc[r]);
-                                    win[jj] = fir[jj * S + nxt];  // x[8 q + jb + jj + 8] replaces x[8 q + jb + jj]
-                                }
-                            }
-                            const int nxt = q + 1 + jb / FP;
-#pragma unroll
-                            for (int jj = 0; jj < FP - 1; ++jj) {  // the window % 8 last taps
-                                if (jb + jj < window) {
-                                    const double cj = coeffs[jb + jj];
-#pragma unroll
-                                    for (int r = 0; r < FP; ++r) acc[r] = fma(cj, win[(jj + r) & (FP - 1)], acc[r]);
-                                    win[jj] = fir[jj * S + nxt];
-                                }
-                            }
-#pragma unroll
-                            for (int r = 0; r < FP; ++r)
-                                if (FP * q + r < no) put(o0 + FP * q + r, acc[r]);
-                        }
-                    }
-                } else {
-                    for (int i = o_lo + tid; i < o_hi; i += nt) {
-                        const double *x = fm + (i - half);
-                        double acc = 0.0;
-                        for (int j = 0; j < window; ++j) acc = fma(coeffs[j], x[j], acc);
-                        put(i, acc);
-                    }
-                }
-                // edges: polynomial refit of the first / last `window` samples (mode='interp').  The two windows are
-                // staged in LDS; thread (side, r) streams row r of the operator (stored transposed, [side][tap][row]:
-                // lanes read neighbouring rows) with 8 loads in flight — the plain tap loop was a chain of ~400
-                // dependent L2 round trips and had become the longest part of the segment.
-                __syncthreads();
-                for (int e = tid; e < 2 * window; e += nt)
-                    fir[e] = e < window ? fm[l + e] : fm[h - window + (e - window)];
-                __syncthreads();
-                const int np1 = polyorder + 1;
-                if (edge_minv && 2 * window + 2 * np1 <= FIR_LDS) {
-                    // The edge outputs are the least-squares polynomial of the side's `window` samples evaluated at the
-                    // output's position: p + 1 moments sum_j u_j^b x_j per side (one wave per moment), beta = M^-1 m,
-                    // then a Horner evaluation per output — O(window p) per segment instead of the half x window
-                    // operator rows (401 dependent FMAs per output on L2-resident rows: after the moment-form interior
-                    // this was most of the segment).  Abscissae scaled to [-1, 1] as on the host; polyorder <= 5.
-                    const double c0 = 0.5 * (double)(window - 1), sc = c0 > 0.0 ? c0 : 1.0;
-                    double *mom = fir + 2 * window;
-                    const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
-                    for (int pair = wv; pair < 2 * np1; pair += nwv) {
-                        const int side = pair / np1, b = pair - side * np1;
-                        const double *x = fir + side * window;
-                        double sm = 0.0;
-                        for (int j = lane; j < window; j += 64) {
-                            const double u = ((double)j - c0) / sc;
-                            double ub = 1.0;
-                            for (int q = 0; q < b; ++q) ub *= u;
-                            sm = fma(ub, x[j], sm);
-                        }
-                        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-                        if (lane == 0) mom[pair] = sm;
-                    }
-                    __syncthreads();
-                    for (int e = tid; e < 2 * half; e += nt) {
-                        const int side = e >= half, r = e - side * half;
-                        const int pos = side ? (window - half + r) : r;
-                        const double u = ((double)pos - c0) / sc;
-                        double acc = 0.0;
-                        for (int a = np1 - 1; a >= 0; --a) {
-                            double beta = 0.0;
-                            for (int b = 0; b < np1; ++b) beta = fma(edge_minv[a * np1 + b], mom[side * np1 + b], beta);
-                            acc = fma(acc, u, beta);
-                        }
-                        put(side ? (h - half + r) : (l + r), acc);
-                    }
-                } else {
-                for (int e = tid; e < 2 * half; e += nt) {
-                    const int side = e >= half, r = e - side * half;
-                    const double *x = fir + side * window;
-                    const double *E = edge + (size_t)side * half * window + r;
-                    double acc = 0.0;
-                    int j = 0;
-                    for (; j + 8 <= window; j += 8) {
-                        double ev[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) ev[u] = E[(size_t)(j + u) * half];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) acc = fma(ev[u], x[j + u], acc);
-                    }
-                    for (; j < window; ++j) acc = fma(E[(size_t)j * half], x[j], acc);
-                    put(side ? (h - half + r) : (l + r), acc);
-                }
-                }
-            }
-            __syncthreads();
-        }
-        // ---- clip: |flux - trend| < sigma * nanstd(flux - trend) + 1e-14   (:1049-1052)
-        {
-            lap(8);
-            auto resid = [&](int i) { return fm[i] - tr[i]; };
-            // nanstd of the residuals from the sums gathered above (mean ~ 0: nothing cancels in s2 - s1^2 / n)
-            const double s1 = block_sum_fast(rs1, shd), s2 = block_sum_fast(rs2, shd);
-            const double sd = sqrt(fmax(0.0, (s2 - s1 * s1 / (double)nm) / (double)nm));
-            const double lim = sd * sigma + 1e-14;
-            // mask1, and mask[mask] &= mask1 (:1060-1063) in the same sweep
-            int removed = 0;
-            strided_pass<8>(nm, resid, [&](int i, double r) {
-                const bool keepit = fabs(r) < lim;
-                mask1[i] = keepit ? 1 : 0;
-                if (!keepit) {
-                    mask[idx[i]] = 0;
-                    removed = 1;
-                }
-            });
-            removed_any = __syncthreads_or(removed);
-            lap(9);
-        }
-        // ---- linear interpolation / extrapolation of the kept trend onto every cadence   (:1053-1058).  The reference
-        // recomputes it in every iteration and keeps the last one; only the last one is computed here — the last one
-        // being either iteration niters - 1 or the first iteration that clipped nothing (the mask, hence every later
-        // iteration, would repeat exactly).
-        if (!last && removed_any) continue;
-        const int n2 = strip_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
-        if (n2 < 2) {
-            for (int i = tid; i < N; i += nt) trend[i] = qnan;
-        } else {
-            strided_pass<8>(n2, [&](int j) { return idx2[j]; }, [&](int j, int c) {
-                xk[j] = tm[c];
-                yk[j] = tr[c];
-            });
-            // After the update above mask[c] == 1 exactly for the knot cadences, in knot order.  np.searchsorted(x, xn,
-            // 'left') = number of knots with x < xn = number of knot cadences before cadence k (times are sorted), less
-            // any that share k's time.  Each wave owns a contiguous strip of cadences and carries a running knot count:
-            // no search, no barrier inside the sweep.
-            const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
-            const int strip = ((N + nw - 1) / nw + 63) & ~63;
-            const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
-            int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-            __syncthreads();
-            if (lane == 0) shi[wv] = c;
-            __syncthreads();  // also orders the xk / yk stores above before the loads below
-            int base = 0;
-            for (int w = 0; w < wv; ++w) base += shi[w];
-            for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
-                // four 64-cadence groups in flight: every stage of the dependent chain (mask/time -> knot index ->
-                // knot abscissae -> knot ordinates) is issued for all four before the next stage starts
-                bool in[4], kf[4];
-                double xn[4];
-                unsigned mk[4];
-                int j[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);  // clamped, unconditional, pinned (see the gather)
-                    in[u] = k < k_hi;
-                    mk[u] = mask[kc];
-                    xn[u] = t[kc];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    asm volatile("" : "+v"(mk[u]), "+v"(xn[u]));
-                    kf[u] = in[u] && mk[u] != 0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned long long bal = __ballot(kf[u]);
-                    j[u] = base + __popcll(bal & ((1ull << lane) - 1ull));
-                    base += __popcll(bal);
-                }
-                double xb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xb[u] = xk[max(j[u] - 1, 0)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    asm volatile("" : "+v"(xb[u]));
-                    xb[u] = (in[u] && j[u] > 0) ? xb[u] : -INFINITY;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (in[u] && xb[u] >= xn[u]) {  // equal times: those knots are not "< xn" (rare)
-                        --j[u];
-                        while (j[u] > 0 && xk[j[u] - 1] >= xn[u]) --j[u];
-                    }
-                }
-                double x0[4], x1[4], y0[4], y1[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int hi_i = min(max(j[u], 1), n2 - 1), lo_i = hi_i - 1;
-                    x0[u] = xk[lo_i];
-                    x1[u] = xk[hi_i];
-                    y0[u] = yk[lo_i];
-                    y1[u] = yk[hi_i];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (in[u]) {
-                        const double slope = (y1[u] - y0[u]) / (x1[u] - x0[u]);
-                        trend[k0 + 64 * u + lane] = isnan(xn[u]) ? qnan : slope * (xn[u] - x0[u]) + y0[u];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        lap(10);
-        if (!removed_any) break;
-    }
-    if (final_mask)
-        for (int i = tid; i < N; i += nt) final_mask[i] = mask[i];
-#undef lap
-}
-
-
 // ================================================================================================ phase-split pipeline
-// Round 5.  The monolithic kernel above runs ~75 barrier-separated sweeps of one light curve in one 512-thread workgroup
-// at ONE register budget (128 VGPRs with 79 spilled, two workgroups per CU): it is bound by memory latency at 16 waves per
-// CU.  The same phases as separate kernels — state in the per-target slab plus a 64-byte FlatState — give every phase its own
-// register budget and occupancy (the streaming phases run 4 workgroups per CU, i.e. all 1000 light curves of the bench in
-// ONE wave of workgroups instead of two), and the embarrassingly parallel phases (trend tiles, final interpolation) can
-// use more than one workgroup per light curve.  A kernel boundary costs ~2 us; 1 + 4 niters + 1 = 14 of them per call.
-// The arithmetic of every phase is the monolithic kernel's, statement for statement.
+// One light curve = one workgroup PER PHASE KERNEL (the trend phase: T workgroups); state between the kernels lives in the
+// per-target slab (compacted times / fluxes, trend, knots, index map, segment starts, masks) plus a 64-byte FlatState.
+// LDS plan of the select / trend kernels (dynamic): sh[max(nt, 264)] 64-bit words | fir[FIR_LDS + 2] doubles | shi[nt] ints;
+// `fir` holds the candidates of the sampled order statistics (block_select.hpp) or the tile arrays of the trend kernel.
+//
+// Rounds 1-4 ran all ~75 barrier-separated sweeps of a light curve inside ONE 512-thread workgroup at one register budget
+// (128 VGPRs with 79 spilled, two workgroups per CU, an LDS-resident variant for <= 1 900 cadences): 2.39 ms per 1000 x
+// 20 000 cadences, bound by memory latency at 16 waves per CU.  The same phases as separate kernels give every phase its own
+// register budget and occupancy (the streaming and select phases run 4 workgroups per CU: all 1000 light curves of the
+// bench in ONE wave of workgroups), per-phase times straight from a kernel trace, and more than one workgroup per light
+// curve where a phase is embarrassingly parallel.  A kernel boundary costs ~2 us; 1 + 4 niters + 1 = 14 of them per call.
+// With one wave of workgroups per launch the SLOWEST light curve sets the time of every launch — which is what exposed the
+// rare slow routes of the sampled select (a 4096-key sort for ~9 % of the light curves, a bracket miss for ~0.4 %) and led
+// to the histogram select and the 4-sigma bracket of block_select.hpp.  Measured (A/B on one box, tools/ab_flatten.sh):
+// 2.39 -> 1.77 ms (20 000 cadences, window 401), 0.90 -> 0.59 ms (4500, window 101), 1.05 -> 0.50 ms (3500), and it
+// beats the LDS-resident monolith on short light curves too (2000 x 1200: 0.89 -> 0.76 ms), so that kernel is gone.
 struct FlatState {
     double dmed_prev, dspacing, rs1, rs2;
     int nm, nm_prev, nseg, removed_any, t_nan, done, want_interp, pad;
@@ -1151,13 +569,17 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
             // (y, u y, u^2 y; u = position relative to the tile centre) instead of `window` FMAs.  A tile spans at
             // most 4 windows, which keeps the cancellation in S2 = W2 - 2 v W1 + v^2 W0 to a few bits: the result is
             // within ~1e-14 of the tap-by-tap sum (tests state 1e-10).  Used for long windows only (quad_b != 0).
-            const int QCAP = QUAD ? FIR_LDS / 4 : FIR_LDS / 3;
+            const int QCAP = QUAD ? ((FIR_LDS / 4 - 1) * 32) / 33 : FIR_LDS / 3;  // (QUAD: 4 arrays of QCAP + QCAP / 32 + 1 doubles)
             const int QNI = min(QCAP, 4 * window), QTO = QNI - (window - 1);
             if (QUAD && quad_b != 0.0 && QTO >= 64) {
                 // p0..p2: the tile's three prefix sums; xs: its inputs (the residual of an output needs its own flux: from LDS,
                 // not a second global round trip).  The inputs of this workgroup's NEXT tile are fetched (clamped, unconditional)
                 // before the scans of the current one: a tile costs one memory latency, hidden behind the previous tile.
-                double *p0 = fir, *p1 = fir + QCAP, *p2 = fir + 2 * QCAP, *xs = fir + 3 * QCAP;
+                // A thread writes the prefixes of 4 consecutive inputs: unpadded, lanes l and l + 8 would hit the same LDS banks
+                // (8-way conflicts on 16 stores per tile); one pad double per 32 entries (PX) spreads them over all banks.
+                auto PX = [](int e) { return e + (e >> 5); };
+                const int QS = QCAP + (QCAP >> 5) + 1;
+                double *p0 = fir, *p1 = fir + QS, *p2 = fir + 2 * QS, *xs = fir + 3 * QS;
                 const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
                 const int ntile = (o_hi - o_lo + QTO - 1) / QTO;
                 int j = ((y - item) % T + T) % T;  // the first tile of this segment that is this workgroup's
@@ -1243,10 +665,10 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                                 r0 += yv;
                                 r1 = fma(u, yv, r1);
                                 r2 = fma(u * u, yv, r2);
-                                p0[e] = r0;
-                                p1[e] = r1;
-                                p2[e] = r2;
-                                xs[e] = yv;
+                                p0[PX(e)] = r0;
+                                p1[PX(e)] = r1;
+                                p2[PX(e)] = r2;
+                                xs[PX(e)] = yv;
                             }
                     } else {
                         for (int e = e0; e < e1; ++e) {
@@ -1254,26 +676,26 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                             r0 += yv;
                             r1 = fma(u, yv, r1);
                             r2 = fma(u * u, yv, r2);
-                            p0[e] = r0;
-                            p1[e] = r1;
-                            p2[e] = r2;
-                            xs[e] = yv;
+                            p0[PX(e)] = r0;
+                            p1[PX(e)] = r1;
+                            p2[PX(e)] = r2;
+                            xs[PX(e)] = yv;
                         }
                     }
                     __syncthreads();
                     for (int q = tid; q < no; q += nt) {
                         const int hi = q + window - 1;
-                        double w0 = p0[hi], w1 = p1[hi], w2 = p2[hi];
+                        double w0 = p0[PX(hi)], w1 = p1[PX(hi)], w2 = p2[PX(hi)];
                         if (q > 0) {
-                            w0 -= p0[q - 1];
-                            w1 -= p1[q - 1];
-                            w2 -= p2[q - 1];
+                            w0 -= p0[PX(q - 1)];
+                            w1 -= p1[PX(q - 1)];
+                            w2 -= p2[PX(q - 1)];
                         }
                         const double v = (double)(q + half) - uc;
                         const double m2 = fma(v, fma(v, w0, -2.0 * w1), w2);  // sum (u - v)^2 y
                         const double tv = fma(quad_b, m2, quad_a * w0);
                         tr[o0 + q] = tv;
-                        const double r = xs[q + half] - tv;
+                        const double r = xs[PX(q + half)] - tv;
                         rs1 += r;
                         rs2 = fma(r, r, rs2);
                     }
@@ -1463,17 +885,59 @@ __global__ __launch_bounds__(FLAT_NT, 8) void flat_interp_kernel(const double *_
     if (!st.want_interp) return;
     const double *tm = sl.tm, *tr = sl.tr;
     double *xk = sl.xk, *yk = sl.yk;
-    int *idx2 = sl.idx2;
     const int nm = st.nm;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-    const int n2 = strip_compact(nm, [&](int i) { return mask1[i] != 0; }, idx2, shi);
+    // the knots = the kept cadences that survived the clip (mask1), compacted in order straight into xk / yk: every wave owns
+    // a strip of the kept cadences, counts its survivors, and after one exchange of the wave totals writes them at
+    // ballot-prefix positions (the compaction kernel's scheme; no index array in between)
+    int n2;
+    {
+        const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+        const int strip = ((nm + nw - 1) / nw + 63) & ~63;
+        const int k_lo = min(wv * strip, nm), k_hi = min(k_lo + strip, nm);
+        int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask1[k] != 0; });
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) shi[wv] = c;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w = 0; w < nw; ++w) {
+            if (w < wv) base += shi[w];
+            total += shi[w];
+        }
+        n2 = total;
+        __syncthreads();  // shi is reused below
+        if (n2 >= 2)
+            for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
+                bool m[4];
+                unsigned mk[4];
+                double tv[4], yv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // clamped, unconditional, pinned loads: four groups in flight
+                    const int kc = min(k0 + 64 * u + lane, k_hi - 1);
+                    mk[u] = mask1[kc];
+                    tv[u] = tm[kc];
+                    yv[u] = tr[kc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" : "+v"(mk[u]), "+v"(tv[u]), "+v"(yv[u]));
+                    m[u] = k0 + 64 * u + lane < k_hi && mk[u] != 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long bal = __ballot(m[u]);
+                    if (m[u]) {
+                        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                        xk[pos] = tv[u];
+                        yk[pos] = yv[u];
+                    }
+                    base += __popcll(bal);
+                }
+            }
+    }
     if (n2 < 2) {
         for (int i = tid; i < N; i += nt) trend[i] = qnan;
     } else {
-        strided_pass<8>(n2, [&](int j) { return idx2[j]; }, [&](int j, int c) {
-            xk[j] = tm[c];
-            yk[j] = tr[c];
-        });
         // After the update above mask[c] == 1 exactly for the knot cadences, in knot order.  np.searchsorted(x, xn,
         // 'left') = number of knots with x < xn = number of knot cadences before cadence k (times are sorted), less
         // any that share k's time.  Each wave owns a contiguous strip of cadences and carries a running knot count:
@@ -1634,88 +1098,56 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
-    // resident variant: every light curve of the batch short enough for its four hot arrays to sit in LDS behind the work
-    // areas (a smaller FIR / candidate area than the streaming variant's: the windows that go with short light curves are
-    // short) — one 1024-thread workgroup per CU
     int64_t nmax = 0;
     for (int b = 0; b < B; ++b) nmax = std::max(nmax, n_off_host[b + 1] - n_off_host[b]);
-    constexpr int res_nt = 512, res_fir = 2048;
-    const size_t res_work = (size_t)std::max(res_nt, 264) * 8 + (size_t)(res_fir + 2) * 8 + (size_t)((res_nt + 3) & ~3) * 4;
-    const size_t res_arrays = (size_t)((nmax + 7) & ~(int64_t)7) * 28;
-    // TWO workgroups per CU must still fit (76 KB each): one 1024-thread resident workgroup per CU was measured at the
-    // 4500-cadence shape and lost to the streaming variant (0.965 against 0.907 ms per 1000 light curves) — what it gains in
-    // latency per sweep it loses in the overlap of two workgroups' barrier-bound phases
-    const bool resident = window <= res_fir / 2 + 1 && res_work + res_arrays + 64 <= (size_t)76 * 1024;
-    const int flat_nt = 512;  // two 512-thread workgroups per CU overlap each other's barrier-bound phases best
-    constexpr int fir_lds_env = 4896;  // 8 x 612: 4096-output tiles at window 401
-    int fir_lds = resident ? res_fir : std::max(512, fir_lds_env & ~1);
-    while (!resident && fir_lds < 16384 && window > fir_lds / 2 + 1) fir_lds *= 2;  // keep the tiled FIR path for long windows
-    const size_t lds = resident ? res_work + res_arrays + 64
-                                : (size_t)std::max(flat_nt, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)flat_nt * 4;
-    {
-        // (__syncthreads_or keeps a few bytes of static LDS: the dynamic part may not claim all 160 KB)
-        int rc_ = want_lds(h, reinterpret_cast<const void *>(flatten_kernel<false>), 152 * 1024);
-        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flatten_kernel<true>), 152 * 1024);
-        if (rc_) return rc_;
-    }
+    // FIR / candidate area of the tap-by-tap trend kernel (short windows): 8 x 612 doubles = 4096-output tiles; doubled until
+    // the window fits a tile
+    int fir_lds = 4896;
+    while (fir_lds < 16384 && window > fir_lds / 2 + 1) fir_lds *= 2;
+    const size_t lds_sel = (size_t)std::max(FLAT_NT, 264) * 8 + (size_t)(fir_lds + 2) * 8 + (size_t)FLAT_NT * 4;
 #ifdef LK_FLAT_PROFILE
-    const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see the kernel
+    const int stop_at = getenv("LK_FLAT_STOP") ? atoi(getenv("LK_FLAT_STOP")) : -1;  // profiling aid, see flat_init_kernel
 #else
     constexpr int stop_at = -1;
 #endif
-#ifdef LK_FLAT_MONO
-    if (resident)
-        hipLaunchKernelGGL(flatten_kernel<true>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
-                           break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
-    else
-        hipLaunchKernelGGL(flatten_kernel<false>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
-                           break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
-#else
-    if (resident) {
-        hipLaunchKernelGGL(flatten_kernel<true>, dim3(B), dim3(flat_nt), lds, stream, t, flux, user_mask, d_off, window, polyorder,
-                           break_tol, niters, sigma, d_c, d_e, d_s, d_soff, trend, final_mask, fir_lds, stop_at, quad_a, quad_b, d_minv, near_on);
-    } else {
-        // the phase-split pipeline: 1 + 4 niters + 1 launches, state in the slab + FlatState
-        FlatState *d_state = (FlatState *)h->ws.alloc((size_t)B * sizeof(FlatState));
-        const size_t lds_sel = lds;  // sh | candidates / FIR area | shi: the select phases and the tap-by-tap trend kernel
-        // trend workgroups per light curve: enough tiles for each (a 20 000-cadence light curve has ~17 tiles of 1204 outputs at
-        // window 401; a 4500-cadence one 4), and B x T >= ~4 workgroups per CU
-        const int trend_T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nmax / 4096));
-        double2 *d_rs = (double2 *)h->ws.alloc((size_t)B * trend_T * sizeof(double2));
-        LK_REQUIRE(d_state != nullptr && d_rs != nullptr, "workspace exhausted (flatten state)");
-        // the moment-form trend kernel keeps four tile arrays (three prefix sums + the inputs): a third more LDS than the select
-        // phases' candidate area gives it the same 4-window tiles
-        // (1470 doubles per array: three 512-thread workgroups of this kernel fit a CU's 160 KB of LDS)
-        const int fir_trend = std::max(4 * 1470, ((window > 1470 / 2 ? fir_lds : 0) / 3) * 4);
-        const bool quad_kernel = quad_b != 0.0 && std::min(fir_trend / 4, 4 * window) - (window - 1) >= 64;
-        const size_t lds_trend = quad_kernel ? (size_t)std::max(FLAT_NT, 264) * 8 + (size_t)(fir_trend + 2) * 8 + (size_t)FLAT_NT * 4 : lds_sel;
-        int rc_ = want_lds(h, reinterpret_cast<const void *>(flat_init_kernel), 152 * 1024);
-        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_dtseg_kernel), 152 * 1024);
-        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_trend_kernel<true>), 152 * 1024);
-        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_trend_kernel<false>), 152 * 1024);
-        if (rc_) return rc_;
-        // the select phases: a 4096-double candidate area (the sampled selects collect <= ~1800 candidates) keeps FOUR of their
-        // workgroups on a CU — 1024 slots: the 1000 light curves of the bench shape run as one wave of workgroups
-        constexpr int fir_pick = 4096;
-        const size_t lds_pick = (size_t)std::max(FLAT_NT, 264) * 8 + (size_t)(fir_pick + 2) * 8 + (size_t)FLAT_NT * 4;
-        hipLaunchKernelGGL(flat_init_kernel, dim3(B), dim3(FLAT_NT), lds_pick, stream, flux, user_mask, d_off, sigma, d_s, d_soff,
-                           d_state, fir_pick, (stop_at >= 99 && stop_at < 200) ? stop_at - 100 : -1);
-        for (int it = 0; it < niters; ++it) {
-            hipLaunchKernelGGL(flat_compact_kernel, dim3(B), dim3(FLAT_NT), 0, stream, t, flux, d_off, d_s, d_soff, d_state, trend, it);
-            hipLaunchKernelGGL(flat_dtseg_kernel, dim3(B), dim3(FLAT_NT), lds_pick, stream, d_off, break_tol, d_s, d_soff, d_state,
-                               fir_pick, it, near_on, stop_at >= 200 ? stop_at - 200 : -1);
-            if (quad_kernel)
-                hipLaunchKernelGGL(flat_trend_kernel<true>, dim3(B, trend_T), dim3(FLAT_NT), lds_trend, stream, d_off, window, polyorder,
-                                   break_tol, d_c, d_e, d_s, d_soff, d_state, fir_trend, quad_a, quad_b, d_minv, d_rs);
-            else
-                hipLaunchKernelGGL(flat_trend_kernel<false>, dim3(B, trend_T), dim3(FLAT_NT), lds_sel, stream, d_off, window, polyorder,
-                                   break_tol, d_c, d_e, d_s, d_soff, d_state, fir_lds, quad_a, quad_b, d_minv, d_rs);
-            hipLaunchKernelGGL(flat_clip_kernel, dim3(B), dim3(FLAT_NT), 0, stream, d_off, sigma, d_s, d_soff, d_state,
-                               it == niters - 1 ? 1 : 0, d_rs, trend_T);
-        }
-        hipLaunchKernelGGL(flat_interp_kernel, dim3(B), dim3(FLAT_NT), 0, stream, t, d_off, d_s, d_soff, d_state, trend, final_mask);
+    FlatState *d_state = (FlatState *)h->ws.alloc((size_t)B * sizeof(FlatState));
+    // trend workgroups per light curve: enough tiles for each (a 20 000-cadence light curve has ~19 tiles of ~1070 outputs at
+    // window 401; a 4500-cadence one 4), and B x T >= ~4 workgroups per CU
+    const int trend_T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nmax / 4096));
+    double2 *d_rs = (double2 *)h->ws.alloc((size_t)B * trend_T * sizeof(double2));
+    LK_REQUIRE(d_state != nullptr && d_rs != nullptr, "workspace exhausted (flatten state)");
+    // the moment-form trend kernel keeps four tile arrays (three prefix sums + the inputs) of 1470 doubles: three 512-thread
+    // workgroups of it fit a CU's 160 KB of LDS (longer windows: sized from the tap kernel's area)
+    const int fir_trend = std::max(4 * 1470, ((window > 1470 / 2 ? fir_lds : 0) / 3) * 4);
+    const int quad_cap = ((fir_trend / 4 - 1) * 32) / 33;  // the kernel's QCAP (arrays padded by one double per 32)
+    const bool quad_kernel = quad_b != 0.0 && std::min(quad_cap, 4 * window) - (window - 1) >= 64;
+    const size_t lds_trend = quad_kernel ? (size_t)std::max(FLAT_NT, 264) * 8 + (size_t)(fir_trend + 2) * 8 + (size_t)FLAT_NT * 4 : lds_sel;
+    // (__syncthreads_or keeps a few bytes of static LDS: the dynamic part may not claim all 160 KB)
+    int rc_ = want_lds(h, reinterpret_cast<const void *>(flat_init_kernel), 152 * 1024);
+    if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_dtseg_kernel), 152 * 1024);
+    if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_trend_kernel<true>), 152 * 1024);
+    if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(flat_trend_kernel<false>), 152 * 1024);
+    if (rc_) return rc_;
+    // the select phases: a 4096-double candidate area (the sampled selects collect ~2600 candidates) keeps FOUR of their
+    // workgroups on a CU — 1024 slots: the 1000 light curves of the bench shape run as one wave of workgroups
+    constexpr int fir_pick = 4096;
+    const size_t lds_pick = (size_t)std::max(FLAT_NT, 264) * 8 + (size_t)(fir_pick + 2) * 8 + (size_t)FLAT_NT * 4;
+    hipLaunchKernelGGL(flat_init_kernel, dim3(B), dim3(FLAT_NT), lds_pick, stream, flux, user_mask, d_off, sigma, d_s, d_soff,
+                       d_state, fir_pick, (stop_at >= 99 && stop_at < 200) ? stop_at - 100 : -1);
+    for (int it = 0; it < niters; ++it) {
+        hipLaunchKernelGGL(flat_compact_kernel, dim3(B), dim3(FLAT_NT), 0, stream, t, flux, d_off, d_s, d_soff, d_state, trend, it);
+        hipLaunchKernelGGL(flat_dtseg_kernel, dim3(B), dim3(FLAT_NT), lds_pick, stream, d_off, break_tol, d_s, d_soff, d_state,
+                           fir_pick, it, near_on, stop_at >= 200 ? stop_at - 200 : -1);
+        if (quad_kernel)
+            hipLaunchKernelGGL(flat_trend_kernel<true>, dim3(B, trend_T), dim3(FLAT_NT), lds_trend, stream, d_off, window, polyorder,
+                               break_tol, d_c, d_e, d_s, d_soff, d_state, fir_trend, quad_a, quad_b, d_minv, d_rs);
+        else
+            hipLaunchKernelGGL(flat_trend_kernel<false>, dim3(B, trend_T), dim3(FLAT_NT), lds_sel, stream, d_off, window, polyorder,
+                               break_tol, d_c, d_e, d_s, d_soff, d_state, fir_lds, quad_a, quad_b, d_minv, d_rs);
+        hipLaunchKernelGGL(flat_clip_kernel, dim3(B), dim3(FLAT_NT), 0, stream, d_off, sigma, d_s, d_soff, d_state,
+                           it == niters - 1 ? 1 : 0, d_rs, trend_T);
     }
-#endif
+    hipLaunchKernelGGL(flat_interp_kernel, dim3(B), dim3(FLAT_NT), 0, stream, t, d_off, d_s, d_soff, d_state, trend, final_mask);
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;
 }

@@ -7,6 +7,7 @@ for r in $(seq $reps); do
     tag=$(basename $lib .so)
     LK_LIB_PATH=$PWD/$lib python bench.py --workload flatten --no-cpu-baseline --steps 10 --warmup 2 > $out/$tag.a$r.json 2> $out/$tag.a$r.err
     LK_LIB_PATH=$PWD/$lib python bench.py --workload flatten --cadences 4500 --flatten-window 101 --no-cpu-baseline --steps 10 --warmup 2 > $out/$tag.b$r.json 2> $out/$tag.b$r.err
-    echo "$tag rep $r 20000: $(grep -o 'ms_per_step[^,]*' $out/$tag.a$r.json | head -1)  4500: $(grep -o 'ms_per_step[^,]*' $out/$tag.b$r.json | head -1)"
+    LK_LIB_PATH=$PWD/$lib python bench.py --workload flatten --cadences 3500 --flatten-window 101 --no-cpu-baseline --steps 10 --warmup 2 > $out/$tag.c$r.json 2> $out/$tag.c$r.err
+    echo "$tag rep $r 20000: $(grep -o 'ms_per_step[^,]*' $out/$tag.a$r.json | head -1)  4500: $(grep -o 'ms_per_step[^,]*' $out/$tag.b$r.json | head -1)  3500: $(grep -o 'ms_per_step[^,]*' $out/$tag.c$r.json | head -1)"
   done
 done
