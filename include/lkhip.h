@@ -73,6 +73,12 @@ int lk_init(int device_id, lk_handle **out);
 /* Chunk size (MiB of spectra) of the pinned, double-buffered host pipeline behind lk_ls_fast_*_batch; default 64, or the
  * environment variable LK_HOST_CHUNK_MB read once by lk_init — the library's only environment knob. */
 int lk_set_host_chunk_mb(lk_handle *h, int mb);
+/* BLS histogram form.  The fast form adds a wave's 64 cadences to their phase bins with one LDS ds_add_f64 per array and
+ * relies on the hardware applying same-address lanes in lane order (checked on the device, once per handle); where that
+ * check fails the library switches by itself to an atomic-free form in which one lane at a time updates its bins —
+ * bit-identical results, ~64 x the LDS instructions in the histogram phase.  on != 0 forces that form (tests, diagnosis of
+ * a suspected ordering problem); 0 returns to the automatic choice. */
+int lk_bls_set_ordered_histogram(lk_handle *h, int on);
 void lk_destroy(lk_handle *h);
 /* Block until every kernel / copy issued through this handle's GPU has finished (hipDeviceSynchronize): for callers
  * of the *_dev entry points that do not hold a HIP runtime of their own. */

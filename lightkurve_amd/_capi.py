@@ -32,6 +32,7 @@ SIGNATURES = [
     ("lk_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     ("lk_destroy", None, [_vp]),
     ("lk_set_host_chunk_mb", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("lk_bls_set_ordered_histogram", ctypes.c_int, [_vp, ctypes.c_int]),
     ("lk_workspace_bytes", ctypes.c_int64, [_vp]),
     ("lk_synchronize", ctypes.c_int, [_vp]),
     ("lk_ls_power_batch", ctypes.c_int,
@@ -244,6 +245,11 @@ class Handle:
 
     def workspace_bytes(self):
         return int(_lib.lk_workspace_bytes(self._h))
+
+    def bls_set_ordered_histogram(self, on):
+        """Force (True) the atomic-free BLS histogram — the form the library falls back to by itself on a device whose LDS
+        ds_add_f64 is not lane-ordered; False returns to the automatic choice."""
+        _check(_lib.lk_bls_set_ordered_histogram(self._h, int(bool(on))))
 
     def set_host_chunk_mb(self, mb):
         """MiB of spectra per chunk of the pinned host pipeline behind ls_fast_batch / ls_fast_peaks_batch (default 64, or

@@ -173,7 +173,9 @@ __device__ __forceinline__ void bls_team_body(
     // workgroup holds G = blockDim / 64 one-wave teams on G consecutive periods of the sorted grid (short periods); they
     // share the duration tables, the barriers, and — the point — the prefix pass: lane 2g + c of wave 0 runs the chain
     // of team g's component c, so the serial chain instructions are spent on 2 G lanes instead of 2.
-    const int nh_cap = shape >> 8, multi = shape & 1;  // shape: bit 0 multi-period workgroup, bits 8.. histogram waves
+    // shape: bit 0 multi-period workgroup, bit 1 ordered (atomic-free) histogram, bits 8.. histogram waves
+    const int nh_cap = shape >> 8, multi = shape & 1;
+    const bool serial_hist = (shape & 2) != 0;
     const int wtid = threadIdx.x, lane = wtid & 63;
     const int wwave = __builtin_amdgcn_readfirstlane(wtid >> 6);
     const int G = multi ? ((int)blockDim.x >> 6) : 1;
@@ -291,12 +293,29 @@ __device__ __forceinline__ void bls_team_body(
                 while (*s_ticket != g) __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
             }
+            if (serial_hist) {
+                // The fall-back for a device whose ds_add_f64 does not apply same-address lanes in lane order
+                // (bls_selftest_kernel): one lane at a time performs a plain read-add-write of its two bins.  A wave's LDS
+                // instructions execute in program order, so lane l + 1 reads what lane l wrote: the bins accumulate in
+                // cadence order by construction, with no atomic at all.  64 x the LDS instructions of the atomic form.
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (act[u]) {
-                    atomicAdd(&ya[ind[u]], v[u].x);
-                    atomicAdd(&wa[ind[u]], v[u].y);
-                }
+                for (int u = 0; u < U; ++u)
+                    for (int l = 0; l < 64; ++l) {
+                        if (lane == l && act[u]) {
+                            volatile double *yp = ya + ind[u], *wp = wa + ind[u];
+                            *yp = *yp + v[u].x;
+                            *wp = *wp + v[u].y;
+                        }
+                        wave_sync();
+                    }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (act[u]) {
+                        atomicAdd(&ya[ind[u]], v[u].x);
+                        atomicAdd(&wa[ind[u]], v[u].y);
+                    }
+            }
             if (NH > 1) {
                 asm volatile("" ::: "memory");
                 // lgkmcnt(0): the wave's LDS atomics above have been executed before the ticket store is issued (LDS
@@ -945,13 +964,12 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         int bad = -1;
         LK_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, stream));
         LK_HIP_CHECK(hipStreamSynchronize(stream));
-        if (bad != 0) {
-            lk::set_error("BLS self-test: LDS ds_add_f64 is not lane-ordered on this device (%d mismatching bins); the "
-                          "bit-exact histogram cannot run", bad);
-            return LK_EHIP;
-        }
+        // not lane-ordered: the histogram falls back to its atomic-free form (one lane at a time, see the kernel) — slower,
+        // still bit-exact
+        h->bls_serial_hist = bad != 0 ? 1 : 0;
         h->bls_attr_set = 1;
     }
+    const int serial_hist = (h->bls_serial_hist || h->bls_force_serial_hist) ? 2 : 0;
     // debug knobs, read once per process: LK_BLS_ABLATE skips phases (results wrong; phase costs by difference),
     // LK_BLS_PROF=1 prints the wall time of every launch, =2 adds per-phase clocks (their atomics distort short teams)
 #ifdef LK_BLS_DEBUG   // `make DEBUG=1`: the phase-ablation and profiling switches of the development builds
@@ -1028,7 +1046,7 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         const size_t nwg = (size_t)((B + 7) / 8) * 8 * (((size_t)npg + gsel * multi + (1 - multi) - 1) / (multi ? gsel : 1));
         LK_REQUIRE(nwg < ((size_t)1 << 31), "grid too large");
         const bool deep = !multi && waves_cu <= 16;  // <= 4 waves per SIMD: the 128-VGPR build fits
-        const int shape = multi | ((nw <= 2 ? nh_of_nw2 : nw <= 4 ? nh_of_nw4 : kHistWaves) << 8);
+        const int shape = multi | serial_hist | ((nw <= 2 ? nh_of_nw2 : nw <= 4 ? nh_of_nw4 : kHistWaves) << 8);
         if (deep)
             hipLaunchKernelGGL(bls_team_deep_kernel, dim3((unsigned)nwg), dim3(nt), lds, stream, d_tm, d_yw, d_off, d_stats,
                                period_dev, d_pidx + g0, npg, nP, B, d_dur, nd, max_dur, bin_duration, oversample,

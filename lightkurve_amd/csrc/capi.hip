@@ -123,6 +123,12 @@ int lk_set_host_chunk_mb(lk_handle *h, int mb) {
     return LK_OK;
 }
 
+int lk_bls_set_ordered_histogram(lk_handle *h, int on) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    h->bls_force_serial_hist = on ? 1 : 0;
+    return LK_OK;
+}
+
 void lk_destroy(lk_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);

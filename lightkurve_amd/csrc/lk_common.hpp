@@ -75,7 +75,9 @@ struct lk_handle {
     int *h_plan = nullptr;         // 64 B of pinned host memory: device -> host plan words (lsfast.hip)
     std::vector<const void *> lds_attr_done;  // kernels whose dynamic-LDS attribute has been raised on this device
     int lds_attr_rc = 0;                      // first failure of want_lds inside a void launch helper (take_lds_error)
-    int bls_attr_set = 0;          // bls.hip: kernel attributes set and the LDS-atomic order self-test passed on this device
+    int bls_attr_set = 0;          // bls.hip: kernel attributes set and the LDS-atomic order self-test run on this device
+    int bls_serial_hist = 0;       // ... which found ds_add_f64 NOT lane-ordered: the histogram runs its atomic-free form
+    int bls_force_serial_hist = 0; // lk_bls_set_ordered_histogram: the caller asked for that form (tests, diagnosis)
 };
 
 namespace lk {

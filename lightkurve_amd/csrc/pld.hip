@@ -38,6 +38,14 @@ namespace lk {
 constexpr int PLD_LMAX = 64;  // largest small eigenproblem kept in LDS
 constexpr int PLD_DIRECT_MAX = 138;  // largest P whose Gram matrix fits LDS for the direct Jacobi (512 threads)
 #ifndef PLD_F32_RES
+// Stop of the subspace iteration: ||C r - theta r|| <= tol * theta_max * sqrt(k).  PLD design matrices: 1e-7 — the residual falls
+// 4.8 -> 1.5e-2 -> 1.5e-5 -> 8.5e-9 -> 3.2e-12 per Rayleigh-Ritz step on the 816-column blocks, and the corrected flux / the outlier
+// masks of every reference golden are UNCHANGED for any threshold down to 1e-6 (profiles/r05_pld_tol_sweep.txt: 1.5e-8 / 4.7e-8 /
+// 1.4e-8 at 1e-10 ... 1e-6, first movement — 2.2e-7 on pld_k2sin_order3 — at 1e-5; masks identical to 1e-3): the fifth step
+// bought digits nothing downstream sees.  Stated parity 1e-6 on the corrected flux.  The standalone PCA (lk_pca_batch /
+// DesignMatrix.pca), whose OUTPUT is the basis, keeps 1e-10.
+#define PLD_EIG_TOL 1e-7
+#define PCA_EIG_TOL 1e-10
 #define PLD_F32_RES 1e-3  // relative residual above which the Chebyshev filter reads the float32 copy of C
 #endif
 constexpr int PLD_KC = 64;    // rows of the basis staged in LDS per step of the MFMA product C Q (64 x 66 doubles also hold
@@ -1827,13 +1835,14 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
 // top-k eigenpairs of the B Gram matrices G (P x P, leading dimension ldg) -> V (B x P x k), lam (B x k), both allocated
 // from ws.  mirror: G holds the upper 64 x 64 blocks only (gram_plain_launch) and is completed in place first.
 static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool products, bool mirror, double **V_out,
-                    double **lam_out, hipStream_t stream, Arena &ws, const float *G32 = nullptr) {
+                    double **lam_out, hipStream_t stream, Arena &ws, const float *G32 = nullptr, double tol = PLD_EIG_TOL) {
     constexpr int direct_max = PLD_DIRECT_MAX;
-    // Convergence: || C r - theta r || <= eig_tol * theta_max * sqrt(k) over the k wanted pairs.  1e-10 (round 3; 1e-13 before)
-    // costs one Rayleigh-Ritz step less per matrix (816 columns: 4.0 instead of 5.0) and moves the corrected flux of the
-    // reference-generated C5 golden by 1e-11 relative — the reference's own PCA is a randomised range finder run for a fixed
-    // 10 iterations, three orders of magnitude less reproducible than that (the golden itself sits 1.5e-8 away either way).
-    constexpr double eig_tol = 1e-10;
+    // Convergence: || C r - theta r || <= eig_tol * theta_max * sqrt(k) over the k wanted pairs (PLD_EIG_TOL / PCA_EIG_TOL above).
+#ifdef LK_PLD_DEBUG   // development builds: LK_PLD_TOL sweeps the stop (tools/pld_tol_sweep.py -> profiles/r05_pld_tol_sweep.txt)
+    const double eig_tol = getenv("LK_PLD_TOL") ? atof(getenv("LK_PLD_TOL")) : tol;
+#else
+    const double eig_tol = tol;
+#endif
     constexpr int npow_std = 3;  // C^3 (or the degree-3 Chebyshev filter) between two Rayleigh-Ritz steps
     // mid-size product blocks: a product with the 136 x 136 C is cheap next to the l x l Jacobi and the Cholesky-QR of a
     // Rayleigh-Ritz step, and their flat spectrum keeps C^8 R well conditioned — 8 products per step need 5 steps where 3
@@ -1972,7 +1981,8 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
 
 // PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
 static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
-                     int col0, hipStream_t stream, Arena &ws, bool centred = false, bool products = false) {
+                     int col0, hipStream_t stream, Arena &ws, bool centred = false, bool products = false,
+                     double tol = PLD_EIG_TOL) {
     if (!centred) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
     const int KB = (P + 63) / 64, ldg = KB * 64;
     double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
@@ -1982,7 +1992,7 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
     }
     gram_plain_launch(A, d_off, B, P, G, stream, h);
     double *V = nullptr, *lam = nullptr;
-    const int rc = eig_topk(h, G, ldg, B, P, k, products, true, &V, &lam, stream, ws);
+    const int rc = eig_topk(h, G, ldg, B, P, k, products, true, &V, &lam, stream, ws, nullptr, tol);
     if (rc) return rc;
     {
         const dim3 grid((N + 63) / 64, B), blk(256);
@@ -2311,7 +2321,7 @@ int dm_pca_launch(lk_handle *h, int B, int N, int P, int k, const double *A_in, 
     double *A = (double *)h->ws.alloc((size_t)B * N * P * 8);
     LK_REQUIRE(A != nullptr, "workspace exhausted");
     LK_HIP_CHECK(hipMemcpyAsync(A, A_in, (size_t)B * N * P * 8, hipMemcpyDeviceToDevice, stream));
-    rc = pca_block(h, A, B, N, P, k, d_off, U, k, 0, stream, h->ws, false);
+    rc = pca_block(h, A, B, N, P, k, d_off, U, k, 0, stream, h->ws, false, false, PCA_EIG_TOL);
     if (rc) return rc;
     LK_HIP_CHECK(hipGetLastError());
     return LK_OK;

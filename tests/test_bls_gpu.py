@@ -169,3 +169,34 @@ def test_randomised_configurations_bit_exact():
         ref = O.bls(t, yy, ivar, period, duration, oversample, use_like)
         for field, r in zip(_capi.BLS_FIELDS, ref):
             assert np.array_equal(res[field][0], r, equal_nan=True), (c, field, n, oversample, use_like)
+
+
+def test_ordered_histogram_fallback_is_bit_exact(golden):
+    """on a device whose LDS ds_add_f64 is not lane-ordered (bls_selftest_kernel) the library falls back to an
+    atomic-free histogram instead of refusing to run.  The fall-back is forced here (lk_bls_set_ordered_histogram) and must
+    reproduce the reference golden (astropy's compiled run_bls) and the atomic form bit for bit — sorted, unsorted and
+    ragged input, short and long periods (one-wave teams, multi-wave teams with ticketed histogram waves)."""
+    h = _capi.Handle.get(0)
+    g = golden("bls_2500")
+    t, y, ivar = g["raw_t"], g["raw_y"], g["raw_ivar"]
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(t))
+    ts, ys, es, _ = synth.bls_target(3, 1, 6000, cadence_days=10.0 / 1440.0)
+    t2, y2, w2, _ = O.lk_bls_inputs(ts, ys, es)
+    long_p = np.linspace(15.0, 39.0, 40)           # thousands of bins: the multi-wave teams
+    fast = [_capi.bls_batch(t, y, ivar, [0, len(t)], g["period"], g["duration"]),
+            _capi.bls_batch(np.concatenate([t[perm], t2]), np.concatenate([y[perm], y2]), np.concatenate([ivar[perm], w2]),
+                            [0, len(t), len(t) + len(t2)], long_p, [0.05, 0.2])]
+    h.bls_set_ordered_histogram(True)
+    try:
+        slow = [_capi.bls_batch(t, y, ivar, [0, len(t)], g["period"], g["duration"]),
+                _capi.bls_batch(np.concatenate([t[perm], t2]), np.concatenate([y[perm], y2]), np.concatenate([ivar[perm], w2]),
+                                [0, len(t), len(t) + len(t2)], long_p, [0.05, 0.2])]
+    finally:
+        h.bls_set_ordered_histogram(False)
+    for a, b in zip(fast, slow):
+        for name in _capi.BLS_FIELDS:
+            assert np.array_equal(a[name], b[name]), name
+    for name in _capi.BLS_FIELDS:
+        if name != "transit_time":
+            assert np.array_equal(slow[0][name][0], g["likelihood_" + name]), name
