@@ -105,7 +105,7 @@ int lk_ls_power_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const 
  * least-squares fit of [1,] sin(m w t), cos(m w t), m = 1..nterms; power = (X^T y)^T (X^T X)^-1 (X^T y), normalised as
  * above.  The trig sums are exact direct sums, so the result is what 'chi2' returns (which 'fastchi2' approximates by
  * extirpolation + FFT).  nterms = 1 is lk_ls_power_batch.  1 <= nterms <= LK_MAX_NTERMS. */
-#define LK_MAX_NTERMS 4
+#define LK_MAX_NTERMS 8   /* 1..4: regular-grid and FFT kernels; 5..8: exact sums, one thread per frequency (both names) */
 int lk_ls_chi2_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, const double *y, const double *dy,
                      const double *freq, double f0, double df, int64_t M, int nterms, int fit_mean, int center_data,
                      int normalization, const double *scale, double *power);

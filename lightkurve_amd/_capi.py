@@ -280,7 +280,7 @@ def _offsets(n_off, total):
 
 
 # --------------------------------------------------------------------------------------------- Lomb-Scargle
-MAX_NTERMS = 4  # LK_MAX_NTERMS in include/lkhip.h
+MAX_NTERMS = 8  # LK_MAX_NTERMS in include/lkhip.h (5..8: exact sums for both 'chi2' and 'fastchi2')
 
 
 def ls_power_batch(t, y, n_off, dy=None, frequency=None, f0=0.0, df=0.0, M=None, fit_mean=True,

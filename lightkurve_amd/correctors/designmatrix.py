@@ -202,26 +202,14 @@ class SparseDesignMatrixCollection(DesignMatrixCollection):
         return "SparseDesignMatrixCollection:\n" + "".join("\t{}\n".format(m.__repr__()) for m in self.matrices)
 
 
-def _spline_basis_vector(x, degree, i, knots):
-    """Cox-de Boor recursion exactly as the reference writes it (designmatrix.py:853-893): degree-0 pieces are CLOSED on
-    both ends (a sample that sits on a knot belongs to both neighbouring pieces), zero-width denominators give 0."""
-    if degree == 0:
-        B = np.zeros(len(x))
-        B[(x >= knots[i]) & (x <= knots[i + 1])] = 1
-        return B
-    da = knots[degree + i] - knots[i]
-    db = knots[i + degree + 1] - knots[i + 1]
-    alpha1 = (x - knots[i]) / da if da != 0 else np.zeros(len(x))
-    alpha2 = (knots[i + degree + 1] - x) / db if db != 0 else np.zeros(len(x))
-    return _spline_basis_vector(x, degree - 1, i, knots) * alpha1 + _spline_basis_vector(x, degree - 1, i + 1, knots) * alpha2
-
-
-def create_sparse_spline_matrix(x, n_knots=20, knots=None, degree=3, name="spline"):
+def create_sparse_spline_matrix(x, n_knots=20, knots=None, degree=3, name="spline", device=0):
     """The spline block of ``PLDCorrector.create_design_matrix(sparse=True)`` (reference designmatrix.py:896-949): knots at
-    the mid-points between the samples that end each of ``n_knots - degree`` equal chunks of the sorted ``x``, boundary
-    knots repeated ``degree`` times, all-zero basis vectors dropped.  A different basis from the patsy splines of the dense
-    path (designmatrix.py:952-997), so ``sparse=True`` and ``sparse=False`` differ in the reference too.  Host-side
-    construction of an N x ~n_knots block, like the knot selection of the dense path."""
+    the mid-points between the samples that end each of ``n_knots - degree`` equal chunks of the sorted ``x``, all-zero
+    basis vectors dropped.  The reference evaluates the basis with a Python Cox-de Boor recursion (:853-893) whose result is
+    the clamped B-spline basis on [min x, knots, max x] — the basis of the dense builder below with other knots (verified
+    against the reference: 3e-16) — so it is evaluated by the same kernel (lk_spline_basis_batch).  ``sparse=True`` and
+    ``sparse=False`` differ in the reference too: different interior knots."""
+    from .. import _capi
     x = np.asarray(x, np.float64)
     if not isinstance(n_knots, (int, np.integer)):
         raise ValueError("`n_knots` must be an integer.")
@@ -230,12 +218,9 @@ def create_sparse_spline_matrix(x, n_knots=20, knots=None, degree=3, name="splin
     if knots is None:
         ends = np.asarray([s_[-1] for s_ in np.array_split(np.argsort(x), n_knots - degree)[:-1]])
         knots = [np.mean([x[k], x[k + 1]]) for k in ends]
-    knots = np.append(np.append(x.min(), knots), x.max())
-    knots = np.unique(knots)
-    knots_wbounds = np.append(np.append([x.min()] * (degree - 1), knots), [x.max()] * degree)
-    cols = [_spline_basis_vector(x, degree, idx, knots_wbounds) for idx in np.arange(-1, len(knots_wbounds) - degree - 1)]
-    cols = [c for c in cols if c.sum() != 0]
-    return SparseDesignMatrix(np.column_stack(cols), name=name)
+    knots = np.unique(np.append(np.append(x.min(), knots), x.max()))
+    basis = _capi.spline_basis_batch(x, knots, degree=int(degree), device=device)
+    return SparseDesignMatrix(basis[:, basis.sum(axis=0) != 0], name=name)
 
 
 def create_spline_matrix(x, n_knots=20, knots=None, degree=3, name="spline", include_intercept=True, device=0):

@@ -432,8 +432,15 @@ __global__ __launch_bounds__(256) void ls_chi2_any_kernel(const CadAny *__restri
     }
 }
 
+// the regular grid f0 + df j as an explicit array (nterms > LK_FAST_NTERMS take the one-thread-per-frequency kernel)
+__global__ __launch_bounds__(256) void ls_freq_grid_kernel(double f0, double df, int64_t M, double *__restrict__ freq) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < M) freq[j] = f0 + df * (double)j;
+}
+
 // ------------------------------------------------------------------------------------------------ launcher
 constexpr int LS_F = 16;
+constexpr int LK_FAST_NTERMS = 4;  // nterms with a regular-grid kernel (6 nterms accumulators x LS_CHI2_F frequencies per lane)
 
 int ls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *dy,
               const double *freq, double f0, double df, int64_t M, int fit_mean, int center_data, int normalization,
@@ -467,11 +474,20 @@ int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
 
     h->ws.reset();
     const size_t need = (size_t)(B + 1) * 8 + (size_t)B * sizeof(TargetStats) + ntot * (sizeof(CadHot) + sizeof(CadGen)) +
-                        4096;
+                        (size_t)M * 8 + 4096;
     int rc = h->ws.reserve(need);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     TargetStats *d_stats = (TargetStats *)h->ws.alloc((size_t)B * sizeof(TargetStats));
+    if (!freq && nterms > LK_FAST_NTERMS) {
+        // 5 .. LK_MAX_NTERMS terms: 6 nterms sums per frequency no longer fit four frequencies per lane — the grid becomes an
+        // explicit array and the one-thread-per-frequency kernel runs (exact sums, ~7 x the cost per pair: rare requests)
+        LK_REQUIRE(B <= 65535, "at most 65535 targets per call with nterms > %d (got %d)", LK_FAST_NTERMS, B);
+        double *d_freq = (double *)h->ws.alloc((size_t)M * 8);
+        LK_REQUIRE(d_freq != nullptr, "workspace exhausted (frequency grid)");
+        hipLaunchKernelGGL(ls_freq_grid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, f0, df, M, d_freq);
+        freq = d_freq;
+    }
     {
         const int rcs = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, stream);
         if (rcs) return rcs;
@@ -493,7 +509,11 @@ int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
                 break;
             case 2: LK_CHI2_ANY(2); break;
             case 3: LK_CHI2_ANY(3); break;
-            default: LK_CHI2_ANY(4); break;
+            case 4: LK_CHI2_ANY(4); break;
+            case 5: LK_CHI2_ANY(5); break;
+            case 6: LK_CHI2_ANY(6); break;
+            case 7: LK_CHI2_ANY(7); break;
+            default: LK_CHI2_ANY(8); break;
         }
 #undef LK_CHI2_ANY
     } else if (nterms > 1) {

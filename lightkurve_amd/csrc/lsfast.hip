@@ -1646,6 +1646,11 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
     if (nterms == 1)
         return lsfast_launch(h, B, n_off_host, t, y, dy, f0, df, M, fit_mean, center_data, normalization, scale,
                              oversampling, power, stream, nullptr, nullptr);
+    // 5 .. LK_MAX_NTERMS terms: served by the EXACT sums (ls_chi2_launch) — the reference's `chi2` of the same nterms to 1e-9,
+    // i.e. its `fastchi2` up to that method's own extirpolation error; the FFT power kernel is instantiated for <= 4 terms
+    if (nterms > 4)
+        return ls_chi2_launch(h, B, n_off_host, t, y, dy, nullptr, f0, df, M, nterms, fit_mean, center_data, normalization, scale,
+                              power, stream);
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
     LK_REQUIRE(M >= 0, "M must be >= 0");
     if (B == 0 || M == 0) return LK_OK;

@@ -19,6 +19,12 @@
 
 namespace lk {
 
+// Largest number of regressors: the global-memory LU (solve_kernel / invert_kernel) keeps one column of multipliers in LDS.
+// 1023 until round 4; wider matrices (a spline with a knot per 5 cadences of a 20 000-cadence light curve, split design
+// matrices) are rare and slow — O(K^3) in one workgroup — but they stay on the device.
+constexpr int REG_KMAX = 4095;
+
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int GR_BLK = 64;    // output block edge
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256) void solve_kernel(const double *__restrict__ G
     if (done && done[blockIdx.x]) return;
     __shared__ double s_val[256];
     __shared__ int s_idx[256];
-    __shared__ double s_col[1024];  // pivot-column multipliers (K <= 1024)
+    __shared__ double s_col[REG_KMAX + 1];  // pivot-column multipliers
     const int target = blockIdx.x, tid = threadIdx.x;
     const double *Gt = G + (size_t)target * Kp * Kp;
     const int Ka = K + 1;
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(256) void invert_kernel(const double *__restrict__ 
                                                       double *__restrict__ Awork, double *__restrict__ inv) {
     __shared__ double s_val[256];
     __shared__ int s_idx[256];
-    __shared__ double s_col[1024];  // column j of every row (K <= 1023)
+    __shared__ double s_col[REG_KMAX + 1];  // column j of every row
     const int target = blockIdx.x, tid = threadIdx.x;
     const double *Gt = G + (size_t)target * Kp * Kp;
     const int W = 2 * K;
@@ -1007,7 +1013,7 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
                    double *w_cov) {
     LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
     if (B == 0) return LK_OK;
-    LK_REQUIRE(K >= 1 && K <= 1023, "K=%d outside the supported range 1..1023", K);
+    LK_REQUIRE(K >= 1 && K <= REG_KMAX, "K=%d outside the supported range 1..%d", K, REG_KMAX);
     LK_REQUIRE(B <= 65535, "at most 65535 targets per call on this path (got %d): split the batch", B);
     LK_REQUIRE(X && y && w && model && outl, "NULL buffer");
     LK_REQUIRE((prior_mu == nullptr) == (prior_sigma == nullptr), "Please specify both `prior_mu` and `prior_sigma`");

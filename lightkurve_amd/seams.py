@@ -4,8 +4,11 @@
 
 * S1  astropy Lomb-Scargle method registry (reached from src/lightkurve/periodogram.py:961-964): ``'fast'`` (lightkurve's
       default, :650), ``'fastchi2'``, ``'chi2'`` are replaced, ``'hip'`` (exact direct sums) is added; astropy's own
-      implementations stay reachable as ``'fast_cpu'``, ``'fastchi2_cpu'``, ``'chi2_cpu'`` and are called for what the
-      kernels do not cover (``nterms`` > 4, a ``'fast'`` call with ``use_fft=False``).
+      implementations stay reachable as ``'fast_cpu'``, ``'fastchi2_cpu'``, ``'chi2_cpu'`` and are called only for ``nterms``
+      > 8.  A ``'fast'`` / ``'fastchi2'`` call with ``use_fft=False`` IS the exact trig sums (fast_impl.py / utils.py:154-156) and
+      runs the exact kernels; so does one with ``Mfft`` != 4 or ``nterms`` 5..8 (the FFT kernels extirpolate with astropy's
+      default Mfft = 4 and are instantiated for <= 4 terms): the result is then the sums astropy's approximation converges
+      to, not its approximation error.
 * S2  ``astropy.timeseries.periodograms.bls.methods.bls_fast`` (reached from periodogram.py:1169).
 * S3  ``lightkurve.lightcurve.LightCurve.flatten`` (lightcurve.py:943-1078): the mask / segmentation / savgol / clip /
       interpolation loop (:996-1063) is ONE call of lk_savgol_trend_batch; the object handling around it stays lightkurve's.
@@ -15,8 +18,11 @@
       lk_regress_cov_batch call); ``PLDCorrector.create_design_matrix`` (pldcorrector.py:125-287) builds its PCA blocks with
       lk_pld_design_batch (``sparse=True`` included: same PCA blocks, the reference's sparse spline basis beside them);
       ``DesignMatrix.pca`` / ``.standardize`` (designmatrix.py:215-282) go to lk_pca_batch / lk_standardize_batch for every
-      caller.  Sparse collections are densified; ``pca_components=0``, more than 1023 regressors, ``pca`` beyond 48 terms
-      or a sparse collection that would not fit densified go to the original methods.
+      caller; ``create_spline_matrix`` / ``create_sparse_spline_matrix`` (designmatrix.py:896-997; PLD, SFF, user code) evaluate
+      their B-spline bases with lk_spline_basis_batch instead of patsy / the Python recursion.  Sparse collections are
+      densified; more than 4095 regressors, ``pca`` beyond 48 terms or a sparse collection that would not fit densified go to
+      the original methods, and so does ``pca_components=0`` — there the reference itself calls ``fbpca.pca(k=0)`` for the
+      background block (pldcorrector.py:223), which fbpca rejects: the seam hands the call over unchanged.
       Every call handed back to a CPU implementation logs one ``log.debug`` line saying which seam and why.
 
 ``backend`` is the module that provides the compute entry points (default: ``lightkurve_amd._capi``, i.e. the GPU).  The
@@ -38,7 +44,7 @@ _BACKEND = _capi
 _ORIG = {}
 
 # limits of lk_regress_cov_batch (include/lkhip.h) and a budget for densified sparse collections
-_MAX_REGRESSORS = 1023
+_MAX_REGRESSORS = 4095
 _DENSE_BUDGET_BYTES = 8 << 30
 
 
@@ -91,15 +97,12 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
     """Signature of astropy's lombscargle_fast / lombscargle_fastchi2 (fast_impl.py:6, fastchi2_impl.py:8): the
     f0/df/Nf form every 'fast*' method receives; ``nterms`` > 1 arrives only under the name 'fastchi2'."""
     kw = dict(trig_sum_kwds or {})
-    unsupported = nterms > _capi.MAX_NTERMS or not use_fft or int(kw.get("Mfft", 4)) != 4
-    if unsupported and ("fastchi2" if nterms > 1 else "fast") in _ORIG:
+    if nterms > _capi.MAX_NTERMS and ("fastchi2" if nterms > 1 else "fast") in _ORIG:
         name = "fastchi2" if nterms > 1 else "fast"
-        extra = dict(nterms=nterms) if nterms > 1 else {}
-        _fell_back("lombscargle METHODS['%s']" % name,
-                   "nterms=%d > %d" % (nterms, _capi.MAX_NTERMS) if nterms > _capi.MAX_NTERMS else
-                   ("use_fft=False" if not use_fft else "Mfft=%s (the kernels extirpolate with Mfft=4)" % kw.get("Mfft")))
+        _fell_back("lombscargle METHODS['%s']" % name, "nterms=%d > %d" % (nterms, _capi.MAX_NTERMS))
         return _ORIG[name](t, y, dy, f0=f0, df=df, Nf=Nf, center_data=center_data, fit_mean=fit_mean,
-                           normalization=normalization, use_fft=use_fft, trig_sum_kwds=trig_sum_kwds, **extra)
+                           normalization=normalization, use_fft=use_fft, trig_sum_kwds=trig_sum_kwds, nterms=nterms)
+    exact = (not use_fft) or int(kw.get("Mfft", 4)) != 4 or nterms > 4
     if not 1 <= nterms <= _capi.MAX_NTERMS:
         raise ValueError("the HIP kernels are instantiated for 1 <= nterms <= %d" % _capi.MAX_NTERMS)
     norm, finish = _split_normalization(normalization)
@@ -110,6 +113,11 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
     if Nf <= 0:
         raise ValueError("Number of frequencies must be positive")
     t = np.asarray(t, dtype=np.float64)
+    if exact:
+        # use_fft=False: astropy's trig_sum then forms the exact sums (utils.py:154-156) — what ls_grid_kernel computes; a
+        # request for a wider extirpolation stencil or more than four terms gets the same exact sums
+        return finish(_be().ls_power_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
+                                           center_data=center_data, normalization=norm, nterms=nterms)[0])
     return finish(_be().ls_fast_batch(t, y, [0, len(t)], dy=dy, f0=float(f0), df=float(df), M=int(Nf), fit_mean=fit_mean,
                                       center_data=center_data, normalization=norm,
                                       oversampling=int(kw.get("oversampling", 5)), nterms=nterms)[0])
@@ -325,7 +333,7 @@ def _make_create_design_matrix(lk_pld_mod):
         import warnings
         if sparse:
             # reference :194-199, 226-230: the sparse collection carries the reference's OTHER spline basis
-            # (create_sparse_spline_matrix, host-side like the knot selection); the pixel and background blocks are the same
+            # (create_sparse_spline_matrix: its own knots, the same kernel once the spline seam is installed); the pixel and background blocks are the same
             # PCA'd matrices, built on the GPU above
             sp = lk_pld_mod.create_sparse_spline_matrix(time, n_knots=spline_n_knots, degree=spline_degree).append_constant()
             sp.prior_sigma = np.ones(sp.shape[1]) * ps[-1]
@@ -375,6 +383,79 @@ def _make_dm_standardize(lk_dm_mod):
 
     standardize.__doc__ = orig.__doc__
     return standardize
+
+
+def _make_spline_builders(lk_dm_mod):
+    """``create_spline_matrix`` (designmatrix.py:952-997: patsy ``bs(x, df | knots, degree, include_intercept) - 1``) and
+    ``create_sparse_spline_matrix`` (:896-949: a Python Cox-de Boor recursion) build the SAME kind of basis — clamped
+    B-splines on [min x, interior knots, max x] — and differ only in where they put the interior knots (equally spaced
+    percentiles of x / mid-points between the samples that end equal chunks of the sorted x).  Knot placement stays the
+    reference's arithmetic on the host; the N x n_knots basis is lk_spline_basis_batch (agrees with patsy to 1e-12 and with
+    the recursion to 4e-16, tests/test_designmatrix_gpu.py, tests/seams_lk_worker.py)."""
+    import pandas as pd
+    orig_dense, orig_sparse = lk_dm_mod.create_spline_matrix, lk_dm_mod.create_sparse_spline_matrix
+
+    def create_spline_matrix(x, n_knots=20, knots=None, degree=3, name="spline", include_intercept=True):
+        xx = np.asarray(getattr(x, "value", x), dtype=np.float64)
+        if xx.ndim != 1 or len(xx) < 2 or not np.all(np.isfinite(xx)) or not 0 <= int(degree) <= 7:
+            _fell_back("create_spline_matrix", "x / degree outside the kernel's range")
+            return orig_dense(x, n_knots=n_knots, knots=knots, degree=degree, name=name, include_intercept=include_intercept)
+        order = int(degree) + 1
+        if knots is not None:
+            inner = np.sort(np.asarray(knots, dtype=np.float64))
+        else:
+            n_inner = int(n_knots) - order + (0 if include_intercept else 1)
+            if n_inner < 0:     # patsy's own error message for this
+                return orig_dense(x, n_knots=n_knots, knots=knots, degree=degree, name=name,
+                                  include_intercept=include_intercept)
+            inner = np.percentile(xx, np.linspace(0, 100, n_inner + 2)[1:-1]) if n_inner > 0 else np.zeros(0)
+        full = np.concatenate([[np.min(xx)], inner, [np.max(xx)]])
+        basis = _be().spline_basis_batch(xx, full, degree=int(degree))
+        if not include_intercept:
+            basis = basis[:, 1:]
+        df = pd.DataFrame(basis, columns=["knot{}".format(i + 1) for i in range(basis.shape[1])])
+        return lk_dm_mod.DesignMatrix(df, name=name)
+
+    def create_sparse_spline_matrix(x, n_knots=20, knots=None, degree=3, name="spline"):
+        from scipy.sparse import csr_matrix
+        xx = np.asarray(x, np.float64)
+        if not isinstance(n_knots, int):
+            raise ValueError("`n_knots` must be an integer.")
+        if n_knots - degree <= 0:
+            raise ValueError("n_knots must be greater than degree.")
+        if xx.ndim != 1 or len(xx) < 2 or not np.all(np.isfinite(xx)) or not 1 <= int(degree) <= 7:
+            _fell_back("create_sparse_spline_matrix", "x / degree outside the kernel's range")
+            return orig_sparse(x, n_knots=n_knots, knots=knots, degree=degree, name=name)
+        if knots is None:
+            ends = np.asarray([s_[-1] for s_ in np.array_split(np.argsort(xx), n_knots - degree)[:-1]])
+            knots = [np.mean([xx[k], xx[k + 1]]) for k in ends]
+        kn = np.unique(np.append(np.append(xx.min(), knots), xx.max()))
+        basis = _be().spline_basis_batch(xx, kn, degree=int(degree))
+        basis = basis[:, basis.sum(axis=0) != 0]                      # the reference drops all-zero basis vectors
+        return lk_dm_mod.SparseDesignMatrix(csr_matrix(basis), name=name)
+
+    create_spline_matrix.__doc__ = orig_dense.__doc__
+    create_sparse_spline_matrix.__doc__ = orig_sparse.__doc__
+    return create_spline_matrix, create_sparse_spline_matrix
+
+
+_SPLINE_MODULES = ("lightkurve.correctors.designmatrix", "lightkurve.correctors.pldcorrector",
+                   "lightkurve.correctors.sffcorrector", "lightkurve.correctors")
+
+
+def _set_spline_builders(dense, sparse):
+    """The builders are imported by name into several modules (pldcorrector.py:26, sffcorrector.py:18): every namespace that
+    holds them gets the replacement."""
+    import importlib
+    for modname in _SPLINE_MODULES:
+        try:
+            mod = importlib.import_module(modname)
+        except ImportError:
+            continue
+        if hasattr(mod, "create_spline_matrix"):
+            mod.create_spline_matrix = dense
+        if hasattr(mod, "create_sparse_spline_matrix"):
+            mod.create_sparse_spline_matrix = sparse
 
 
 # ------------------------------------------------------------------------------------------------ install / uninstall
@@ -427,6 +508,10 @@ def install(backend=None, lightkurve=True, full_loop=True):
     lk_dm.DesignMatrix.pca = _make_dm_pca(lk_dm)
     lk_dm.DesignMatrix.standardize = _make_dm_standardize(lk_dm)
     done += ["lightkurve:DesignMatrix.pca", "lightkurve:DesignMatrix.standardize"]
+    _ORIG.setdefault("create_spline_matrix", lk_dm.create_spline_matrix)
+    _ORIG.setdefault("create_sparse_spline_matrix", lk_dm.create_sparse_spline_matrix)
+    _set_spline_builders(*_make_spline_builders(lk_dm))
+    done += ["lightkurve:create_spline_matrix", "lightkurve:create_sparse_spline_matrix"]
     return done
 
 
@@ -461,3 +546,5 @@ def uninstall():
         lk_dm.DesignMatrix.pca = _ORIG["dm_pca"]
     if "dm_standardize" in _ORIG:
         lk_dm.DesignMatrix.standardize = _ORIG["dm_standardize"]
+    if "create_spline_matrix" in _ORIG:
+        _set_spline_builders(_ORIG["create_spline_matrix"], _ORIG["create_sparse_spline_matrix"])

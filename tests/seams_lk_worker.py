@@ -48,7 +48,17 @@ def run_all(lk):
     out["ls_psd"] = lc.to_periodogram(normalization="psd", freq_unit="microhertz")
     out["ls_slow_period_grid"] = lc.to_periodogram(period=np.linspace(0.5, 5, 300), ls_method="slow")
     out["ls_chi2_nterms2"] = lc.to_periodogram(nterms=2, ls_method="chi2", oversample_factor=2)
-    out["ls_chi2_nterms5"] = lc.to_periodogram(nterms=5, ls_method="chi2", oversample_factor=1)   # beyond the kernels
+    out["ls_chi2_nterms5"] = lc.to_periodogram(nterms=5, ls_method="chi2", oversample_factor=1)   # 5..8 terms: exact sums
+    # round 5: requests the FFT kernels do not cover stay on the device as exact sums (astropy called directly, as the
+    # reference's users can: use_fft=False is astropy's own exact route; Mfft / nterms > 4 converge to the same sums)
+    from astropy.timeseries import LombScargle
+    ls = LombScargle(t, y)
+    fgrid = dict(minimum_frequency=0.02, maximum_frequency=8.0, samples_per_peak=3)
+    out["raw_ls_fast_nofft"] = np.asarray(ls.power(ls.autofrequency(**fgrid), method="fast", method_kwds=dict(use_fft=False)))
+    out["raw_ls_fast_mfft8"] = np.asarray(ls.power(ls.autofrequency(**fgrid), method="fast",
+                                               method_kwds=dict(trig_sum_kwds=dict(Mfft=8, oversampling=10))))
+    ls5 = LombScargle(t, y, nterms=5)
+    out["raw_ls_fastchi2_nterms5"] = np.asarray(ls5.power(ls5.autofrequency(**fgrid), method="fastchi2"))
     tb, yb, eb, _ = synth.bls_target(3, 9, 2500, cadence_days=10.0 / 1440.0)
     lcb = lk.LightCurve(time=tb + 2000.0, flux=yb, flux_err=eb)
     out["bls"] = lcb.to_periodogram(method="bls", period=np.linspace(0.7, 8, 500), duration=[0.05, 0.1, 0.2])   # S2
@@ -80,6 +90,11 @@ def run_all(lk):
     dmA = DesignMatrix(pd.DataFrame(Ad), name="A")
     U = dmA.pca(4).values
     out["dm_pca_projector"] = U @ U.T @ Ad[:, :3]              # invariant under sign flips / rotations of the basis
+    # the spline builders (round 5): patsy's bs() / the reference's Cox-de Boor recursion vs lk_spline_basis_batch
+    from lightkurve.correctors.designmatrix import create_spline_matrix, create_sparse_spline_matrix
+    out["spline_dense"] = create_spline_matrix(t, n_knots=14, degree=3).values
+    out["spline_dense_knots"] = create_spline_matrix(t, knots=[2.0, 5.5, 9.0], degree=2, include_intercept=False).values
+    out["spline_sparse"] = np.asarray(create_sparse_spline_matrix(t, n_knots=12, degree=3).X.todense())
     Sd = Ad.copy()
     Sd[rng.random(Sd.shape) < 0.03] = 0.0
     Sd[:, 2] = 1.5
@@ -117,7 +132,9 @@ def compare(bname):
             seams.uninstall()
         again = run_all(lk)                                  # uninstall really restores the reference path
     res = {"installed": installed, "errors": {}, "types": {}}
-    tol = {"pld": 1e-6, "pld_sparse": 1e-6, "dm_pca_projector": 1e-6}
+    # ls_fast_mfft8 / ls_fastchi2_nterms5: the exact sums against astropy's own extirpolated approximation of them
+    tol = {"pld": 1e-6, "pld_sparse": 1e-6, "dm_pca_projector": 1e-6, "raw_ls_fast_mfft8": 1e-5, "raw_ls_fastchi2_nterms5": 5e-3,
+           "spline_dense": 1e-12, "spline_dense_knots": 1e-12, "spline_sparse": 1e-12}
     for k, r in ref.items():
         g = got[k]
         assert type(g) is type(r), (k, type(g), type(r))

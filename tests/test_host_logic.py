@@ -202,16 +202,6 @@ def test_underfit_metric_neighbors_properties():
     assert abs(underfit_metric_neighbors(good, noise) - 0.95) < 0.05
 
 
-def test_sparse_spline_matrix_matches_reference_golden(golden):
-    """create_sparse_spline_matrix (reference designmatrix.py:896-949, the spline block of PLDCorrector(sparse=True))."""
-    from lightkurve_amd.correctors import create_sparse_spline_matrix
-    g = golden("pld_k2sin_order3_sparse")
-    w = int(g["block_widths"][-1])
-    sp = create_sparse_spline_matrix(g["time"], n_knots=10, degree=5).append_constant()
-    assert sp.shape == (len(g["time"]), w)
-    assert np.array_equal(sp.X, g["X"][:, -w:])
-
-
 def test_acf2d_host_side_smoothing_and_plan(golden):
     """Host half of estimate_numax_acf2d: default numaxs / window / spacing, window index arithmetic and the Gaussian
     smoothing of the metric (astropy convolve, boundary='extend'), against the reference's diagnostics."""

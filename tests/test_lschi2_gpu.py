@@ -136,3 +136,25 @@ def test_fastchi2_reproduces_the_reference_fastchi2(golden):
     for b in range(2):
         ref = O.ls_power_fastchi2(ts[b], ys[b], None, f[0], df, len(f), nterms=4, normalization="psd")
         check(p4[b], ref, f * ts[b][-1] >= 4.0, 1.0)
+
+
+@pytest.mark.parametrize("nterms", [5, 6, 8])
+def test_five_to_eight_terms_run_the_exact_kernel(nterms):
+    """Round 5: nterms 5..8 stay on the device — exact sums, one thread per frequency — for the regular-grid
+    form, the explicit-frequency form and the 'fastchi2' entry point alike; vs the oracle restatement of astropy's
+    lombscargle_chi2 (chi2_impl.py:5-86) at the tolerances stated on top."""
+    t, y, e, _ = synth.ls_target(2, nterms, 1500, cadence_days=10.0 / 1440.0)
+    t = t - t[0]
+    f0, df, M = 0.3, 0.011, 400          # f T >= 3 everywhere: 2 nterms + 1 = 17 columns stay well posed
+    f = f0 + df * np.arange(M)
+    ref = O.ls_power_chi2(t, y, e, f, nterms=nterms, normalization="standard")
+    ok = np.ones(M, bool)
+    off = [0, len(t)]
+    a = _capi.ls_power_batch(t, y, off, dy=e, f0=f0, df=df, M=M, normalization="standard", nterms=nterms)[0]
+    b = _capi.ls_power_batch(t, y, off, dy=e, frequency=f, normalization="standard", nterms=nterms)[0]
+    c = _capi.ls_fast_batch(t, y, off, dy=e, f0=f0, df=df, M=M, normalization="standard", nterms=nterms)[0]
+    check(a, ref, ok, loose=1e-7)
+    check(b, ref, ok, loose=1e-7)
+    assert np.array_equal(a, c)
+    with pytest.raises(ValueError):
+        _capi.ls_power_batch(t, y, off, f0=f0, df=df, M=M, nterms=9)
