@@ -24,3 +24,11 @@ echo "## reference test files with the seams active (hip backend)"
     "test_lightcurve.py::test_flatten_with_nans" "test_lightcurve.py::test_flatten_robustness" \
     "test_lightcurve.py::test_flatten_returns_normalized" "test_lightcurve.py::test_iterative_flatten" 2>&1 | tail -15 )
 } | tee $O/seams_e2e_gpu.log
+# 3. B = 1 latency table (tools/seams_latency.py) and the PLD block with lightkurve itself as the CPU baseline
+{
+echo "# $(date -u) B = 1 latency through the seams on the GPU box"
+$CONDA -W ignore tools/seams_latency.py 2>&1 | grep -v "Warning\|warn" | tail -40
+} | tee $O/seams_latency.txt
+unset LD_PRELOAD PYTHONPATH
+python bench.py --workload pld --steps 5 --warmup 2 > $O/bench_pld_reference_baseline.json 2> $O/bench_pld.err
+grep -o '"cpu_baseline": {[^}]*' $O/bench_pld_reference_baseline.json | head -c 900
