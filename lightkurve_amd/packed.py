@@ -66,13 +66,13 @@ def _chunks(n_items, weights_cum):
 
 
 def any_nan(x):
-    """True if the float64 array holds a NaN: sum of squares per chunk (NaN iff a NaN is present — every term is >= 0, so
-    an inf never cancels), chunks over the thread pool; no temporary."""
+    """True if the float64 array holds a NaN: the minimum of a chunk is NaN iff the chunk holds one (numpy's min propagates
+    NaN; a vectorised pass without a temporary and without BLAS threads of its own), chunks over the thread pool."""
     n = x.size
     if n == 0:
         return False
     step = max(1 << 20, -(-n // _threads()))
-    parts = _pmap(lambda a, b: float(np.dot(x[a:b], x[a:b])), [(a, min(n, a + step)) for a in range(0, n, step)])
+    parts = _pmap(lambda a, b: float(np.min(x[a:b])), [(a, min(n, a + step)) for a in range(0, n, step)])
     return bool(np.isnan(parts).any())
 
 
