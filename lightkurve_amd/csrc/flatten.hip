@@ -1090,7 +1090,7 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         soff[b + 1] = soff[b] + ((5 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + (size_t)B * (64 + 8 * 16) + 8192);
+    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + (size_t)B * (64 + 16 * 16) + 8192);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     int64_t *d_soff = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
@@ -1113,7 +1113,10 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     FlatState *d_state = (FlatState *)h->ws.alloc((size_t)B * sizeof(FlatState));
     // trend workgroups per light curve: enough tiles for each (a 20 000-cadence light curve has ~19 tiles of ~1070 outputs at
     // window 401; a 4500-cadence one 4), and B x T >= ~4 workgroups per CU
-    const int trend_T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nmax / 4096));
+    int trend_T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nmax / 4096));
+#ifdef LK_FLAT_PROFILE
+    if (getenv("LK_FLAT_T")) trend_T = std::max(1, std::min(16, atoi(getenv("LK_FLAT_T"))));
+#endif
     double2 *d_rs = (double2 *)h->ws.alloc((size_t)B * trend_T * sizeof(double2));
     LK_REQUIRE(d_state != nullptr && d_rs != nullptr, "workspace exhausted (flatten state)");
     // the moment-form trend kernel keeps four tile arrays (three prefix sums + the inputs) of 1470 doubles: three 512-thread

@@ -1,9 +1,9 @@
 #!/bin/bash
 # End-to-end proof on the GPU box: an UNMODIFIED lightkurve (staged by tools/stage_reference.sh, unpacked to /tmp — outside
 # the repo) with lightkurve_amd.seams installed returns its own LightCurve / Periodogram objects from liblkhip.so:
-#   1. tests/seams_lk_worker.py compare hip   — all eleven seams through lightkurve's public API against the reference path
+#   1. tests/seams_lk_worker.py compare hip   — all thirteen seams through lightkurve's public API against the reference path
 #   2. tests/seams_lk_worker.py reftests hip  — the reference's own periodogram / corrector / flatten tests, seams active
-# The log is what profiles/r03_seams_e2e_gpu.log holds.
+# The logs are what profiles/r05_seams_e2e_gpu.log and r05_seams_latency.txt hold.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/seams_e2e; mkdir -p $O
 if [ ! -f .stage/lkref.tar.gz ]; then echo "no .stage/lkref.tar.gz: run tools/stage_reference.sh first"; exit 2; fi
