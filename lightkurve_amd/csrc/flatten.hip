@@ -518,7 +518,9 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                                                              const int64_t *__restrict__ scratch_off,
                                                              const FlatState *__restrict__ state, int FIR_LDS, double quad_a,
                                                              double quad_b, const double *__restrict__ edge_minv,
-                                                             double2 *__restrict__ rs_part) {
+                                                             double2 *__restrict__ rs_part, int dbg) {
+    // dbg (development builds, LK_FLAT_STOP=300+k; results wrong, launch time = the cost of what is left): 0 return after the
+    // state / segment reads, 1 interior tiles only, 2 edges and short segments only, 3 tiles without their output phase
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
     unsigned long long *sh = dyn_lds;
     const int sh_words = max((int)blockDim.x, 264);
@@ -535,6 +537,10 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
     const int nm = st.nm, nseg = st.nseg;
     const int half = window / 2;
     const int T = gridDim.y, y = blockIdx.y;
+    if (dbg == 0) {
+        if (nseg > 0 && segs[nseg - 1] < 0) tr[0] = 0.0;   // (keeps the reads alive)
+        return;
+    }
     int item = 0;  // running work-item number (workgroup-uniform): this workgroup takes those with item % T == y
     double rs1 = 0.0, rs2 = 0.0;
     auto put = [&](int i, double v) {
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
         const int l = segs[sg], h = (sg + 1 < nseg) ? segs[sg + 1] : nm;
         const int len = h - l;
         if (window > len || (double)len < break_tol) {
-            if ((item++ % T) != y) continue;
+            if ((item++ % T) != y || dbg == 1 || dbg == 3) continue;
             __syncthreads();
             const double med = flat_segment_median(fm + l, len, sh, fir, FIR_LDS);
             for (int i = l + tid; i < h; i += nt) put(i, med);
@@ -594,6 +600,7 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                     for (int q = 0; q < 4; ++q) xn[q] = xq[min(e0n + q, nin - 1)];
                 };
                 if (CHF <= 4 && j < ntile) fetch(j);
+                if (dbg == 2) j = ntile;
                 for (; j < ntile; j += T) {
                     const int o0 = o_lo + j * QTO;
                     const int no = min(QTO, o_hi - o0), ni = no + window - 1;
@@ -683,6 +690,7 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                         }
                     }
                     __syncthreads();
+                    if (dbg == 3) continue;
                     for (int q = tid; q < no; q += nt) {
                         const int hi = q + window - 1;
                         double w0 = p0[PX(hi)], w1 = p1[PX(hi)], w2 = p2[PX(hi)];
@@ -753,7 +761,7 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
             // staged in LDS; thread (side, r) streams row r of the operator (stored transposed, [side][tap][row]:
             // lanes read neighbouring rows) with 8 loads in flight — the plain tap loop was a chain of ~400
             // dependent L2 round trips and had become the longest part of the segment.
-            if ((item++ % T) != y) continue;  // the pair of edges of this segment: one work item
+            if ((item++ % T) != y || dbg == 1 || dbg == 3) continue;  // the pair of edges of this segment: one work item
             __syncthreads();
             for (int e = tid; e < 2 * window; e += nt)
                 fir[e] = e < window ? fm[l + e] : fm[h - window + (e - window)];
@@ -1140,13 +1148,15 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     for (int it = 0; it < niters; ++it) {
         hipLaunchKernelGGL(flat_compact_kernel, dim3(B), dim3(FLAT_NT), 0, stream, t, flux, d_off, d_s, d_soff, d_state, trend, it);
         hipLaunchKernelGGL(flat_dtseg_kernel, dim3(B), dim3(FLAT_NT), lds_pick, stream, d_off, break_tol, d_s, d_soff, d_state,
-                           fir_pick, it, near_on, stop_at >= 200 ? stop_at - 200 : -1);
+                           fir_pick, it, near_on, (stop_at >= 200 && stop_at < 300) ? stop_at - 200 : -1);
         if (quad_kernel)
             hipLaunchKernelGGL(flat_trend_kernel<true>, dim3(B, trend_T), dim3(FLAT_NT), lds_trend, stream, d_off, window, polyorder,
-                               break_tol, d_c, d_e, d_s, d_soff, d_state, fir_trend, quad_a, quad_b, d_minv, d_rs);
+                               break_tol, d_c, d_e, d_s, d_soff, d_state, fir_trend, quad_a, quad_b, d_minv, d_rs,
+                               stop_at >= 300 ? stop_at - 300 : -1);
         else
             hipLaunchKernelGGL(flat_trend_kernel<false>, dim3(B, trend_T), dim3(FLAT_NT), lds_sel, stream, d_off, window, polyorder,
-                               break_tol, d_c, d_e, d_s, d_soff, d_state, fir_lds, quad_a, quad_b, d_minv, d_rs);
+                               break_tol, d_c, d_e, d_s, d_soff, d_state, fir_lds, quad_a, quad_b, d_minv, d_rs,
+                               stop_at >= 300 ? stop_at - 300 : -1);
         hipLaunchKernelGGL(flat_clip_kernel, dim3(B), dim3(FLAT_NT), 0, stream, d_off, sigma, d_s, d_soff, d_state,
                            it == niters - 1 ? 1 : 0, d_rs, trend_T);
     }
