@@ -519,8 +519,10 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                                                              const FlatState *__restrict__ state, int FIR_LDS, double quad_a,
                                                              double quad_b, const double *__restrict__ edge_minv,
                                                              double2 *__restrict__ rs_part, int dbg) {
-    // dbg (development builds, LK_FLAT_STOP=300+k; results wrong, launch time = the cost of what is left): 0 return after the
-    // state / segment reads, 1 interior tiles only, 2 edges and short segments only, 3 tiles without their output phase
+    // dbg (development builds, LK_FLAT_STOP=300+k; results wrong, launch time = the cost of what is left — read it off the
+    // FIRST iteration's launch in a --timeline, the later ones run on the garbage this leaves): 0 return after the state /
+    // segment reads, 1 interior tiles only, 2 edges and short segments only, 3 tiles without their output phase, 4 no trend
+    // stores, 6 / 7 / 8 tiles up to the local moments / the wave scans / the barriers around the wave totals
     extern __shared__ __attribute__((aligned(16))) unsigned long long dyn_lds[];
     unsigned long long *sh = dyn_lds;
     const int sh_words = max((int)blockDim.x, 264);
@@ -633,6 +635,10 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                             s2 = fma(u * u, yv, s2);
                         }
                     }
+                    if (dbg == 6) {   // (ablation: loads + local moments only)
+                        rs1 += s0 + s1 + s2;
+                        continue;
+                    }
                     double i0 = s0, i1 = s1, i2 = s2;  // inclusive scan over the wave, then over the waves
                     for (int off = 1; off < 64; off <<= 1) {
                         const double a0 = __shfl_up(i0, off), a1 = __shfl_up(i1, off), a2 = __shfl_up(i2, off);
@@ -642,6 +648,10 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                             i2 += a2;
                         }
                     }
+                    if (dbg == 7) {   // (ablation: + the wave scans, no barrier)
+                        rs1 += i0 + i1 + i2;
+                        continue;
+                    }
                     __syncthreads();  // shd and the prefix arrays of the previous tile are free
                     if (lane == 63) {
                         shd[wv * 3 + 0] = i0;
@@ -650,6 +660,10 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                     }
                     __syncthreads();
                     double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+                    if (dbg == 8) {   // (ablation: + the two barriers around the wave totals, no carries / LDS stores)
+                        rs1 += i0;
+                        continue;
+                    }
                     for (int w2 = 0; w2 < wv && w2 < nwv; ++w2) {
                         r0 += shd[w2 * 3 + 0];
                         r1 += shd[w2 * 3 + 1];
@@ -702,7 +716,7 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                         const double v = (double)(q + half) - uc;
                         const double m2 = fma(v, fma(v, w0, -2.0 * w1), w2);  // sum (u - v)^2 y
                         const double tv = fma(quad_b, m2, quad_a * w0);
-                        tr[o0 + q] = tv;
+                        if (dbg != 4) tr[o0 + q] = tv;
                         const double r = xs[PX(q + half)] - tv;
                         rs1 += r;
                         rs2 = fma(r, r, rs2);
