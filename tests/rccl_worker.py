@@ -18,24 +18,36 @@ def _free_port():
 
 
 def main():
+    """argv: [rank world port] — default one rank.  With world > 1 every rank sees ALL GPUs (no HIP_VISIBLE_DEVICES) and
+    drives GPU `rank`: tensors, stream and lk_handle of the device-resident gather must all belong to that one device
+    (the handle used to default to device 0)."""
     import torch
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    rank, world, port = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]) if len(sys.argv) > 3 else (0, 1, str(_free_port()))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     from lightkurve_amd import batch, synth
+    from lightkurve_amd.distributed import shard_bounds
+    from lightkurve_amd.ingest import LightCurveBatch
     from lightkurve_amd.lightcurve import LightCurve
     try:
         lcs = []
-        for i, n in enumerate((900, 300, 1500)):
+        for i, n in enumerate((900, 300, 1500, 700, 1100)[: 3 if world == 1 else 5]):
             t, y, e, _ = synth.ls_target(5, i, n)
             lcs.append(LightCurve(time=t, flux=y, flux_err=e))
         f = synth.ls_frequency_grid(400, fmax=50.0)
-        full = batch.lombscargle_batch(lcs, f)                       # gathered over RCCL
-        local = batch.lombscargle_batch(lcs, f, gather=False)        # this rank's block only
-        # the whole 'fast' path is bitwise reproducible (ordered LDS accumulation): gathered (device-resident route) and
-        # local (host route) results are the same bits
-        assert full.shape == (3, 400) and np.array_equal(full, local, equal_nan=True)
+        full = batch.lombscargle_batch(lcs, f)                       # gathered over RCCL (device-resident route)
+        local = batch.lombscargle_batch(lcs, f, gather=False)        # this rank's block only (host route)
+        b = shard_bounds(len(lcs), world, [len(lc) for lc in lcs])
+        # the whole 'fast' path is bitwise reproducible (ordered LDS accumulation): gathered and local results are the same bits
+        assert full.shape == (len(lcs), 400) and np.array_equal(full[b[rank]:b[rank + 1]], local, equal_nan=True)
+        assert torch.cuda.current_device() == rank                   # the calls left the thread's device alone
+        pk = batch.lombscargle_peaks_batch(LightCurveBatch.from_lightcurves(lcs), f)
+        assert np.array_equal(pk[:, 0], np.nanmax(full, axis=1)) and np.array_equal(pk[:, 1], np.nanargmax(full, axis=1))
+        if world > 1:
+            print("RCCL_WORKER_OK rank %d" % rank)
+            return
         for b, lc in enumerate(lcs):
             single = lc.to_periodogram(frequency=f)
             assert np.max(np.abs(full[b] - np.asarray(single.power))) <= 1e-11 * np.max(full[b])

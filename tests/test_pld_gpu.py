@@ -153,7 +153,8 @@ def test_golden_sparse_design_matrix_branch(golden):
     assert isinstance(dmc, SparseDesignMatrixCollection)
     assert dmc.X.shape == g["X"].shape
     w = int(g["block_widths"][-1])
-    assert np.array_equal(dmc.X[:, -w:], g["X"][:, -w:])               # the sparse spline block, element for element
+    assert np.max(np.abs(dmc.X[:, -w:] - g["X"][:, -w:])) < 1e-12      # the sparse spline block: the de Boor kernel on the
+    #                                                                    reference's knots vs its Python recursion (4e-16)
     assert np.allclose(dmc.prior_sigma, g["prior_sigma"], rtol=1e-6)
     assert np.array_equal(pld.outlier_mask, g["outlier_mask"])
     assert np.max(np.abs(clc.flux - g["corrected"])) / np.median(g["corrected"]) < 1e-6
