@@ -121,23 +121,6 @@ int savgol_design_host(int window, int polyorder, double *coeffs, double *edge) 
 }
 
 // ------------------------------------------------------------------------------------------------ device helpers
-// order-preserving compaction of {i < n : pred(i)} into out[]; returns the count (same in every thread).
-// Every thread owns one contiguous chunk; the chunk counts are scanned with wave shuffles (two barriers in all).
-template <class Pred>
-__device__ int block_compact(int n, Pred pred, int *out, int *sh) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int chunk = (n + nt - 1) / nt;
-    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
-    int c = 0;
-    for (int i = lo; i < hi; ++i) c += pred(i) ? 1 : 0;
-    int total;
-    int w = block_exscan_int(c, sh, &total);
-    for (int i = lo; i < hi; ++i)
-        if (pred(i)) out[w++] = i;
-    __syncthreads();
-    return total;
-}
-
 // Number of k in [k_lo + lane, k_hi) step 64 with pred(k) — eight loads in flight per lane (clamped indices, pinned): one
 // load per trip made these counting loops chains of ~40 memory round trips per wave.
 template <class Pred>
@@ -156,7 +139,7 @@ __device__ __forceinline__ int strided_count64(int k_lo, int k_hi, int lane, Pre
     return c;
 }
 
-// The same compaction with coalesced accesses: every wave owns one contiguous strip of the index range and walks it 64
+// Order-preserving compaction of {i < n : pred(i)} into out[] (returns the count, the same in every thread) with coalesced accesses: every wave owns one contiguous strip of the index range and walks it 64
 // entries at a time (four groups in flight), positions from ballot prefixes; two barriers.
 template <class Pred>
 __device__ int strip_compact(int n, Pred pred, int *out, int *sh) {
@@ -219,7 +202,7 @@ struct FlatState {
 
 struct FlatSlab {
     double *tm, *fm, *tr, *xk, *yk;
-    int *idx, *idx2, *segs;
+    int *idx, *segs;
     uint8_t *mask, *mask1;
 };
 
@@ -233,8 +216,7 @@ __device__ __forceinline__ FlatSlab flat_slab(char *scratch, const int64_t *scra
     sl.xk = sl.tr + Npad;
     sl.yk = sl.xk + Npad;
     sl.idx = reinterpret_cast<int *>(sl.yk + Npad);
-    sl.idx2 = sl.idx + Npad;
-    sl.segs = sl.idx2 + Npad;
+    sl.segs = sl.idx + Npad;
     sl.mask = reinterpret_cast<uint8_t *>(sl.segs + Npad + 8);
     sl.mask1 = sl.mask + Npad;
     return sl;
@@ -1109,7 +1091,8 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         const int64_t n = n_off_host[b + 1] - n_off_host[b];
         LK_REQUIRE(n >= 1 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
         const int64_t np = (n + 7) & ~(int64_t)7;
-        soff[b + 1] = soff[b] + ((5 * np * 8 + 3 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
+        // slab: tm, fm, tr, xk, yk (8 B each) | idx, segs (4 B each, segs + 8 entries) | mask, mask1 (1 B each)
+        soff[b + 1] = soff[b] + ((5 * np * 8 + 2 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + (size_t)B * (64 + 16 * 16) + 8192);

@@ -5,7 +5,7 @@ mkdir -p $out
 for r in $(seq $reps); do
   for lib in "$@"; do
     tag=$(basename $lib .so)
-    LK_LIB_PATH=$PWD/$lib python bench.py --no-bls --no-pld --no-flatten --no-host --no-cpu-baseline --ls-method fast --steps 20 --warmup 3 > $out/$tag.$r.json 2> $out/$tag.$r.err
+    LK_LIB_PATH=$PWD/$lib python bench.py --no-bls --no-pld --no-flatten --no-host --no-cpu-baseline --ls-method fast --no-api --steps 20 --warmup 3 > $out/$tag.$r.json 2> $out/$tag.$r.err
     echo "$tag rep $r $(grep -o 'ms_per_step[^,]*' $out/$tag.$r.json | head -1)"
   done
 done
