@@ -146,3 +146,31 @@ def test_infinite_flux_sample_and_leading_nans():
     ref = O.flatten_trend(t, y2, 101, 2, 5, 3, 3)[0]
     ok = np.isfinite(ref)
     assert np.array_equal(ok, np.isfinite(got)) and np.allclose(got[ok], ref[ok], rtol=RTOL, atol=0)
+
+
+def test_segment_cuts_ride_on_the_median_pass_and_fall_back():
+    """Round 5: the segment cuts are noted as candidates during the dt median's own pass (flat_dtseg_kernel) and re-tested
+    against the exact threshold; a list of more than 384 candidates, a non-positive break tolerance or a median route without
+    a bracket falls back to the two-sweep compaction.  Every regime against the oracle: many gaps (overflow), gaps at the
+    threshold, break_tolerance 0 / negative / tiny / None, time steps with heavy ties (a regular grid)."""
+    rng = np.random.default_rng(8)
+    n = 12000
+    base = np.arange(n) * (2.0 / 1440.0)
+    cases = []
+    cases.append(("479 gaps: the candidate list overflows", np.cumsum(np.r_[0.0, np.where(np.arange(1, n) % 25 == 0, 0.05, 2.0 / 1440.0)])))
+    cases.append(("regular grid (all steps tie)", base))
+    tj = base + rng.normal(0, 1e-5, n)
+    tj.sort()
+    tg = tj.copy()
+    tg[4000:] += 5.0 * (2.0 / 1440.0) * 0.999999        # a gap just below / above 5 x the median step
+    tg[8000:] += 5.0 * (2.0 / 1440.0) * 1.000001
+    cases.append(("gaps at the threshold", tg))
+    cases.append(("three plain gaps", np.r_[tj[:3000], tj[3000:7000] + 0.7, tj[7000:] + 1.9]))
+    y0 = 1 + 0.01 * np.sin(2 * np.pi * base / 3.3) + 5e-4 * rng.standard_normal(n)
+    y0[rng.integers(0, n, 40)] += 0.02
+    for name, tt in cases:
+        lc = LightCurve(time=tt, flux=y0)
+        for bt in (5, 0.5, 0, -1.0, 1e-9, None):
+            tr = flatten_trend_batch([lc], window_length=51, polyorder=2, break_tolerance=bt, niters=3, sigma=3)[0]
+            ref, _ = O.flatten_trend(tt, y0, 51, 2, bt, 3, 3)
+            assert np.allclose(tr, ref, rtol=RTOL, atol=0, equal_nan=True), (name, bt)
