@@ -365,6 +365,18 @@ int lk_pld_design_batch_dev(lk_handle *h, int B, int N, int P, int Pb, const flo
                             int pld_order, int pca_components, int n_knots, int spline_degree, int normalize_bkg,
                             int K, double *X, double *prior_sigma, void *stream);
 
+/* ---- PLDCorrector.correct (correctors/pldcorrector.py:304-427) for B same-shaped cutouts in ONE call: the design
+ * matrices above, RegressionCorrector.correct over them (prior_mu = 0, prior_sigma from the design, y / err = the SAP
+ * light curve in float64, cadence_mask nullable) and — `spline_part`, nullable — the spline block's share of the model
+ * X[:, K-(n_knots+1):] w[K-(n_knots+1):] that restore_trend adds back (pldcorrector.py:418-420, before its median is
+ * removed).  Host pointers; X stays in device memory between the two stages.  pld_pix == bkg_pix (same pointer, P == Pb)
+ * is uploaded once.  Outputs as lk_regress_batch: w B x K, model B x N (median removed), outlier B x N bytes. */
+int lk_pld_correct_batch(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
+                         const float *lc_flux, const double *time, const double *knots, int n_inner, int pld_order,
+                         int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, const double *y,
+                         const double *err, const uint8_t *cadence_mask, double clip_sigma, int niters, double *w,
+                         double *model, uint8_t *outlier, double *spline_part);
+
 /* ---- Standalone design-matrix operations (correctors/designmatrix.py) for B same-shaped matrices ----------------
  * lk_pca_batch          <- DesignMatrix.pca(nterms), designmatrix.py:252-282 (fbpca.pca(values, nterms) -> U): the first
  *                          k = nterms left singular vectors of the column-centred matrix; A: B x N x P row-major,

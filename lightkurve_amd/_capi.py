@@ -145,6 +145,10 @@ SIGNATURES = [
     ("lk_pld_design_batch_dev", ctypes.c_int,
      [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    ("lk_pld_correct_batch", ctypes.c_int,
+     [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp, _c_fp, _c_fp, _c_dp, _c_dp, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp, _c_u8p,
+      ctypes.c_double, ctypes.c_int, _c_dp, _c_dp, _c_u8p, _c_dp]),
     ("lk_pca_batch", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp]),
     ("lk_pca_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     ("lk_spline_basis_batch", ctypes.c_int,
@@ -656,6 +660,48 @@ def pld_design_batch(pld_pix, bkg_pix, lc_flux, time, knots, pld_order, pca_comp
                                     _ptr(time), _ptr(knots), n_inner, int(pld_order), int(pca_components), n_knots,
                                     int(spline_degree), int(bool(normalize_bkg)), K, _ptr(X), _ptr(ps)))
     return X, ps
+
+
+def pld_correct_batch(pld_pix, bkg_pix, lc_flux, time, knots, y, err, pld_order, pca_components, spline_degree,
+                      normalize_bkg=True, cadence_mask=None, sigma=5.0, niters=5, want_spline=True, device=0):
+    """``PLDCorrector.correct`` numerics for B same-shaped cutouts in ONE call (design matrices, regression + clip loop, the
+    spline block's share of the model); the design matrices stay in device memory.  Inputs as ``pld_design_batch`` plus
+    y / err (B, N) float64 = the SAP light curve; pass the SAME array as ``pld_pix`` and ``bkg_pix`` when both apertures
+    are equal (uploaded once).  Returns dict(coefficients[B, K], model[B, N] (median removed), outlier_mask[B, N] bool,
+    spline[B, N] or None)."""
+    h = Handle.get(device)
+    same = pld_pix is bkg_pix
+    bkg_pix = np.ascontiguousarray(bkg_pix, dtype=np.float32)
+    B, N, Pb = bkg_pix.shape
+    P = 0
+    if pld_pix is not None and np.size(pld_pix):
+        pld_pix = bkg_pix if same else np.ascontiguousarray(pld_pix, dtype=np.float32)
+        if pld_pix.ndim != 3 or pld_pix.shape[:2] != (B, N):
+            raise ValueError("pld_pix must be (B, N, P) with the B, N of bkg_pix (got %s)" % (pld_pix.shape,))
+        P = pld_pix.shape[2]
+    else:
+        pld_pix = None
+    lc_flux = np.ascontiguousarray(lc_flux, dtype=np.float32)
+    time, knots, y = _f64(time), _f64(knots), _f64(y)
+    err = None if err is None else _f64(err)
+    if lc_flux.shape != (B, N) or time.shape != (B, N) or knots.shape[0] != B or y.shape != (B, N) or (
+            err is not None and err.shape != (B, N)):
+        raise ValueError("inconsistent PLD batch shapes")
+    cm = None if cadence_mask is None else np.ascontiguousarray(cadence_mask, dtype=np.uint8)
+    if cm is not None and cm.shape != (B, N):
+        raise ValueError("cadence_mask must be (B, N)")
+    n_inner = knots.shape[1] - 2
+    n_knots = n_inner + int(spline_degree) + 1
+    K = pld_design_width(P, Pb, pld_order, pca_components, n_knots)
+    w = np.empty((B, K), dtype=np.float64)
+    model = np.empty((B, N), dtype=np.float64)
+    outl = np.empty((B, N), dtype=np.uint8)
+    sp = np.empty((B, N), dtype=np.float64) if want_spline else None
+    _check(_lib.lk_pld_correct_batch(h._h, B, N, P, Pb, _ptr(pld_pix, _c_fp), _ptr(bkg_pix, _c_fp), _ptr(lc_flux, _c_fp),
+                                     _ptr(time), _ptr(knots), n_inner, int(pld_order), int(pca_components), n_knots,
+                                     int(spline_degree), int(bool(normalize_bkg)), K, _ptr(y), _ptr(err), _ptr(cm, _c_u8p),
+                                     float(sigma), int(niters), _ptr(w), _ptr(model), _ptr(outl, _c_u8p), _ptr(sp)))
+    return dict(coefficients=w, model=model, outlier_mask=outl.astype(bool), spline=sp)
 
 
 # --------------------------------------------------------------------------------------------- design-matrix operations

@@ -121,17 +121,34 @@ class PixelCube(object):
     def to_lightcurve(self, aperture_mask=None):
         """Simple aperture photometry, flux_method='sum' (targetpixelfile.py:868-923); numpy keeps float32 cubes
         float32 here exactly like the reference does."""
-        ap = self._parse_aperture_mask(aperture_mask)
-        with np.errstate(all="ignore"):
-            flux = np.nansum(self.flux[:, ap], axis=1)
-            flux = np.asarray(flux)
-            flux[~np.any(np.isfinite(self.flux[:, ap]), axis=1)] = np.nan
-            flux[np.all(self.flux == 0, axis=(1, 2))] = np.nan
-            flux_err = np.nansum(self.flux_err[:, ap] ** 2, axis=1) ** 0.5
+        flux, flux_err = self._aperture_sums(self._parse_aperture_mask(aperture_mask))
         lc = LightCurve(time=self.time, flux=flux, flux_err=flux_err, meta=dict(self.meta))
         lc._flux_f32 = np.asarray(flux, dtype=np.float32)   # the value the reference carries (float32 for FITS cubes)
         return lc
 
+
+    def _aperture_sums(self, ap):
+        """(flux, flux_err) of the aperture `ap` (boolean image) per cadence, in the cube's dtype.  The gather `cube[:, ap]`
+        is kept even for a full aperture: numpy lays its result out pixel-major, so the float32 sums below add the pixels
+        of a cadence one after the other — reshaping the cube instead would sum pairwise and round differently (1e-7)."""
+        n = len(self.time)
+        with np.errstate(all="ignore"):
+            pix = self.flux[:, ap]
+            perr = self.flux_err[:, ap]
+            flux = np.asarray(np.sum(pix, axis=1))
+            flux_err = np.sum(perr ** 2, axis=1)
+            if pix.shape[1] and np.all(np.isfinite(flux)) and np.all(np.isfinite(flux_err)):
+                # every aperture pixel is finite (a NaN / inf would have reached its row's sum): nansum == sum, no cadence
+                # is empty, and only a row that sums to zero can be all zeros
+                for r in np.flatnonzero(flux == 0):
+                    if np.all(self.flux[r] == 0):
+                        flux[r] = np.nan
+                return flux, flux_err ** 0.5
+            flux = np.asarray(np.nansum(pix, axis=1))
+            flux[~np.any(np.isfinite(pix), axis=1)] = np.nan
+            flux[np.all(self.flux.reshape(n, -1) == 0, axis=1)] = np.nan
+            flux_err = np.nansum(perr ** 2, axis=1) ** 0.5
+        return flux, flux_err
 
     def pixel_periodograms(self, frequency=None, corrector="remove_outliers", sigma=5.0, normalization="amplitude",
                            ls_method="fast", device=0, **kwargs):
@@ -296,37 +313,92 @@ class PLDCorrector(RegressionCorrector):
         return clc
 
 
+def _all_finite(a):
+    """np.all(np.isfinite(a)) without the boolean temporary in the common case: a finite float64 total implies it."""
+    with np.errstate(all="ignore"):
+        return bool(np.isfinite(a.sum(dtype=np.float64))) or bool(np.all(np.isfinite(a)))
+
+
+def _batch_cutout(c, ap, pm, bm):
+    """One cutout's share of pld_correct_batch: what ``PLDCorrector(c, aperture_mask)`` keeps (the SAP light curve without its
+    NaN cadences, pldcorrector.py:109-120) and the pixel series of the two apertures, without the object construction.
+    Returns (time, flux float64, flux_err float64, flux float32, pld pixels (n, P), background pixels (n, Pb))."""
+    flux, ferr = c._aperture_sums(ap)
+    keep = ~(np.isnan(flux) | np.isnan(ferr))
+    everything = bool(keep.all())
+    n_all = len(c.time)
+
+    def pixels(mask):
+        px = c.flux.reshape(n_all, -1) if bool(np.all(mask)) else c.flux[:, mask]
+        return px if everything else px[keep]
+
+    pld = pixels(pm)
+    bkg = pld if (pm.shape == bm.shape and np.array_equal(pm, bm)) else pixels(bm)
+    if not everything:
+        flux, ferr = flux[keep], ferr[keep]
+    return (c.time if everything else c.time[keep], np.asarray(flux, dtype=np.float64), np.asarray(ferr, dtype=np.float64),
+            np.asarray(flux, dtype=np.float32), pld, bkg)
+
+
 def pld_correct_batch(cubes, aperture_mask="all", pld_aperture_mask="all", background_aperture_mask="all",
                       pld_order=3, pca_components=16, spline_n_knots=None, spline_degree=5,
                       normalize_background_pixels=True, restore_trend=True, sigma=5, niters=5, device=0):
-    """PLDCorrector(...).correct(...) for a list of same-shaped cutouts in two GPU calls (design + regression).
-    Masks are given once and shared by the batch.  Returns (corrected_flux[B, N], outlier_mask[B, N])."""
-    cors = [PLDCorrector(c, aperture_mask=aperture_mask) for c in cubes]
-    n = len(cors[0].lc)
-    if any(len(c.lc) != n for c in cors):
+    """PLDCorrector(...).correct(...) for a list of same-shaped cutouts in ONE GPU call (``lk_pld_correct_batch``: design
+    matrices, regression and the spline block's share of the model; the design matrices never leave the device).  Masks are
+    given once and shared by the batch ("threshold" / "background" are evaluated on the first cutout).  The per-cutout host
+    work (aperture sums, NaN-cadence removal, pixel gathers, percentile knots) runs on the packing thread pool and lands in
+    page-locked staging buffers.  Returns (corrected_flux[B, N], outlier_mask[B, N])."""
+    from .. import packed
+    cubes = list(cubes)
+    if not cubes:
+        raise ValueError("pld_correct_batch needs at least one cutout")
+    if pca_components is None or pca_components < 1:
+        raise NotImplementedError("pca_components must be >= 1 on the HIP path")
+    first = cubes[0]
+    ap = first._parse_aperture_mask(first.create_threshold_mask(3) if aperture_mask is None else aperture_mask)
+    pm = first._parse_aperture_mask(pld_aperture_mask)
+    bm = first._parse_aperture_mask(background_aperture_mask)
+    for c in cubes:
+        if c.shape[1:] != first.shape[1:]:
+            raise ValueError("pld_correct_batch needs cutouts of one shape (got %s and %s)" % (c.shape, first.shape))
+    parts = packed._pmap(_batch_cutout, [(c, ap, pm, bm) for c in cubes])
+    n = len(parts[0][0])
+    if any(len(p[0]) != n for p in parts):
         raise ValueError("pld_correct_batch needs cutouts with the same number of valid cadences")
-    pm = cors[0].tpf._parse_aperture_mask(pld_aperture_mask)
-    bm = cors[0].tpf._parse_aperture_mask(background_aperture_mask)
+    B, P, Pb = len(parts), parts[0][4].shape[1], parts[0][5].shape[1]
+    shared = parts[0][5] is parts[0][4]
     if spline_n_knots is None:
         spline_n_knots = int(n / 50)
-    pld = np.stack([c.tpf.flux[:, pm].reshape(n, -1) for c in cors]).astype(np.float32)
-    bkg = np.stack([c.tpf.flux[:, bm].reshape(n, -1) for c in cors]).astype(np.float32)
-    if not (np.all(np.isfinite(pld)) and np.all(np.isfinite(bkg))):
+
+    def staged(key, shape, dtype):
+        count = int(np.prod(shape))
+        try:
+            return _capi.pinned_pool("pld_" + key, count, dtype).reshape(shape)
+        except (OSError, RuntimeError, MemoryError):
+            return np.empty(shape, dtype=dtype)
+
+    pld = staged("pix", (B, n, P), np.float32)
+    bkg = pld if shared else staged("bkg", (B, n, Pb), np.float32)
+    lcf = staged("lcf", (B, n), np.float32)
+    t, y, err = (staged(k, (B, n), np.float64) for k in ("t", "y", "err"))
+    knots = np.empty((B, max(spline_n_knots - spline_degree - 1, 0) + 2), dtype=np.float64)
+
+    def fill(b):
+        tb, fb, eb, f32, px, bx = parts[b]
+        t[b], y[b], err[b], lcf[b] = tb, fb, eb, f32
+        pld[b] = px
+        if not shared:
+            bkg[b] = bx
+        knots[b] = _percentile_knots(tb, spline_n_knots, spline_degree)
+        return _all_finite(px) and (shared or _all_finite(bx))
+
+    if not all(packed._pmap(fill, [(b,) for b in range(B)])):
         raise ValueError("pld_correct_batch needs finite pixels inside the masks")
-    lcf = np.stack([c.lc._flux_f32 for c in cors])
-    t = np.stack([c.lc.time for c in cors])
-    knots = np.stack([_percentile_knots(c.lc.time, spline_n_knots, spline_degree) for c in cors])
-    X, ps = _capi.pld_design_batch(pld if pld.shape[2] else None, bkg, lcf, t, knots, pld_order, pca_components,
-                                   spline_degree, normalize_background_pixels, device=device)
-    B, _, K = X.shape
-    y = np.concatenate([c.lc.flux for c in cors])
-    err = np.concatenate([c.lc.flux_err for c in cors])
-    off = np.arange(B + 1, dtype=np.int64) * n
-    res = _capi.regress_batch(X.reshape(B * n, K), y, off, err=err, prior_mu=np.zeros((B, K)), prior_sigma=ps,
-                              sigma=sigma, niters=niters, device=device)
-    corrected = (y - res["model"]).reshape(B, n)
+    res = _capi.pld_correct_batch(pld if P else None, bkg, lcf, t, knots, y, err, pld_order, pca_components, spline_degree,
+                                  normalize_background_pixels, sigma=sigma, niters=niters, want_spline=restore_trend,
+                                  device=device)
+    corrected = y - res["model"]
     if restore_trend:
-        nsp = spline_n_knots + 1
-        sp = np.einsum("bnk,bk->bn", X[:, :, K - nsp:], res["coefficients"][:, K - nsp:])
-        corrected = corrected + sp - np.median(sp, axis=1)[:, None]
-    return corrected, res["outlier_mask"].reshape(B, n)
+        sp = res["spline"]
+        corrected += sp - np.median(sp, axis=1)[:, None]
+    return corrected, res["outlier_mask"]

@@ -614,6 +614,63 @@ int lk_pld_design_batch(lk_handle *h, int B, int N, int P, int Pb, const float *
     return LK_OK;
 }
 
+// PLDCorrector.correct for B same-shaped cutouts, host pointers in and out: design matrices, regression + clip loop and the
+// spline block's share of the model in one call — X (B x N x K doubles, 1.7 GB per 500 K2 cutouts) never leaves HBM.
+int lk_pld_correct_batch(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
+                         const float *lc_flux, const double *time, const double *knots, int n_inner, int pld_order,
+                         int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, const double *y,
+                         const double *err, const uint8_t *cadence_mask, double clip_sigma, int niters, double *w,
+                         double *model, uint8_t *outlier, double *spline_part) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(B >= 1 && N >= 2 && P >= 0 && Pb >= 1 && K >= 1, "bad shapes");
+    LK_REQUIRE(bkg_pix && lc_flux && time && knots && y && w && model && outlier, "NULL buffer");
+    LK_REQUIRE(n_knots + 1 <= K, "K=%d is narrower than the spline block (%d columns)", K, n_knots + 1);
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    const size_t bn = (size_t)B * N;
+    const bool has_pld = P > 0 && pld_pix != nullptr;
+    const bool shared = has_pld && pld_pix == bkg_pix && P == Pb;  // one aperture for both blocks: one upload
+    const size_t pb = bn * P * 4, bb = bn * Pb * 4, lb = bn * 4, nb = bn * 8, kb = (size_t)B * (n_inner + 2) * 8;
+    const size_t xb = bn * K * 8, sb = (size_t)B * K * 8;
+    h->staging.reset();
+    int rc = h->staging.reserve(pb + bb + lb + kb + xb + 3 * (sb + 256) + 5 * (nb + 256) + 2 * (bn + 256) + 8 * 256 + 4096);
+    if (rc) return rc;
+    float *dp = (has_pld && !shared) ? (float *)h->staging.alloc(pb) : nullptr;
+    float *db = (float *)h->staging.alloc(bb), *dl = (float *)h->staging.alloc(lb);
+    double *dt = (double *)h->staging.alloc(nb), *dk = (double *)h->staging.alloc(kb);
+    double *dX = (double *)h->staging.alloc(xb), *ds = (double *)h->staging.alloc(sb), *dmu = (double *)h->staging.alloc(sb);
+    double *dw = (double *)h->staging.alloc(sb), *dy = (double *)h->staging.alloc(nb);
+    double *derr = err ? (double *)h->staging.alloc(nb) : nullptr;
+    double *dmodel = (double *)h->staging.alloc(nb), *dsp = spline_part ? (double *)h->staging.alloc(nb) : nullptr;
+    uint8_t *dcm = cadence_mask ? (uint8_t *)h->staging.alloc(bn) : nullptr, *dout = (uint8_t *)h->staging.alloc(bn);
+    LK_REQUIRE(dout != nullptr, "staging arena exhausted");
+    if (dp) LK_HIP_CHECK(hipMemcpy(dp, pld_pix, pb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(db, bkg_pix, bb, hipMemcpyHostToDevice));
+    if (shared) dp = db;
+    LK_HIP_CHECK(hipMemcpy(dl, lc_flux, lb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dt, time, nb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dk, knots, kb, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemcpy(dy, y, nb, hipMemcpyHostToDevice));
+    if (err) LK_HIP_CHECK(hipMemcpy(derr, err, nb, hipMemcpyHostToDevice));
+    if (cadence_mask) LK_HIP_CHECK(hipMemcpy(dcm, cadence_mask, bn, hipMemcpyHostToDevice));
+    LK_HIP_CHECK(hipMemsetAsync(dmu, 0, sb, nullptr));   // prior_mu = 0 for every PLD column (pldcorrector.py:240-287)
+    rc = lk::pld_design_launch(h, B, N, dp ? P : 0, Pb, dp, db, dl, dt, dk, n_inner, pld_order, pca_components, n_knots,
+                               spline_degree, normalize_bkg, K, dX, ds, nullptr);
+    if (rc) return rc;
+    std::vector<int64_t> off((size_t)B + 1);
+    for (int b = 0; b <= B; ++b) off[b] = (int64_t)b * N;
+    rc = lk::regress_launch(h, B, off.data(), K, dX, dy, derr, dcm, dmu, ds, clip_sigma, niters, dw, dmodel, dout, nullptr);
+    if (rc) return rc;
+    if (dsp) {
+        rc = lk::model_part_launch(h, B, N, K, K - (n_knots + 1), K, dX, dw, dsp, nullptr);
+        if (rc) return rc;
+    }
+    LK_HIP_CHECK(hipMemcpy(w, dw, sb, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(model, dmodel, nb, hipMemcpyDeviceToHost));
+    LK_HIP_CHECK(hipMemcpy(outlier, dout, bn, hipMemcpyDeviceToHost));
+    if (dsp) LK_HIP_CHECK(hipMemcpy(spline_part, dsp, nb, hipMemcpyDeviceToHost));
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ design-matrix operations
 int lk_pca_batch_dev(lk_handle *h, int B, int N, int P, int k, const double *A, double *U, void *stream) {
     LK_REQUIRE(h != nullptr, "handle is NULL");

@@ -121,6 +121,8 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
                    const double *err, const uint8_t *cmask, const double *prior_mu, const double *prior_sigma,
                    double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream,
                    double *w_cov = nullptr);
+int model_part_launch(lk_handle *h, int B, int N, int K, int c0, int c1, const double *X, const double *w, double *out,
+                      hipStream_t stream);
 int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *flux,
                    const uint8_t *user_mask, int window, int polyorder, double break_tol, int niters, double sigma,
                    double *trend, uint8_t *final_mask, hipStream_t stream);

@@ -1081,6 +1081,34 @@ int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const 
     return LK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ a sub-matrix's share of the model
+// out[b][n] = sum_{c0 <= k < c1} X[b][n][k] w[b][k] for B same-shaped matrices: the `diagnostic_lightcurves[name]` of one
+// sub-matrix of the collection (reference regressioncorrector.py:281-307, before its median is taken off) — PLDCorrector's
+// restore_trend needs the spline block's (pldcorrector.py:418-420).  One wavefront per cadence row, lanes over the columns.
+__global__ __launch_bounds__(256) void model_part_kernel(const double *__restrict__ X, const double *__restrict__ w, int N, int K,
+                                                          int c0, int c1, double *__restrict__ out) {
+    const int target = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *wt = w + (size_t)target * K;
+    for (int r = blockIdx.x * 4 + wave; r < N; r += gridDim.x * 4) {
+        const double *row = X + ((size_t)target * N + r) * K;
+        double acc = 0.0;
+        for (int k = c0 + lane; k < c1; k += 64) acc = fma(row[k], wt[k], acc);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) out[(size_t)target * N + r] = acc;
+    }
+}
+
+int model_part_launch(lk_handle *h, int B, int N, int K, int c0, int c1, const double *X, const double *w, double *out,
+                      hipStream_t stream) {
+    (void)h;
+    LK_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && K >= 1, "bad shapes");
+    LK_REQUIRE(0 <= c0 && c0 <= c1 && c1 <= K, "column range [%d, %d) outside 0..%d", c0, c1, K);
+    LK_REQUIRE(X && w && out, "NULL buffer");
+    hipLaunchKernelGGL(model_part_kernel, dim3(64, B), dim3(256), 0, stream, X, w, N, K, c0, c1, out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ DesignMatrix.standardize
 // correctors/designmatrix.py:215-250: per column, zeros count as missing; subtract the nanmedian and divide by the nanstd of
 // the remaining values, missing values come back as 0; a column whose values are all equal (nanstd == 0) is left unchanged.

@@ -248,3 +248,37 @@ def test_designmatrix_validate_mirrors_the_reference():
     assert sp.shape == (6, 6) and sp.columns == ["a 1", "b 1", "a 2", "b 2", "a 3", "b 3"]
     assert np.array_equal(sp.values[:2, :2], [[0, 1], [2, 3]]) and np.all(sp.values[:2, 2:] == 0)
     assert np.array_equal(sp.prior_mu, [1, 2] * 3) and np.array_equal(sp.prior_sigma, [3, 4] * 3)
+
+
+def test_aperture_sums_fast_path_is_the_reference_formula():
+    """PixelCube._aperture_sums (shared by PLDCorrector and pld_correct_batch) against the formula of
+    TargetPixelFile.extract_aperture_photometry (reference targetpixelfile.py:868-923) written out plainly — float32 sums in
+    numpy's order for the gathered pixels, all-NaN and all-zero cadences -> NaN — with and without non-finite pixels."""
+    from lightkurve_amd import synth
+    from lightkurve_amd.correctors.pldcorrector import PixelCube
+    t, flux, err, _ = synth.pld_cutout(4, 3, n=300, npix=9)
+
+    def plain(c, ap):
+        with np.errstate(all="ignore"):
+            f = np.asarray(np.nansum(c.flux[:, ap], axis=1))
+            f[~np.any(np.isfinite(c.flux[:, ap]), axis=1)] = np.nan
+            f[np.all(c.flux == 0, axis=(1, 2))] = np.nan
+            e = np.nansum(c.flux_err[:, ap] ** 2, axis=1) ** 0.5
+        return f, e
+
+    for case in range(4):
+        fl, er = flux.copy(), err.copy()
+        if case == 1:
+            fl[10] = 0.0
+        if case == 2:
+            fl[20] = np.nan
+            fl[30, 2, 3] = np.nan
+        if case == 3:
+            fl[5] = 0.0
+            er[7, 1, 1] = np.nan
+            fl[9, 0, 0] = np.inf
+        c = PixelCube(t, fl, er)
+        for ap in (np.ones((9, 9), bool), np.pad(np.ones((5, 5), bool), 2)):
+            got, want = c._aperture_sums(ap), plain(c, ap)
+            assert got[0].dtype == np.float32
+            assert np.array_equal(got[0], want[0], equal_nan=True) and np.array_equal(got[1], want[1], equal_nan=True), case

@@ -204,3 +204,76 @@ def test_target_pixel_file_to_cube_vs_reference_classes(golden, fname, tag, kw):
     assert np.array_equal(cube.flux_bkg, g[tag + "_flux_bkg"], equal_nan=True)
     assert np.array_equal(cube.pipeline_mask, g[tag + "_pipeline_mask"])
     assert cube.meta["MISSION"] in ("K2", "TESS") and cube.meta["TARGETID"] == 4242
+
+
+def test_one_call_correct_equals_design_then_regress():
+    """lk_pld_correct_batch (design matrices kept in device memory) against the two host-pointer calls it fuses,
+    lk_pld_design_batch + lk_regress_batch: same kernels on the same inputs, so coefficients, model and outlier mask are the
+    same bits; the spline block's share of the model against numpy on the downloaded design matrix."""
+    from lightkurve_amd import _capi, synth
+    from lightkurve_amd.correctors.pldcorrector import _percentile_knots
+    B, n, npix = 3, 900, 7
+    pix = np.empty((B, n, npix * npix), np.float32)
+    t = np.empty((B, n))
+    y, err = np.empty((B, n)), np.empty((B, n))
+    for b in range(B):
+        tb, flux, ferr, _ = synth.pld_cutout(4, 40 + b, n=n, npix=npix)
+        pix[b], t[b] = flux.reshape(n, -1), tb
+        y[b], err[b] = flux.reshape(n, -1).sum(axis=1), np.sqrt((ferr.reshape(n, -1).astype(np.float64) ** 2).sum(axis=1))
+    lcf = y.astype(np.float32)
+    knots = np.stack([_percentile_knots(t[b], n // 50, 5) for b in range(B)])
+    cm = np.ones((B, n), bool)
+    cm[1, 100:140] = False
+    for cmask in (None, cm):
+        X, ps = _capi.pld_design_batch(pix, pix, lcf, t, knots, 2, 8, 5, True)
+        K = X.shape[2]
+        two = _capi.regress_batch(X.reshape(B * n, K), y.ravel(), np.arange(B + 1) * n, err=err.ravel(),
+                                  cadence_mask=None if cmask is None else cmask.ravel(), prior_mu=np.zeros((B, K)),
+                                  prior_sigma=ps, sigma=5, niters=5)
+        one = _capi.pld_correct_batch(pix, pix, lcf, t, knots, y, err, 2, 8, 5, True, cadence_mask=cmask, sigma=5, niters=5)
+        assert np.array_equal(one["coefficients"], two["coefficients"])
+        assert np.array_equal(one["model"].ravel(), two["model"])
+        assert np.array_equal(one["outlier_mask"].ravel(), two["outlier_mask"])
+        nsp = n // 50 + 1
+        sp = np.einsum("bnk,bk->bn", X[:, :, K - nsp:], two["coefficients"][:, K - nsp:])
+        assert np.max(np.abs(one["spline"] - sp)) <= 1e-12 * np.max(np.abs(sp))
+    # separate (copied) pixel arrays for the two blocks take the two-upload route: same result
+    sep = _capi.pld_correct_batch(pix, pix.copy(), lcf, t, knots, y, err, 2, 8, 5, True, cadence_mask=cm, sigma=5, niters=5)
+    assert np.array_equal(sep["model"], one["model"]) and np.array_equal(sep["coefficients"], one["coefficients"])
+    no_sp = _capi.pld_correct_batch(pix, pix, lcf, t, knots, y, err, 2, 8, 5, True, cadence_mask=cm, want_spline=False)
+    assert no_sp["spline"] is None and np.array_equal(no_sp["model"], one["model"])
+
+
+def test_batch_front_end_matches_the_per_object_corrector():
+    """pld_correct_batch's own host work (aperture sums, NaN-cadence removal, pixel gathers on the thread pool) against
+    PLDCorrector(c).correct(...) per cutout — with a partial aperture, distinct PLD / background masks, cadences whose flux
+    is all NaN or all zero (dropped by the corrector, pldcorrector.py:109-120) and restore_trend on and off."""
+    from lightkurve_amd import synth
+    rng = np.random.default_rng(8)
+    ap = np.zeros((9, 9), bool)
+    ap[2:7, 2:7] = True
+    pm = np.zeros((9, 9), bool)
+    pm[1:8, 1:8] = True
+    bm = ~ap
+    cubes = []
+    for i in range(3):
+        t, flux, err, _ = synth.pld_cutout(4, 50 + i, n=800, npix=9)
+        flux, err = flux.copy(), err.copy()
+        bad = rng.choice(800, 7, replace=False)       # the same COUNT of dropped cadences per cutout, at different places
+        flux[bad[:4]] = np.nan
+        flux[bad[4:]] = 0.0
+        cubes.append(PixelCube(t, flux, err, mission="K2"))
+    for restore in (True, False):
+        corrected, outl = pld_correct_batch(cubes, aperture_mask=ap, pld_aperture_mask=pm, background_aperture_mask=bm,
+                                            pld_order=2, pca_components=8, restore_trend=restore)
+        assert corrected.shape == (3, 793)
+        for i, c in enumerate(cubes):
+            pld = PLDCorrector(c, aperture_mask=ap)
+            clc = pld.correct(pld_order=2, pca_components=8, pld_aperture_mask=pm, background_aperture_mask=bm,
+                              normalize_background_pixels=True, restore_trend=restore)
+            assert len(clc.flux) == 793
+            assert np.array_equal(outl[i], pld.outlier_mask), i
+            assert np.max(np.abs(corrected[i] - clc.flux)) <= 1e-9 * np.median(clc.flux), i
+    with pytest.raises(ValueError):
+        pld_correct_batch(cubes + [PixelCube(cubes[0].time[:-1], cubes[0].flux[:-1], cubes[0].flux_err[:-1])], pld_order=2,
+                          pca_components=8)
