@@ -820,9 +820,9 @@ def main():
               "executed_gram_flop_per_step": flop, "plain_gram_flop_per_step": flop_plain,
               "dominant_kernel": {"kernel": "pld_topk_eig_kernel<2> (subspace iteration on the 816-column block's 5.3-MB Gram "
                                             "matrices; the 121- and 136-column blocks take the direct tridiagonal solver)",
-                                  "bound": "hbm", "ms_per_step": 11.0, "hbm_bytes_per_step": 2.74e10,
-                                  "achieved_GBps": 2.74e10 / 11.0e-3 / 1e9, "frac": 2.74e10 / 11.0e-3 / 1e9 / HBM_PEAK_GBS,
-                                  "source": "profiles/r04_pld_kernel_stats.txt (11.03 ms per launch), r04_pld_pmc_fetch.txt / "
+                                  "bound": "hbm", "ms_per_step": 7.7, "hbm_bytes_per_step": 1.91e10,
+                                  "achieved_GBps": 1.91e10 / 7.7e-3 / 1e9, "frac": 1.91e10 / 7.7e-3 / 1e9 / HBM_PEAK_GBS,
+                                  "source": "profiles/r05_pld_kernel_stats.txt (7.7-7.9 ms per launch), r05_pld_pmc_fetch.txt / "
                                             "_write.txt (FETCH_SIZE + WRITE_SIZE of this kernel, 4 steps); constants of the "
                                             "committed passes, not re-measured in this run"},
               "frac_plain_gram_equivalent": flop_plain / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,

@@ -18,6 +18,8 @@
  *   lk_ls_chi2_batch* / lk_ls_fastchi2_batch* <- astropy lombscargle_chi2 / lombscargle_fastchi2 (nterms > 1,
  *                           periodogram.py:948-967).
  *   lk_pld_design_batch* <- PLDCorrector.create_design_matrix, src/lightkurve/correctors/pldcorrector.py:125-287.
+ *   lk_pld_correct_batch <- PLDCorrector.correct (pldcorrector.py:304-427) for a batch of cutouts: the two above fused, the
+ *                           design matrices staying in device memory.
  *   lk_fold_batch*       <- LightCurve.fold, src/lightkurve/lightcurve.py:1089-1214 (astropy TimeSeries.fold + sort).
  *   lk_pg_logmedian_batch* / lk_pg_boxsmooth_batch* <- Periodogram.smooth, periodogram.py:182-284.
  *
