@@ -403,8 +403,9 @@ __global__ __launch_bounds__(FLAT_NT, 8) void flat_dtseg_kernel(const int64_t *_
     double dmed = qnan, dspacing = st.dspacing;
     bool have_cuts = false;  // cut_i[0..cut_n) holds every step that can exceed the threshold (workgroup-uniform)
     if (nm >= 2) {
+        const bool t_nan = st.t_nan != 0;
         auto dval = [&](int i) { return tm[i + 1] - tm[i]; };
-        auto dkeep = [&](int i) { return !isnan(tm[i + 1] - tm[i]); };
+        auto dkeep = [&](int i) { return !t_nan || !isnan(tm[i + 1] - tm[i]); };  // (no NaN time: nothing to re-read)
         // step i (between kept cadences i and i + 1) cuts in front of cadence i + 1 if it exceeds break_tol * median; with
         // break_tol >= 0 and a bound lo <= median, break_tol * lo <= break_tol * median (rounding is monotone)
         const bool bound_ok = break_tol >= 0.0;
