@@ -833,7 +833,23 @@ def main():
                       "projections, LU, clipping included) against the fp64 MFMA dense peak.  frac_plain_gram_equivalent: "
                       "the same time priced with the flop of plain upper-triangle Grams (round 2's count), for comparison "
                       "across rounds only" % (tiles2, tiles3)}
-        return {"dt": dt, "kernel_ms": kms, "units_per_step": Bc, "steps": steps, "warmup": warmup,
+        api = None
+        if rank == 0 and first_index == 0 and not dist_on and not args.no_api:
+            # the product's list-of-objects entry point (what replaces a loop over PLDCorrector(tpf).correct()): host pointers,
+            # per-cutout aperture sums / NaN-cadence removal on the packing threads, ONE lk_pld_correct_batch call
+            na = min(Bc, 100)
+            ca = [PixelCube(cubes[i][0], cubes[i][1], cubes[i][2], mission="K2") for i in range(na)]
+            pld_correct_batch(ca, pld_order=3, pca_components=16)
+            ws = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pld_correct_batch(ca, pld_order=3, pca_components=16)
+                ws.append(time.perf_counter() - t0)
+            w = float(np.median(ws))
+            api = {"call": "pld_correct_batch(list of %d PixelCube, pld_order=3, pca_components=16)" % na, "wall_ms": 1e3 * w,
+                   "ms_per_cutout": 1e3 * w / na, "kernel_ms_per_cutout": kms / Bc, "value": na / w,
+                   "note": "wall clock of one Python call, median of 3 after one warm-up, host arrays in and out (PCIe included)"}
+        return {"dt": dt, "kernel_ms": kms, "units_per_step": Bc, "steps": steps, "warmup": warmup, "api_end_to_end": api,
                 "metric": "PLD cutouts/sec (design matrix + regression)", "unit": "cutouts/sec",
                 "workload": "configs[4]: %d K2-like 11x11-pixel cutouts x %d cadences, 3rd-order design matrix (K=%d), "
                             "MFMA Gram per GPU" % (Bc, Nc, K), "roofline": rl, "accuracy": acc, "Nc": Nc}
@@ -888,6 +904,8 @@ def main():
                "roofline": res["roofline"]}
         if res.get("accuracy"):
             blk["accuracy"] = res["accuracy"]
+        if res.get("api_end_to_end"):
+            blk["api_end_to_end"] = res["api_end_to_end"]
         if base is not None:
             blk["cpu_baseline"] = {k: v for k, v in base.items() if not k.startswith("_")}
             blk["speedup_vs_cpu_baseline"] = val / base["value"]
@@ -1236,6 +1254,8 @@ def main():
         metric, unit, workload, roofline = pres["metric"], pres["unit"], pres["workload"], pres["roofline"]
         if pres["accuracy"]:
             extra["accuracy"] = pres["accuracy"]
+        if pres.get("api_end_to_end"):
+            extra["api_end_to_end"] = pres["api_end_to_end"]
         B, N = args.cutouts, pres["Nc"]
     elif args.workload == "flatten":
         fres = run_flatten(B, first, args.steps, args.warmup, cpu_base)
