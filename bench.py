@@ -891,7 +891,27 @@ def main():
               "traffic": traffic_all.get("flatten"), "kernel": "the phase-split pipeline of flatten.hip: flat_init + niters x (flat_compact, flat_dtseg, flat_trend, "
                                                               "flat_clip) + flat_interp, whole step", "kernel_ms_per_step": kms,
               "note": "algorithmic 24 B per cadence (time, flux in; trend out)"}
-        return {"dt": dt, "kernel_ms": kms, "units_per_step": int(off[-1]), "steps": steps, "warmup": warmup,
+        api = None
+        if rank == 0 and first_index == 0 and not dist_on and not args.no_api:
+            # the list-of-objects entry point (what replaces a loop over lc.flatten(), lightcurve.py:943-1078): packing into
+            # page-locked staging, sortedness check, lk_savgol_trend_batch over PCIe, per-target result views
+            from lightkurve_amd import batch as LB
+            from lightkurve_amd.lightcurve import LightCurve
+            lcs = [LightCurve(time=t[off[i]:off[i + 1]], flux=y[off[i]:off[i + 1]], flux_err=dy[off[i]:off[i + 1]]) for i in range(Bf)]
+            got = LB.flatten_batch(lcs, window_length=args.flatten_window)
+            same = bool(np.array_equal(np.concatenate(got), d_tr.cpu().numpy(), equal_nan=True))
+            ws = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                LB.flatten_batch(lcs, window_length=args.flatten_window)
+                ws.append(time.perf_counter() - t0)
+            w = float(np.median(ws))
+            api = {"call": "flatten_batch(list of %d LightCurve, window_length=%d)" % (Bf, args.flatten_window), "wall_ms": 1e3 * w,
+                   "ms_per_target": 1e3 * w / Bf, "kernel_ms_per_target": kms / Bf, "value": float(off[-1]) / w,
+                   "trends_match_device_path": same,
+                   "note": "wall clock of one Python call, median of 3 after one warm-up, host arrays in and out (24 B per cadence "
+                           "over PCIe around the kernels)"}
+        return {"dt": dt, "kernel_ms": kms, "units_per_step": int(off[-1]), "steps": steps, "warmup": warmup, "api_end_to_end": api,
                 "metric": "flatten cadences/sec (window %d, niters 3)" % args.flatten_window, "unit": "cadences/sec",
                 "workload": "flatten: %d light curves x %d cadences, window %d, polyorder 2, niters 3 per GPU" % (Bf, N, args.flatten_window),
                 "roofline": rl, "accuracy": acc}
@@ -949,15 +969,17 @@ def main():
                        "kernel time of the device-pointer step above (so it includes PCIe).  list_*: a list of B LightCurve "
                        "objects (packed into the pinned staging pool inside the call); batch_*: a LightCurveBatch whose "
                        "arrays are page-locked (LightCurveBatch.from_lightcurves(lcs, pinned=True), built once: "
-                       "`pack_once`).  *_spectra_pinned_out: out= a reused page-locked (B, M) array; *_spectra: a fresh "
-                       "pageable numpy result"}
+                       "`pack_once`).  *_spectra_pinned_out: out= a reused page-locked (B, M) array; *_spectra: no out= — "
+                       "the result comes from _capi.result_empty's recycled page-locked buffers (reused once the caller has "
+                       "dropped the previous result; LK_RESULT_POOL=0 gives a fresh pageable array per call: + ~50 ms of "
+                       "first-touch page faults per 800 MB)"}
         sec, pk = wall(lambda: LB.lombscargle_peaks_batch(lcs, freq))
         res["list_to_peaks"] = entry(sec, {"peaks_match_device_path": bool(np.array_equal(pk[:, 0], dev_peaks[0]) and
                                                                            np.array_equal(pk[:, 1].astype(np.int64), dev_peaks[1]))})
         h_pow = _capi.pinned_empty((Bq, M))
         sec, pw = wall(lambda: LB.lombscargle_batch(lcs, freq, out=h_pow))
         res["list_to_spectra_pinned_out"] = entry(sec, {"spectra_match_device_path": bool(np.array_equal(pw, d_pow.cpu().numpy(), equal_nan=True))})
-        sec, pw = wall(lambda: LB.lombscargle_batch(lcs, freq), reps=2)
+        sec, pw = wall(lambda: LB.lombscargle_batch(lcs, freq))
         res["list_to_spectra"] = entry(sec)
         del pw
         t0 = time.perf_counter()
@@ -1264,6 +1286,8 @@ def main():
         metric, unit, workload, roofline = fres["metric"], fres["unit"], fres["workload"], fres["roofline"]
         if fres["accuracy"]:
             extra["accuracy"] = fres["accuracy"]
+        if fres.get("api_end_to_end"):
+            extra["api_end_to_end"] = fres["api_end_to_end"]
     elif args.workload == "regress":
         Bc, Nc, K = args.cutouts, args.pld_cadences, args.regressors
         g = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -308,7 +308,7 @@ def ls_power_batch(t, y, n_off, dy=None, frequency=None, f0=0.0, df=0.0, M=None,
         M = frequency.size
     M = int(M)
     scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
-    power = np.empty((B, M), dtype=np.float64)
+    power = result_empty((B, M))
     _check(_lib.lk_ls_chi2_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), _ptr(frequency),
                                  float(f0), float(df), M, int(nterms), int(bool(fit_mean)), int(bool(center_data)),
                                  NORM[normalization], _ptr(scale), _ptr(power)))
@@ -339,7 +339,7 @@ def ls_fast_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, cent
     dy = None if dy is None else _f64(np.broadcast_to(dy, t.shape))
     B, M = n_off.size - 1, int(M)
     scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
-    power = np.empty((B, M), dtype=np.float64)
+    power = result_empty((B, M))
     _check(_lib.lk_ls_fastchi2_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(dy), float(f0), float(df), M,
                                      int(nterms), int(bool(fit_mean)), int(bool(center_data)), NORM[normalization],
                                      _ptr(scale), int(oversampling), _ptr(power)))
@@ -400,6 +400,49 @@ def pinned_pool(key, count, dtype=np.float64):
 
 def release_pinned_pool():
     _POOL.clear()
+    del _RESULTS[:]
+
+
+# Recycled RESULT buffers.  A fresh 160-MB / 800-MB numpy result costs more in first-touch page faults (10 / 50 ms) than its
+# transfer from the device (3 / 15 ms); results therefore come out of a few long-lived page-locked buffers, and a buffer is
+# handed out again only when NO array that views it is alive any more (every view of a buffer holds a reference to its
+# root ndarray, so the root's reference count says whether the caller still has the previous result).  A caller that keeps its
+# results keeps the buffer; the next call then simply allocates another one.  LK_RESULT_POOL=0 turns the recycling off.
+_RESULTS = []
+_RESULT_POOL_MAX = 4
+_RESULT_POOL_MIN_BYTES = 1 << 22
+
+
+def _result_root(nbytes):
+    """uint8[nbytes] ndarray that every view of the buffer reports as its base: page-locked when the runtime is there."""
+    try:
+        a = pinned_empty(nbytes, np.uint8)
+    except (OSError, RuntimeError, MemoryError):
+        a = np.empty(nbytes, dtype=np.uint8)
+    while isinstance(a.base, np.ndarray):
+        a = a.base
+    return a
+
+
+def result_empty(shape, dtype=np.float64):
+    """Uninitialised array for a large result of a batch call (``np.empty`` semantics), from the recycled buffers."""
+    import sys
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+    dtype = np.dtype(dtype)
+    need = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if need < _RESULT_POOL_MIN_BYTES or os.environ.get("LK_RESULT_POOL", "1") == "0":
+        return np.empty(shape, dtype=dtype)
+    free = [i for i in range(len(_RESULTS)) if sys.getrefcount(_RESULTS[i]) == 2]   # (the list + getrefcount's argument)
+    fit = [i for i in free if _RESULTS[i].nbytes >= need]
+    if fit:
+        root = _RESULTS[min(fit, key=lambda i: _RESULTS[i].nbytes)]
+    else:
+        for i in sorted(free, reverse=True):        # none of the idle buffers is large enough: they make room
+            del _RESULTS[i]
+        root = _result_root(need)
+        if len(_RESULTS) < _RESULT_POOL_MAX:
+            _RESULTS.append(root)
+    return root[:need].view(dtype).reshape(shape)
 
 
 def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True,
@@ -420,7 +463,7 @@ def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True
     scale = None if scale is None else _f64(np.broadcast_to(scale, (B,)))
     power = None
     if want_power:
-        power = out if out is not None else np.empty((B, M), dtype=np.float64)
+        power = out if out is not None else result_empty((B, M))
         if power.shape != (B, M) or power.dtype != np.float64 or not power.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous float64 array of shape (B, M)")
     if not want_power and not want_peaks:
@@ -540,7 +583,7 @@ def bls_batch(t, y, ivar, n_off, period, duration, oversample=10, use_likelihood
         raise ValueError("t, y, ivar must have the same length")
     period, duration = _f64(period).ravel(), _f64(duration).ravel()
     B, nP = n_off.size - 1, period.size
-    out = np.empty((7, B, nP), dtype=np.float64)
+    out = result_empty((7, B, nP))
     _check(_lib.lk_bls_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(ivar), _ptr(period), nP,
                              _ptr(duration), duration.size, int(oversample), int(bool(use_likelihood)), _ptr(out)))
     return {k: out[i] for i, k in enumerate(BLS_FIELDS)}
@@ -617,7 +660,7 @@ def savgol_trend_batch(t, flux, n_off, mask=None, window_length=101, polyorder=2
     if m is not None and m.shape != t.shape:
         raise ValueError("mask must have one entry per cadence (got shape %s, need %s)" % (m.shape, t.shape))
     bt = float("nan") if break_tolerance is None else float(break_tolerance)
-    trend = np.empty(t.size, dtype=np.float64)
+    trend = result_empty(t.size)
     fm = np.empty(t.size, dtype=np.uint8) if return_fit_mask else None
     _check(_lib.lk_savgol_trend_batch(h._h, n_off.size - 1, _ptr(n_off, _c_ip), _ptr(t), _ptr(flux), _ptr(m, _c_u8p),
                                       int(window_length), int(polyorder), bt, int(niters), float(sigma), _ptr(trend),

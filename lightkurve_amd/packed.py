@@ -143,13 +143,22 @@ def rebase_times(time, n_off):
 
 def check_sorted(time, n_off):
     """True if every light curve's times are non-decreasing (one vectorised pass; boundaries between light curves excluded)."""
-    if time.size < 2:
+    n = time.size
+    if n < 2:
         return True
-    d = time[1:] < time[:-1]
     inner = n_off[1:-1]
-    inner = inner[(inner > 0) & (inner < time.size)]
-    d[inner - 1] = False
-    return not d.any()
+    inner = inner[(inner > 0) & (inner < n)]            # first cadence of a later light curve: its step is a boundary
+
+    def part(a, b):                                       # steps a .. b - 1 (step i: time[i] -> time[i + 1])
+        d = time[a + 1:b + 1] < time[a:b]
+        if not d.any():
+            return True
+        lo, hi = np.searchsorted(inner, [a + 1, b + 1])   # boundaries inner[lo:hi] sit at steps inner - 1 in [a, b)
+        d[inner[lo:hi] - 1 - a] = False
+        return not d.any()
+
+    step = max(1 << 20, -(-(n - 1) // _threads()))
+    return all(_pmap(part, [(a, min(n - 1, a + step)) for a in range(0, n - 1, step)]))
 
 
 class LsGridPlan(object):

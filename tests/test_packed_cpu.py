@@ -196,3 +196,47 @@ def test_packed_batches_shard_gloo_world2(tmp_path, oracle_capi):
         assert eq(z["part"], ref[b[r]:b[r + 1]])
         assert eq(z["peaks"][:, 0], np.nanmax(ref, axis=1)) and eq(z["peaks"][:, 1], np.nanargmax(ref, axis=1))
         assert np.array_equal(z["bls"], ref_bls)
+
+
+def test_check_sorted_over_thread_chunks():
+    """check_sorted cuts the packed times into chunks for the thread pool: a descending step is found in any chunk, a light
+    curve boundary is excused wherever it falls (also exactly at a chunk edge), empty light curves in between do not matter."""
+    n1, n2 = 3_000_000, 2_500_000
+    off = np.array([0, n1, n1, n1 + n2], dtype=np.int64)                     # (an empty light curve in the middle)
+    t = np.concatenate([np.arange(n1, dtype=np.float64), np.arange(n2, dtype=np.float64)])
+    assert packed.check_sorted(t, off)                                        # the boundary step n1 - 1 descends: excused
+    for i in (0, (1 << 20) - 1, 1 << 20, n1 - 2, n1, n1 + n2 - 2):
+        bad = t.copy()
+        bad[i + 1] = bad[i] - 1.0
+        assert not packed.check_sorted(bad, off), i
+    t[n1 - 1] = 1e12                                                          # a huge last time before the boundary: still sorted
+    assert packed.check_sorted(t, off)
+
+
+def test_result_buffers_are_recycled_only_when_released():
+    """_capi.result_empty hands out views of a few long-lived buffers: the same memory again once every view of the previous
+    result is gone, different memory while the caller still holds any view of it; small results are plain numpy arrays."""
+    from lightkurve_amd import _capi
+    n = 1 << 20
+
+    def addr(x):
+        return x.__array_interface__["data"][0]
+
+    a = _capi.result_empty(n)
+    first = addr(a)
+    keep = a[5:100]
+    del a
+    b = _capi.result_empty(n)
+    assert addr(b) != first                         # `keep` still views the first buffer
+    del keep
+    c = _capi.result_empty((2, n // 2))
+    assert addr(c) == first and c.shape == (2, n // 2) and c.dtype == np.float64
+    d = _capi.result_empty((4, n))                  # larger than any idle buffer: a new one
+    assert addr(d) not in (first, addr(b)) and d.nbytes == 32 * n
+    assert _capi.result_empty(10).base is None
+    import os
+    os.environ["LK_RESULT_POOL"] = "0"
+    try:
+        assert _capi.result_empty(n).base is None
+    finally:
+        del os.environ["LK_RESULT_POOL"]
