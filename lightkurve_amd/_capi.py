@@ -7,6 +7,7 @@ first compute call raises.  numpy arrays in -> numpy arrays out (host-pointer en
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -409,6 +410,7 @@ def release_pinned_pool():
 # root ndarray, so the root's reference count says whether the caller still has the previous result).  A caller that keeps its
 # results keeps the buffer; the next call then simply allocates another one.  LK_RESULT_POOL=0 turns the recycling off.
 _RESULTS = []
+_RESULT_LOCK = threading.Lock()
 _RESULT_POOL_MAX = 4
 _RESULT_POOL_MIN_BYTES = 1 << 22
 
@@ -432,17 +434,18 @@ def result_empty(shape, dtype=np.float64):
     need = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if need < _RESULT_POOL_MIN_BYTES or os.environ.get("LK_RESULT_POOL", "1") == "0":
         return np.empty(shape, dtype=dtype)
-    free = [i for i in range(len(_RESULTS)) if sys.getrefcount(_RESULTS[i]) == 2]   # (the list + getrefcount's argument)
-    fit = [i for i in free if _RESULTS[i].nbytes >= need]
-    if fit:
-        root = _RESULTS[min(fit, key=lambda i: _RESULTS[i].nbytes)]
-    else:
-        for i in sorted(free, reverse=True):        # none of the idle buffers is large enough: they make room
-            del _RESULTS[i]
-        root = _result_root(need)
-        if len(_RESULTS) < _RESULT_POOL_MAX:
-            _RESULTS.append(root)
-    return root[:need].view(dtype).reshape(shape)
+    with _RESULT_LOCK:   # (two threads must not pick the same idle buffer: the view is taken before the lock is released)
+        free = [i for i in range(len(_RESULTS)) if sys.getrefcount(_RESULTS[i]) == 2]   # (the list + getrefcount's argument)
+        fit = [i for i in free if _RESULTS[i].nbytes >= need]
+        if fit:
+            root = _RESULTS[min(fit, key=lambda i: _RESULTS[i].nbytes)]
+        else:
+            for i in sorted(free, reverse=True):        # none of the idle buffers is large enough: they make room
+                del _RESULTS[i]
+            root = _result_root(need)
+            if len(_RESULTS) < _RESULT_POOL_MAX:
+                _RESULTS.append(root)
+        return root[:need].view(dtype).reshape(shape)
 
 
 def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True,
