@@ -480,6 +480,26 @@ __global__ __launch_bounds__(FLAT_NT, 8) void flat_dtseg_kernel(const int64_t *_
     }
 }
 
+// Inclusive scan of a double over the 64 lanes on the DPP network (no LDS crossbar): Hillis-Steele inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8; a lane without a source adds 0), then lane 15 of a row broadcast to the next row (rows 1 and 3) and
+// lane 31 to rows 2 and 3 — the GFX9 scan idiom.  Three of these per tile replaced 6 x 3 ds_bpermute round trips.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double flat_dpp0(double x) {   // the DPP-selected lane's x, 0.0 where there is none / row masked
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double flat_wave_scan(double x) {
+    x += flat_dpp0<0x111, 0xF>(x);   // row_shr:1
+    x += flat_dpp0<0x112, 0xF>(x);   // row_shr:2
+    x += flat_dpp0<0x114, 0xF>(x);   // row_shr:4
+    x += flat_dpp0<0x118, 0xF>(x);   // row_shr:8
+    x += flat_dpp0<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3
+    x += flat_dpp0<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // median of a short segment (fewer cadences than the window): the rare path of the trend kernel, kept out of line so that its
 // select machinery does not set the register budget of the streaming paths
 __device__ __noinline__ double flat_segment_median(const double *x, int len, unsigned long long *sh, double *cand, int cap) {
@@ -622,15 +642,8 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                         rs1 += s0 + s1 + s2;
                         continue;
                     }
-                    double i0 = s0, i1 = s1, i2 = s2;  // inclusive scan over the wave, then over the waves
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const double a0 = __shfl_up(i0, off), a1 = __shfl_up(i1, off), a2 = __shfl_up(i2, off);
-                        if (lane >= off) {
-                            i0 += a0;
-                            i1 += a1;
-                            i2 += a2;
-                        }
-                    }
+                    // inclusive scan over the wave, then over the waves
+                    const double i0 = flat_wave_scan(s0), i1 = flat_wave_scan(s1), i2 = flat_wave_scan(s2);
                     if (dbg == 7) {   // (ablation: + the wave scans, no barrier)
                         rs1 += i0 + i1 + i2;
                         continue;
@@ -652,14 +665,9 @@ __global__ __launch_bounds__(FLAT_NT, QUAD ? 6 : 4) void flat_trend_kernel(const
                         r1 += shd[w2 * 3 + 1];
                         r2 += shd[w2 * 3 + 2];
                     }
-                    {
-                        const double x0 = __shfl_up(i0, 1), x1 = __shfl_up(i1, 1), x2 = __shfl_up(i2, 1);
-                        if (lane > 0) {
-                            r0 += x0;
-                            r1 += x1;
-                            r2 += x2;
-                        }
-                    }
+                    r0 += flat_dpp0<0x138, 0xF>(i0);   // wave_shr:1 — the previous lane's inclusive sum, 0 in lane 0
+                    r1 += flat_dpp0<0x138, 0xF>(i1);
+                    r2 += flat_dpp0<0x138, 0xF>(i2);
                     if (CH <= 4) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
