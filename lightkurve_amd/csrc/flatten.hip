@@ -180,7 +180,7 @@ __device__ int strip_compact(int n, Pred pred, int *out, int *sh) {
 
 // ================================================================================================ phase-split pipeline
 // One light curve = one workgroup PER PHASE KERNEL (the trend phase: T workgroups); state between the kernels lives in the
-// per-target slab (compacted times / fluxes, trend, knots, index map, segment starts, masks) plus a 64-byte FlatState.
+// per-target slab (compacted times / fluxes, trend, index map, segment starts, masks) plus a 64-byte FlatState.
 // LDS plan of the select / trend kernels (dynamic): sh[max(nt, 264)] 64-bit words | fir[FIR_LDS + 2] doubles | shi[nt] ints;
 // `fir` holds the candidates of the sampled order statistics (block_select.hpp) or the tile arrays of the trend kernel.
 //
@@ -201,7 +201,7 @@ struct FlatState {
 };
 
 struct FlatSlab {
-    double *tm, *fm, *tr, *xk, *yk;
+    double *tm, *fm, *tr;
     int *idx, *segs;
     uint8_t *mask, *mask1;
 };
@@ -213,9 +213,7 @@ __device__ __forceinline__ FlatSlab flat_slab(char *scratch, const int64_t *scra
     sl.tm = reinterpret_cast<double *>(s);
     sl.fm = sl.tm + Npad;
     sl.tr = sl.fm + Npad;
-    sl.xk = sl.tr + Npad;
-    sl.yk = sl.xk + Npad;
-    sl.idx = reinterpret_cast<int *>(sl.yk + Npad);
+    sl.idx = reinterpret_cast<int *>(sl.tr + Npad);
     sl.segs = sl.idx + Npad;
     sl.mask = reinterpret_cast<uint8_t *>(sl.segs + Npad + 8);
     sl.mask1 = sl.mask + Npad;
@@ -862,7 +860,7 @@ __global__ __launch_bounds__(FLAT_NT) void flat_clip_kernel(const int64_t *__res
         const bool keepit = fabs(r) < lim;
         mask1[i] = keepit ? 1 : 0;
         if (!keepit) {
-            mask[idx[i]] = 0;
+            if (!last) mask[idx[i]] = 0;  // (the last iteration's survivors stay in mask1: flat_interp_kernel reads both)
             removed = 1;
         }
     });
@@ -878,11 +876,21 @@ __global__ __launch_bounds__(FLAT_NT) void flat_clip_kernel(const int64_t *__res
 
 // ---- phase 5 (once, after the loop): linear interpolation / extrapolation of the kept trend onto every cadence,
 // lightcurve.py:1053-1058, from the frozen state of the light curve's last iteration; and the final mask.
+// The knots — the kept cadences that survived the last clip — are NOT compacted into arrays of their own: `mask` still marks
+// the kept cadences of the frozen iteration (the last clip leaves it alone), i.e. the compacted arrays tm / tr, and `mask1`
+// marks the survivors among those.  For cadence c with x = t[c], p = the first compacted entry with time >= x (the number of
+// kept cadences before c, less any that share c's time); np.searchsorted(knots, x, 'left') names the first KNOT at or after p
+// as the upper end of the interpolation interval and the knot before it as the lower end — p itself and p - 1 unless an entry
+// was clipped there, so the six values an output needs (two flags, two times, two trends) are requested in ONE round, from
+// arrays neighbouring lanes share.  Clipped entries at p or p - 1, equal times and the two ends (interp1d's clamp of the
+// interval to the first / last pair of knots = extrapolation) take a scalar search.  This dropped the knot gather of rounds
+// 1-5a (17 B read + 16 B written per kept cadence, and two dependent rounds of gathers from it): 277 -> ~150 us per launch.
 __global__ __launch_bounds__(FLAT_NT, 8) void flat_interp_kernel(const double *__restrict__ t, const int64_t *__restrict__ n_off,
                                                               char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
                                                               const FlatState *__restrict__ state, double *__restrict__ trend,
                                                               uint8_t *__restrict__ final_mask) {
-    __shared__ int shi[FLAT_NT];
+    __shared__ int shi[FLAT_NT / 64], shk[FLAT_NT / 64];
+    __shared__ int ends[4];  // first, second, second-last, last knot (indices into the compacted arrays)
     const int target = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const FlatState st = state[target];
     const int64_t lo = n_off[target];
@@ -891,136 +899,131 @@ __global__ __launch_bounds__(FLAT_NT, 8) void flat_interp_kernel(const double *_
     trend += lo;
     const FlatSlab sl = flat_slab(scratch, scratch_off, target, N);
     const uint8_t *mask = sl.mask, *mask1 = sl.mask1;
-    if (final_mask) {
-        final_mask += lo;
-        for (int i = tid; i < N; i += nt) final_mask[i] = mask[i];
+    if (final_mask) final_mask += lo;
+    if (!st.want_interp) {  // (no kept cadence: the trend is all NaN already; nothing survived)
+        if (final_mask)
+            for (int i = tid; i < N; i += nt) final_mask[i] = 0;
+        return;
     }
-    if (!st.want_interp) return;
     const double *tm = sl.tm, *tr = sl.tr;
-    double *xk = sl.xk, *yk = sl.yk;
     const int nm = st.nm;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-    // the knots = the kept cadences that survived the clip (mask1), compacted in order straight into xk / yk: every wave owns
-    // a strip of the kept cadences, counts its survivors, and after one exchange of the wave totals writes them at
-    // ballot-prefix positions (the compaction kernel's scheme; no index array in between)
-    int n2;
-    {
-        const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
-        const int strip = ((nm + nw - 1) / nw + 63) & ~63;
-        const int k_lo = min(wv * strip, nm), k_hi = min(k_lo + strip, nm);
-        int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask1[k] != 0; });
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) shi[wv] = c;
-        __syncthreads();
-        int base = 0, total = 0;
-        for (int w = 0; w < nw; ++w) {
-            if (w < wv) base += shi[w];
-            total += shi[w];
-        }
-        n2 = total;
-        __syncthreads();  // shi is reused below
-        if (n2 >= 2)
-            for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
-                bool m[4];
-                unsigned mk[4];
-                double tv[4], yv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {  // clamped, unconditional, pinned loads: four groups in flight
-                    const int kc = min(k0 + 64 * u + lane, k_hi - 1);
-                    mk[u] = mask1[kc];
-                    tv[u] = tm[kc];
-                    yv[u] = tr[kc];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    asm volatile("" : "+v"(mk[u]), "+v"(tv[u]), "+v"(yv[u]));
-                    m[u] = k0 + 64 * u + lane < k_hi && mk[u] != 0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned long long bal = __ballot(m[u]);
-                    if (m[u]) {
-                        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                        xk[pos] = tv[u];
-                        yk[pos] = yv[u];
-                    }
-                    base += __popcll(bal);
-                }
-            }
+    const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+    // every wave owns a contiguous strip of cadences: kept cadences per strip (-> the compacted index a strip starts at), and
+    // the number of knots (strips of the compacted arrays)
+    const int strip = ((N + nw - 1) / nw + 63) & ~63;
+    const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
+    int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
+    const int mstrip = ((nm + nw - 1) / nw + 63) & ~63;
+    const int m_lo = min(wv * mstrip, nm), m_hi = min(m_lo + mstrip, nm);
+    int ck = strided_count64(m_lo, m_hi, lane, [&](int k) { return mask1[k] != 0; });
+    for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_xor(c, o);
+        ck += __shfl_xor(ck, o);
     }
-    if (n2 < 2) {
+    if (lane == 0) {
+        shi[wv] = c;
+        shk[wv] = ck;
+    }
+    if (tid == 0) {
+        int f1 = 0;
+        while (f1 < nm && !mask1[f1]) ++f1;
+        int f2 = f1 + 1;
+        while (f2 < nm && !mask1[f2]) ++f2;
+        int l1 = nm - 1;
+        while (l1 >= 0 && !mask1[l1]) --l1;
+        int l2 = l1 - 1;
+        while (l2 >= 0 && !mask1[l2]) --l2;
+        ends[0] = f1;
+        ends[1] = f2;
+        ends[2] = l2;
+        ends[3] = l1;
+    }
+    __syncthreads();
+    int base = 0, n2 = 0;
+    for (int w = 0; w < nw; ++w) {
+        if (w < wv) base += shi[w];
+        n2 += shk[w];
+    }
+    if (n2 < 2) {  // (interp1d needs two knots: the trend is all NaN; the survivors are still reported)
         for (int i = tid; i < N; i += nt) trend[i] = qnan;
-    } else {
-        // After the update above mask[c] == 1 exactly for the knot cadences, in knot order.  np.searchsorted(x, xn,
-        // 'left') = number of knots with x < xn = number of knot cadences before cadence k (times are sorted), less
-        // any that share k's time.  Each wave owns a contiguous strip of cadences and carries a running knot count:
-        // no search, no barrier inside the sweep.
-        const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
-        const int strip = ((N + nw - 1) / nw + 63) & ~63;
-        const int k_lo = min(wv * strip, N), k_hi = min(k_lo + strip, N);
-        int c = strided_count64(k_lo, k_hi, lane, [&](int k) { return mask[k] != 0; });
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        __syncthreads();
-        if (lane == 0) shi[wv] = c;
-        __syncthreads();  // also orders the xk / yk stores above before the loads below
-        int base = 0;
-        for (int w = 0; w < wv; ++w) base += shi[w];
-        for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
-            // four 64-cadence groups in flight: every stage of the dependent chain (mask/time -> knot index ->
-            // knot abscissae -> knot ordinates) is issued for all four before the next stage starts
-            bool in[4], kf[4];
-            double xn[4];
-            unsigned mk[4];
-            int j[4];
+        if (final_mask && tid == 0) {
+            int kept = 0;
+            for (int i = 0; i < N; ++i) final_mask[i] = (mask[i] && mask1[kept++]) ? 1 : 0;
+        }
+        return;
+    }
+    const int F1 = ends[0], F2 = ends[1], L2 = ends[2], L1 = ends[3];
+    for (int k0 = k_lo; k0 < k_hi; k0 += 256) {
+        // four 64-cadence groups in flight; per group: mask / time -> compacted index p -> one round of neighbour loads
+        bool in[4], kf[4];
+        double xn[4];
+        unsigned mk[4];
+        int p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);  // clamped, unconditional, pinned (see the gather)
-                in[u] = k < k_hi;
-                mk[u] = mask[kc];
-                xn[u] = t[kc];
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u + lane, kc = min(k, k_hi - 1);  // clamped, unconditional, pinned loads
+            in[u] = k < k_hi;
+            mk[u] = mask[kc];
+            xn[u] = t[kc];
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                asm volatile("" : "+v"(mk[u]), "+v"(xn[u]));
-                kf[u] = in[u] && mk[u] != 0;
-            }
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("" : "+v"(mk[u]), "+v"(xn[u]));
+            kf[u] = in[u] && mk[u] != 0;
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned long long bal = __ballot(kf[u]);
-                j[u] = base + __popcll(bal & ((1ull << lane) - 1ull));
-                base += __popcll(bal);
-            }
-            double xb[4];
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long bal = __ballot(kf[u]);
+            p[u] = base + __popcll(bal & ((1ull << lane) - 1ull));
+            base += __popcll(bal);
+        }
+        double xa[4], xb[4], ya[4], yb[4];
+        unsigned fa[4], fb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xb[u] = xk[max(j[u] - 1, 0)];
+        for (int u = 0; u < 4; ++u) {
+            const int pa = min(max(p[u] - 1, 0), nm - 1), pb = min(p[u], nm - 1);
+            xa[u] = tm[pa];
+            xb[u] = tm[pb];
+            ya[u] = tr[pa];
+            yb[u] = tr[pb];
+            fa[u] = mask1[pa];
+            fb[u] = mask1[pb];
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                asm volatile("" : "+v"(xb[u]));
-                xb[u] = (in[u] && j[u] > 0) ? xb[u] : -INFINITY;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (in[u] && xb[u] >= xn[u]) {  // equal times: those knots are not "< xn" (rare)
-                    --j[u];
-                    while (j[u] > 0 && xk[j[u] - 1] >= xn[u]) --j[u];
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("" : "+v"(xa[u]), "+v"(xb[u]), "+v"(ya[u]), "+v"(yb[u]), "+v"(fa[u]), "+v"(fb[u]));
+            if (!in[u]) continue;
+            const int k = k0 + 64 * u + lane;
+            if (final_mask) final_mask[k] = (kf[u] && fb[u] != 0) ? 1 : 0;  // (a kept cadence IS entry p: fb is its own flag)
+            const double x = xn[u];
+            double x0 = xa[u], x1 = xb[u], y0 = ya[u], y1 = yb[u];
+            // the common case: entries p - 1 and p exist, both are knots, p is neither the first knot nor past the last, and
+            // the entry before p is strictly earlier (no equal times)
+            const bool plain = p[u] >= 1 && p[u] < nm && fa[u] != 0 && fb[u] != 0 && xa[u] < x;
+            if (!plain) {
+                int q = min(p[u], nm);
+                while (q > 0 && tm[q - 1] >= x) --q;  // equal times: those entries are not "< x"
+                int hi_i = q;
+                while (hi_i < nm && !mask1[hi_i]) ++hi_i;  // the first knot at or after q
+                int lo_i;
+                if (hi_i > L1) {          // no knot at or after q: the last pair (extrapolation)
+                    hi_i = L1;
+                    lo_i = L2;
+                } else if (hi_i == F1) {  // no knot before q: the first pair
+                    hi_i = F2;
+                    lo_i = F1;
+                } else {
+                    lo_i = hi_i - 1;
+                    while (!mask1[lo_i]) --lo_i;  // (a knot exists below: hi_i > F1)
                 }
+                x0 = tm[lo_i];
+                x1 = tm[hi_i];
+                y0 = tr[lo_i];
+                y1 = tr[hi_i];
             }
-            double x0[4], x1[4], y0[4], y1[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int hi_i = min(max(j[u], 1), n2 - 1), lo_i = hi_i - 1;
-                x0[u] = xk[lo_i];
-                x1[u] = xk[hi_i];
-                y0[u] = yk[lo_i];
-                y1[u] = yk[hi_i];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (in[u]) {
-                    const double slope = (y1[u] - y0[u]) / (x1[u] - x0[u]);
-                    trend[k0 + 64 * u + lane] = isnan(xn[u]) ? qnan : slope * (xn[u] - x0[u]) + y0[u];
-                }
-            }
+            const double slope = (y1 - y0) / (x1 - x0);
+            trend[k] = isnan(x) ? qnan : slope * (x - x0) + y0;
         }
     }
 }
@@ -1100,8 +1103,8 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         const int64_t n = n_off_host[b + 1] - n_off_host[b];
         LK_REQUIRE(n >= 1 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
         const int64_t np = (n + 7) & ~(int64_t)7;
-        // slab: tm, fm, tr, xk, yk (8 B each) | idx, segs (4 B each, segs + 8 entries) | mask, mask1 (1 B each)
-        soff[b + 1] = soff[b] + ((5 * np * 8 + 2 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
+        // slab: tm, fm, tr (8 B each) | idx, segs (4 B each, segs + 8 entries) | mask, mask1 (1 B each)
+        soff[b + 1] = soff[b] + ((3 * np * 8 + 2 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + (size_t)B * (64 + 16 * 16) + 8192);
