@@ -1109,12 +1109,19 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + (size_t)B * (64 + 16 * 16) + 8192);
     if (rc) return rc;
-    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
-    int64_t *d_soff = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    // the two offset tables travel as ONE staged copy through the handle's pinned ring (captured before this function
+    // returns, ordered on the caller's stream): no host synchronisation in the launcher (it used to idle the GPU ~50 us per call)
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 16);
+    int64_t *d_soff = d_off + (B + 1);
     char *d_s = (char *)h->ws.alloc((size_t)soff[B]);
-    LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
-    LK_HIP_CHECK(hipMemcpyAsync(d_soff, soff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
-    LK_HIP_CHECK(hipStreamSynchronize(stream));  // soff goes out of scope
+    LK_REQUIRE(d_off && d_s, "workspace exhausted");
+    {
+        std::vector<int64_t> both((size_t)2 * (B + 1));
+        std::copy(n_off_host, n_off_host + B + 1, both.begin());
+        std::copy(soff.begin(), soff.end(), both.begin() + B + 1);
+        const int rcs = h->stage.copy(d_off, both.data(), both.size() * 8, stream);
+        if (rcs) return rcs;
+    }
     int64_t nmax = 0;
     for (int b = 0; b < B; ++b) nmax = std::max(nmax, n_off_host[b + 1] - n_off_host[b]);
     // FIR / candidate area of the tap-by-tap trend kernel (short windows): 8 x 612 doubles = 4096-output tiles; doubled until
