@@ -1107,21 +1107,32 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         soff[b + 1] = soff[b] + ((3 * np * 8 + 2 * np * 4 + 32 + 2 * np + 255) & ~(int64_t)255);
     }
     h->ws.reset();
-    int rc = h->ws.reserve((size_t)(B + 1) * 16 + (size_t)soff[B] + (size_t)B * (64 + 16 * 16) + 8192);
+    int rc = h->ws.reserve((size_t)soff[B] + (size_t)B * (64 + 16 * 16) + 8192);
     if (rc) return rc;
     // the two offset tables travel as ONE staged copy through the handle's pinned ring (captured before this function
     // returns, ordered on the caller's stream): no host synchronisation in the launcher (it used to idle the GPU ~50 us per call)
-    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 16);
-    int64_t *d_soff = d_off + (B + 1);
+    // They live in a buffer of the handle's own and are re-sent only when they differ from the previous call's (batches of one
+    // shape follow each other in a pipeline): the copy and the queue hand-over around it cost ~15 us of idle GPU per call.
     char *d_s = (char *)h->ws.alloc((size_t)soff[B]);
-    LK_REQUIRE(d_off && d_s, "workspace exhausted");
-    {
-        std::vector<int64_t> both((size_t)2 * (B + 1));
-        std::copy(n_off_host, n_off_host + B + 1, both.begin());
-        std::copy(soff.begin(), soff.end(), both.begin() + B + 1);
-        const int rcs = h->stage.copy(d_off, both.data(), both.size() * 8, stream);
-        if (rcs) return rcs;
+    LK_REQUIRE(d_s, "workspace exhausted");
+    std::vector<int64_t> both((size_t)2 * (B + 1));
+    std::copy(n_off_host, n_off_host + B + 1, both.begin());
+    std::copy(soff.begin(), soff.end(), both.begin() + B + 1);
+    if (h->flat_tab_cap < both.size()) {
+        h->flat_tab_host.clear();
+        if (h->flat_tab_dev) LK_HIP_CHECK(hipFree(h->flat_tab_dev));   // (synchronises: no kernel reads it any more)
+        h->flat_tab_dev = nullptr;
+        h->flat_tab_cap = 0;
+        LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&h->flat_tab_dev), (both.size() + 1024) * 8));
+        h->flat_tab_cap = both.size() + 1024;
     }
+    if (h->flat_tab_host != both) {
+        h->flat_tab_host.clear();
+        const int rcs = h->stage.copy(h->flat_tab_dev, both.data(), both.size() * 8, stream);
+        if (rcs) return rcs;
+        h->flat_tab_host = both;
+    }
+    const int64_t *d_off = h->flat_tab_dev, *d_soff = d_off + (B + 1);
     int64_t nmax = 0;
     for (int b = 0; b < B; ++b) nmax = std::max(nmax, n_off_host[b + 1] - n_off_host[b]);
     // FIR / candidate area of the tap-by-tap trend kernel (short windows): 8 x 612 doubles = 4096-output tiles; doubled until
