@@ -547,13 +547,79 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         });
         if (side_ran) *side_ran = true;
         if (dbg == 2) return 0.0;
-        const long long n_less = block_count_fast(c_less, reinterpret_cast<long long *>(sh));
-        const long long n_eqlo = block_count_fast(c_eqlo, reinterpret_cast<long long *>(sh));
-        const long long n_eqhi = block_count_fast(c_eqhi, reinterpret_cast<long long *>(sh));
+        long long n_less = block_count_fast(c_less, reinterpret_cast<long long *>(sh));
+        long long n_eqlo = block_count_fast(c_eqlo, reinterpret_cast<long long *>(sh));
+        long long n_eqhi = block_count_fast(c_eqhi, reinterpret_cast<long long *>(sh));
         __syncthreads();
-        const int nc = ictl[0];
-        if (nc > cap) return fallback();
+        int nc = ictl[0];
         if (spacing && nc > 0 && isfinite(lo) && isfinite(hi)) *spacing = (hi - lo) / (double)nc;
+        double slo = lo, shi_v = hi;  // the bracket the candidates in cand[] lie strictly inside
+        if (nc > cap) {
+            // More values inside the bracket than the LDS list holds: its expected content grows as n / sqrt(sample), past
+            // `cap` beyond ~50 000 values (a stitched multi-sector light curve).  One more pass bins the bracket's values
+            // (SEL_NB counters over the linear map of (lo, hi), which is monotone: a lower bin holds smaller values), the bins
+            // that hold the wanted ranks become the new bracket, and a last pass collects just those — three passes in all
+            // where the radix select behind fallback() takes eight per rank.
+            const long long q0 = k - n_less - n_eqlo;
+            const bool wa = q0 >= 0 && q0 < (long long)nc, wb = want_next && k + 1 < count && q0 + 1 >= 0 && q0 + 1 < (long long)nc;
+            if (!(wa || wb) || !isfinite(lo) || !isfinite(hi) || !(hi > lo) || cap < SEL_NB) return fallback();
+            const long long r_first = wa ? q0 : q0 + 1, r_last = wb ? q0 + 1 : q0;
+            int *hist = reinterpret_cast<int *>(cand);
+            int *ctl = reinterpret_cast<int *>(sh + 210);  // [0] first bin, [1] values below it, [2] last bin, [3] values through it
+            __syncthreads();
+            for (int i = tid; i < SEL_NB; i += nt) hist[i] = 0;
+            if (tid == 0) ctl[0] = ctl[2] = -1;
+            __syncthreads();
+            const double scale = (double)SEL_NB / (hi - lo);
+            auto bin = [&](double v) { return min(max((int)((v - lo) * scale), 0), SEL_NB - 1); };
+            strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
+                if (keep(i) && v > lo && v < hi) atomicAdd(&hist[bin(v)], 1);
+            });
+            __syncthreads();
+            const int BPT = (SEL_NB + nt - 1) / nt, b0 = tid * BPT;
+            int local = 0;
+            for (int u = 0; u < BPT; ++u)
+                if (b0 + u < SEL_NB) local += hist[b0 + u];
+            int tot;
+            int run = block_exscan_int(local, reinterpret_cast<int *>(sh), &tot);
+            for (int u = 0; u < BPT; ++u)
+                if (b0 + u < SEL_NB) {
+                    const int c = hist[b0 + u];
+                    if (r_first >= run && r_first < run + c) {
+                        ctl[0] = b0 + u;
+                        ctl[1] = run;
+                    }
+                    if (r_last >= run && r_last < run + c) {
+                        ctl[2] = b0 + u;
+                        ctl[3] = run + c;
+                    }
+                    run += c;
+                }
+            __syncthreads();
+            const int ba = ctl[0], bb = ctl[2], below = ctl[1], through = ctl[3];
+            __syncthreads();  // (hist aliases cand: every thread has its bins before the list is rebuilt)
+            if (ba < 0 || bb < ba || tot != nc || through - below > cap) return fallback();
+            if (tid == 0) ictl[0] = 0;
+            __syncthreads();
+            strided_pass<8>(n, [&](int i) { return val(i); }, [&](int i, double v) {
+                if (keep(i) && v > lo && v < hi) {
+                    const int b = bin(v);
+                    if (b >= ba && b <= bb) {
+                        const int slot = atomicAdd(&ictl[0], 1);
+                        if (slot < cap) cand[slot] = v;
+                    }
+                }
+            });
+            __syncthreads();
+            if (ictl[0] != through - below) return fallback();
+            // the values below the sub-bracket now count as "less"; its edges only steer the next histogram (clamped bins)
+            n_less += n_eqlo + below;
+            n_eqlo = 0;
+            n_eqhi = 0;
+            nc = through - below;
+            slo = lo + (double)ba / scale;
+            shi_v = lo + (double)(bb + 1) / scale;
+        }
         if (dbg == 3) return 0.0;
         // ranks k and k + 1 relative to the candidates; if they fall among them: histogram select, else (and when that does
         // not apply) the candidates are sorted once (keys[] aliases cand[]) and rank lookups are plain LDS reads
@@ -562,7 +628,7 @@ __device__ double block_select_sampled(int n, long long count, long long k, Val 
         const bool need_b = want_next && k + 1 < count && qb >= 0 && qb < (long long)nc;
         double hva = 0.0, hvb = 0.0;
         const bool hist_ok = (need_a || need_b) &&
-                             lds_hist_select(cand, nc, cap, need_a ? (int)qa : -1, need_b ? (int)qb : -1, lo, hi, sh, &hva, &hvb);
+                             lds_hist_select(cand, nc, cap, need_a ? (int)qa : -1, need_b ? (int)qb : -1, slo, shi_v, sh, &hva, &hvb);
         int S2 = 2;
         while (S2 < nc) S2 <<= 1;
         const bool sorted = !hist_ok && (need_a || need_b) && S2 <= cap;

@@ -174,3 +174,28 @@ def test_segment_cuts_ride_on_the_median_pass_and_fall_back():
             tr = flatten_trend_batch([lc], window_length=51, polyorder=2, break_tolerance=bt, niters=3, sigma=3)[0]
             ref, _ = O.flatten_trend(tt, y0, 51, 2, bt, 3, 3)
             assert np.allclose(tr, ref, rtol=RTOL, atol=0, equal_nan=True), (name, bt)
+
+
+@pytest.mark.parametrize("n,window", [(120_000, 401), (260_000, 101)])
+def test_long_light_curves_refine_the_bracket_by_histogram(n, window):
+    """Stitched multi-sector light curves (> ~50 000 cadences): the sampled select's bracket holds more values than its LDS
+    list, so the bins of one more counting pass narrow it (block_select.hpp) instead of the eight-pass radix select.  Gaps,
+    NaN fluxes, a few outliers; the flux median, the time-step median of all three iterations and the final trend go through
+    it.  Also a batch that mixes one long light curve with short ones."""
+    rng = np.random.default_rng(n)
+    t = np.cumsum(np.where(rng.random(n) < 2e-4, rng.uniform(0.5, 3.0, n), 2.0 / 1440.0 * (1 + 1e-9 * rng.standard_normal(n))))
+    y = 1.0 + 2e-3 * np.sin(2 * np.pi * t / 3.7) + 5e-4 * rng.standard_normal(n)
+    y[rng.choice(n, 40, replace=False)] += 0.02
+    y[rng.choice(n, 25, replace=False)] = np.nan
+    off = np.array([0, n], dtype=np.int64)
+    got = _capi.savgol_trend_batch(t, y, off, window_length=window)
+    ref = O.flatten_trend(t, y, window_length=window)[0]
+    ok = np.isfinite(ref)
+    assert np.array_equal(ok, np.isfinite(got)) and np.allclose(got[ok], ref[ok], rtol=RTOL, atol=0)
+    ts, ys, _, _ = synth.ls_target(6, 3, 3000)
+    t2 = np.concatenate([ts, t, ts + 1.0])
+    y2 = np.concatenate([1.0 + ys, y, 1.0 + ys])
+    off2 = np.array([0, 3000, 3000 + n, 6000 + n], dtype=np.int64)
+    got2 = _capi.savgol_trend_batch(t2, y2, off2, window_length=window)
+    assert np.array_equal(got2[3000:3000 + n], got, equal_nan=True)
+    assert np.allclose(got2[:3000], O.flatten_trend(ts, 1.0 + ys, window_length=window)[0], rtol=RTOL, atol=0)

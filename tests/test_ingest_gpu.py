@@ -143,3 +143,31 @@ def test_read_dispatches_on_file_type(golden):
     assert np.array_equal(hard.flux, g["kepler_hard_sap_flux"], equal_nan=True)
     cube = lka.read(os.path.join(fdir, "kepler_tpf.fits"))
     assert isinstance(cube, PixelCube) and np.array_equal(cube.flux, g["ktpf_default_flux"], equal_nan=True)
+
+
+def test_median_of_long_light_curves_is_the_exact_order_statistic():
+    """The sampled select behind `normalize` (block_select.hpp) on inputs whose bracket overflows its LDS list (> ~50 000
+    values): the histogram refinement must return numpy's nanmedian exactly — odd and even counts (the two middle ranks may
+    fall into different bins), smooth and clustered values, heavy ties inside the bracket (the refinement gives up: radix
+    select), a constant series, and NaNs that change the count."""
+    from lightkurve_amd import _capi
+    rng = np.random.default_rng(12)
+    cases = {
+        "gauss_odd": rng.standard_normal(200_001),
+        "gauss_even": rng.standard_normal(300_000),
+        "lognormal": np.exp(3 * rng.standard_normal(150_000)),
+        "two_clusters": np.concatenate([rng.normal(0, 1e-6, 90_000), rng.normal(5, 1e-6, 90_000)]),  # the middle ranks straddle the gap
+        "heavy_ties": np.round(rng.standard_normal(180_000), 2),
+        "constant": np.full(120_000, 3.25),
+        "with_nans": np.where(rng.random(250_000) < 0.1, np.nan, rng.standard_normal(250_000) ** 3),
+        "tiny_spread": 1.0 + 1e-15 * rng.integers(0, 50, 140_000),
+    }
+    for name, f in cases.items():
+        t = np.arange(f.size, dtype=np.float64)
+        _, _, _, _, med = _capi.ingest_batch(t, f, np.array([0, f.size]), normalize=False)
+        assert med[0] == np.nanmedian(f), name
+    # several long light curves of different lengths in one call
+    fs = [rng.standard_normal(n) for n in (70_000, 130_001, 55_000)]
+    off = np.concatenate([[0], np.cumsum([f.size for f in fs])])
+    _, _, _, _, med = _capi.ingest_batch(np.arange(off[-1], dtype=np.float64), np.concatenate(fs), off, normalize=False)
+    assert np.array_equal(med, [np.median(f) for f in fs])
