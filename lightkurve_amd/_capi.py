@@ -33,6 +33,7 @@ SIGNATURES = [
     ("lk_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     ("lk_destroy", None, [_vp]),
     ("lk_set_host_chunk_mb", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("lk_bls_max_period", ctypes.c_int, [_c_dp, ctypes.c_int, ctypes.c_int, _c_dp]),
     ("lk_bls_set_ordered_histogram", ctypes.c_int, [_vp, ctypes.c_int]),
     ("lk_workspace_bytes", ctypes.c_int64, [_vp]),
     ("lk_synchronize", ctypes.c_int, [_vp]),
@@ -590,6 +591,15 @@ def bls_batch(t, y, ivar, n_off, period, duration, oversample=10, use_likelihood
     _check(_lib.lk_bls_batch(h._h, B, _ptr(n_off, _c_ip), _ptr(t), _ptr(y), _ptr(ivar), _ptr(period), nP,
                              _ptr(duration), duration.size, int(oversample), int(bool(use_likelihood)), _ptr(out)))
     return {k: out[i] for i, k in enumerate(BLS_FIELDS)}
+
+
+def bls_max_period(duration, oversample=10):
+    """The longest period ``bls_batch`` admits for these durations (its phase bins live in LDS); host-only."""
+    load_library()
+    duration = _f64(np.atleast_1d(duration)).ravel()
+    out = ctypes.c_double(0.0)
+    _check(_lib.lk_bls_max_period(_ptr(duration), duration.size, int(oversample), ctypes.byref(out)))
+    return float(out.value)
 
 
 def bls_batch_dev(handle, B, n_off_host, t_ptr, y_ptr, ivar_ptr, period_host, period_ptr, duration_host, oversample,

@@ -858,6 +858,47 @@ __global__ __launch_bounds__(64) void bls_selftest_kernel(int *__restrict__ bad)
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
+// The LDS plan of a team: the packed duration tables + 16 B per phase bin (ya | wa) + the block maxima.  bls_plan_max_bins
+// answers "how many phase bins fit" for a set of durations — bls_launch's own limit and lk_bls_max_period's answer (the
+// seam into astropy sends longer periods to the original implementation: methods.bls_fast has no such limit).
+static size_t bls_region_of(int cap, int nw_) {
+    return ((size_t)cap * 16 + 48 + (size_t)nw_ * 16 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8 + 15) & ~(size_t)15;
+}
+static int bls_max_bins_for(size_t tab_bytes) {
+    int lo = 0, hi = 16384;  // largest even cap with tab_bytes + region_of(cap, 16) <= 156 KB; bins = cap - 2
+    while (lo < hi) {
+        const int mid = ((lo + hi + 2) / 2) & ~1;
+        if (tab_bytes + bls_region_of(mid, 16) <= 156 * 1024)
+            lo = mid;
+        else
+            hi = mid - 2;
+    }
+    return lo - 2;
+}
+
+int bls_max_period_host(const double *duration_host, int nD, int oversample, double *max_period) {
+    LK_REQUIRE(duration_host && max_period && nD >= 1 && oversample >= 1, "bad arguments");
+    double min_duration = duration_host[0];
+    for (int k = 0; k < nD; ++k) {
+        LK_REQUIRE(std::isfinite(duration_host[k]) && duration_host[k] >= DBL_EPSILON, "Invalid inputs for period and/or duration");
+        min_duration = std::min(min_duration, duration_host[k]);
+    }
+    const double bin_duration = min_duration / ((double)oversample);
+    std::vector<int> dur_bins;
+    for (int k = 0; k < nD; ++k) {
+        const int d = (int)(std::round(duration_host[k] / bin_duration));
+        if (std::find(dur_bins.begin(), dur_bins.end(), d) == dur_bins.end()) dur_bins.push_back(d);
+    }
+    const int nd = (int)dur_bins.size(), max_dur = *std::max_element(dur_bins.begin(), dur_bins.end());
+    LK_REQUIRE(nd < 65535 && max_dur < 65535, "too many / too long durations for the packed duration table");
+    const size_t tab_bytes = (((size_t)(2 * nd + 1 + max_dur + 2) * 4 + 15) / 16) * 16;
+    LK_REQUIRE(tab_bytes <= 24 * 1024, "%d durations up to %d bins: the LDS plan holds 24 KB of duration tables", nd, max_dur);
+    // n_bins(P) = ceil(P / bin_duration) + oversample <= max_bins
+    const int max_bins = bls_max_bins_for(tab_bytes);
+    *max_period = (double)(max_bins - oversample) * bin_duration;
+    return LK_OK;
+}
+
 int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *ivar,
                const double *period_host, const double *period_dev, int64_t nP, const double *duration_host, int nD,
                int oversample, int use_likelihood, double *out7, hipStream_t stream) {
@@ -924,12 +965,10 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     const int max_bins = nbins_of(order[0]);
     const size_t tab_bytes16 = tab_bytes;
     // LDS of one team: ya | wa | header | s_best[NW] | block maxima (bls_team_body's carve)
-    auto region_of = [&](int cap, int nw_) {
-        return ((size_t)cap * 16 + 48 + (size_t)nw_ * 16 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8 + 15) & ~(size_t)15;
-    };
+    auto region_of = [&](int cap, int nw_) { return bls_region_of(cap, nw_); };
     LK_REQUIRE(tab_bytes16 + region_of((max_bins + 2) & ~1, 16) <= 156 * 1024,
-               "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most about %d", max_bins,
-               (int)((156 * 1024 - tab_bytes16 - 512) / 17.2));
+               "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most %d "
+               "(lk_bls_max_period names the longest period these durations admit)", max_bins, bls_max_bins_for(tab_bytes16));
 
     const size_t ntot = (size_t)n_off_host[B];
     h->ws.reset();

@@ -460,6 +460,10 @@ int lk_bls_batch(lk_handle *h, int B, const int64_t *n_off, const double *t, con
     return LK_OK;
 }
 
+int lk_bls_max_period(const double *duration, int nD, int oversample, double *max_period) {
+    return lk::bls_max_period_host(duration, nD, oversample, max_period);
+}
+
 // ------------------------------------------------------------------------------------------------ regression
 int lk_regress_cov_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
                              const double *err, const uint8_t *cadence_mask, const double *prior_mu,

@@ -122,6 +122,7 @@ int argmax_launch(lk_handle *h, int B, int64_t M, const double *x, double *max_o
 int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, const double *y, const double *ivar,
                const double *period_host, const double *period_dev, int64_t nP, const double *duration_host,
                int nD, int oversample, int use_likelihood, double *out7, hipStream_t stream);
+int bls_max_period_host(const double *duration_host, int nD, int oversample, double *max_period);
 int regress_launch(lk_handle *h, int B, const int64_t *n_off_host, int K, const double *X, const double *y,
                    const double *err, const uint8_t *cmask, const double *prior_mu, const double *prior_sigma,
                    double clip_sigma, int niters, double *w, double *model, uint8_t *outl, hipStream_t stream,
