@@ -517,7 +517,11 @@ class BoxLeastSquaresPeriodogram(Periodogram):
     @staticmethod
     def from_lightcurve(lc, device=0, **kwargs):
         """Same contract as the reference constructor: kwargs ``duration``, ``period``, ``minimum_period``,
-        ``maximum_period``, ``frequency_factor``, ``time_unit``, ``objective``, ``oversample``, ``method``."""
+        ``maximum_period``, ``frequency_factor``, ``time_unit``, ``objective``, ``oversample``, ``method``.
+        One limit the reference does not have: a period's phase bins (period / (shortest duration / oversample)) live in
+        LDS, so periods beyond ``_capi.bls_max_period(duration, oversample)`` raise a ValueError naming the limit (46 d for
+        0.05-d durations at oversample 10, 232 d for lightkurve's default 0.25 d); there is no CPU route in this class — the
+        lightkurve seam sends exactly those periods to astropy's own ``bls_fast``."""
         plan = _bls_plan(lc, **kwargs)
         n = len(plan["t"])
         res = _capi.bls_batch(plan["t"], plan["y"], plan["ivar"], [0, n], plan["period"], plan["duration"],
