@@ -199,3 +199,55 @@ def test_long_light_curves_refine_the_bracket_by_histogram(n, window):
     got2 = _capi.savgol_trend_batch(t2, y2, off2, window_length=window)
     assert np.array_equal(got2[3000:3000 + n], got, equal_nan=True)
     assert np.allclose(got2[:3000], O.flatten_trend(ts, 1.0 + ys, window_length=window)[0], rtol=RTOL, atol=0)
+
+
+def test_interpolation_without_knot_gather_edge_cases():
+    """flat_interp_kernel's scalar search paths against the oracle: outliers clipped in the LAST iteration at the very ends of
+    the light curve (the interval clamps to the first / last pair of surviving knots: extrapolation), runs of clipped cadences
+    (the neighbouring compacted entries are not knots), duplicated time stamps next to clipped cadences (np.searchsorted 'left'
+    semantics), user-masked and NaN cadences before the first and after the last knot, and light curves left with fewer than
+    two knots.  80 random draws + hand-made cases, window 11..51."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for trial in range(80):
+        n = int(rng.integers(60, 900))
+        t = np.cumsum(rng.uniform(0.5, 1.5, n) * 0.02)
+        if trial % 3 == 0:                                   # duplicated time stamps (pairs and triples)
+            d = rng.choice(n - 2, max(1, n // 15), replace=False) + 1
+            t[d] = t[d - 1]
+            t = np.sort(t)
+        y = 1.0 + 0.01 * np.sin(t / 0.7) + 1e-3 * rng.standard_normal(n)
+        k = int(rng.integers(1, 6))
+        y[:k] += rng.choice([-1, 1], k) * rng.uniform(0.004, 0.2, k)           # outliers at the very start ...
+        y[n - k:] += rng.choice([-1, 1], k) * rng.uniform(0.004, 0.2, k)       # ... and end, of sizes that survive until different iterations
+        r0 = int(rng.integers(5, n - 12))
+        y[r0:r0 + int(rng.integers(1, 5))] += 0.05                             # a run of outliers
+        y[rng.choice(n, 3, replace=False)] = np.nan
+        m = np.zeros(n, bool)
+        if trial % 2:
+            m[:int(rng.integers(0, 4))] = True
+            m[n - int(rng.integers(1, 4)):] = True
+        cases.append((t, y, m, int(rng.choice([11, 21, 51])), float(rng.choice([2.0, 3.0]))))
+    # almost everything clipped: one or zero knots left
+    t = np.arange(40) * 0.02
+    y = np.where(np.arange(40) % 2 == 0, 1.0, 5.0)
+    y[7] = 1.0
+    cases.append((t, y, np.zeros(40, bool), 11, 0.2))
+    off = np.concatenate([[0], np.cumsum([len(c[0]) for c in cases])]).astype(np.int64)
+    for w in (11, 21, 51):
+        for s in (2.0, 3.0, 0.2):
+            sel = [i for i, c in enumerate(cases) if c[3] == w and c[4] == s]
+            if not sel:
+                continue
+            tt = np.concatenate([cases[i][0] for i in sel])
+            yy = np.concatenate([cases[i][1] for i in sel])
+            mm = np.concatenate([cases[i][2] for i in sel])
+            oo = np.concatenate([[0], np.cumsum([len(cases[i][0]) for i in sel])]).astype(np.int64)
+            got, fit = _capi.savgol_trend_batch(tt, yy, oo, mask=mm, window_length=w, sigma=s, return_fit_mask=True)
+            for j, i in enumerate(sel):
+                ref, rfit = O.flatten_trend(cases[i][0], cases[i][1], window_length=w, sigma=s, mask=cases[i][2])
+                g = got[oo[j]:oo[j + 1]]
+                ok = np.isfinite(ref)
+                assert np.array_equal(ok, np.isfinite(g)), (i, w, s)
+                assert np.allclose(g[ok], ref[ok], rtol=1e-9, atol=0), (i, w, s, np.max(np.abs(g[ok] - ref[ok]) / np.abs(ref[ok])))
+                assert np.array_equal(fit[oo[j]:oo[j + 1]], rfit), (i, w, s)
