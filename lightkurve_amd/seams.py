@@ -2,10 +2,13 @@
 ``lc.to_periodogram()``, ``lc.to_periodogram(method="bls")``, ``lc.flatten()``, ``RegressionCorrector.correct``,
 ``PLDCorrector.correct`` — returns its own LightCurve / Periodogram objects with the arithmetic done in liblkhip.so.
 
-* S1  astropy Lomb-Scargle method registry (reached from src/lightkurve/periodogram.py:961-964): ``'fast'`` (lightkurve's
-      default, :650), ``'fastchi2'``, ``'chi2'`` are replaced, ``'hip'`` (exact direct sums) is added; astropy's own
-      implementations stay reachable as ``'fast_cpu'``, ``'fastchi2_cpu'``, ``'chi2_cpu'`` and are called only for ``nterms``
-      > 8.  A ``'fast'`` / ``'fastchi2'`` call with ``use_fft=False`` IS the exact trig sums (fast_impl.py / utils.py:154-156) and
+* S1  astropy Lomb-Scargle method registry (reached from src/lightkurve/periodogram.py:961-964): EVERY name of the registry
+      (implementations/main.py:20-25) is replaced — ``'fast'`` (lightkurve's default, :650), ``'fastchi2'``, ``'chi2'``, and
+      the exact single-term names ``'slow'`` (what lightkurve itself rewrites ``'fast'`` to for every grid that is not
+      regular in frequency, i.e. every ``period=`` request: periodogram.py:933-946), ``'cython'`` and ``'scipy'`` —
+      and ``'hip'`` (exact direct sums) is added; ``'auto'`` only picks among those names (main.py:79-106), so it lands
+      on the GPU too.  astropy's own implementations stay reachable as ``'<name>_cpu'`` and are called only for
+      ``nterms`` > 8.  A ``'fast'`` / ``'fastchi2'`` call with ``use_fft=False`` IS the exact trig sums (fast_impl.py / utils.py:154-156) and
       runs the exact kernels; so does one with ``Mfft`` != 4 or ``nterms`` 5..8 (the FFT kernels extirpolate with astropy's
       default Mfft = 4 and are instantiated for <= 4 terms): the result is then the sums astropy's approximation converges
       to, not its approximation error.
@@ -90,6 +93,15 @@ def lombscargle_hip(t, y, dy=None, frequency=None, normalization="standard", fit
     if grid is not None:
         return finish(_be().ls_power_batch(t, y, [0, len(t)], f0=grid[0], df=grid[1], M=len(frequency), **kw)[0])
     return finish(_be().ls_power_batch(t, y, [0, len(t)], frequency=frequency, **kw)[0])
+
+
+def lombscargle_scipy_hip(t, y, frequency, normalization="standard", center_data=True):
+    """Signature of astropy's lombscargle_scipy (scipy_impl.py:4-5): main.py:194-202 strips ``dy`` and ``fit_mean`` (which
+    must be False) before it calls METHODS['scipy'].  ``scipy.signal.lombscargle`` of the optionally centred data is the
+    classical periodogram — the exact kernel with unit weights and no floating mean; scipy_impl.py:59-66's four
+    normalisations are the same maps of it as everywhere else."""
+    return lombscargle_hip(t, y, None, frequency=frequency, normalization=normalization, fit_mean=False,
+                           center_data=center_data)
 
 
 def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True, fit_mean=True,
@@ -488,6 +500,8 @@ def _set_spline_builders(dense, sparse):
 
 
 # ------------------------------------------------------------------------------------------------ install / uninstall
+_LS_NAMES = ("fast", "fastchi2", "chi2", "slow", "cython", "scipy")     # astropy's whole registry (main.py:20-25)
+
 def install(backend=None, lightkurve=True, full_loop=True):
     """Patch astropy (S1, S2) and, if it is importable and ``lightkurve`` is true, lightkurve (S3, S4) in place; returns
     the list of seams installed.  ``full_loop``: replace ``RegressionCorrector.correct`` (all clip iterations in one
@@ -496,10 +510,17 @@ def install(backend=None, lightkurve=True, full_loop=True):
     _BACKEND = backend if backend is not None else _capi
     from astropy.timeseries.periodograms.bls import methods as bls_methods
     from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main
-    for name in ("fast", "fastchi2", "chi2"):
+    for name in _LS_NAMES:
         _ORIG.setdefault(name, ls_main.METHODS.get(name + "_cpu", ls_main.METHODS[name]))
         ls_main.METHODS.setdefault(name + "_cpu", _ORIG[name])
     ls_main.METHODS["hip"] = lombscargle_hip
+    # the exact single-term names.  'slow' is where lightkurve's own switch sends every request whose grid is not regular
+    # in frequency (periodogram.py:933-946: any period= / minimum_period= call); 'cython' is what method='auto' picks for
+    # short or irregular grids and 'scipy' what it picks without errors and floating mean (main.py:96-104).  All three
+    # receive the raw frequency array, like 'hip'
+    ls_main.METHODS["slow"] = lombscargle_hip
+    ls_main.METHODS["cython"] = lombscargle_hip
+    ls_main.METHODS["scipy"] = lombscargle_scipy_hip
     # multi-term fits (lightkurve nterms > 1 requires the name 'chi2' or 'fastchi2', periodogram.py:948-958):
     # 'chi2' receives the raw frequency array like 'hip' does, so it can be replaced one-to-one
     ls_main.METHODS["chi2"] = lombscargle_hip
@@ -508,7 +529,8 @@ def install(backend=None, lightkurve=True, full_loop=True):
     ls_main.METHODS["fastchi2"] = lombscargle_fast_hip
     bls_methods._bls_fast_reference = getattr(bls_methods, "_bls_fast_reference", bls_methods.bls_fast)
     bls_methods.bls_fast = bls_fast_hip
-    done = ["lombscargle:METHODS['hip']", "lombscargle:METHODS['chi2']", "lombscargle:METHODS['fast']",
+    done = ["lombscargle:METHODS['hip']", "lombscargle:METHODS['slow']", "lombscargle:METHODS['cython']",
+            "lombscargle:METHODS['scipy']", "lombscargle:METHODS['chi2']", "lombscargle:METHODS['fast']",
             "lombscargle:METHODS['fastchi2']", "bls:methods.bls_fast"]
     if not lightkurve:
         return done
@@ -550,7 +572,7 @@ def uninstall():
     _BACKEND = _capi
     from astropy.timeseries.periodograms.bls import methods as bls_methods
     from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main
-    for name in ("fast", "fastchi2", "chi2"):
+    for name in _LS_NAMES:
         if name in _ORIG:
             ls_main.METHODS[name] = _ORIG[name]
     ls_main.METHODS.pop("hip", None)

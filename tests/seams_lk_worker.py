@@ -47,6 +47,9 @@ def run_all(lk):
     out["ls_default"] = lc.to_periodogram()                                        # S1, default method 'fast'
     out["ls_psd"] = lc.to_periodogram(normalization="psd", freq_unit="microhertz")
     out["ls_slow_period_grid"] = lc.to_periodogram(period=np.linspace(0.5, 5, 300), ls_method="slow")
+    # lightkurve's own switch (periodogram.py:933-946): the DEFAULT method on a period grid is rewritten 'fast' -> 'slow'
+    out["ls_period_grid_default_method"] = lc.to_periodogram(minimum_period=0.4, maximum_period=6.0)
+    out["ls_cython_period_grid"] = lc.to_periodogram(period=np.linspace(0.5, 5, 300), ls_method="cython", normalization="psd")
     out["ls_chi2_nterms2"] = lc.to_periodogram(nterms=2, ls_method="chi2", oversample_factor=2)
     out["ls_chi2_nterms5"] = lc.to_periodogram(nterms=5, ls_method="chi2", oversample_factor=1)   # 5..8 terms: exact sums
     # round 5: requests the FFT kernels do not cover stay on the device as exact sums (astropy called directly, as the
@@ -57,6 +60,10 @@ def run_all(lk):
     out["raw_ls_fast_nofft"] = np.asarray(ls.power(ls.autofrequency(**fgrid), method="fast", method_kwds=dict(use_fft=False)))
     out["raw_ls_fast_mfft8"] = np.asarray(ls.power(ls.autofrequency(**fgrid), method="fast",
                                                method_kwds=dict(trig_sum_kwds=dict(Mfft=8, oversampling=10))))
+    # method='auto' picks 'cython' for a short grid, 'scipy' without errors and floating mean (main.py:96-104)
+    out["raw_ls_auto_short_grid"] = np.asarray(ls.power(np.linspace(0.05, 4.0, 150), method="auto"))
+    out["raw_ls_auto_scipy"] = np.asarray(LombScargle(t, y, fit_mean=False).power(np.linspace(0.05, 4.0, 150), method="auto",
+                                                                              normalization="psd"))
     ls5 = LombScargle(t, y, nterms=5)
     out["raw_ls_fastchi2_nterms5"] = np.asarray(ls5.power(ls5.autofrequency(**fgrid), method="fastchi2"))
     tb, yb, eb, _ = synth.bls_target(3, 9, 2500, cadence_days=10.0 / 1440.0)

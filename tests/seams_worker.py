@@ -36,6 +36,24 @@ def main():
         per = np.linspace(0.1, 5, 400)     # irregular frequency grid
         errs["irregular_%s" % ("dy" if dy is not None else "nody")] = float(
             np.max(np.abs(ls.power(1 / per, method="hip") - ls.power(1 / per, method="slow"))))
+    # round 6: every exact single-term NAME of astropy's registry is the HIP kernel; the originals are kept as '<name>_cpu'
+    from astropy.timeseries.periodograms.lombscargle.implementations import main as ls_main0
+    per = np.linspace(0.1, 5, 400)
+    for name in ("slow", "cython", "scipy"):
+        assert ls_main0.METHODS[name] is not ls_main0.METHODS[name + "_cpu"], name
+        for norm in ("standard", "psd", "log", "model"):
+            kw = dict(frequency=1 / per, normalization=norm)
+            if name == "scipy":
+                args = (t - t[0], y)
+            else:
+                args = (t - t[0], y, e)
+                kw["fit_mean"] = True
+            ref = ls_main0.METHODS[name + "_cpu"](*args, **kw)
+            got = ls_main0.METHODS[name](*args, **kw)
+            errs["%s_vs_cpu_%s" % (name, norm)] = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+    ls_a = LombScargle(t - t[0], y, fit_mean=False, center_data=True)
+    errs["auto_scipy_vs_cpu"] = float(np.max(np.abs(
+        ls_a.power(1 / per, method="auto") - ls_main0.METHODS["scipy_cpu"](t - t[0], y, frequency=1 / per))))
     # multi-term: LombScargle(nterms=2).power(method='chi2') now runs on the GPU; astropy's own kept as 'chi2_cpu'
     ls = LombScargle(t - t[0], y, e, nterms=2)
     fm = f[f * (t[-1] - t[0]) >= 2.0]

@@ -148,3 +148,26 @@ def test_error_paths():
     with pytest.raises(ValueError):
         _capi.ls_power_batch(t, t[:5], [0, 10], f0=0.1, df=1.0, M=5)
     assert _capi.ls_power_batch(t, t, [0, 10], f0=0.1, df=1.0, M=0).shape == (1, 0)
+
+
+def test_seam_functions_behind_every_exact_astropy_method_name(golden):
+    """What seams.install() registers as METHODS['slow'] / ['cython'] / ['scipy'] (astropy implementations/main.py:20-25; 'slow' is
+    where lightkurve's irregular-grid switch lands, periodogram.py:933-946), called with the arguments astropy's dispatcher
+    passes (main.py:182-217), against the reference's own outputs for those names: goldens amp_slow / amp_cython."""
+    from lightkurve_amd import seams
+    g = golden("ls_tess3000")
+    t, y, f = g["time"] - g["time"][0], g["flux"], g["frequency"]      # (astropy hands the methods t - t[0], core.py:119-126)
+    to_amp = lambda p: np.sqrt(p) * np.sqrt(4.0 / len(t))            # lightkurve's amplitude normalisation (:974-975)
+    for name, key in (("slow", "amp_slow"), ("cython", "amp_cython")):
+        p = seams.lombscargle_hip(t, y, None, frequency=f, normalization="psd", fit_mean=True, center_data=True)
+        assert relmax(to_amp(p), g[key]) < TOL, name
+    # an IRREGULAR grid (uniform in period), the case the switch exists for: seam vs the oracle's exact sums
+    per = np.linspace(0.3, 9.0, 700)
+    p = seams.lombscargle_hip(t, y, None, frequency=1.0 / per, normalization="psd")
+    ref = O.ls_power(t, y, None, 1.0 / per, normalization="psd")
+    assert relmax(p, ref) < TOL
+    # 'scipy' = the classical periodogram: unit weights, no floating mean (scipy_impl.py:56-66)
+    for norm in ("psd", "standard"):
+        p = seams.lombscargle_scipy_hip(t, y, 1.0 / per, normalization=norm, center_data=True)
+        ref = O.ls_power(t, y, None, 1.0 / per, normalization=norm, fit_mean=False, center_data=True)
+        assert relmax(p, ref) < TOL, norm

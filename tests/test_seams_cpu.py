@@ -39,7 +39,7 @@ def test_all_seams_return_lightkurve_objects_with_reference_values():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_LK_RESULT ")][-1]
     res = json.loads(line[len("SEAMS_LK_RESULT "):])
-    assert len(res["installed"]) == 13
+    assert len(res["installed"]) == 16
     # every seam was really taken
     assert set(res["calls"]) >= {"ls_fast_batch", "ls_power_batch", "bls_batch", "savgol_trend_batch", "regress_batch",
                                  "pld_design_batch", "pca_batch", "standardize_batch", "spline_basis_batch"}

@@ -30,7 +30,7 @@ def test_astropy_seams_under_conda():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_RESULT ")][-1]
     res = json.loads(line[len("SEAMS_RESULT "):])
-    assert len(res["installed"]) == 5
+    assert len(res["installed"]) == 8
     for k, v in res["ls_relerr"].items():
         assert v < 1e-9, (k, v)
     assert res["bls_bit_exact"]["likelihood"] and res["bls_bit_exact"]["snr"]
@@ -41,10 +41,10 @@ def test_astropy_seams_under_conda():
 
 
 def test_all_seams_through_real_lightkurve_when_staged():
-    """The nine seams through an UNMODIFIED lightkurve with the HIP backend (tests/seams_lk_worker.py compare hip).
+    """All seams through an UNMODIFIED lightkurve with the HIP backend (tests/seams_lk_worker.py compare hip).
     lightkurve is not installed on the GPU box: the test runs wherever a checkout is reachable — LK_REFERENCE_ROOT (what
     tools/seams_e2e_gpu.sh sets after unpacking the staged tarball to /tmp) or /root/reference — and skips otherwise; the
-    kept log of such a run is profiles/r03_seams_e2e_gpu.log."""
+    kept log of such a run is profiles/r06_seams_e2e_gpu.log."""
     ref = os.environ.get("LK_REFERENCE_ROOT", "/root/reference")
     if not os.path.exists(CONDA) or not os.path.isdir(os.path.join(ref, "src", "lightkurve")):
         pytest.skip("no lightkurve checkout reachable on this box (see tools/seams_e2e_gpu.sh)")
@@ -58,5 +58,5 @@ def test_all_seams_through_real_lightkurve_when_staged():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_LK_RESULT ")][-1]
     res = json.loads(line[len("SEAMS_LK_RESULT "):])
-    assert len(res["installed"]) == 13 and res["library"].endswith("liblkhip.so")
+    assert len(res["installed"]) == 16 and res["library"].endswith("liblkhip.so")
     assert res["errors"]["bls"] == 0.0
