@@ -218,6 +218,63 @@ int lk_ls_fast_peaks_lc_batch(lk_handle *h, int B, const int64_t *n_off, const d
 int lk_host_alloc(void **ptr, size_t bytes);
 int lk_host_free(void *ptr);
 
+/* ---- device-resident batches ("FITS -> ragged device arrays ... on device") ----------------------
+ * The reference chains its steps per object — lk.read(...) -> lc.remove_nans().normalize() -> lc.flatten() ->
+ * lc.to_periodogram() -> lc.fold() (src/lightkurve/collections.py:145 over lightcurve.py:1300-1327, 1216-1292, 943-1078,
+ * 2490-2535, 1089-1214); the batch form keeps the packed arrays in HBM between the `_dev` entry points.  For callers that do
+ * not hold a HIP runtime of their own (ctypes, cgo, JNI): device memory, streams and copies by plain pointers.  Copies are
+ * hipMemcpyAsync on `stream` (page-locked host buffers from lk_host_alloc make them truly asynchronous; pageable ones block
+ * the host inside the call); lk_stream_synchronize (or lk_synchronize) before the host touches a d2h destination.
+ * lk_dev_free synchronises the device (hipFree): recycle buffers in a pipeline (lightkurve_amd/device.py does). */
+int lk_dev_alloc(lk_handle *h, void **ptr, size_t bytes);
+int lk_dev_free(lk_handle *h, void *ptr);
+int lk_stream_create(lk_handle *h, void **stream);
+int lk_stream_destroy(lk_handle *h, void *stream);
+int lk_stream_synchronize(lk_handle *h, void *stream);
+int lk_memcpy_h2d(lk_handle *h, void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int lk_memcpy_d2h(lk_handle *h, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int lk_memcpy_d2d(lk_handle *h, void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+/* LightCurve.flatten's last lines (lightcurve.py:1064-1070): flux_out = flux / trend, flux_err_out = flux_err / trend over
+ * the n packed cadences (flux_err nullable -> NaN errors; flux_err_out nullable; in-place allowed). */
+int lk_flatten_apply_batch_dev(lk_handle *h, int64_t n, const double *flux, const double *flux_err, const double *trend,
+                               double *flux_out, double *flux_err_out, void *stream);
+/* lk_ls_fast_peaks_lc_batch with DEVICE pointers: `time` holds the light curves' own (absolute) times; they are rebased to
+ * t - t[first cadence of the light curve] (astropy lombscargle/core.py:119-126) into scratch of the handle, `time` itself is
+ * not modified.  power required; max_power / argmax nullable together. */
+int lk_ls_fast_peaks_lc_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, const double *flux,
+                                  const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                                  int normalization, const double *scale, int oversampling, double *power,
+                                  double *max_power, int64_t *argmax, void *stream);
+/* t_out = time - time[first cadence of its light curve] (out of place): what astropy's LombScargle hands every method,
+ * for the exact entry points (lk_ls_power_batch_dev / lk_ls_chi2_batch_dev) of a device-resident batch. */
+int lk_rebase_times_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, double *t_out,
+                              void *stream);
+/* Per light curve: descents_host[b] = number of cadences whose time is smaller than the previous one's (flatten, bin and
+ * the bit-exact BLS need 0), finite_host[b] = number of finite values of x (LightCurve.bin's "has a finite error" test,
+ * lightcurve.py:1712-1716).  time / descents_host and x / finite_host are nullable in pairs.  Synchronises `stream`. */
+int lk_segment_probe_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, const double *x,
+                               int64_t *descents_host, int64_t *finite_host, void *stream);
+/* What BoxLeastSquaresPeriodogram.from_lightcurve + astropy BoxLeastSquares hand to bls_fast (periodogram.py:1093-1100,
+ * 1146-1169; astropy bls/core.py:277-327), per light curve of a packed batch WITHOUT NaN flux: t_out = (t - t[0]) -
+ * min(t - t[0]); y_out = flux - numpy.median(flux); ivar_out = 1 / flux_err^2 if every error of the light curve is finite,
+ * else ones (flux_err NULL: ones); t_ref_out[b] (device, nullable) = min(t - t[0]) + t[0], the zero of transit_time. */
+int lk_bls_prepare_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, const double *flux,
+                             const double *flux_err, double *t_out, double *y_out, double *ivar_out, double *t_ref_out,
+                             void *stream);
+/* Further per-cadence columns (quality flags, centroids, ...) through lk_ingest_batch's compaction: cols_out[c][new_off[b] +
+ * k] = cols_in[c][...] for the k-th cadence of light curve b whose flux is not NaN.  ncols <= 8 device pointers in two
+ * HOST arrays; elem_bytes 4 or 8; n_off / new_off: the offsets lk_ingest_batch_dev was given and returned. */
+int lk_compact_columns_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const int64_t *new_off_host,
+                                 const double *flux, int ncols, int elem_bytes, const void *const *cols_in,
+                                 void *const *cols_out, void *stream);
+/* dst_host[i] = src_dev[idx_host[i]], i < n (the first / last time of every light curve for lightkurve's psd scale,
+ * periodogram.py:865-868).  Synchronises `stream`. */
+int lk_gather_f64_dev(lk_handle *h, int n, const int64_t *idx_host, const double *src_dev, double *dst_host, void *stream);
+/* The shader clock [MHz] sustained over `spin_ms` milliseconds, measured ON the device (shader-cycle counter against the
+ * constant-rate counter) by one wave on a stream of its own — i.e. under whatever load the caller has queued.  What
+ * bench.py prints beside its roofline fractions: box-to-box spread of a bandwidth fraction is mostly this number. */
+int lk_shader_clock_mhz(lk_handle *h, double spin_ms, double *mhz);
+
 /* ---- batch ingest: the steps before the hot path, for B ragged light curves -------------------
  * lk_ingest_batch: LightCurve.remove_nans (src/lightkurve/lightcurve.py:1300-1327) + LightCurve.normalize (:1216-1292).
  * Cadences whose flux is NaN are dropped (order kept), the batch is repacked contiguously: new_off (B + 1, HOST, written

@@ -10,6 +10,7 @@ __version__ = "0.1.0"
 
 from .lightcurve import FoldedLightCurve, LightCurve  # noqa: F401
 from .ingest import LightCurveBatch  # noqa: F401
+from .device import DeviceLightCurveBatch  # noqa: F401
 from .fitsio import read  # noqa: F401
 from .periodogram import (BoxLeastSquaresPeriodogram, LightkurveWarning, LombScarglePeriodogram,  # noqa: F401
                           Periodogram)

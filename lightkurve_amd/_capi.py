@@ -70,6 +70,25 @@ SIGNATURES = [
     ("lk_ls_fast_peaks_lc_batch", ctypes.c_int,
      [_vp, ctypes.c_int, _c_ip, _c_dp, _c_dp, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
       ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int, _c_dp, _c_dp, _c_ip]),
+    ("lk_dev_alloc", ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_size_t]),
+    ("lk_dev_free", ctypes.c_int, [_vp, _vp]),
+    ("lk_stream_create", ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    ("lk_stream_destroy", ctypes.c_int, [_vp, _vp]),
+    ("lk_stream_synchronize", ctypes.c_int, [_vp, _vp]),
+    ("lk_memcpy_h2d", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    ("lk_memcpy_d2h", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    ("lk_memcpy_d2d", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    ("lk_flatten_apply_batch_dev", ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("lk_ls_fast_peaks_lc_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+      ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    ("lk_rebase_times_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp]),
+    ("lk_segment_probe_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, _vp, _c_ip, _c_ip, _vp]),
+    ("lk_bls_prepare_batch_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("lk_compact_columns_batch_dev", ctypes.c_int,
+     [_vp, ctypes.c_int, _c_ip, _c_ip, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    ("lk_gather_f64_dev", ctypes.c_int, [_vp, ctypes.c_int, _c_ip, _vp, _c_dp, _vp]),
+    ("lk_shader_clock_mhz", ctypes.c_int, [_vp, ctypes.c_double, _c_dp]),
     ("lk_host_alloc", ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
     ("lk_host_free", ctypes.c_int, [_vp]),
     ("lk_fold_batch", ctypes.c_int,

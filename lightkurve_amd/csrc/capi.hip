@@ -139,6 +139,8 @@ void lk_destroy(lk_handle *h) {
         for (int i = 0; i < 2; ++i)
             if (arr[i]) (void)hipEventDestroy(arr[i]);
     if (h->h_plan) (void)hipHostFree(h->h_plan);
+    if (h->s_probe) (void)hipStreamDestroy(h->s_probe);
+    if (h->clk_buf) (void)hipHostFree(h->clk_buf);
     if (h->flat_tab_dev) (void)hipFree(h->flat_tab_dev);
     h->ws.release();
     h->staging.release();

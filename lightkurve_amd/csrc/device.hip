@@ -1,0 +1,461 @@
+// device.hip — device-RESIDENT batches ("FITS -> ragged device arrays, remove_nans / normalize / bin /
+// fold / create_transit_mask on device").  The hot-path kernels all have `_dev` entry points; what a ctypes caller without
+// a HIP runtime of its own lacked was (1) a way to HOLD device memory and order work on a stream, and (2) the small
+// element-wise steps the reference performs BETWEEN the hot-path calls of a chained pipeline, which would otherwise force a
+// device -> host -> device round trip at every arrow of
+//     lk.read(...) -> lc.remove_nans().normalize() -> lc.flatten() -> lc.to_periodogram() / (method="bls") -> lc.fold()
+// (reference loop being replaced: src/lightkurve/collections.py:145 over lightcurve.py:1300-1327, 1216-1292, 943-1078,
+// 2490-2535, 1089-1214).
+//
+//   lk_dev_alloc / lk_dev_free / lk_memcpy_{h2d,d2h,d2d} / lk_stream_*     plain device memory + stream management
+//   lk_flatten_apply_batch_dev   flatten_lc.flux = flux / trend; flux_err = flux_err / trend      (lightcurve.py:1064-1070)
+//   lk_ls_fast_peaks_lc_batch_dev   the device-pointer twin of lk_ls_fast_peaks_lc_batch: ABSOLUTE times in HBM, rebased to
+//                                t - t[first cadence] (astropy lombscargle/core.py:119-126) into scratch, then the FFT path
+//   lk_bls_prepare_batch_dev     what BoxLeastSquaresPeriodogram.from_lightcurve + astropy BoxLeastSquares hand to bls_fast
+//                                (periodogram.py:1093-1100, 1146-1169; astropy bls/core.py:277-327): t - min(t),
+//                                y - median(y), ivar = 1 / err^2
+//   lk_compact_columns_batch_dev further per-cadence columns (quality flags, centroids, ...) carried through remove_nans
+//   lk_gather_f64_dev            a few elements of a device array to the host (first / last time of every light curve)
+//   lk_shader_clock_mhz          the sustained shader clock, measured on the device while other work runs (bench.py)
+#include <cmath>
+#include <vector>
+
+#include "block_select.hpp"
+#include "lk_common.hpp"
+
+namespace lk {
+
+// ------------------------------------------------------------------------------------------------ flux / trend
+__global__ __launch_bounds__(256) void flatten_apply_kernel(int64_t n, const double *__restrict__ flux,
+                                                             const double *__restrict__ err,
+                                                             const double *__restrict__ trend, double *__restrict__ f_out,
+                                                             double *__restrict__ e_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double tr = trend[i];
+    f_out[i] = flux[i] / tr;
+    if (e_out) e_out[i] = err ? err[i] / tr : __longlong_as_double(0x7ff8000000000000ll);
+}
+
+// ------------------------------------------------------------------------------------------------ t - t[0] (out of place)
+__global__ __launch_bounds__(1024) void rebase_copy_kernel(const double *__restrict__ t, const int64_t *__restrict__ off,
+                                                           double *__restrict__ out) {
+    const int64_t lo = off[blockIdx.x], n = off[blockIdx.x + 1] - lo;
+    if (n <= 0) return;
+    const double t0 = t[lo];
+    for (int64_t i = threadIdx.x; i < n; i += 1024) out[lo + i] = t[lo + i] - t0;
+}
+
+// ------------------------------------------------------------------------------------------------ BLS inputs
+// One workgroup per light curve.  The arithmetic is the host front end's (lightkurve_amd/packed.py: bls_inputs), itself the
+// reference's per object: trel = t - t[0]; t_out = trel - min(trel); y_out = flux - numpy.median(flux); ivar = 1 / err^2 when
+// EVERY error of the light curve is finite, else ones (periodogram.py:1093-1100: a light curve with non-finite errors is
+// searched unweighted); t_ref = min(trel) + t[0], what transit_time is measured from.
+constexpr int BLSP_NT = 512;
+__global__ __launch_bounds__(BLSP_NT) void bls_prepare_kernel(const double *__restrict__ t, const double *__restrict__ flux,
+                                                               const double *__restrict__ err,
+                                                               const int64_t *__restrict__ n_off, double *__restrict__ t_out,
+                                                               double *__restrict__ y_out, double *__restrict__ ivar_out,
+                                                               double *__restrict__ t_ref, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long blsp_lds[];
+    unsigned long long *sh = blsp_lds;                              // 512 words
+    double *cand = reinterpret_cast<double *>(blsp_lds + 512);      // cap doubles
+    __shared__ double red[BLSP_NT / 64];
+    __shared__ int redi[BLSP_NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = n_off[b];
+    const int n = (int)(n_off[b + 1] - lo);
+    if (n <= 0) {
+        if (tid == 0 && t_ref) t_ref[b] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    t += lo, flux += lo, t_out += lo, y_out += lo, ivar_out += lo;
+    if (err) err += lo;
+    const double t0 = t[0];
+    double mn = __longlong_as_double(0x7ff0000000000000ll);
+    int fin = 1;
+    for (int i = tid; i < n; i += BLSP_NT) {
+        mn = fmin(mn, t[i] - t0);
+        if (err) fin &= isfinite(err[i]) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, o));
+        fin &= __shfl_xor(fin, o);
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = mn, redi[tid >> 6] = fin;
+    __syncthreads();
+    for (int w = 0; w < BLSP_NT / 64; ++w) mn = fmin(mn, red[w]), fin &= redi[w];
+    __syncthreads();
+    auto val = [&](int i) { return flux[i]; };
+    auto keep = [&](int) { return true; };
+    const double med = block_median_sampled(n, (long long)n, val, keep, sh, cand, cap);
+    for (int i = tid; i < n; i += BLSP_NT) {
+        const double trel = t[i] - t0;
+        t_out[i] = trel - mn;
+        y_out[i] = flux[i] - med;
+        double w = 1.0;
+        if (err && fin) {
+            const double e = err[i];
+            w = 1.0 / (e * e);
+        }
+        ivar_out[i] = w;
+    }
+    if (tid == 0 && t_ref) t_ref[b] = mn + t0;
+}
+
+// ------------------------------------------------------------------------------------------------ carried columns
+// Order-preserving compaction of `ncols` further per-cadence columns by the SAME test lk_ingest_batch applies (flux is not
+// NaN): wave strips + ballot prefixes, as ingest_pack_kernel.  elem = 4 or 8 bytes.
+struct ColPtrs {
+    const void *in[8];
+    void *out[8];
+};
+template <class T>
+__global__ __launch_bounds__(512) void compact_columns_kernel(const double *__restrict__ flux,
+                                                               const int64_t *__restrict__ n_off,
+                                                               const int64_t *__restrict__ new_off, int ncols, ColPtrs cp) {
+    __shared__ int shi[8];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t lo = n_off[b], olo = new_off[b];
+    const int n = (int)(n_off[b + 1] - lo);
+    flux += lo;
+    const int nw = nt >> 6, wv = tid >> 6, lane = tid & 63;
+    const int strip = ((n + nw - 1) / nw + 63) & ~63;
+    const int k_lo = min(wv * strip, n), k_hi = min(k_lo + strip, n);
+    int c = 0;
+    for (int k = k_lo + lane; k < k_hi; k += 64) c += isnan(flux[k]) ? 0 : 1;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) shi[wv] = c;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += shi[w];
+    for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+        const int k = k0 + lane;
+        const bool m = k < k_hi && !isnan(flux[k]);
+        const unsigned long long bal = __ballot(m);
+        if (m) {
+            const int64_t pos = olo + base + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int cidx = 0; cidx < ncols; ++cidx)
+                static_cast<T *>(cp.out[cidx])[pos] = static_cast<const T *>(cp.in[cidx])[lo + k];
+        }
+        base += __popcll(bal);
+    }
+}
+
+// per light curve: how often the time steps backwards (flatten / bin / fold need non-decreasing times) and how many values
+// of x are finite (LightCurve.bin: "has at least one finite error")
+__global__ __launch_bounds__(256) void segment_probe_kernel(const double *__restrict__ t, const double *__restrict__ x,
+                                                             const int64_t *__restrict__ n_off,
+                                                             int64_t *__restrict__ descents, int64_t *__restrict__ finite) {
+    __shared__ long long sh[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = n_off[b], n = n_off[b + 1] - lo;
+    long long d = 0, f = 0;
+    for (int64_t i = tid; i < n; i += 256) {
+        if (t && i + 1 < n) d += t[lo + i + 1] < t[lo + i] ? 1 : 0;
+        if (x) f += isfinite(x[lo + i]) ? 1 : 0;
+    }
+    const long long dt = block_count_fast(d, sh);
+    __syncthreads();
+    const long long ft = block_count_fast(f, sh);
+    if (tid == 0) {
+        if (descents) descents[b] = dt;
+        if (finite) finite[b] = ft;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_f64_kernel(int n, const int64_t *__restrict__ idx,
+                                                          const double *__restrict__ src, double *__restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// One wave spins on the constant-rate counter (s_memrealtime) and reads the shader-clock counter (s_memtime: one tick per
+// shader cycle, /opt/skills/guides/MI355X_MICROARCH.md) at both ends.
+__global__ void clock_probe_kernel(unsigned long long wall_ticks, unsigned long long *out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < wall_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w1 = wall_clock64();
+    }
+    out[0] = clock64() - c0;
+    out[1] = w1 - w0;
+}
+
+static int offsets_ok(int B, const int64_t *n_off_host) {
+    LK_REQUIRE(B >= 0 && n_off_host != nullptr, "bad batch description");
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(n_off_host[0] == 0, "n_off[0] must be 0");
+    for (int b = 0; b < B; ++b) {
+        const int64_t n = n_off_host[b + 1] - n_off_host[b];
+        LK_REQUIRE(n >= 0 && n < ((int64_t)1 << 30), "target %d has %lld cadences", b, (long long)n);
+    }
+    return LK_OK;
+}
+
+}  // namespace lk
+
+using lk::set_error;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ memory / streams
+int lk_dev_alloc(lk_handle *h, void **ptr, size_t bytes) {
+    LK_REQUIRE(h != nullptr && ptr != nullptr, "handle / ptr is NULL");
+    *ptr = nullptr;
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipMalloc(ptr, bytes ? bytes : 1));
+    return LK_OK;
+}
+
+int lk_dev_free(lk_handle *h, void *ptr) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    if (!ptr) return LK_OK;
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipFree(ptr));
+    return LK_OK;
+}
+
+int lk_stream_create(lk_handle *h, void **stream) {
+    LK_REQUIRE(h != nullptr && stream != nullptr, "handle / stream is NULL");
+    *stream = nullptr;
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = nullptr;
+    LK_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return LK_OK;
+}
+
+int lk_stream_destroy(lk_handle *h, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    if (!stream) return LK_OK;
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return LK_OK;
+}
+
+int lk_stream_synchronize(lk_handle *h, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return LK_OK;
+}
+
+int lk_memcpy_h2d(lk_handle *h, void *dst_dev, const void *src_host, size_t bytes, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    if (!bytes) return LK_OK;
+    LK_REQUIRE(dst_dev && src_host, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return LK_OK;
+}
+
+int lk_memcpy_d2h(lk_handle *h, void *dst_host, const void *src_dev, size_t bytes, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    if (!bytes) return LK_OK;
+    LK_REQUIRE(dst_host && src_dev, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    return LK_OK;
+}
+
+int lk_memcpy_d2d(lk_handle *h, void *dst_dev, const void *src_dev, size_t bytes, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    if (!bytes) return LK_OK;
+    LK_REQUIRE(dst_dev && src_dev, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    LK_HIP_CHECK(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ flux / trend
+int lk_flatten_apply_batch_dev(lk_handle *h, int64_t n, const double *flux, const double *flux_err, const double *trend,
+                               double *flux_out, double *flux_err_out, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(n >= 0, "n must be >= 0");
+    if (n == 0) return LK_OK;
+    LK_REQUIRE(flux && trend && flux_out, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(lk::flatten_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), n, flux, flux_err, trend, flux_out, flux_err_out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LS 'fast', absolute times
+int lk_ls_fast_peaks_lc_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, const double *flux,
+                                  const double *dy, double f0, double df, int64_t M, int fit_mean, int center_data,
+                                  int normalization, const double *scale, int oversampling, double *power,
+                                  double *max_power, int64_t *argmax, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(power != nullptr, "power must be non-NULL for the device flavour (the spectra stay in HBM anyway)");
+    int rc = lk::offsets_ok(B, n_off_host);
+    if (rc) return rc;
+    if (B == 0 || M == 0) return LK_OK;
+    LK_REQUIRE(time && flux, "time, flux must be non-NULL");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the rebased times live in the handle's SECOND arena (the kernels' scratch arena is reset by lsfast_launch); it is the
+    // staging arena of the host-pointer entry points, free whenever a *_dev call runs (one stream per handle)
+    const size_t ntot = (size_t)n_off_host[B];
+    h->staging.reset();
+    rc = h->staging.reserve(ntot * 8 + (size_t)(B + 1) * 8 + 1024);
+    if (rc) return rc;
+    double *d_trel = (double *)h->staging.alloc(ntot * 8);
+    int64_t *d_off = (int64_t *)h->staging.alloc((size_t)(B + 1) * 8);
+    rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lk::rebase_copy_kernel, dim3(B), dim3(1024), 0, st, time, d_off, d_trel);
+    return lk::lsfast_launch(h, B, n_off_host, d_trel, flux, dy, f0, df, M, fit_mean, center_data, normalization, scale,
+                             oversampling, power, st, max_power, argmax);
+}
+
+int lk_rebase_times_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, double *t_out,
+                              void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    int rc = lk::offsets_ok(B, n_off_host);
+    if (rc) return rc;
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(time && t_out && time != t_out, "time, t_out must be two non-NULL buffers");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    h->ws.reset();
+    rc = h->ws.reserve((size_t)(B + 1) * 8 + 1024);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    if ((rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, st))) return rc;
+    hipLaunchKernelGGL(lk::rebase_copy_kernel, dim3(B), dim3(1024), 0, st, time, d_off, t_out);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+int lk_segment_probe_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, const double *x,
+                               int64_t *descents_host, int64_t *finite_host, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    int rc = lk::offsets_ok(B, n_off_host);
+    if (rc) return rc;
+    if (B == 0) return LK_OK;
+    LK_REQUIRE((time && descents_host) || (x && finite_host), "nothing to probe");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    h->ws.reset();
+    rc = h->ws.reserve(3 * ((size_t)(B + 1) * 8 + 256) + 1024);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    int64_t *d_desc = (int64_t *)h->ws.alloc((size_t)B * 8);
+    int64_t *d_fin = (int64_t *)h->ws.alloc((size_t)B * 8);
+    if ((rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, st))) return rc;
+    hipLaunchKernelGGL(lk::segment_probe_kernel, dim3(B), dim3(256), 0, st, descents_host ? time : nullptr,
+                       finite_host ? x : nullptr, d_off, d_desc, d_fin);
+    if (descents_host) LK_HIP_CHECK(hipMemcpyAsync(descents_host, d_desc, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    if (finite_host) LK_HIP_CHECK(hipMemcpyAsync(finite_host, d_fin, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ BLS inputs
+int lk_bls_prepare_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const double *time, const double *flux,
+                             const double *flux_err, double *t_out, double *y_out, double *ivar_out, double *t_ref_out,
+                             void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    int rc = lk::offsets_ok(B, n_off_host);
+    if (rc) return rc;
+    if (B == 0) return LK_OK;
+    LK_REQUIRE(time && flux && t_out && y_out && ivar_out, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    h->ws.reset();
+    rc = h->ws.reserve((size_t)(B + 1) * 8 + 1024);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, st);
+    if (rc) return rc;
+    constexpr int cap = 4096;
+    const size_t lds = 512 * 8 + (size_t)cap * 8;
+    rc = lk::want_lds(h, reinterpret_cast<const void *>(lk::bls_prepare_kernel), 160 * 1024);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lk::bls_prepare_kernel, dim3(B), dim3(lk::BLSP_NT), lds, st, time, flux, flux_err, d_off, t_out,
+                       y_out, ivar_out, t_ref_out, cap);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ carried columns
+int lk_compact_columns_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const int64_t *new_off_host,
+                                 const double *flux, int ncols, int elem_bytes, const void *const *cols_in,
+                                 void *const *cols_out, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    int rc = lk::offsets_ok(B, n_off_host);
+    if (rc) return rc;
+    LK_REQUIRE(new_off_host != nullptr, "new_off is NULL");
+    LK_REQUIRE(ncols >= 0 && ncols <= 8, "at most 8 columns per call (got %d)", ncols);
+    LK_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "columns of 4- or 8-byte elements (got %d)", elem_bytes);
+    if (B == 0 || ncols == 0) return LK_OK;
+    LK_REQUIRE(flux && cols_in && cols_out, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    lk::ColPtrs cp;
+    for (int c = 0; c < 8; ++c) cp.in[c] = c < ncols ? cols_in[c] : nullptr, cp.out[c] = c < ncols ? cols_out[c] : nullptr;
+    for (int c = 0; c < ncols; ++c) LK_REQUIRE(cp.in[c] && cp.out[c], "column %d is NULL", c);
+    h->ws.reset();
+    rc = h->ws.reserve(2 * ((size_t)(B + 1) * 8 + 256) + 1024);
+    if (rc) return rc;
+    int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    int64_t *d_new = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
+    if ((rc = h->stage.copy(d_off, n_off_host, (size_t)(B + 1) * 8, st))) return rc;
+    if ((rc = h->stage.copy(d_new, new_off_host, (size_t)(B + 1) * 8, st))) return rc;
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(lk::compact_columns_kernel<uint32_t>, dim3(B), dim3(512), 0, st, flux, d_off, d_new, ncols, cp);
+    else
+        hipLaunchKernelGGL(lk::compact_columns_kernel<uint64_t>, dim3(B), dim3(512), 0, st, flux, d_off, d_new, ncols, cp);
+    LK_HIP_CHECK(hipGetLastError());
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ a few elements -> host
+int lk_gather_f64_dev(lk_handle *h, int n, const int64_t *idx_host, const double *src_dev, double *dst_host, void *stream) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(n >= 0, "n must be >= 0");
+    if (n == 0) return LK_OK;
+    LK_REQUIRE(idx_host && src_dev && dst_host, "NULL buffer");
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    h->ws.reset();
+    int rc = h->ws.reserve(2 * ((size_t)n * 8 + 256) + 1024);
+    if (rc) return rc;
+    int64_t *d_idx = (int64_t *)h->ws.alloc((size_t)n * 8);
+    double *d_val = (double *)h->ws.alloc((size_t)n * 8);
+    if ((rc = h->stage.copy(d_idx, idx_host, (size_t)n * 8, st))) return rc;
+    hipLaunchKernelGGL(lk::gather_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_idx, src_dev, d_val);
+    LK_HIP_CHECK(hipMemcpyAsync(dst_host, d_val, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    LK_HIP_CHECK(hipStreamSynchronize(st));
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ sustained shader clock
+int lk_shader_clock_mhz(lk_handle *h, double spin_ms, double *mhz) {
+    LK_REQUIRE(h != nullptr && mhz != nullptr, "handle / mhz is NULL");
+    LK_REQUIRE(spin_ms > 0.0 && spin_ms <= 1000.0, "spin_ms must be in (0, 1000]");
+    *mhz = 0.0;
+    LK_HIP_CHECK(hipSetDevice(h->device));
+    int wall_khz = 0;
+    LK_HIP_CHECK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, h->device));
+    LK_REQUIRE(wall_khz > 0, "the device reports no wall-clock rate");
+    if (!h->s_probe) LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_probe, hipStreamNonBlocking));   // overlaps the caller's queued work
+    if (!h->clk_buf) LK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h->clk_buf), 16, hipHostMallocDefault));
+    volatile unsigned long long *h_out = h->clk_buf;
+    h_out[0] = h_out[1] = 0;
+    hipLaunchKernelGGL(lk::clock_probe_kernel, dim3(1), dim3(64), 0, h->s_probe, (unsigned long long)(spin_ms * wall_khz),
+                       h->clk_buf);
+    LK_HIP_CHECK(hipStreamSynchronize(h->s_probe));
+    if (h_out[1] == 0) {
+        set_error("clock probe returned no wall-clock ticks");
+        return LK_EHIP;
+    }
+    *mhz = (double)h_out[0] / (double)h_out[1] * (double)wall_khz * 1e-3;
+    return LK_OK;
+}
+
+}  // extern "C"

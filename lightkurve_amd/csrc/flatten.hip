@@ -1126,11 +1126,15 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         LK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&h->flat_tab_dev), (both.size() + 1024) * 8));
         h->flat_tab_cap = both.size() + 1024;
     }
-    if (h->flat_tab_host != both) {
+    // (a call on ANOTHER stream re-sends them even when they are equal: the cached copy is ordered on the stream it was
+    // queued on, not on this one — ADVICE r5; calls on different streams must still be separated by a synchronisation,
+    // include/lkhip.h "Conventions")
+    if (h->flat_tab_host != both || h->flat_tab_stream != stream) {
         h->flat_tab_host.clear();
         const int rcs = h->stage.copy(h->flat_tab_dev, both.data(), both.size() * 8, stream);
         if (rcs) return rcs;
         h->flat_tab_host = both;
+        h->flat_tab_stream = stream;
     }
     const int64_t *d_off = h->flat_tab_dev, *d_soff = d_off + (B + 1);
     int64_t nmax = 0;

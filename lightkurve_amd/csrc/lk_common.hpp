@@ -83,6 +83,10 @@ struct lk_handle {
     int64_t *flat_tab_dev = nullptr;
     size_t flat_tab_cap = 0;                // entries
     std::vector<int64_t> flat_tab_host;     // what flat_tab_dev holds (empty: nothing valid)
+    hipStream_t flat_tab_stream = nullptr;  // the stream the table's upload was queued on (a call on another stream re-uploads)
+    // device.hip: lk_shader_clock_mhz's own stream and 16 pinned bytes (kept: freeing either would synchronise the device)
+    hipStream_t s_probe = nullptr;
+    unsigned long long *clk_buf = nullptr;
 };
 
 namespace lk {

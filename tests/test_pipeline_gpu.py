@@ -59,3 +59,49 @@ def test_fits_to_folded_light_curve():
         assert min(abs(best - truth), abs(best - 2 * truth), abs(2 * best - truth)) < 0.03, (best, truth)
         folded = one.fold(period=best, epoch_time=float(one.time[0]))
         assert len(folded.time) == len(one.time) and np.all(np.diff(folded.time) >= 0)
+
+
+def test_fits_to_folded_light_curve_device_resident():
+    """The same chain with the batch RESIDENT in HBM from the FITS bytes to the folded light curve (SURVEY §8(f) N4;
+    lightkurve_amd/device.py): no per-stage host round trip, no `to_lightcurves()` in the middle — and every stage `==`
+    (bit for bit, stated) the staged host path on the same files, which the test above pins to the oracle."""
+    from lightkurve_amd import _capi
+    from lightkurve_amd.device import DeviceLightCurveBatch
+    paths = [os.path.join(FDIR, n) for n in ("kepler_llc.fits", "tess_lc.fits")]
+    f = 0.2 + 0.01 * np.arange(1500)
+    periods = np.linspace(0.5, 2.0, 400)
+    durations = np.array([0.05, 0.08, 0.12])
+    # ---- resident chain: one upload (the tables' bytes), D2H only of what is asked back
+    dev = DeviceLightCurveBatch.from_fits(paths).remove_nans().normalize()
+    flat = dev.flatten(window_length=51, polyorder=2, break_tolerance=5, niters=3, sigma=3)
+    power, peaks = flat.to_periodogram_power(f, ls_method="slow", want_peaks=True)
+    bls = flat.bls(periods, durations)
+    best = bls.peaks()
+    folded = flat.fold(period=best["period"], epoch_time=best["transit_time"]).to_host()
+    # ---- staged host path, stage by stage
+    host = LightCurveBatch.from_fits(paths).remove_nans().normalize()
+    trend = host.flatten_trend(window_length=51, polyorder=2, break_tolerance=5, niters=3, sigma=3)
+    hflat = LightCurveBatch(host.time, host.flux / trend, host.flux_err / trend, host.n_off)
+    got = flat.to_host()
+    assert np.array_equal(got.n_off, hflat.n_off) and np.array_equal(got.time, hflat.time)
+    assert np.array_equal(got.flux, hflat.flux, equal_nan=True) and np.array_equal(got.flux_err, hflat.flux_err, equal_nan=True)
+    hp = hflat.to_periodogram_power(f, ls_method="slow")
+    assert np.array_equal(power, hp)
+    assert np.array_equal(peaks[:, 0], np.nanmax(hp, axis=1)) and np.array_equal(peaks[:, 1], np.nanargmax(hp, axis=1))
+    hb = bls_batch(hflat, periods, durations)
+    assert np.array_equal(bls.to_host(), hb)
+    am = np.argmax(hb[:, 0, :], axis=1)
+    assert np.array_equal(best["argmax"], am) and np.array_equal(best["transit_time"], hb[np.arange(len(am)), 4, am])
+    ok = ~np.isnan(hflat.flux)           # the BLS / LS stages drop NaN flux themselves; fold keeps every cadence
+    assert ok.all()
+    ph, order, (fl, fe) = _capi.fold_batch(hflat.time, hflat.n_off, periods[am], hb[np.arange(len(am)), 4, am],
+                                           columns=(hflat.flux, hflat.flux_err))
+    assert np.array_equal(folded["phase"], ph) and np.array_equal(folded["order"], order)
+    assert np.array_equal(folded["flux"], fl) and np.array_equal(folded["flux_err"], fe, equal_nan=True)
+    # and the oracle on the resident stages' own outputs
+    for b in range(len(host)):
+        s = slice(host.n_off[b], host.n_off[b + 1])
+        ref, _ = O.flatten_trend(host.time[s], host.flux[s], 51, 2, 5, 3, 3, mask=None)
+        assert np.allclose(host.flux[s] / got.flux[s], ref, rtol=1e-10, atol=0, equal_nan=True)
+        ref = O.ls_power(got.time[s] - got.time[s][0], got.flux[s], None, f, normalization="lk_amplitude")
+        assert np.max(np.abs(power[b] - ref)) <= 1e-9 * np.max(ref)

@@ -44,8 +44,13 @@ def cases(lk, N):
     out = [
         ("lc.to_periodogram()  [default grid, ls_method='fast']", lambda: lc.to_periodogram(), 5),
         ("lc.to_periodogram(frequency=1e5 grid)", lambda: lc.to_periodogram(frequency=freq), 5),
-        ("lc.to_periodogram(frequency=1e5 grid, ls_method='slow')" if N <= 4000 else None,
+        # lightkurve rewrites the default 'fast' to 'slow' for every grid that is not regular in frequency (periodogram.py:933-946)
+        ("lc.to_periodogram(period=2000 periods)  ['fast' -> 'slow' by lightkurve]",
+         lambda: lc.to_periodogram(period=np.linspace(0.5, 20.0, 2000)), 2),
+        # (astropy's own 'slow' builds ~12 N x M temporaries: 1e4 frequencies x 20 000 cadences do not fit the host)
+        ("lc.to_periodogram(frequency=1e4 grid, ls_method='slow')" if N <= 4000 else None,
          lambda: lc.to_periodogram(frequency=freq[::10], ls_method="slow"), 2),
+        ("lc.to_periodogram(period=1e5 periods, ls_method='slow')  [HIP only]" if False else None, None, 0),
         ("lc.to_periodogram(method='bls', 5000 periods x 6 durations)", lambda: lcb.to_periodogram(method="bls", period=periods), 3),
         ("lc.flatten(window_length=101)", lambda: lc.flatten(window_length=101), 5),
         ("lc.flatten(window_length=401)", lambda: lc.flatten(window_length=401), 5),
