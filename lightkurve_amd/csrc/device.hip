@@ -374,8 +374,6 @@ int lk_bls_prepare_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, con
     if (rc) return rc;
     constexpr int cap = 4096;
     const size_t lds = 512 * 8 + (size_t)cap * 8;
-    rc = lk::want_lds(h, reinterpret_cast<const void *>(lk::bls_prepare_kernel), 160 * 1024);
-    if (rc) return rc;
     hipLaunchKernelGGL(lk::bls_prepare_kernel, dim3(B), dim3(lk::BLSP_NT), lds, st, time, flux, flux_err, d_off, t_out,
                        y_out, ivar_out, t_ref_out, cap);
     LK_HIP_CHECK(hipGetLastError());
