@@ -81,6 +81,12 @@ int lk_set_host_chunk_mb(lk_handle *h, int mb);
  * bit-identical results, ~64 x the LDS instructions in the histogram phase.  on != 0 forces that form (tests, diagnosis of
  * a suspected ordering problem); 0 returns to the automatic choice. */
 int lk_bls_set_ordered_histogram(lk_handle *h, int on);
+/* Stop criterion of the subspace iteration behind the PCA blocks of lk_pld_design_batch* / lk_pld_correct_batch
+ * (DesignMatrix.pca inside PLDCorrector.create_design_matrix, correctors/designmatrix.py:252-282): residual
+ * ||C r - theta r|| <= tol * theta_max * sqrt(k).  Default (tol = 0) 1e-7: two decades below the first visible change of the
+ * corrected flux on the reference goldens (profiles/r05_pld_tol_sweep.txt).  lk_pca_batch (whose OUTPUT is the basis) always
+ * uses 1e-10. */
+int lk_pld_set_eig_tolerance(lk_handle *h, double tol);
 void lk_destroy(lk_handle *h);
 /* Block until every kernel / copy issued through this handle's GPU has finished (hipDeviceSynchronize): for callers
  * of the *_dev entry points that do not hold a HIP runtime of their own. */

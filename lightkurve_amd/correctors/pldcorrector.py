@@ -319,14 +319,35 @@ def _all_finite(a):
         return bool(np.isfinite(a.sum(dtype=np.float64))) or bool(np.all(np.isfinite(a)))
 
 
-def _batch_cutout(c, ap, pm, bm):
+def _shared_mask(first, spec, sap=False):
+    """A mask every cutout of the batch shares — given as an array, or by a name that depends on the cutout's SHAPE only
+    ('all', 'empty'; None = all pixels for the PLD / background masks) — as a boolean image; None for the specs the reference
+    evaluates on each target-pixel file's own DATA ('threshold', 'background'; None for the photometric aperture =
+    ``create_threshold_mask(3)``, pldcorrector.py:99-107): those are resolved per cutout in ``_batch_cutout``."""
+    if spec is None:
+        return None if sap else first._parse_aperture_mask(None)
+    if isinstance(spec, str) and spec in ("threshold", "background"):
+        return None
+    return first._parse_aperture_mask(spec)
+
+
+def _batch_cutout(c, ap, pm, bm, specs):
     """One cutout's share of pld_correct_batch: what ``PLDCorrector(c, aperture_mask)`` keeps (the SAP light curve without its
     NaN cadences, pldcorrector.py:109-120) and the pixel series of the two apertures, without the object construction.
+    ``ap`` / ``pm`` / ``bm``: shared boolean images, or None = evaluate ``specs`` (aperture, PLD, background) on THIS cutout as
+    the per-object corrector does — the photometric aperture on the whole cutout (``PLDCorrector.__init__``), the other
+    two on the cutout without its NaN cadences (``create_design_matrix`` sees ``self.tpf = tpf[~nan_mask]``).
     Returns (time, flux float64, flux_err float64, flux float32, pld pixels (n, P), background pixels (n, Pb))."""
+    if ap is None:
+        ap = c._parse_aperture_mask(c.create_threshold_mask(3) if specs[0] is None else specs[0])
     flux, ferr = c._aperture_sums(ap)
     keep = ~(np.isnan(flux) | np.isnan(ferr))
     everything = bool(keep.all())
     n_all = len(c.time)
+    if pm is None or bm is None:
+        ck = c if everything else c[keep]
+        pm = ck._parse_aperture_mask(specs[1]) if pm is None else pm
+        bm = ck._parse_aperture_mask(specs[2]) if bm is None else bm
 
     def pixels(mask):
         px = c.flux.reshape(n_all, -1) if bool(np.all(mask)) else c.flux[:, mask]
@@ -344,8 +365,11 @@ def pld_correct_batch(cubes, aperture_mask="all", pld_aperture_mask="all", backg
                       pld_order=3, pca_components=16, spline_n_knots=None, spline_degree=5,
                       normalize_background_pixels=True, restore_trend=True, sigma=5, niters=5, device=0):
     """PLDCorrector(...).correct(...) for a list of same-shaped cutouts in ONE GPU call (``lk_pld_correct_batch``: design
-    matrices, regression and the spline block's share of the model; the design matrices never leave the device).  Masks are
-    given once and shared by the batch ("threshold" / "background" are evaluated on the first cutout).  The per-cutout host
+    matrices, regression and the spline block's share of the model; the design matrices never leave the device).  Masks
+    given as arrays (or 'all' / 'empty') are shared by the batch; the data-dependent ones — ``aperture_mask=None`` (the
+    reference's default, ``create_threshold_mask(3)``), 'threshold', 'background' — are evaluated on EVERY cutout, as a loop
+    over ``PLDCorrector(tpf, aperture_mask).correct(...)`` would (pldcorrector.py:99-107, 203-207); such PLD / background
+    masks must then select the same NUMBER of pixels in every cutout (one design-matrix width per call).  The per-cutout host
     work (aperture sums, NaN-cadence removal, pixel gathers, percentile knots) runs on the packing thread pool and lands in
     page-locked staging buffers.  Returns (corrected_flux[B, N], outlier_mask[B, N])."""
     from .. import packed
@@ -355,18 +379,24 @@ def pld_correct_batch(cubes, aperture_mask="all", pld_aperture_mask="all", backg
     if pca_components is None or pca_components < 1:
         raise NotImplementedError("pca_components must be >= 1 on the HIP path")
     first = cubes[0]
-    ap = first._parse_aperture_mask(first.create_threshold_mask(3) if aperture_mask is None else aperture_mask)
-    pm = first._parse_aperture_mask(pld_aperture_mask)
-    bm = first._parse_aperture_mask(background_aperture_mask)
+    specs = (aperture_mask, pld_aperture_mask, background_aperture_mask)
+    ap = _shared_mask(first, aperture_mask, sap=True)
+    pm = _shared_mask(first, pld_aperture_mask)
+    bm = _shared_mask(first, background_aperture_mask)
     for c in cubes:
         if c.shape[1:] != first.shape[1:]:
             raise ValueError("pld_correct_batch needs cutouts of one shape (got %s and %s)" % (c.shape, first.shape))
-    parts = packed._pmap(_batch_cutout, [(c, ap, pm, bm) for c in cubes])
+    parts = packed._pmap(_batch_cutout, [(c, ap, pm, bm, specs) for c in cubes])
     n = len(parts[0][0])
     if any(len(p[0]) != n for p in parts):
         raise ValueError("pld_correct_batch needs cutouts with the same number of valid cadences")
     B, P, Pb = len(parts), parts[0][4].shape[1], parts[0][5].shape[1]
-    shared = parts[0][5] is parts[0][4]
+    if any(p[4].shape[1] != P or p[5].shape[1] != Pb for p in parts):
+        raise ValueError("pld_correct_batch: the per-cutout '%s' / '%s' masks select different numbers of pixels (%s PLD, %s "
+                         "background); pass masks of one size or correct these cutouts one by one"
+                         % (pld_aperture_mask, background_aperture_mask, sorted({p[4].shape[1] for p in parts}),
+                            sorted({p[5].shape[1] for p in parts})))
+    shared = all(p[5] is p[4] for p in parts)
     if spline_n_knots is None:
         spline_n_knots = int(n / 50)
 

@@ -129,6 +129,13 @@ int lk_bls_set_ordered_histogram(lk_handle *h, int on) {
     return LK_OK;
 }
 
+int lk_pld_set_eig_tolerance(lk_handle *h, double tol) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(tol >= 0.0 && tol < 1.0, "tolerance must be in [0, 1) (0 = the default)");
+    h->pld_eig_tol = tol;
+    return LK_OK;
+}
+
 void lk_destroy(lk_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);

@@ -1836,7 +1836,8 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
 // top-k eigenpairs of the B Gram matrices G (P x P, leading dimension ldg) -> V (B x P x k), lam (B x k), both allocated
 // from ws.  mirror: G holds the upper 64 x 64 blocks only (gram_plain_launch) and is completed in place first.
 static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool products, bool mirror, double **V_out,
-                    double **lam_out, hipStream_t stream, Arena &ws, const float *G32 = nullptr, double tol = PLD_EIG_TOL) {
+                    double **lam_out, hipStream_t stream, Arena &ws, const float *G32 = nullptr, double tol = -1.0) {
+    if (!(tol > 0.0)) tol = h->pld_eig_tol > 0.0 ? h->pld_eig_tol : PLD_EIG_TOL;   // (lk_pld_set_eig_tolerance)
     constexpr int direct_max = PLD_DIRECT_MAX;
     // Convergence: || C r - theta r || <= eig_tol * theta_max * sqrt(k) over the k wanted pairs (PLD_EIG_TOL / PCA_EIG_TOL above).
 #ifdef LK_PLD_DEBUG   // development builds: LK_PLD_TOL sweeps the stop (tools/pld_tol_sweep.py -> profiles/r05_pld_tol_sweep.txt)
@@ -1983,7 +1984,7 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
 // PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
 static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
                      int col0, hipStream_t stream, Arena &ws, bool centred = false, bool products = false,
-                     double tol = PLD_EIG_TOL) {
+                     double tol = -1.0) {
     if (!centred) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
     const int KB = (P + 63) / 64, ldg = KB * 64;
     double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);

@@ -214,29 +214,92 @@ def test_check_sorted_over_thread_chunks():
 
 
 def test_result_buffers_are_recycled_only_when_released():
-    """_capi.result_empty hands out views of a few long-lived buffers: the same memory again once every view of the previous
-    result is gone, different memory while the caller still holds any view of it; small results are plain numpy arrays."""
+    """_capi.result_empty places large results in recycled page-locked blocks.  A block is handed out again only after the
+    array, every view of it AND every buffer export of it (memoryview, np.frombuffer over it) has been garbage collected —
+    numpy's own ownership rule (the old `sys.getrefcount` test did not see exports); idle blocks are capped
+    and `release_pinned_pool()` frees them.  The pool logic runs here over malloc'd blocks (no GPU: no pinned memory)."""
+    import ctypes
+    import gc
     from lightkurve_amd import _capi
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = ctypes.c_void_p, [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    freed = []
+
+    def free(addr):
+        freed.append(addr)
+        libc.free(addr)
+
     n = 1 << 20
-
-    def addr(x):
-        return x.__array_interface__["data"][0]
-
-    a = _capi.result_empty(n)
-    first = addr(a)
-    keep = a[5:100]
-    del a
-    b = _capi.result_empty(n)
-    assert addr(b) != first                         # `keep` still views the first buffer
-    del keep
-    c = _capi.result_empty((2, n // 2))
-    assert addr(c) == first and c.shape == (2, n // 2) and c.dtype == np.float64
-    d = _capi.result_empty((4, n))                  # larger than any idle buffer: a new one
-    assert addr(d) not in (first, addr(b)) and d.nbytes == 32 * n
-    assert _capi.result_empty(10).base is None
-    import os
-    os.environ["LK_RESULT_POOL"] = "0"
+    pool = _capi._ResultPool(libc.malloc, free, idle_limit_bytes=24 * n)
+    saved = _capi._RESULT_POOL
+    _capi._RESULT_POOL = pool
     try:
-        assert _capi.result_empty(n).base is None
+        def addr(x):
+            return x.__array_interface__["data"][0]
+
+        a = _capi.result_empty(n)
+        first = addr(a)
+        a[:] = 1.0
+        keep = a[5:100]
+        del a
+        gc.collect()
+        b = _capi.result_empty(n)
+        assert addr(b) != first and pool.leased == 2        # `keep` still views the first block
+        del keep
+        gc.collect()
+        c = _capi.result_empty((2, n // 2))
+        assert addr(c) == first and c.shape == (2, n // 2) and c.dtype == np.float64
+        # a buffer export without any ndarray reference blocks reuse too
+        mv = memoryview(c)
+        del c
+        gc.collect()
+        d = _capi.result_empty(n)
+        assert addr(d) not in (first, addr(b))
+        raw = np.frombuffer(mv, dtype=np.uint8)
+        del mv
+        gc.collect()
+        assert addr(_capi.result_empty(n)) != first          # ... and so does an array built over the export
+        assert first not in [a_ for _c, a_ in pool.idle]
+        del raw
+        gc.collect()
+        assert first in [a_ for _c, a_ in pool.idle]         # only now is the block idle again
+        e = _capi.result_empty(n)
+        big = _capi.result_empty((4, n))                     # larger than any idle block: a new one
+        assert addr(big) not in (first, addr(b), addr(d)) and big.nbytes == 32 * n
+        # the idle cap: a returned block beyond it is freed at once, not kept
+        del big, e, d, b
+        gc.collect()
+        assert pool.leased == 0 and pool.idle_bytes() <= 24 * n and len(freed) >= 1
+        _capi.release_pinned_pool()
+        assert pool.idle_bytes() == 0
+        assert _capi.result_empty(10).base is None           # small results are plain numpy arrays
+        import os
+        os.environ["LK_RESULT_POOL"] = "0"
+        try:
+            assert _capi.result_empty(n).base is None
+        finally:
+            del os.environ["LK_RESULT_POOL"]
     finally:
-        del os.environ["LK_RESULT_POOL"]
+        _capi._RESULT_POOL = saved
+
+
+def test_staging_pool_is_per_thread():
+    """_capi.pinned_pool keys its staging buffers by (thread, key): two threads packing concurrently never share one
+    (ADVICE r5).  Without a GPU runtime the allocation itself fails — then there is nothing to share either."""
+    import threading
+    from lightkurve_amd import _capi
+    out = {}
+
+    def work(name):
+        try:
+            out[name] = _capi.pinned_pool("t:x", 1000).__array_interface__["data"][0]
+        except (OSError, RuntimeError, MemoryError) as e:
+            out[name] = repr(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in ("a", "b")]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    if all(isinstance(v, int) for v in out.values()):
+        assert out["a"] != out["b"]
+    assert all(k[1] == "t:x" and isinstance(k[0], int) for k in _capi._POOL if isinstance(k, tuple) and k[1] == "t:x")

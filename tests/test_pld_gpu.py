@@ -277,3 +277,85 @@ def test_batch_front_end_matches_the_per_object_corrector():
     with pytest.raises(ValueError):
         pld_correct_batch(cubes + [PixelCube(cubes[0].time[:-1], cubes[0].flux[:-1], cubes[0].flux_err[:-1])], pld_order=2,
                           pca_components=8)
+
+
+def test_batch_resolves_data_dependent_masks_per_cutout():
+    """``aperture_mask=None`` (the reference's default: ``create_threshold_mask(3)`` of EACH target-pixel file,
+    pldcorrector.py:99-107), 'threshold' and 'background' are functions of a cutout's own pixels — the batch must give every
+    cutout the SAP aperture (and NaN-cadence set) its own ``PLDCorrector(tpf)`` would, not the first cutout's."""
+    from lightkurve_amd import synth
+    cubes = []
+    for i in range(3):
+        t, flux, err, _ = synth.pld_cutout(4, 70 + i, n=700, npix=9)
+        sh = i - 1                                     # the star sits on a different pixel in every cutout
+        cubes.append(PixelCube(t, np.roll(flux, (sh, -sh), axis=(1, 2)), np.roll(err, (sh, -sh), axis=(1, 2)), mission="K2"))
+    masks = [c.create_threshold_mask(3) for c in cubes]
+    assert not (np.array_equal(masks[0], masks[1]) and np.array_equal(masks[0], masks[2]))
+    corrected, outl = pld_correct_batch(cubes, aperture_mask=None, pld_order=2, pca_components=8)
+    for i, c in enumerate(cubes):
+        pld = PLDCorrector(c)                          # aperture_mask=None -> this cutout's own threshold mask
+        assert np.array_equal(pld.aperture_mask, masks[i])
+        clc = pld.correct(pld_order=2, pca_components=8, pld_aperture_mask="all", background_aperture_mask="all",
+                          normalize_background_pixels=True)
+        assert np.array_equal(outl[i], pld.outlier_mask), i
+        assert np.max(np.abs(corrected[i] - clc.flux)) <= 1e-9 * np.median(clc.flux), i
+    # the order of the batch does not matter any more (before: every cutout got cubes[0]'s aperture)
+    c2, _ = pld_correct_batch(cubes[::-1], aperture_mask=None, pld_order=2, pca_components=8)
+    assert np.array_equal(c2[::-1], corrected)
+    # data-dependent PLD / background masks: per cutout too; one design-matrix width per call
+    nb = [int((~c.create_threshold_mask(threshold=0, reference_pixel=None)).sum()) for c in cubes]
+    if len(set(nb)) > 1:
+        with pytest.raises(ValueError, match="different numbers of pixels"):
+            pld_correct_batch(cubes, aperture_mask=None, background_aperture_mask="background", pld_order=2, pca_components=8)
+    else:
+        cb, ob = pld_correct_batch(cubes, aperture_mask=None, background_aperture_mask="background", pld_order=2, pca_components=8)
+        for i, c in enumerate(cubes):
+            pld = PLDCorrector(c)
+            clc = pld.correct(pld_order=2, pca_components=8, pld_aperture_mask="all", background_aperture_mask="background",
+                              normalize_background_pixels=True)
+            assert np.array_equal(ob[i], pld.outlier_mask) and np.max(np.abs(cb[i] - clc.flux)) <= 1e-9 * np.median(clc.flux)
+
+
+def _pld_first_block(pix32, flux32, k, N):
+    """X[:, :k] of a first-order PLD design matrix (PCA(PCA(pixels / flux)), pldcorrector.py:233-262) for one cutout."""
+    t = np.linspace(0.0, 30.0, N)
+    nkn, deg = 8, 3
+    knots = np.concatenate([[t.min()], np.percentile(t, np.linspace(0, 100, nkn - deg - 1 + 2)[1:-1]), [t.max()]])
+    X, _ = _capi.pld_design_batch(pix32[None], pix32[None, :, :4], flux32[None], t[None], knots[None], 1, k, deg, True)
+    return X[0][:, :k]
+
+
+def test_pld_pca_block_backward_error_on_a_near_degenerate_spectrum():
+    """the PLD blocks' subspace iteration stops at a relative residual of 1e-7 (pld.hip PLD_EIG_TOL; the goldens
+    do not move down to 1e-6) — bound the SUBSPACE error itself where it is hardest: singular values 8, 9 and 10 agree to
+    1e-4, so a principal-angle test against an SVD is ill-posed there, but the backward error is not: with G = A A^T of the
+    centred float32 ratios and Q the returned basis, ||G Q - Q (Q^T G Q)||_F <= 1e-6 ||G||_2 sqrt(k) (stated), Q orthonormal to
+    1e-10.  A well-separated spectrum is then compared with the exact SVD: ||P_svd - P_got||_2 <= 1e-6.  P = 180 columns >
+    138: the blocks take pld_topk_eig_kernel, not the direct tridiagonal solver."""
+    rng = np.random.default_rng(17)
+    N, P, k = 900, 180, 8
+    U0 = np.linalg.qr(rng.standard_normal((N, P)))[0]
+    V0 = np.linalg.qr(rng.standard_normal((P, P)))[0]
+    flux = (1000.0 * (1.0 + 0.02 * np.sin(np.linspace(0, 20, N)))).astype(np.float32)
+    h = _capi.Handle.get(0)
+    for name, s in (("near-degenerate", np.r_[5, 4.5, 4, 3.5, 3, 2.5, 2.0, 1.5, 1.4999, 1.4998, 0.3 * rng.random(P - 10)]),
+                    ("separated", np.r_[5, 4.5, 4, 3.5, 3, 2.5, 2.0, 1.5, 0.3 * rng.random(P - 8)])):
+        A = (U0 * s) @ V0.T
+        pix32 = ((1.0 + 0.01 * A) * flux[:, None].astype(np.float64)).astype(np.float32)
+        ratio = (pix32 / flux[:, None]).astype(np.float64)            # float32 division, as the reference's numpy does
+        Ac = ratio - ratio.mean(axis=0)
+        G = Ac @ Ac.T
+        Us, ss, _ = np.linalg.svd(Ac, full_matrices=False)
+        for tol in (0.0, 1e-10):
+            h.pld_set_eig_tolerance(tol)
+            try:
+                Q = _pld_first_block(pix32, flux, k, N)
+            finally:
+                h.pld_set_eig_tolerance(0.0)
+            assert np.max(np.abs(Q.T @ Q - np.eye(k))) < 1e-10, name
+            R = G @ Q - Q @ (Q.T @ G @ Q)
+            bound = (1e-6 if tol == 0.0 else 1e-8) * ss[0] ** 2 * np.sqrt(k)
+            assert np.linalg.norm(R) <= bound, (name, tol, np.linalg.norm(R) / (ss[0] ** 2 * np.sqrt(k)))
+            assert np.trace(Q.T @ G @ Q) >= np.sum(ss[:k] ** 2) * (1 - 1e-5), name
+            if name == "separated":
+                assert np.linalg.norm(Us[:, :k] @ Us[:, :k].T - Q @ Q.T, 2) <= 1e-6
