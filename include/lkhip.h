@@ -372,9 +372,10 @@ int lk_bls_batch_dev(lk_handle *h, int B, const int64_t *n_off_host, const doubl
                      const double *duration_host, int nD, int oversample, int use_likelihood, double *out7,
                      void *stream);
 
-/* Host-only helper (no GPU): the longest period lk_bls_batch admits for these durations and this oversample — the kernels keep
- * a period's phase bins (period / (min duration / oversample) of them) in LDS.  astropy's bls_fast has no such limit: the seam
- * (lightkurve_amd.seams) hands longer periods to it and merges the rows. */
+/* Host-only helper (no GPU): the longest period whose phase bins (period / (min duration / oversample) of them) the LDS
+ * kernels hold for these durations and this oversample.  Longer periods are accepted all the same (astropy's bls_fast has no
+ * limit): they run a global-memory kernel, bit-identical, ~100 x the cost per (target, period) — a multi-year baseline
+ * searched with short durations. */
 int lk_bls_max_period(const double *duration, int nD, int oversample, double *max_period);
 
 /* ---- RegressionCorrector: Gaussian-prior weighted least squares, iterated with sigma clipping ----------

@@ -685,7 +685,8 @@ def bls_batch(t, y, ivar, n_off, period, duration, oversample=10, use_likelihood
 
 
 def bls_max_period(duration, oversample=10):
-    """The longest period ``bls_batch`` admits for these durations (its phase bins live in LDS); host-only."""
+    """The longest period the LDS kernels of ``bls_batch`` take for these durations; longer ones run the (slower, bit-identical)
+    global-memory kernel.  Host-only."""
     load_library()
     duration = _f64(np.atleast_1d(duration)).ravel()
     out = ctypes.c_double(0.0)

@@ -861,6 +861,174 @@ __global__ __launch_bounds__(64) void bls_selftest_kernel(int *__restrict__ bad)
 // The LDS plan of a team: the packed duration tables + 16 B per phase bin (ya | wa) + the block maxima.  bls_plan_max_bins
 // answers "how many phase bins fit" for a set of durations — bls_launch's own limit and lk_bls_max_period's answer (the
 // seam into astropy sends longer periods to the original implementation: methods.bls_fast has no such limit).
+
+// ------------------------------------------------------------------------------------------------ wide periods
+// Periods whose phase bins do not fit LDS (period / (min duration / oversample) beyond ~9 000 bins: a multi-year baseline
+// searched with short durations) — astropy's run_bls has no such limit, so neither may the seam (round 5 merged those rows
+// from astropy on the CPU).  One 1024-thread workgroup per (target, period), bins in a global-memory slab of the
+// workgroup's own, every step arranged so that the bits are the reference's:
+//   histogram  thread j OWNS the bins [j c, (j + 1) c): the cadences pass by in order, 2048 at a time through LDS (bin
+//              index, y * ivar, ivar), and every thread adds the ones that fall into its range — each bin accumulates in
+//              cadence order with no atomics at all (N compares per thread; the price of a path that runs for a handful
+//              of periods per search)
+//   prefix     2048-bin tiles through LDS, one lane per array runs the sequential chain with the carry in a register
+//   scan       every (duration, start bin) candidate with the reference's exact arithmetic, durations in the CALLER's order,
+//              a thread's start bins ascending: "first best wins" per thread, then (objective desc, duration index asc,
+//              start bin asc) across threads — the reference's loop order
+// ~0.1-1 ms per (target, period): 100 x the LDS kernels' cost per period, for periods they cannot take at all.
+constexpr int BLSW_NT = 1024, BLSW_CH = 2048;
+__global__ __launch_bounds__(BLSW_NT) void bls_wide_kernel(const double *__restrict__ tm, const double2 *__restrict__ yw,
+                                                            const int64_t *__restrict__ n_off,
+                                                            const BlsStats *__restrict__ stats,
+                                                            const double *__restrict__ period, const int *__restrict__ pidx,
+                                                            int n_wide, int64_t nP, int B, const int *__restrict__ dur_caller,
+                                                            int n_dur, double bin_duration, int oversample, int obj_flag,
+                                                            double *__restrict__ out7, double *__restrict__ slabs,
+                                                            size_t cap) {
+    __shared__ int s_ind[BLSW_CH];
+    __shared__ double s_y[BLSW_CH], s_w[BLSW_CH];
+    __shared__ BlsBest s_best[BLSW_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *ya = slabs + (size_t)blockIdx.x * 2 * cap, *wa = ya + cap;
+    const long long pairs = (long long)B * n_wide;
+    for (long long pair = blockIdx.x; pair < pairs; pair += gridDim.x) {
+        const int target = (int)(pair / n_wide), p = pidx[pair % n_wide];
+        const double P = period[p], invP = 1.0 / P;
+        const int64_t lo = n_off[target];
+        const int N = (int)(n_off[target + 1] - lo);
+        const BlsStats st = stats[target];
+        const double sum_y = st.sum_y, sum_ivar = st.sum_ivar;
+        const int n_bins = (int)(ceil(P / bin_duration)) + oversample;
+        for (int i = tid; i <= n_bins; i += BLSW_NT) ya[i] = 0.0, wa[i] = 0.0;
+        __syncthreads();
+        // ---- histogram
+        const int c = (n_bins + 1 + BLSW_NT - 1) / BLSW_NT;
+        const int b_lo = tid * c, b_hi = min(b_lo + c, n_bins + 1);
+        for (int c0 = 0; c0 < N; c0 += BLSW_CH) {
+            const int cn = min(BLSW_CH, N - c0);
+            for (int i = tid; i < cn; i += BLSW_NT) {
+                double k, r;
+                fold_exact(tm[lo + c0 + i], P, invP, &k, &r);
+                const double2 v = yw[lo + c0 + i];
+                s_ind[i] = bin_of(r, bin_duration);
+                s_y[i] = v.x;
+                s_w[i] = v.y;
+            }
+            __syncthreads();
+            if (b_lo < b_hi)
+                for (int i = 0; i < cn; ++i) {
+                    const int ind = s_ind[i];
+                    if (ind >= b_lo && ind < b_hi) {
+                        ya[ind] += s_y[i];
+                        wa[ind] += s_w[i];
+                    }
+                }
+            __syncthreads();
+        }
+        // ---- wrap (sources 1 .. oversample and destinations n_bins - oversample .. n_bins - 1 are disjoint: n_bins is large)
+        for (int n = 1 + tid; n <= oversample; n += BLSW_NT) {
+            const int ind = n_bins - oversample + n - 1;
+            ya[ind] = ya[n];
+            wa[ind] = wa[n];
+        }
+        __syncthreads();
+        // ---- inclusive prefix sums, sequential like the reference
+        double cy = ya[0], cw = wa[0];   // (used by threads 0 and 64 only)
+        for (int t0 = 1; t0 <= n_bins; t0 += BLSW_CH) {
+            const int tn = min(BLSW_CH, n_bins + 1 - t0);
+            for (int i = tid; i < tn; i += BLSW_NT) s_y[i] = ya[t0 + i], s_w[i] = wa[t0 + i];
+            __syncthreads();
+            if (tid == 0)
+                for (int i = 0; i < tn; ++i) {
+                    cy = s_y[i] + cy;
+                    s_y[i] = cy;
+                }
+            if (tid == 64)
+                for (int i = 0; i < tn; ++i) {
+                    cw = s_w[i] + cw;
+                    s_w[i] = cw;
+                }
+            __syncthreads();
+            for (int i = tid; i < tn; i += BLSW_NT) ya[t0 + i] = s_y[i], wa[t0 + i] = s_w[i];
+            __syncthreads();
+        }
+        // ---- scan
+        double best = -INFINITY;
+        int bk = -1, bn = 0;
+        for (int k = 0; k < n_dur; ++k) {
+            const int dur = dur_caller[k], n_max = n_bins - dur;
+            for (int n = tid; n <= n_max; n += BLSW_NT) {
+                double y_in = ya[n + dur] - ya[n];
+                const double ivar_in = wa[n + dur] - wa[n];
+                double y_out = sum_y - y_in;
+                const double ivar_out = sum_ivar - ivar_in;
+                if ((ivar_in < DBL_EPSILON) || (ivar_out < DBL_EPSILON)) continue;
+                y_in /= ivar_in;
+                y_out /= ivar_out;
+                double obj;
+                if (obj_flag) {
+                    const double arg = y_out - y_in;
+                    obj = 0.5 * ivar_in * arg * arg;
+                } else {
+                    const double depth = y_out - y_in;
+                    const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+                    obj = depth / depth_err;
+                }
+                if (y_out >= y_in && obj > best) {
+                    best = obj;
+                    bk = k;
+                    bn = n;
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double oo = __shfl_xor(best, o);
+            const int ok = __shfl_xor(bk, o), on = __shfl_xor(bn, o);
+            const bool take = ok >= 0 && (bk < 0 || oo > best || (oo == best && (ok < bk || (ok == bk && on < bn))));
+            if (take) best = oo, bk = ok, bn = on;
+        }
+        if (lane == 0) s_best[wave] = BlsBest{best, bk, bn};
+        __syncthreads();
+        if (tid == 0) {
+            BlsBest w = s_best[0];
+            for (int i = 1; i < BLSW_NT / 64; ++i) {
+                const BlsBest o = s_best[i];
+                const bool take = o.k >= 0 && (w.k < 0 || o.obj > w.obj || (o.obj == w.obj && (o.k < w.k || (o.k == w.k && o.n < w.n))));
+                if (take) w = o;
+            }
+            const size_t stride = (size_t)B * (size_t)nP;
+            double *o = out7 + (size_t)target * (size_t)nP + (size_t)p;
+            if (w.k < 0) {
+                o[0] = -INFINITY;
+                for (int f = 1; f < 7; ++f) o[f * stride] = 0.0;
+            } else {
+                const int dur = dur_caller[w.k], n = w.n;
+                double y_in = ya[n + dur] - ya[n];
+                const double ivar_in = wa[n + dur] - wa[n];
+                double y_out = sum_y - y_in;
+                const double ivar_out = sum_ivar - ivar_in;
+                y_in /= ivar_in;
+                y_out /= ivar_out;
+                const double arg = y_out - y_in;
+                const double log_like = 0.5 * ivar_in * arg * arg;
+                const double depth = y_out - y_in;
+                const double depth_err = sqrt(1.0 / ivar_in + 1.0 / ivar_out);
+                const double depth_snr = depth / depth_err;
+                const double duration = dur * bin_duration;
+                const double phase = fmod(n * bin_duration + 0.5 * duration + st.min_t, P);
+                o[0] = w.obj;
+                o[1 * stride] = depth;
+                o[2 * stride] = depth_err;
+                o[3 * stride] = duration;
+                o[4 * stride] = phase;
+                o[5 * stride] = depth_snr;
+                o[6 * stride] = log_like;
+            }
+        }
+        __syncthreads();   // the slab is reused by this workgroup's next (target, period)
+    }
+}
+
 static size_t bls_region_of(int cap, int nw_) {
     return ((size_t)cap * 16 + 48 + (size_t)nw_ * 16 + (size_t)((cap >> 3) + (cap >> 6) + 4) * 8 + 15) & ~(size_t)15;
 }
@@ -962,18 +1130,22 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     std::iota(order.begin(), order.end(), 0);
     auto nbins_of = [&](int p) { return (int)(std::ceil(period_host[p] / bin_duration)) + oversample; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return period_host[a] > period_host[b]; });
+    LK_REQUIRE(max_period / bin_duration < 1.0e9, "max period / (min duration / oversample) = %.3g phase bins: too many",
+               max_period / bin_duration);
     const int max_bins = nbins_of(order[0]);
     const size_t tab_bytes16 = tab_bytes;
     // LDS of one team: ya | wa | header | s_best[NW] | block maxima (bls_team_body's carve)
     auto region_of = [&](int cap, int nw_) { return bls_region_of(cap, nw_); };
-    LK_REQUIRE(tab_bytes16 + region_of((max_bins + 2) & ~1, 16) <= 156 * 1024,
-               "max period / (min duration / oversample) gives %d phase bins; the LDS plan holds at most %d "
-               "(lk_bls_max_period names the longest period these durations admit)", max_bins, bls_max_bins_for(tab_bytes16));
+    // periods whose bins do not fit LDS (the head of `order`) take bls_wide_kernel: bins in a global-memory slab per workgroup
+    int n_wide = 0;
+    while (n_wide < (int)nP && tab_bytes16 + region_of((nbins_of(order[n_wide]) + 2) & ~1, 16) > 156 * 1024) ++n_wide;
+    const size_t wide_cap = n_wide ? (((size_t)max_bins + 2 + 31) & ~(size_t)31) : 0;
+    const int wide_slabs = n_wide ? (int)std::min<long long>((long long)B * n_wide, 2 * (long long)h->num_cu) : 0;
 
     const size_t ntot = (size_t)n_off_host[B];
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(BlsStats) + 3 * (ntot * 8 + 256) +
-                           (size_t)nP * 4 + dur_tab.size() * 4 + 8192);
+                           (size_t)nP * 4 + dur_tab.size() * 4 + (size_t)nd * 4 + (size_t)wide_slabs * 2 * wide_cap * 8 + 8192);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
     BlsStats *d_stats = (BlsStats *)h->ws.alloc((size_t)B * sizeof(BlsStats));
@@ -981,6 +1153,10 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
     double2 *d_yw = (double2 *)h->ws.alloc(ntot * 16);
     int *d_pidx = (int *)h->ws.alloc((size_t)nP * 4);
     int *d_dur = (int *)h->ws.alloc(dur_tab.size() * 4);
+    int *d_dur_caller = (int *)h->ws.alloc((size_t)nd * 4);
+    double *d_slabs = n_wide ? (double *)h->ws.alloc((size_t)wide_slabs * 2 * wide_cap * 8) : nullptr;
+    LK_REQUIRE(!n_wide || d_slabs, "workspace exhausted (wide-period slabs)");
+    LK_HIP_CHECK(hipMemcpyAsync(d_dur_caller, dur_bins.data(), (size_t)nd * 4, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_off, n_off_host, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_pidx, order.data(), (size_t)nP * 4, hipMemcpyHostToDevice, stream));
     LK_HIP_CHECK(hipMemcpyAsync(d_dur, dur_tab.data(), dur_tab.size() * 4, hipMemcpyHostToDevice, stream));
@@ -1037,7 +1213,11 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         LK_HIP_CHECK(hipEventCreate(&pe0));
         LK_HIP_CHECK(hipEventCreate(&pe1));
     }
-    size_t g0 = 0;
+    if (n_wide)
+        hipLaunchKernelGGL(bls_wide_kernel, dim3((unsigned)wide_slabs), dim3(BLSW_NT), 0, stream, d_tm, d_yw, d_off, d_stats,
+                           period_dev, d_pidx, n_wide, nP, B, d_dur_caller, nd, bin_duration, oversample,
+                           use_likelihood ? 1 : 0, out7, d_slabs, wide_cap);
+    size_t g0 = (size_t)n_wide;
     while (g0 < (size_t)nP) {
         const int head_bins = nbins_of(order[g0]);
         if (prof_on) LK_HIP_CHECK(hipEventRecord(pe0, stream));

@@ -518,10 +518,9 @@ class BoxLeastSquaresPeriodogram(Periodogram):
     def from_lightcurve(lc, device=0, **kwargs):
         """Same contract as the reference constructor: kwargs ``duration``, ``period``, ``minimum_period``,
         ``maximum_period``, ``frequency_factor``, ``time_unit``, ``objective``, ``oversample``, ``method``.
-        One limit the reference does not have: a period's phase bins (period / (shortest duration / oversample)) live in
-        LDS, so periods beyond ``_capi.bls_max_period(duration, oversample)`` raise a ValueError naming the limit (46 d for
-        0.05-d durations at oversample 10, 232 d for lightkurve's default 0.25 d); there is no CPU route in this class — the
-        lightkurve seam sends exactly those periods to astropy's own ``bls_fast``."""
+        No period limit, like the reference: periods whose phase bins (period / (shortest duration / oversample)) do not fit
+        LDS — beyond ``_capi.bls_max_period(duration, oversample)``: 46 d for 0.05-d durations at oversample 10 — run the
+        global-memory kernel (same bits, ~100 x the cost per period)."""
         plan = _bls_plan(lc, **kwargs)
         n = len(plan["t"])
         res = _capi.bls_batch(plan["t"], plan["y"], plan["ivar"], [0, n], plan["period"], plan["duration"],

@@ -12,7 +12,7 @@
       runs the exact kernels; so does one with ``Mfft`` != 4 or ``nterms`` 5..8 (the FFT kernels extirpolate with astropy's
       default Mfft = 4 and are instantiated for <= 4 terms): the result is then the sums astropy's approximation converges
       to, not its approximation error.
-* S2  ``astropy.timeseries.periodograms.bls.methods.bls_fast`` (reached from periodogram.py:1169).
+* S2  ``astropy.timeseries.periodograms.bls.methods.bls_fast`` (reached from periodogram.py:1169), every period on the device.
 * S3  ``lightkurve.lightcurve.LightCurve.flatten`` (lightcurve.py:943-1078): the mask / segmentation / savgol / clip /
       interpolation loop (:996-1063) is ONE call of lk_savgol_trend_batch; the object handling around it stays lightkurve's.
       Calls the kernel does not cover (extra ``savgol_filter`` keyword arguments, unsorted time) go to the original method.
@@ -137,37 +137,11 @@ def lombscargle_fast_hip(t, y, dy=None, f0=0, df=None, Nf=None, center_data=True
 
 # ------------------------------------------------------------------------------------------------ S2
 def bls_fast_hip(t, y, ivar, period, duration, oversample, use_likelihood):
-    """Signature of astropy's methods.bls_fast (bls/methods.py:55-95).  The kernels keep a period's phase bins in LDS; periods
-    beyond ``bls_max_period(duration, oversample)`` (a multi-year baseline searched with short durations) go to the original
-    compiled implementation, which has no such limit, and the rows are merged — every period is independent, and both
-    sides produce the same bits."""
-    be = _be()
-    period = np.ascontiguousarray(period, dtype=np.float64)
-    limit = None
-    if hasattr(be, "bls_max_period") and period.ndim == 1 and period.size:
-        try:
-            limit = be.bls_max_period(duration, oversample)
-        except ValueError:
-            limit = None          # (invalid durations: the kernel's own input checks raise the reference's error below)
-    if limit is not None:
-        far = period > limit
-        if far.any():
-            from astropy.timeseries.periodograms.bls import methods as bls_methods
-            orig = getattr(bls_methods, "_bls_fast_reference", None)
-            if orig is not None:
-                _fell_back("bls_fast", "%d of %d periods are longer than %.4g (%d phase bins per period is what LDS holds "
-                                       "for these durations)" % (int(far.sum()), period.size, limit,
-                                                                 int(round(limit / (np.min(duration) / oversample)))))
-                cpu = orig(t, y, ivar, period[far], duration, oversample, use_likelihood)
-                out = [np.empty(period.shape, dtype=np.asarray(c).dtype) for c in cpu]
-                for o, c in zip(out, cpu):
-                    o[far] = c
-                if (~far).any():
-                    res = be.bls_batch(t, y, ivar, [0, len(t)], period[~far], duration, oversample, use_likelihood)
-                    for o, k in zip(out, _capi.BLS_FIELDS):
-                        o[~far] = res[k][0]
-                return tuple(out)
-    res = be.bls_batch(t, y, ivar, [0, len(t)], period, duration, oversample, use_likelihood)
+    """Signature of astropy's methods.bls_fast (bls/methods.py:55-95).  Every period runs on the device: those whose phase
+    bins fit LDS in the team kernels, longer ones (a multi-year baseline searched with short durations) in the
+    global-memory kernel — same bits either way (round 5 merged the long ones from astropy's CPU implementation)."""
+    res = _be().bls_batch(t, y, ivar, [0, len(t)], np.ascontiguousarray(period, dtype=np.float64), duration, oversample,
+                          use_likelihood)
     return tuple(res[k][0] for k in _capi.BLS_FIELDS)
 
 

@@ -69,7 +69,7 @@ def run_all(lk):
     tb, yb, eb, _ = synth.bls_target(3, 9, 2500, cadence_days=10.0 / 1440.0)
     lcb = lk.LightCurve(time=tb + 2000.0, flux=yb, flux_err=eb)
     out["bls"] = lcb.to_periodogram(method="bls", period=np.linspace(0.7, 8, 500), duration=[0.05, 0.1, 0.2])   # S2
-    # periods beyond what the kernels' LDS plan holds for 0.05-d durations (46 d): those rows come from astropy's own bls_fast
+    # periods beyond what the kernels' LDS plan holds for 0.05-d durations (46 d): the global-memory kernel, same bits
     tl, yl, el, _ = synth.bls_target(3, 10, 6000, cadence_days=30.0 / 1440.0)
     out["bls_long_periods"] = lk.LightCurve(time=tl + 2000.0, flux=yl, flux_err=el).to_periodogram(
         method="bls", period=np.linspace(2.0, 60.0, 120), duration=[0.05, 0.1])

@@ -200,3 +200,42 @@ def test_ordered_histogram_fallback_is_bit_exact(golden):
     for name in _capi.BLS_FIELDS:
         if name != "transit_time":
             assert np.array_equal(slow[0][name][0], g["likelihood_" + name]), name
+
+
+@pytest.mark.parametrize("use_like", [True, False])
+def test_periods_beyond_the_lds_plan_bit_exact(use_like):
+    """Periods whose phase bins do not fit LDS (period > lk_bls_max_period: a long baseline searched with short durations)
+    run bls_wide_kernel — bins in global memory, owner-thread histogram, sequential prefix, exhaustive exact scan — and
+    must equal the oracle (pinned to astropy's compiled run_bls) bit for bit (`==`, stated) like every other period,
+    alone, mixed with LDS-sized periods in one call, for ragged batches and for unsorted times."""
+    rng = np.random.default_rng(23)
+    durations = np.array([0.02, 0.05, 0.033])                       # bin = 0.002 d at oversample 10 (caller's order kept)
+    limit = _capi.bls_max_period(durations, 10)
+    assert 5.0 < limit < 40.0
+    periods = np.concatenate([np.linspace(limit * 1.02, 3.5 * limit, 9), np.linspace(0.7, 0.98 * limit, 11)])
+    rng.shuffle(periods)
+    ts, ys, ws = [], [], []
+    for b, n in enumerate((2500, 1700, 3100)):
+        t = np.sort(rng.uniform(0.0, 400.0, n))
+        y = 1e-3 * rng.standard_normal(n)
+        p0, t0 = 0.6 * limit * (2.2 + b), 3.0 + b
+        y[np.abs((t - t0 + 0.5 * p0) % p0 - 0.5 * p0) < 0.04] -= 6e-3
+        if b == 1:                                                  # unsorted: the histogram is order-exact all the same
+            perm = rng.permutation(n)
+            t, y = t[perm], y[perm]
+        ts.append(t - t.min()), ys.append(y - np.median(y)), ws.append(rng.uniform(0.5, 2.0, n) * 1e6)
+    t, off = synth.pack_ragged(ts)
+    y, w = synth.pack_ragged(ys)[0], synth.pack_ragged(ws)[0]
+    res = _capi.bls_batch(t, y, w, off, periods, durations, 10, use_like)
+    for b in range(3):
+        ref = O.bls(ts[b], ys[b], ws[b], periods, durations, 10, use_like)
+        for k, r in zip(_capi.BLS_FIELDS, ref):
+            assert np.array_equal(res[k][b], r), (b, k)
+    only_wide = periods[periods > limit][:3]
+    one = _capi.bls_batch(ts[0], ys[0], ws[0], [0, len(ts[0])], only_wide, durations, 10, use_like)
+    ref = O.bls(ts[0], ys[0], ws[0], only_wide, durations, 10, use_like)
+    assert all(np.array_equal(one[k][0], r) for k, r in zip(_capi.BLS_FIELDS, ref))
+    # a period with several hundred thousand bins (1000 d at 0.002 d per bin): accepted, like astropy
+    far = _capi.bls_batch(ts[2], ys[2], ws[2], [0, len(ts[2])], [1000.0], durations, 10, use_like)
+    ref = O.bls(ts[2], ys[2], ws[2], np.array([1000.0]), durations, 10, use_like)
+    assert all(np.array_equal(far[k][0], r) for k, r in zip(_capi.BLS_FIELDS, ref))
