@@ -27,6 +27,10 @@
       the original methods, and so does ``pca_components=0`` — there the reference itself calls ``fbpca.pca(k=0)`` for the
       background block (pldcorrector.py:223), which fbpca rejects: the seam hands the call over unchanged.
       Every call handed back to a CPU implementation logs one ``log.debug`` line saying which seam and why.
+* §8(f)  ``Periodogram.smooth`` (periodogram.py:182-284, hence ``Periodogram.flatten`` :381-429) -> lk_pg_boxsmooth_batch /
+      lk_pg_logmedian_batch; ``LightCurve.estimate_cdpp`` (lightcurve.py:1764-1833) -> lk_savgol_trend_batch +
+      lk_sigma_clip_batch; ``overfit_metric_lombscargle`` (correctors/metrics.py:23-124; CBVCorrector's goodness scan calls it
+      per trial) -> its n_samples noise periodograms in one lk_ls_fast_batch call.
 
 ``backend`` is the module that provides the compute entry points (default: ``lightkurve_amd._capi``, i.e. the GPU).  The
 tests pass a stand-in to check the wiring against a real lightkurve on a machine without a GPU (tests/test_seams_cpu.py);
@@ -454,6 +458,163 @@ def _make_spline_builders(lk_dm_mod):
     return create_spline_matrix, create_sparse_spline_matrix
 
 
+
+# ------------------------------------------------------------------------------------------------ §8(f) rows: N2, N3, CDPP
+def _make_pg_smooth(lk_pg_mod):
+    """``Periodogram.smooth`` (periodogram.py:182-284; ``Periodogram.flatten`` :381-429 divides by its result): 'boxkernel' is
+    astropy's NaN-interpolating convolution with a Box1DKernel -> lk_pg_boxsmooth_batch (the kernel ARRAY stays astropy's
+    own); 'logmedian' is a Python ``while`` loop with one ``np.nanmedian`` per log-frequency window -> lk_pg_logmedian_batch
+    (the window bookkeeping — which depends on the grid only — is the reference loop's, run once)."""
+    import math
+    from .periodogram import _logmedian_windows
+    orig = lk_pg_mod.Periodogram.smooth
+    u = lk_pg_mod.u
+
+    def smooth(self, method="boxkernel", filter_width=0.1):
+        method = lk_pg_mod.validate_method(method, ["boxkernel", "logmedian"])
+        power = np.asarray(self.power.value, dtype=np.float64)
+        if method == "boxkernel":
+            if filter_width <= 0.0:
+                raise ValueError("the `filter_width` parameter must be larger than 0 for the 'boxkernel' method.")
+            try:
+                filter_width = u.Quantity(filter_width, self.frequency.unit)
+            except u.UnitConversionError:
+                raise ValueError("the `filter_width` parameter must have frequency units.")
+            if not self._is_evenly_spaced():
+                raise ValueError("the 'boxkernel' method requires the periodogram to have a grid of evenly spaced frequencies.")
+            fs = np.mean(np.diff(self.frequency))
+            kernel = np.asarray(lk_pg_mod.Box1DKernel(math.ceil((filter_width / fs).value)).array, dtype=np.float64)
+            if kernel.size > power.size:
+                _fell_back("Periodogram.smooth", "a %d-tap box over %d frequencies" % (kernel.size, power.size))
+                return orig(self, method=method, filter_width=filter_width)
+            smooth_power = _be().pg_boxsmooth_batch(power, kernel)[0]
+        else:
+            if isinstance(filter_width, u.Quantity):
+                raise ValueError("the 'logmedian' method requires a dimensionless value for `filter_width` in "
+                                 "log10(frequency) space.")
+            freq = np.asarray(self.frequency.value, dtype=np.float64)
+            if freq.size < 2 or not np.all(np.isfinite(freq)) or freq[0] <= 0 or np.any(np.diff(freq) < 0) or not filter_width > 0:
+                _fell_back("Periodogram.smooth", "frequency grid not positive / ascending, or filter_width <= 0")
+                return orig(self, method=method, filter_width=filter_width)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                smooth_power = _be().pg_logmedian_batch(power, *_logmedian_windows(freq, filter_width))[0]
+        smooth_pg = self.copy()
+        smooth_pg.power = u.Quantity(smooth_power, self.power.unit)
+        return smooth_pg
+
+    smooth.__doc__ = orig.__doc__
+    return smooth
+
+
+def _make_estimate_cdpp(lk_lightcurve_mod):
+    """``LightCurve.estimate_cdpp`` (lightcurve.py:1764-1833): flatten -> remove_outliers (astropy sigma_clip) ->
+    normalize("ppm") -> std of the running mean.  The flatten is lk_savgol_trend_batch, the clip lk_sigma_clip_batch; the
+    O(N) tail (one division, a cumulative sum, np.std) is the reference's own numpy, as in
+    ``lightkurve_amd.lightcurve.estimate_cdpp_batch``."""
+    orig = lk_lightcurve_mod.LightCurve.estimate_cdpp
+    running_mean = lk_lightcurve_mod.running_mean
+
+    def estimate_cdpp(self, transit_duration=13, savgol_window=101, savgol_polyorder=2, sigma=5.0):
+        if not isinstance(transit_duration, int):
+            raise ValueError("transit_duration must be an integer in units number of cadences, got {}.".format(transit_duration))
+        time = _plain(self.time.value)
+        flux = self.flux
+        fl = _plain(flux)
+        if hasattr(flux, "mask"):
+            fl = np.where(np.asarray(flux.mask, dtype=bool), np.nan, fl)
+        if len(time) < 2 or np.any(np.diff(time) < 0) or savgol_window % 2 != 1 or not np.any(np.isfinite(fl)):
+            _fell_back("LightCurve.estimate_cdpp", "unsorted time, even window or no finite flux")
+            return orig(self, transit_duration=transit_duration, savgol_window=savgol_window,
+                        savgol_polyorder=savgol_polyorder, sigma=sigma)
+        if savgol_polyorder >= savgol_window:
+            savgol_polyorder = savgol_window - 1
+        trend = _be().savgol_trend_batch(np.ascontiguousarray(time), np.ascontiguousarray(fl), [0, len(time)],
+                                         window_length=savgol_window, polyorder=savgol_polyorder)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            flat = fl / trend
+        clipped = _be().sigma_clip_batch(flat, [0, len(flat)], sigma=sigma, maxiters=5)
+        kept = flat[~clipped]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ppm = kept / np.nanmedian(kept) * 1e6                       # normalize("ppm"), :1283-1292
+        # the reference returns what np.std makes of its ppm-valued Quantity column: a Quantity in ppm
+        return lk_lightcurve_mod.u.Quantity(np.std(running_mean(data=ppm, window_size=transit_duration)), "ppm")
+
+    estimate_cdpp.__doc__ = orig.__doc__
+    return estimate_cdpp
+
+
+def _make_overfit_metric(lk_metrics_mod):
+    """``overfit_metric_lombscargle`` (correctors/metrics.py:23-124): per sample three default periodograms — the original
+    light curve, the corrected one on the same grid, a white-noise light curve at the level of the corrected uncertainties.
+    The first two do not depend on the sample (computed once, through seam S1); the ``n_samples`` noise periodograms share
+    the original's grid (a default grid is a function of the times alone) and are ONE lk_ls_fast_batch call.  The noise is
+    drawn from the global ``np.random`` stream in the reference's order: same seed, same metric."""
+    orig = lk_metrics_mod.overfit_metric_lombscargle
+
+    def overfit_metric_lombscargle(original_lc, corrected_lc, n_samples=10):
+        orig_lc = original_lc.copy().remove_nans().normalize()
+        orig_lc -= 1.0
+        corrected_lc = corrected_lc.copy().remove_nans().normalize()
+        corrected_lc -= 1.0
+        if len(corrected_lc) == 0:
+            return 1.0
+        n = len(orig_lc)
+        if n < 2 or int(n_samples) < 1:
+            _fell_back("overfit_metric_lombscargle", "fewer than two cadences / no samples")
+            return orig(original_lc, corrected_lc, n_samples=n_samples)
+        pg_orig = orig_lc.to_periodogram()
+        pg_corr = corrected_lc.to_periodogram(frequency=pg_orig.frequency)
+        import astropy.units as u
+        f_day = np.asarray(pg_orig.frequency.to(1 / u.day).value, dtype=np.float64)
+        from .periodogram import exact_grid
+        grid = exact_grid(f_day) if len(f_day) > 1 else None
+        mean_unc = np.nanmean(_plain(corrected_lc.flux_err))
+        noise = np.stack([(np.random.randn(n, 1) * mean_unc).T[0] for _ in range(int(n_samples))])
+        if grid is None or str(getattr(pg_orig, "ls_method", "fast")) != "fast":
+            # (a default grid is regular; anything else keeps the reference's per-sample loop, each call through seam S1)
+            Lc = type(original_lc)
+            powers = [np.asarray(Lc(time=orig_lc.time, flux=noise[k], flux_err=np.zeros(n)).to_periodogram().power)
+                      for k in range(int(n_samples))]
+        else:
+            t = _plain(orig_lc.time.value)
+            trel = np.tile(t - t[0], int(n_samples))
+            off = np.arange(int(n_samples) + 1, dtype=np.int64) * n
+            powers = _be().ls_fast_batch(trel, noise.ravel(), off, f0=grid[0], df=grid[1], M=len(f_day),
+                                         normalization="lk_amplitude")
+        change = np.array(pg_corr.power) - np.array(pg_orig.power)
+        change = change[~np.isnan(change)]
+        n_up = len(np.nonzero(change > 0.0)[0])
+        per_iter = []
+        for k in range(int(n_samples)):
+            mean_noise_power = np.nanmean(np.asarray(powers[k]))
+            if n_up == 0:
+                per_iter.append(0.0)
+            else:
+                den = n_up * mean_noise_power
+                per_iter.append(np.inf if den == 0 else np.sum(change[change > 0.0]) / den)
+        metric = np.mean(per_iter)
+        with np.errstate(over="ignore"):
+            return 2.0 / (1 + np.exp(np.max([metric, 0.0])))
+
+    overfit_metric_lombscargle.__doc__ = orig.__doc__
+    return overfit_metric_lombscargle
+
+
+_METRIC_MODULES = ("lightkurve.correctors.metrics", "lightkurve.correctors.cbvcorrector", "lightkurve.correctors.corrector")
+
+
+def _set_overfit_metric(fn):
+    """imported by name into cbvcorrector.py:33 and corrector.py:9: every namespace that holds it gets the replacement."""
+    import importlib
+    for modname in _METRIC_MODULES:
+        try:
+            mod = importlib.import_module(modname)
+        except ImportError:
+            continue
+        if hasattr(mod, "overfit_metric_lombscargle"):
+            mod.overfit_metric_lombscargle = fn
+
+
 _SPLINE_MODULES = ("lightkurve.correctors.designmatrix", "lightkurve.correctors.pldcorrector",
                    "lightkurve.correctors.sffcorrector", "lightkurve.correctors")
 
@@ -537,6 +698,17 @@ def install(backend=None, lightkurve=True, full_loop=True):
     _ORIG.setdefault("create_sparse_spline_matrix", lk_dm.create_sparse_spline_matrix)
     _set_spline_builders(*_make_spline_builders(lk_dm))
     done += ["lightkurve:create_spline_matrix", "lightkurve:create_sparse_spline_matrix"]
+    # SURVEY §8(f) rows N2 / N3 and the CDPP metric (round 6)
+    import lightkurve.periodogram as lk_pg
+    import lightkurve.correctors.metrics as lk_met
+    _ORIG.setdefault("pg_smooth", lk_pg.Periodogram.smooth)
+    _ORIG.setdefault("estimate_cdpp", lk_lc.LightCurve.estimate_cdpp)
+    _ORIG.setdefault("overfit_metric", lk_met.overfit_metric_lombscargle)
+    lk_pg.Periodogram.smooth = _make_pg_smooth(lk_pg)
+    lk_lc.LightCurve.estimate_cdpp = _make_estimate_cdpp(lk_lc)
+    _set_overfit_metric(_make_overfit_metric(lk_met))
+    done += ["lightkurve:Periodogram.smooth", "lightkurve:LightCurve.estimate_cdpp",
+             "lightkurve:overfit_metric_lombscargle"]
     return done
 
 
@@ -573,3 +745,10 @@ def uninstall():
         lk_dm.DesignMatrix.standardize = _ORIG["dm_standardize"]
     if "create_spline_matrix" in _ORIG:
         _set_spline_builders(_ORIG["create_spline_matrix"], _ORIG["create_sparse_spline_matrix"])
+    if "pg_smooth" in _ORIG:
+        import lightkurve.periodogram as lk_pg
+        lk_pg.Periodogram.smooth = _ORIG["pg_smooth"]
+    if "estimate_cdpp" in _ORIG:
+        lk_lc.LightCurve.estimate_cdpp = _ORIG["estimate_cdpp"]
+    if "overfit_metric" in _ORIG:
+        _set_overfit_metric(_ORIG["overfit_metric"])

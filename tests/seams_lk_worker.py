@@ -110,6 +110,20 @@ def run_all(lk):
     Sd[rng.random(Sd.shape) < 0.03] = 0.0
     Sd[:, 2] = 1.5
     out["dm_standardize"] = DesignMatrix(pd.DataFrame(Sd), name="S").standardize().values
+    # SURVEY 8(f) rows through the reference's own classes (round 6): Periodogram.smooth / .flatten, estimate_cdpp, the
+    # over-fitting metric
+    pg_psd = lc.to_periodogram(normalization="psd", minimum_frequency=5, maximum_frequency=2500)
+    out["pg_smooth_box"] = pg_psd.smooth(method="boxkernel", filter_width=40.0)
+    out["pg_smooth_logmedian"] = pg_psd.smooth(method="logmedian", filter_width=0.05)
+    out["pg_flatten_snr"] = pg_psd.flatten()
+    cd = [lcf.remove_nans().estimate_cdpp(), lcr.estimate_cdpp(transit_duration=7, savgol_window=51)]
+    assert all(str(getattr(c, "unit", None)) == "ppm" for c in cd), cd          # the reference returns a Quantity in ppm
+    out["cdpp"] = np.asarray([c.value for c in cd])
+    from lightkurve.correctors.metrics import overfit_metric_lombscargle
+    np.random.seed(42)
+    lcc = lcr.copy()
+    lcc.flux = lcc.flux + 2e-4 * np.sin(2 * np.pi * val(lcr.time.value) / 0.37) * lcr.flux.unit
+    out["overfit_metric"] = np.asarray([overfit_metric_lombscargle(lcr, lcc, n_samples=4)])
     ref_data = os.path.join(os.environ.get("LK_REFERENCE_ROOT", "/root/reference"),
                             "tests/data/synthetic/synthetic-k2-sinusoid.targ.fits.gz")
     if os.path.exists(ref_data):
@@ -150,7 +164,11 @@ def compare(bname):
         g = got[k]
         assert type(g) is type(r), (k, type(g), type(r))
         res["types"][k] = type(g).__name__
-        if k.startswith("ls_") or k.startswith("bls"):
+        if k.startswith("pg_"):
+            assert g.frequency.unit == r.frequency.unit and g.power.unit == r.power.unit, k
+            assert np.array_equal(val(g.frequency), val(r.frequency)), k
+            res["errors"][k] = relerr(g.power, r.power)
+        elif k.startswith("ls_") or k.startswith("bls"):
             assert g.frequency.unit == r.frequency.unit and g.power.unit == r.power.unit, k
             assert np.array_equal(val(g.frequency), val(r.frequency)), k
             res["errors"][k] = relerr(g.power, r.power)

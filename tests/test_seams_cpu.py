@@ -39,7 +39,7 @@ def test_all_seams_return_lightkurve_objects_with_reference_values():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_LK_RESULT ")][-1]
     res = json.loads(line[len("SEAMS_LK_RESULT "):])
-    assert len(res["installed"]) == 16
+    assert len(res["installed"]) == 19
     # every seam was really taken
     assert set(res["calls"]) >= {"ls_fast_batch", "ls_power_batch", "bls_batch", "savgol_trend_batch", "regress_batch",
                                  "pld_design_batch", "pca_batch", "standardize_batch", "spline_basis_batch"}
@@ -55,7 +55,7 @@ def test_reference_test_suites_pass_with_seams_active():
              os.path.join(REF, "tests", "correctors", "test_metrics.py") + "::test_overfit_metric_lombscargle"]
     files += [os.path.join(REF, "tests", "test_lightcurve.py") + "::" + t for t in
               ("test_flatten_with_nans", "test_flatten_robustness", "test_flatten_returns_normalized",
-               "test_iterative_flatten")]
+               "test_iterative_flatten", "test_cdpp")]
     p = subprocess.run([CONDA, "-W", "ignore", os.path.join(ROOT, "tests", "seams_lk_worker.py"), "reftests", "oracle"] + files,
                        env=_env(), capture_output=True, timeout=2400, cwd=os.path.join(REF, "tests"))
     tail = p.stdout.decode()[-2500:] + p.stderr.decode()[-1500:]

@@ -58,5 +58,5 @@ def test_all_seams_through_real_lightkurve_when_staged():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("SEAMS_LK_RESULT ")][-1]
     res = json.loads(line[len("SEAMS_LK_RESULT "):])
-    assert len(res["installed"]) == 16 and res["library"].endswith("liblkhip.so")
+    assert len(res["installed"]) == 19 and res["library"].endswith("liblkhip.so")
     assert res["errors"]["bls"] == 0.0

@@ -1,9 +1,9 @@
 #!/bin/bash
 # End-to-end proof on the GPU box: an UNMODIFIED lightkurve (staged by tools/stage_reference.sh, unpacked to /tmp — outside
 # the repo) with lightkurve_amd.seams installed returns its own LightCurve / Periodogram objects from liblkhip.so:
-#   1. tests/seams_lk_worker.py compare hip   — all thirteen seams through lightkurve's public API against the reference path
+#   1. tests/seams_lk_worker.py compare hip   — all nineteen seams through lightkurve's public API against the reference path
 #   2. tests/seams_lk_worker.py reftests hip  — the reference's own periodogram / corrector / flatten tests, seams active
-# The logs are what profiles/r05_seams_e2e_gpu.log and r05_seams_latency.txt hold.
+# The logs are what profiles/r06_seams_e2e_gpu.log and r06_seams_latency.txt hold.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/seams_e2e; mkdir -p $O
 if [ ! -f .stage/lkref.tar.gz ]; then echo "no .stage/lkref.tar.gz: run tools/stage_reference.sh first"; exit 2; fi
@@ -22,7 +22,8 @@ echo "## reference test files with the seams active (hip backend)"
     test_periodogram.py correctors/test_regressioncorrector.py correctors/test_designmatrix.py \
     "correctors/test_metrics.py::test_overfit_metric_lombscargle" \
     "test_lightcurve.py::test_flatten_with_nans" "test_lightcurve.py::test_flatten_robustness" \
-    "test_lightcurve.py::test_flatten_returns_normalized" "test_lightcurve.py::test_iterative_flatten" 2>&1 | tail -15 )
+    "test_lightcurve.py::test_flatten_returns_normalized" "test_lightcurve.py::test_iterative_flatten" \
+    "test_lightcurve.py::test_cdpp" 2>&1 | tail -15 )
 } | tee $O/seams_e2e_gpu.log
 # 3. B = 1 latency table (tools/seams_latency.py) and the PLD block with lightkurve itself as the CPU baseline
 {

@@ -41,6 +41,11 @@ def cases(lk, N):
     yr = 1 + X[:, :19] @ (1e-3 * rng.standard_normal(19)) + 3e-4 * rng.standard_normal(N)
     lcr = lk.LightCurve(time=t + 2000.0, flux=yr, flux_err=np.full(N, 3e-4))
     dm = DesignMatrix(pd.DataFrame(X), name="X")
+    # SURVEY 8(f) rows (round 6): Periodogram.smooth / .flatten, estimate_cdpp, the over-fitting metric
+    from lightkurve.correctors.metrics import overfit_metric_lombscargle
+    pg = lc.to_periodogram(frequency=freq, normalization="psd", freq_unit="1/d")
+    lcc = lcr.copy()
+    lcc.flux = lcc.flux + 2e-4 * np.sin(2 * np.pi * t / 0.37) * lcr.flux.unit
     out = [
         ("lc.to_periodogram()  [default grid, ls_method='fast']", lambda: lc.to_periodogram(), 5),
         ("lc.to_periodogram(frequency=1e5 grid)", lambda: lc.to_periodogram(frequency=freq), 5),
@@ -50,11 +55,15 @@ def cases(lk, N):
         # (astropy's own 'slow' builds ~12 N x M temporaries: 1e4 frequencies x 20 000 cadences do not fit the host)
         ("lc.to_periodogram(frequency=1e4 grid, ls_method='slow')" if N <= 4000 else None,
          lambda: lc.to_periodogram(frequency=freq[::10], ls_method="slow"), 2),
-        ("lc.to_periodogram(period=1e5 periods, ls_method='slow')  [HIP only]" if False else None, None, 0),
         ("lc.to_periodogram(method='bls', 5000 periods x 6 durations)", lambda: lcb.to_periodogram(method="bls", period=periods), 3),
         ("lc.flatten(window_length=101)", lambda: lc.flatten(window_length=101), 5),
         ("lc.flatten(window_length=401)", lambda: lc.flatten(window_length=401), 5),
         ("RegressionCorrector(lc).correct(dm)  [K = 20]", lambda: RegressionCorrector(lcr).correct(dm), 5),
+        ("pg.smooth(method='logmedian', filter_width=0.01)  [1e5 frequencies]", lambda: pg.smooth(method="logmedian", filter_width=0.01), 3),
+        ("pg.smooth(method='boxkernel', filter_width=0.5)  [1e5 frequencies]", lambda: pg.smooth(method="boxkernel", filter_width=0.5), 3),
+        ("pg.flatten()  [1e5 frequencies]", lambda: pg.flatten(), 3),
+        ("lc.estimate_cdpp()", lambda: lc.estimate_cdpp(), 5),
+        ("overfit_metric_lombscargle(lc, corrected, n_samples=10)", lambda: overfit_metric_lombscargle(lcr, lcc, n_samples=10), 2),
     ]
     return [c for c in out if c[0] is not None]
 
