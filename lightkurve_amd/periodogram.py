@@ -203,11 +203,24 @@ def _logmedian_windows(frequency, filter_width):
         centres.append(x0)
         x0 += 0.5 * filter_width
     lo, hi = [], []
-    for c in centres:  # the mask |lf - c| < filter_width is a contiguous run of the sorted grid
-        m = np.flatnonzero(np.abs(lf - c) < filter_width)
-        if m.size:
-            lo.append(m[0])
-            hi.append(m[-1] + 1)
+    n = len(f)
+    # the mask |lf - c| < filter_width is a contiguous run of the sorted grid (fl(lf - c) is monotone in lf): its ends come
+    # from two binary searches, then the reference's own predicate decides the few entries next to them (the searches
+    # compare lf with fl(c -/+ filter_width), which may round across a boundary the predicate does not)
+    a0 = np.searchsorted(lf, np.asarray(centres) - filter_width, side="left")
+    b0 = np.searchsorted(lf, np.asarray(centres) + filter_width, side="right")
+    for c, a, b in zip(centres, a0.tolist(), b0.tolist()):
+        l0, h0 = max(a - 2, 0), min(b + 2, n)
+        if h0 - l0 <= 12:                                     # short (or empty) run: the predicate on all of it
+            ins = np.flatnonzero(np.abs(lf[l0:h0] - c) < filter_width)
+            if ins.size:
+                lo.append(l0 + int(ins[0]))
+                hi.append(l0 + int(ins[-1]) + 1)
+            continue
+        left = np.flatnonzero(np.abs(lf[l0:a + 3] - c) < filter_width)      # lf[a + 2] is well inside
+        right = np.flatnonzero(np.abs(lf[b - 3:h0] - c) < filter_width)     # so is lf[b - 3]
+        lo.append(l0 + int(left[0]))
+        hi.append(b - 3 + int(right[-1]) + 1)
     lo, hi = np.asarray(lo, dtype=np.int32), np.asarray(hi, dtype=np.int32)
     j = np.arange(len(f))
     klo = np.searchsorted(hi, j, side="right").astype(np.int32)      # first window with hi > j

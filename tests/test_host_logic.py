@@ -139,6 +139,21 @@ def test_logmedian_windows_and_box_kernel_reproduce_the_reference_bookkeeping(go
     assert np.allclose(P._box1d_kernel(4), [0.125, 0.25, 0.25, 0.25, 0.125])
     with pytest.raises(NotImplementedError):
         P._logmedian_windows(f[::-1], 0.01)
+    # the window ends come from binary searches + the reference's own predicate at the edges: identical to the reference
+    # loop's masks (periodogram.py:274-275) also where grid points sit exactly on window boundaries, repeat, or leave
+    # windows empty
+    rng = np.random.default_rng(0)
+    for ff, fw in ((10 ** (0.005 * np.arange(900)), 0.01), (10 ** (0.005 * np.arange(900)), 0.005),
+                   (np.array([1.0, 1.0000001, 10, 10.5, 1000]), 0.02), (np.sort(rng.uniform(0.01, 50, 5000)), 0.05),
+                   (np.sort(np.r_[rng.uniform(1, 2, 300), np.full(40, 1.5)]), 0.01)):
+        lf, x0, lo_ref, hi_ref = np.log10(ff), np.log10(ff[0]), [], []
+        while x0 < np.log10(ff[-1]):
+            m = np.flatnonzero(np.abs(lf - x0) < fw)
+            if m.size:
+                lo_ref.append(m[0]), hi_ref.append(m[-1] + 1)
+            x0 += 0.5 * fw
+        lo, hi, _klo, _khi = P._logmedian_windows(ff, fw)
+        assert np.array_equal(lo, lo_ref) and np.array_equal(hi, hi_ref), fw
 
 
 def test_periodogram_bin_matches_reference(golden):
