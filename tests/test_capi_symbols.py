@@ -34,3 +34,21 @@ def test_no_gpu_fails_loudly_not_silently():
     t = np.linspace(0, 1, 10)
     with pytest.raises((RuntimeError, ValueError)):
         _capi.ls_power_batch(t, t, [0, 10], f0=0.1, df=0.1, M=4)
+
+
+def test_kernel_resource_table_names_every_kernel():
+    """profiles/kernel_resources.md (tools/kernel_resources.py: registers / spills / occupancy straight from the compiler, what
+    DESIGN.md quotes) must list every __global__ kernel of the sources — a kernel added or renamed without regenerating the
+    table fails here (the numbers themselves are checked by `tools/kernel_resources.py --check`, which compiles)."""
+    import re
+    csrc = os.path.join(ROOT, "lightkurve_amd", "csrc")
+    table = open(os.path.join(ROOT, "profiles", "kernel_resources.md")).read()
+    missing = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".hip"):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"__global__[^;{]*?\bvoid\s+(\w+)\s*\(", src):
+            if ("`%s" % m.group(1)) not in table:
+                missing.append((f, m.group(1)))
+    assert not missing, missing
