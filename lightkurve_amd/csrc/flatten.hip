@@ -221,9 +221,20 @@ __device__ __forceinline__ FlatSlab flat_slab(char *scratch, const int64_t *scra
 }
 
 constexpr int FLAT_NT = 512;
+// waves per SIMD the select / interpolation kernels are compiled for (8 = the 64-VGPR cap that keeps FOUR 512-thread workgroups
+// on a CU: 1024 slots, the bench's 1000 light curves in one wave of workgroups)
+#ifndef FLAT_INIT_WAVES
+#define FLAT_INIT_WAVES 8
+#endif
+#ifndef FLAT_DTSEG_WAVES
+#define FLAT_DTSEG_WAVES 8
+#endif
+#ifndef FLAT_INTERP_WAVES
+#define FLAT_INTERP_WAVES 6
+#endif
 
 // ---- phase 0: initial mask (finite & |flux - nanmedian| <= sigma nanstd & ~user_mask), lightcurve.py:1002-1010
-__global__ __launch_bounds__(FLAT_NT, 8) void flat_init_kernel(const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
+__global__ __launch_bounds__(FLAT_NT, FLAT_INIT_WAVES) void flat_init_kernel(const double *__restrict__ flux, const uint8_t *__restrict__ user_mask,
                                                             const int64_t *__restrict__ n_off, double sigma,
                                                             char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
                                                             FlatState *__restrict__ state, int FIR_LDS, int dbg) {
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(FLAT_NT) void flat_compact_kernel(const double *__r
 // the cut predicate) only when that list overflows or no bound was available.
 constexpr int FLAT_CUT_CAP = 384;
 
-__global__ __launch_bounds__(FLAT_NT, 8) void flat_dtseg_kernel(const int64_t *__restrict__ n_off, double break_tol,
+__global__ __launch_bounds__(FLAT_NT, FLAT_DTSEG_WAVES) void flat_dtseg_kernel(const int64_t *__restrict__ n_off, double break_tol,
                                                              char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
                                                              FlatState *__restrict__ state, int FIR_LDS, int it, int near_on,
                                                              int dbg) {
@@ -885,7 +896,7 @@ __global__ __launch_bounds__(FLAT_NT) void flat_clip_kernel(const int64_t *__res
 // arrays neighbouring lanes share.  Clipped entries at p or p - 1, equal times and the two ends (interp1d's clamp of the
 // interval to the first / last pair of knots = extrapolation) take a scalar search.  This dropped the knot gather of rounds
 // 1-5a (17 B read + 16 B written per kept cadence, and two dependent rounds of gathers from it): 277 -> ~150 us per launch.
-__global__ __launch_bounds__(FLAT_NT, 8) void flat_interp_kernel(const double *__restrict__ t, const int64_t *__restrict__ n_off,
+__global__ __launch_bounds__(FLAT_NT, FLAT_INTERP_WAVES) void flat_interp_kernel(const double *__restrict__ t, const int64_t *__restrict__ n_off,
                                                               char *__restrict__ scratch, const int64_t *__restrict__ scratch_off,
                                                               const FlatState *__restrict__ state, double *__restrict__ trend,
                                                               uint8_t *__restrict__ final_mask) {

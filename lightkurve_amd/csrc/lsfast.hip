@@ -621,6 +621,17 @@ __global__ __launch_bounds__(256) void fft_cols_reg_kernel(double2 *__restrict__
 // once and kept in registers over the Q passes; rows keep their natural order k1 = Q q + s.
 constexpr int PRUNED_CT = 16;
 
+// Scheduling experiments of round 6 (tools/build_variant.sh ... "-DLSF_PRIO=<bits>"; profiles/r06_lsfast_setprio_ab.txt): wave
+// priority 3 over bit 0 the store phase of a pass, bit 1 the extirpolation phase of the column kernel, bit 2 the loads of the
+// row kernel.  Release builds compile none of them (measured: no gain at two waves per SIMD).
+#ifndef LSF_PRIO
+#define LSF_PRIO 0
+#endif
+#define LSF_SETPRIO(bit, p)                                         \
+    do {                                                            \
+        if (LSF_PRIO & (bit)) __builtin_amdgcn_s_setprio(p);        \
+    } while (0)
+
 // Extirpolation fused in (ordered targets, `tab16` given): the workgroup's input — the cells of its 16 columns in the rows
 // that can hold samples — is not read from a spread grid but built here: the 16-cell-granular tables of lsf_tables_kernel
 // name, for every tile row, the cadences whose 4-point stencils reach it; a wave owns a contiguous range of rows, a group of
@@ -656,6 +667,7 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
         for (int e = tid; e < ru * CT; e += NT) acc[e] = make_double2(0.0, 0.0);
         __syncthreads();
         if (!(g == 1 && !fit_mean)) {  // (the unused grid stays zero)
+            LSF_SETPRIO(2, 3);
             const int b = b0 + lbt;
             const int64_t lo = n_off[b];
             const FastStats st = stats[b];
@@ -724,6 +736,7 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
                     }
                 }
             }
+            LSF_SETPRIO(2, 0);
         }
         __syncthreads();
         if (p1) {
@@ -785,12 +798,14 @@ __global__ __launch_bounds__(PRUNED_CT * (1 << ((LP + 1) / 2)), 2) void fft_cols
             for (int j = 0; j < Bq; ++j) u[j] = row[j];
             reg_fft<LB>(u);
             double2 w = wout;
+            LSF_SETPRIO(1, 3);
 #pragma unroll
             for (int kb = 0; kb < Bq; ++kb) {
                 const int q = jk + A * kb;
                 O[(size_t)(Q * q + s) * CT + f] = cmul(u[brev_c(kb, LB)], w);
                 w = cmul(w, stepc);
             }
+            LSF_SETPRIO(1, 0);
         }
         wjs = cmul(wjs, wj);
         wqs = cmul(wqs, wq);
@@ -979,11 +994,13 @@ __global__ __launch_bounds__(Rows512::NT, 2) void fft_rows512_power_kernel(
     };
     double2 v[16];
     auto load = [&](const double2 *G) {
+        LSF_SETPRIO(4, 3);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const lk_d2v q = __builtin_nontemporal_load(reinterpret_cast<const lk_d2v *>(G + ((size_t)i << (m1 + 5))));
             v[i] = make_double2(q.x, q.y);
         }
+        LSF_SETPRIO(4, 0);
     };
     double2 step1, step4;  // W_512^j, W_512^{4 j}
     {
