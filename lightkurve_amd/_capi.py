@@ -36,6 +36,7 @@ SIGNATURES = [
     ("lk_bls_max_period", ctypes.c_int, [_c_dp, ctypes.c_int, ctypes.c_int, _c_dp]),
     ("lk_bls_set_ordered_histogram", ctypes.c_int, [_vp, ctypes.c_int]),
     ("lk_pld_set_eig_tolerance", ctypes.c_int, [_vp, ctypes.c_double]),
+    ("lk_pld_set_eig_mode", ctypes.c_int, [_vp, ctypes.c_int]),
     ("lk_workspace_bytes", ctypes.c_int64, [_vp]),
     ("lk_synchronize", ctypes.c_int, [_vp]),
     ("lk_ls_power_batch", ctypes.c_int,
@@ -280,6 +281,11 @@ class Handle:
     def pld_set_eig_tolerance(self, tol):
         """Stop of the subspace iteration behind the PLD design matrices' PCA blocks (relative residual; 0 = the default 1e-7)."""
         _check(_lib.lk_pld_set_eig_tolerance(self._h, float(tol)))
+
+    def pld_set_eig_mode(self, mode):
+        """0 (default): the one-kernel subspace iteration behind the wide PCA blocks; 1: its phase-split form (one launch per phase
+        over all matrices) — same results to rounding, kept for per-phase profiling (include/lkhip.h)."""
+        _check(_lib.lk_pld_set_eig_mode(self._h, int(mode)))
 
     def set_host_chunk_mb(self, mb):
         """MiB of spectra per chunk of the pinned host pipeline behind ls_fast_batch / ls_fast_peaks_batch (default 64, or

@@ -129,6 +129,13 @@ int lk_bls_set_ordered_histogram(lk_handle *h, int on) {
     return LK_OK;
 }
 
+int lk_pld_set_eig_mode(lk_handle *h, int mode) {
+    LK_REQUIRE(h != nullptr, "handle is NULL");
+    LK_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (one kernel per matrix) or 1 (phase-split launches)");
+    h->pld_eig_split = mode;
+    return LK_OK;
+}
+
 int lk_pld_set_eig_tolerance(lk_handle *h, double tol) {
     LK_REQUIRE(h != nullptr, "handle is NULL");
     LK_REQUIRE(tol >= 0.0 && tol < 1.0, "tolerance must be in [0, 1) (0 = the default)");

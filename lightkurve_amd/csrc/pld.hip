@@ -52,6 +52,15 @@ constexpr int PLD_DIRECT_MAX = 138;  // largest P whose Gram matrix fits LDS for
 constexpr int PLD_KC = 64;    // rows of the basis staged in LDS per step of the MFMA product C Q (64 x 66 doubles also hold
                               // eig_xty's 16 partial tiles; 128 rows left no room for a second workgroup on the CU)
 constexpr int PLD_QS = PLD_LMAX + 2;  // LDS row stride of that stage (doubles)
+// row stride (floats) of the float32 stage of eig_cq32 for a basis of NA 16-column tiles: 16 NA + 16, so the four k-rows of an
+// MFMA operand read start 16 banks apart and the 64 lanes hit 64 different banks
+__host__ __device__ constexpr int pld_qs32(int na) { return 16 * na + 16; }
+// Relative residual above which the Rayleigh-Ritz product itself reads the float32 copy of C on the float32 matrix cores (round 6):
+// a step that starts three decades above the float32 noise floor cannot pass the 1e-7 stop, so its Ritz pairs only have to
+// steer the filter; convergence is only ever declared from a float64 product.
+#ifndef PLD_RR32_RES
+#define PLD_RR32_RES 1e-3
+#endif
 typedef double pld_d4 __attribute__((ext_vector_type(4)));
 
 static int ncombos(int k, int order) {  // C(k + order - 1, order)
@@ -681,6 +690,17 @@ __global__ __launch_bounds__(256) void pld_spline_kernel(const double *__restric
 // (LDS) — rows p and q of Wt are what a rotation touches, so the accesses stay coalesced.
 // M, W, rot, shred are OFFSETS (in doubles) into the workgroup's dynamic LDS: a non-inlined function that took them as
 // plain pointers would address LDS through flat loads and stores.
+__device__ __forceinline__ double jac_rsq(double x) {  // 1 / sqrt(x), x > 0 and normal
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+    return fma(0.5 * y, fma(-x * y, y, 1.0), y);
+}
+__device__ __forceinline__ double jac_rcp(double x) {  // 1 / x, x > 0 and normal
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return fma(y, fma(-x, y, 1.0), y);
+}
+
 template <bool WT>
 static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld, int orot, int oshred, double *Wt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
@@ -734,14 +754,19 @@ static __device__ __noinline__ void jacobi_eig_lds(int oM, int oW, int n, int ld
                 }
                 const double app = M[p * ld + p], aqq = M[q * ld + q], apq = M[p * ld + q];
                 double c = 1.0, s = 0.0;
-                if (fabs(apq) > 1e-300) {
+                if (fabs(apq) > 1e-140) {  // (its square below must not underflow)
                     // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = d / b, written as sgn(d) b / (|d| + hypot(d, b)): one
                     // square root, one division and one reciprocal square root on the round's critical path instead of
                     // three divisions and two square roots (the same rotation up to rounding)
+                    // (round 6: the square root, the division and the reciprocal square root are the hardware estimates + two Newton
+                    // steps each instead of the IEEE expansions with their scaling and fix-up code — this chain is the critical
+                    // path of every round; c^2 + s^2 = c^2 (1 + t^2) stays 1 to an ulp or two, and a rotation angle that is off in
+                    // its last bits still annihilates a_pq to ~1e-16 of its size)
                     const double d = aqq - app, b2 = 2.0 * apq;
-                    const double hh = sqrt(fma(d, d, b2 * b2));
-                    const double t = (d >= 0.0 ? b2 : -b2) / (fabs(d) + hh);
-                    c = rsqrt(fma(t, t, 1.0));
+                    const double h2 = fma(d, d, b2 * b2);
+                    const double hh = h2 * jac_rsq(h2);
+                    const double t = (d >= 0.0 ? b2 : -b2) * jac_rcp(fabs(d) + hh);
+                    c = jac_rsq(fma(t, t, 1.0));
                     s = t * c;
                 }
                 roti[2 * tid] = p;
@@ -819,6 +844,7 @@ struct EigCtx {
     const float *G32b;                  // its float32 copy for the filter products of the early steps (or nullptr)
     int ldg, P, k, l, ld;
     int kc;                             // rows of the basis per LDS stage of eig_cq (a multiple of 8)
+    int kc32;                           // rows per stage of eig_cq32 (float32 stage in the same LDS region; a multiple of 24 = 8 PF)
 };
 #define LK_EIG_LDS extern __shared__ __attribute__((aligned(16))) double lds_dyn[]
 // likewise the global operands: as plain pointer arguments they would be read with flat loads
@@ -884,9 +910,11 @@ static __device__ __noinline__ void eig_xty(EigCtx c, const double *X_, const do
 // out = X Mm (P x l times the l x l matrix Mm in LDS, leading dimension ld), optionally out2 = X2 Mm in the same pass.
 // A wave owns 16-row strips; the single-matrix form loads a whole strip of X before it stores, so out may alias X.  With
 // theta != nullptr the return value is this thread's share of sum_{c < k} || out2[:, c] - theta[c] out[:, c] ||^2.
+// sc_ie != 0 (TWO only): out2 is stored as (X2 Mm - sc_c X Mm) sc_ie — the first term of the Chebyshev recurrence, which used to be
+// a sweep of its own over the two outputs (the residual is still taken from the unscaled products).
 template <int NA, bool TWO>
 static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double *out_, const double *X2_, double *out2_,
-                                             int oMm, int otheta) {
+                                             int oMm, int otheta, double sc_c = 0.0, double sc_ie = 0.0) {
     LK_EIG_LDS;
     cgdouble *X = (cgdouble *)X_, *X2 = (cgdouble *)X2_;
     gdouble *out = (gdouble *)out_, *out2 = (gdouble *)out2_;
@@ -935,7 +963,7 @@ static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double 
                 if (i < P && col < l) {
                     out[(size_t)i * l + col] = acc[t][r];
                     if (TWO) {
-                        out2[(size_t)i * l + col] = acc2[t][r];
+                        out2[(size_t)i * l + col] = sc_ie != 0.0 ? (acc2[t][r] - sc_c * acc[t][r]) * sc_ie : acc2[t][r];
                         if (theta && col < c.k) {
                             const double d = acc2[t][r] - theta[col] * acc[t][r];
                             part = fma(d, d, part);
@@ -949,6 +977,13 @@ static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double 
     return part;
 }
 
+// Optional epilogue of a product (the phase-split iteration's filter steps): dst = alpha C src - beta src - gamma prev, i.e. one
+// step of the Chebyshev recurrence written by the product's own stores instead of a separate sweep over three P x l arrays.
+struct EigEpi {
+    double alpha, beta, gamma;
+    const double *prev;
+};
+
 // dst = C src (P x l, row-major): dst^T (l x P) = src^T (l x P) C (P x P).  The A operand (src^T) comes from an LDS stage
 // of PLD_KC rows of src; the B operand straight from global: a wave owns 64 consecutive columns of C and a lane loads
 // FOUR of them per row (32 B, so one load instruction covers 4 rows x 512 contiguous bytes) — component j of the load
@@ -957,8 +992,8 @@ static __device__ __noinline__ double eig_xm(EigCtx c, const double *X_, double 
 // ahead of the matrix cores.  Every element of C is streamed exactly once per product.
 // One pass of dst = C src over the column tiles [tile0, tile0 + nwv * NT): wave w owns NT consecutive tiles (16 NT columns),
 // a lane NT neighbouring columns of each row.  All waves of the workgroup call it together (it stages src through LDS).
-template <int NA, int NT, bool C32>
-static __device__ __noinline__ void eig_cq_pass(EigCtx c, const double *src_, double *dst_, int tile0) {
+template <int NA, int NT, bool C32, bool EPI = false>
+static __device__ __noinline__ void eig_cq_pass(EigCtx c, const double *src_, double *dst_, int tile0, EigEpi ep = EigEpi{1.0, 0.0, 0.0, nullptr}) {
     cgdouble *src = (cgdouble *)src_;
     gdouble *dst = (gdouble *)dst_;
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
@@ -1063,7 +1098,13 @@ static __device__ __noinline__ void eig_cq_pass(EigCtx c, const double *src_, do
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a = ai * 16 + lq + 4 * r;
-                if (colok[t] && a < l) dst[(size_t)n * l + a] = acc[t][ai][r];
+                if (colok[t] && a < l) {
+                    if (EPI)
+                        dst[(size_t)n * l + a] = ep.alpha * acc[t][ai][r] - ep.beta * src[(size_t)n * l + a] -
+                                                 ep.gamma * ((cgdouble *)ep.prev)[(size_t)n * l + a];
+                    else
+                        dst[(size_t)n * l + a] = acc[t][ai][r];
+                }
             }
     }
 }
@@ -1071,23 +1112,181 @@ static __device__ __noinline__ void eig_cq_pass(EigCtx c, const double *src_, do
 // dst = C src: full passes of NTMAX tiles per wave, then ONE last pass with as few tiles per wave as cover the rest —
 // 816 columns = 51 tiles on 8 waves ran as 4 + 4 tiles per wave (the second pass with 5 of 8 waves busy); 4 + 3 is an eighth
 // less (a pass costs what its busiest wave costs).
-template <int NA, bool C32 = false>
-static __device__ __forceinline__ void eig_cq(EigCtx c, const double *src, double *dst) {
+template <int NA, bool C32 = false, bool EPI = false>
+static __device__ __forceinline__ void eig_cq(EigCtx c, const double *src, double *dst, EigEpi ep = EigEpi{1.0, 0.0, 0.0, nullptr}) {
     const int nwv = (int)blockDim.x >> 6, tiles = (c.P + 15) >> 4;
     // NTMAX tiles (= consecutive columns per lane) per wave: 4 while the 4 x NA accumulator tiles fit the register budget
     // of a 1024-thread workgroup, 2 for the wide basis (NA = 4: 4 x 4 tiles would be all 128 VGPRs)
     constexpr int NTMAX = NA <= 2 ? 4 : 2;
     int t0 = 0;
-    for (; tiles - t0 > nwv * (NTMAX - 1); t0 += nwv * NTMAX) eig_cq_pass<NA, NTMAX, C32>(c, src, dst, t0);
+    for (; tiles - t0 > nwv * (NTMAX - 1); t0 += nwv * NTMAX) eig_cq_pass<NA, NTMAX, C32, EPI>(c, src, dst, t0, ep);
     const int rest = tiles - t0;
     if (rest > 0) {
         const int ntl = (rest + nwv - 1) / nwv;  // 1 .. NTMAX - 1
         if (ntl == 1)
-            eig_cq_pass<NA, 1, C32>(c, src, dst, t0);
+            eig_cq_pass<NA, 1, C32, EPI>(c, src, dst, t0, ep);
         else if (NTMAX > 2 && ntl == 2)
-            eig_cq_pass<NA, 2, C32>(c, src, dst, t0);
+            eig_cq_pass<NA, 2, C32, EPI>(c, src, dst, t0, ep);
         else if (NTMAX > 3)
-            eig_cq_pass<NA, 3, C32>(c, src, dst, t0);
+            eig_cq_pass<NA, 3, C32, EPI>(c, src, dst, t0, ep);
+    }
+    __syncthreads();
+}
+
+// dst = C32 src on the FLOAT32 matrix cores (v_mfma_f32_16x16x4_f32: twice the fp64 MFMA rate on gfx950, half the bytes of C,
+// half the accumulator registers): the products of the Chebyshev filter and of the Rayleigh-Ritz steps that are still far
+// from the stop.  Same dataflow as eig_cq_pass — dst^T (l x P) = src^T C, the A operand (src^T, rounded to float32 while it is
+// staged) from LDS, the B operand straight from the float32 copy of C, NT neighbouring columns per lane — but with up to 8
+// column tiles per wave, so the 816-column blocks (51 tiles on 8 waves) take ONE pass over the staged basis instead of two.
+// Operand layout of the instruction: A [row = lane & 15][k = lane >> 4], B [k = lane >> 4][col = lane & 15],
+// D [row = 4 (lane >> 4) + r][col = lane & 15] — a lane ends with FOUR CONSECUTIVE basis columns of one column of C, i.e. one
+// 32-byte store into the row-major dst.  Products accumulate in float32: a relative 1e-6 on quantities that only steer the
+// iteration (the float64 Rayleigh-Ritz step before the stop restores every digit).
+typedef float pld_f4 __attribute__((ext_vector_type(4)));
+template <int NA, int NT, bool EPI = false>
+static __device__ __noinline__ void eig_cq32_pass(EigCtx c, const double *src_, double *dst_, int tile0, EigEpi ep = EigEpi{1.0, 0.0, 0.0, nullptr}) {
+    constexpr int QS32 = pld_qs32(NA);
+    cgdouble *src = (cgdouble *)src_;
+    gdouble *dst = (gdouble *)dst_;
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
+    const int lq = lane >> 4, lr = lane & 15, l = c.l, P = c.P, ldg = c.ldg, na = (l + 15) >> 4;
+    LK_EIG_LDS;
+    float *qs = reinterpret_cast<float *>(lds_dyn + c.qstage);
+    typedef __attribute__((address_space(1))) const float cgfloat;
+    const int nsteps = (P + 3) >> 2, KC = c.kc32;
+    const int col_w = (tile0 + wave * NT) << 4;  // first column of this wave
+    const bool active = col_w < P;
+    const int n0 = col_w + NT * lr;
+    // unconditional loads (see eig_cq_pass): rows clamped to P - 1, idle waves re-read the first columns of row 0
+    cgfloat *cp = (cgfloat *)c.G32b + (active ? n0 : NT * lr);
+    const size_t rstride = active ? (size_t)ldg : 0;
+    bool colok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) colok[j] = active && n0 + j < P;
+    struct BRow { float v[NT]; };
+    auto load_b = [&](int st) -> BRow {
+        const int krow = min(st * 4 + lq, P - 1);
+        cgfloat *q = cp + (size_t)krow * rstride;
+        BRow r;
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // (dword-aligned multi-dword global loads)
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        int j = 0;
+#pragma unroll
+        for (; j + 4 <= NT; j += 4) {
+            const f4u f = *(__attribute__((address_space(1))) const f4u *)(q + j);
+            r.v[j] = f[0];
+            r.v[j + 1] = f[1];
+            r.v[j + 2] = f[2];
+            r.v[j + 3] = f[3];
+        }
+        if (NT - j >= 2) {
+            const f2u f = *(__attribute__((address_space(1))) const f2u *)(q + j);
+            r.v[j] = f[0];
+            r.v[j + 1] = f[1];
+            j += 2;
+        }
+        if (NT - j >= 1) r.v[j] = q[j];
+        return r;
+    };
+    pld_f4 acc[NT][NA];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ai = 0; ai < NA; ++ai) acc[t][ai] = pld_f4{0.f, 0.f, 0.f, 0.f};
+    // The loads of C run PF k-steps (4 PF rows x 64 NT bytes per wave) ahead of the matrix cores, in TWO register sets used in
+    // turn: a step consumes one set while the load of the step PF ahead lands in the other.  (With one set the loop-carried
+    // registers had to be copied before their reload, the compiler put all copies — and so the waits for ALL outstanding loads —
+    // at the top of the trip, and sank the loads below the MFMAs: no load ever overlapped an MFMA, a product of 500 matrices
+    // took 370-446 us against the 250 us of its bytes whether 250 or 500 workgroups ran.)  The scheduling fences keep each
+    // load in front of its step's MFMAs.
+    constexpr int PF = 3;
+    BRow qa[PF], qb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) qa[u] = load_b(u);
+    auto mstep = [&](const BRow &cb, int kk) {
+        float av[NA];
+#pragma unroll
+        for (int ai = 0; ai < NA; ++ai) av[ai] = qs[(kk + lq) * QS32 + ai * 16 + lr];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float bv = colok[t] ? cb.v[t] : 0.f;
+#pragma unroll
+            for (int ai = 0; ai < NA; ++ai)
+                acc[t][ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ai], bv, acc[t][ai], 0, 0, 0);
+        }
+    };
+    for (int k0 = 0; k0 < P; k0 += KC) {
+        __syncthreads();
+        for (int e = tid; e < KC * 16 * na; e += nt) {
+            const int kk = e / (16 * na), a = e - kk * (16 * na);
+            qs[kk * QS32 + a] = (k0 + kk < P && a < l) ? (float)src[(size_t)(k0 + kk) * l + a] : 0.f;
+        }
+        __syncthreads();
+        const int s_lo = k0 >> 2, s_hi = min(nsteps, (k0 + KC) >> 2);
+        for (int st = s_lo; st < s_hi; st += 2 * PF) {  // kc32 is a multiple of 8 PF: the 2 PF steps of a trip stay inside the stage
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                qb[u] = load_b(st + PF + u);
+                __builtin_amdgcn_sched_barrier(0);
+                mstep(qa[u], (st + u) * 4 - k0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                qa[u] = load_b(st + 2 * PF + u);
+                __builtin_amdgcn_sched_barrier(0);
+                mstep(qb[u], (st + PF + u) * 4 - k0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t;
+#pragma unroll
+        for (int ai = 0; ai < NA; ++ai) {
+            const int a0 = ai * 16 + 4 * lq;
+            if (colok[t]) {
+                if (a0 + 3 < l && (l & 3) == 0) {  // rows of dst are 32-byte aligned: one store
+                    pld_d4 o = pld_d4{(double)acc[t][ai][0], (double)acc[t][ai][1], (double)acc[t][ai][2], (double)acc[t][ai][3]};
+                    if (EPI) {
+                        const pld_d4 cu = *(cgd4 *)(src + (size_t)n * l + a0), pv = *(cgd4 *)((cgdouble *)ep.prev + (size_t)n * l + a0);
+                        o = ep.alpha * o - ep.beta * cu - ep.gamma * pv;
+                    }
+                    *(__attribute__((address_space(1))) pld_d4 *)(dst + (size_t)n * l + a0) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (a0 + r < l) {
+                            double o = (double)acc[t][ai][r];
+                            if (EPI)
+                                o = ep.alpha * o - ep.beta * src[(size_t)n * l + a0 + r] -
+                                    ep.gamma * ((cgdouble *)ep.prev)[(size_t)n * l + a0 + r];
+                            dst[(size_t)n * l + a0 + r] = o;
+                        }
+                }
+            }
+        }
+    }
+}
+
+template <int NA, bool EPI = false>
+static __device__ __forceinline__ void eig_cq32(EigCtx c, const double *src, double *dst, EigEpi ep = EigEpi{1.0, 0.0, 0.0, nullptr}) {
+    const int nwv = (int)blockDim.x >> 6, tiles = (c.P + 15) >> 4;
+    constexpr int NTMAX = NA <= 2 ? 8 : 4;  // accumulators: NT x NA x 4 VGPRs
+    for (int t0 = 0; t0 < tiles;) {
+        const int ntl = min(NTMAX, (tiles - t0 + nwv - 1) / nwv);
+        switch (ntl) {
+            case 1: eig_cq32_pass<NA, 1, EPI>(c, src, dst, t0, ep); break;
+            case 2: eig_cq32_pass<NA, 2, EPI>(c, src, dst, t0, ep); break;
+            case 3: eig_cq32_pass<NA, 3, EPI>(c, src, dst, t0, ep); break;
+            case 4: eig_cq32_pass<NA, 4, EPI>(c, src, dst, t0, ep); break;
+            case 5: if (NTMAX >= 5) eig_cq32_pass<NA, NTMAX >= 5 ? 5 : 1, EPI>(c, src, dst, t0, ep); break;
+            case 6: if (NTMAX >= 6) eig_cq32_pass<NA, NTMAX >= 6 ? 6 : 1, EPI>(c, src, dst, t0, ep); break;
+            case 7: if (NTMAX >= 7) eig_cq32_pass<NA, NTMAX >= 7 ? 7 : 1, EPI>(c, src, dst, t0, ep); break;
+            default: if (NTMAX >= 8) eig_cq32_pass<NA, NTMAX >= 8 ? 8 : 1, EPI>(c, src, dst, t0, ep); break;
+        }
+        t0 += nwv * ntl;
     }
     __syncthreads();
 }
@@ -1142,6 +1341,7 @@ static __device__ __noinline__ bool eig_cholqr(EigCtx c, const double *Yin, doub
     double *T = lds_dyn + c.T, *W = lds_dyn + c.W, *vec = lds_dyn + c.vec;
     int *order = reinterpret_cast<int *>(lds_dyn + c.order);
     const double *cur = Yin;
+    bool one_pass = false;
     for (int pass = 0; pass < 2; ++pass) {
         eig_xty(c, cur, cur, c.W);
         if (tid < l) vec[tid] = W[tid * ld + tid] > 0.0 ? 1.0 / sqrt(W[tid * ld + tid]) : 0.0;
@@ -1155,11 +1355,14 @@ static __device__ __noinline__ bool eig_cholqr(EigCtx c, const double *Yin, doub
             }
         }
         __syncthreads();
+        // (The smallest pivot of the unit-diagonal Gram matrix decides below whether a second pass is needed.)
         // T = L L^T in place (lower), then W = L^-1, both on one wave (l <= 64: lane = row)
         if (tid < 64) {
             int ok = 1;
+            double dmin = 1.0;
             for (int j = 0; j < l; ++j) {
                 const double d = T[j * ld + j];
+                dmin = fmin(dmin, d);
                 if (!(d > 1e-12)) {
                     ok = 0;
                     break;
@@ -1176,7 +1379,10 @@ static __device__ __noinline__ bool eig_cholqr(EigCtx c, const double *Yin, doub
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            if (tid == 0) order[0] = ok;
+            if (tid == 0) {
+                order[0] = ok;
+                order[1] = (pass == 0 && dmin >= 0.1) ? 1 : 0;
+            }
             if (ok && tid < l) {
                 // COLUMN cc of L^-1 solves L x = e_cc: lane = column, forward substitution down the rows
                 const int cc = tid;
@@ -1189,6 +1395,11 @@ static __device__ __noinline__ bool eig_cholqr(EigCtx c, const double *Yin, doub
         }
         __syncthreads();
         const bool ok = order[0] != 0;
+        // Well conditioned already?  With unit diagonal and every pivot >= 0.1 the Gram matrix's condition number is a few
+        // tens at most: one pass leaves ||Q^T Q - I|| ~ 1e-14, five decades below anything the iteration resolves, and the second
+        // pass (a Gram sweep, a factorisation and a product: half of this function) is skipped.  True for the pseudo-random
+        // start and for filtered Ritz vectors.
+        if (pass == 0) one_pass = order[1] != 0;
         __syncthreads();
         if (!ok) return false;
         // Mm[a][cc] = vec[a] Linv[cc][a] (a <= cc): out = cur diag(vec) L^-T
@@ -1199,9 +1410,24 @@ static __device__ __noinline__ bool eig_cholqr(EigCtx c, const double *Yin, doub
         __syncthreads();
         eig_xm<NA, false>(c, cur, Qout, nullptr, nullptr, c.T, -1);
         cur = Qout;
+        if (one_pass) break;
     }
     return true;
 }
+
+// Per-matrix state of the phase-split iteration (pld_eigs_* kernels below), 64 bytes in global memory.
+struct EigsState {
+    int done;       // nothing left to do here: converged, or handed to the one-kernel iteration (converged == 0)
+    int converged;
+    int it;         // Rayleigh-Ritz steps taken
+    int rr_var;     // product variant of the NEXT Rayleigh-Ritz step: 0 = float32 C on the float32 matrix cores, 2 = float64
+    int f_var;      // variant of this step's two filter products: 0, 1 = float32 C with float64 products, 2
+    int cheb;       // Chebyshev filter (else plain powers of C)
+    int pad[2];
+    double cc, ie;  // filter interval [0, theta_cut]: centre = half-width = cc, ie = 1 / cc
+    double res, th0;
+};
+static_assert(sizeof(EigsState) == 64, "EigsState is indexed with a 64-byte stride");
 
 // Top-k eigenpairs of the P x P Gram matrix of matrix b -> V (P x k, row-major), lam (k).  One workgroup per matrix.
 // scratch per matrix: 4 * P * l doubles (Q, Z, R, Y).  NA = number of 16-column tiles of the basis (l <= 16 NA): a
@@ -1212,9 +1438,11 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
                                                              double *__restrict__ scratch, double *__restrict__ V,
                                                              double *__restrict__ lam, long long *__restrict__ iters_out,
                                                              int max_it, int *__restrict__ status, int cheb_on, int kc,
-                                                             int mirror, double tol, const float *__restrict__ G32 = nullptr) {
+                                                             int mirror, double tol, const float *__restrict__ G32 = nullptr,
+                                                             const EigsState *__restrict__ skip = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    if (skip && skip[b].converged) return;  // the phase-split iteration already delivered this matrix
     double *Gb = G + (size_t)b * ldg * ldg;
     double *Vb = V + (size_t)b * P * k, *lamb = lam + (size_t)b * k;
     const int ld = l + 1;                      // odd leading dimension: conflict-free column walks
@@ -1284,7 +1512,8 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
 
     // ---- subspace iteration with Rayleigh-Ritz steps
     double *Q = scratch + (size_t)b * 4 * P * l, *Z = Q + (size_t)P * l, *R = Z + (size_t)P * l, *Y = R + (size_t)P * l;
-    const EigCtx ctx{oT, oW, orot, oshred, ovec, oqstage, oorder, Gb, G32 ? G32 + (size_t)b * ldg * ldg : nullptr, ldg, P, k, l, ld, kc};
+    const int kc32 = (int)(((size_t)kc * PLD_QS * 8) / ((size_t)pld_qs32(NA) * 4)) / 24 * 24;  // the float32 stage fills the same LDS region
+    const EigCtx ctx{oT, oW, orot, oshred, ovec, oqstage, oorder, Gb, G32 ? G32 + (size_t)b * ldg * ldg : nullptr, ldg, P, k, l, ld, kc, kc32};
     long long tprof[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = iters_out ? (long long)wall_clock64() : 0;
     auto lap = [&](int slot) {  // debug (LK_PLD_ITERS=1): per-phase 100 MHz ticks
         if (iters_out) {
@@ -1315,8 +1544,12 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
     int it = 0;
     bool converged = false;
     double *theta = vec + l;  // sorted Ritz values of the current step
+    bool rr32 = ctx.G32b != nullptr;  // this step's Rayleigh-Ritz product on the float32 matrix cores (PLD_RR32_RES)
     for (; it < max_it; ++it) {
-        eig_cq<NA>(ctx, Q, Z);  // Z = C Q
+        if (rr32)
+            eig_cq32<NA>(ctx, Q, Z);  // Z = C32 Q
+        else
+            eig_cq<NA>(ctx, Q, Z);  // Z = C Q
         lap(1);
         eig_xty(ctx, Q, Z, oW);  // T = Q^T Z (symmetrised)
         for (int e = tid; e < l * l; e += nt) {
@@ -1337,16 +1570,23 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
             T[a * ld + c] = W[a * ld + order[c]];
         }
         __syncthreads();
-        const double part = eig_xm<NA, true>(ctx, Q, R, Z, Y, oT, ovec + l);
-        const double res = sqrt(block_sum_dyn(part, shred));
         const double th0 = fabs(theta[0]), th_k = theta[k - 1], th_cut = theta[l - 1];
+        // (the filter decision needs the Ritz values only, so it is taken BEFORE the pass that writes R and Y: with the Chebyshev
+        // filter that pass stores Y as the recurrence's first term X1 = (C R - c R) / e straight away — one sweep over two P x l
+        // arrays less per step; unused if this step converges)
+        const bool cheb = npow >= 2 && th_cut > 0.0 &&
+                          (((cheb_on & 1) && th_k < 1.5 * th_cut && th0 < 30.0 * th_cut) || (cheb_on & 2));  // bit 1 (LK_PLD_CHEB=2/3): always
+        const double cc = 0.5 * th_cut, ie = cheb ? 1.0 / cc : 0.0;
+        const double part = eig_xm<NA, true>(ctx, Q, R, Z, Y, oT, ovec + l, cc, ie);
+        const double res = sqrt(block_sum_dyn(part, shred));
         if (tid < k) lamb[tid] = theta[tid];
         __syncthreads();
         lap(4);
-        if (res <= tol * th0 * sqrt((double)k)) {
+        if (!rr32 && res <= tol * th0 * sqrt((double)k)) {  // (only a float64 product can declare convergence)
             converged = true;
             break;
         }
+        rr32 = ctx.G32b != nullptr && res > PLD_RR32_RES * th0;
         // next basis: orthonormalised p(C) R with npow - 1 more products between two Rayleigh-Ritz steps.
         //  * flat spectrum (the wanted Ritz values sit close to the first unwanted one: product blocks): p = the Chebyshev
         //    polynomial of degree npow that is bounded by 1 on the unwanted interval [0, theta_cut] and grows fastest
@@ -1355,14 +1595,10 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         //  * steep spectrum: the same filter (option bit 1, default) — the factors between the columns differ by many
         //    orders of magnitude, but the Cholesky-QR scales the columns to unit length first, and measured it needs 5.0
         //    steps where p = C^npow (option bit 1 off) needs 7.2.
-        const bool cheb = npow >= 2 && th_cut > 0.0 &&
-                          (((cheb_on & 1) && th_k < 1.5 * th_cut && th0 < 30.0 * th_cut) || (cheb_on & 2));  // bit 1 (LK_PLD_CHEB=2/3): always
         double *src = Y, *dst = Z;
         if (cheb) {
-            // x = (C - c) / e with c = e = theta_cut / 2:  X0 = R, X1 = (C R - c R) / e, X_{j+1} = (2/e)(C X_j - c X_j) - X_{j-1}
-            const double cc = 0.5 * th_cut, ie = 1.0 / cc;
-            for (int e = tid; e < P * l; e += nt) Y[e] = (Y[e] - cc * R[e]) * ie;
-            __syncthreads();
+            // x = (C - c) / e with c = e = theta_cut / 2:  X0 = R, X1 = (C R - c R) / e (stored by eig_xm above),
+            // X_{j+1} = (2/e)(C X_j - c X_j) - X_{j-1} (written by the product's own stores: EigEpi)
             double *prev = R, *cur = Y, *free1 = Z, *free2 = Q;
             // While the residual is far from the tolerance the filter's products read the FLOAT32 copy of C (half the bytes
             // of a stream that is all of the product's time): the filter only has to amplify the wanted directions — the
@@ -1371,12 +1607,13 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
             const bool f32 = ctx.G32b != nullptr && res > PLD_F32_RES * th0;
             for (int pw = 1; pw < npow; ++pw) {
                 double *nxt = free1;
-                if (f32)
-                    eig_cq<NA, true>(ctx, cur, nxt);
+                const EigEpi ep{2.0 * ie, 2.0 * ie * cc, 1.0, prev};
+                if (f32 && res > PLD_RR32_RES * th0)  // far from the stop: float32 matrix cores (noise floor ~2e-6 of the subspace)
+                    eig_cq32<NA, true>(ctx, cur, nxt, ep);
+                else if (f32)                         // float32 C, float64 products: a FIXED perturbation of C, floor ~1e-8
+                    eig_cq<NA, true, true>(ctx, cur, nxt, ep);
                 else
-                    eig_cq<NA>(ctx, cur, nxt);
-                for (int e = tid; e < P * l; e += nt) nxt[e] = 2.0 * ie * (nxt[e] - cc * cur[e]) - prev[e];
-                __syncthreads();
+                    eig_cq<NA, false, true>(ctx, cur, nxt, ep);
                 free1 = free2;
                 free2 = prev;
                 prev = cur;
@@ -1407,6 +1644,186 @@ __global__ __launch_bounds__(1024) void pld_topk_eig_kernel(double *__restrict__
         for (int s2 = 0; s2 < 7; ++s2) iters_out[(size_t)b * 8 + 1 + s2] = tprof[s2];
     }
     if (tid == 0 && status) status[b] = converged ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ phase-split iteration
+// Round 6.  The one-kernel iteration above keeps a matrix on one workgroup from the random start to the last Ritz vector: its
+// products with C (HBM streams) and its l x l eigenproblems / Cholesky factorisations (latency chains on one wave) share one
+// register budget (128 VGPRs, ~60 spilled around the calls), and since the 500 workgroups of a batch start together and do
+// identical work, the two workgroups of a CU sit in the SAME phase at the same time — the serial stretches were never hidden
+// behind the other workgroup's stream (per matrix 2.5 ms of serial phases + 4.95 ms of products = the kernel's 7.45 ms).
+// Here every phase is its own launch over all matrices, state in global memory:
+//   pld_eigs_init_kernel   mirror the Gram blocks, pseudo-random start, Cholesky-QR            (once)
+//   pld_eigs_prod_kernel   dst = C src with the filter recurrence fused into its stores        (3 per step: Rayleigh-Ritz, filter 1, 2)
+//   pld_eigs_rr_kernel     Q^T Z, l x l Jacobi, Ritz vectors + residual, stop test, filter plan
+//   pld_eigs_orth_kernel   Cholesky-QR of the filtered block
+// A product launch is nothing but streams (deep register prefetch, no serial phase inside); the small phases run two workgroups
+// per CU with nobody streaming beside them.  Per-matrix control flow lives in EigsState: converged matrices drop out of every
+// later launch by their `done` flag, precision follows the residual (float32 matrix cores -> float32 C with float64 products ->
+// float64), and whatever has not converged after the fixed number of steps the launcher queues — or hits a Cholesky breakdown —
+// is handed to the one-kernel iteration (which restarts it; `skip` = the converged flags).  No host synchronisation.
+struct EigsLds {
+    int T, W, rot, shred, vec, order, qstage;
+};
+__device__ __forceinline__ EigsLds eigs_lds(int l, int nt) {
+    const int ld = l + 1;
+    EigsLds o;
+    o.T = 0;
+    o.W = l * ld;
+    o.rot = 2 * l * ld;
+    o.shred = o.rot + 2 * l;
+    o.vec = o.shred + nt;
+    o.order = o.vec + 2 * l;
+    o.qstage = o.order + (l + 1) / 2 + 1;
+    return o;
+}
+static size_t eigs_small_lds_bytes(int l, int nt, int kc) {
+    const int ld = l + 1;
+    return ((size_t)2 * l * ld + 2 * l + nt + 2 * l + (l + 1) / 2 + 1 + (size_t)kc * PLD_QS) * 8 + 64;
+}
+
+template <int NA>
+__global__ __launch_bounds__(512) void pld_eigs_init_kernel(double *__restrict__ G, int ldg, int P, int k, int l,
+                                                            double *__restrict__ scratch, EigsState *__restrict__ state, int kc,
+                                                            int mirror, int have32) {
+    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    double *Gb = G + (size_t)b * ldg * ldg;
+    const EigsLds o = eigs_lds(l, nt);
+    const EigCtx ctx{o.T, o.W, o.rot, o.shred, o.vec, o.qstage, o.order, Gb, nullptr, ldg, P, k, l, l + 1, kc, 0};
+    double *Q = scratch + (size_t)b * 4 * P * l;
+    if (mirror)
+        for (int e = tid; e < P * P; e += nt) {
+            const int i = e / P, j = e - i * P;
+            if ((j >> 6) < (i >> 6)) Gb[(size_t)i * ldg + j] = Gb[(size_t)j * ldg + i];
+        }
+    for (int e = tid; e < P * l; e += nt) {  // the deterministic pseudo-random start of the one-kernel iteration
+        unsigned int x = (unsigned int)(e + 1) * 2654435761u;
+        x ^= x >> 15;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        Q[e] = (double)(x & 0xffffffu) / 8388608.0 - 1.0;
+    }
+    __syncthreads();
+    if (!eig_cholqr<NA>(ctx, Q, Q)) eig_svqb<NA>(ctx, Q);
+    if (tid == 0) {
+        EigsState st;
+        st.done = 0;
+        st.converged = 0;
+        st.it = 0;
+        st.rr_var = have32 ? 0 : 2;
+        st.f_var = 2;
+        st.cheb = 0;
+        st.pad[0] = st.pad[1] = 0;
+        st.cc = st.ie = 0.0;
+        st.res = 1e300;
+        st.th0 = 0.0;
+        state[b] = st;
+    }
+}
+
+// which = 0: Z = C Q (Rayleigh-Ritz product, variant rr_var); 1: Z = a C Y - b Y - g R; 2: Q = a C Z - b Z - g Y (filter, f_var)
+// with (a, b, g) = (2 / e, 2 c / e, 1) for the Chebyshev recurrence and (1, 0, 0) for plain powers.
+template <int NA>
+__global__ __launch_bounds__(512, 4) void pld_eigs_prod_kernel(const double *__restrict__ G, const float *__restrict__ G32, int ldg,
+                                                               int P, int l, double *__restrict__ scratch,
+                                                               const EigsState *__restrict__ state, int which, int kc, int kc32) {
+    const int b = blockIdx.x;
+    const EigsState st = state[b];
+    if (st.done) return;
+    double *Q = scratch + (size_t)b * 4 * P * l, *Z = Q + (size_t)P * l, *R = Z + (size_t)P * l, *Y = R + (size_t)P * l;
+    const EigCtx ctx{0, 0, 0, 0, 0, 0, 0, const_cast<double *>(G) + (size_t)b * ldg * ldg, G32 ? G32 + (size_t)b * ldg * ldg : nullptr,
+                     ldg, P, 0, l, l + 1, kc, kc32};
+    const double *src = which == 0 ? Q : which == 1 ? Y : Z, *prev = which == 1 ? R : Y;
+    double *dst = which == 2 ? Q : Z;
+    const int var = which == 0 ? st.rr_var : st.f_var;
+    if (which == 0) {
+        if (var == 0)
+            eig_cq32<NA>(ctx, src, dst);
+        else
+            eig_cq<NA>(ctx, src, dst);
+        return;
+    }
+    const EigEpi ep = st.cheb ? EigEpi{2.0 * st.ie, 2.0 * st.ie * st.cc, 1.0, prev} : EigEpi{1.0, 0.0, 0.0, prev};
+    if (var == 0)
+        eig_cq32<NA, true>(ctx, src, dst, ep);
+    else if (var == 1)
+        eig_cq<NA, true, true>(ctx, src, dst, ep);
+    else
+        eig_cq<NA, false, true>(ctx, src, dst, ep);
+}
+
+template <int NA>
+__global__ __launch_bounds__(512) void pld_eigs_rr_kernel(int P, int k, int l, double *__restrict__ scratch,
+                                                          EigsState *__restrict__ state, double *__restrict__ V,
+                                                          double *__restrict__ lam, int kc, double tol, int cheb_on, int last,
+                                                          int have32) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    const EigsState st = state[b];
+    if (st.done) return;
+    const EigsLds o = eigs_lds(l, nt);
+    const int ld = l + 1;
+    const EigCtx ctx{o.T, o.W, o.rot, o.shred, o.vec, o.qstage, o.order, nullptr, nullptr, 0, P, k, l, ld, kc, 0};
+    double *T = lds + o.T, *W = lds + o.W, *shred = lds + o.shred, *vec = lds + o.vec, *theta = vec + l;
+    int *order = reinterpret_cast<int *>(lds + o.order);
+    double *Q = scratch + (size_t)b * 4 * P * l, *Z = Q + (size_t)P * l, *R = Z + (size_t)P * l, *Y = R + (size_t)P * l;
+    eig_xty(ctx, Q, Z, o.W);  // T = Q^T Z (symmetrised)
+    for (int e = tid; e < l * l; e += nt) {
+        const int a = e / l, c = e % l;
+        T[a * ld + c] = 0.5 * (W[a * ld + c] + W[c * ld + a]);
+    }
+    __syncthreads();
+    jacobi_eig_lds<false>(o.T, o.W, l, ld, o.rot, o.shred);
+    sort_desc_lds(T, l, ld, order);
+    if (tid < l) theta[tid] = T[order[tid] * ld + order[tid]];
+    __syncthreads();
+    for (int e = tid; e < l * l; e += nt) {
+        const int a = e / l, c = e % l;
+        T[a * ld + c] = W[a * ld + order[c]];
+    }
+    __syncthreads();
+    const double th0 = fabs(theta[0]), th_k = theta[k - 1], th_cut = theta[l - 1];
+    const bool cheb = th_cut > 0.0 && (((cheb_on & 1) && th_k < 1.5 * th_cut && th0 < 30.0 * th_cut) || (cheb_on & 2));
+    const double cc = 0.5 * th_cut, ie = cheb ? 1.0 / cc : 0.0;
+    // R = Q W (Ritz vectors by Ritz value), Y = Z W = C R and the residual of the k wanted pairs in one pass; with the Chebyshev
+    // filter Y is stored as the recurrence's first term X1 = (C R - c R) / e straight away (unused if this step converges)
+    const double part = eig_xm<NA, true>(ctx, Q, R, Z, Y, o.T, o.vec + l, cc, ie);
+    const double res = sqrt(block_sum_dyn(part, shred));
+    // only a float64 product can declare convergence
+    const bool conv = st.rr_var == 2 && res <= tol * th0 * sqrt((double)k);
+    if (conv) {
+        double *Vb = V + (size_t)b * P * k;
+        for (int e = tid; e < P * k; e += nt) Vb[e] = R[(size_t)(e / k) * l + (e % k)];
+        if (tid < k) lam[(size_t)b * k + tid] = theta[tid];
+    }
+    if (tid == 0) {
+        EigsState nx = st;
+        nx.it = st.it + 1;
+        nx.res = res;
+        nx.th0 = th0;
+        nx.converged = conv ? 1 : 0;
+        nx.done = (conv || last) ? 1 : 0;
+        nx.cheb = cheb ? 1 : 0;
+        nx.cc = cc;
+        nx.ie = ie;
+        const bool far = have32 && res > PLD_RR32_RES * th0;
+        nx.rr_var = far ? 0 : 2;
+        nx.f_var = far ? 0 : (have32 && res > PLD_F32_RES * th0) ? 1 : 2;
+        state[b] = nx;
+    }
+}
+
+template <int NA>
+__global__ __launch_bounds__(512) void pld_eigs_orth_kernel(int P, int k, int l, double *__restrict__ scratch,
+                                                            EigsState *__restrict__ state, int kc) {
+    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    if (state[b].done) return;
+    const EigsLds o = eigs_lds(l, nt);
+    const EigCtx ctx{o.T, o.W, o.rot, o.shred, o.vec, o.qstage, o.order, nullptr, nullptr, 0, P, k, l, l + 1, kc, 0};
+    double *Q = scratch + (size_t)b * 4 * P * l;
+    if (!eig_cholqr<NA>(ctx, Q, Q)) {  // breakdown (never seen on PLD blocks): the one-kernel iteration restarts this matrix
+        if (tid == 0) state[b].done = 1;
+    }
 }
 
 // U = A V diag(lam)^-1/2 into X[:, col0 : col0 + k] on the fp64 matrix cores.  One WAVE = 16 rows of A against all of V
@@ -1928,6 +2345,93 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
             set_error("PLD workspace exhausted (subspace)");
             return LK_ENOMEM;
         }
+        // ---- phase-split form (see pld_eigs_*): the blocks beyond the direct solver's reach with the standard three products
+        // per step.  A fixed number of steps is queued (converged matrices drop out of each launch by their flag); the
+        // one-kernel iteration below then runs for whatever is left, skipping the converged ones.
+        EigsState *d_state = nullptr;
+#ifdef LK_PLD_DEBUG
+        if (getenv("LK_PLD_SPLIT")) h->pld_eig_split = atoi(getenv("LK_PLD_SPLIT"));  // 0: one-kernel form, 1: phase-split
+        const bool split_on = h->pld_eig_split != 0;
+#else
+        const bool split_on = h->pld_eig_split != 0;
+#endif
+        const bool split = !two_pass && !wide_sub && npow == 3 && split_on;
+        if (split) {
+            d_state = (EigsState *)ws.alloc((size_t)B * sizeof(EigsState));
+            if (!d_state) {
+                set_error("PLD workspace exhausted (state)");
+                return LK_ENOMEM;
+            }
+            const int have32 = G32 != nullptr ? 1 : 0;
+            const int kc_s = l <= 32 ? 32 : 64;                       // eig_xty's partial tiles: (512 / 64) or 16 x 256 doubles
+            const int kc_p = 128;                                     // rows per float64 stage of a product: 66 KB
+            const int kc32_p = (int)(((size_t)kc_p * PLD_QS * 8) / ((size_t)pld_qs32(l <= 32 ? 2 : 4) * 4)) / 24 * 24;  // (a multiple of 8 x eig_cq32_pass's PF)
+            const size_t lds_s = eigs_small_lds_bytes(l, 512, kc_s), lds_p = (size_t)kc_p * PLD_QS * 8 + 64;
+            constexpr int nsteps_split = 6;
+            int rc_ = 0;
+#define LK_EIGS_WANT(NA_)                                                                                              \
+    do {                                                                                                               \
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(pld_eigs_init_kernel<NA_>), 160 * 1024);             \
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(pld_eigs_prod_kernel<NA_>), 160 * 1024);             \
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(pld_eigs_rr_kernel<NA_>), 160 * 1024);               \
+        if (!rc_) rc_ = want_lds(h, reinterpret_cast<const void *>(pld_eigs_orth_kernel<NA_>), 160 * 1024);             \
+    } while (0)
+            // matrices [b0_, b0_ + nb_) on stream st_: every array is indexed by matrix, so a part of the batch is an offset
+#define LK_EIGS_RUN(NA_, b0_, nb_, st_)                                                                                   \
+    do {                                                                                                               \
+        double *G_ = G + (size_t)(b0_) * ldg * ldg, *scr_ = scr + (size_t)(b0_) * 4 * P * l;                            \
+        const float *G32_ = G32 ? G32 + (size_t)(b0_) * ldg * ldg : nullptr;                                            \
+        EigsState *state_ = d_state + (b0_);                                                                           \
+        double *V_ = V + (size_t)(b0_) * P * k, *lam_ = lam + (size_t)(b0_) * k;                                        \
+        hipLaunchKernelGGL(pld_eigs_init_kernel<NA_>, dim3(nb_), dim3(512), lds_s, st_, G_, ldg, P, k, l, scr_, state_, \
+                           kc_s, mirror ? 1 : 0, have32);                                                              \
+        for (int it_ = 0; it_ < nsteps_split; ++it_) {                                                                 \
+            const int last_ = it_ + 1 == nsteps_split ? 1 : 0;                                                         \
+            hipLaunchKernelGGL(pld_eigs_prod_kernel<NA_>, dim3(nb_), dim3(512), lds_p, st_, G_, G32_, ldg, P, l, scr_,  \
+                               state_, 0, kc_p, kc32_p);                                                               \
+            hipLaunchKernelGGL(pld_eigs_rr_kernel<NA_>, dim3(nb_), dim3(512), lds_s, st_, P, k, l, scr_, state_, V_,    \
+                               lam_, kc_s, eig_tol, cheb_on, last_, have32);                                           \
+            if (last_) break;                                                                                          \
+            hipLaunchKernelGGL(pld_eigs_prod_kernel<NA_>, dim3(nb_), dim3(512), lds_p, st_, G_, G32_, ldg, P, l, scr_,  \
+                               state_, 1, kc_p, kc32_p);                                                               \
+            hipLaunchKernelGGL(pld_eigs_prod_kernel<NA_>, dim3(nb_), dim3(512), lds_p, st_, G_, G32_, ldg, P, l, scr_,  \
+                               state_, 2, kc_p, kc32_p);                                                               \
+            hipLaunchKernelGGL(pld_eigs_orth_kernel<NA_>, dim3(nb_), dim3(512), lds_s, st_, P, k, l, scr_, state_,      \
+                               kc_s);                                                                                  \
+        }                                                                                                              \
+    } while (0)
+            // (Measured and dropped: the batch in two halves on two streams, the second started one product late so that one half's
+            // serial phases meet the other half's products — profiles/r06_pld_eig_modes_ab.txt: +1 % on the PLD step over one
+            // stream; a half-batch product takes as long as a full one while a small-phase launch runs beside it.)
+            if (l <= 32)
+                LK_EIGS_WANT(2);
+            else
+                LK_EIGS_WANT(4);
+            if (rc_) return rc_;
+            if (l <= 32)
+                LK_EIGS_RUN(2, 0, B, stream);
+            else
+                LK_EIGS_RUN(4, 0, B, stream);
+#undef LK_EIGS_WANT
+#undef LK_EIGS_RUN
+#ifdef LK_PLD_DEBUG
+            if (dbg_iters) {
+                std::vector<EigsState> hs((size_t)B);
+                LK_HIP_CHECK(hipMemcpyAsync(hs.data(), d_state, (size_t)B * sizeof(EigsState), hipMemcpyDeviceToHost, stream));
+                LK_HIP_CHECK(hipStreamSynchronize(stream));
+                long long sum = 0, mx = 0, nconv = 0;
+                double rmax = 0.0;
+                for (int b2 = 0; b2 < B; ++b2) {
+                    sum += hs[b2].it;
+                    mx = std::max<long long>(mx, hs[b2].it);
+                    nconv += hs[b2].converged;
+                    rmax = std::max(rmax, hs[b2].res / std::max(hs[b2].th0, 1e-300));
+                }
+                fprintf(stderr, "[pld eig split] P=%d k=%d l=%d: Rayleigh-Ritz steps mean %.1f max %lld, %lld of %d converged in the queued "
+                                "steps, largest final relative residual %.2e\n", P, k, l, (double)sum / B, mx, nconv, B, rmax);
+            }
+#endif
+        }
         // 512-thread workgroups, two per CU (LDS 57 KB each): one matrix's serial stretches (l x l Jacobi, Cholesky on one
         // wave, the random start) overlap the other's stream through C — 97.2 -> 86.6 ms per PLD step against one
         // 1024-thread workgroup per CU
@@ -1939,10 +2443,10 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
         long long *d_it = dbg_iters ? (long long *)ws.alloc((size_t)B * 64) : nullptr;
         if (l <= 32)
             hipLaunchKernelGGL(pld_topk_eig_kernel<2>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol, G32);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, (mirror && !split) ? 1 : 0, eig_tol, G32, d_state);
         else
             hipLaunchKernelGGL(pld_topk_eig_kernel<4>, dim3(B), dim3(nt_sub), lds, stream, G, ldg, P, k, l, npow, scr, V, lam,
-                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, mirror ? 1 : 0, eig_tol, G32);
+                               d_it, two_pass ? 8 : 400, status, cheb_on, kc, (mirror && !split) ? 1 : 0, eig_tol, G32, d_state);
         if (d_it) {
             std::vector<long long> hit((size_t)B * 8);
             LK_HIP_CHECK(hipMemcpyAsync(hit.data(), d_it, (size_t)B * 64, hipMemcpyDeviceToHost, stream));
@@ -2158,7 +2662,8 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
     }
     // blocks that go to the subspace iteration (too wide for the direct solver) also get a float32 copy of C: the
     // early steps' filter products stream it instead (half the bytes); optional — without workspace nothing changes
-    float *G32 = (Pc > PLD_DIRECT_MAX && (Pc & 3) == 0) ? (float *)ws.alloc((size_t)B * ldg * ldg * 4) : nullptr;
+    // (+ 4 KB: the product kernels' unconditional loads of the last row may run a few columns past the last matrix)
+    float *G32 = (Pc > PLD_DIRECT_MAX && (Pc & 3) == 0) ? (float *)ws.alloc((size_t)B * ldg * ldg * 4 + 4096) : nullptr;
     hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 511) / 512, B), dim3(256), 0, stream, Mcan,
                        (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G, G32);
     double *V = nullptr, *lam = nullptr;
