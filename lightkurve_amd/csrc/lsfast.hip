@@ -252,17 +252,25 @@ __device__ __forceinline__ Stencil4 stencil4(double x, int nfft) {
 
 // The scatter kernels add with GLOBAL atomics, whose order is not fixed.  To be reproducible bit for bit all the same,
 // every addend is first rounded to a multiple of a quantum q = 2^e chosen per target AND per kind of grid (2^-50 of the
-// largest possible addend, i.e. about the addend's own last bit): sums of such multiples are exact in double as long as they
-// stay below 2^53 q = 4 x the largest possible addend, and exact additions commute.  That holds wherever the grid is sparsely
-// filled — the 5-fold oversampled grids of real periodograms receive ~0.15 cadences per cell; a cell that piles up more
-// (tiny grids, many coinciding times) is rounded like any double sum: as accurate as before, merely no longer
-// order-independent.  The w grids and the w (y - ybar) grids have their own quanta (FastStats::wmax, ::vmax): one shared
+// largest possible addend, i.e. about the addend's own last bit) and the multiples are accumulated as 64-BIT INTEGERS in the
+// grid cells (atomic add on the cell's bits): integer additions are exact and commute whatever piles up in a cell — 2^13 of
+// the largest possible addends fit — and lsf_unquantize_kernel turns the sums into doubles (one rounding, of the final sum)
+// before the transform reads them.  (Rounds 2-5 added the rounded addends as doubles: exact, hence order-independent, only
+// while a cell's sum stayed below 2^53 q = 4 x the largest addend — true on the 5-fold oversampled grids of real
+// periodograms, ~0.15 cadences per cell, but a small grid with a few coinciding stencils gave run-to-run differences in the
+// last bit: tests/test_batch_api_gpu.py caught one in round 6.)  The w grids and the w (y - ybar) grids have their own quanta (FastStats::wmax, ::vmax): one shared
 // quantum, scaled by w, would leave the w y addends of a normalised low-amplitude light curve only 2^-30 of relative
 // precision.  (A coarser quantum with more headroom was tried first: 2^-46 cost 1e-9 of the power where the five-point fit
 // is ill-conditioned.)
 struct Quantum {
     double q, iq;
-    __device__ __forceinline__ double operator()(double v) const { return q > 0.0 ? rint(v * iq) * q : v; }
+    // add v to the cell: as an integer multiple of q on the cell's bits, or (no quantum: a zero or non-finite scale) as a double
+    __device__ __forceinline__ void add(double *cell, double v) const {
+        if (q > 0.0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)(long long)rint(v * iq));
+        else
+            unsafeAtomicAdd(cell, v);
+    }
 };
 __device__ __forceinline__ Quantum make_quantum(double vmax) {
     const double q = (vmax > 0.0 && isfinite(vmax)) ? ldexp(1.0, ilogb(1.25 * vmax) - 49) : 0.0;
@@ -274,8 +282,8 @@ __device__ __forceinline__ void extirpolate4(double2 *__restrict__ grid, const S
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < sp.n) {
-            unsafeAtomicAdd(&grid[sp.i0 + k].x, Q(hr * sp.wt[k]));
-            unsafeAtomicAdd(&grid[sp.i0 + k].y, Q(hi * sp.wt[k]));
+            Q.add(&grid[sp.i0 + k].x, hr * sp.wt[k]);
+            Q.add(&grid[sp.i0 + k].y, hi * sp.wt[k]);
         }
 }
 
@@ -1284,6 +1292,26 @@ __global__ __launch_bounds__(256) void lsf_power_kernel(const double2 *__restric
                                                       0.5 * st.wsum, n, scale ? scale[b] : 1.0);
 }
 
+// the scatter kernels' integer sums -> doubles, in place: grid g of a target (ngp grids per target, the first n_wy of them
+// w (y - ybar) grids) over the rows that can hold samples (rows_used == nullptr: all N1 rows)
+__global__ __launch_bounds__(256) void lsf_unquantize_kernel(double2 *__restrict__ grids, int m1, int m2,
+                                                              const int *__restrict__ rows_used,
+                                                              const FastStats *__restrict__ stats, int b0, int ngp, int n_wy) {
+    const int lbt = blockIdx.y / ngp, g = blockIdx.y % ngp;
+    if (rows_used && rows_used[lbt * 4 + 3]) return;  // ordered target: spread with LDS atomics in a fixed order, as doubles
+    const int ru = rows_used ? rows_used[lbt * 4 + g] : (1 << m1);
+    const FastStats st = stats[b0 + lbt];
+    const double q = make_quantum(g < n_wy ? st.vmax : st.wmax).q;
+    if (!(q > 0.0)) return;  // (the scatter added plain doubles)
+    const int N2 = 1 << m2;
+    double2 *G = grids + ((size_t)blockIdx.y << (m1 + m2));
+    for (int r = blockIdx.x * 8; r < min(blockIdx.x * 8 + 8, ru); ++r)
+        for (int c = threadIdx.x; c < N2; c += 256) {
+            const double2 v = G[(size_t)r * N2 + c];
+            G[(size_t)r * N2 + c] = make_double2((double)__double_as_longlong(v.x) * q, (double)__double_as_longlong(v.y) * q);
+        }
+}
+
 // zero only the grid rows that can receive samples (the column transform treats the others as zeros)
 __global__ __launch_bounds__(256) void lsf_zero_kernel(double2 *__restrict__ grids, int m1, int m2,
                                                         const int *__restrict__ rows_used) {
@@ -1611,10 +1639,13 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
             hipLaunchKernelGGL(lsf_zero_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, stream, gr, m1, m2,
                                d_rows + (size_t)b0 * 4);
         }
-        if (!reg_path || n_unordered > 0)
+        if (!reg_path || n_unordered > 0) {
             hipLaunchKernelGGL(lsf_scatter_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, y,
                                dy, d_off, d_stats, b0, f0, df, nfft, fit_mean, gr,
                                reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr);
+            hipLaunchKernelGGL(lsf_unquantize_kernel, dim3((N1 + 7) / 8, nb * 3), dim3(256), 0, stream, gr, m1, m2,
+                               reg_path ? d_rows + (size_t)b0 * 4 : (const int *)nullptr, d_stats, b0, 3, 1);
+        }
         // ordered targets: spread by the pruned column kernel itself, or (other shapes) by the owner-computes spreader
         if (reg_path && !lp && n_unordered < B)
             hipLaunchKernelGGL(lsf_spread_owner_kernel, dim3((unsigned)spread_blocks, nb, 2), dim3(256), 0, stream, t, y, dy,
@@ -1716,6 +1747,8 @@ int lsfastchi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const doub
         LK_HIP_CHECK(hipMemsetAsync(d_grids, 0, (size_t)nb * per_target, stream));
         hipLaunchKernelGGL(lsf_scatter_multi_kernel, dim3((unsigned)((nmax + 255) / 256), nb), dim3(256), 0, stream, t, y,
                            dy, d_off, d_stats, b0, f0, df, nfft, nterms, d_grids);
+        hipLaunchKernelGGL(lsf_unquantize_kernel, dim3((N1 + 7) / 8, nb * NG), dim3(256), 0, stream, d_grids, m1, m2,
+                           (const int *)nullptr, d_stats, b0, NG, nterms);
         if (reg_path) {
             launch_cols_reg(h, m1, m2, nb * NG, d_grids, nullptr, nullptr, 1, stream);
             launch_rows_reg(h, m1, m2, nb * NG, d_grids, (int)M, d_spec, stream);

@@ -1915,7 +1915,8 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
 // Residuals ||C v - lambda v|| <= 1e-15 lambda_max in the numpy restatement this was written from (steep pixel-block
 // spectra, flat product-block spectra, repeated eigenvalues).  One 1024-thread workgroup per matrix (LDS: 76 KB triangle +
 // 18 KB vectors + 36 KB scratch of the twisted factorisations).
-constexpr int TD_NT = 1024, TD_LANES = 16;  // eigenvectors factorised at a time (LDS scratch 2 P doubles each)
+constexpr int TD_NT = 1024, TD_LANES = 16;  // eigenvectors factorised at a time (LDS scratch 2 P doubles each); 8 where that lets two
+                                            // workgroups share a CU (td_plan)
 
 // Wave-wide sum in every lane without the LDS crossbar: four DPP levels inside each row of 16 lanes (quad swaps, half-row and
 // row mirrors), then the four row sums through v_readlane.  ~10x shorter than six dependent ds_bpermute round trips — the
@@ -1944,9 +1945,13 @@ __device__ __forceinline__ double td_wave_sum(double x) {
 
 __device__ __forceinline__ int td_tri(int i, int j) { return ((i * (i + 1)) >> 1) + j; }  // j <= i
 
-__global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__restrict__ G, int ldg, int P, int k,
-                                                                 double *__restrict__ V, double *__restrict__ lam,
-                                                                 unsigned long long *__restrict__ clk) {
+// Round 6: the eigenvectors live in their output array V (global, L2-resident) instead of LDS and the twisted factorisations run
+// `tdl` (8 or 16) at a time, so that a 121-column matrix needs 79 KB of LDS instead of 111 — with the kernel at 64 VGPRs TWO
+// 1024-thread workgroups share a CU and a batch of 500 runs as one wave of workgroups whose barrier-separated Householder steps
+// interleave, instead of two rounds of one latency-bound workgroup per CU.
+__global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double *__restrict__ G, int ldg, int P, int k,
+                                                                    double *__restrict__ V, double *__restrict__ lam,
+                                                                    unsigned long long *__restrict__ clk, int tdl) {
 #ifdef LK_PLD_DEBUG   // per-phase clocks of matrix 0 (100 MHz wall clock), `make DEBUG=1`
 #define TD_CLK(slot)                                                                 \
     do {                                                                             \
@@ -1970,8 +1975,9 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
     double *vb = pb + P;                    // the current reflector
     double *e2 = pb;                        // squared off-diagonal of T (phase 2 on)
     double *lamv = vb + P;                  // k eigenvalues (descending)
-    double *Z = lamv + ((k + 1) & ~1);      // P x k eigenvectors (row-major, like V)
-    double *ws = Z + (size_t)P * k;         // TD_LANES x 2 x P scratch of the twisted factorisations, [which][i][lane]
+    double *zinv = lamv + ((k + 1) & ~1);   // 1 / norm of the k twisted-factorisation vectors
+    double *ws = zinv + ((k + 1) & ~1);     // tdl x 2 x P scratch of the twisted factorisations, [which][i][lane]
+    double *Z = V + (size_t)b * P * k;      // P x k eigenvectors (row-major): the output array itself
     // ---- load the lower triangle (G's upper triangle is always valid: element (i, j <= i) = G[j][i])
     for (int j = wave; j < P; j += NW)  // row j of G from its diagonal on: coalesced
         for (int i = j + lane; i < P; i += 64) At[td_tri(i, j)] = Gb[(size_t)j * ldg + i];
@@ -2078,40 +2084,47 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
     const double tnorm = fmax(fabs(gl), fabs(gu)), eps = 2.220446049250313e-16;
     const double tinv = tnorm > 0.0 ? 1.0 / tnorm : 1.0;
     double *ddn = vb;
+    // (round 6) e2 is kept >= 1e-140: after an exactly vanishing p_i the next term -e_i^2 p_{i-1} is then non-zero, so the loop
+    // below needs no test for zeros at all (a zero may carry either sign: the sign changes over it and its successor add up to
+    // one, the Sturm convention) — and a block that decouples exactly (a constant pixel: e = 0) cannot stall the recurrence.  The
+    // shift of the eigenvalues is < 1e-70 |T|.
     for (int i = tid; i < P; i += TD_NT) {
         ddn[i] = dd[i] * tinv;
-        if (i < P - 1) e2[i] = (ee[i] * tinv) * (ee[i] * tinv);
+        if (i < P - 1) e2[i] = fmax((ee[i] * tinv) * (ee[i] * tinv), 1e-140);
     }
     __syncthreads();
     const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2max);
+    // Sign changes are counted on the sign BITS (xor of the high words, shift, add: three 32-bit operations) and p is rescaled once per
+    // 8 steps outside the unrolled body: 6 VALU instructions per step.  Round 5's form (a zero test and the rescale's two compares,
+    // two products and eight selects evaluated EVERY step: 45 instructions, profiles/r06_pld_tridiag.txt) made this phase 300-380 us
+    // of the kernel's ~950 per matrix, bound by instruction issue with one wave per eigenvalue.
     auto count_below = [&](double x) {  // eigenvalues of T below x
         const double xs = x * tinv;
-        int cnt = 0;
         double p0 = 1.0, p1 = ddn[0] - xs;
-        if (p1 == 0.0) p1 = -1e-300;
-        bool neg = p1 < 0.0;
-        cnt += neg;
-        double dn = ddn[1], en = e2[0];  // (P >= 3) the next step's coefficients are requested one step ahead
-        for (int i = 1; i < P; ++i) {
-            const double di = dn, ei = en;
-            if (i + 1 < P) {
-                dn = ddn[i + 1];
-                en = e2[i];
-            }
-            double pn = fma(di - xs, p1, -(ei * p0));
-            if (pn == 0.0) pn = neg ? 1e-300 : -1e-300;
-            const bool nneg = pn < 0.0;
-            cnt += nneg != neg;
-            neg = nneg;
+        int cnt = (int)((unsigned)__double2hiint(p1) >> 31);
+        auto step = [&](double di, double ei) {
+            const double pn = fma(di - xs, p1, -(ei * p0));
+            cnt += (int)((unsigned)(__double2hiint(pn) ^ __double2hiint(p1)) >> 31);
             p0 = p1;
             p1 = pn;
-            if ((i & 7) == 0) {
-                const double ap = fabs(p1);
-                const double sc = ap > 1e150 ? 1e-150 : (ap < 1e-150 ? 1e150 : 1.0);
-                p1 *= sc;
-                p0 *= sc;
+        };
+        int i = 1;
+        for (; i + 8 <= P; i += 8) {
+            double d8[8], e8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {  // (LDS broadcasts, all requested before the chain starts)
+                d8[u] = ddn[i + u];
+                e8[u] = e2[i + u - 1];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(d8[u], e8[u]);
+            // |p| grows or shrinks by at most ~3 per step on the scaled matrix (8 steps: < 1e4): one test per block keeps it in range
+            const double ap = fmax(fabs(p1), fabs(p0));
+            const double sc = ap > 1e150 ? 1e-150 : (ap < 1e-150 ? 1e150 : 1.0);
+            p1 *= sc;
+            p0 *= sc;
         }
+        for (; i < P; ++i) step(ddn[i], e2[i - 1]);
         return cnt;
     };
     for (int j = wave; j < k; j += NW) {
@@ -2140,25 +2153,25 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
     // z_r = 1, z_{i+1} = -U_i z_i below it and z_{i-1} = -L_{i-1} z_i above it.  One pass, 2 P doubles of scratch per vector
     // (the LU-based inverse iteration this replaced kept 4 P and swept the matrix four times).
     const double cl_tol = 1e-3 * tnorm;  // "close" eigenvalues: orthogonalised against each other afterwards
-    for (int j0 = 0; j0 < k; j0 += TD_LANES) {
-        if (wave == 0 && lane < TD_LANES && j0 + lane < k) {
+    for (int j0 = 0; j0 < k; j0 += tdl) {
+        if (wave == 0 && lane < tdl && j0 + lane < k) {
             const int j = j0 + lane;
             double x0 = lamv[j];
             // equal eigenvalues are perturbed apart so that their factorisations (hence their vectors) differ
             int rank_in_cluster = 0;
             for (int jj = 0; jj < j; ++jj) rank_in_cluster += fabs(lamv[jj] - lamv[j]) < 10.0 * eps * tnorm ? 1 : 0;
             x0 -= 10.0 * eps * tnorm * (double)rank_in_cluster;
-            double *Ls = ws + lane, *Ds = Ls + (size_t)P * TD_LANES;  // [i][lane]
+            double *Ls = ws + lane, *Ds = Ls + (size_t)P * tdl;  // [i][lane]
             const double floor_ = eps * eps * tnorm;                    // breakdown guard for a vanishing pivot
             double dp = dd[0] - x0;
             for (int i = 0; i < P - 1; ++i) {
                 if (fabs(dp) < floor_) dp = dp < 0.0 ? -floor_ : floor_;
                 const double ei = ee[i], li = ei / dp;
-                Ds[(size_t)i * TD_LANES] = dp;
-                Ls[(size_t)i * TD_LANES] = li;
+                Ds[(size_t)i * tdl] = dp;
+                Ls[(size_t)i * tdl] = li;
                 dp = (dd[i + 1] - x0) - li * ei;
             }
-            Ds[(size_t)(P - 1) * TD_LANES] = dp;
+            Ds[(size_t)(P - 1) * tdl] = dp;
             // from the bottom: D-_i, gamma_i, the twist; U_i overwrites D+_{i+1} (no longer needed once gamma_{i+1} is known)
             double dm = dd[P - 1] - x0;
             double gbest = fabs(dp + dm - (dd[P - 1] - x0));
@@ -2166,9 +2179,9 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
             for (int i = P - 2; i >= 0; --i) {
                 if (fabs(dm) < floor_) dm = dm < 0.0 ? -floor_ : floor_;
                 const double ei = ee[i], ui = ei / dm;
-                Ds[(size_t)(i + 1) * TD_LANES] = ui;  // U_i lives at slot i + 1
+                Ds[(size_t)(i + 1) * tdl] = ui;  // U_i lives at slot i + 1
                 dm = (dd[i] - x0) - ui * ei;
-                const double g = fabs(Ds[(size_t)i * TD_LANES] + dm - (dd[i] - x0));
+                const double g = fabs(Ds[(size_t)i * tdl] + dm - (dd[i] - x0));
                 if (g < gbest) {
                     gbest = g;
                     r = i;
@@ -2177,21 +2190,27 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
             double nrm2 = 1.0, zi = 1.0;
             Z[(size_t)r * k + j] = 1.0;
             for (int i = r; i < P - 1; ++i) {
-                zi = -Ds[(size_t)(i + 1) * TD_LANES] * zi;
+                zi = -Ds[(size_t)(i + 1) * tdl] * zi;
                 Z[(size_t)(i + 1) * k + j] = zi;
                 nrm2 = fma(zi, zi, nrm2);
             }
             zi = 1.0;
             for (int i = r; i > 0; --i) {
-                zi = -Ls[(size_t)(i - 1) * TD_LANES] * zi;
+                zi = -Ls[(size_t)(i - 1) * tdl] * zi;
                 Z[(size_t)(i - 1) * k + j] = zi;
                 nrm2 = fma(zi, zi, nrm2);
             }
-            const double inv = 1.0 / sqrt(nrm2);
-            for (int i = 0; i < P; ++i) Z[(size_t)i * k + j] *= inv;
+            zinv[j] = 1.0 / sqrt(nrm2);
         }
         __syncthreads();
+        // normalise the batch's vectors (every thread; the vectors sit in global memory)
+        const int nb = min(tdl, k - j0);
+        for (int e = tid; e < P * nb; e += TD_NT) {
+            const int i = e / nb, jj = j0 + (e - i * nb);
+            Z[(size_t)i * k + jj] *= zinv[jj];
+        }
     }
+    __syncthreads();
     TD_CLK(3);
     // modified Gram-Schmidt inside clusters, in eigenvalue order (a wave per step; rare: spectra of real blocks are separated)
     if (wave == 0) {
@@ -2243,8 +2262,6 @@ __global__ __launch_bounds__(TD_NT) void pld_tridiag_eig_kernel(const double *__
     }
     __syncthreads();
     TD_CLK(5);
-    double *Vb = V + (size_t)b * P * k;
-    for (int e = tid; e < P * k; e += TD_NT) Vb[e] = Z[e];
     if (tid < k) lam[(size_t)b * k + tid] = lamv[tid];
 #undef TD_CLK
 }
@@ -2292,8 +2309,14 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
     // direct tridiagonal solver — ~0.5 ms per launch and matrix instead of the 2-3 ms of a subspace iteration's
     // Rayleigh-Ritz steps at this size
     // (P = 134 .. 138 with k in the 40s needs more than 160 KB: those shapes fall through to the subspace iteration)
-    const size_t td_lds = ((size_t)((((P * (P + 1)) / 2) + 1) & ~1) + 6 * (size_t)P + ((k + 1) & ~1) + (size_t)P * k +
-                           (size_t)TD_LANES * 2 * P) * 8 + 16;
+    // LDS of the direct solver: packed triangle + six P-vectors + eigenvalues and vector norms + the twisted factorisations' scratch
+    // (the eigenvectors themselves live in V).  8 factorisations at a time instead of 16 where that brings a workgroup under half
+    // a CU's LDS (P <= ~122 at k = 16: the 121-column pixel / background blocks).
+    auto td_lds_bytes = [&](int tdl_) {
+        return ((size_t)((((P * (P + 1)) / 2) + 1) & ~1) + 6 * (size_t)P + 2 * (size_t)((k + 1) & ~1) + (size_t)tdl_ * 2 * P) * 8 + 16;
+    };
+    const int tdl = (td_lds_bytes(TD_LANES) > 80 * 1024 && td_lds_bytes(TD_LANES / 2) <= 80 * 1024) ? TD_LANES / 2 : TD_LANES;
+    const size_t td_lds = td_lds_bytes(tdl);
     if (P >= 3 && P <= PLD_DIRECT_MAX && td_lds <= 160 * 1024) {
         const size_t lds = td_lds;
         int rc_ = want_lds(h, reinterpret_cast<const void *>(pld_tridiag_eig_kernel), 160 * 1024);
@@ -2302,7 +2325,7 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
 #ifdef LK_PLD_DEBUG
         if (dbg_iters) d_clk = (unsigned long long *)ws.alloc(64);
 #endif
-        hipLaunchKernelGGL(pld_tridiag_eig_kernel, dim3(B), dim3(TD_NT), lds, stream, G, ldg, P, k, V, lam, d_clk);
+        hipLaunchKernelGGL(pld_tridiag_eig_kernel, dim3(B), dim3(TD_NT), lds, stream, G, ldg, P, k, V, lam, d_clk, tdl);
 #ifdef LK_PLD_DEBUG
         if (d_clk) {
             unsigned long long hc[8];
