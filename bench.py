@@ -1285,6 +1285,7 @@ def main():
         dt, kern_ms = results[headline]
         roofline = ls_roofline(headline, kern_ms)
         if len(rep_kms) > 1:
+            roofline["kernel_ms_per_step_by_block"] = [float(k) for k in rep_kms]   # in the order they ran
             fr = sorted(ls_roofline(headline, k)["frac"] for k in rep_kms)
             roofline["frac_runs"] = fr
             roofline["frac_median"], roofline["frac_min"], roofline["frac_max"] = float(np.median(fr)), fr[0], fr[-1]

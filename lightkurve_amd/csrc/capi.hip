@@ -154,6 +154,11 @@ void lk_destroy(lk_handle *h) {
             if (arr[i]) (void)hipEventDestroy(arr[i]);
     if (h->h_plan) (void)hipHostFree(h->h_plan);
     if (h->s_probe) (void)hipStreamDestroy(h->s_probe);
+    for (int a = 0; a < 3; ++a) {
+        if (h->s_ls_aux[a]) (void)hipStreamDestroy(h->s_ls_aux[a]);
+        if (h->ev_ls_join[a]) (void)hipEventDestroy(h->ev_ls_join[a]);
+    }
+    if (h->ev_ls_fork) (void)hipEventDestroy(h->ev_ls_fork);
     if (h->clk_buf) (void)hipHostFree(h->clk_buf);
     if (h->flat_tab_dev) (void)hipFree(h->flat_tab_dev);
     h->ws.release();

@@ -635,6 +635,15 @@ constexpr int PRUNED_CT = 16;
 #ifndef LSF_PRIO
 #define LSF_PRIO 0
 #endif
+#ifndef LSF_TWO_STREAMS
+#define LSF_TWO_STREAMS 1   // number of EXTRA streams of the chunk loop (0 .. 3); 1: -2 % on the step (profiles/r06_lsfast_two_streams_ab.txt)
+#endif
+#ifndef LSF_STAGGER
+#define LSF_STAGGER 0
+#endif
+#ifndef LSF_CHUNK_HALF_GB
+#define LSF_CHUNK_HALF_GB 3  // bytes of grids per chunk, in units of 2^29 (1.5 GiB = 60 targets at Nfft = 2^19)
+#endif
 #define LSF_SETPRIO(bit, p)                                         \
     do {                                                            \
         if (LSF_PRIO & (bit)) __builtin_amdgcn_s_setprio(p);        \
@@ -1564,9 +1573,9 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int nfft = 1 << m, m1 = (m + 1) / 2, m2 = m / 2;
     const int N1 = 1 << m1, N2 = 1 << m2;
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
-    // targets per chunk: the grids (3 x 16 B x Nfft per target) stay within 2 GiB (smaller chunks leave too few workgroups
-    // per launch; larger ones measured the same)
-    const size_t chunk_bytes = (size_t)2 << 30;
+    // targets per chunk: the grids (3 x 16 B x Nfft per target) stay within 1.5 GiB (LSF_CHUNK_HALF_GB; 1, 1.5 and 2 GiB
+    // measure the same within the rep noise once two streams share the chunks, 4 GiB no better)
+    const size_t chunk_bytes = (size_t)LSF_CHUNK_HALF_GB << 29;
     int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     if (Bc >= 8) Bc &= ~3;  // N1 / 8 row tiles per target x a multiple of 4 targets: a whole number of rounds of 2 x 256 workgroups
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
@@ -1583,7 +1592,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int ntab_max = std::max(ntab256, ntab16);
     h->ws.reset();
     int rc = h->ws.reserve((size_t)(B + 1) * 8 + (size_t)B * sizeof(FastStats) + 512 +
-                           (size_t)Bc * 3 * nfft * 16 * 2 + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
+                           (size_t)Bc * 3 * nfft * 16 * (2 + (LSF_TWO_STREAMS > 1 ? LSF_TWO_STREAMS - 1 : 0)) + (size_t)Bc * 3 * M * 16 + (size_t)B * 16 +
                            (size_t)B * 4 * ntab_max * 4 + (size_t)(B + 1) * nparts_max * sizeof(PeakPart) + 16384);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
@@ -1595,6 +1604,11 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int tw = tile_width(m1, m2);
     double2 *d_grids2 = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16) : nullptr;
     LK_REQUIRE(!fused || d_grids2 != nullptr, "workspace exhausted");
+    double2 *d_grids3[2] = {nullptr, nullptr};
+    for (int a = 0; a < LSF_TWO_STREAMS - 1 && a < 2; ++a) {
+        d_grids3[a] = fused ? (double2 *)h->ws.alloc((size_t)Bc * 3 * nfft * 16) : nullptr;
+        LK_REQUIRE(!fused || d_grids3[a] != nullptr, "workspace exhausted");
+    }
     int *d_rows = (int *)h->ws.alloc((size_t)B * 4 * 4);
     int *d_plan = (int *)h->ws.alloc(64);
     int *d_tab = reg_path ? (int *)h->ws.alloc((size_t)B * 4 * ntab_max * 4) : nullptr;
@@ -1628,9 +1642,29 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         (void)want_lds(h, reinterpret_cast<const void *>(fft_rows_kernel), 100 * 1024);
     }
     const size_t ldsA = ((size_t)CT * N1 + N1 / 2 + 1) * 16, ldsB = ((size_t)RT * N2 + N2 / 2 + 1) * 16;
-    for (int b0 = 0; b0 < B; b0 += Bc) {
+    // Chunks alternate between the caller's stream and a second one (each with its own intermediate: the spread-grid buffer is
+    // free when every target is ordered and the pruned column kernel spreads by itself), so that the tail of a chunk's row
+    // kernel and the head of the next chunk's column kernel — and, throughout, a store-heavy and a load-heavy kernel — share the
+    // GPU.  LSF_TWO_STREAMS (experiment of round 6, profiles/r06_lsfast_two_streams_ab.txt).
+    const int nstreams = (LSF_TWO_STREAMS && fused && lp != 0 && n_unordered == 0 && B > Bc) ? std::min(LSF_TWO_STREAMS + 1, 4) : 1;
+    double2 *inter_buf[4] = {d_grids2, d_grids, d_grids3[0], d_grids3[1]};
+    if (nstreams > 1) {
+        if (!h->ev_ls_fork) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ls_fork, hipEventDisableTiming));
+        LK_HIP_CHECK(hipEventRecord(h->ev_ls_fork, stream));
+        for (int a = 0; a < nstreams - 1; ++a) {
+            if (!h->s_ls_aux[a]) LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_ls_aux[a], hipStreamNonBlocking));
+            if (!h->ev_ls_join[a]) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ls_join[a], hipEventDisableTiming));
+            if (!LSF_STAGGER) LK_HIP_CHECK(hipStreamWaitEvent(h->s_ls_aux[a], h->ev_ls_fork, 0));
+        }
+    }
+    hipStream_t caller_stream = stream;
+    int chunk_no = 0;
+    for (int b0 = 0; b0 < B; b0 += Bc, ++chunk_no) {
         const int nb = std::min(Bc, B - b0);
         double2 *gr = d_grids;
+        const int lane_s = chunk_no % nstreams;
+        stream = lane_s ? h->s_ls_aux[lane_s - 1] : caller_stream;
+        double2 *inter = inter_buf[lane_s];
         // targets that are not "ordered" (unsorted time, or a 2f grid that wraps): zero their live rows, scatter with global
         // atomics.  Skipped when the plan found none (the usual batch).
         if (!reg_path) {
@@ -1658,15 +1692,26 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
                                d_peaks ? d_peaks + (size_t)b0 * nparts : nullptr};
             if (lp) {
                 const SpreadArgs sa{t, y, dy, d_off, d_stats, b0, f0, df, fit_mean, n_unordered < B ? d_tab : nullptr, ntab};
-                LK_REQUIRE(launch_cols_pruned(h, lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, sa, stream),
+                LK_REQUIRE(launch_cols_pruned(h, lp, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, inter, sa, stream),
                            "no pruned column kernel for 2^%d rows", lp);
+                if (LSF_STAGGER && nstreams > 1 && chunk_no == 0) {  // the other streams start one column kernel late: opposite phases
+                    LK_HIP_CHECK(hipEventRecord(h->ev_ls_fork, stream));
+                    for (int a = 0; a < nstreams - 1; ++a) LK_HIP_CHECK(hipStreamWaitEvent(h->s_ls_aux[a], h->ev_ls_fork, 0));
+                }
             } else {
-                launch_cols_reg(h, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, d_grids2, tw, stream);
+                launch_cols_reg(h, m1, m2, nb * 3, gr, d_rows + (size_t)b0 * 4, inter, tw, stream);
             }
-            LK_REQUIRE(launch_rows_power(h, m1, m2, nb, d_grids2, fa, lp ? PRUNED_CT : tw, stream),
+            LK_REQUIRE(launch_rows_power(h, m1, m2, nb, inter, fa, lp ? PRUNED_CT : tw, stream),
                        "no step-2 kernel for this layout");
-            if (d_peaks && b0 + nb == B)
-                hipLaunchKernelGGL(lsf_peaks_kernel, dim3(B), dim3(64), 0, stream, d_peaks, nparts, 0, max_out, arg_out);
+            if (b0 + nb == B) {
+                for (int a = 0; a < nstreams - 1; ++a) {  // join: the caller's stream continues when all have drained
+                    LK_HIP_CHECK(hipEventRecord(h->ev_ls_join[a], h->s_ls_aux[a]));
+                    LK_HIP_CHECK(hipStreamWaitEvent(caller_stream, h->ev_ls_join[a], 0));
+                }
+                stream = caller_stream;
+                if (d_peaks)
+                    hipLaunchKernelGGL(lsf_peaks_kernel, dim3(B), dim3(64), 0, stream, d_peaks, nparts, 0, max_out, arg_out);
+            }
             continue;
         }
         if (reg_path) {
@@ -1680,6 +1725,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         hipLaunchKernelGGL(lsf_power_kernel, dim3((unsigned)((M + 255) / 256), nb), dim3(256), 0, stream, d_spec,
                            d_off, d_stats, b0, f0, df, M, fit_mean, normalization, scale, power);
     }
+    stream = caller_stream;
     if (const int lrc = take_lds_error(h)) return lrc;  // a launch helper could not raise a kernel's dynamic-LDS limit
     LK_HIP_CHECK(hipGetLastError());
     if (max_out && !fused) return argmax_launch(h, B, M, power, max_out, arg_out, stream);
