@@ -61,8 +61,10 @@ SYS_STDCXX = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # defaults: the LS step is 11 ms and takes ~5 calls to reach its steady state after an idle GPU (20.1, 11.3, 10.9, 10.8, 10.76,
+    # 10.70 ... ms per call, profiles/r06_lsfast_two_streams_ab.txt): 3 warm-up + 20 timed steps; the other blocks cap their own counts
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--targets", type=int, default=1000, help="targets per GPU (B), weak scaling")
     ap.add_argument("--total-targets", type=int, default=0,
                     help="strong scaling: total targets of the job, sharded over the ranks (configs[2]: 10000)")

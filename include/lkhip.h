@@ -89,7 +89,7 @@ int lk_bls_set_ordered_histogram(lk_handle *h, int on);
 int lk_pld_set_eig_tolerance(lk_handle *h, double tol);
 /* Form of that subspace iteration for Gram matrices beyond the direct solver (P > 138): 0 (default) = one workgroup carries a
  * matrix through the whole iteration in ONE kernel (pld_topk_eig_kernel); 1 = every phase — products with C, Rayleigh-Ritz,
- * Cholesky-QR — is its own launch over all matrices with the state in global memory (pld_eigs_* kernels: no spilled VGPRs,
+ * Cholesky-QR — is its own launch over all matrices with the state in global memory (pld_eigs_* kernels: no spilled VGPRs in the small phases,
  * per-phase times in a plain kernel trace), converged matrices dropping out by flag and the one-kernel form finishing whatever is
  * left.  Same arithmetic, same results to rounding; 0 is 1-2 % faster on the PLD step (profiles/r06_pld_eig_modes_ab.txt). */
 int lk_pld_set_eig_mode(lk_handle *h, int mode);
