@@ -9,11 +9,11 @@ tools/trace_lsfast.sh $out/ls
 tools/pmc_pass.sh $out ls_fetch FETCH_SIZE --no-bls --no-pld --no-flatten --no-host --no-cpu-baseline --ls-method fast --no-api --no-pipeline --c2-targets 0 --targets 180 --steps 3 --warmup 1 --repeats 1
 tools/pmc_pass.sh $out ls_write WRITE_SIZE --no-bls --no-pld --no-flatten --no-host --no-cpu-baseline --ls-method fast --no-api --no-pipeline --c2-targets 0 --targets 180 --steps 3 --warmup 1 --repeats 1
 tools/trace_pld.sh $out/pld
-tools/pmc_pass.sh $out pld_fetch FETCH_SIZE --workload pld --no-cpu-baseline --steps 3 --warmup 1
-tools/pmc_pass.sh $out pld_write WRITE_SIZE --workload pld --no-cpu-baseline --steps 3 --warmup 1
+tools/pmc_pass.sh $out pld_fetch FETCH_SIZE --workload pld --no-cpu-baseline --no-api --steps 3 --warmup 1
+tools/pmc_pass.sh $out pld_write WRITE_SIZE --workload pld --no-cpu-baseline --no-api --steps 3 --warmup 1
 tools/trace_flatten.sh $out/flat
-tools/pmc_pass.sh $out flat_fetch FETCH_SIZE --workload flatten --no-cpu-baseline --steps 3 --warmup 1
-tools/pmc_pass.sh $out flat_write WRITE_SIZE --workload flatten --no-cpu-baseline --steps 3 --warmup 1
+tools/pmc_pass.sh $out flat_fetch FETCH_SIZE --workload flatten --no-cpu-baseline --no-api --steps 3 --warmup 1
+tools/pmc_pass.sh $out flat_write WRITE_SIZE --workload flatten --no-cpu-baseline --no-api --steps 3 --warmup 1
 if [ -f build/ab/pld_dbg.so ]; then
   LK_PLD_ITERS=1 LK_LIB_PATH=$PWD/build/ab/pld_dbg.so python bench.py --workload pld --no-cpu-baseline --steps 1 --warmup 1 2>&1 >/dev/null | grep "pld tridiag\|pld eig" | head -8 > $out/pld_phase_clocks.txt
 fi
