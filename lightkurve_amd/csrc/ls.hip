@@ -284,20 +284,26 @@ __global__ __launch_bounds__(64, (F <= 10 ? 3 : 2)) void ls_grid_kernel(const Ca
 // ------------------------------------------------------------------------------------------------ arbitrary frequencies
 // One thread per frequency, one exactly-reduced sincos per (cadence, frequency) pair (~7x the grid kernel's cost).
 // Used when the requested grid is not regular in frequency (lightkurve then picks 'slow': periodogram.py:933-946).
+// Cadence-sliced form (round 6): a seam call at B = 1 with a few thousand irregular frequencies — lightkurve's 'fast' -> 'slow'
+// switch for every period= request, periodogram.py:933-946 — put 2000 threads on a 256-CU chip and walked all N cadences in each
+// (6.7 ms at N = 20 000).  blockIdx.z = slice of the cadences; with nslice > 1 the six sums of a slice go to
+// part[target][slice][sum][j] and ls_any_finish_kernel adds the slices in slice order (a fixed order: bitwise reproducible) and
+// forms the power.  nslice depends on (B, M, longest target) only.
 __global__ __launch_bounds__(256) void ls_any_kernel(const CadAny *__restrict__ cad,
                                                       const int64_t *__restrict__ n_off,
                                                       const TargetStats *__restrict__ stats,
                                                       const double *__restrict__ freq, int64_t M, int norm,
                                                       int fit_mean, const double *__restrict__ scale,
-                                                      double *__restrict__ power) {
-    const int target = blockIdx.y;
+                                                      double *__restrict__ power, int nslice, double *__restrict__ part) {
+    const int target = blockIdx.y, slice = blockIdx.z;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t lo = n_off[target];
     const int n = (int)(n_off[target + 1] - lo);
     cad += lo;
     const double f = (j < M) ? freq[j] : 0.0;
     double Sh = 0, Ch = 0, S = 0, C = 0, S2 = 0, C2 = 0;
-    for (int i = 0; i < n; ++i) {
+    const int i_lo = (int)((int64_t)n * slice / nslice), i_hi = (int)((int64_t)n * (slice + 1) / nslice);
+    for (int i = i_lo; i < i_hi; ++i) {
         const CadAny q = cad[i];  // uniform -> scalar load
         double sn, cs;
         sincos2pi_prod(f, q.t, &sn, &cs);
@@ -309,12 +315,40 @@ __global__ __launch_bounds__(256) void ls_any_kernel(const CadAny *__restrict__ 
         S2 = fma(a, b, S2);
         C2 = fma(a, a, C2);
     }
-    if (j < M) {
+    if (j >= M) return;
+    if (nslice == 1) {
         const TargetStats st = stats[target];
         power[(size_t)target * (size_t)M + j] =
             gls_power(Sh, Ch, S, C, S2, C2, fit_mean, norm, st.YY, 0.5 * st.wsum, (double)n,
                       scale ? scale[target] : 1.0);
+    } else {
+        double *p = part + ((size_t)target * nslice + slice) * 6 * (size_t)M + j;
+        p[0] = Sh;
+        p[(size_t)M] = Ch;
+        p[2 * (size_t)M] = S;
+        p[3 * (size_t)M] = C;
+        p[4 * (size_t)M] = S2;
+        p[5 * (size_t)M] = C2;
     }
+}
+
+__global__ __launch_bounds__(256) void ls_any_finish_kernel(const double *__restrict__ part, const int64_t *__restrict__ n_off,
+                                                             const TargetStats *__restrict__ stats, int64_t M, int nslice,
+                                                             int norm, int fit_mean, const double *__restrict__ scale,
+                                                             double *__restrict__ power) {
+    const int target = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    double sm[6] = {0, 0, 0, 0, 0, 0};
+    for (int sl = 0; sl < nslice; ++sl) {
+        const double *p = part + ((size_t)target * nslice + sl) * 6 * (size_t)M + j;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sm[q] += p[(size_t)q * M];
+    }
+    const TargetStats st = stats[target];
+    const int n = (int)(n_off[target + 1] - n_off[target]);
+    power[(size_t)target * (size_t)M + j] = gls_power(sm[0], sm[1], sm[2], sm[3], sm[4], sm[5], fit_mean, norm, st.YY, 0.5 * st.wsum,
+                                                      (double)n, scale ? scale[target] : 1.0);
 }
 
 // ------------------------------------------------------------------------------------------------ multi-term (chi2)
@@ -473,8 +507,16 @@ int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
         LK_REQUIRE(n_off_host[b + 1] - n_off_host[b] < (int64_t)1 << 30, "target %d too long", b);
 
     h->ws.reset();
+    // irregular single-term grids with few (target, frequency) pairs: slices of the cadences fill the chip (ls_any_kernel)
+    int any_slices = 1;
+    if (freq && nterms == 1) {
+        int64_t nmax = 1;
+        for (int b = 0; b < B; ++b) nmax = std::max<int64_t>(nmax, n_off_host[b + 1] - n_off_host[b]);
+        const int64_t threads = (int64_t)B * ((M + 255) / 256) * 256;
+        any_slices = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(256, nmax / 64), ((int64_t)1 << 17) / threads));
+    }
     const size_t need = (size_t)(B + 1) * 8 + (size_t)B * sizeof(TargetStats) + ntot * (sizeof(CadHot) + sizeof(CadGen)) +
-                        (size_t)M * 8 + 4096;
+                        (size_t)M * 8 + (any_slices > 1 ? (size_t)B * any_slices * 6 * (size_t)M * 8 + 256 : 0) + 4096;
     int rc = h->ws.reserve(need);
     if (rc) return rc;
     int64_t *d_off = (int64_t *)h->ws.alloc((size_t)(B + 1) * 8);
@@ -503,10 +545,17 @@ int ls_chi2_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
     hipLaunchKernelGGL(ls_chi2_any_kernel<NT>, grid, dim3(256), 0, stream, d_any, d_off, d_stats, freq, M,           \
                        normalization, fit_mean, scale, power)
         switch (nterms) {
-            case 1:
-                hipLaunchKernelGGL(ls_any_kernel, grid, dim3(256), 0, stream, d_any, d_off, d_stats, freq, M,
-                                   normalization, fit_mean, scale, power);
+            case 1: {
+                double *d_part = any_slices > 1 ? (double *)h->ws.alloc((size_t)B * any_slices * 6 * (size_t)M * 8) : nullptr;
+                LK_REQUIRE(any_slices == 1 || d_part != nullptr, "workspace exhausted (partial sums)");
+                LK_REQUIRE(B <= 65535, "at most 65535 targets per call on an irregular frequency grid (got %d)", B);
+                hipLaunchKernelGGL(ls_any_kernel, dim3(grid.x, grid.y, (unsigned)any_slices), dim3(256), 0, stream, d_any, d_off,
+                                   d_stats, freq, M, normalization, fit_mean, scale, power, any_slices, d_part);
+                if (any_slices > 1)
+                    hipLaunchKernelGGL(ls_any_finish_kernel, grid, dim3(256), 0, stream, d_part, d_off, d_stats, M, any_slices,
+                                       normalization, fit_mean, scale, power);
                 break;
+            }
             case 2: LK_CHI2_ANY(2); break;
             case 3: LK_CHI2_ANY(3); break;
             case 4: LK_CHI2_ANY(4); break;

@@ -1658,6 +1658,18 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
         }
     }
     hipStream_t caller_stream = stream;
+    // an error return between the fork and the join must not leave work on the second stream behind (the next call resets the
+    // workspace those kernels use): the guard drains it
+    struct AuxGuard {
+        lk_handle *h;
+        int n;
+        bool joined;
+        ~AuxGuard() {
+            if (!joined)
+                for (int a = 0; a < n; ++a)
+                    if (h->s_ls_aux[a]) (void)hipStreamSynchronize(h->s_ls_aux[a]);
+        }
+    } aux_guard{h, nstreams - 1, nstreams == 1};
     int chunk_no = 0;
     for (int b0 = 0; b0 < B; b0 += Bc, ++chunk_no) {
         const int nb = std::min(Bc, B - b0);
@@ -1708,6 +1720,7 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
                     LK_HIP_CHECK(hipEventRecord(h->ev_ls_join[a], h->s_ls_aux[a]));
                     LK_HIP_CHECK(hipStreamWaitEvent(caller_stream, h->ev_ls_join[a], 0));
                 }
+                aux_guard.joined = true;
                 stream = caller_stream;
                 if (d_peaks)
                     hipLaunchKernelGGL(lsf_peaks_kernel, dim3(B), dim3(64), 0, stream, d_peaks, nparts, 0, max_out, arg_out);
