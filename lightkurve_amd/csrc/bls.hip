@@ -58,25 +58,53 @@ __global__ __launch_bounds__(256) void bls_prep_kernel(const double *__restrict_
     }
     const double min_t = sh[0];
     __syncthreads();
+    // tm, yw and the two sums in ONE sweep of 1024-cadence chunks: every thread forms its cadences' y * ivar and ivar, parks them in
+    // LDS, and one lane per sum adds the chunk SEQUENTIALLY from there (the reference's order: bit-exactness of the outputs rests on
+    // it) — eight LDS reads in flight in front of eight dependent additions.  (Round 6: the sums used to walk global memory one
+    // dependent load at a time — 640 us for 20 000 cadences, a fifth of a B = 1 call.)
+    __shared__ double sa[1024], sb[1024];
     int unsorted = 0;
-    for (int64_t i = tid; i < n; i += 256) {
-        tm[lo + i] = t[lo + i] - min_t;
-        yw[lo + i] = make_double2(y[lo + i] * ivar[lo + i], ivar[lo + i]);
-        if (i + 1 < n && !(t[lo + i] <= t[lo + i + 1])) unsorted = 1;
+    double sum_a = 0.0, sum_b = 0.0;  // (lane 0 of wave 0 / of wave 1)
+    for (int64_t c0 = 0; c0 < n; c0 += 1024) {
+        const int cn = (int)min((int64_t)1024, n - c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = tid + 256 * u;
+            if (k < cn) {
+                const int64_t i = c0 + k;
+                const double ti = t[lo + i], yi = y[lo + i], wi = ivar[lo + i];
+                tm[lo + i] = ti - min_t;
+                const double yw_ = yi * wi;
+                yw[lo + i] = make_double2(yw_, wi);
+                sa[k] = yw_;
+                sb[k] = wi;
+                if (i + 1 < n && !(ti <= t[lo + i + 1])) unsorted = 1;
+            }
+        }
+        __syncthreads();
+        if (tid == 0 || tid == 64) {
+            const double *src = tid == 0 ? sa : sb;
+            double s = tid == 0 ? sum_a : sum_b;
+            int k = 0;
+            for (; k + 8 <= cn; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = src[k + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += v[q];
+            }
+            for (; k < cn; ++k) s += src[k];
+            if (tid == 0)
+                sum_a = s;
+            else
+                sum_b = s;
+        }
+        __syncthreads();
     }
     unsorted = __syncthreads_or(unsorted);
-    if (tid == 0) {
-        double s = 0.0;
-        for (int64_t i = 0; i < n; ++i) s += y[lo + i] * ivar[lo + i];
-        sh[0] = s;
-    }
-    if (tid == 64) {
-        double s = 0.0;
-        for (int64_t i = 0; i < n; ++i) s += ivar[lo + i];
-        sh[1] = s;
-    }
+    if (tid == 64) sh[1] = sum_b;
     __syncthreads();
-    if (tid == 0) stats[b] = BlsStats{min_t, sh[0], sh[1], unsorted ? 0.0 : 1.0};
+    if (tid == 0) stats[b] = BlsStats{min_t, sum_a, sh[1], unsorted ? 0.0 : 1.0};
 }
 
 // exact k = trunc(t/P), r = fmod(t, P) for t >= 0, P > 0 (fmod results are always representable, so the
@@ -1217,9 +1245,36 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         hipLaunchKernelGGL(bls_wide_kernel, dim3((unsigned)wide_slabs), dim3(BLSW_NT), 0, stream, d_tm, d_yw, d_off, d_stats,
                            period_dev, d_pidx, n_wide, nP, B, d_dur_caller, nd, bin_duration, oversample,
                            use_likelihood ? 1 : 0, out7, d_slabs, wide_cap);
+    // Small jobs (a seam call at B = 1: ~20 groups of a few hundred teams, every launch less than one wave of workgroups and
+    // ~100 us of one team's latency): the groups are independent — they write different periods' outputs — so they are spread
+    // over the handle's streams and run side by side (round 6: 2.4 -> 0.7 ms of team kernels per 5000-period call).
+    const int n_spread = (!prof_on && (size_t)B * (size_t)nP <= 65536) ? 4 : 1;
+    hipStream_t caller_stream = stream;
+    struct SpreadGuard {  // an error return between fork and join drains the side streams
+        lk_handle *h;
+        int n;
+        bool joined;
+        ~SpreadGuard() {
+            if (!joined)
+                for (int a = 0; a < n; ++a)
+                    if (h->s_ls_aux[a]) (void)hipStreamSynchronize(h->s_ls_aux[a]);
+        }
+    } spread_guard{h, n_spread - 1, n_spread == 1};
+    if (n_spread > 1) {
+        if (!h->ev_ls_fork) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ls_fork, hipEventDisableTiming));
+        LK_HIP_CHECK(hipEventRecord(h->ev_ls_fork, caller_stream));
+        for (int a = 0; a < n_spread - 1; ++a) {
+            if (!h->s_ls_aux[a]) LK_HIP_CHECK(hipStreamCreateWithFlags(&h->s_ls_aux[a], hipStreamNonBlocking));
+            if (!h->ev_ls_join[a]) LK_HIP_CHECK(hipEventCreateWithFlags(&h->ev_ls_join[a], hipEventDisableTiming));
+            LK_HIP_CHECK(hipStreamWaitEvent(h->s_ls_aux[a], h->ev_ls_fork, 0));
+        }
+    }
+    int group_no = 0;
     size_t g0 = (size_t)n_wide;
     while (g0 < (size_t)nP) {
         const int head_bins = nbins_of(order[g0]);
+        stream = (group_no % n_spread) ? h->s_ls_aux[group_no % n_spread - 1] : caller_stream;
+        ++group_no;
         if (prof_on) LK_HIP_CHECK(hipEventRecord(pe0, stream));
         // groups: cut whenever the LDS need drops below 7/8 of the group's head (occupancy stays close to the need) — and
         // where one more single-period team would fit a CU (a group that straddles such a step runs all its periods at the
@@ -1294,6 +1349,12 @@ int bls_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *t, 
         }
         g0 = g1;
     }
+    stream = caller_stream;
+    for (int a = 0; a < n_spread - 1; ++a) {
+        LK_HIP_CHECK(hipEventRecord(h->ev_ls_join[a], h->s_ls_aux[a]));
+        LK_HIP_CHECK(hipStreamWaitEvent(caller_stream, h->ev_ls_join[a], 0));
+    }
+    spread_guard.joined = true;
     if (d_prof) LK_HIP_CHECK(hipFree(d_prof));
     if (pe0) {
         (void)hipEventDestroy(pe0);

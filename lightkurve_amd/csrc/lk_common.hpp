@@ -80,7 +80,8 @@ struct lk_handle {
     int bls_force_serial_hist = 0; // lk_bls_set_ordered_histogram: the caller asked for that form (tests, diagnosis)
     double pld_eig_tol = 0.0;      // lk_pld_set_eig_tolerance: stop of the PLD blocks' subspace iteration (0: the built-in 1e-7)
     int pld_eig_split = 0;         // lk_pld_set_eig_mode: 0 = the one-kernel subspace iteration (default: the faster, profiles/r06_pld_eig_modes_ab.txt), 1 = its phase-split form (pld_eigs_* kernels) in front of it
-    // lsfast.hip: second stream of the chunk loop + fork / join events (LSF_TWO_STREAMS builds; created on first use)
+    // side streams of the handle + fork / join events, created on first use: lsfast.hip runs its chunk loop on two streams, bls.hip
+    // spreads the period groups of a small job over four; every call joins them back into the caller's stream before it returns
     hipStream_t s_ls_aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_ls_fork = nullptr, ev_ls_join[3] = {nullptr, nullptr, nullptr};
     // flatten.hip: the batch's two offset tables (cadence offsets | scratch-slab offsets) stay on the device between calls; a
