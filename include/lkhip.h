@@ -36,7 +36,9 @@
  *     thread-safe.  ALL calls on one handle must use ONE stream (or be separated by a stream/device
  *     synchronisation): every launcher carves its kernel scratch from the handle's single arena, so two calls
  *     in flight on different streams would overwrite each other's live scratch.  Use one handle per stream /
- *     per thread if you need concurrency on one GPU.
+ *     per thread if you need concurrency on one GPU.  (Inside a call the library may fork side streams of its own —
+ *     lk_ls_fast_* runs its chunks on two, lk_bls_* spreads the period groups of a small job over four — and joins them
+ *     back into `stream` by events before it returns: to the caller the call is still ordered on `stream`.)
  *     Multi-GPU = one handle per rank, targets sharded by the caller (no data-path collective).
  *   - Deviations from the ABI sketched in SURVEY.md §8(b), on purpose: lk_init takes ONE device id (one handle
  *     = one GPU = one process, the torch.distributed model; the sketch's device list would put multi-GPU fan-out
