@@ -293,6 +293,12 @@ __global__ __launch_bounds__(256) void pld_products_kernel(const double *__restr
 // LDS (o reads and o - 1 multiplications per element).  A wave owns up to 4 x 4 tiles (a "wave tile" of the host-built
 // list: first row in row order, first column, 16-bit mask of the tiles that hold canonical pairs).
 constexpr int MG_CH = 64;  // cadences per LDS stage
+#ifndef MG_UNIFORM
+#define MG_UNIFORM 0
+#endif
+#ifndef MG_ALL_ROWS
+#define MG_ALL_ROWS 0   // 1: the masked launch generates all 4 + 4 operand rows of a wave tile (no branch around their LDS reads)
+#endif
 constexpr int kMomentMinCols = 100;  // product blocks at least this wide take the moment form
 template <int O, bool FULL, int PRE, int KS>  // KS: LDS row stride (k | 1) when known at compile time, else 0; PRE: MG_CH * k / 256 elements of the next stage wait in registers (4: k <= 16, 12: k <= 48)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pld_moment_gram_kernel(
@@ -300,15 +306,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint8_t *__restrict__ comb, const int4 *__restrict__ wt, int nwt, double *__restrict__ Mcan,
     const int *__restrict__ rperm, double *__restrict__ mean) {
     extern __shared__ __attribute__((aligned(16))) double mg_us[];  // 2 x MG_CH x ks
-    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
+#if MG_UNIFORM
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    const int wave = tid >> 6;
+#endif
     const int ks = KS > 0 ? KS : (k | 1);
     const int w = blockIdx.x * 4 + wave;
     const int4 t = wt[min(w, nwt - 1)];
+#if MG_UNIFORM
+    // the wave tile is the same for the 64 lanes of a wave: say so (the compiler cannot see it through `threadIdx.x >> 6` and
+    // guarded each MFMA and each operand row with an exec-mask branch — s_and_saveexec + s_cbranch_execz, 46 per step)
+    const int r0 = __builtin_amdgcn_readfirstlane(t.x), c0 = __builtin_amdgcn_readfirstlane(t.y);
+    const unsigned mask = w < nwt ? (unsigned)__builtin_amdgcn_readfirstlane(t.z) : 0u;
+#else
     const int r0 = t.x, c0 = t.y;
     const unsigned mask = w < nwt ? (unsigned)t.z : 0u;
+#endif
     // bit i: this wave tile is the one that also sums the products of row tile i over the cadences (their column means:
     // every (row, cadence) pair passes through exactly one lane of the A operand)
+#if MG_UNIFORM
+    const unsigned mflag = (!FULL && w < nwt) ? (unsigned)__builtin_amdgcn_readfirstlane(t.w) : 0u;  // (the host keeps such wave tiles out of the FULL launch)
+#else
     const unsigned mflag = (!FULL && w < nwt) ? (unsigned)t.w : 0u;  // (the host keeps such wave tiles out of the FULL launch)
+#endif
     double msum[4] = {0.0, 0.0, 0.0, 0.0};
     // rows / columns past the end are clamped, not zeroed: their accumulator entries are simply never stored
     int ia[4][O], ib[4][O];
@@ -352,8 +374,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     bool ua[4], ub[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        ua[i] = FULL || (mask & (0xfu << (4 * i))) != 0;
-        ub[i] = FULL || (mask & (0x1111u << i)) != 0;
+        ua[i] = FULL || MG_ALL_ROWS || (mask & (0xfu << (4 * i))) != 0;
+        ub[i] = FULL || MG_ALL_ROWS || (mask & (0x1111u << i)) != 0;
 #pragma unroll
         for (int pos = 0; pos < O; ++pos) {
             oa[i][pos] = ia[i][pos] * 8;
