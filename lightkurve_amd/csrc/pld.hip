@@ -293,11 +293,17 @@ __global__ __launch_bounds__(256) void pld_products_kernel(const double *__restr
 // LDS (o reads and o - 1 multiplications per element).  A wave owns up to 4 x 4 tiles (a "wave tile" of the host-built
 // list: first row in row order, first column, 16-bit mask of the tiles that hold canonical pairs).
 constexpr int MG_CH = 64;  // cadences per LDS stage
+// Round 6, the masked launch (profiles/r06_pld_moment_gram.txt: 39 % of its wave cycles parked, 46 exec-mask branches per step):
+//   MG_UNIFORM   the wave-tile descriptor is read through readfirstlane — the compiler could not see through `threadIdx.x >> 6` that
+//                a wave's 64 lanes share it, and guarded every MFMA and every operand row with s_and_saveexec + s_cbranch_execz;
+//   MG_ALL_ROWS  all 4 + 4 operand rows of a wave tile are generated, needed or not: the reads of a row no tile uses sat behind a
+//                branch of their own, each with its wait — 24 unconditional ds_read_b64 per step cost less than the serialised few.
+// A/B on one box, PLD step of 500 cutouts, 3 interleaved reps: neither 29.49 ms | ALL_ROWS 28.67 | UNIFORM 29.33 | both 28.59.
 #ifndef MG_UNIFORM
-#define MG_UNIFORM 0
+#define MG_UNIFORM 1
 #endif
 #ifndef MG_ALL_ROWS
-#define MG_ALL_ROWS 0   // 1: the masked launch generates all 4 + 4 operand rows of a wave tile (no branch around their LDS reads)
+#define MG_ALL_ROWS 1
 #endif
 constexpr int kMomentMinCols = 100;  // product blocks at least this wide take the moment form
 template <int O, bool FULL, int PRE, int KS>  // KS: LDS row stride (k | 1) when known at compile time, else 0; PRE: MG_CH * k / 256 elements of the next stage wait in registers (4: k <= 16, 12: k <= 48)
