@@ -239,3 +239,22 @@ def test_periods_beyond_the_lds_plan_bit_exact(use_like):
     far = _capi.bls_batch(ts[2], ys[2], ws[2], [0, len(ts[2])], [1000.0], durations, 10, use_like)
     ref = O.bls(ts[2], ys[2], ws[2], np.array([1000.0]), durations, 10, use_like)
     assert all(np.array_equal(far[k][0], r) for k, r in zip(_capi.BLS_FIELDS, ref))
+
+
+def test_small_job_on_four_streams_equals_the_single_stream_path():
+    """A call with B x nP <= 65 536 (a seam call at B = 1) spreads its period groups over four streams of the handle (round 6); the
+    same light curve inside a batch beyond that threshold runs them one after the other on the caller's stream.  Seven outputs,
+    bit for bit."""
+    t, y, e, truth = synth.bls_target(3, 7, 6000)
+    tt, yy, ivar, _ = O.lk_bls_inputs(t, y, e)
+    period = np.exp(np.linspace(np.log(0.4), np.log(11.0), 3000))
+    duration = np.array([0.05, 0.1, 0.2])
+    one = _capi.bls_batch(tt, yy, ivar, [0, len(tt)], period, duration)
+    nb = 24                                                   # 24 x 3000 > 65 536
+    T, off = synth.pack_ragged([tt] * nb)
+    Y, _ = synth.pack_ragged([yy] * nb)
+    W, _ = synth.pack_ragged([ivar] * nb)
+    many = _capi.bls_batch(T, Y, W, off, period, duration)
+    for name in _capi.BLS_FIELDS:
+        assert np.array_equal(one[name][0], many[name][0]), name
+        assert np.array_equal(many[name][0], many[name][-1]), name

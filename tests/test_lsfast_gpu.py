@@ -88,3 +88,23 @@ def test_full_size_fast_vs_exact_and_peak():
         assert np.argmax(np.where(ok, Pf[b], 0)) == np.argmax(Pe[b])
     ref = O.ls_power_fast(t[:N], y[:N], None, df, df, M, normalization="lk_amplitude")
     assert relmax(Pf[0], ref) < TOL
+
+
+def test_chunks_on_two_streams_equal_single_chunk_calls():
+    """130 targets at Nfft = 2^19 are three chunks (60 + 60 + 10) that lsfast.hip runs alternately on the caller's stream and a
+    second one, each with its own intermediate buffer (round 6).  The kernels are the same whatever stream carries them: the
+    spectra and the fused peaks must equal, bit for bit, those of calls that fit one chunk (no second stream involved)."""
+    B, N, M = 130, 2000, 100000
+    t, y, dy, off = synth.ls_batch(1, B, N)
+    for b in range(B):
+        t[off[b]:off[b + 1]] -= t[off[b]]
+    df = 360.0 / M
+    P, mx, am = _capi.ls_fast_peaks_batch(t, y, off, f0=df, df=df, M=M, normalization="lk_amplitude")
+    assert np.all(np.isfinite(mx)) and P.shape == (B, M)
+    for b0 in (0, 50, 100):
+        b1 = min(B, b0 + 50)
+        sl = slice(off[b0], off[b1])
+        Pc, mxc, amc = _capi.ls_fast_peaks_batch(t[sl], y[sl], off[b0:b1 + 1] - off[b0], f0=df, df=df, M=M,
+                                                 normalization="lk_amplitude")
+        assert np.array_equal(P[b0:b1], Pc, equal_nan=True), b0
+        assert np.array_equal(mx[b0:b1], mxc) and np.array_equal(am[b0:b1], amc), b0
