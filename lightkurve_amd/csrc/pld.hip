@@ -2016,9 +2016,16 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
         const int m = P - kk - 1, r0 = kk + 1;  // trailing block: rows / columns r0 .. P - 1; x_i = A[r0 + i][kk]
         // every wave: alpha, sigma = sum_{i >= 1} x_i^2 (same order in every wave: identical bits, and no barrier)
         double part = 0.0;
-        for (int i = 1 + lane; i < m; i += 64) {
-            const double x = At[td_tri(r0 + i, kk)];
-            part = fma(x, x, part);
+        {   // (m <= 137: three masked loads issued together instead of a loop of dependent LDS round trips; same order of sums)
+            double x[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = 1 + lane + 64 * u;
+                x[u] = At[td_tri(r0 + min(i, m - 1), kk)];
+                if (i >= m) x[u] = 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) part = fma(x[u], x[u], part);
         }
         const double sigma = td_wave_sum(part), alpha = At[td_tri(r0, kk)];
         double tk = 0.0, sc = 0.0, beta = alpha;
@@ -2035,26 +2042,53 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
             scl[kk] = sc;
         }
         if (tk != 0.0) {  // (workgroup-uniform)
-            // v into LDS once (vb), then p = tau S v with FOUR threads per row (a quarter of the columns each, two shuffles)
+            // v into LDS once (vb), then p = tau S v with EIGHT threads per row (an eighth of the columns each, three DPP
+            // steps).  The row's chunk is walked four columns at a time with all eight LDS reads issued before the first
+            // multiply-add (clamped addresses, masked operands): the plain loop compiled to one LDS round trip per column —
+            // ds_read x 2, s_waitcnt lgkmcnt(0), v_fmac — twice over (row part, column part, each to the wave's longest trip),
+            // and those ~2 x m / 4 dependent round trips were most of a Householder step (profiles/r06_pld_tridiag.txt).
             if (tid < m) vb[tid] = tid == 0 ? 1.0 : At[td_tri(r0 + tid, kk)] * sc;
             __syncthreads();
             {
-                const int i = tid >> 2, q = tid & 3;
-                double acc = 0.0;
-                if (i < m) {
-                    const int jq = (m + 3) >> 2, j_lo = q * jq, j_hi = min(m, j_lo + jq);
-                    const int rowbase = td_tri(r0 + i, r0);
-                    int j = j_lo;
-                    for (; j < min(j_hi, i + 1); ++j) acc = fma(At[rowbase + j], vb[j], acc);       // S_ij, j <= i: row i
-                    for (; j < j_hi; ++j) acc = fma(At[td_tri(r0 + j, r0 + i)], vb[j], acc);         // j > i: column i
+                const int q = tid & 7;
+                const int jq = (m + 7) >> 3, j_lo = q * jq, j_hi = min(m, j_lo + jq);
+                for (int i = tid >> 3; i < ((m + 127) & ~127); i += 128) {  // (uniform trip count: all lanes reach the DPP sums)
+                    double acc = 0.0;
+                    if (i < m) {
+                        const int rowbase = td_tri(r0 + i, r0), colbase = r0 + i;
+                        for (int j0 = j_lo; j0 < j_hi; j0 += 4) {
+                            double a[4], v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int jc = min(j0 + u, j_hi - 1), rj = r0 + jc;
+                                // S_ij: row i for j <= i, column i (row j) for j > i
+                                const int addr = jc <= i ? rowbase + jc : (int)(__umul24(rj, rj + 1) >> 1) + colbase;
+                                a[u] = At[addr];
+                                v[u] = vb[jc];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) acc = fma(a[u], j0 + u < j_hi ? v[u] : 0.0, acc);
+                        }
+                    }
+                    acc = td_quad_sum(acc);
+                    acc += td_dpp<0x141>(acc);  // row_half_mirror: the other quad of the row's eight threads
+                    if (i < m && q == 0) pb[i] = tk * acc;
                 }
-                acc = td_quad_sum(acc);
-                if (i < m && q == 0) pb[i] = tk * acc;
             }
             __syncthreads();
             // every wave: K = tau / 2 p^T v;  w = p - K v
             double dot = 0.0;
-            for (int i = lane; i < m; i += 64) dot = fma(pb[i], vb[i], dot);
+            {
+                double pp[3], vv[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int i = lane + 64 * u, ic = min(i, m - 1);
+                    pp[u] = i < m ? pb[ic] : 0.0;
+                    vv[u] = vb[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) dot = fma(pp[u], vv[u], dot);
+            }
             const double Kc = 0.5 * tk * td_wave_sum(dot);
             // rank-2 update of the lower triangle, S_ij -= v_i w_j + w_i v_j: seven threads per row, four columns at a time —
             // the operands of a batch are all loaded before its read-modify-writes (left to the compiler, every store to the
