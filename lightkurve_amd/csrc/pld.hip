@@ -28,6 +28,8 @@
 #include <algorithm>
 #include <type_traits>
 #include <mutex>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "block_select.hpp"
@@ -1983,7 +1985,11 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
 #ifdef LK_PLD_DEBUG   // per-phase clocks of matrix 0 (100 MHz wall clock), `make DEBUG=1`
 #define TD_CLK(slot)                                                                 \
     do {                                                                             \
-        if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[slot] = wall_clock64();  \
+        if (clk && threadIdx.x == 0) {                                               \
+            const unsigned long long c_ = wall_clock64();                            \
+            if (blockIdx.x == 0) clk[slot] = c_;                                     \
+            clk[8 + 4 * (size_t)gridDim.x + 8 * (size_t)blockIdx.x + slot] = c_;    \
+        }                                                                            \
     } while (0)
 #else
 #define TD_CLK(slot) do { } while (0)
@@ -1992,6 +1998,12 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     constexpr int NW = TD_NT / 64;
+#ifdef LK_PLD_DEBUG   // every workgroup's start, end and place (XCC, HW_ID): clk[8 + 4 b ..]
+    if (clk && tid == 0) {
+        clk[8 + 4 * (size_t)b] = wall_clock64();
+        clk[8 + 4 * (size_t)b + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+    }
+#endif
     const double *Gb = G + (size_t)b * ldg * ldg;
     const int ntri = (P * (P + 1)) >> 1;
     double *At = lds;                       // packed lower triangle
@@ -2012,47 +2024,54 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
     __syncthreads();
     TD_CLK(0);
     // ---- 1. tridiagonalisation
+    // What bounds it (round 6, the workgroup timeline of a 500-matrix launch in the development build: every workgroup's start,
+    // end and phase clocks): INSTRUCTION ISSUE.  Alone on a CU a workgroup takes ~370 us here; of two sharing a CU the first
+    // takes ~400 and the second ~800 — the older waves go first and leave it nothing.  So instructions are what to save, in
+    // every wave: the reflector (norm, square root, two divisions) is formed by wave 0 alone — the others pick tau up behind the
+    // barrier they wait at anyway — and waves whose rows lie beyond the trailing block skip the product.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     for (int kk = 0; kk < P - 2; ++kk) {
         const int m = P - kk - 1, r0 = kk + 1;  // trailing block: rows / columns r0 .. P - 1; x_i = A[r0 + i][kk]
-        // every wave: alpha, sigma = sum_{i >= 1} x_i^2 (same order in every wave: identical bits, and no barrier)
-        double part = 0.0;
-        {   // (m <= 137: three masked loads issued together instead of a loop of dependent LDS round trips; same order of sums)
-            double x[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = 1 + lane + 64 * u;
-                x[u] = At[td_tri(r0 + min(i, m - 1), kk)];
-                if (i >= m) x[u] = 0.0;
+        if (wave_u == 0) {
+            // alpha, sigma = sum_{i >= 1} x_i^2, the column in registers (m <= 137: three entries per lane)
+            double x0 = At[td_tri(r0 + min(lane, m - 1), kk)];
+            double x1 = At[td_tri(r0 + min(lane + 64, m - 1), kk)];
+            double x2 = At[td_tri(r0 + min(lane + 128, m - 1), kk)];
+            if (lane >= m) x0 = 0.0;
+            if (lane + 64 >= m) x1 = 0.0;
+            if (lane + 128 >= m) x2 = 0.0;
+            const double alpha = td_readlane(x0, 0);
+            const double sigma = td_wave_sum(fma(lane == 0 ? 0.0 : x0, x0, fma(x1, x1, x2 * x2)));
+            double tk0 = 0.0, sc = 0.0, beta = alpha;
+            if (sigma != 0.0) {
+                const double nrm = sqrt(fma(alpha, alpha, sigma));
+                beta = alpha >= 0.0 ? -nrm : nrm;
+                tk0 = (beta - alpha) / beta;
+                sc = 1.0 / (alpha - beta);
             }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) part = fma(x[u], x[u], part);
+            if (lane == 0) {
+                dd[kk] = At[td_tri(kk, kk)];
+                ee[kk] = beta;
+                tau[kk] = tk0;
+                scl[kk] = sc;
+            }
+            // v = [1, x[1:] * scale] into LDS (vb)
+            if (lane < m) vb[lane] = lane == 0 ? 1.0 : x0 * sc;
+            if (lane + 64 < m) vb[lane + 64] = x1 * sc;
+            if (lane + 128 < m) vb[lane + 128] = x2 * sc;
         }
-        const double sigma = td_wave_sum(part), alpha = At[td_tri(r0, kk)];
-        double tk = 0.0, sc = 0.0, beta = alpha;
-        if (sigma != 0.0) {
-            const double nrm = sqrt(fma(alpha, alpha, sigma));
-            beta = alpha >= 0.0 ? -nrm : nrm;
-            tk = (beta - alpha) / beta;
-            sc = 1.0 / (alpha - beta);
-        }
-        if (tid == 0) {
-            dd[kk] = At[td_tri(kk, kk)];
-            ee[kk] = beta;
-            tau[kk] = tk;
-            scl[kk] = sc;
-        }
-        if (tk != 0.0) {  // (workgroup-uniform)
-            // v into LDS once (vb), then p = tau S v with EIGHT threads per row (an eighth of the columns each, three DPP
-            // steps).  The row's chunk is walked four columns at a time with all eight LDS reads issued before the first
-            // multiply-add (clamped addresses, masked operands): the plain loop compiled to one LDS round trip per column —
-            // ds_read x 2, s_waitcnt lgkmcnt(0), v_fmac — twice over (row part, column part, each to the wave's longest trip),
-            // and those ~2 x m / 4 dependent round trips were most of a Householder step (profiles/r06_pld_tridiag.txt).
-            if (tid < m) vb[tid] = tid == 0 ? 1.0 : At[td_tri(r0 + tid, kk)] * sc;
-            __syncthreads();
+        __syncthreads();
+        const double tk = tau[kk];  // (broadcast read: workgroup-uniform)
+        if (tk != 0.0) {
+            // p = tau S v with EIGHT threads per row (an eighth of the columns each, three DPP steps).  The row's chunk is
+            // walked four columns at a time with all eight LDS reads issued before the first multiply-add (clamped addresses,
+            // masked operands): the plain loop compiled to one LDS round trip per column — ds_read x 2, s_waitcnt lgkmcnt(0),
+            // v_fmac — twice over (row part, column part, each to the wave's longest trip).
             {
                 const int q = tid & 7;
                 const int jq = (m + 7) >> 3, j_lo = q * jq, j_hi = min(m, j_lo + jq);
-                for (int i = tid >> 3; i < ((m + 127) & ~127); i += 128) {  // (uniform trip count: all lanes reach the DPP sums)
+                for (int ib = wave_u * 8; ib < m; ib += 128) {  // (wave-uniform trips: all lanes reach the DPP sums)
+                    const int i = ib + (lane >> 3);
                     double acc = 0.0;
                     if (i < m) {
                         const int rowbase = td_tri(r0 + i, r0), colbase = r0 + i;
@@ -2076,7 +2095,8 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
                 }
             }
             __syncthreads();
-            // every wave: K = tau / 2 p^T v;  w = p - K v
+            // every wave with rows to update: K = tau / 2 p^T v;  w = p - K v
+            if (wave_u * 4 < ((m + 1) >> 1)) {
             double dot = 0.0;
             {
                 double pp[3], vv[3];
@@ -2090,30 +2110,44 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
                 for (int u = 0; u < 3; ++u) dot = fma(pp[u], vv[u], dot);
             }
             const double Kc = 0.5 * tk * td_wave_sum(dot);
-            // rank-2 update of the lower triangle, S_ij -= v_i w_j + w_i v_j: seven threads per row, four columns at a time —
-            // the operands of a batch are all loaded before its read-modify-writes (left to the compiler, every store to the
-            // triangle fences the loads behind it: they may alias)
+            // rank-2 update of the lower triangle, S_ij -= v_i w_j + w_i v_j.  Row i holds i + 1 entries: rows i and m - 1 - i are
+            // walked as ONE strip of m + 1 entries by sixteen threads, four entries each per batch — every thread has the same
+            // two batches at m = 120 where a thread-group per row left the last rows five (the phase ends with its slowest wave).
+            // The operands of a batch are all loaded before its read-modify-writes (left to the compiler, every store to the
+            // triangle fences the loads behind it: they may alias).  The arithmetic per entry is unchanged.
             {
-                const int i = tid / 7, q = tid - i * 7;
-                if (i < m) {
-                    const double vi = vb[i], wi = pb[i] - Kc * vi;
-                    const int rowbase = td_tri(r0 + i, r0);
-                    for (int c0 = q; c0 <= i; c0 += 28) {
+                const int q = tid & 15, npair = (m + 1) >> 1;
+                for (int pi = tid >> 4; pi < npair; pi += TD_NT / 16) {
+                    const int ia = pi, ib = m - 1 - pi;
+                    const double via = vb[ia], vib = vb[ib];
+                    const double wia = pb[ia] - Kc * via, wib = pb[ib] - Kc * vib;
+                    const int base_a = td_tri(r0 + ia, r0), base_b = td_tri(r0 + ib, r0) - (ia + 1);
+                    const int len = ia == ib ? ia + 1 : m + 1;
+                    for (int p0 = q; p0 < len; p0 += 64) {
                         double vj[4], pj[4], av[4];
+                        int ad[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const int c = min(c0 + 7 * u, i);
+                            const int pos = min(p0 + 16 * u, len - 1);
+                            const bool in_a = pos <= ia;
+                            const int c = in_a ? pos : pos - ia - 1;
+                            ad[u] = (in_a ? base_a : base_b) + pos;
                             vj[u] = vb[c];
                             pj[u] = pb[c];
-                            av[u] = At[rowbase + c];
+                            av[u] = At[ad[u]];
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const int c = c0 + 7 * u;
-                            if (c <= i) At[rowbase + c] = av[u] - fma(vi, pj[u] - Kc * vj[u], wi * vj[u]);
+                            const int pos = p0 + 16 * u;
+                            if (pos < len) {
+                                const bool in_a = pos <= ia;
+                                const double vr = in_a ? via : vib, wr = in_a ? wia : wib;
+                                At[ad[u]] = av[u] - fma(vr, pj[u] - Kc * vj[u], wr * vj[u]);
+                            }
                         }
                     }
                 }
+            }
             }
         }
         __syncthreads();
@@ -2274,56 +2308,125 @@ __global__ __launch_bounds__(TD_NT, 8) void pld_tridiag_eig_kernel(const double 
     }
     __syncthreads();
     TD_CLK(3);
-    // modified Gram-Schmidt inside clusters, in eigenvalue order (a wave per step; rare: spectra of real blocks are separated)
-    if (wave == 0) {
-        for (int j = 1; j < k; ++j) {
-            bool any = false;
-            for (int jj = 0; jj < j; ++jj)
-                if (fabs(lamv[jj] - lamv[j]) < cl_tol) {
-                    any = true;
-                    double dot = 0.0;
-                    for (int i = lane; i < P; i += 64) dot = fma(Z[(size_t)i * k + j], Z[(size_t)i * k + jj], dot);
+    // Modified Gram-Schmidt inside clusters of close eigenvalues, in eigenvalue order, and 4. the back-transformation
+    // V = H_0 H_1 ... H_{P-3} Z — a wave per vector with the vector in REGISTERS (P <= 192: three entries per lane), no LDS
+    // traffic but the reflector itself.
+    // k <= 16 (round 6): wave j owns vector j through BOTH phases.  Round jj of the Gram-Schmidt: wave jj (by then orthogonal to
+    // its earlier neighbours; normalised now if it changed) publishes its vector in LDS, the waves of the later vectors within
+    // cl_tol of it subtract their component along it — the arithmetic of the sequential loop it replaces (vector j against
+    // jj = 0 .. j - 1 in order), but the steep spectra of pixel blocks put 8-10 of the 16 wanted eigenvalues within 1e-3 |T|
+    // of each other, and one wave walking ~30 (j, jj) pairs through L2 took 82-96 us of the ~1000 per matrix; rounds without a
+    // later neighbour are skipped (the masks are wave-uniform: ballots over the eigenvalues held one per lane).
+    if (k <= NW) {
+        const int j = wave;
+        const bool own = j < k;
+        double z0 = own && lane < P ? Z[(size_t)lane * k + j] : 0.0;
+        double z1 = own && lane + 64 < P ? Z[(size_t)(lane + 64) * k + j] : 0.0;
+        double z2 = own && lane + 128 < P ? Z[(size_t)(lane + 128) * k + j] : 0.0;
+        const double lam_l = lane < k ? lamv[lane] : 0.0;
+        double *pub = ws;  // P doubles (the twisted factorisations are done with their scratch)
+        bool dirty = false;
+        auto normalise = [&]() {
+            const double inv = 1.0 / sqrt(td_wave_sum(fma(z0, z0, fma(z1, z1, z2 * z2))));
+            z0 *= inv;
+            z1 *= inv;
+            z2 *= inv;
+            dirty = false;
+        };
+        for (int jj = 0; jj + 1 < k; ++jj) {
+            const double lam_jj = td_readlane(lam_l, jj);
+            const unsigned long long later = __ballot(lane > jj && lane < k && fabs(lam_l - lam_jj) < cl_tol);
+            if (later == 0ull) continue;  // (workgroup-uniform)
+            if (j == jj) {
+                if (dirty) normalise();
+                if (lane < P) pub[lane] = z0;
+                if (lane + 64 < P) pub[lane + 64] = z1;
+                if (lane + 128 < P) pub[lane + 128] = z2;
+            }
+            __syncthreads();
+            if (own && ((later >> j) & 1ull)) {
+                const double u0 = lane < P ? pub[lane] : 0.0, u1 = lane + 64 < P ? pub[lane + 64] : 0.0,
+                             u2 = lane + 128 < P ? pub[lane + 128] : 0.0;
+                const double dot = td_wave_sum(fma(z0, u0, fma(z1, u1, z2 * u2)));
+                z0 = fma(-dot, u0, z0);
+                z1 = fma(-dot, u1, z1);
+                z2 = fma(-dot, u2, z2);
+                dirty = true;
+            }
+            __syncthreads();
+        }
+        if (dirty) normalise();
+        TD_CLK(4);
+        if (own) {
+            for (int kk = P - 3; kk >= 0; --kk) {
+                const double tk = tau[kk];
+                if (tk == 0.0) continue;
+                const int r0 = kk + 1;
+                const double sc = scl[kk];
+                // v_i for row i: 0 above r0, 1 at r0, the stored column entry times the scale below
+                auto vrow = [&](int i) { return i < r0 ? 0.0 : (i == r0 ? 1.0 : (i < P ? At[td_tri(i, kk)] * sc : 0.0)); };
+                const double v0 = vrow(lane), v1 = vrow(lane + 64), v2 = vrow(lane + 128);
+                const double f = tk * td_wave_sum(fma(v0, z0, fma(v1, z1, v2 * z2)));
+                z0 = fma(-f, v0, z0);
+                z1 = fma(-f, v1, z1);
+                z2 = fma(-f, v2, z2);
+            }
+            if (lane < P) Z[(size_t)lane * k + j] = z0;
+            if (lane + 64 < P) Z[(size_t)(lane + 64) * k + j] = z1;
+            if (lane + 128 < P) Z[(size_t)(lane + 128) * k + j] = z2;
+        }
+    } else {
+        // more vectors than waves: the Gram-Schmidt by one wave on the vectors in V (global), then a wave per vector in turn
+        if (wave == 0) {
+            for (int j = 1; j < k; ++j) {
+                bool any = false;
+                for (int jj = 0; jj < j; ++jj)
+                    if (fabs(lamv[jj] - lamv[j]) < cl_tol) {
+                        any = true;
+                        double dot = 0.0;
+                        for (int i = lane; i < P; i += 64) dot = fma(Z[(size_t)i * k + j], Z[(size_t)i * k + jj], dot);
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-                    for (int i = lane; i < P; i += 64) Z[(size_t)i * k + j] -= dot * Z[(size_t)i * k + jj];
+                        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+                        for (int i = lane; i < P; i += 64) Z[(size_t)i * k + j] -= dot * Z[(size_t)i * k + jj];
+                    }
+                if (any) {
+                    double n2 = 0.0;
+                    for (int i = lane; i < P; i += 64) n2 = fma(Z[(size_t)i * k + j], Z[(size_t)i * k + j], n2);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
+                    const double inv = 1.0 / sqrt(n2);
+                    for (int i = lane; i < P; i += 64) Z[(size_t)i * k + j] *= inv;
                 }
-            if (any) {
-                double n2 = 0.0;
-                for (int i = lane; i < P; i += 64) n2 = fma(Z[(size_t)i * k + j], Z[(size_t)i * k + j], n2);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
-                const double inv = 1.0 / sqrt(n2);
-                for (int i = lane; i < P; i += 64) Z[(size_t)i * k + j] *= inv;
             }
         }
-    }
-    __syncthreads();
-    TD_CLK(4);
-    // ---- 4. back-transformation: V = H_0 H_1 ... H_{P-3} Z, a wave per vector with the vector in REGISTERS (P <= 192: three
-    // entries per lane) — no barrier, no LDS traffic but the reflector itself
-    for (int j = wave; j < k; j += NW) {
-        double z0 = lane < P ? Z[(size_t)lane * k + j] : 0.0;
-        double z1 = lane + 64 < P ? Z[(size_t)(lane + 64) * k + j] : 0.0;
-        double z2 = lane + 128 < P ? Z[(size_t)(lane + 128) * k + j] : 0.0;
-        for (int kk = P - 3; kk >= 0; --kk) {
-            const double tk = tau[kk];
-            if (tk == 0.0) continue;
-            const int r0 = kk + 1;
-            const double sc = scl[kk];
-            // v_i for row i: 0 above r0, 1 at r0, the stored column entry times the scale below
-            auto vrow = [&](int i) { return i < r0 ? 0.0 : (i == r0 ? 1.0 : (i < P ? At[td_tri(i, kk)] * sc : 0.0)); };
-            const double v0 = vrow(lane), v1 = vrow(lane + 64), v2 = vrow(lane + 128);
-            const double f = tk * td_wave_sum(fma(v0, z0, fma(v1, z1, v2 * z2)));
-            z0 = fma(-f, v0, z0);
-            z1 = fma(-f, v1, z1);
-            z2 = fma(-f, v2, z2);
+        __syncthreads();
+        TD_CLK(4);
+        for (int j = wave; j < k; j += NW) {
+            double z0 = lane < P ? Z[(size_t)lane * k + j] : 0.0;
+            double z1 = lane + 64 < P ? Z[(size_t)(lane + 64) * k + j] : 0.0;
+            double z2 = lane + 128 < P ? Z[(size_t)(lane + 128) * k + j] : 0.0;
+            for (int kk = P - 3; kk >= 0; --kk) {
+                const double tk = tau[kk];
+                if (tk == 0.0) continue;
+                const int r0 = kk + 1;
+                const double sc = scl[kk];
+                auto vrow = [&](int i) { return i < r0 ? 0.0 : (i == r0 ? 1.0 : (i < P ? At[td_tri(i, kk)] * sc : 0.0)); };
+                const double v0 = vrow(lane), v1 = vrow(lane + 64), v2 = vrow(lane + 128);
+                const double f = tk * td_wave_sum(fma(v0, z0, fma(v1, z1, v2 * z2)));
+                z0 = fma(-f, v0, z0);
+                z1 = fma(-f, v1, z1);
+                z2 = fma(-f, v2, z2);
+            }
+            if (lane < P) Z[(size_t)lane * k + j] = z0;
+            if (lane + 64 < P) Z[(size_t)(lane + 64) * k + j] = z1;
+            if (lane + 128 < P) Z[(size_t)(lane + 128) * k + j] = z2;
         }
-        if (lane < P) Z[(size_t)lane * k + j] = z0;
-        if (lane + 64 < P) Z[(size_t)(lane + 64) * k + j] = z1;
-        if (lane + 128 < P) Z[(size_t)(lane + 128) * k + j] = z2;
     }
     __syncthreads();
     TD_CLK(5);
+#ifdef LK_PLD_DEBUG
+    if (clk && tid == 0) clk[8 + 4 * (size_t)b + 1] = wall_clock64();
+#endif
     if (tid < k) lam[(size_t)b * k + tid] = lamv[tid];
 #undef TD_CLK
 }
@@ -2385,7 +2488,7 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
         if (rc_) return rc_;
         unsigned long long *d_clk = nullptr;
 #ifdef LK_PLD_DEBUG
-        if (dbg_iters) d_clk = (unsigned long long *)ws.alloc(64);
+        if (dbg_iters) d_clk = (unsigned long long *)ws.alloc(64 + 96 * (size_t)B + 64);
 #endif
         hipLaunchKernelGGL(pld_tridiag_eig_kernel, dim3(B), dim3(TD_NT), lds, stream, G, ldg, P, k, V, lam, d_clk, tdl);
 #ifdef LK_PLD_DEBUG
@@ -2396,6 +2499,56 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
             fprintf(stderr, "[pld tridiag] P=%d k=%d per matrix us: tridiagonalise %.0f | eigenvalues %.0f | twisted factorisation %.0f | "
                             "Gram-Schmidt %.0f | back-transform %.0f\n", P, k, (hc[1] - hc[0]) * 0.01, (hc[2] - hc[1]) * 0.01,
                     (hc[3] - hc[2]) * 0.01, (hc[4] - hc[3]) * 0.01, (hc[5] - hc[4]) * 0.01);
+            // the launch as a whole: when each workgroup started and ended, and where it ran
+            std::vector<unsigned long long> tl(4 * (size_t)B);
+            LK_HIP_CHECK(hipMemcpyAsync(tl.data(), d_clk + 8, 32 * (size_t)B, hipMemcpyDeviceToHost, stream));
+            LK_HIP_CHECK(hipStreamSynchronize(stream));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < B; ++i) {
+                t0 = std::min(t0, tl[4 * i]);
+                t1 = std::max(t1, tl[4 * i + 1]);
+            }
+            std::vector<double> st(B), du(B);
+            std::map<unsigned, int> per_cu;
+            for (int i = 0; i < B; ++i) {
+                st[i] = (tl[4 * i] - t0) * 0.01;
+                du[i] = (tl[4 * i + 1] - tl[4 * i]) * 0.01;
+                const unsigned hw = (unsigned)tl[4 * i + 2], xcc = (unsigned)(tl[4 * i + 2] >> 32) & 0xf;
+                per_cu[(xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)]++;
+            }
+            std::sort(st.begin(), st.end());
+            std::sort(du.begin(), du.end());
+            {   // phases of the fast and of the slow workgroups
+                std::vector<unsigned long long> ph(8 * (size_t)B);
+                LK_HIP_CHECK(hipMemcpyAsync(ph.data(), d_clk + 8 + 4 * (size_t)B, 64 * (size_t)B, hipMemcpyDeviceToHost, stream));
+                LK_HIP_CHECK(hipStreamSynchronize(stream));
+                const double cut = 1.25 * du[B / 2];
+                double acc[2][6] = {{0}};
+                int cnt[2] = {0, 0};
+                for (int i = 0; i < B; ++i) {
+                    const int gsl = (tl[4 * i + 1] - tl[4 * i]) * 0.01 > cut ? 1 : 0;
+                    cnt[gsl]++;
+                    acc[gsl][0] += (ph[8 * i] - tl[4 * i]) * 0.01;
+                    for (int q = 1; q < 6; ++q) acc[gsl][q] += (ph[8 * i + q] - ph[8 * i + q - 1]) * 0.01;
+                }
+                for (int gsl = 0; gsl < 2; ++gsl)
+                    if (cnt[gsl])
+                        fprintf(stderr, "[pld tridiag timeline] %s workgroups (%d): load %.0f | tridiagonalise %.0f | eigenvalues %.0f | twisted %.0f | "
+                                        "Gram-Schmidt %.0f | back-transform %.0f\n", gsl ? "slow" : "fast", cnt[gsl], acc[gsl][0] / cnt[gsl],
+                                acc[gsl][1] / cnt[gsl], acc[gsl][2] / cnt[gsl], acc[gsl][3] / cnt[gsl], acc[gsl][4] / cnt[gsl], acc[gsl][5] / cnt[gsl]);
+                std::string slow_ids;
+                for (int i = 0; i < B && slow_ids.size() < 200; ++i)
+                    if ((tl[4 * i + 1] - tl[4 * i]) * 0.01 > cut) slow_ids += std::to_string(i) + " ";
+                fprintf(stderr, "[pld tridiag timeline] slow ids: %s\n", slow_ids.c_str());
+            }
+            int mx = 0;
+            for (auto &kv : per_cu) mx = std::max(mx, kv.second);
+            int late = 0;
+            for (int i = 0; i < B; ++i) late += st[i] > 50.0 ? 1 : 0;
+            fprintf(stderr, "[pld tridiag timeline] span %.0f us | workgroup duration min %.0f median %.0f p90 %.0f max %.0f | starts: median %.0f "
+                            "p90 %.0f max %.0f, %d of %d later than 50 us | %zu CUs used, at most %d workgroups on one\n",
+                    (t1 - t0) * 0.01, du[0], du[B / 2], du[(B * 9) / 10], du[B - 1], st[B / 2], st[(B * 9) / 10], st[B - 1], late, B,
+                    per_cu.size(), mx);
         }
 #endif
         *V_out = V;
