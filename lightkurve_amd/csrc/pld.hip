@@ -2700,6 +2700,17 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
                     "[pld eig] P=%d k=%d l=%d opt=%d: Rayleigh-Ritz steps mean %.1f max %lld over %d matrices; per matrix us: "
                     "init %.0f | C*Q %.0f | Q^T Z %.0f | Jacobi %.0f | Ritz+resid %.0f | power products %.0f | CholQR %.0f\n",
                     P, k, l, cheb_on, (double)sum / B, mx, B, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+            if (B > 256) {  // the first workgroup of every CU against the one that came second onto it
+                for (int grp = 0; grp < 2; ++grp) {
+                    const int b_lo = grp ? 256 : 0, b_hi = grp ? std::min(B, 512) : 256;
+                    double pg[7] = {0, 0, 0, 0, 0, 0, 0};
+                    for (int b2 = b_lo; b2 < b_hi; ++b2)
+                        for (int s2 = 0; s2 < 7; ++s2) pg[s2] += (double)hit[(size_t)b2 * 8 + 1 + s2] / (b_hi - b_lo) * 0.01;
+                    fprintf(stderr, "[pld eig] matrices %d-%d: init %.0f | C*Q %.0f | Q^T Z %.0f | Jacobi %.0f | Ritz+resid %.0f | power products %.0f | "
+                                    "CholQR %.0f | sum %.0f\n", b_lo, b_hi - 1, pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6],
+                            pg[0] + pg[1] + pg[2] + pg[3] + pg[4] + pg[5] + pg[6]);
+                }
+            }
         }
     }
     if (P <= PLD_LMAX || two_pass) {  // direct Jacobi on C
