@@ -482,32 +482,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // G[i][j] = moment of the merged multiset of columns i and j (looked up through the host-built index table) minus
 // N mean_i mean_j: the Gram matrix of the CENTRED products, written in full (both triangles).
+#ifndef MEXP_U
+#define MEXP_U 8
+#endif
 __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__restrict__ Mcan, size_t mstride,
                                                                  const uint32_t *__restrict__ src,
                                                                  const double *__restrict__ mean, int Pc, int ldg, double Nd,
                                                                  double *__restrict__ G, float *__restrict__ G32 = nullptr) {
-    // a thread writes two groups of four neighbouring columns (16-byte reads of the index table, 32-byte stores); both
-    // groups' index reads are issued before the gathers of either (the kernel is a chain index -> gather -> store, and one
-    // group per thread left it at 2 TB/s of stores)
+    // a thread writes MEXP_U groups of four neighbouring columns (16-byte reads of the index table, 32-byte stores); all
+    // groups' index reads are issued before the gathers of any (the kernel is a chain index -> gather -> store: one
+    // group per thread left it at 2 TB/s of stores, two at 3)
     const int b = blockIdx.y;
     const int q4 = (Pc + 3) >> 2, tot = Pc * q4;
-    const int e0 = blockIdx.x * 512 + threadIdx.x;  // the thread's groups: e0 and e0 + 256 (full-density wave stores)
+    constexpr int U = MEXP_U;
+    const int e0 = blockIdx.x * (256 * U) + threadIdx.x;  // the thread's groups: e0, e0 + 256, ... (full-density wave stores)
     if (e0 >= tot) return;
     const double *mb = mean + (size_t)b * Pc, *Mb = Mcan + (size_t)b * mstride;
     double *Gb = G + (size_t)b * ldg * ldg;
     if ((Pc & 3) == 0) {
-        int ii[2], jj[2];
-        uint4 sv[2];
+        int ii[U], jj[U];
+        uint4 sv[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int e = min(e0 + 256 * u, tot - 1);
             ii[u] = e / q4;
             jj[u] = (e - ii[u] * q4) * 4;
             sv[u] = *reinterpret_cast<const uint4 *>(src + (size_t)ii[u] * Pc + jj[u]);
         }
-        double v[2][4], mj[2][4], mi[2];
+        double v[U][4], mj[U][4], mi[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             v[u][0] = Mb[sv[u].x];
             v[u][1] = Mb[sv[u].y];
             v[u][2] = Mb[sv[u].z];
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__
             for (int t = 0; t < 4; ++t) mj[u][t] = mb[jj[u] + t];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
             if (e0 + 256 * u < tot) {
                 pld_d4 o;
 #pragma unroll
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__
                         make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
             }
     } else {
-        for (int u = 0; u < 2 && e0 + 256 * u < tot; ++u) {
+        for (int u = 0; u < U && e0 + 256 * u < tot; ++u) {
             const int e = e0 + 256 * u, i = e / q4, j0 = (e - i * q4) * 4;
             const double mi = Nd * mb[i];
             const uint32_t *sp = src + (size_t)i * Pc + j0;
@@ -2913,7 +2917,7 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
     // early steps' filter products stream it instead (half the bytes); optional — without workspace nothing changes
     // (+ 4 KB: the product kernels' unconditional loads of the last row may run a few columns past the last matrix)
     float *G32 = (Pc > PLD_DIRECT_MAX && (Pc & 3) == 0) ? (float *)ws.alloc((size_t)B * ldg * ldg * 4 + 4096) : nullptr;
-    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 511) / 512, B), dim3(256), 0, stream, Mcan,
+    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 256 * MEXP_U - 1) / (256 * MEXP_U), B), dim3(256), 0, stream, Mcan,
                        (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G, G32);
     double *V = nullptr, *lam = nullptr;
     const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws, G32);
