@@ -1594,7 +1594,11 @@ int lsfast_launch(lk_handle *h, int B, const int64_t *n_off_host, const double *
     const int CT = std::max(1, std::min(N2, 4096 / N1)), RT = std::max(1, std::min(N1, 4096 / N2));
     // targets per chunk: the grids (3 x 16 B x Nfft per target) stay within 1.5 GiB (LSF_CHUNK_HALF_GB; 1, 1.5 and 2 GiB
     // measure the same within the rep noise once two streams share the chunks, 4 GiB no better)
+#ifdef LSF_CHUNK_MB   // (experiments: chunks small enough for the 256-MiB Infinity Cache)
+    const size_t chunk_bytes = (size_t)LSF_CHUNK_MB << 20;
+#else
     const size_t chunk_bytes = (size_t)LSF_CHUNK_HALF_GB << 29;
+#endif
     int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, chunk_bytes / ((size_t)48 * nfft)));
     if (Bc >= 8) Bc &= ~3;  // N1 / 8 row tiles per target x a multiple of 4 targets: a whole number of rounds of 2 x 256 workgroups
     const bool reg_path = m1 >= 4 && m1 <= 10 && m2 >= 4 && m2 <= 10;
