@@ -85,3 +85,25 @@ def test_sparse_spline_matrix_matches_reference_golden(golden):
     sp = create_sparse_spline_matrix(g["time"], n_knots=10, degree=5).append_constant()
     assert sp.shape == (len(g["time"]), w)
     assert np.max(np.abs(sp.X - g["X"][:, -w:])) < 1e-12
+
+
+def test_direct_solver_with_repeated_singular_values_both_gram_schmidt_paths():
+    """The direct tridiagonal solver (64 < P <= 138) orthogonalises eigenvectors of clustered eigenvalues by modified
+    Gram-Schmidt: with a wave per vector in registers for k <= 16, by one wave on the output array beyond.  Repeated singular
+    values (exact multiplets inside the wanted set, the cut between distinct values) exercise both: orthonormal columns, the
+    reference's subspace (np.linalg.svd of the centred matrix; designmatrix.py:252-282 keeps the leading left vectors)."""
+    rng = np.random.default_rng(21)
+    N, P = 400, 100
+    sv = np.concatenate([[5, 5, 5, 4, 4, 3, 3, 3, 3, 2, 1.5, 1.5, 1.2, 1.1, 1.0, 0.9, 0.8, 0.8, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3],
+                         np.geomspace(0.1, 1e-4, P - 24)])
+    Qn = np.linalg.qr(rng.normal(size=(N, P)))[0]
+    Qp = np.linalg.qr(rng.normal(size=(P, P)))[0]
+    A = (Qn * sv) @ Qp.T
+    Ac = A - A.mean(axis=0)
+    Uref, sref, _ = np.linalg.svd(Ac, full_matrices=False)
+    for k in (10, 16, 23):                                             # cuts between distinct singular values of the centred matrix
+        assert sref[k - 1] - sref[k] > 0.05 * sref[k - 1], k
+        U = _capi.pca_batch(A, k)
+        assert U.shape == (N, k)
+        assert np.max(np.abs(U.T @ U - np.eye(k))) < 1e-9, k
+        assert _subspace_gap(U, Uref[:, :k]) < 1e-6, k
