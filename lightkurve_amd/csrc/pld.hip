@@ -569,56 +569,73 @@ __global__ __launch_bounds__(256) void pld_mean_proj_kernel(const double *__rest
 // U = (products - mean) V diag(lam)^-1/2 into X[:, col0 : col0 + kk] with the products generated on the fly from the
 // first-order components (X[:, col1 : col1 + k1]).  One wave = 16 cadences; the summation index of an MFMA step is the
 // product column p = p0 + (lane >> 4), its factor tuple one packed dword of LDS.
-template <int O, int KT>
+// WR row tiles of 16 cadences per wave share every operand of V and every factor tuple (round 6: with one row tile a step was one
+// global load, four LDS reads and two multiplications per MFMA and the kernel ran at 0.41 of the fp64 MFMA rate; four row tiles for
+// the 816-column block, two for the 136-column one: 1.47 -> 1.17 ms and 0.30 -> 0.28 ms per 500 cutouts.  Requesting the next step's
+// operands of V ahead of a step's MFMAs — two register sets, a scheduling fence — measured nothing: four to five waves per SIMD
+// already cover that round trip.  What is left is the operand generation: ~64 fp64 multiplications and ~130 integer
+// instructions per 16 MFMAs on the same SIMD.)
+template <int O, int KT, int WR>
 __global__ __launch_bounds__(256) void pld_project_products_kernel(const double *__restrict__ Xin, int ldx, int col1, int k1,
                                                                     int N, int Pc, const uint32_t *__restrict__ packed,
                                                                     const double *__restrict__ mvg,
                                                                     const double *__restrict__ V,
                                                                     const double *__restrict__ lam, int kk, int col0,
                                                                     double *__restrict__ Xout) {
-    extern __shared__ __attribute__((aligned(16))) double pp_lds[];  // us[64][ks] | tup[Pc] (dwords)
+    extern __shared__ __attribute__((aligned(16))) double pp_lds[];  // us[64 WR][ks] | tup[Pc] (dwords)
     const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lr = lane & 15;
     const int ks = k1 | 1;
+    constexpr int ROWS = 64 * WR;
     double *us = pp_lds;
-    uint32_t *tup = reinterpret_cast<uint32_t *>(us + 64 * ks);
-    const int nb = blockIdx.x * 64;
-    for (int e = tid; e < 64 * k1; e += 256) {
+    uint32_t *tup = reinterpret_cast<uint32_t *>(us + ROWS * ks);
+    const int nb = blockIdx.x * ROWS;
+    for (int e = tid; e < ROWS * k1; e += 256) {
         const int r = e / k1, c = e - r * k1;
         us[r * ks + c] = nb + r < N ? Xin[((size_t)b * N + nb + r) * ldx + col1 + c] : 0.0;
     }
     for (int e = tid; e < Pc; e += 256) tup[e] = packed[e];
     const double *Vb = V + (size_t)b * Pc * kk, *mv = mvg + (size_t)b * kk;
     __syncthreads();
-    const int n0 = nb + wave * 16;
+    const int n0 = nb + wave * 16 * WR;
     if (n0 >= N) return;
-    const double *row = us + (wave * 16 + lr) * ks;
-    pld_d4 acc[KT];
+    const double *row[WR];
 #pragma unroll
-    for (int c = 0; c < KT; ++c) acc[c] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    for (int w = 0; w < WR; ++w) row[w] = us + (wave * 16 * WR + 16 * w + lr) * ks;
+    pld_d4 acc[WR][KT];
+#pragma unroll
+    for (int w = 0; w < WR; ++w)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) acc[w][c] = pld_d4{0.0, 0.0, 0.0, 0.0};
     // Out-of-range columns are handled by CLAMPED unconditional loads times a 0 / 1 factor: a guarded load ends up behind a
     // branch with a full s_waitcnt right after it, one L2 round trip per MFMA (all operands are finite).
     double cflag[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c) cflag[c] = c * 16 + lr < kk ? 1.0 : 0.0;
     for (int p0 = 0; p0 < Pc; p0 += 16) {
-        double prod[4], bv[4][KT];
+        double prod[WR][4], bv[4][KT];
         uint32_t tp[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) tp[q] = tup[min(p0 + 4 * q + lq, Pc - 1)];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int p = p0 + 4 * q + lq, pc = min(p, Pc - 1);
-            double pr = row[tp[q] & 255u];
+            const double live = p < Pc ? 1.0 : 0.0;
 #pragma unroll
-            for (int pos = 1; pos < O; ++pos) pr *= row[(tp[q] >> (8 * pos)) & 255u];
-            prod[q] = pr * (p < Pc ? 1.0 : 0.0);
+            for (int w = 0; w < WR; ++w) {
+                double pr = row[w][tp[q] & 255u];
+#pragma unroll
+                for (int pos = 1; pos < O; ++pos) pr *= row[w][(tp[q] >> (8 * pos)) & 255u];
+                prod[w][q] = pr * live;
+            }
 #pragma unroll
             for (int c = 0; c < KT; ++c) bv[q][c] = Vb[(size_t)pc * kk + min(c * 16 + lr, kk - 1)] * cflag[c];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int c = 0; c < KT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(prod[q], bv[q][c], acc[c], 0, 0, 0);
+            for (int w = 0; w < WR; ++w)
+#pragma unroll
+                for (int c = 0; c < KT; ++c) acc[w][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(prod[w][q], bv[q][c], acc[w][c], 0, 0, 0);
     }
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
@@ -626,10 +643,12 @@ __global__ __launch_bounds__(256) void pld_project_products_kernel(const double 
         if (a < kk) {
             const double sc = sqrt(fmax(lam[(size_t)b * kk + a], 1e-300));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + lq + 4 * r;
-                if (n < N) Xout[((size_t)b * N + n) * ldx + col0 + a] = (acc[c][r] - mv[a]) / sc;
-            }
+            for (int w = 0; w < WR; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + 16 * w + lq + 4 * r;
+                    if (n < N) Xout[((size_t)b * N + n) * ldx + col0 + a] = (acc[w][c][r] - mv[a]) / sc;
+                }
         }
     }
 }
@@ -2923,18 +2942,19 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
     const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws, G32);
     if (rc) return rc;
     {
-        const size_t lds = (size_t)(64 * (k1 | 1)) * 8 + (size_t)Pc * 4;
-        const dim3 grid((N + 63) / 64, B);
         const int kt = (ko + 15) / 16;
+        const int wr = kt <= 1 ? (o >= 3 ? 4 : 2) : 1;  // row tiles per wave (the wider bases keep one: their accumulators are the registers)
+        const size_t lds = (size_t)(64 * wr * (k1 | 1)) * 8 + (size_t)Pc * 4;
+        const dim3 grid((N + 64 * wr - 1) / (64 * wr), B);
         double *d_mv = (double *)ws.alloc((size_t)B * ko * 8);
         if (!d_mv) {
             set_error("PLD workspace exhausted (mean projection)");
             return LK_ENOMEM;
         }
         hipLaunchKernelGGL(pld_mean_proj_kernel, dim3(B), dim3(256), 0, stream, d_mean, V, Pc, ko, d_mv);
-#define LK_PP(O, KT) hipLaunchKernelGGL((pld_project_products_kernel<O, KT>), grid, dim3(256), lds, stream, X, K, col1, k1, N, Pc, \
-                                        pl.d_packed, d_mv, V, lam, ko, col0, X)
-#define LK_PPO(O) do { if (kt <= 1) LK_PP(O, 1); else if (kt == 2) LK_PP(O, 2); else LK_PP(O, 3); } while (0)
+#define LK_PP(O, KT, WR) hipLaunchKernelGGL((pld_project_products_kernel<O, KT, WR>), grid, dim3(256), lds, stream, X, K, col1, k1, N, Pc, \
+                                            pl.d_packed, d_mv, V, lam, ko, col0, X)
+#define LK_PPO(O) do { if (kt <= 1) LK_PP(O, 1, (O >= 3 ? 4 : 2)); else if (kt == 2) LK_PP(O, 2, 1); else LK_PP(O, 3, 1); } while (0)
         if (o == 2) LK_PPO(2); else if (o == 3) LK_PPO(3); else LK_PPO(4);
 #undef LK_PPO
 #undef LK_PP
