@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel time of ONE 500-cutout PLD step from a kernel trace: the averages of rocprofv3 --stats mix the bench's big launches with the
 # 3-cutout accuracy launches (bandwidth-bound kernels take ~10 us there, latency-bound ones as long as in a big launch), so this sums each
-# kernel's dispatches inside the LAST timed step instead.  tools/pld_step_breakdown.sh <outdir> [VAR=value ...]
+# kernel's dispatches inside ONE timed step (the middle one of the 500-cutout steps) instead.  tools/pld_step_breakdown.sh <outdir> [VAR=value ...]
 out=$1; shift; mkdir -p "$out"; R=$PWD; export TMPDIR=/tmp; cd /tmp
 env "$@" rocprofv3 --kernel-trace -d "$R/$out/trace" -o pld -- python "$R/bench.py" --workload pld --no-cpu-baseline --no-api --steps 3 --warmup 1 > "$R/$out/bench.json" 2> "$R/$out/bench.err"
 cd "$R"
@@ -27,13 +27,17 @@ spans = [(begins[j], begins[j + 1]) for j in range(len(begins) - 1)] + [(begins[
 dur = [(sum(r[2] - r[1] for r in rows[a:b]), a, b) for a, b in spans if b > a]
 big = max(dur)[0]
 cand = [(a, b) for d, a, b in dur if d > 0.7 * big]
-a, b = cand[-1]
+a, b = cand[len(cand) // 2]  # a timed step (the first steps after an idle GPU run 5-20 % slower: clocks)
 acc = collections.OrderedDict()
 for name, st, en in rows[a:b]:
     short = name.split("(")[0].replace("void ", "").replace("lk::", "")
     acc.setdefault(short, [0, 0.0])
     acc[short][0] += 1
     acc[short][1] += (en - st) * 1e-3
+# every launch of the three longest kernels, in order (spread between steps / clock block / accuracy launches)
+for key in ("pld_moment_gram_kernelILi3ELb0", "pld_topk_eig_kernel", "pld_project_kernel"):
+    ds = ["%.0f" % ((en - st) * 1e-3) for name, st, en in rows if key in name]
+    print("# all launches of %s: %s" % (key, " ".join(ds)))
 tot = sum(v[1] for v in acc.values())
 print("# one 500-cutout PLD step: span %.0f us, kernels %.0f us" % ((rows[b - 1][2] - rows[a][1]) * 1e-3, tot))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
