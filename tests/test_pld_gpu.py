@@ -37,7 +37,9 @@ def test_golden_third_order_path(golden):
     w = g["block_widths"]
     assert subspace_gap(X[:, :16], g["X"][:, :16]) < 1e-6          # order 1 (the reference's re-PCA only rotates it)
     assert subspace_gap(X[:, 16:32], g["X"][:, 16:32]) < 1e-5      # order 2 (136 -> 16)
-    assert subspace_gap(X[:, 32:48], g["X"][:, 32:48]) < 1e-4      # order 3 (816 -> 16)
+    # order 3 (816 -> 16): the iteration stops at a 1e-7 residual and the 16th / 17th eigenvalues are close — numerically equivalent
+    # builds of the first-order solver move this gap between 8e-6 and 1.4e-4 (tools/pld_gap_check.py prints it; shipped: 2.4e-5)
+    assert subspace_gap(X[:, 32:48], g["X"][:, 32:48]) < 1e-4
     # background: float32 row-sum normalisation + noise-dominated trailing components (2.5e-5 even CPU vs CPU)
     assert subspace_gap(X[:, 48:48 + w[1]], g["X"][:, 48:48 + w[1]]) < 1e-3
 
