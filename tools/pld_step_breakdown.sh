@@ -38,6 +38,7 @@ for name, st, en in rows[a:b]:
 for key in ("pld_moment_gram_kernelILi3ELb0", "pld_topk_eig_kernel", "pld_project_kernel"):
     ds = ["%.0f" % ((en - st) * 1e-3) for name, st, en in rows if key in name]
     print("# all launches of %s: %s" % (key, " ".join(ds)))
+print("# the step's launches in order (us): " + " | ".join("%s %.0f" % (name.split("(")[0].replace("void ", "").replace("lk::", "").replace("_kernel", "")[:28], (en - st) * 1e-3) for name, st, en in rows[a:b] if "clock_probe" not in name))
 tot = sum(v[1] for v in acc.values())
 print("# one 500-cutout PLD step: span %.0f us, kernels %.0f us" % ((rows[b - 1][2] - rows[a][1]) * 1e-3, tot))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
