@@ -130,18 +130,26 @@ __global__ __launch_bounds__(256) void pld_ratio_kernel(const float *__restrict_
 
 // float32 row sums of the background pixels (the divisor of mode 2 above, same arithmetic), one wave per cadence
 __global__ __launch_bounds__(256) void pld_rowdiv_kernel(const float *__restrict__ pix, int N, int P, float *__restrict__ div) {
-    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int q = 0; q < 8; ++q) {  // 32 cadences per workgroup
-        const int n = blockIdx.x * 32 + q * 4 + wave;
-        if (n >= N) return;
+    // SIXTEEN lanes per cadence (round 6; a wave per cadence spent six 64-wide shuffle steps on 121 pixels — 2 loads per lane — and the
+    // kernel ran at 2.5 TB/s): a lane's pixels l, l + 16, ... are requested together, summed in double in that order, then four
+    // xor steps inside the group (the partial sums meet in a fixed order: reproducible; <= 1 ulp(f32) from numpy's pairwise sum).
+    const int b = blockIdx.y, grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+#pragma unroll 1
+    for (int q = 0; q < 2; ++q) {  // 32 cadences per workgroup, 16 at a time
+        const int n = blockIdx.x * 32 + q * 16 + grp;
+        if (n >= N) return;  // (whole 16-lane groups leave together; shuffles below stay inside a group)
         const float *row = pix + ((size_t)b * N + n) * P;
         double sm = 0.0;
-        for (int p = lane; p < P; p += 64) {
-            const float v = row[p];
-            if (v == v) sm += (double)v;
+        for (int p0 = l; p0 < P; p0 += 128) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[min(p0 + 16 * u, P - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + 16 * u < P && v[u] == v[u]) sm += (double)v[u];
         }
-        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-        if (lane == 0) div[(size_t)b * N + n] = (float)sm;
+        for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        if (l == 0) div[(size_t)b * N + n] = (float)sm;
     }
 }
 
