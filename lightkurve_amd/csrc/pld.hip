@@ -1894,6 +1894,10 @@ __global__ __launch_bounds__(512) void pld_eigs_orth_kernel(int P, int k, int l,
 // [col = lane & 15].  The summation index of an MFMA step is free to permute: lane group q = lane >> 4 owns columns
 // p0 + 4 q .. + 3 of A (one 32-byte load when P % 4 == 0 — the four groups cover a 128-byte line of each row) and feeds
 // component j at step j, with the matching row p0 + 4 q + j of V as the B operand (4 x 128-byte rows, from L1/L2).
+#ifndef PROJ_U4
+#define PROJ_U4 1
+#endif
+typedef double pld_d4u __attribute__((ext_vector_type(4), aligned(8)));
 template <int KT, bool VEC4>  // KT = 16-column tiles of V (k <= 16 KT); VEC4: P % 4 == 0, rows of A are 32-byte aligned
 __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restrict__ A, const double *__restrict__ V,
                                                            const double *__restrict__ lam, int N, int P, int k, int ldx,
@@ -1918,10 +1922,23 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= f;
         } else {
+#if PROJ_U4
+            // P not a multiple of four (121: rows neither 16- nor 32-byte aligned): still ONE 32-byte request per lane — four
+            // 8-byte loads per lane put ~24 cache lines under every instruction and fetched each line four times through an L1
+            // that 32 waves' rows do not fit.  The last group starts at P - 4 and its elements are shifted into place.
+            const int st = min(p, P - 4), sh = p - st;  // sh = 0 except in the row's last group
+            const pld_d4u raw = *reinterpret_cast<const pld_d4u *>(Ar + st);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double x = sh == 0 ? raw[j] : (sh == 1 ? raw[min(j + 1, 3)] : (sh == 2 ? raw[min(j + 2, 3)] : raw[3]));
+                v[j] = x * ((row < N && p + j < P) ? 1.0 : 0.0);
+            }
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = Ar[min(p + j, P - 1)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= (row < N && p + j < P) ? 1.0 : 0.0;
+#endif
         }
         return v;
     };
