@@ -145,6 +145,8 @@ int flatten_launch(lk_handle *h, int B, const int64_t *n_off_host, const double 
 int savgol_design_host(int window, int polyorder, double *coeffs, double *edge);
 int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, double *G, hipStream_t stream,
                       lk_handle *h = nullptr);
+int gram_plain_f32_launch(const float *pix, const float *div, const double *mean, int mode, const int64_t *d_off, int B, int K,
+                          double *G, hipStream_t stream, lk_handle *h);
 int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pld_pix, const float *bkg_pix,
                       const float *lc_flux, const double *time, const double *knots, int n_inner, int pld_order,
                       int pca_components, int n_knots, int spline_degree, int normalize_bkg, int K, double *X,

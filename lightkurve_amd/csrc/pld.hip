@@ -1977,6 +1977,73 @@ __global__ __launch_bounds__(256) void pld_project_kernel(const double *__restri
     }
 }
 
+// The same projection straight from the float32 pixels (round 6): A = (double)(pix / div[row]) - mean[col] is formed in the lane
+// that feeds it to the matrix cores — pld_ratio_kernel used to write A out as float64 (1.7 GB per 121-column block of 500 cutouts)
+// for the Gram kernel and this one to read back.  Same arithmetic, same summation order: the same bits.  Needs P >= 4.
+typedef float pld_f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int KT>
+__global__ __launch_bounds__(256) void pld_project_f32_kernel(const float *__restrict__ pix, const float *__restrict__ divv,
+                                                               const double *__restrict__ mean, int mode,
+                                                               const double *__restrict__ V, const double *__restrict__ lam,
+                                                               int N, int P, int k, int ldx, int col0, double *__restrict__ X) {
+    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = (blockIdx.x * 4 + wave) * 16;
+    if (n0 >= N) return;
+    const int lq = lane >> 4, lr = lane & 15, row = n0 + lr, rowc = min(row, N - 1);
+    const float *Pr = pix + ((size_t)b * N + rowc) * P;
+    const double *mb = mean + (size_t)b * P, *Vb = V + (size_t)b * P * k;
+    const float dv = (mode != 0 && divv) ? divv[(size_t)b * N + rowc] : 1.0f;
+    auto load_a = [&](int p0) -> pld_d4 {
+        const int p = p0 + 4 * lq;
+        const int st = min(p, P - 4), sh = p - st;  // (sh = 0 except in the row's last group)
+        const pld_f4u raw = *reinterpret_cast<const pld_f4u *>(Pr + st);
+        const pld_d4u mr = *reinterpret_cast<const pld_d4u *>(mb + st);
+        pld_d4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int js = min(j + sh, 3);
+            const float x = js == 0 ? raw[0] : (js == 1 ? raw[1] : (js == 2 ? raw[2] : raw[3]));
+            const double m = js == 0 ? mr[0] : (js == 1 ? mr[1] : (js == 2 ? mr[2] : mr[3]));
+            const double q = (double)(mode == 0 ? x : x / dv) - m;
+            v[j] = (row < N && p + j < P) ? q : 0.0;  // (a select, not a product: q may be Inf / NaN where the reference's is, but only inside the matrix)
+        }
+        return v;
+    };
+    pld_d4 acc[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) acc[c] = pld_d4{0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        pld_d4 a4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] = load_a(p0 + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + 16 * u + 4 * lq + j;
+#pragma unroll
+                for (int c = 0; c < KT; ++c) {
+                    const int col = c * 16 + lr;
+                    const double vraw = Vb[(size_t)min(p, P - 1) * k + min(col, k - 1)];
+                    const double bv = vraw * ((p < P && col < k) ? 1.0 : 0.0);
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[u][j], bv, acc[c], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        const int a = c * 16 + lr;
+        if (a < k) {
+            const double sc = sqrt(fmax(lam[(size_t)b * k + a], 1e-300));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + lq + 4 * r;
+                if (n < N) X[((size_t)b * N + n) * ldx + col0 + a] = acc[c][r] / sc;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ direct solver, P <= 138
 // Top-k eigenpairs of a Gram matrix that fits LDS (the 121-column pixel and background blocks, the 136-column 2nd-order
 // product block), computed DIRECTLY instead of by subspace iteration (whose Rayleigh-Ritz steps — a 32 x 32 Jacobi and a
@@ -2783,17 +2850,35 @@ static int eig_topk(lk_handle *h, double *G, int ldg, int B, int P, int k, bool 
 }
 
 // PCA of B centred matrices A (N x P) -> top-k left singular vectors into X[:, col0:col0+k]
+struct PcaF32Source {  // the block as float32 pixels: A = (double)(mode == 0 ? pix : pix / div[row]) - mean[col], never written out
+    const float *pix, *div;
+    const double *mean;
+    int mode;
+};
+#ifndef PLD_F32_SOURCE
+#define PLD_F32_SOURCE 1
+#endif
+// (can the narrow Gram kernel and the float32 projection take this block?  P >= 4 columns, at most 9 column tiles, k <= 48)
+static bool pca_f32_ok(int P, int k) { return PLD_F32_SOURCE && P >= 4 && (P + 15) / 16 <= 9 && k <= 48; }
 static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const int64_t *d_off, double *X, int ldx,
                      int col0, hipStream_t stream, Arena &ws, bool centred = false, bool products = false,
-                     double tol = -1.0) {
-    if (!centred) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
+                     double tol = -1.0, PcaF32Source fs = PcaF32Source{nullptr, nullptr, nullptr, 0}) {
+    const bool f32src = fs.pix != nullptr;
+    if (!centred && !f32src) hipLaunchKernelGGL(pld_center_kernel, dim3((P + 31) / 32, B), dim3(256), 0, stream, A, N, P);
     const int KB = (P + 63) / 64, ldg = KB * 64;
     double *G = (double *)ws.alloc((size_t)B * ldg * ldg * 8);
     if (!G) {
         set_error("PLD workspace exhausted (Gram)");
         return LK_ENOMEM;
     }
-    gram_plain_launch(A, d_off, B, P, G, stream, h);
+    if (f32src) {
+        if (gram_plain_f32_launch(fs.pix, fs.div, fs.mean, fs.mode, d_off, B, P, G, stream, h) == 0) {
+            set_error("PLD: the float32-source Gram kernel refused a %d-column block", P);
+            return LK_EHIP;
+        }
+    } else {
+        gram_plain_launch(A, d_off, B, P, G, stream, h);
+    }
     double *V = nullptr, *lam = nullptr;
     const int rc = eig_topk(h, G, ldg, B, P, k, products, true, &V, &lam, stream, ws, nullptr, tol);
     if (rc) return rc;
@@ -2801,6 +2886,12 @@ static int pca_block(lk_handle *h, double *A, int B, int N, int P, int k, const 
         const dim3 grid((N + 63) / 64, B), blk(256);
         const int kt = (k + 15) / 16;
         const bool v4 = (P & 3) == 0 && P >= 4;
+        if (f32src) {
+#define LK_PROJF(KT) hipLaunchKernelGGL((pld_project_f32_kernel<KT>), grid, blk, 0, stream, fs.pix, fs.div, fs.mean, fs.mode, V, lam, N, P, k, ldx, col0, X)
+            if (kt <= 1) LK_PROJF(1); else if (kt == 2) LK_PROJF(2); else LK_PROJF(3);
+#undef LK_PROJF
+            return LK_OK;
+        }
 #define LK_PROJ(KT, V4) hipLaunchKernelGGL((pld_project_kernel<KT, V4>), grid, blk, 0, stream, A, V, lam, N, P, k, ldx, col0, X)
         if (kt <= 1) {
             if (v4) LK_PROJ(1, true); else LK_PROJ(1, false);
@@ -3024,8 +3115,12 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
         double *d_cm = (double *)h->ws.alloc((size_t)B * P * 8);
         LK_REQUIRE(d_cm != nullptr, "PLD workspace exhausted (column means)");
         hipLaunchKernelGGL(pld_colmean_kernel, dim3(B), dim3(1024), 0, stream, pld_pix, lc_flux, 1, N, P, d_cm);
-        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, pld_pix, lc_flux, 1, N, P, A, d_cm, (const float *)nullptr);
-        rc = pca_block(h, A, B, N, P, k1, d_off, X, K, col, stream, h->ws, true);
+        if (pca_f32_ok(P, k1)) {  // the Gram kernel and the projection form pix / flux - mean themselves
+            rc = pca_block(h, nullptr, B, N, P, k1, d_off, X, K, col, stream, h->ws, true, false, -1.0, PcaF32Source{pld_pix, lc_flux, d_cm, 1});
+        } else {
+            hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, pld_pix, lc_flux, 1, N, P, A, d_cm, (const float *)nullptr);
+            rc = pca_block(h, A, B, N, P, k1, d_off, X, K, col, stream, h->ws, true);
+        }
         if (rc) return rc;
         const int col1 = col;
         col += k1;
@@ -3083,17 +3178,26 @@ int pld_design_launch(lk_handle *h, int B, int N, int P, int Pb, const float *pl
     }
     const int n_pld_cols = col;
     h->ws.used = mark;
+    bool bkg_f32 = false;
+    PcaF32Source bkg_src{nullptr, nullptr, nullptr, 0};
     {
         double *d_cm = (double *)h->ws.alloc((size_t)B * Pb * 8);
         float *d_div = normalize_bkg ? (float *)h->ws.alloc((size_t)B * N * 4) : nullptr;
         LK_REQUIRE(d_cm != nullptr && (!normalize_bkg || d_div != nullptr), "PLD workspace exhausted (column means)");
         if (normalize_bkg) hipLaunchKernelGGL(pld_rowdiv_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, N, Pb, d_div);
         hipLaunchKernelGGL(pld_colmean_kernel, dim3(B), dim3(1024), 0, stream, bkg_pix, d_div, normalize_bkg ? 2 : 0, N, Pb, d_cm);
-        hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, lc_flux,
-                           normalize_bkg ? 2 : 0, N, Pb, A, d_cm, d_div);
+        bkg_f32 = pca_f32_ok(Pb, std::min(pca_components, Pb));
+        if (bkg_f32)
+            bkg_src = PcaF32Source{bkg_pix, d_div, d_cm, normalize_bkg ? 2 : 0};
+        else
+            hipLaunchKernelGGL(pld_ratio_kernel, dim3((N + 31) / 32, B), dim3(256), 0, stream, bkg_pix, lc_flux,
+                               normalize_bkg ? 2 : 0, N, Pb, A, d_cm, d_div);
     }
     const int kb = std::min(pca_components, Pb);
-    rc = pca_block(h, A, B, N, Pb, kb, d_off, X, K, col, stream, h->ws, true);
+    if (bkg_f32)
+        rc = pca_block(h, nullptr, B, N, Pb, kb, d_off, X, K, col, stream, h->ws, true, false, -1.0, bkg_src);
+    else
+        rc = pca_block(h, A, B, N, Pb, kb, d_off, X, K, col, stream, h->ws, true);
     if (rc) return rc;
     col += kb;
     hipLaunchKernelGGL(pld_spline_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, time, knots, n_inner,

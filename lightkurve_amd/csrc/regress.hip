@@ -181,23 +181,37 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
 // the same LDS value as the right operand of that tile column, times the cadence weight (X / err^2 as the reference forms
 // it): no second tile.  Off-diagonal tiles are written to both triangles.
 constexpr int GT_RC = 32, GT_LDC = 34, GT_NT = 512, GT_MAXT = 9;
+// optional float32 source of gram_tri_kernel: element (row, col) = (double)(mode == 0 ? pix : pix / div[row]) - mean[col]
+// (div: per-cadence float32 divisors of the batch, mean: per-target column means, either may be null = no division / no centring)
+struct GramF32Source {
+    const float *pix, *div;
+    const double *mean;
+    int mode;
+};
 
 // NS = tiles per wave = ceil(T (T + 1) / 2 / 8).  The hot loop is branch-free: a wave with fewer tiles than NS repeats its
 // last one (the copy is not written), every slot reads both its operands, every global load is unconditional (clamped
 // address, value selected afterwards) — a branch around a load or an MFMA makes the compiler wait for everything in flight.
-template <bool WEIGHTED, int NS>
+template <bool WEIGHTED, int NS, bool F32SRC = false>  // F32SRC: the matrix comes from float32 pixels (GramF32Source); a template so the float64 instances keep their registers
 __global__ __launch_bounds__(GT_NT) void gram_tri_kernel(const double *__restrict__ X, const double *__restrict__ y,
                                                          const double *__restrict__ err,
                                                          const uint8_t *__restrict__ cmask,
                                                          const uint8_t *__restrict__ outl,
                                                          const int64_t *__restrict__ n_off, int K, int ldg,
-                                                         double *__restrict__ G, const int *__restrict__ done = nullptr) {
+                                                         double *__restrict__ G, const int *__restrict__ done = nullptr,
+                                                         GramF32Source fs = GramF32Source{nullptr, nullptr, nullptr, 0}) {
     if (done && done[blockIdx.x]) return;
     extern __shared__ __attribute__((aligned(16))) double gt_sm[];
     const int target = blockIdx.x;
     const int64_t lo = n_off[target];
     const int n = (int)(n_off[target + 1] - lo);
-    X += lo * K;
+    // fs.pix: the matrix is not X but (double)(pix / div[row]) - mean[col] formed on the way into LDS from float32 pixels (the PLD
+    // pixel blocks: what pld_ratio_kernel used to write out as float64, 1.7 GB per block, for this kernel and the projection to read back)
+    constexpr bool f32src = F32SRC;
+    const float *pixb = f32src ? fs.pix + lo * K : nullptr;
+    const float *divb = (f32src && fs.div) ? fs.div + lo : nullptr;
+    const double *meanb = (f32src && fs.mean) ? fs.mean + (size_t)target * K : nullptr;
+    if (!f32src) X += lo * K;
     if (y) y += lo;
     const int Ka = K + (y ? 1 : 0), T = (Ka + 15) >> 4, Tc = T << 4;
     double *tile = gt_sm;                               // [2][Tc][GT_LDC]
@@ -240,24 +254,41 @@ __global__ __launch_bounds__(GT_NT) void gram_tri_kernel(const double *__restric
     const int c16 = tid & 15, rp = (tid >> 4) & 15, tcs = tid >> 8;
     constexpr int NP = (GT_MAXT + 1) / 2;
     const double *cbase[NP];
+    const float *pbase[NP];
     int cstride[NP];
     bool clive[NP];
+    double cmean[NP];
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         const int col = ((tcs + 2 * u) << 4) + c16;
         const bool isx = col < K, isy = (col == K) && y != nullptr;
         clive[u] = isx || isy;
-        cbase[u] = isx ? X + col : (isy ? y : X);
+        cbase[u] = f32src ? y : (isx ? X + col : (isy ? y : X));           // (float32 source: only the y column is float64)
+        pbase[u] = f32src ? (isx ? pixb + col : pixb) : nullptr;
         cstride[u] = isx ? K : (isy ? 1 : 0);
+        cmean[u] = (meanb && isx) ? meanb[col] : 0.0;
     }
     double f0[NP], f1[NP], wv = 1.0;
+    float g0[NP], g1[NP], da = 1.0f, db = 1.0f;  // float32 source: raw pixels and the two rows' divisors (nothing is consumed here)
     uint8_t wc = 1, wo = 0;
     auto fetch = [&](int n0) {
         const int r0 = n0 + 2 * rp, ra = min(r0, n - 1), rb = min(r0 + 1, n - 1);
+        if (f32src) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                g0[u] = pbase[u][(size_t)ra * cstride[u]];
+                g1[u] = pbase[u][(size_t)rb * cstride[u]];
+            }
+            if (divb) {
+                da = divb[ra];
+                db = divb[rb];
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             f0[u] = cbase[u][(size_t)ra * cstride[u]];
             f1[u] = cbase[u][(size_t)rb * cstride[u]];
+        }
         }
         if (WEIGHTED && tid < GT_RC) {  // raw values only: nothing here may wait for a load (the MFMAs of the stage follow)
             const int64_t g = lo + min(n0 + tid, n - 1);
@@ -269,6 +300,13 @@ __global__ __launch_bounds__(GT_NT) void gram_tri_kernel(const double *__restric
     auto stash = [&](int buf, int n0) {  // values beyond the matrix or the batch become zeros on their way into LDS
         double *tb = tile + (size_t)buf * Tc * GT_LDC;
         const int r0 = n0 + 2 * rp;
+        if (f32src) {  // the ratio in float32 as the reference forms it, then float64, then the column mean (pld_ratio_kernel's arithmetic)
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                f0[u] = (double)(fs.mode == 0 ? g0[u] : g0[u] / da) - cmean[u];
+                f1[u] = (double)(fs.mode == 0 ? g1[u] : g1[u] / db) - cmean[u];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NP; ++u)
             if (tcs + 2 * u < T) {
@@ -328,17 +366,24 @@ __global__ __launch_bounds__(GT_NT) void gram_tri_kernel(const double *__restric
 template <bool WEIGHTED, int NS>
 static void gram_tri_go(lk_handle *h, int *rc, size_t lds, const double *X, const double *y, const double *err,
                         const uint8_t *cmask, const uint8_t *outl, const int64_t *d_off, int B, int K, int ldg, double *G,
-                        const int *done, hipStream_t stream) {
+                        const int *done, hipStream_t stream, GramF32Source fs) {
+    if (!WEIGHTED && fs.pix != nullptr) {  // (the float32 source exists for plain Grams only)
+        *rc = want_lds(h, reinterpret_cast<const void *>(gram_tri_kernel<false, NS, true>), 160 * 1024);
+        if (*rc) return;
+        hipLaunchKernelGGL((gram_tri_kernel<false, NS, true>), dim3(B), dim3(GT_NT), lds, stream, X, y, err, cmask, outl, d_off, K,
+                           ldg, G, done, fs);
+        return;
+    }
     *rc = want_lds(h, reinterpret_cast<const void *>(gram_tri_kernel<WEIGHTED, NS>), 160 * 1024);
     if (*rc) return;
     hipLaunchKernelGGL((gram_tri_kernel<WEIGHTED, NS>), dim3(B), dim3(GT_NT), lds, stream, X, y, err, cmask, outl, d_off, K, ldg,
-                       G, done);
+                       G, done, fs);
 }
 
 // launch helper: true if the narrow kernel took the job
 static bool gram_tri_try(lk_handle *h, const double *X, const double *y, const double *err, const uint8_t *cmask,
                          const uint8_t *outl, const int64_t *d_off, int B, int K, int ldg, double *G, const int *done,
-                         hipStream_t stream) {
+                         hipStream_t stream, GramF32Source fs = GramF32Source{nullptr, nullptr, nullptr, 0}) {
     const int Ka = K + (y ? 1 : 0), T = (Ka + 15) / 16;
     if (!h || T > GT_MAXT || ldg < 16 * T) return false;
     const size_t lds = ((size_t)2 * 16 * T * GT_LDC + 2 * GT_RC) * 8;
@@ -348,9 +393,9 @@ static bool gram_tri_try(lk_handle *h, const double *X, const double *y, const d
 #define GT_CASE(NS_)                                                                                              \
     case NS_:                                                                                                     \
         if (weighted)                                                                                             \
-            gram_tri_go<true, NS_>(h, &rc, lds, X, y, err, cmask, outl, d_off, B, K, ldg, G, done, stream);       \
+            gram_tri_go<true, NS_>(h, &rc, lds, X, y, err, cmask, outl, d_off, B, K, ldg, G, done, stream, fs);       \
         else                                                                                                      \
-            gram_tri_go<false, NS_>(h, &rc, lds, X, y, err, cmask, outl, d_off, B, K, ldg, G, done, stream);      \
+            gram_tri_go<false, NS_>(h, &rc, lds, X, y, err, cmask, outl, d_off, B, K, ldg, G, done, stream, fs);      \
         break;
     switch (ns) {
         GT_CASE(1)
@@ -1005,6 +1050,17 @@ int gram_plain_launch(const double *A, const int64_t *d_off, int B, int K, doubl
     hipLaunchKernelGGL(gram_mfma_kernel<false>, dim3(KB * (KB + 1) / 2, B), dim3(256), 0, stream, A, (const double *)nullptr,
                        (const double *)nullptr, (const uint8_t *)nullptr, (const uint8_t *)nullptr, d_off, K, KB, G);
     return KB * GR_BLK;  // leading dimension of each G_b
+}
+
+// Plain Gram of the matrix (double)(mode == 0 ? pix : pix / div[row]) - mean[col] formed from float32 pixels on the fly (narrow
+// blocks only: returns 0 if the narrow kernel cannot take the shape, and the caller materialises the matrix instead).
+int gram_plain_f32_launch(const float *pix, const float *div, const double *mean, int mode, const int64_t *d_off, int B, int K,
+                          double *G, hipStream_t stream, lk_handle *h) {
+    const int KB = (K + GR_BLK - 1) / GR_BLK;
+    if (gram_tri_try(h, nullptr, nullptr, nullptr, nullptr, nullptr, d_off, B, K, KB * GR_BLK, G, nullptr, stream,
+                     GramF32Source{pix, div, mean, mode}))
+        return KB * GR_BLK;
+    return 0;
 }
 
 // astropy.stats.sigma_clip(y, sigma, maxiters, cenfunc=median, stdfunc=std).mask for B ragged arrays — what
