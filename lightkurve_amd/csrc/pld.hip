@@ -550,6 +550,85 @@ __global__ __launch_bounds__(256) void pld_moment_expand_kernel(const double *__
     }
 }
 
+// The same expansion by SYMMETRIC 64 x 64 tiles (Pc a multiple of 4): the kernel above is bound by its gathers — 64 divergent 8-byte
+// reads per instruction keep the texture addresser busy a cycle per lane (contiguous reads in their place: 680 -> 381 us per launch) —
+// and C is symmetric.  A workgroup takes a tile pair (ti <= tj): gathers the block (rows of ti, columns of tj) once, writes it, and
+// writes its transpose to (tj, ti) through LDS (rows of 65 doubles): half the gathers and half the index reads, every store still a
+// 32-byte (float64) / 16-byte (float32) run.  Same values, same bits.
+#ifndef MEXP_SYM
+#define MEXP_SYM 1
+#endif
+__global__ __launch_bounds__(256) void pld_moment_expand_sym_kernel(const double *__restrict__ Mcan, size_t mstride,
+                                                                     const uint32_t *__restrict__ src,
+                                                                     const double *__restrict__ mean, int Pc, int ldg, double Nd,
+                                                                     double *__restrict__ G, float *__restrict__ G32, int T) {
+    __shared__ double tile[64][65];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    // tile pair p -> (ti <= tj), row-major over the upper triangle of T x T tiles
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= T - ti) {
+        rem -= T - ti;
+        ++ti;
+    }
+    const int tj = ti + rem;
+    const double *mb = mean + (size_t)b * Pc, *Mb = Mcan + (size_t)b * mstride;
+    double *Gb = G + (size_t)b * ldg * ldg;
+    float *G32b = G32 ? G32 + (size_t)b * ldg * ldg : nullptr;
+    const int c4 = tid & 15, r0 = tid >> 4;  // a thread: columns 4 c4 .. 4 c4 + 3 of rows r0, r0 + 16, r0 + 32, r0 + 48
+    const int jg = tj * 64 + 4 * c4;
+    const bool jok = jg < Pc;  // (Pc % 4 == 0: a group is inside or outside as a whole)
+    int ii[4];
+    uint4 sv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        ii[u] = ti * 64 + r0 + 16 * u;
+        sv[u] = *reinterpret_cast<const uint4 *>(src + (size_t)min(ii[u], Pc - 1) * Pc + min(jg, Pc - 4));
+    }
+    double v[4][4], mj[4], mi[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) mj[t] = mb[min(jg, Pc - 4) + t];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        v[u][0] = Mb[sv[u].x];
+        v[u][1] = Mb[sv[u].y];
+        v[u][2] = Mb[sv[u].z];
+        v[u][3] = Mb[sv[u].w];
+        mi[u] = Nd * mb[min(ii[u], Pc - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        pld_d4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            o[t] = v[u][t] - mi[u] * mj[t];
+            tile[r0 + 16 * u][4 * c4 + t] = o[t];
+        }
+        if (ii[u] < Pc && jok) {
+            *reinterpret_cast<pld_d4 *>(Gb + (size_t)ii[u] * ldg + jg) = o;
+            if (G32b)
+                *reinterpret_cast<float4 *>(G32b + (size_t)ii[u] * ldg + jg) =
+                    make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        }
+    }
+    if (ti == tj) return;  // (workgroup-uniform; the diagonal tile is its own transpose, gathered in full)
+    __syncthreads();
+    // the transpose: element (row j of tile tj, column i of tile ti) = tile[i][j]
+    const int ig = ti * 64 + 4 * c4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int jl = r0 + 16 * u, jr = tj * 64 + jl;
+        if (jr < Pc && ig < Pc) {
+            pld_d4 o;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = tile[4 * c4 + t][jl];
+            *reinterpret_cast<pld_d4 *>(Gb + (size_t)jr * ldg + ig) = o;
+            if (G32b)
+                *reinterpret_cast<float4 *>(G32b + (size_t)jr * ldg + ig) =
+                    make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+        }
+    }
+}
+
 // mv[b][a] = sum_p mean[b][p] V[b][p][a]: the projection of the column means, subtracted from every cadence by the
 // projection kernel below (one workgroup per cutout; inside the projection kernel this was a 204-step dependent chain
 // of global loads in front of every workgroup's MFMA loop)
@@ -3052,8 +3131,14 @@ static int pca_products_moment(lk_handle *h, const MomentPlan &pl, int B, int N,
     // early steps' filter products stream it instead (half the bytes); optional — without workspace nothing changes
     // (+ 4 KB: the product kernels' unconditional loads of the last row may run a few columns past the last matrix)
     float *G32 = (Pc > PLD_DIRECT_MAX && (Pc & 3) == 0) ? (float *)ws.alloc((size_t)B * ldg * ldg * 4 + 4096) : nullptr;
-    hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 256 * MEXP_U - 1) / (256 * MEXP_U), B), dim3(256), 0, stream, Mcan,
-                       (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G, G32);
+    if (MEXP_SYM && (Pc & 3) == 0 && Pc >= 128) {
+        const int T = (Pc + 63) / 64;
+        hipLaunchKernelGGL(pld_moment_expand_sym_kernel, dim3(T * (T + 1) / 2, B), dim3(256), 0, stream, Mcan, (size_t)pl.ldm * pl.ldm,
+                           pl.d_src, d_mean, Pc, ldg, (double)N, G, G32, T);
+    } else {
+        hipLaunchKernelGGL(pld_moment_expand_kernel, dim3((Pc * ((Pc + 3) / 4) + 256 * MEXP_U - 1) / (256 * MEXP_U), B), dim3(256), 0, stream, Mcan,
+                           (size_t)pl.ldm * pl.ldm, pl.d_src, d_mean, Pc, ldg, (double)N, G, G32);
+    }
     double *V = nullptr, *lam = nullptr;
     const int rc = eig_topk(h, G, ldg, B, Pc, ko, true, false, &V, &lam, stream, ws, G32);
     if (rc) return rc;
